@@ -1,0 +1,221 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference; see oracle/ref_harness.py).
+    python oracle/gen_golden.py            # regenerates every fixture
+The reference never travels: what is committed are the inputs and the reference's outputs
+(plain .npz data) plus this script.  Weights are NOT stored -- they come from the seeded
+generator in danbo-pytorch_amd/core/utils/synthetic.py, which the tests call again with
+the seed recorded in each fixture.
+
+Fixtures
+  danbo_stages.npz   D-H36M (danbo_base net), 48 rays = 2 poses x 24, 12+6 samples, framecode
+                     idx per ray: every stage-boundary tensor of SURVEY §8(c)
+  danbo_surreal.npz  D-Surr (box near/far, no frame codes), whole 64x64 frame as ONE 4096-ray
+                     chunk incl. rays that miss the cylinder (NaN back-fill), 32+16: final maps
+  danbo_perfcap.npz  D-Perf (relray/root_local view branch, box near/far), 256 rays, 32+16,
+                     mean frame code (idx -1): raw + final maps
+  pose_rot6d.npz     axis-angle -> rot6d incl. tiny angles (pytorch3d boundary, cross-checked
+                     with scipy in the tests)
+"""
+import contextlib
+import importlib.util
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+spec = importlib.util.spec_from_file_location(
+    "danbo_synthetic", os.path.join(ROOT, "danbo-pytorch_amd", "core", "utils", "synthetic.py"))
+syn = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(syn)
+
+CONFIGS = {
+    "danbo_base": "configs/h36m_zju/danbo_base.txt",
+    "danbo_fast": "configs/h36m_zju/danbo_fast.txt",
+    "danbo_perfcap": "configs/perfcap/danbo_fast.txt",
+    "danbo_surreal": "configs/surreal/danbo_fast.txt",
+    "anerf_base": "configs/h36m_zju/anerf_base.txt",
+}
+
+
+def T(x, dtype=torch.float32):
+    return torch.tensor(np.asarray(x), dtype=dtype)
+
+
+def build(cfg_name, seed, n_framecodes=20):
+    cfg = syn.model_config(cfg_name)
+    args = rh.parse_reference_config(CONFIGS[cfg_name])
+    rest = syn.rest_pose(cfg["rest_scale"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        caster, kw_train, kw_test = rh.build_reference_caster(args, rest, n_framecodes, tempfile.mkdtemp())
+    sd = syn.make_state_dict(cfg, seed=seed, n_framecodes=n_framecodes, rest=rest, lively=True)
+    caster.network.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    caster.eval()
+    return cfg, args, caster, kw_test, rest
+
+
+def body_rays(scene, view, n, seed):
+    """Pick n rays of a full-grid view whose pixels fall on the projected skeleton bbox."""
+    ro, rd = scene["rays"][view]
+    H, W = scene["H"], scene["W"]
+    rng = np.random.default_rng(seed)
+    js, is_ = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    sel = ((np.abs(is_ - W / 2) < W * 0.22) & (np.abs(js - H / 2) < H * 0.40)).reshape(-1)
+    idx = rng.choice(np.nonzero(sel)[0], size=n, replace=False)
+    idx.sort()
+    return ro[idx], rd[idx]
+
+
+def per_ray(scene, pose_of_ray):
+    return (scene["kps"][pose_of_ray], scene["skts"][pose_of_ray], scene["bones"][pose_of_ray],
+            scene["cyls"][pose_of_ray])
+
+
+def call_caster(caster, kw_test, rb, kps, skts, cyls, bones, cams, N_samples, N_importance, n_uniques):
+    kw = {k: v for k, v in kw_test.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
+    with torch.no_grad():
+        out = caster(T(rb), N_samples=N_samples, kp_batch=T(kps), skts=T(skts), cyls=T(cyls),
+                     bones=T(bones), cams=cams, N_importance=N_importance, N_uniques=n_uniques, **kw)
+    return {k: v.numpy() for k, v in out.items()}
+
+
+def gen_danbo_stages():
+    seed = 11
+    cfg, args, caster, kw_test, rest = build("danbo_base", seed)
+    net = caster.network
+    scene = syn.make_scene(n_poses=2, H=64, W=64, n_views=2, pose_seed=5)
+    n_per = 24
+    ro, rd, pose = [], [], []
+    for p in range(2):
+        o, d = body_rays(scene, p, n_per, seed=100 + p)
+        ro.append(o); rd.append(d); pose += [p] * n_per
+    ro, rd, pose = np.concatenate(ro), np.concatenate(rd), np.array(pose)
+    rb = syn.ray_batch(ro, rd)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    cam_idx = (np.arange(len(pose)) % 7).astype(np.int64)
+    S, Sf = 12, 6
+    fin = call_caster(caster, kw_test, rb, kps, skts, cyls, bones, T(cam_idx, torch.long), S, Sf, 2)
+
+    with torch.no_grad():
+        rays_o, rays_d = T(ro), T(rd)
+        near, far = caster.get_near_far(rays_o, rays_d, T(cyls), near=T(rb[:, 6:7]), far=T(rb[:, 7:8]), skts=T(skts))
+        pts, z = caster.sample_pts(rays_o, rays_d, near, far, len(pose), S, 0., False)
+        inputs = caster.get_nerf_inputs(pts, [rays_o[:, None, :], rays_d[:, None, :]], T(kps), T(skts), T(bones),
+                                        cam_idxs=T(cam_idx, torch.long), N_uniques=2)
+        enc0 = net.pts_embedder.encode_pts(pts, T(kps), T(skts), T(bones), inputs["align_transforms"], inputs["rest_pose"])
+        w = net.pts_embedder.encode_graph_inputs(T(kps), T(bones), T(skts), 2)["w"]
+        vols = net.forward_graph(net.graph_pe_fn(w)[0])
+        part_feat, invalid = net.extract_graph_feat(vols, enc0["pts_t"])
+        dens_in, enc = net.encode_pts(inputs)
+        view_in, _ = net.encode_views(inputs, refs=enc["pts_t"], encoded_pts=enc)
+        raw, _ = net(inputs)
+        out0 = net.raw2outputs(raw, z, rays_d, B=1.0, act_fn=torch.relu)
+        z_all, z_fine, order = __import__("core.utils.ray_utils", fromlist=["x"]).isample_from_lineseg(
+            z, out0["weights"], Sf, det=True, is_only=True)
+    np.savez_compressed(
+        os.path.join(OUT, "danbo_stages.npz"),
+        cfg_name="danbo_base", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=2,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
+        pose_of_ray=pose, cam_idx=cam_idx, rest_pose=rest,
+        align=caster.transforms[0].numpy(), near=near.numpy(), far=far.numpy(), z_coarse=z.numpy(),
+        pts=pts.numpy(), pts_t=enc0["pts_t"].numpy(), rot6d=w.numpy(), volumes=vols.numpy(),
+        part_feat=part_feat.numpy(), invalid=invalid.numpy(), confd=enc["confd"].numpy(),
+        agg_p=enc["agg_p"].numpy(), density_inputs=dens_in.numpy(), view_inputs=view_in.numpy()[::S].copy(),
+        raw_coarse=raw.numpy(), weights_coarse=out0["weights"].numpy(), alpha_coarse=out0["alpha"].numpy(),
+        rgb_coarse=out0["rgb_map"].numpy(), z_fine=z_fine.numpy(), z_sorted=z_all.numpy(),
+        sorted_idxs=order.numpy(), **{"final_" + k: v for k, v in fin.items()})
+    print("danbo_stages: valid frac", 1 - invalid.numpy().mean(), "acc mean", fin["acc_map"].mean())
+
+
+def gen_danbo_surreal():
+    seed = 12
+    cfg, args, caster, kw_test, rest = build("danbo_surreal", seed, n_framecodes=4)
+    scene = syn.make_scene(n_poses=1, H=64, W=64, n_views=3, pose_seed=2, rest_scale=cfg["rest_scale"], cam_dist=5.0)
+    ro, rd = scene["rays"][1]
+    rb = syn.ray_batch(ro, rd)
+    pose = np.zeros(len(ro), dtype=np.int64)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    S, Sf = 32, 16
+    fin = call_caster(caster, kw_test, rb, kps, skts, cyls, bones, None, S, Sf, 1)
+    with torch.no_grad():
+        near, far = caster.get_near_far(T(ro), T(rd), T(cyls), near=T(rb[:, 6:7]), far=T(rb[:, 7:8]), skts=T(skts))
+        from core.utils.ray_utils import get_near_far_in_cylinder
+        cn, cf = get_near_far_in_cylinder(T(ro), T(rd), T(cyls), near=T(rb[:, 6:7]), far=T(rb[:, 7:8]))
+    np.savez_compressed(
+        os.path.join(OUT, "danbo_surreal.npz"),
+        cfg_name="danbo_surreal", weight_seed=seed, n_framecodes=4, N_samples=S, N_importance=Sf, n_uniques=1,
+        pose_seed=2, cam_dist=5.0, view=1, H=64, W=64,
+        near=near.numpy(), far=far.numpy(), cyl_near=cn.numpy(), cyl_far=cf.numpy(),
+        **{"final_" + k: v for k, v in fin.items() if k in ("rgb_map", "disp_map", "acc_map", "rgb0", "acc0")})
+    miss = np.isnan(np.sqrt(1.0)).sum()
+    print("danbo_surreal: acc mean", fin["acc_map"].mean(), "rays", len(ro))
+
+
+def gen_danbo_perfcap():
+    seed = 13
+    cfg, args, caster, kw_test, rest = build("danbo_perfcap", seed)
+    scene = syn.make_scene(n_poses=1, H=96, W=96, n_views=4, pose_seed=9)
+    ro, rd = body_rays(scene, 2, 256, seed=3)
+    rb = syn.ray_batch(ro, rd)
+    pose = np.zeros(len(ro), dtype=np.int64)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    S, Sf = 32, 16
+    cams = T(-np.ones(len(ro)), torch.long)
+    fin = call_caster(caster, kw_test, rb, kps, skts, cyls, bones, cams, S, Sf, 1)
+    net = caster.network
+    with torch.no_grad():
+        rays_o, rays_d = T(ro), T(rd)
+        near, far = caster.get_near_far(rays_o, rays_d, T(cyls), near=T(rb[:, 6:7]), far=T(rb[:, 7:8]), skts=T(skts))
+        pts, z = caster.sample_pts(rays_o, rays_d, near, far, len(ro), S, 0., False)
+        inputs = caster.get_nerf_inputs(pts, [rays_o[:, None, :], rays_d[:, None, :]], T(kps), T(skts), T(bones),
+                                        cam_idxs=cams, N_uniques=1)
+        raw, _ = net(inputs)
+        dens_in, enc = net.encode_pts(inputs)
+        view_in, _ = net.encode_views(inputs, refs=enc["pts_t"], encoded_pts=enc)
+    np.savez_compressed(
+        os.path.join(OUT, "danbo_perfcap.npz"),
+        cfg_name="danbo_perfcap", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=1,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
+        rest_pose=rest, near=near.numpy(), far=far.numpy(), raw_coarse=raw.numpy(),
+        view_inputs=view_in.numpy()[::S].copy(),
+        **{"final_" + k: v for k, v in fin.items()})
+    print("danbo_perfcap: acc mean", fin["acc_map"].mean())
+
+
+def gen_pose_rot6d():
+    rh.install_stubs()
+    from core.utils.skeleton_utils import axisang_to_rot6d
+    rng = np.random.default_rng(0)
+    aa = rng.normal(0, 0.6, size=(6, 24, 3)).astype(np.float32)
+    aa[0, :4] = 0.0
+    aa[0, 4] = [1e-8, -2e-8, 1e-9]
+    aa[0, 5] = [3e-7, 0, 0]
+    aa[1, 0] = [np.pi - 1e-3, 0, 0]
+    out = axisang_to_rot6d(T(aa)).numpy()
+    np.savez_compressed(os.path.join(OUT, "pose_rot6d.npz"), axis_angle=aa, rot6d=out)
+
+
+if __name__ == "__main__":
+    assert rh.reference_available(), "needs /root/reference (build container only)"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d"]
+    if "stages" in which:
+        gen_danbo_stages()
+    if "surreal" in which:
+        gen_danbo_surreal()
+    if "perfcap" in which:
+        gen_danbo_perfcap()
+    if "rot6d" in which:
+        gen_pose_rot6d()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

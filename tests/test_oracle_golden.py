@@ -1,0 +1,241 @@
+"""Pin the numpy oracle (oracle/danbo_oracle.py) to the reference's own outputs.
+
+Golden vectors were produced by importing /root/reference in the build container
+(oracle/gen_golden.py).  Tolerances are absolute fp32 round-off levels, written per stage.
+"""
+import numpy as np
+import pytest
+
+import danbo_oracle as o
+from helpers import golden, oracle_for, max_err, rel_err
+
+
+@pytest.fixture(scope="module")
+def stages():
+    g = golden("danbo_stages")
+    orc, cfg, sd, rest = oracle_for(g)
+    pose = g["pose_of_ray"]
+    ret = orc.render(g["ray_batch"], g["skts"][pose], g["bones"][pose], g["cyls"][pose],
+                     cam_idxs=g["cam_idx"], n_uniques=int(g["n_uniques"]),
+                     N_samples=int(g["N_samples"]), N_importance=int(g["N_importance"]), stages=True)
+    return g, orc, ret
+
+
+def test_rest_pose_and_align_transforms(stages):
+    g, orc, _ = stages
+    assert max_err(orc.rest_pose, g["rest_pose"]) == 0.0
+    assert max_err(orc.align, g["align"]) == 0.0
+
+
+def test_align_maps_bone_to_plus_z(stages):
+    # known answer: rotation takes the rest-pose bone to +z, t = -|bone|/2 z
+    g, orc, _ = stages
+    rest = g["rest_pose"]
+    child_of = {4: 7, 7: 10, 18: 20}  # knee->ankle->foot, elbow->wrist: single-child bones
+    for parent, child in child_of.items():
+        d = rest[child] - rest[parent]
+        r = orc.align[parent, :3, :3].astype(np.float64) @ d
+        assert abs(r[0]) < 1e-6 and abs(r[1]) < 1e-6 and abs(r[2] - np.linalg.norm(d)) < 1e-6
+        assert abs(orc.align[parent, 2, 3] + 0.5 * np.linalg.norm(d)) < 1e-6
+    for j in (0, 9, 10, 15, 22):  # root, 3-children spine3, end effectors -> identity
+        assert np.array_equal(orc.align[j], np.eye(4, dtype=np.float32))
+
+
+def test_near_far_and_coarse_samples(stages):
+    g, _, ret = stages
+    assert max_err(ret["near"], g["near"]) == 0.0
+    assert max_err(ret["far"], g["far"]) == 0.0
+    assert max_err(ret["z_coarse"], g["z_coarse"]) == 0.0
+
+
+def test_bone_local_points_bit_exact(stages):
+    g, _, ret = stages
+    assert np.array_equal(ret["enc"]["pts_t"], g["pts_t"])
+
+
+def test_in_volume_mask_bit_exact(stages):
+    g, _, ret = stages
+    inv = (~ret["enc"]["valid"]).astype(np.float32)
+    assert int((inv != g["invalid"]).sum()) == 0
+    assert (1 - g["invalid"]).sum() > 50  # the fixture does exercise the mask
+
+
+def test_pose_graph_and_volumes(stages):
+    g, _, ret = stages
+    assert max_err(o.rot6d(g["bones"]), g["rot6d"]) < 5e-7
+    assert max_err(ret["enc"]["volumes"], g["volumes"]) < 2e-5  # |v| up to ~7
+
+
+def test_factorised_gather_and_window(stages):
+    g, _, ret = stages
+    assert max_err(ret["enc"]["part_feat"], g["part_feat"]) < 5e-6
+
+
+def test_assignment_and_blend(stages):
+    g, _, ret = stages
+    e = ret["enc"]
+    assert max_err(e["confd"], g["confd"]) < 1e-5
+    assert max_err(e["agg_p"], g["agg_p"]) < 2e-6
+    assert max_err(e["density_inputs"], g["density_inputs"]) < 2e-4  # sin(32 h) amplifies 1e-6
+
+
+def test_view_inputs(stages):
+    g, _, ret = stages
+    S = int(g["N_samples"])
+    assert max_err(ret["enc"]["view_inputs"][::S], g["view_inputs"]) < 1e-6
+
+
+def test_mlp_raw(stages):
+    g, _, ret = stages
+    assert rel_err(ret["raw_coarse"], g["raw_coarse"], floor=1.0) < 1e-4  # north_star tolerance
+
+
+def test_coarse_composite(stages):
+    g, _, ret = stages
+    assert max_err(ret["weights_coarse"], g["weights_coarse"]) < 2e-5
+    assert max_err(ret["alpha0"], g["alpha_coarse"]) < 2e-5
+    assert max_err(ret["rgb0"], g["rgb_coarse"]) < 2e-5
+
+
+def test_importance_samples_and_merge(stages):
+    g, _, ret = stages
+    assert max_err(ret["z_fine"], g["z_fine"]) < 5e-5
+    assert max_err(ret["z_sorted"], g["z_sorted"]) < 5e-5
+    assert int((ret["sorted_idxs"] != g["sorted_idxs"]).sum()) == 0
+
+
+def test_final_maps(stages):
+    # end-to-end: the importance samples are a function of the coarse weights, so fp32
+    # round-off in raw (<=1e-4 rel) moves z_fine by ~1e-5 and, with densities up to ~30,
+    # alpha by a few 1e-4.  Stage-wise parity on identical inputs is checked above/below.
+    g, _, ret = stages
+    for k in ("rgb_map", "acc_map", "alpha", "T_i", "rgb0", "acc0", "alpha0"):
+        assert max_err(ret[k], g["final_" + k]) < 5e-4, k
+    for k in ("disp_map", "disp0"):
+        assert rel_err(ret[k], g["final_" + k], floor=1.0) < 5e-4, k
+    assert o.psnr(ret["rgb_map"], g["final_rgb_map"]) > 70.0
+
+
+def test_fine_pass_on_golden_samples(stages):
+    # decoupled: feed the reference's own sorted samples / merge order
+    g, orc, ret = stages
+    pose = g["pose_of_ray"]
+    rb = g["ray_batch"]
+    pts_f = o.sample_points(rb[:, 0:3], rb[:, 3:6], g["z_fine"])
+    raw_f, _ = orc.forward(pts_f, rb[:, 3:6], g["skts"][pose], g["bones"][pose], g["cam_idx"], int(g["n_uniques"]))
+    raw_all = np.take_along_axis(np.concatenate([g["raw_coarse"], raw_f], 1), g["sorted_idxs"][..., None], 1)
+    out = o.composite(raw_all, g["z_sorted"], rb[:, 3:6])
+    assert max_err(out["alpha"], g["final_alpha"]) < 5e-5
+    assert max_err(out["weights"], g["final_T_i"]) < 5e-5
+    assert max_err(out["rgb_map"], g["final_rgb_map"]) < 5e-5
+    assert max_err(out["acc_map"], g["final_acc_map"]) < 5e-5
+
+
+def _scene_inputs(g, cfg):
+    from core.utils import synthetic as syn
+    scene = syn.make_scene(n_poses=1, H=int(g["H"]), W=int(g["W"]), n_views=3, pose_seed=int(g["pose_seed"]),
+                           rest_scale=cfg["rest_scale"], cam_dist=float(g["cam_dist"]))
+    ro, rd = scene["rays"][int(g["view"])]
+    rb = syn.ray_batch(ro, rd)
+    z = np.zeros(len(ro), dtype=np.int64)
+    return rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z]
+
+
+def test_surreal_full_frame_box_near_far_and_nan_backfill():
+    g = golden("danbo_surreal")
+    orc, cfg, sd, rest = oracle_for(g)
+    rb, skts, bones, cyls = _scene_inputs(g, cfg)
+    cn, cf = o.near_far_cylinder(rb[:, 0:3], rb[:, 3:6], cyls, rb[:, 6:7], rb[:, 7:8])
+    # rays that miss the cylinder exist in this frame and take the chunk-wide nan-mean
+    n_miss = int(o.cylinder_miss_mask(rb[:, 0:3], rb[:, 3:6], cyls, rb[:, 6:7], rb[:, 7:8]).sum())
+    assert 50 < n_miss < 2000
+    assert max_err(cn, g["cyl_near"]) < 2e-6 and max_err(cf, g["cyl_far"]) < 2e-6
+    n, f = orc.near_far(rb[:, 0:3], rb[:, 3:6], cyls, skts, rb[:, 6:7], rb[:, 7:8])
+    # step = |p - o| / |d| is ill-conditioned for grazing hits: 1e-5 on a handful of rays
+    assert max_err(n, g["near"]) < 3e-5 and max_err(f, g["far"]) < 3e-5
+    assert (np.abs(n - g["near"]) > 2e-6).sum() < 10
+    changed = (np.abs(g["near"] - g["cyl_near"]) > 1e-6).mean()
+    assert 0.05 < changed < 0.9  # box near/far applies to a real fraction of the frame
+    # the network is checked on the reference's own bounds (a 1-ulp change of near moves
+    # every sample of the ray; the random-weight net is steep enough to turn that into 1e-2)
+    ret = orc.render(rb, skts, bones, cyls, None, 1, int(g["N_samples"]), int(g["N_importance"]),
+                     near_far=(g["near"], g["far"]))
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
+        assert max_err(ret[k], g["final_" + k]) < 1e-3, k
+    assert o.psnr(ret["rgb_map"], g["final_rgb_map"]) > 70.0
+
+
+def test_perfcap_root_local_view_branch():
+    g = golden("danbo_perfcap")
+    orc, cfg, sd, rest = oracle_for(g)
+    z = np.zeros(len(g["ray_batch"]), dtype=np.int64)
+    rb = g["ray_batch"]
+    n, f = orc.near_far(rb[:, 0:3], rb[:, 3:6], g["cyls"][z], g["skts"][z], rb[:, 6:7], rb[:, 7:8])
+    assert max_err(n, g["near"]) < 5e-6 and max_err(f, g["far"]) < 5e-6
+    ret = orc.render(rb, g["skts"][z], g["bones"][z], g["cyls"][z], -np.ones(len(rb), dtype=np.int64), 1,
+                     int(g["N_samples"]), int(g["N_importance"]), stages=True, near_far=(g["near"], g["far"]))
+    S = int(g["N_samples"])
+    assert max_err(ret["enc"]["view_inputs"][::S], g["view_inputs"]) < 2e-6
+    assert rel_err(ret["raw_coarse"], g["raw_coarse"], floor=1.0) < 1e-4
+    for k in ("rgb_map", "acc_map", "alpha", "T_i", "rgb0", "acc0"):
+        assert max_err(ret[k], g["final_" + k]) < 1e-3, k
+    assert o.psnr(ret["rgb_map"], g["final_rgb_map"]) > 70.0
+
+
+def test_rot6d_against_reference_and_scipy():
+    from scipy.spatial.transform import Rotation
+    g = golden("pose_rot6d")
+    aa = g["axis_angle"]
+    mine = o.rot6d(aa)
+    assert max_err(mine, g["rot6d"]) < 1e-6
+    ref = Rotation.from_rotvec(aa.reshape(-1, 3).astype(np.float64)).as_matrix()[:, :, :2].reshape(aa.shape[:-1] + (6,))
+    assert max_err(mine, ref) < 1e-6
+    assert max_err(o.rot6d(np.zeros((1, 3), np.float32)), np.array([[1, 0, 0, 1, 0, 0]], np.float32)) == 0.0
+
+
+# ---- closed-form known answers (the reference has no tests of its own) ----
+def test_pe_of_zero_and_order():
+    pe = o.positional_encoding(np.zeros((1, 3), np.float32), 2)
+    assert pe.tolist() == [[0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1]]
+    x = np.array([[0.5, -0.25]], np.float32)
+    pe = o.positional_encoding(x, 2)
+    exp = np.concatenate([x, np.sin(x), np.cos(x), np.sin(2 * x), np.cos(2 * x)], -1)
+    assert max_err(pe, exp) < 1e-7
+
+
+def test_composite_constant_density():
+    # sigma const, unit spacing: alpha = 1-exp(-sigma), w_i = alpha (1-alpha)^i, last alpha = 1
+    S, sigma = 6, 0.7
+    raw = np.zeros((1, S, 4), np.float32)
+    raw[..., 3] = sigma
+    z = np.arange(S, dtype=np.float32)[None] + 2
+    out = o.composite(raw, z, np.array([[0, 0, 1.]], np.float32))
+    a = 1 - np.exp(-sigma)
+    exp = np.array([a * (1 - a) ** i for i in range(S - 1)] + [(1 - a) ** (S - 1)])
+    assert max_err(out["weights"][0], exp) < 1e-6
+    assert abs(out["acc_map"][0] - 1.0) < 1e-6
+    assert max_err(out["rgb_map"][0], np.full(3, 0.5 * 1.002 - 0.001)) < 1e-6
+
+
+def test_in_volume_boundary_is_inclusive():
+    sc = np.full((24, 3), 0.3, np.float32)
+    p = np.zeros((1, 1, 24, 3), np.float32)
+    p[0, 0, 1, 0] = np.float32(0.3)                      # exactly on the face -> valid
+    p[0, 0, 2, 1] = np.nextafter(np.float32(0.3), np.float32(1))   # one ulp outside -> invalid
+    p[0, 0, 3, 2] = -np.float32(0.3)
+    _, valid = o.in_volume(p, sc)
+    assert valid[0, 0, 1] and not valid[0, 0, 2] and valid[0, 0, 3]
+    # the division-free form used by the HIP kernel is equivalent
+    assert np.array_equal(valid, ~(np.abs(p) > sc[None, None]).any(-1))
+
+
+def test_identity_skeleton_transform():
+    pts = np.random.default_rng(0).normal(size=(3, 4, 3)).astype(np.float32)
+    skts = np.tile(np.eye(4, dtype=np.float32), (3, 24, 1, 1))
+    align = np.tile(np.eye(4, dtype=np.float32), (24, 1, 1))
+    out = o.bone_local(pts, skts, align)
+    assert np.array_equal(out, np.broadcast_to(pts[:, :, None, :], out.shape))
+
+
+def test_adjacency_has_70_nonzeros():
+    assert int(o.adjacency().sum()) == 70
