@@ -1,0 +1,65 @@
+"""ctypes binding of libdanbo_hip.so (C ABI declared in include/danbo_hip.h).
+
+The library is the only compute backend of this package: there is NO PyTorch/CPU fallback.
+`lib()` raises if the shared object is missing, and every wrapper in hip_ops raises if a
+tensor is not a CUDA(HIP) tensor.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdanbo_hip.so")
+
+P = c_void_p  # device pointer
+I = c_int
+F = c_float
+
+# name -> argtypes, exactly as declared in include/danbo_hip.h
+SIGNATURES = {
+    "danbo_abi_version": [],
+    "danbo_device_info": [POINTER(c_int), POINTER(c_int), c_char_p, I],
+    "danbo_pose_volumes_fwd": [P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "danbo_near_far_cylinder": [P, P, P, I, I, F, F, I, P, P, P, P],
+    "danbo_near_far_boxes": [P, P, P, P, P, I, I, P, P, P],
+    "danbo_coarse_samples": [P, P, I, I, P, P, P],
+    "danbo_bone_cull": [P, P, P, P, I, I, I, P, P, P, P, P, P, P],
+    "danbo_bone_gather_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P, P],
+    "danbo_assign_blend_fwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
+    "danbo_gather_assign_blend_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
+    "danbo_mlp_pack": [POINTER(c_void_p), P, P, I, P, P, P],
+    "danbo_view_consts": [P, P, I, I, I, I, I, P, I, I, P, P, P, P, P, P, P, P, P, P],
+    "danbo_pe_mlp_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P, P],
+    "danbo_fill_raw": [P, I, I, P, P],
+    "danbo_composite_fwd": [P, P, P, I, I, F, P, P, P, P, P, P, P],
+    "danbo_importance_samples": [P, P, I, I, I, P, P, P, P, P],
+    "danbo_merge_samples": [P, P, P, I, I, I, I, P, P],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C danbo-pytorch_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback.")
+        import torch  # noqa: F401  (loads torch's bundled libamdhip64 first so both share one HIP runtime)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = l
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(code, name):
+    if code != 0:
+        raise HipError(f"{name} failed with code {code}" + (" (invalid argument)" if code == -22 else ""))

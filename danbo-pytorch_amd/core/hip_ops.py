@@ -1,0 +1,228 @@
+"""Torch-tensor wrappers around the C ABI (include/danbo_hip.h).
+
+PyTorch is used here for device memory and streams only.  Every function enqueues on
+`torch.cuda.current_stream()` and returns without synchronising.  Non-CUDA tensors are
+rejected: there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+
+J = 24
+VOL = 240
+FEAT = 15
+H_STRIDE = 16
+MLP_PACKED_FLOATS = 659456
+VIEW_W = 128
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/HIP tensor -- libdanbo_hip has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _call(name, *args):
+    _hip.check(getattr(_hip.lib(), name)(*args), name)
+
+
+# --------------------------------------------------------------------------------------
+def pose_volumes(bones, gw, L_graph=5):
+    """bones [G,24,3]; gw: dict(w0,adjw0,b0,w1,adjw1,b1,w2,b2,w3,b3) -> volumes [G,24,240]."""
+    bones = _f32(bones, "bones")
+    G = bones.shape[0]
+    W = gw["w1"].shape[-1]
+    scratch = torch.empty(3 * G * J * W, device=bones.device, dtype=torch.float32)
+    vol = torch.empty(G, J, VOL, device=bones.device, dtype=torch.float32)
+    _call("danbo_pose_volumes_fwd", _p(bones), G, L_graph, W,
+          _p(gw["w0"]), _p(gw["adjw0"]), _p(gw["b0"]), _p(gw["w1"]), _p(gw["adjw1"]), _p(gw["b1"]),
+          _p(gw["w2"]), _p(gw["b2"]), _p(gw["w3"]), _p(gw["b3"]), _p(scratch), _p(vol), _stream())
+    return vol
+
+
+def near_far_cylinder(rays_o, rays_d, cyl, near0=0.0, far0=1.0, chunk=4096):
+    rays_o, rays_d, cyl = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(cyl, "cyl")
+    R, G = rays_o.shape[0], cyl.shape[0]
+    nchunk = (R + chunk - 1) // chunk
+    scratch = torch.empty(nchunk * 8, device=rays_o.device, dtype=torch.float32)
+    near = torch.empty(R, device=rays_o.device, dtype=torch.float32)
+    far = torch.empty_like(near)
+    _call("danbo_near_far_cylinder", _p(rays_o), _p(rays_d), _p(cyl), R, G, float(near0), float(far0), int(chunk),
+          _p(scratch), _p(near), _p(far), _stream())
+    return near, far
+
+
+def near_far_boxes(rays_o, rays_d, skts, align, axis_scale, near, far):
+    """updates near/far in place"""
+    R, G = rays_o.shape[0], skts.shape[0]
+    _call("danbo_near_far_boxes", _p(_f32(rays_o, "rays_o")), _p(_f32(rays_d, "rays_d")), _p(_f32(skts, "skts")),
+          _p(_f32(align, "align")), _p(_f32(axis_scale, "axis_scale")), R, G, _p(near), _p(far), _stream())
+    return near, far
+
+
+def coarse_samples(near, far, S, t_rand=None):
+    R = near.shape[0]
+    z = torch.empty(R, S, device=near.device, dtype=torch.float32)
+    _call("danbo_coarse_samples", _p(near), _p(far), R, S, _p(_f32(t_rand, "t_rand")), _p(z), _stream())
+    return z
+
+
+class Geometry:
+    """Per-call bundle of the geometric inputs shared by K1a / K1b / K2."""
+
+    def __init__(self, rays_o, rays_d, skts, align, axis_scale, z=None, pts=None):
+        self.rays_o = _f32(rays_o, "rays_o")
+        self.rays_d = _f32(rays_d, "rays_d")
+        self.skts = _f32(skts, "skts")          # [G,24,4,4]
+        self.align = _f32(align, "align")        # [24,4,4]
+        self.axis_scale = _f32(axis_scale, "axis_scale")
+        self.z = _f32(z, "z")
+        self.pts = _f32(pts, "pts")
+        assert (self.z is None) != (self.pts is None)
+        self.R = self.rays_o.shape[0]
+        self.G = self.skts.shape[0]
+        self.S = self.z.shape[1] if self.z is not None else self.pts.shape[1]
+        self.M = self.R * self.S
+        self.device = self.rays_o.device
+
+    def head(self):
+        return (_p(self.rays_o), _p(self.rays_d), _p(self.z), _p(self.pts), self.R, self.S, self.G,
+                _p(self.skts), _p(self.align), _p(self.axis_scale))
+
+
+def bone_cull(geo, compact=True):
+    """-> valid_bits [M] (int32 view of uint32), list [M] int32 or None, count [1] int32 or None."""
+    bits = torch.empty(geo.M, device=geo.device, dtype=torch.int32)
+    lst = cnt = None
+    if compact:
+        lst = torch.empty(geo.M, device=geo.device, dtype=torch.int32)
+        cnt = torch.zeros(1, device=geo.device, dtype=torch.int32)
+    _call("danbo_bone_cull", *geo.head(), _p(bits), _p(lst), _p(cnt), _stream())
+    return bits, lst, cnt
+
+
+def bone_gather(geo, volumes, lst=None, cnt=None, n=None):
+    n = geo.M if n is None else n
+    out = torch.empty(n, J, FEAT, device=geo.device, dtype=torch.float32)
+    _call("danbo_bone_gather_fwd", *geo.head(), _p(volumes), _p(lst), _p(cnt), n, _p(out), _stream())
+    return out
+
+
+def assign_blend(part_feat, bits, aw, lst=None, cnt=None, n=None, want_confd=False):
+    n = part_feat.shape[0] if n is None else n
+    h = torch.empty(n, H_STRIDE, device=part_feat.device, dtype=torch.float32)
+    confd = torch.empty(n, J, device=part_feat.device, dtype=torch.float32) if want_confd else None
+    _call("danbo_assign_blend_fwd", _p(part_feat), _p(bits), _p(lst), _p(cnt), n,
+          _p(aw["w0"]), _p(aw["adjw"]), _p(aw["b0"]), _p(aw["w1"]), _p(aw["b1"]), _p(aw["w2"]), _p(aw["b2"]),
+          _p(h), _p(confd), _stream())
+    return h, confd
+
+
+def gather_assign_blend(geo, volumes, bits, aw, lst=None, cnt=None, n=None, want_confd=False):
+    n = geo.M if n is None else n
+    h = torch.empty(n, H_STRIDE, device=geo.device, dtype=torch.float32)
+    confd = torch.empty(n, J, device=geo.device, dtype=torch.float32) if want_confd else None
+    _call("danbo_gather_assign_blend_fwd", *geo.head(), _p(volumes), _p(bits), _p(lst), _p(cnt), n,
+          _p(aw["w0"]), _p(aw["adjw"]), _p(aw["b0"]), _p(aw["w1"]), _p(aw["b1"]), _p(aw["w2"]), _p(aw["b2"]),
+          _p(h), _p(confd), _stream())
+    return h, confd
+
+
+def mlp_pack(pts_w, feature_w, views_w):
+    """pts_w: 8 tensors; views_w [128, 256+Cv] -> (packed [659456], views_w_ray_t [Cv,128])."""
+    dev = feature_w.device
+    Cv = views_w.shape[1] - 256
+    packed = torch.empty(MLP_PACKED_FLOATS, device=dev, dtype=torch.float32)
+    wrt = torch.empty(max(Cv, 1), VIEW_W, device=dev, dtype=torch.float32)
+    pts_w = [_f32(w, "pts_w") for w in pts_w]
+    _call("danbo_mlp_pack", _ptr_array(pts_w), _p(_f32(feature_w, "feature_w")), _p(_f32(views_w, "views_w")), Cv,
+          _p(packed), _p(wrt), _stream())
+    return packed, wrt
+
+
+def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code, cam_idx, wrt, views_b,
+                rgb_w, rgb_b, empty_consts=None):
+    rays_d = _f32(rays_d, "rays_d")
+    R, G = rays_d.shape[0], skts.shape[0]
+    Cf = 0 if mean_code is None else mean_code.shape[0]
+    n_codes = 0 if framecodes is None else framecodes.shape[0]
+    cview = torch.empty(R, VIEW_W, device=rays_d.device, dtype=torch.float32)
+    raw_empty = torch.empty(R, 4, device=rays_d.device, dtype=torch.float32) if empty_consts is not None else None
+    if cam_idx is not None:
+        cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
+    _call("danbo_view_consts", _p(rays_d), _p(_f32(skts, "skts")), R, G, int(ray_mode), int(normalise), int(L_view),
+          _p(framecodes), n_codes, Cf, _p(mean_code), _p(cam_idx), _p(wrt), _p(views_b), _p(rgb_w), _p(rgb_b),
+          _p(empty_consts), _p(cview), _p(raw_empty), _stream())
+    return cview, raw_empty
+
+
+def pe_mlp(h, S, packed, pts_b, alpha_w, alpha_b, feature_b, cview, rgb_w, rgb_b, raw_out,
+           lst=None, cnt=None, n=None, aux=False):
+    n = h.shape[0] if n is None else n
+    aux_out = torch.empty(n, VIEW_W + 1, device=h.device, dtype=torch.float32) if aux else None
+    _call("danbo_pe_mlp_fwd", _p(h), _p(lst), _p(cnt), n, S, _p(packed), _ptr_array(pts_b), _p(alpha_w), _p(alpha_b),
+          _p(feature_b), _p(cview), _p(rgb_w), _p(rgb_b), _p(raw_out), _p(aux_out), _stream())
+    return aux_out
+
+
+def fill_raw(raw_empty, S):
+    R = raw_empty.shape[0]
+    raw = torch.empty(R, S, 4, device=raw_empty.device, dtype=torch.float32)
+    _call("danbo_fill_raw", _p(raw_empty), R, S, _p(raw), _stream())
+    return raw
+
+
+def composite(raw, z, rays_d, B=1.0, noise=None):
+    raw, z, rays_d = _f32(raw, "raw"), _f32(z, "z"), _f32(rays_d, "rays_d")
+    R, S = z.shape
+    dev = raw.device
+    rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+    disp = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    w = torch.empty(R, S, device=dev, dtype=torch.float32)
+    al = torch.empty(R, S, device=dev, dtype=torch.float32)
+    _call("danbo_composite_fwd", _p(raw), _p(z), _p(rays_d), R, S, float(B), _p(_f32(noise, "noise")),
+          _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _stream())
+    return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
+
+
+def importance_samples(z, weights, Sf, u=None):
+    R, S = z.shape
+    dev = z.device
+    zf = torch.empty(R, Sf, device=dev, dtype=torch.float32)
+    zs = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
+    idx = torch.empty(R, S + Sf, device=dev, dtype=torch.int32)
+    _call("danbo_importance_samples", _p(_f32(z, "z")), _p(_f32(weights, "weights")), R, S, Sf, _p(_f32(u, "u")),
+          _p(zf), _p(zs), _p(idx), _stream())
+    return zs, zf, idx
+
+
+def merge_samples(a, b, idx):
+    """a [R,S,C], b [R,Sf,C], idx int32 [R,S+Sf] -> [R,S+Sf,C]"""
+    R, S = a.shape[:2]
+    Sf = b.shape[1]
+    C = a[0, 0].numel()
+    out = torch.empty((R, S + Sf) + tuple(a.shape[2:]), device=a.device, dtype=torch.float32)
+    _call("danbo_merge_samples", _p(_f32(a, "a")), _p(_f32(b, "b")), _p(idx), R, S, Sf, C, _p(out), _stream())
+    return out

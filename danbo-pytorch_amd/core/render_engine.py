@@ -1,0 +1,141 @@
+"""Orchestration of the HIP kernels for the DANBO render path (eval forward).
+
+`DanboEngine` owns nothing but *views* of the model parameters plus two derived buffers
+(MFMA-packed MLP weights, empty-space constants) that are rebuilt whenever a parameter's
+version counter changes.  All work is enqueued on the current HIP stream; no call in here
+synchronises with the host.
+
+Stage map (reference file:line in include/danbo_hip.h):
+    pose_volumes -> [near/far -> coarse z] -> K1a cull+compact -> K1b+K2 gather/assign/blend
+    -> view consts + raw fill -> K3 PE+MLP (scatter) -> K4 composite -> importance -> fine pass
+"""
+import torch
+
+from . import hip_ops as ops
+
+
+class DanboEngine:
+    def __init__(self, cfg, params, align, buffers=None):
+        """cfg: dict (see core/utils/synthetic.model_config); params: name -> CUDA tensor using the
+        reference's state_dict names; align: [24,4,4] bone-align transforms."""
+        self.cfg = cfg
+        self.p = params
+        self.align = align.float().contiguous()
+        self._packed_key = None
+        self.packed = self.wrt = self.empty_consts = None
+        self.mean_code = None
+
+    # ------------------------------------------------------------------ derived buffers
+    def _key(self):
+        return tuple((k, v.data_ptr(), v._version) for k, v in sorted(self.p.items()))
+
+    def refresh(self):
+        key = self._key()
+        if key == self._packed_key:
+            return
+        p = self.p
+        dev = p["alpha_linear.weight"].device
+        self.pts_w = [p[f"pts_linears.{i}.weight"] for i in range(8)]
+        self.pts_b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(8)]
+        self.packed, self.wrt = ops.mlp_pack(self.pts_w, p["feature_linear.weight"], p["views_linears.0.weight"])
+        self.alpha_w = p["alpha_linear.weight"].reshape(-1).contiguous()
+        self.alpha_b = p["alpha_linear.bias"].contiguous()
+        self.feature_b = p["feature_linear.bias"].contiguous()
+        self.views_b = p["views_linears.0.bias"].contiguous()
+        self.rgb_w = p["rgb_linear.weight"].contiguous()
+        self.rgb_b = p["rgb_linear.bias"].contiguous()
+        g = "graph_net.layers."
+        self.gw = dict(
+            w0=p[g + "0.lin.weight"].contiguous(), adjw0=(p[g + "0.adj_w"] * p[g + "0.adj"])[0].contiguous(),
+            b0=p[g + "0.bias"].contiguous(),
+            w1=p[g + "1.lin.weight"].contiguous(), adjw1=(p[g + "1.adj_w"] * p[g + "1.adj"])[0].contiguous(),
+            b1=p[g + "1.bias"].contiguous(),
+            w2=p[g + "2.weight"].contiguous(), b2=p[g + "2.bias"].reshape(24, -1).contiguous(),
+            w3=p[g + "3.weight"].contiguous(), b3=p[g + "3.bias"].reshape(24, -1).contiguous())
+        a = "prob_linears.layers."
+        self.aw = dict(
+            w0=p[a + "0.lin.weight"].contiguous(), adjw=(p[a + "0.adj_w"] * p[a + "0.adj"])[0].contiguous(),
+            b0=p[a + "0.bias"].contiguous(), w1=p[a + "1.weight"].contiguous(),
+            b1=p[a + "1.bias"].reshape(24, -1).contiguous(), w2=p[a + "2.weight"].reshape(24, -1).contiguous(),
+            b2=p[a + "2.bias"].reshape(-1).contiguous())
+        self.axis_scale = p["graph_net.axis_scale"].contiguous()
+        if self.cfg["use_framecode"]:
+            self.framecodes = p["framecodes.codes.weight"].contiguous()
+            self.mean_code = self.framecodes.mean(0).contiguous()
+        else:
+            self.framecodes = self.mean_code = None
+        # empty-space constants: one zero row through the MLP without the per-ray view term
+        h0 = torch.zeros(1, ops.H_STRIDE, device=dev)
+        scratch_raw = torch.empty(1, 4, device=dev)
+        aux = ops.pe_mlp(h0, 1, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, None,
+                         self.rgb_w, self.rgb_b, scratch_raw, aux=True)
+        self.empty_consts = aux.reshape(-1).contiguous()
+        self._packed_key = key
+
+    # ------------------------------------------------------------------ network forward
+    def volumes(self, bones):
+        self.refresh()
+        return ops.pose_volumes(bones, self.gw, self.cfg["multires_graph"])
+
+    def view_constants(self, rays_d, skts, cam_idx):
+        cfg = self.cfg
+        ray_mode = {"world": 0, "root_local": 1}[cfg["ray_tr_type"]]
+        normalise = 1 if cfg["view_type"] == "relray" else 0
+        return ops.view_consts(rays_d, skts, ray_mode, normalise, cfg["multires_views"], self.framecodes,
+                               self.mean_code, cam_idx, self.wrt, self.views_b, self.rgb_w, self.rgb_b,
+                               self.empty_consts)
+
+    def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
+                        want_confd=False, volumes=None, view=None):
+        """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
+
+        dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
+                     the per-ray empty-space raw (identical values).
+        dense=True : every sample goes through every kernel (the reference's executed work)."""
+        self.refresh()
+        geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts)
+        vols = self.volumes(bones) if volumes is None else volumes
+        cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
+        S = geo.S
+        bits, lst, cnt = ops.bone_cull(geo, compact=not dense)
+        h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
+        raw = ops.fill_raw(raw_empty, S)
+        ops.pe_mlp(h, S, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
+                   self.rgb_w, self.rgb_b, raw, lst, cnt, geo.M)
+        extras = dict(valid_bits=bits, list=lst, count=cnt, confd_rows=confd, h_rows=h, volumes=vols)
+        return raw, extras
+
+    # ------------------------------------------------------------------ RayCaster.render_rays (eval)
+    def near_far(self, rays_o, rays_d, cyls, skts, near0=0.0, far0=1.0, chunk=4096):
+        self.refresh()
+        near, far = ops.near_far_cylinder(rays_o, rays_d, cyls, near0, far0, chunk)
+        if self.cfg["use_volume_near_far"]:
+            ops.near_far_boxes(rays_o, rays_d, skts, self.align, self.axis_scale, near, far)
+        return near, far
+
+    def render(self, rays_o, rays_d, skts, bones, cyls, cam_idx=None, N_samples=None, N_importance=None,
+               chunk=4096, near_far=None, dense=False, keep=False):
+        cfg = self.cfg
+        S = N_samples or cfg["N_samples"]
+        Sf = N_importance or cfg["N_importance"]
+        B = cfg["density_scale"]
+        self.refresh()
+        near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
+        z = ops.coarse_samples(near, far, S)
+        vols = self.volumes(bones)
+        view = self.view_constants(rays_d, skts, cam_idx)
+        raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view)
+        out0 = ops.composite(raw, z, rays_d, B)
+        z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
+        raw_f, ex_f = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z_fine, dense=dense,
+                                           volumes=vols, view=view)
+        raw_all = ops.merge_samples(raw, raw_f, order)
+        out = ops.composite(raw_all, z_all, rays_d, B)
+        ret = dict(rgb_map=out["rgb_map"], disp_map=out["disp_map"], acc_map=out["acc_map"], alpha=out["alpha"],
+                   T_i=out["weights"], rgb0=out0["rgb_map"], disp0=out0["disp_map"], acc0=out0["acc_map"],
+                   alpha0=out0["alpha"])
+        if keep:
+            ret.update(near=near, far=far, z_coarse=z, raw_coarse=raw, weights_coarse=out0["weights"], z_fine=z_fine,
+                       z_sorted=z_all, sorted_idxs=order, raw_fine=raw_f, raw_sorted=raw_all,
+                       count_coarse=ex["count"], count_fine=ex_f["count"], valid_bits=ex["valid_bits"])
+        return ret

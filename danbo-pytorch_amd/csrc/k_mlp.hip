@@ -1,0 +1,496 @@
+// K3: positional encoding + density/colour MLP of DANBO (D=8, W=256, skip after layer 4,
+// view_W=128) as ONE persistent kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
+// fp32 == an fmaf chain; MI355X peak 157 TFLOP/s).  gfx950 only.
+//
+// Workgroup = 256 threads = 4 wavefronts, one 64-row tile at a time:
+//   * activations stay in LDS for all 11 GEMMs: X0 = PE(h) [64 x 200] (kept for the skip
+//     connection) and ACT [64 x 256]; row strides 204 / 260 floats make both the MFMA A-fragment
+//     ds_read_b128 (lane = row) and the epilogue ds_write_b32 (lane = column) conflict-free;
+//   * each wavefront owns 64 (view layer: 32) output columns and streams its weights straight
+//     from L2 into registers -- weights are pre-packed by danbo_mlp_pack into fragment order so a
+//     wavefront's load is one contiguous 1 KB request ([col-tile][k-chunk of 8][lane][4]);
+//     2.6 MB of packed weights stay L2-resident (4 MB L2 per XCD);
+//   * per k-chunk: 2 ds_read_b128 (A, two row tiles) + 2 global_load_dwordx4 (B, two column
+//     tiles) feed 16 MFMAs (1024 cycles of matrix pipe per wavefront);
+//   * the per-ray part of the view layer arrives pre-reduced in `cview` (danbo_view_consts).
+#include "common.hpp"
+
+namespace danbo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_BM = 64;
+constexpr int MLP_W = 256;
+constexpr int MLP_VW = 128;
+constexpr int MLP_IN = 195;   // 15 * (1 + 2*6)
+constexpr int MLP_IN_PAD = 200;
+constexpr int LDX = 204;      // X0 row stride (floats)
+constexpr int LDA = 260;      // ACT row stride (floats)
+constexpr int L_VOX = 6;
+
+// packed weight offsets (floats)
+constexpr int CH0 = MLP_IN_PAD / 8;            // 25 k-chunks
+constexpr int CHW = MLP_W / 8;                 // 32
+constexpr int CH5 = CH0 + CHW;                 // 57
+constexpr int OFF_L0 = 0;
+constexpr int OFF_L1 = OFF_L0 + 8 * CH0 * 256;           // 51200
+constexpr int OFF_L5 = OFF_L1 + 4 * 8 * CHW * 256;       // 313344
+constexpr int OFF_L6 = OFF_L5 + 8 * CH5 * 256;           // 430080
+constexpr int OFF_FEAT = OFF_L6 + 2 * 8 * CHW * 256;     // 561152
+constexpr int OFF_VIEW = OFF_FEAT + 8 * CHW * 256;       // 626688
+constexpr int PACKED_TOTAL = OFF_VIEW + 4 * CHW * 256;   // 659456
+static_assert(PACKED_TOTAL == DANBO_MLP_PACKED_FLOATS, "header constant out of date");
+
+struct MlpPackArgs {
+    const float* pts_w[8];
+    const float* feature_w;
+    const float* views_w;
+    int Cv;
+};
+
+__device__ __forceinline__ int layer_offset(int layer) {
+    switch (layer) {
+        case 0: return OFF_L0;
+        case 1: case 2: case 3: case 4: return OFF_L1 + (layer - 1) * 8 * CHW * 256;
+        case 5: return OFF_L5;
+        case 6: case 7: return OFF_L6 + (layer - 6) * 8 * CHW * 256;
+        case 8: return OFF_FEAT;
+        default: return OFF_VIEW;
+    }
+}
+
+// one thread per packed float
+__global__ __launch_bounds__(256) void k_mlp_pack(MlpPackArgs a, float* __restrict__ packed,
+                                                  float* __restrict__ views_w_ray_t) {
+    const int total = PACKED_TOTAL + a.Cv * MLP_VW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i >= PACKED_TOTAL) {  // per-ray slice of views_linears.0, transposed to [Cv][128]
+            const int q = i - PACKED_TOTAL;
+            const int c = q % MLP_VW, k = q / MLP_VW;
+            views_w_ray_t[q] = a.views_w[(size_t)c * (MLP_W + a.Cv) + MLP_W + k];
+            continue;
+        }
+        int layer = 9;
+        if (i < OFF_L1) layer = 0;
+        else if (i < OFF_L5) layer = 1 + (i - OFF_L1) / (8 * CHW * 256);
+        else if (i < OFF_L6) layer = 5;
+        else if (i < OFF_FEAT) layer = 6 + (i - OFF_L6) / (8 * CHW * 256);
+        else if (i < OFF_VIEW) layer = 8;
+        const int nch = layer == 0 ? CH0 : (layer == 5 ? CH5 : CHW);
+        const int q = i - layer_offset(layer);
+        const int t = q & 3, lane = (q >> 2) & 63, kc = (q >> 8) % nch, ct = (q >> 8) / nch;
+        const int n = ct * 32 + (lane & 31);
+        const int kp = kc * 8 + 4 * (lane >> 5) + t;
+        float v = 0.f;
+        if (layer == 0) {
+            if (kp < MLP_IN) v = a.pts_w[0][(size_t)n * MLP_IN + kp];
+        } else if (layer == 5) {
+            const int ld = MLP_IN + MLP_W;
+            if (kp < MLP_IN) v = a.pts_w[5][(size_t)n * ld + kp];
+            else if (kp >= MLP_IN_PAD) v = a.pts_w[5][(size_t)n * ld + MLP_IN + (kp - MLP_IN_PAD)];
+        } else if (layer <= 7) {
+            v = a.pts_w[layer][(size_t)n * MLP_W + kp];
+        } else if (layer == 8) {
+            v = a.feature_w[(size_t)n * MLP_W + kp];
+        } else {
+            v = a.views_w[(size_t)n * (MLP_W + a.Cv) + kp];
+        }
+        packed[i] = v;
+    }
+}
+
+// colour head shared by the MLP kernel and the empty-sample path of k_view_consts so that both
+// produce bit-identical logits:  sequential fmaf over k = 0..127, bias added last.
+__device__ __forceinline__ float rgb_dot(const float* x /*LDS, 16-B aligned*/, const float* __restrict__ w, float b) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < MLP_VW; k += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        acc = fmaf(xv.x, w[k], acc);
+        acc = fmaf(xv.y, w[k + 1], acc);
+        acc = fmaf(xv.z, w[k + 2], acc);
+        acc = fmaf(xv.w, w[k + 3], acc);
+    }
+    return acc + b;
+}
+
+// ======================================================================================
+// per-ray view constants
+// ======================================================================================
+constexpr int VIEW_RPB = 8;  // rays per workgroup iteration
+
+__global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ rays_d, const float* __restrict__ skts,
+                                                     int R, int G, int ray_mode, int normalise, int L_view,
+                                                     const float* __restrict__ framecodes, int n_codes, int Cf,
+                                                     const float* __restrict__ mean_code,
+                                                     const int64_t* __restrict__ cam_idx,
+                                                     const float* __restrict__ wt /*[Cv][128]*/,
+                                                     const float* __restrict__ views_b, const float* __restrict__ rgb_w,
+                                                     const float* __restrict__ rgb_b,
+                                                     const float* __restrict__ empty_consts,
+                                                     float* __restrict__ cview, float* __restrict__ raw_empty) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Cpe = 3 * (1 + 2 * L_view);
+    const int Cv = Cpe + Cf;
+    const int Cvp = (Cv + 3) & ~3;
+    float* s_w = smem;                       // [Cv][128]
+    float* s_v = s_w + Cv * MLP_VW;          // [RPB][Cvp]
+    float* s_x = s_v + VIEW_RPB * Cvp;       // [RPB][128]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < Cv * MLP_VW; i += 256) s_w[i] = wt[i];
+    const int rays_per_pose = R / G;
+
+    for (int r0 = blockIdx.x * VIEW_RPB; r0 < R; r0 += gridDim.x * VIEW_RPB) {
+        __syncthreads();
+        // ---- build the per-ray view vectors [PE(dir) | frame code] ----
+        if (tid < VIEW_RPB * 3) {
+            const int rl = tid / 3, k = tid % 3;
+            const int r = min(r0 + rl, R - 1);
+            float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+            if (ray_mode == 1) {
+                const float* M = skts + (size_t)min(r / rays_per_pose, G - 1) * J * 16;  // bone 0 = root
+                float q[3];
+                for (int a = 0; a < 3; ++a)
+                    q[a] = add_rn(add_rn(mul_rn(M[4 * a], d[0]), mul_rn(M[4 * a + 1], d[1])), mul_rn(M[4 * a + 2], d[2]));
+                d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+            }
+            if (normalise) {
+                const float nrm = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
+                const float den = fmaxf(nrm, 1e-12f);
+                d[0] = div_rn(d[0], den); d[1] = div_rn(d[1], den); d[2] = div_rn(d[2], den);
+            }
+            float* v = s_v + rl * Cvp;
+            v[k] = d[k];
+            for (int l = 0; l < L_view; ++l) {
+                const float xf = mul_rn(d[k], (float)(1 << l));
+                float sn, cs;
+                sincosf(xf, &sn, &cs);
+                v[3 * (1 + 2 * l) + k] = sn;
+                v[3 * (2 + 2 * l) + k] = cs;
+            }
+        }
+        for (int i = tid; i < VIEW_RPB * Cf; i += 256) {
+            const int rl = i / Cf, k = i % Cf;
+            const int r = min(r0 + rl, R - 1);
+            const long idx = cam_idx ? (long)cam_idx[r] : -1;
+            float val;
+            if (idx < 0) val = mean_code[k];
+            else val = framecodes[(size_t)min(idx, (long)n_codes - 1) * Cf + k];
+            s_v[rl * Cvp + Cpe + k] = val;
+        }
+        __syncthreads();
+        // ---- cview[r][c] = sum_i W[c][256+i] v[i] + b[c] ----
+        const int c = tid & 127;
+        for (int rl = tid >> 7; rl < VIEW_RPB; rl += 2) {
+            const float* v = s_v + rl * Cvp;
+            float acc = 0.f;
+            for (int i = 0; i < Cv; ++i) acc = fmaf(v[i], s_w[i * MLP_VW + c], acc);
+            acc += views_b[c];
+            const int r = r0 + rl;
+            if (r < R) cview[(size_t)r * MLP_VW + c] = acc;
+            if (empty_consts) s_x[rl * MLP_VW + c] = fmaxf(empty_consts[c] + acc, 0.f);
+        }
+        if (empty_consts) {
+            __syncthreads();
+            if (tid < VIEW_RPB * 4) {
+                const int rl = tid >> 2, ch = tid & 3;
+                const int r = r0 + rl;
+                if (r < R) {
+                    const float val = ch < 3 ? rgb_dot(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch]) : empty_consts[MLP_VW];
+                    raw_empty[(size_t)r * 4 + ch] = val;
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// the fused MLP
+// ======================================================================================
+struct MlpArgs {
+    const float* h;
+    const int32_t* list;
+    const int32_t* count;
+    int n_cap;
+    int S;
+    const float* packed;
+    const float* pts_b[8];
+    const float* alpha_w;
+    const float* alpha_b;
+    const float* feature_b;
+    const float* cview;
+    const float* rgb_w;
+    const float* rgb_b;
+    float* raw_out;
+    float* aux_out;
+};
+
+// acc[rt][ct] += A[64 x 8*nch] (LDS, row stride lda) * Wp   for this wavefront's NCT column tiles
+template <int NCT>
+__device__ __forceinline__ void gemm_accumulate(f32x16 (&acc)[2][NCT], const float* __restrict__ A, int lda, int nch,
+                                                const float4* __restrict__ wp /* + lane */, int ct_stride /*float4*/) {
+    const int lane = threadIdx.x & 63;
+    const float* a_ptr0 = A + (lane & 31) * lda + 4 * (lane >> 5);
+    const float* a_ptr1 = a_ptr0 + 32 * lda;
+    float4 bq[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bq[ct] = wp[ct * ct_stride];
+    float4 a0 = *reinterpret_cast<const float4*>(a_ptr0);
+    float4 a1 = *reinterpret_cast<const float4*>(a_ptr1);
+#pragma unroll 1
+    for (int kc = 0; kc < nch; ++kc) {
+        float4 bn[NCT];
+        float4 a0n = a0, a1n = a1;
+        if (kc + 1 < nch) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bn[ct] = wp[ct * ct_stride + (kc + 1) * 64];
+            a0n = *reinterpret_cast<const float4*>(a_ptr0 + (kc + 1) * 8);
+            a1n = *reinterpret_cast<const float4*>(a_ptr1 + (kc + 1) * 8);
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bn[ct] = bq[ct];
+        }
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
+        const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float bv = t == 0 ? bq[ct].x : (t == 1 ? bq[ct].y : (t == 2 ? bq[ct].z : bq[ct].w));
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv, acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv, acc[1][ct], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) bq[ct] = bn[ct];
+        a0 = a0n;
+        a1 = a1n;
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+}
+
+// ACT[row][col] = act(acc + bias[col]);  C/D layout of the 32x32 MFMA:
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <int NCT, bool RELU>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[2][NCT], float* __restrict__ ACT,
+                                          const float* __restrict__ bias, int col_base) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int col = col_base + ct * 32 + (lane & 31);
+        const float b = bias[col];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                float v = acc[rt][ct][reg] + b;
+                if (RELU) v = fmaxf(v, 0.f);
+                ACT[row * LDA + col] = v;
+            }
+        }
+    }
+}
+
+constexpr int MLP_LDS_FLOATS = MLP_BM * LDX + MLP_BM * LDA + 4 * MLP_BM /*alpha partials*/ + MLP_BM /*alpha*/ +
+                               MLP_BM * 4 /*rgb*/ + MLP_BM /*ray*/ + MLP_BM /*dst*/;
+
+__global__ __launch_bounds__(256, 1) void k_pe_mlp(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X0 = smem;
+    float* ACT = X0 + MLP_BM * LDX;
+    float* s_part = ACT + MLP_BM * LDA;   // [4][64]
+    float* s_alpha = s_part + 4 * MLP_BM;  // [64]
+    float* s_rgb = s_alpha + MLP_BM;       // [64][4]
+    int* s_ray = reinterpret_cast<int*>(s_rgb + MLP_BM * 4);  // [64]
+    int* s_dst = s_ray + MLP_BM;                               // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = resolve_count(a.count, a.n_cap);
+    const int ntiles = (n + MLP_BM - 1) / MLP_BM;
+    const float4* wp = reinterpret_cast<const float4*>(a.packed) + lane;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * MLP_BM;
+        __syncthreads();  // previous tile completely consumed
+        // ---------------- prologue: X0 = PE(h), per-row bookkeeping ----------------
+        {
+            const int row = tid >> 2, part = tid & 3;
+            const int grow = row0 + row;
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow < n) hv = reinterpret_cast<const float4*>(a.h + (size_t)grow * DANBO_H_STRIDE)[part];
+            const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+            float* xr = X0 + row * LDX;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = part * 4 + e;
+                if (k < FEAT) {
+                    const float v = hvv[e];
+                    xr[k] = v;
+#pragma unroll
+                    for (int l = 0; l < L_VOX; ++l) {
+                        float sn, cs;
+                        sincosf(v * (float)(1 << l), &sn, &cs);
+                        xr[FEAT * (1 + 2 * l) + k] = sn;
+                        xr[FEAT * (2 + 2 * l) + k] = cs;
+                    }
+                }
+            }
+            if (part == 3) {
+#pragma unroll
+                for (int k = MLP_IN; k < LDX; ++k) xr[k] = 0.f;
+            }
+            if (part == 0) {
+                int m = -1;
+                if (grow < n) m = a.list ? a.list[grow] : grow;
+                s_dst[row] = m;
+                s_ray[row] = m >= 0 ? m / a.S : 0;
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[2][2];
+        // ---------------- density trunk ----------------
+#pragma unroll 1
+        for (int layer = 0; layer < 8; ++layer) {
+            zero_acc<2>(acc);
+            // segment 1: X0 for the input layer and for the skip layer, ACT otherwise
+            const bool from_x0 = (layer == 0) || (layer == 5);
+            const int nch_total = layer == 0 ? CH0 : (layer == 5 ? CH5 : CHW);
+            const float4* wl = wp + layer_offset(layer) / 4 + (wave * 2) * nch_total * 64;
+            gemm_accumulate<2>(acc, from_x0 ? X0 : ACT, from_x0 ? LDX : LDA, from_x0 ? CH0 : CHW, wl, nch_total * 64);
+            if (layer == 5) gemm_accumulate<2>(acc, ACT, LDA, CHW, wl + CH0 * 64, nch_total * 64);
+            __syncthreads();  // every wavefront finished reading ACT
+            store_act<2, true>(acc, ACT, a.pts_b[layer], wave * 64);
+            __syncthreads();
+        }
+        // ---------------- density logit: alpha = h8 . alpha_w + b ----------------
+        {
+            const int row = lane, q = wave;
+            const float* hr = ACT + row * LDA + q * 64;
+            const float* wq = a.alpha_w + q * 64;
+            float s = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < 64; k += 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(hr + k);
+                s = fmaf(xv.x, wq[k], s);
+                s = fmaf(xv.y, wq[k + 1], s);
+                s = fmaf(xv.z, wq[k + 2], s);
+                s = fmaf(xv.w, wq[k + 3], s);
+            }
+            s_part[q * MLP_BM + row] = s;
+        }
+        // ---------------- feature = feature_linear(h8) (no activation) ----------------
+        zero_acc<2>(acc);
+        gemm_accumulate<2>(acc, ACT, LDA, CHW, wp + OFF_FEAT / 4 + (wave * 2) * CHW * 64, CHW * 64);
+        __syncthreads();
+        if (tid < MLP_BM)
+            s_alpha[tid] = ((s_part[tid] + s_part[MLP_BM + tid]) + s_part[2 * MLP_BM + tid]) + s_part[3 * MLP_BM + tid] + a.alpha_b[0];
+        store_act<2, false>(acc, ACT, a.feature_b, wave * 64);
+        __syncthreads();
+        // ---------------- view layer: relu(W_v[:, :256] feature + cview[ray]) ----------------
+        {
+            f32x16 accv[2][1];
+            zero_acc<1>(accv);
+            gemm_accumulate<1>(accv, ACT, LDA, CHW, wp + OFF_VIEW / 4 + wave * CHW * 64, CHW * 64);
+            __syncthreads();
+            const int col = wave * 32 + (lane & 31);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const float pre = accv[rt][0][reg];
+                    const float cv = a.cview ? a.cview[(size_t)s_ray[row] * MLP_VW + col] : 0.f;
+                    ACT[row * LDA + col] = fmaxf(pre + cv, 0.f);
+                    if (a.aux_out && s_dst[row] >= 0) a.aux_out[(size_t)(row0 + row) * (MLP_VW + 1) + col] = pre;
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- rgb head + output ----------------
+        if (wave < 3) s_rgb[lane * 4 + wave] = rgb_dot(ACT + lane * LDA, a.rgb_w + wave * MLP_VW, a.rgb_b[wave]);
+        __syncthreads();
+        if (tid < MLP_BM) {
+            const int m = s_dst[tid];
+            if (m >= 0) {
+                const float al = s_alpha[tid];
+                reinterpret_cast<float4*>(a.raw_out)[m] = make_float4(s_rgb[tid * 4], s_rgb[tid * 4 + 1], s_rgb[tid * 4 + 2], al);
+                if (a.aux_out) a.aux_out[(size_t)(row0 + tid) * (MLP_VW + 1) + MLP_VW] = al;
+            }
+        }
+    }
+}
+
+}  // namespace danbo
+
+using namespace danbo;
+
+extern "C" int danbo_mlp_pack(const float* const* pts_w, const float* feature_w, const float* views_w, int Cv,
+                               float* packed, float* views_w_ray_t, void* stream) {
+    DANBO_CHECK_ARG(pts_w && feature_w && views_w && packed && Cv >= 0 && (Cv == 0 || views_w_ray_t));
+    MlpPackArgs a;
+    for (int i = 0; i < 8; ++i) a.pts_w[i] = pts_w[i];
+    a.feature_w = feature_w;
+    a.views_w = views_w;
+    a.Cv = Cv;
+    hipLaunchKernelGGL(k_mlp_pack, dim3(1024), dim3(256), 0, (hipStream_t)stream, a, packed, views_w_ray_t);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise,
+                                  int L_view, const float* framecodes, int n_codes, int Cf, const float* mean_code,
+                                  const int64_t* cam_idx, const float* views_w_ray_t, const float* views_b,
+                                  const float* rgb_w, const float* rgb_b, const float* empty_consts, float* cview,
+                                  float* raw_empty, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && L_view >= 0 && Cf >= 0);
+    DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
+    DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
+    const int Cv = 3 * (1 + 2 * L_view) + Cf;
+    const int Cvp = (Cv + 3) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + VIEW_RPB * Cvp + VIEW_RPB * MLP_VW);
+    DANBO_CHECK_ARG(lds <= 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_view_consts),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int iters = ceil_div(R, VIEW_RPB);
+    const int grid = iters < NUM_CU ? iters : NUM_CU;
+    hipLaunchKernelGGL(k_view_consts, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
+                       normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
+                       rgb_b, empty_consts, cview, raw_empty);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
+                                 const float* packed, const float* const* pts_b, const float* alpha_w,
+                                 const float* alpha_b, const float* feature_b, const float* cview, const float* rgb_w,
+                                 const float* rgb_b, float* raw_out, float* aux_out, void* stream) {
+    DANBO_CHECK_ARG(n >= 0 && S > 0 && h && packed && pts_b && raw_out);
+    if (n == 0) return 0;
+    MlpArgs a;
+    a.h = h; a.list = list; a.count = count; a.n_cap = n; a.S = S; a.packed = packed;
+    for (int i = 0; i < 8; ++i) a.pts_b[i] = pts_b[i];
+    a.alpha_w = alpha_w; a.alpha_b = alpha_b; a.feature_b = feature_b; a.cview = cview;
+    a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.raw_out = raw_out; a.aux_out = aux_out;
+    const size_t lds = sizeof(float) * MLP_LDS_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pe_mlp),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntiles = ceil_div(n, MLP_BM);
+    const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
+    hipLaunchKernelGGL(k_pe_mlp, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}

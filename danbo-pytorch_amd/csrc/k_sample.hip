@@ -1,0 +1,492 @@
+// Ray bounds, sampling, world->bone transform + in-volume cull (K1a), factorised gather
+// (K1b), alpha compositing (K4), importance sampling and merge.  gfx950 only.
+//
+// Layout notes (MI355X): samples of a pass are addressed m = r*S + s, so a wavefront's 64
+// lanes read 64 consecutive z values (256 B, one coalesced request) and the 12+12 B of at most
+// two rays (broadcast).  Per-pose skeleton transforms (24 x 3x4), the 24 bone-align transforms
+// and |axis_scale| live in LDS for the whole workgroup; the 23 KB factorised volume of the
+// pose is staged in LDS by the gather kernel.
+#include "common.hpp"
+
+namespace danbo {
+
+// ======================================================================================
+// near / far in the bounding cylinder
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_cylinder_pass1(const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d,
+                                                        const float* __restrict__ cyl, int R, int G,
+                                                        float near0, float far0, int chunk,
+                                                        double* __restrict__ acc,  // [nchunk][4]
+                                                        float* __restrict__ near_out,
+                                                        float* __restrict__ far_out) {
+    const int rays_per_pose = R / G;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const int g = min(r / rays_per_pose, G - 1);
+        float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        float c[3] = {cyl[5 * g], cyl[5 * g + 1], cyl[5 * g + 2]};
+        float nr, fr;
+        const bool hit = cylinder_bounds(o, d, c, near0, far0, &nr, &fr);
+        near_out[r] = nr;
+        far_out[r] = fr;
+        if (hit) {
+            double* a = acc + 4 * (r / chunk);
+            atomicAdd(a + 0, (double)nr);
+            atomicAdd(a + 1, (double)fr);
+            atomicAdd(a + 2, 1.0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cylinder_pass2(int R, float near0, float far0, int chunk,
+                                                        const double* __restrict__ acc,
+                                                        float* __restrict__ near_out,
+                                                        float* __restrict__ far_out) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const float nr = near_out[r];
+        if (nr != nr) {  // ray missed the cylinder: chunk-wide nan-mean (ray_utils.py:330-344)
+            const double* a = acc + 4 * (r / chunk);
+            const double cnt = a[2];
+            near_out[r] = cnt > 0.0 ? (float)(a[0] / cnt) : near0;
+            far_out[r] = cnt > 0.0 ? (float)(a[1] / cnt) : far0;
+        }
+    }
+}
+
+// ======================================================================================
+// per-bone box near / far (fast configs)
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_box_bounds(const float* __restrict__ rays_o,
+                                                    const float* __restrict__ rays_d,
+                                                    const float* __restrict__ skts,
+                                                    const float* __restrict__ align,
+                                                    const float* __restrict__ axis_scale, int R, int G,
+                                                    float* __restrict__ near_io, float* __restrict__ far_io) {
+    __shared__ float s_align[J * 16];
+    __shared__ float s_scale[J * 3];
+    for (int i = threadIdx.x; i < J * 16; i += blockDim.x) s_align[i] = align[i];
+    for (int i = threadIdx.x; i < J * 3; i += blockDim.x) s_scale[i] = fabsf(axis_scale[i]);
+    __syncthreads();
+    const int rays_per_pose = R / G;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const int g = min(r / rays_per_pose, G - 1);
+        float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        float vnear = 100000.0f, vfar = -100000.0f;
+        bool any = false;
+        for (int j = 0; j < J; ++j) {
+            float sk[12];
+            const float* src = skts + ((size_t)g * J + j) * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) sk[i] = src[i];
+            float lo, hi;
+            if (bone_box_steps(sk, s_align + 16 * j, s_scale + 3 * j, o, d, &lo, &hi)) {
+                any = true;
+                vnear = fminf(vnear, lo);
+                vfar = fmaxf(vfar, hi);
+            }
+        }
+        if (any) {
+            near_io[r] = vnear;
+            far_io[r] = vfar;
+        }
+    }
+}
+
+// ======================================================================================
+// coarse samples
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_coarse_samples(const float* __restrict__ nr, const float* __restrict__ fr,
+                                                        int R, int S, const float* __restrict__ t_rand,
+                                                        float* __restrict__ z) {
+    const long M = (long)R * S;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(m / S), s = (int)(m % S);
+        const float n_ = nr[r], f_ = fr[r];
+        float v = coarse_z(n_, f_, s, S);
+        if (t_rand) {  // stratified jitter (ray_utils.py:233-248)
+            const float zp = s > 0 ? coarse_z(n_, f_, s - 1, S) : v;
+            const float zn = s + 1 < S ? coarse_z(n_, f_, s + 1, S) : v;
+            const float lower = s > 0 ? mul_rn(0.5f, add_rn(v, zp)) : v;
+            const float upper = s + 1 < S ? mul_rn(0.5f, add_rn(zn, v)) : v;
+            v = add_rn(lower, mul_rn(sub_rn(upper, lower), t_rand[m]));
+        }
+        z[m] = v;
+    }
+}
+
+// sample point m: either o + d*z (two roundings, core/raycasters.py:463) or read from pts
+__device__ __forceinline__ void load_point(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                           const float* __restrict__ z, const float* __restrict__ pts, long m, int S,
+                                           float* p) {
+    if (pts != nullptr) {
+        p[0] = pts[3 * m]; p[1] = pts[3 * m + 1]; p[2] = pts[3 * m + 2];
+    } else {
+        const int r = (int)(m / S);
+        const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        sample_point(o, d, z[m], p);
+    }
+}
+
+// ======================================================================================
+// K1a: transform + cull
+// ======================================================================================
+constexpr int CULL_BLOCK = 256;
+constexpr int CULL_SPT = 4;  // samples per thread -> 1024 consecutive samples per workgroup
+
+__global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restrict__ rays_o,
+                                                          const float* __restrict__ rays_d,
+                                                          const float* __restrict__ z,
+                                                          const float* __restrict__ pts, int R, int S, int G,
+                                                          const float* __restrict__ skts,
+                                                          const float* __restrict__ align,
+                                                          const float* __restrict__ axis_scale, int np_lds,
+                                                          uint32_t* __restrict__ valid_bits,
+                                                          int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_align = smem;                 // [24][16]
+    float* s_scale = smem + J * 16;        // [24][4]
+    float* s_skt = smem + J * 16 + J * 4;  // [np_lds][24][16]
+
+    const long M = (long)R * S;
+    const long spp = (long)(R / G) * S;  // samples per pose
+    const long base = (long)blockIdx.x * (CULL_BLOCK * CULL_SPT);
+    const long last = min(base + CULL_BLOCK * CULL_SPT, M) - 1;
+    const int g0 = (int)min(base / spp, (long)G - 1);
+    const int g1 = (int)min(last / spp, (long)G - 1);
+
+    for (int i = threadIdx.x; i < J * 16; i += CULL_BLOCK) s_align[i] = align[i];
+    for (int i = threadIdx.x; i < J * 4; i += CULL_BLOCK) s_scale[i] = (i & 3) < 3 ? fabsf(axis_scale[(i >> 2) * 3 + (i & 3)]) : 0.f;
+    const int npose = g1 - g0 + 1;  // <= np_lds by construction of the launch
+    for (int i = threadIdx.x; i < npose * J * 16; i += CULL_BLOCK) s_skt[i] = skts[(size_t)g0 * J * 16 + i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int it = 0; it < CULL_SPT; ++it) {
+        const long m = base + it * CULL_BLOCK + threadIdx.x;
+        uint32_t bits = 0;
+        if (m < M) {
+            const int g = (int)min(m / spp, (long)G - 1);
+            float p[3];
+            load_point(rays_o, rays_d, z, pts, m, S, p);
+            const float* sk = s_skt + (g - g0) * J * 16;
+#pragma unroll 4
+            for (int j = 0; j < J; ++j) {
+                float pt[3];
+                bone_local(sk + 16 * j, s_align + 16 * j, p, pt);
+                bits |= (in_volume(pt, s_scale + 4 * j) ? 1u : 0u) << j;
+            }
+            valid_bits[m] = bits;
+        }
+        if (list != nullptr) {  // wave-aggregated append of in-volume samples
+            const unsigned long long ball = __ballot(bits != 0);
+            if (ball != 0ull) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(count, __popcll(ball));
+                wbase = __shfl(wbase, 0, 64);
+                if (bits != 0) list[wbase + __popcll(ball & ((1ull << lane) - 1ull))] = (int32_t)m;
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// K1b: factorised gather -> part_feat [n,24,15]
+// ======================================================================================
+constexpr int GATHER_TS = 16;               // samples per tile
+constexpr int GATHER_BLOCK = GATHER_TS * J;  // 384 threads: one (sample, bone) item each
+
+__global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __restrict__ rays_o,
+                                                              const float* __restrict__ rays_d,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ pts, int R, int S, int G,
+                                                              const float* __restrict__ skts,
+                                                              const float* __restrict__ align,
+                                                              const float* __restrict__ axis_scale,
+                                                              const float* __restrict__ volumes,
+                                                              const int32_t* __restrict__ list,
+                                                              const int32_t* __restrict__ count, int n_cap,
+                                                              float* __restrict__ part_feat) {
+    __shared__ __attribute__((aligned(16))) float s_vol[J * VOL];          // 23040 B
+    __shared__ __attribute__((aligned(16))) float s_out[GATHER_TS * J * FEAT];  // 23040 B
+    __shared__ __attribute__((aligned(16))) float s_skt[J * 16];
+    __shared__ __attribute__((aligned(16))) float s_align[J * 16];
+    __shared__ float s_scale[J * 4];
+
+    const int n = resolve_count(count, n_cap);
+    const int ntiles = (n + GATHER_TS - 1) / GATHER_TS;
+    const long spp = (long)(R / G) * S;
+    const int tid = threadIdx.x;
+    const int sl = tid / J, j = tid % J;
+
+    for (int i = tid; i < J * 16; i += GATHER_BLOCK) s_align[i] = align[i];
+    for (int i = tid; i < J * 4; i += GATHER_BLOCK) s_scale[i] = (i & 3) < 3 ? fabsf(axis_scale[(i >> 2) * 3 + (i & 3)]) : 1.f;
+    int g_lds = -1;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * GATHER_TS;
+        const int first = list ? list[row0] : row0;
+        const int g_tile = (int)min((long)first / spp, (long)G - 1);
+        __syncthreads();  // previous tile's s_out fully stored, s_vol no longer read
+        if (g_tile != g_lds) {
+            const float4* src = reinterpret_cast<const float4*>(volumes + (size_t)g_tile * J * VOL);
+            float4* dst = reinterpret_cast<float4*>(s_vol);
+            for (int i = tid; i < J * VOL / 4; i += GATHER_BLOCK) dst[i] = src[i];
+            for (int i = tid; i < J * 16; i += GATHER_BLOCK) s_skt[i] = skts[(size_t)g_tile * J * 16 + i];
+            g_lds = g_tile;
+        }
+        __syncthreads();
+        const int row = row0 + sl;
+        float* o_ = s_out + (sl * J + j) * FEAT;
+        if (row < n) {
+            const long m = list ? list[row] : row;
+            const int g = (int)min(m / spp, (long)G - 1);
+            float p[3], pt[3], f[FEAT];
+            load_point(rays_o, rays_d, z, pts, m, S, p);
+            if (g == g_lds) {
+                bone_local(s_skt + 16 * j, s_align + 16 * j, p, pt);
+                gather_bone_features(s_vol + j * VOL, pt, s_scale + 4 * j, f);
+            } else {  // tile straddles two poses (multi-pose chunks only): read through L1/L2
+                float sk[12];
+                const float* src = skts + ((size_t)g * J + j) * 16;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) sk[i] = src[i];
+                bone_local(sk, s_align + 16 * j, p, pt);
+                gather_bone_features(volumes + ((size_t)g * J + j) * VOL, pt, s_scale + 4 * j, f);
+            }
+#pragma unroll
+            for (int k = 0; k < FEAT; ++k) o_[k] = f[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < FEAT; ++k) o_[k] = 0.f;
+        }
+        __syncthreads();
+        // coalesced 16-B stores of the 16 x 1440 B tile
+        const int rows_here = min(GATHER_TS, n - row0);
+        const int nvec = rows_here * (J * FEAT / 4);
+        float4* dst = reinterpret_cast<float4*>(part_feat + (size_t)row0 * J * FEAT);
+        const float4* src = reinterpret_cast<const float4*>(s_out);
+        for (int i = tid; i < nvec; i += GATHER_BLOCK) dst[i] = src[i];
+    }
+}
+
+// ======================================================================================
+// raw fill / merge
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_fill_raw(const float4* __restrict__ raw_empty, int R, int S,
+                                                  float4* __restrict__ raw) {
+    const long M = (long)R * S;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x)
+        raw[m] = raw_empty[m / S];
+}
+
+__global__ __launch_bounds__(256) void k_merge_samples(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const int32_t* __restrict__ idx, int R, int S, int Sf, int C,
+                                                       float* __restrict__ out) {
+    const int St = S + Sf;
+    const long N = (long)R * St;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / St);
+        const int src = idx[i];
+        const float* s = src < S ? a + ((size_t)r * S + src) * C : b + ((size_t)r * Sf + (src - S)) * C;
+        float* o = out + (size_t)i * C;
+        if (C == 4) {
+            *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(s);
+        } else {
+            for (int c = 0; c < C; ++c) o[c] = s[c];
+        }
+    }
+}
+
+// ======================================================================================
+// K4: alpha compositing, one wavefront per ray, exclusive cumprod by wave scan
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ raw, const float* __restrict__ z,
+                                                   const float* __restrict__ rays_d, int R, int S, float B,
+                                                   const float* __restrict__ noise, float* __restrict__ rgb_map,
+                                                   float* __restrict__ disp, float* __restrict__ acc_out,
+                                                   float* __restrict__ weights, float* __restrict__ alpha_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < R; r += nwaves) {
+        const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
+        const float dn = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz_, dz_)));
+        float carry = 1.0f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+        for (int c0 = 0; c0 < S; c0 += 64) {
+            const int s = c0 + lane;
+            const bool act = s < S;
+            const size_t m = (size_t)r * S + (act ? s : S - 1);
+            const float4 rw = raw[m];
+            const float zs = z[m];
+            const float zn = (s + 1 < S) ? z[m + 1] : zs;
+            const float dist = mul_rn((s + 1 < S) ? sub_rn(zn, zs) : 1e10f, dn);
+            float sig = div_rn(rw.w, B);
+            if (noise) sig = add_rn(sig, noise[m]);
+            sig = fmaxf(sig, 0.f);
+            float al = sub_rn(1.0f, expf(-mul_rn(sig, dist)));
+            if (!act) al = 0.f;
+            const float t = act ? add_rn(sub_rn(1.0f, al), 1e-10f) : 1.0f;
+            // inclusive product scan across the wave
+            float p = t;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float q = __shfl_up(p, off, 64);
+                if (lane >= off) p = mul_rn(p, q);
+            }
+            float excl = __shfl_up(p, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = mul_rn(carry, excl);
+            carry = mul_rn(carry, __shfl(p, 63, 64));
+            const float w = mul_rn(al, T);
+            if (act) {
+                if (weights) weights[m] = w;
+                if (alpha_out) alpha_out[m] = al;
+            }
+            const float cr = sub_rn(mul_rn(sigmoidf_(rw.x), 1.002f), 0.001f);
+            const float cg = sub_rn(mul_rn(sigmoidf_(rw.y), 1.002f), 0.001f);
+            const float cb = sub_rn(mul_rn(sigmoidf_(rw.z), 1.002f), 0.001f);
+            sr += wave_sum(w * cr);
+            sg += wave_sum(w * cg);
+            sb += wave_sum(w * cb);
+            sd += wave_sum(w * zs);
+            sa += wave_sum(w);
+        }
+        if (lane == 0) {
+            rgb_map[3 * r] = sr;
+            rgb_map[3 * r + 1] = sg;
+            rgb_map[3 * r + 2] = sb;
+            float dsp = div_rn(1.0f, fmaxf(1e-10f, div_rn(sd, add_rn(sa, 1e-10f))));
+            if (fabsf(sa) <= 1e-8f) dsp = 0.f;
+            disp[r] = dsp;
+            acc_out[r] = fminf(sa, 1.0f);
+        }
+    }
+}
+
+// ======================================================================================
+// importance sampling + merge: one thread per ray, rows of the outputs double as scratch
+// ======================================================================================
+__global__ __launch_bounds__(64) void k_importance(const float* __restrict__ z, const float* __restrict__ weights,
+                                                   int R, int S, int Sf, const float* __restrict__ u,
+                                                   float* __restrict__ z_fine, float* __restrict__ z_sorted,
+                                                   int32_t* __restrict__ sorted_idx) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        // cdf scratch: the tail of this ray's z_sorted row is free until the final merge, but the
+        // merge writes from the front; S-1 <= S+Sf so we use a private region at the back and the
+        // merge never reads cdf.  To stay safe with any S/Sf, cdf lives in sorted_idx's row
+        // (reinterpreted), which is only written by the merge after the cdf is dead.
+        float* cdf = reinterpret_cast<float*>(sorted_idx + (size_t)r * (S + Sf));
+        importance_ray(z + (size_t)r * S, weights + (size_t)r * S, S, Sf, u ? u + (size_t)r * Sf : nullptr, cdf,
+                       z_fine + (size_t)r * Sf, z_sorted + (size_t)r * (S + Sf), sorted_idx + (size_t)r * (S + Sf));
+    }
+}
+
+}  // namespace danbo
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+using namespace danbo;
+
+extern "C" int danbo_near_far_cylinder(const float* rays_o, const float* rays_d, const float* cyl, int R, int G,
+                                        float near0, float far0, int chunk, float* scratch, float* near_out,
+                                        float* far_out, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && chunk > 0 && scratch != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ceil_div(R, chunk);
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 4 * nchunk, st);
+    if (e != hipSuccess) return (int)e;
+    const int grid = stream_grid(R, 256);
+    hipLaunchKernelGGL(k_cylinder_pass1, dim3(grid), dim3(256), 0, st, rays_o, rays_d, cyl, R, G, near0, far0, chunk,
+                       reinterpret_cast<double*>(scratch), near_out, far_out);
+    hipLaunchKernelGGL(k_cylinder_pass2, dim3(grid), dim3(256), 0, st, R, near0, far0, chunk,
+                       reinterpret_cast<const double*>(scratch), near_out, far_out);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_near_far_boxes(const float* rays_o, const float* rays_d, const float* skts, const float* align,
+                                     const float* axis_scale, int R, int G, float* near_io, float* far_io,
+                                     void* stream) {
+    DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0);
+    hipLaunchKernelGGL(k_box_bounds, dim3(stream_grid(R, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, skts,
+                       align, axis_scale, R, G, near_io, far_io);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_coarse_samples(const float* near, const float* far, int R, int S, const float* t_rand, float* z,
+                                     void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0);
+    hipLaunchKernelGGL(k_coarse_samples, dim3(stream_grid((long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, near,
+                       far, R, S, t_rand, z);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                                const float* skts, const float* align, const float* axis_scale, uint32_t* valid_bits,
+                                int32_t* list, int32_t* count, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0);
+    DANBO_CHECK_ARG((list == nullptr) == (count == nullptr));
+    DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
+    const long M = (long)R * S;
+    const long spp = (long)(R / G) * S;
+    const int per_block = CULL_BLOCK * CULL_SPT;
+    long np = per_block / spp + 2;
+    if (np > G) np = G;
+    const size_t lds = sizeof(float) * (J * 16 + J * 4 + np * J * 16);
+    DANBO_CHECK_ARG(lds <= 64 * 1024);
+    const int grid = ceil_div(M, per_block);
+    hipLaunchKernelGGL(k_bone_cull, dim3(grid), dim3(CULL_BLOCK), lds, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
+                       G, skts, align, axis_scale, (int)np, valid_bits, list, count);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_bone_gather_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                                      const float* skts, const float* align, const float* axis_scale,
+                                      const float* volumes, const int32_t* list, const int32_t* count, int n,
+                                      float* part_feat, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0 && n >= 0);
+    DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
+    if (n == 0) return 0;
+    const int ntiles = ceil_div(n, GATHER_TS);
+    const int grid = ntiles < NUM_CU * 3 ? ntiles : NUM_CU * 3;
+    hipLaunchKernelGGL(k_bone_gather, dim3(grid), dim3(GATHER_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
+                       G, skts, align, axis_scale, volumes, list, count, n, part_feat);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0);
+    hipLaunchKernelGGL(k_fill_raw, dim3(stream_grid((long)R * S, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(raw_empty), R, S, reinterpret_cast<float4*>(raw));
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_merge_samples(const float* a, const float* b, const int32_t* sorted_idx, int R, int S, int Sf,
+                                    int C, float* out, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && Sf >= 0 && C > 0);
+    hipLaunchKernelGGL(k_merge_samples, dim3(stream_grid((long)R * (S + Sf), 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, sorted_idx, R, S, Sf, C, out);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
+                                    const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
+                                    float* alpha, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && B > 0.f);
+    const int grid = stream_grid((long)R * 64, 256);
+    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(raw), z,
+                       rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_importance_samples(const float* z, const float* weights, int R, int S, int Sf, const float* u,
+                                         float* z_fine, float* z_sorted, int32_t* sorted_idx, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S >= 3 && Sf > 0);
+    hipLaunchKernelGGL(k_importance, dim3(stream_grid(R, 64)), dim3(64), 0, (hipStream_t)stream, z, weights, R, S, Sf, u,
+                       z_fine, z_sorted, sorted_idx);
+    DANBO_LAUNCH_RET();
+}

@@ -1,0 +1,190 @@
+/*
+ * libdanbo_hip.so -- C ABI of the MI355X (gfx950) articulated-NeRF rendering path.
+ *
+ * Drop-in boundary: the Python classes in danbo-pytorch_amd/core/networks
+ * (same names / state_dict keys as the reference's core/networks) call these entry points
+ * through ctypes.  Every pointer is a DEVICE pointer to row-major float32 unless noted; no
+ * function retains a pointer past the call; every kernel is enqueued on `stream` (a
+ * hipStream_t passed as void*) and nothing synchronises with the host.  Return value:
+ * 0 = ok, otherwise a hipError_t, or DANBO_EINVAL (-22) for a rejected argument.
+ *
+ * Each entry cites the reference code (file:line under the reference tree) it replaces.
+ * J = 24 bones everywhere.  "pose" g of ray r is r / (R / G) (equal contiguous groups,
+ * core/encoders.py:465-468, core/networks/gnn_backbone.py:792-794).
+ */
+#ifndef DANBO_HIP_H
+#define DANBO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DANBO_EINVAL (-22)
+#define DANBO_J 24
+#define DANBO_VOL 240       /* voxel_feat(5) * voxel_res(16) * 3 axes               */
+#define DANBO_FEAT 15       /* voxel_feat * 3 ('cat' construct)                     */
+#define DANBO_H_STRIDE 16   /* blended feature rows are padded 15 -> 16 floats      */
+
+/* library / device identification (host only) */
+int danbo_abi_version(void);
+int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------------------------------
+ * Pose stage (once per distinct pose): axis-angle -> rot6d -> PE(L) -> skeleton GNN ->
+ * factorised volumes.   Replaces SamplePointsEmbedder.encode_graph_inputs
+ * (core/encoders.py:460-473), AxisAngtoRot6DEncoder (:859-877), Embedder
+ * (core/cutoff_embedder.py:62-73) and FactorizeGNN/BodyGNN.forward
+ * (core/networks/gnn_backbone.py:683-704) for gcn_D=4, gcn_fc_D=1:
+ *   GCN(6(1+2L)->W) , GCN(W->W) , PerBoneLinear(W->W) , PerBoneLinear(W->240)
+ * incl. mask_root and the doubled first layer (skip_gcn=False quirk).
+ *   bones [G,24,3]; w0 [24,Cin,W]; adjw0/adjw1 [24,24] (already adj_w*adj); b0,b1 [W];
+ *   w1,w2 [24,W,W]; b2 [24,W]; w3 [24,W,240]; b3 [24,240]; scratch >= 3*G*24*W floats.
+ * ------------------------------------------------------------------------------------- */
+int danbo_pose_volumes_fwd(const float* bones, int G, int L_graph, int W,
+                           const float* w0, const float* adjw0, const float* b0,
+                           const float* w1, const float* adjw1, const float* b1,
+                           const float* w2, const float* b2,
+                           const float* w3, const float* b3,
+                           float* scratch, float* volumes /*[G,24,240]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Ray bounds.  get_near_far_in_cylinder (core/utils/ray_utils.py:294-346) incl. the
+ * per-`chunk` nan-mean back-fill (the reference is invoked once per `chunk` rays,
+ * core/trainer.py:75-90) done on device -- no host round trip.
+ *   rays_o, rays_d [R,3]; cyl [G,5]; near0/far0: the placeholder bounds (0/1,
+ *   core/trainer.py:96-98); scratch >= 32*ceil(R/chunk) BYTES (fp64 partial sums).
+ * ------------------------------------------------------------------------------------- */
+int danbo_near_far_cylinder(const float* rays_o, const float* rays_d, const float* cyl, int R, int G,
+                            float near0, float far0, int chunk, float* scratch,
+                            float* near_out /*[R]*/, float* far_out /*[R]*/, void* stream);
+
+/* GraphCaster.get_near_far + get_ray_box_intersections (core/raycasters.py:648-707,
+ * core/utils/ray_utils.py:383-417), fp64 plane hits, bound fixed at 1.3; updates near/far
+ * in place for rays that hit >= 1 bone box.   skts [G,24,4,4]; align [24,4,4];
+ * axis_scale [24,3]. */
+int danbo_near_far_boxes(const float* rays_o, const float* rays_d, const float* skts, const float* align,
+                         const float* axis_scale, int R, int G, float* near_io, float* far_io, void* stream);
+
+/* sample_from_lineseg, perturb=0 / stratified with caller-supplied uniforms
+ * (core/utils/ray_utils.py:206-253): z [R,S]; t_rand NULL or [R,S]. */
+int danbo_coarse_samples(const float* near, const float* far, int R, int S, const float* t_rand,
+                         float* z, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1a  world->bone transform + in-volume cull over ALL samples of the pass.
+ * transform_batch_pts + align (core/encoders.py:288-303,442-444) and the `invalid` test of
+ * FactorizeGNN.sample_from_volume (core/networks/gnn_backbone.py:802,808), bit-exact with
+ * oracle/danbo_oracle.py (unfused fp32 mul/add chain).
+ *   pts = rays_o + rays_d * z  (core/raycasters.py:463), or read from `pts` [R*S,3] when the
+ *   caller already holds sample points (the reference's model(inputs['pts']) entry); exactly
+ *   one of {z, pts} is non-NULL.
+ *   valid_bits[m] bit j = sample m inside bone j's volume.
+ *   If `list` != NULL: indices of samples with valid_bits != 0 are appended to list and
+ *   *count (which the caller zeroes) is incremented -- order unspecified.
+ * ------------------------------------------------------------------------------------- */
+int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                    const float* skts /*[G,24,4,4]*/, const float* align /*[24,4,4]*/,
+                    const float* axis_scale /*[24,3]*/,
+                    uint32_t* valid_bits /*[R*S]*/, int32_t* list /*[R*S] or NULL*/,
+                    int32_t* count /*[1] or NULL*/, void* stream);
+
+/* K1b  factorised tri-axis gather (factorize_grid_sample, core/networks/misc.py:331-351;
+ * windowing + 'cat' construct, gnn_backbone.py:803-826) for the n listed samples
+ * (list == NULL: samples 0..n-1; count != NULL: n is read from *count on device and the
+ * host `n` is only the capacity).  part_feat [n,24,15] is the reference's stage-boundary
+ * tensor (1440 B/sample); this is the HBM-bound kernel of the path. */
+int danbo_bone_gather_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                          const float* skts, const float* align, const float* axis_scale,
+                          const float* volumes /*[G,24,240]*/,
+                          const int32_t* list, const int32_t* count, int n,
+                          float* part_feat /*[n,24,15]*/, void* stream);
+
+/* K2  per-sample bone-assignment GNN + masked sigmoid + blend
+ * (MixGNN, gnn_backbone.py:567-591,602-629; DANBO.sigmoid / blend, danbo.py:299-300,406-415)
+ *   w0 [24,15,32]; adjw [24,24]; b0 [32]; w1 [24,32,32]; b1 [24,32]; w2 [24,32]; b2 [24]
+ *   valid_bits indexed by sample id (list[i] or i); outputs: h [n,16] (15 + zero pad),
+ *   confd [n,24] or NULL. */
+int danbo_assign_blend_fwd(const float* part_feat, const uint32_t* valid_bits,
+                           const int32_t* list, const int32_t* count, int n,
+                           const float* w0, const float* adjw, const float* b0,
+                           const float* w1, const float* b1, const float* w2, const float* b2,
+                           float* h, float* confd, void* stream);
+
+/* K1b + K2 fused (render path): every bone lane recomputes its own transform + gather, the
+ * 1440 B/sample part_feat tensor is never written.  Same results as K1b followed by K2. */
+int danbo_gather_assign_blend_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts,
+                                  int R, int S, int G, const float* skts, const float* align,
+                                  const float* axis_scale, const float* volumes,
+                                  const uint32_t* valid_bits, const int32_t* list, const int32_t* count, int n,
+                                  const float* w0, const float* adjw, const float* b0,
+                                  const float* w1, const float* b1, const float* w2, const float* b2,
+                                  float* h, float* confd, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K3  voxel-feature PE + density/colour MLP on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Embedder (core/cutoff_embedder.py:62-73), NeRF.inference / forward_density /
+ * forward_view (core/networks/nerf.py:176-209) for D=8, W=256, skip after layer 4,
+ * view_W=128.  The per-ray part of the view layer (PE(dir) | frame code) is hoisted into
+ * `cview` by danbo_view_consts.
+ * Weights must first be repacked into MFMA fragment order with danbo_mlp_pack.
+ * ------------------------------------------------------------------------------------- */
+#define DANBO_MLP_PACKED_FLOATS 659456  /* see csrc/k_mlp.hip */
+int danbo_mlp_pack(const float* const* pts_w /*8 ptrs [256,195|256|451]*/, const float* feature_w /*[256,256]*/,
+                   const float* views_w /*[128,256+Cv]*/, int Cv,
+                   float* packed /*[DANBO_MLP_PACKED_FLOATS]*/, float* views_w_ray_t /*[Cv,128]*/, void* stream);
+
+/* per-ray constants: view direction transform (core/encoders.py:179-189,570-578,774-795),
+ * PE(L_view), frame code lookup (core/networks/embedding.py:17-39; cam_idx NULL or <0 ->
+ * mean code), cview[r] = W_view[:,256:] . [PE(dir)|code] + b_view;  if empty_consts != NULL
+ * also raw_empty[r] = (rgb_linear(relu(empty_view_pre + cview[r])), empty_alpha): the raw
+ * of every sample of ray r that lies in no bone volume (blended feature h = 0).
+ *   ray_mode 0: 'world' raw rays_d; 1: 'root_local' (skts[g,0,:3,:3] . d);  normalise: relray */
+int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise,
+                      int L_view, const float* framecodes /*[n_codes,Cf] or NULL*/, int n_codes, int Cf,
+                      const float* mean_code /*[Cf]: codes.mean(0), used where cam_idx < 0*/,
+                      const int64_t* cam_idx /*[R] or NULL*/,
+                      const float* views_w_ray_t /*[Cv,128]*/, const float* views_b /*[128]*/,
+                      const float* rgb_w /*[3,128]*/, const float* rgb_b /*[3]*/,
+                      const float* empty_consts /*[129] or NULL*/,
+                      float* cview /*[R,128]*/, float* raw_empty /*[R,4] or NULL*/, void* stream);
+
+/* rows: h [n,16] (output of K2).  Row i belongs to sample id m = list ? list[i] : i and ray
+ * m / S; raw_out[m] = (rgb logits, density logit).  aux_out (optional) [n,129] receives the
+ * view-layer pre-activation WITHOUT cview and the density logit (used once per weight
+ * update to derive empty_consts from a zero row). */
+int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
+                     const float* packed, const float* const* pts_b /*8 ptrs [256]*/,
+                     const float* alpha_w /*[256]*/, const float* alpha_b /*[1]*/,
+                     const float* feature_b /*[256]*/, const float* cview /*[R,128] or NULL*/,
+                     const float* rgb_w, const float* rgb_b,
+                     float* raw_out /*[R*S,4]*/, float* aux_out, void* stream);
+
+/* raw[r,s,:] = raw_empty[r,:] (broadcast fill before K3 scatters the in-volume rows) */
+int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K4  NeRF.raw2outputs (core/networks/nerf.py:281-347), relu density, one wavefront per ray.
+ *   raw [R,S,4]; z [R,S]; rays_d [R,3]; noise NULL or [R,S] (already scaled by
+ *   raw_noise_std*B); outputs rgb_map [R,3], disp [R], acc [R], weights [R,S], alpha [R,S].
+ * ------------------------------------------------------------------------------------- */
+int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
+                        const float* noise, float* rgb_map, float* disp, float* acc,
+                        float* weights, float* alpha, void* stream);
+
+/* isample_from_lineseg(is_only=True) + sample_pdf (core/utils/ray_utils.py:159-203,257-291)
+ * + the sort of [z, z_fine] (stable, coarse first):  u NULL = linspace(0,1,Sf) (det) else
+ * caller-supplied uniforms [R,Sf].  sorted_idx int32 [R,S+Sf]. */
+int danbo_importance_samples(const float* z, const float* weights, int R, int S, int Sf, const float* u,
+                             float* z_fine /*[R,Sf]*/, float* z_sorted /*[R,S+Sf]*/,
+                             int32_t* sorted_idx /*[R,S+Sf]*/, void* stream);
+
+/* merge_samples (core/raycasters.py:745-761): out[r,i,:] = cat(a[r],b[r])[sorted_idx[r,i],:] */
+int danbo_merge_samples(const float* a /*[R,S,C]*/, const float* b /*[R,Sf,C]*/, const int32_t* sorted_idx,
+                        int R, int S, int Sf, int C, float* out /*[R,S+Sf,C]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANBO_HIP_H */

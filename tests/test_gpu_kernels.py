@@ -1,0 +1,314 @@
+"""GPU parity tests: every HIP kernel (called through the C ABI) against the numpy oracle
+and the committed golden vectors.  Run on the MI355X box with `pytest -m gpu`.
+
+Tolerances: the in-volume mask, sample positions and merge order are bit-exact; everything
+behind a transcendental or a GEMM is fp32 round-off level, with the 1e-4 relative bound of
+BASELINE.json's north_star as the outer limit for RGB / sigma logits.
+"""
+import numpy as np
+import pytest
+import torch
+
+import danbo_oracle as o
+from helpers import golden, oracle_for, max_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(x, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device=DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from core import hip_ops
+    return hip_ops
+
+
+@pytest.fixture(scope="module")
+def stage():
+    """golden stage fixture + oracle + engine with the same seeded weights"""
+    from core.render_engine import DanboEngine
+    g = golden("danbo_stages")
+    orc, cfg, sd, rest = oracle_for(g)
+    params = {k: T(v) for k, v in sd.items()}
+    eng = DanboEngine(cfg, params, T(orc.align))
+    pose = g["pose_of_ray"]
+    ret = orc.render(g["ray_batch"], g["skts"][pose], g["bones"][pose], g["cyls"][pose], cam_idxs=g["cam_idx"],
+                     n_uniques=2, N_samples=int(g["N_samples"]), N_importance=int(g["N_importance"]), stages=True)
+    return dict(g=g, orc=orc, cfg=cfg, sd=sd, eng=eng, ret=ret)
+
+
+def test_library_and_device(ops):
+    import ctypes
+    from core import _hip
+    l = _hip.lib()
+    assert l.danbo_abi_version() == 1
+    cu, lds = ctypes.c_int(), ctypes.c_int()
+    arch = ctypes.create_string_buffer(64)
+    assert l.danbo_device_info(ctypes.byref(cu), ctypes.byref(lds), arch, 64) == 0
+    assert arch.value.decode().startswith("gfx950"), arch.value
+    assert cu.value == 256
+
+
+def test_coarse_samples_bit_exact(ops, stage):
+    g = stage["g"]
+    z = ops.coarse_samples(T(g["near"][:, 0]), T(g["far"][:, 0]), int(g["N_samples"]))
+    assert np.array_equal(N(z), g["z_coarse"])
+
+
+def test_cylinder_near_far(ops, stage):
+    g = stage["g"]
+    rb = g["ray_batch"]
+    near, far = ops.near_far_cylinder(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["cyls"]), 0.0, 1.0, 4096)
+    assert max_err(N(near), g["near"][:, 0]) < 2e-6
+    assert max_err(N(far), g["far"][:, 0]) < 2e-6
+
+
+def _surreal_inputs():
+    from core.utils import synthetic as syn
+    g = golden("danbo_surreal")
+    orc, cfg, sd, rest = oracle_for(g)
+    scene = syn.make_scene(n_poses=1, H=int(g["H"]), W=int(g["W"]), n_views=3, pose_seed=int(g["pose_seed"]),
+                           rest_scale=cfg["rest_scale"], cam_dist=float(g["cam_dist"]))
+    ro, rd = scene["rays"][int(g["view"])]
+    return g, orc, cfg, sd, scene, ro, rd
+
+
+def test_cylinder_nan_backfill_and_box_near_far(ops):
+    from core.render_engine import DanboEngine
+    g, orc, cfg, sd, scene, ro, rd = _surreal_inputs()
+    near, far = ops.near_far_cylinder(T(ro), T(rd), T(scene["cyls"]), 0.0, 1.0, 4096)
+    assert max_err(N(near), g["cyl_near"][:, 0]) < 3e-6 and max_err(N(far), g["cyl_far"][:, 0]) < 3e-6
+    # two chunks: each half gets its own nan-mean, exactly like two calls of the reference
+    n2, f2 = ops.near_far_cylinder(T(ro), T(rd), T(scene["cyls"]), 0.0, 1.0, 2048)
+    z = np.zeros(len(ro), dtype=np.int64)
+    rb = np.concatenate([ro, rd, np.zeros((len(ro), 1), np.float32), np.ones((len(ro), 1), np.float32)], -1)
+    on, of = o.near_far_cylinder(rb[:, 0:3], rb[:, 3:6], scene["cyls"][z], rb[:, 6:7], rb[:, 7:8], chunk=2048)
+    assert max_err(N(n2), on[:, 0]) < 3e-6 and max_err(N(f2), of[:, 0]) < 3e-6
+    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(orc.align))
+    nb, fb = eng.near_far(T(ro), T(rd), T(scene["cyls"]), T(scene["skts"]))
+    assert max_err(N(nb), g["near"][:, 0]) < 3e-5 and max_err(N(fb), g["far"][:, 0]) < 3e-5
+    assert (np.abs(N(nb) - g["near"][:, 0]) > 3e-6).sum() < 10
+
+
+def _stage_geo(ops, stage, z=None):
+    g, eng = stage["g"], stage["eng"]
+    eng.refresh()
+    rb = g["ray_batch"]
+    return ops.Geometry(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), eng.align, eng.axis_scale,
+                        z=T(g["z_coarse"] if z is None else z))
+
+
+def test_bone_cull_mask_bit_exact(ops, stage):
+    g = stage["g"]
+    geo = _stage_geo(ops, stage)
+    bits, lst, cnt = ops.bone_cull(geo, compact=True)
+    bits = N(bits).astype(np.uint32).reshape(g["invalid"].shape[:2])
+    valid = ((bits[..., None] >> np.arange(24, dtype=np.uint32)) & 1).astype(bool)
+    assert np.array_equal(~valid, g["invalid"].astype(bool))          # vs the reference itself
+    assert np.array_equal(valid, stage["ret"]["enc"]["valid"])          # vs the oracle
+    n = int(N(cnt)[0])
+    want = np.nonzero(valid.any(-1).reshape(-1))[0]
+    assert n == len(want)
+    assert np.array_equal(np.sort(N(lst)[:n]), want)
+
+
+def test_bone_cull_from_points(ops, stage):
+    g, eng = stage["g"], stage["eng"]
+    rb = g["ray_batch"]
+    geo_p = ops.Geometry(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), eng.align, eng.axis_scale, pts=T(g["pts"]))
+    b1, _, _ = ops.bone_cull(geo_p, compact=False)
+    b2, _, _ = ops.bone_cull(_stage_geo(ops, stage), compact=False)
+    assert torch.equal(b1, b2)
+
+
+def test_pose_volumes(ops, stage):
+    g, eng = stage["g"], stage["eng"]
+    vol = eng.volumes(T(g["bones"]))
+    assert max_err(N(vol), g["volumes"]) < 2e-5
+    assert max_err(N(vol), stage["ret"]["enc"]["volumes"]) < 2e-5
+
+
+def test_factorised_gather(ops, stage):
+    g = stage["g"]
+    geo = _stage_geo(ops, stage)
+    pf = ops.bone_gather(geo, T(g["volumes"]))
+    assert max_err(N(pf).reshape(g["part_feat"].shape), g["part_feat"]) < 5e-6
+    # compacted list: rows follow the list order
+    bits, lst, cnt = ops.bone_cull(geo, compact=True)
+    n = int(N(cnt)[0])
+    pfc = ops.bone_gather(geo, T(g["volumes"]), lst, cnt, geo.M)
+    want = g["part_feat"].reshape(-1, 24, 15)[N(lst)[:n]]
+    assert max_err(N(pfc)[:n], want) < 5e-6
+
+
+def test_assign_blend_unfused_and_fused(ops, stage):
+    g, eng, ret = stage["g"], stage["eng"], stage["ret"]
+    geo = _stage_geo(ops, stage)
+    bits, _, _ = ops.bone_cull(geo, compact=False)
+    h, confd = ops.assign_blend(T(g["part_feat"].reshape(-1, 24, 15)), bits, eng.aw, want_confd=True)
+    assert max_err(N(confd).reshape(g["confd"].shape), g["confd"]) < 2e-5
+    h_ref = ret["enc"]["h"]
+    assert max_err(N(h)[:, :15], h_ref) < 5e-6
+    assert float(N(h)[:, 15].max()) == 0.0
+    h2, confd2 = ops.gather_assign_blend(geo, T(g["volumes"]), bits, eng.aw, want_confd=True)
+    assert max_err(N(h2)[:, :15], h_ref) < 5e-6
+    assert max_err(N(confd2).reshape(g["confd"].shape), g["confd"]) < 2e-5
+
+
+def test_view_constants_and_empty_raw(ops, stage):
+    g, eng, orc, sd = stage["g"], stage["eng"], stage["orc"], stage["sd"]
+    rb = g["ray_batch"]
+    cview, raw_empty = eng.view_constants(T(rb[:, 3:6]), T(g["skts"]), T(g["cam_idx"], torch.int64))
+    vin = g["view_inputs"]                                   # [R,155] from the reference
+    want = vin @ sd["views_linears.0.weight"][:, 256:].T + sd["views_linears.0.bias"]
+    assert max_err(N(cview), want) < 5e-6
+    # empty-space raw: MLP on PE(0) with this ray's view vector
+    dens0 = o.positional_encoding(np.zeros((1, 15), np.float32), 6)
+    want_raw = o.mlp({k: np.asarray(v) for k, v in sd.items()}, np.repeat(dens0, len(vin), 0), vin)
+    assert rel_err(N(raw_empty), want_raw, floor=1.0) < 1e-4
+
+
+def test_pe_mlp_on_golden_features(ops, stage):
+    g, eng, ret = stage["g"], stage["eng"], stage["ret"]
+    rb = g["ray_batch"]
+    S = int(g["N_samples"])
+    cview, raw_empty = eng.view_constants(T(rb[:, 3:6]), T(g["skts"]), T(g["cam_idx"], torch.int64))
+    h = np.zeros((ret["enc"]["h"].shape[0], 16), np.float32)
+    h[:, :15] = ret["enc"]["h"]
+    raw = torch.zeros(len(rb), S, 4, device=DEV)
+    ops.pe_mlp(T(h), S, eng.packed, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w, eng.rgb_b, raw)
+    assert rel_err(N(raw), g["raw_coarse"], floor=1.0) < 1e-4      # north_star tolerance vs the reference
+    assert rel_err(N(raw), ret["raw_coarse"], floor=1.0) < 1e-4
+
+
+def test_forward_dense_equals_culled_bitwise(stage):
+    g, eng = stage["g"], stage["eng"]
+    rb = g["ray_batch"]
+    args = (T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cam_idx"], torch.int64))
+    raw_c, ex = eng.forward_samples(*args, z=T(g["z_coarse"]), dense=False)
+    raw_d, _ = eng.forward_samples(*args, z=T(g["z_coarse"]), dense=True)
+    assert torch.equal(raw_c, raw_d)
+    assert rel_err(N(raw_c), g["raw_coarse"], floor=1.0) < 1e-4
+    n = int(N(ex["count"])[0])
+    assert 0 < n < raw_c.shape[0] * raw_c.shape[1]
+
+
+def test_composite(ops, stage):
+    g = stage["g"]
+    rb = g["ray_batch"]
+    out = ops.composite(T(g["raw_coarse"]), T(g["z_coarse"]), T(rb[:, 3:6]), 1.0)
+    assert max_err(N(out["weights"]), g["weights_coarse"]) < 2e-6
+    assert max_err(N(out["alpha"]), g["alpha_coarse"]) < 2e-6
+    assert max_err(N(out["rgb_map"]), g["rgb_coarse"]) < 2e-6
+    assert max_err(N(out["acc_map"]), g["final_acc0"]) < 2e-6
+    assert rel_err(N(out["disp_map"]), g["final_disp0"], floor=1.0) < 1e-5
+
+
+def test_composite_long_rays_and_noise(ops):
+    rng = np.random.default_rng(0)
+    R, S = 37, 144                                           # > 64 samples: multi-chunk scan
+    raw = rng.normal(0, 2, size=(R, S, 4)).astype(np.float32)
+    z = np.sort(rng.uniform(2, 5, size=(R, S)).astype(np.float32), -1)
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    noise = rng.normal(size=(R, S)).astype(np.float32)
+    out = ops.composite(T(raw), T(z), T(d), 0.5, T(noise))
+    ref = o.composite(raw, z, d, 0.5, noise)
+    for k in ("weights", "alpha", "rgb_map", "acc_map"):
+        assert max_err(N(out[k]), ref[k]) < 5e-6, k
+    assert rel_err(N(out["disp_map"]), ref["disp_map"], floor=1.0) < 1e-5
+
+
+def test_importance_samples_and_merge(ops, stage):
+    g = stage["g"]
+    Sf = int(g["N_importance"])
+    zs, zf, idx = ops.importance_samples(T(g["z_coarse"]), T(g["weights_coarse"]), Sf)
+    assert max_err(N(zf), g["z_fine"]) < 2e-6
+    assert max_err(N(zs), g["z_sorted"]) < 2e-6
+    assert np.array_equal(N(idx).astype(np.int64), g["sorted_idxs"])
+    a = T(g["raw_coarse"])
+    b = torch.randn(a.shape[0], Sf, 4, device=DEV)
+    m = ops.merge_samples(a, b, idx)
+    want = np.take_along_axis(np.concatenate([g["raw_coarse"], N(b)], 1), g["sorted_idxs"][..., None], 1)
+    assert np.array_equal(N(m), want)
+
+
+def test_render_stage_fixture_end_to_end(stage):
+    g, eng = stage["g"], stage["eng"]
+    rb = g["ray_batch"]
+    out = eng.render(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cyls"]),
+                     T(g["cam_idx"], torch.int64), int(g["N_samples"]), int(g["N_importance"]), keep=True)
+    assert np.array_equal(N(out["z_coarse"]), g["z_coarse"])
+    assert rel_err(N(out["raw_coarse"]), g["raw_coarse"], floor=1.0) < 1e-4
+    for k in ("rgb_map", "acc_map", "alpha", "T_i", "rgb0", "acc0", "alpha0"):
+        assert max_err(N(out[k]), g["final_" + k]) < 5e-4, k
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 70.0
+
+
+def test_render_surreal_full_frame(ops):
+    """whole 64x64 frame, box near/far, no frame codes: final maps vs the reference"""
+    from core.render_engine import DanboEngine
+    g, orc, cfg, sd, scene, ro, rd = _surreal_inputs()
+    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(orc.align))
+    nf = (T(g["near"][:, 0]), T(g["far"][:, 0]))             # the reference's own bounds (see oracle test)
+    out = eng.render(T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(scene["cyls"]), None,
+                     int(g["N_samples"]), int(g["N_importance"]), near_far=nf)
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
+        assert max_err(N(out[k]), g["final_" + k]) < 1e-3, k
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 70.0
+
+
+def test_render_perfcap_view_branch():
+    from core.render_engine import DanboEngine
+    g = golden("danbo_perfcap")
+    orc, cfg, sd, rest = oracle_for(g)
+    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(orc.align))
+    rb = g["ray_batch"]
+    cam = T(-np.ones(len(rb)), torch.int64)
+    cview, _ = eng.view_constants(T(rb[:, 3:6]), T(g["skts"]), cam)
+    want = g["view_inputs"] @ sd["views_linears.0.weight"][:, 256:].T + sd["views_linears.0.bias"]
+    assert max_err(N(cview), want) < 5e-6
+    nf = (T(g["near"][:, 0]), T(g["far"][:, 0]))
+    out = eng.render(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cyls"]), cam,
+                     int(g["N_samples"]), int(g["N_importance"]), near_far=nf, keep=True)
+    assert rel_err(N(out["raw_coarse"]), g["raw_coarse"], floor=1.0) < 1e-4
+    for k in ("rgb_map", "acc_map", "alpha", "T_i", "rgb0", "acc0"):
+        assert max_err(N(out[k]), g["final_" + k]) < 1e-3, k
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 70.0
+
+
+def test_large_random_batch_against_oracle(ops):
+    """8192 rays x 24 samples, 4 poses: mask bit-exact, raw within 1e-4 rel of the oracle"""
+    from core.render_engine import DanboEngine
+    from core.utils import synthetic as syn
+    cfg = syn.model_config("danbo_base")
+    rest = syn.rest_pose(cfg["rest_scale"])
+    sd = syn.make_state_dict(cfg, seed=3, n_framecodes=10, rest=rest)
+    orc = o.DanboOracle(cfg, sd, rest)
+    scene = syn.make_scene(n_poses=4, H=64, W=64, n_views=4, pose_seed=40)
+    ro = np.concatenate([scene["rays"][p][0][1024:3072] for p in range(4)])
+    rd = np.concatenate([scene["rays"][p][1][1024:3072] for p in range(4)])
+    pose = np.repeat(np.arange(4), 2048)
+    rb = syn.ray_batch(ro, rd)
+    near, far = orc.near_far(rb[:, :3], rb[:, 3:6], scene["cyls"][pose], scene["skts"][pose], rb[:, 6:7], rb[:, 7:8])
+    z = o.coarse_z(near, far, 24)
+    cam = (np.arange(len(ro)) % 10).astype(np.int64)
+    raw_ref, enc = orc.forward(o.sample_points(ro, rd, z), rd, scene["skts"][pose], scene["bones"][pose], cam, 4)
+    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(orc.align))
+    raw, ex = eng.forward_samples(T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(cam, torch.int64), z=T(z),
+                                  want_confd=True)
+    bits = N(ex["valid_bits"]).astype(np.uint32).reshape(z.shape)
+    valid = ((bits[..., None] >> np.arange(24, dtype=np.uint32)) & 1).astype(bool)
+    assert np.array_equal(valid, enc["valid"])
+    assert valid.any(-1).mean() > 0.02
+    assert rel_err(N(raw), raw_ref, floor=1.0) < 1e-4
+    n = int(N(ex["count"])[0])
+    rows = N(ex["list"])[:n]
+    assert max_err(N(ex["confd_rows"])[:n], enc["confd"].reshape(-1, 24)[rows]) < 5e-5
