@@ -24,6 +24,8 @@ class DanboEngine:
         self._packed_key = None
         self.packed = self.wrt = self.empty_consts = None
         self.mean_code = None
+        # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
+        self.profile = None
 
     # ------------------------------------------------------------------ derived buffers
     def _key(self):
@@ -78,6 +80,7 @@ class DanboEngine:
         return ops.pose_volumes(bones, self.gw, self.cfg["multires_graph"])
 
     def view_constants(self, rays_d, skts, cam_idx):
+        self.refresh()
         cfg = self.cfg
         ray_mode = {"world": 0, "root_local": 1}[cfg["ray_tr_type"]]
         normalise = 1 if cfg["view_type"] == "relray" else 0
@@ -100,8 +103,14 @@ class DanboEngine:
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense)
         h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
         raw = ops.fill_raw(raw_empty, S)
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         ops.pe_mlp(h, S, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
                    self.rgb_w, self.rgb_b, raw, lst, cnt, geo.M)
+        if self.profile is not None:
+            e1.record()
+            self.profile.setdefault("k_pe_mlp", []).append((e0, e1, cnt if cnt is not None else geo.M))
         extras = dict(valid_bits=bits, list=lst, count=cnt, confd_rows=confd, h_rows=h, volumes=vols)
         return raw, extras
 
