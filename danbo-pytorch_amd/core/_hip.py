@@ -20,7 +20,7 @@ SIGNATURES = {
     "danbo_abi_version": [],
     "danbo_device_info": [POINTER(c_int), POINTER(c_int), c_char_p, I],
     "danbo_pose_volumes_fwd": [P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "danbo_near_far_cylinder": [P, P, P, I, I, F, F, I, P, P, P, P],
+    "danbo_near_far_cylinder": [P, P, P, I, I, F, F, P, P, I, P, P, P, P],
     "danbo_near_far_boxes": [P, P, P, P, P, I, I, P, P, P],
     "danbo_coarse_samples": [P, P, I, I, P, P, P],
     "danbo_bone_cull": [P, P, P, P, I, I, I, P, P, P, P, P, P, P],

@@ -61,15 +61,17 @@ def pose_volumes(bones, gw, L_graph=5):
     return vol
 
 
-def near_far_cylinder(rays_o, rays_d, cyl, near0=0.0, far0=1.0, chunk=4096):
+def near_far_cylinder(rays_o, rays_d, cyl, near0=0.0, far0=1.0, chunk=4096, near_in=None, far_in=None):
+    """near0/far0: scalar placeholder bounds; near_in/far_in: optional per-ray placeholders [R]."""
     rays_o, rays_d, cyl = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(cyl, "cyl")
+    near_in, far_in = _f32(near_in, "near_in"), _f32(far_in, "far_in")
     R, G = rays_o.shape[0], cyl.shape[0]
     nchunk = (R + chunk - 1) // chunk
     scratch = torch.empty(nchunk * 8, device=rays_o.device, dtype=torch.float32)
     near = torch.empty(R, device=rays_o.device, dtype=torch.float32)
     far = torch.empty_like(near)
-    _call("danbo_near_far_cylinder", _p(rays_o), _p(rays_d), _p(cyl), R, G, float(near0), float(far0), int(chunk),
-          _p(scratch), _p(near), _p(far), _stream())
+    _call("danbo_near_far_cylinder", _p(rays_o), _p(rays_d), _p(cyl), R, G, float(near0), float(far0),
+          _p(near_in), _p(far_in), int(chunk), _p(scratch), _p(near), _p(far), _stream())
     return near, far
 
 

@@ -1,0 +1,231 @@
+"""Ray casters (reference: core/raycasters.py): model + optimizer construction, checkpoint
+load, and the two-pass volumetric render of a ray batch.
+
+The render loop is the reference's (`render_rays`, reference :245-377) re-expressed as one
+stream-ordered chain of HIP kernels without host synchronisation:
+    cylinder (+ per-bone box) bounds -> coarse z -> [cull -> gather/assign/blend -> PE+MLP]
+    -> composite -> importance z + merge order -> [same network on the new samples] -> merge
+    -> composite.
+One process drives one GPU; multi-GPU runs shard rays across processes (no nn.DataParallel).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops as ops
+from .encoders import get_pe_embedder, get_pts_embedder
+from .networks import create_nerf
+from .utils.skeleton_utils import SMPLSkeleton, bone_align_transforms, get_skel_profile_from_rest_pose
+
+
+def get_density_fn(args):
+    if args.density_type == 'relu':
+        return F.relu
+    raise NotImplementedError(f'density activation {args.density_type}: only relu is implemented')
+
+
+def get_grad_vars(args, ray_caster):
+    """Trainable parameters of the coarse (and, unless single_net, fine) network."""
+    net, net_fine = ray_caster.get_networks()
+    if getattr(args, 'finetune_light', False):
+        for n, p in net.named_parameters():
+            p.requires_grad = 'framecodes' in n
+    out = [p for p in net.parameters() if p.requires_grad]
+    if net_fine is not None and not args.single_net:
+        out += [p for p in net_fine.parameters() if p.requires_grad]
+    return out
+
+
+def load_ckpt_from_path(ray_caster, optimizer, ckpt_path, finetune=False):
+    ckpt = torch.load(ckpt_path, map_location='cpu')
+    ray_caster.load_state_dict(ckpt)
+    if optimizer is not None and not finetune and "optimizer_state_dict" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    return ckpt["global_step"], ray_caster, optimizer, ckpt
+
+
+def filter_state_dict(model_sd, ckpt_sd):
+    """keep checkpoint entries whose name and shape match the model (non-strict reload)"""
+    return {k: v for k, v in ckpt_sd.items() if k in model_sd and tuple(v.shape) == tuple(model_sd[k].shape)}
+
+
+def create_raycaster(args, data_attrs, device=None):
+    """-> (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, loaded_ckpt)
+    (reference :17-143)."""
+    skel_type = data_attrs["skel_type"]
+    n_framecodes = data_attrs["n_views"] if args.n_framecodes is None else args.n_framecodes
+    pts_embedder, embed_dims = get_pts_embedder(args, data_attrs)
+    pe_fns, dims = get_pe_embedder(args, data_attrs, embed_dims)
+    if args.vol_cal_scale:
+        data_attrs['skel_profile'] = get_skel_profile_from_rest_pose(data_attrs['rest_pose'], skel_type=skel_type)
+    nerf_kwargs = dict(D=args.netdepth, W=args.netwidth, **dims, **pe_fns, pts_embedder=pts_embedder,
+                       use_viewdirs=args.use_viewdirs, use_framecode=args.opt_framecode,
+                       framecode_ch=args.framecode_size, n_framecodes=n_framecodes, skel_type=skel_type,
+                       density_scale=args.density_scale, view_W=args.netwidth_view,
+                       mask_vol_prob=args.mask_vol_prob, agg_type=args.agg_type)
+    model, model_fine, caster_class = create_nerf(args, nerf_kwargs, data_attrs)
+    kw = {}
+    cls = RayCaster
+    if caster_class is not None and caster_class.startswith('graph'):
+        cls, kw = GraphCaster, dict(use_volume_near_far=args.use_volume_near_far)
+    ray_caster = cls(model, network_fine=model_fine, rest_poses=data_attrs['rest_pose'], single_net=args.single_net,
+                     align_bones=args.align_bones, skel_type=skel_type, **kw)
+    if device is not None:
+        ray_caster = ray_caster.to(device)
+    grad_vars = get_grad_vars(args, ray_caster)
+    if args.weight_decay is None:
+        optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    else:
+        optimizer = torch.optim.AdamW(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999),
+                                      weight_decay=args.weight_decay)
+    start, loaded = 0, None
+    if args.ft_path is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f and 'pose' not in f] \
+            if os.path.isdir(d) else []
+    print('Found ckpts', ckpts)
+    if ckpts and not args.no_reload:
+        fin = getattr(args, 'finetune', False) or getattr(args, 'finetune_light', False)
+        start, ray_caster, optimizer, loaded = load_ckpt_from_path(ray_caster, optimizer, ckpts[-1], fin)
+        start = 0 if fin else start
+    preproc = dict(density_scale=args.density_scale, density_fn=get_density_fn(args))
+    train_kw = dict(ray_caster=ray_caster, perturb=args.perturb, N_importance=args.N_importance,
+                    N_samples=args.N_samples, use_viewdirs=args.use_viewdirs, raw_noise_std=args.raw_noise_std,
+                    ray_noise_std=args.ray_noise_std, ext_scale=args.ext_scale, preproc_kwargs=preproc,
+                    lindisp=args.lindisp, nerf_type=args.nerf_type)
+    test_kw = dict(train_kw, preproc_kwargs=dict(preproc), perturb=False, raw_noise_std=0., ray_noise_std=0.)
+    print(f"#parameters: {sum(p.numel() for p in model.parameters() if p.requires_grad)}")
+    optimizer.zero_grad()
+    return train_kw, test_kw, start, grad_vars, optimizer, loaded
+
+
+class RayCaster(nn.Module):
+    def __init__(self, network, network_fine=None, single_net=False, rest_poses=None, align_bones=None,
+                 skel_type=None, **kwargs):
+        super().__init__()
+        self.network, self.network_fine = network, network_fine
+        self.rest_poses, self.skel_type, self.align_bones = rest_poses, skel_type or SMPLSkeleton, align_bones
+        self.single_net = single_net
+        if not single_net and network_fine is not None:
+            raise NotImplementedError("single_net=False (separate fine network) is out of scope")
+        if align_bones is not None:
+            self.init_bone_align_transforms()
+
+    def init_bone_align_transforms(self):
+        if self.align_bones != 'align':
+            raise NotImplementedError("align_bones must be 'align'")
+        rest = np.asarray(self.rest_poses).reshape(-1, len(self.skel_type.joint_trees), 3)
+        self.transforms = torch.tensor(np.stack([bone_align_transforms(r, self.skel_type) for r in rest]))
+        self.child_idxs = None
+
+    def get_networks(self):
+        return self.network, self.network_fine
+
+    def update_embed_fns(self, global_step, args):
+        self.network.update_embed_fns(global_step, args)
+
+    # ---- checkpoint format of the reference (:601-637): one sub-dict per sub-module ----
+    @staticmethod
+    def _ckpt_key(k):
+        if k.endswith("_fine"):
+            return f"{k}_state_dict"
+        if k.endswith("_fn"):
+            return f"{k.split('_fn')[0]}_state_dict"
+        return "network_fn_state_dict" if k == "network" else f"{k}_state_dict"
+
+    def state_dict(self):
+        return {self._ckpt_key(k): m.state_dict() for k, m in self._modules.items() if m is not None}
+
+    def load_state_dict(self, ckpt, strict=True):
+        for k, m in self._modules.items():
+            if m is None:
+                continue
+            key = self._ckpt_key(k)
+            try:
+                m.load_state_dict(ckpt[key], strict=strict)
+            except (KeyError, RuntimeError):
+                if k.startswith('network') and key in ckpt:
+                    print('Error occur when loading state dict for network. Try loading with strict=False now')
+                    m.load_state_dict(filter_state_dict(m.state_dict(), ckpt[key]), strict=False)
+                else:
+                    print(f'Error occurr when loading state dict for {key}. The entity is not in the state dict?')
+
+    # ---- forward dispatch (reference :233-243) ----
+    def forward(self, *args, fwd_type='', **kwargs):
+        if fwd_type == 'density':
+            return self.render_pts_density(*args, **kwargs)
+        if fwd_type == 'mesh':
+            return self.render_mesh_density(*args, **kwargs)
+        if fwd_type:
+            raise NotImplementedError(fwd_type)
+        if self.training:
+            raise NotImplementedError("training render (backward kernels) is not built yet -- DESIGN.md")
+        with torch.no_grad():
+            return self.render_rays(*args, **kwargs)
+
+    def _engine(self):
+        dev = next(self.network.parameters()).device
+        if self.transforms.device != dev:
+            self.transforms = self.transforms.to(dev)
+        eng = self.network.engine(self.transforms[0])
+        eng.cfg['use_volume_near_far'] = bool(getattr(self, 'use_volume_near_far', False))
+        eng.refresh()
+        return eng
+
+    @staticmethod
+    def _per_pose(x, G):
+        return x if x.shape[0] == G else x[::max(x.shape[0] // G, 1)].contiguous()
+
+    def render_rays(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
+                    subject_idxs=None, retraw=False, lindisp=False, perturb=0., N_importance=0, network_fine=None,
+                    raw_noise_std=0., ray_noise_std=0., verbose=False, ext_scale=0.001, pytest=False, N_uniques=1,
+                    render_confd=False, render_entropy=False, preproc_kwargs={}, netchunk=1024 * 64,
+                    nerf_type="nerf", **kwargs):
+        if N_importance <= 0:
+            raise NotImplementedError("N_importance=0 raises in the reference too (raycasters.py:377)")
+        if perturb or raw_noise_std or ray_noise_std or lindisp:
+            raise NotImplementedError("stochastic sampling belongs to the training path")
+        eng = self._engine()
+        G = int(N_uniques)
+        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+        skts_g, bones_g, cyls_g = self._per_pose(skts, G), self._per_pose(bones, G), self._per_pose(cyls, G)
+        R = rays_o.shape[0]
+        near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., R, ray_batch[:, 6], ray_batch[:, 7])
+        if eng.cfg['use_volume_near_far']:
+            ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
+        eng.cfg['density_scale'] = preproc_kwargs.get('density_scale', eng.cfg['density_scale'])
+        return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance,
+                          near_far=(near, far))
+
+    def render_pts_density(self, pts, kps, skts, bones, netchunk=1024 * 64, network=None):
+        assert kps.shape[0] == 1, f'Assuming only one pose is provided, got {kps.shape[0]} instead'
+        eng = self._engine()
+        return eng.density(pts.reshape(-1, 1, 3), skts[:1], bones[:1])
+
+    @torch.no_grad()
+    def render_mesh_density(self, kps, skts, bones, subject_idxs=None, radius=1.0, res=64, render_kwargs=None,
+                            netchunk=1024 * 64, v=None):
+        t = torch.linspace(-radius, radius, res + 1, device=kps.device)
+        gx, gy, gz = torch.meshgrid(t, t, t, indexing='xy')
+        grid = torch.stack([gx, gy, gz], -1)
+        dens = self.render_pts_density(grid.reshape(-1, 1, 3) + kps[0, 0], kps, skts, bones)[..., :1]
+        return dens.reshape(*grid.shape[:-1]).transpose(1, 0)
+
+
+class GraphCaster(RayCaster):
+    def __init__(self, *args, use_volume_near_far=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_volume_near_far = use_volume_near_far
+
+
+def merge_samples(x, x_is, gather_idxs, N_total_samples):
+    """Interleave coarse / importance tensors by the sorted order (reference :745-761);
+    gather_idxs here is the int32 sorted index [R, S+Sf] returned by isample_from_lineseg."""
+    if x is None or x.shape[-1] == 0:
+        return None
+    return ops.merge_samples(x, x_is, gather_idxs)

@@ -114,6 +114,17 @@ class DanboEngine:
         extras = dict(valid_bits=bits, list=lst, count=cnt, confd_rows=confd, h_rows=h, volumes=vols)
         return raw, extras
 
+    def density(self, pts, skts, bones):
+        """NeRF.forward_pts (reference nerf.py:150-154): raw density of arbitrary points [M,1,3]."""
+        self.refresh()
+        M = pts.shape[0]
+        dummy = torch.zeros(M, 3, device=pts.device)
+        raw_empty = torch.zeros(M, 4, device=pts.device)
+        raw_empty[:, 3] = self.empty_consts[128]
+        cview = torch.zeros(M, ops.VIEW_W, device=pts.device)
+        raw, _ = self.forward_samples(dummy, dummy, skts, bones, pts=pts, view=(cview, raw_empty))
+        return raw[..., 3:4].reshape(M, 1)
+
     # ------------------------------------------------------------------ RayCaster.render_rays (eval)
     def near_far(self, rays_o, rays_d, cyls, skts, near0=0.0, far0=1.0, chunk=4096):
         self.refresh()

@@ -16,30 +16,59 @@ namespace danbo {
 __global__ __launch_bounds__(256) void k_cylinder_pass1(const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ cyl, int R, int G,
-                                                        float near0, float far0, int chunk,
+                                                        float near0, float far0,
+                                                        const float* __restrict__ near_in,
+                                                        const float* __restrict__ far_in, int chunk,
                                                         double* __restrict__ acc,  // [nchunk][4]
                                                         float* __restrict__ near_out,
                                                         float* __restrict__ far_out) {
     const int rays_per_pose = R / G;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-        const int g = min(r / rays_per_pose, G - 1);
-        float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
-        float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    // wave-uniform trip count: every lane runs every iteration (inactive ones with act = false)
+    for (int r0 = blockIdx.x * blockDim.x; r0 < R; r0 += gridDim.x * blockDim.x) {
+        const int r = r0 + threadIdx.x;
+        const bool act = r < R;
+        const int rc = act ? r : R - 1;
+        const int g = min(rc / rays_per_pose, G - 1);
+        float o[3] = {rays_o[3 * rc], rays_o[3 * rc + 1], rays_o[3 * rc + 2]};
+        float d[3] = {rays_d[3 * rc], rays_d[3 * rc + 1], rays_d[3 * rc + 2]};
         float c[3] = {cyl[5 * g], cyl[5 * g + 1], cyl[5 * g + 2]};
         float nr, fr;
-        const bool hit = cylinder_bounds(o, d, c, near0, far0, &nr, &fr);
-        near_out[r] = nr;
-        far_out[r] = fr;
-        if (hit) {
-            double* a = acc + 4 * (r / chunk);
-            atomicAdd(a + 0, (double)nr);
-            atomicAdd(a + 1, (double)fr);
+        const bool hit = cylinder_bounds(o, d, c, near_in ? near_in[rc] : near0, far_in ? far_in[rc] : far0, &nr, &fr) && act;
+        if (act) {
+            near_out[r] = nr;
+            far_out[r] = fr;
+        }
+        // chunk-wide sums for the nan-mean back-fill: reduce inside the wavefront first when all
+        // of its rays belong to one chunk (the common case), one fp64 atomic triple per wavefront
+        const int ck = rc / chunk;
+        const int ck0 = __shfl(ck, 0, 64);
+        const bool uniform = __all(ck == ck0);
+        double sn = hit ? (double)nr : 0.0, sf = hit ? (double)fr : 0.0, sc = hit ? 1.0 : 0.0;
+        if (uniform) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sn += __shfl_xor(sn, off, 64);
+                sf += __shfl_xor(sf, off, 64);
+                sc += __shfl_xor(sc, off, 64);
+            }
+            if ((threadIdx.x & 63) == 0 && sc > 0.0) {
+                double* a = acc + 4 * ck;
+                atomicAdd(a + 0, sn);
+                atomicAdd(a + 1, sf);
+                atomicAdd(a + 2, sc);
+            }
+        } else if (hit) {
+            double* a = acc + 4 * ck;
+            atomicAdd(a + 0, sn);
+            atomicAdd(a + 1, sf);
             atomicAdd(a + 2, 1.0);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_cylinder_pass2(int R, float near0, float far0, int chunk,
+__global__ __launch_bounds__(256) void k_cylinder_pass2(int R, float near0, float far0,
+                                                        const float* __restrict__ near_in,
+                                                        const float* __restrict__ far_in, int chunk,
                                                         const double* __restrict__ acc,
                                                         float* __restrict__ near_out,
                                                         float* __restrict__ far_out) {
@@ -48,8 +77,8 @@ __global__ __launch_bounds__(256) void k_cylinder_pass2(int R, float near0, floa
         if (nr != nr) {  // ray missed the cylinder: chunk-wide nan-mean (ray_utils.py:330-344)
             const double* a = acc + 4 * (r / chunk);
             const double cnt = a[2];
-            near_out[r] = cnt > 0.0 ? (float)(a[0] / cnt) : near0;
-            far_out[r] = cnt > 0.0 ? (float)(a[1] / cnt) : far0;
+            near_out[r] = cnt > 0.0 ? (float)(a[0] / cnt) : (near_in ? near_in[r] : near0);
+            far_out[r] = cnt > 0.0 ? (float)(a[1] / cnt) : (far_in ? far_in[r] : far0);
         }
     }
 }
@@ -393,17 +422,17 @@ __global__ __launch_bounds__(64) void k_importance(const float* __restrict__ z, 
 using namespace danbo;
 
 extern "C" int danbo_near_far_cylinder(const float* rays_o, const float* rays_d, const float* cyl, int R, int G,
-                                        float near0, float far0, int chunk, float* scratch, float* near_out,
-                                        float* far_out, void* stream) {
+                                        float near0, float far0, const float* near_in, const float* far_in, int chunk,
+                                        float* scratch, float* near_out, float* far_out, void* stream) {
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && chunk > 0 && scratch != nullptr);
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(R, chunk);
     hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 4 * nchunk, st);
     if (e != hipSuccess) return (int)e;
     const int grid = stream_grid(R, 256);
-    hipLaunchKernelGGL(k_cylinder_pass1, dim3(grid), dim3(256), 0, st, rays_o, rays_d, cyl, R, G, near0, far0, chunk,
-                       reinterpret_cast<double*>(scratch), near_out, far_out);
-    hipLaunchKernelGGL(k_cylinder_pass2, dim3(grid), dim3(256), 0, st, R, near0, far0, chunk,
+    hipLaunchKernelGGL(k_cylinder_pass1, dim3(grid), dim3(256), 0, st, rays_o, rays_d, cyl, R, G, near0, far0, near_in,
+                       far_in, chunk, reinterpret_cast<double*>(scratch), near_out, far_out);
+    hipLaunchKernelGGL(k_cylinder_pass2, dim3(grid), dim3(256), 0, st, R, near0, far0, near_in, far_in, chunk,
                        reinterpret_cast<const double*>(scratch), near_out, far_out);
     DANBO_LAUNCH_RET();
 }

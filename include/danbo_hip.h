@@ -57,7 +57,9 @@ int danbo_pose_volumes_fwd(const float* bones, int G, int L_graph, int W,
  *   core/trainer.py:96-98); scratch >= 32*ceil(R/chunk) BYTES (fp64 partial sums).
  * ------------------------------------------------------------------------------------- */
 int danbo_near_far_cylinder(const float* rays_o, const float* rays_d, const float* cyl, int R, int G,
-                            float near0, float far0, int chunk, float* scratch,
+                            float near0, float far0,
+                            const float* near_in /*[R] or NULL: per-ray placeholders override near0*/,
+                            const float* far_in /*[R] or NULL*/, int chunk, float* scratch,
                             float* near_out /*[R]*/, float* far_out /*[R]*/, void* stream);
 
 /* GraphCaster.get_near_far + get_ray_box_intersections (core/raycasters.py:648-707,

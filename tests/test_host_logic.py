@@ -1,0 +1,224 @@
+"""CPU-only tests of everything that is not a GPU kernel launch:
+  * the C-ABI library loads and exports every symbol include/danbo_hip.h declares,
+  * the kernel bodies that are plain scalar C++ (csrc/sample_math.hpp), host-compiled, agree
+    with the numpy oracle / golden vectors (mask bit-exact),
+  * the core.networks / core.raycasters module surface: names, state_dict keys and shapes,
+    checkpoint round trip, config parsing, and the hard failure without a GPU.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import danbo_oracle as o
+from helpers import ROOT, golden, oracle_for, max_err
+
+F = ctypes.POINTER(ctypes.c_float)
+
+
+def fp(a):
+    return a.ctypes.data_as(F)
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from core import _hip
+    hdr = open(os.path.join(ROOT, "include", "danbo_hip.h")).read()
+    declared = set(re.findall(r"^int\s+(danbo_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 16
+    lib = _hip.lib()                                  # loads without a GPU
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/danbo_hip.h but not exported"
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    assert lib.danbo_abi_version() == 1
+    # argument counts of the ctypes table match the header
+    for name in declared:
+        m = re.search(r"int\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S).strip()
+        n_args = 0 if body in ("void", "") else body.count(",") + 1
+        assert n_args == len(_hip.SIGNATURES[name]), (name, n_args, len(_hip.SIGNATURES[name]))
+
+
+def test_invalid_arguments_are_rejected_without_touching_the_gpu():
+    from core import _hip
+    lib = _hip.lib()
+    # R % G != 0 -> DANBO_EINVAL before any launch
+    rc = lib.danbo_near_far_boxes(None, None, None, None, None, 10, 3, None, None, None)
+    assert rc == -22
+    assert lib.danbo_composite_fwd(None, None, None, 0, 8, 1.0, None, None, None, None, None, None, None) == -22
+
+
+def test_ops_refuse_cpu_tensors():
+    from core import hip_ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip_ops.composite(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+
+
+# ------------------------------------------------------------------ host-compiled kernel bodies
+@pytest.fixture(scope="module")
+def emu():
+    d = os.path.join(ROOT, "tests", "host_emu")
+    subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(os.path.join(d, "libdanbo_emu.so"))
+
+
+def test_emu_transform_cull_gather_vs_golden(emu):
+    g = golden("danbo_stages")
+    rb = np.ascontiguousarray(g["ray_batch"])
+    R, S = g["z_coarse"].shape
+    ro, rd = np.ascontiguousarray(rb[:, 0:3]), np.ascontiguousarray(rb[:, 3:6])
+    z = np.zeros((R, S), np.float32)
+    emu.emu_coarse_z(fp(np.ascontiguousarray(g["near"][:, 0])), fp(np.ascontiguousarray(g["far"][:, 0])), R, S, fp(z))
+    assert np.array_equal(z, g["z_coarse"])
+    orc, cfg, sd, rest = oracle_for(g)
+    bits = np.zeros(R * S, np.uint32)
+    pts_t = np.zeros((R, S, 24, 3), np.float32)
+    pf = np.zeros((R, S, 24, 15), np.float32)
+    emu.emu_cull_gather(fp(ro), fp(rd), fp(z), R, S, 2, fp(np.ascontiguousarray(g["skts"])), fp(orc.align),
+                        fp(np.ascontiguousarray(sd["graph_net.axis_scale"])), fp(np.ascontiguousarray(g["volumes"])),
+                        bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), fp(pts_t), fp(pf))
+    assert np.array_equal(pts_t, g["pts_t"])                       # bit-exact vs the reference
+    valid = ((bits.reshape(R, S)[..., None] >> np.arange(24, dtype=np.uint32)) & 1).astype(bool)
+    assert np.array_equal(~valid, g["invalid"].astype(bool))
+    assert max_err(pf, g["part_feat"]) < 5e-6
+
+
+def test_emu_cylinder_and_boxes_vs_oracle(emu):
+    from core.utils import synthetic as syn
+    g = golden("danbo_surreal")
+    orc, cfg, sd, rest = oracle_for(g)
+    scene = syn.make_scene(n_poses=1, H=64, W=64, n_views=3, pose_seed=int(g["pose_seed"]),
+                           rest_scale=cfg["rest_scale"], cam_dist=float(g["cam_dist"]))
+    ro, rd = scene["rays"][int(g["view"])]
+    R = len(ro)
+    nr, fr, hit = np.zeros(R, np.float32), np.zeros(R, np.float32), np.zeros(R, np.int32)
+    emu.emu_cylinder(fp(ro), fp(rd), fp(scene["cyls"]), R, 1, ctypes.c_float(0.), ctypes.c_float(1.), fp(nr), fp(fr),
+                     hit.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    miss = hit == 0
+    assert 50 < miss.sum() < 2000
+    nr[miss] = np.float32(nr[~miss].astype(np.float64).mean())      # chunk-wide nan-mean
+    fr[miss] = np.float32(fr[~miss].astype(np.float64).mean())
+    assert max_err(nr, g["cyl_near"][:, 0]) < 3e-6 and max_err(fr, g["cyl_far"][:, 0]) < 3e-6
+    emu.emu_boxes(fp(ro), fp(rd), fp(scene["skts"]), fp(orc.align), fp(np.ascontiguousarray(sd["graph_net.axis_scale"])),
+                  R, 1, fp(nr), fp(fr))
+    assert max_err(nr, g["near"][:, 0]) < 3e-5 and max_err(fr, g["far"][:, 0]) < 3e-5
+    assert (np.abs(nr - g["near"][:, 0]) > 3e-6).sum() < 10
+
+
+def test_emu_importance_and_composite_vs_golden(emu):
+    g = golden("danbo_stages")
+    R, S = g["z_coarse"].shape
+    Sf = int(g["N_importance"])
+    zf, zs = np.zeros((R, Sf), np.float32), np.zeros((R, S + Sf), np.float32)
+    idx = np.zeros((R, S + Sf), np.int32)
+    emu.emu_importance(fp(np.ascontiguousarray(g["z_coarse"])), fp(np.ascontiguousarray(g["weights_coarse"])), R, S, Sf,
+                       fp(zf), fp(zs), idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    assert max_err(zf, g["z_fine"]) < 5e-6 and max_err(zs, g["z_sorted"]) < 5e-6
+    assert np.array_equal(idx.astype(np.int64), g["sorted_idxs"])
+    rgb, disp, acc = np.zeros((R, 3), np.float32), np.zeros(R, np.float32), np.zeros(R, np.float32)
+    w, al = np.zeros((R, S), np.float32), np.zeros((R, S), np.float32)
+    rd = np.ascontiguousarray(g["ray_batch"][:, 3:6])
+    emu.emu_composite(fp(np.ascontiguousarray(g["raw_coarse"])), fp(np.ascontiguousarray(g["z_coarse"])), fp(rd), R, S,
+                      ctypes.c_float(1.0), None, fp(rgb), fp(disp), fp(acc), fp(w), fp(al))
+    assert max_err(w, g["weights_coarse"]) < 2e-6 and max_err(rgb, g["rgb_coarse"]) < 2e-6
+    assert max_err(acc, g["final_acc0"]) < 2e-6
+
+
+# ------------------------------------------------------------------ module surface
+def _build(cfg_file, extra=()):
+    from core.config import parse_args
+    from core.raycasters import create_raycaster
+    from core.utils import synthetic as syn
+    from core.utils.skeleton_utils import SMPLSkeleton
+    args = parse_args(["--no_reload", *extra], config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", cfg_file))
+    scale = 0.714 if "surreal" in cfg_file else 0.48
+    da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=20, rest_pose=syn.rest_pose(scale), hwf=(64, 64, 80.))
+    return args, create_raycaster(args, da)
+
+
+@pytest.mark.parametrize("cfg_file,cfg_name", [("h36m_zju/danbo_base.txt", "danbo_base"),
+                                               ("perfcap/danbo_fast.txt", "danbo_perfcap"),
+                                               ("surreal/danbo_fast.txt", "danbo_surreal")])
+def test_state_dict_names_and_shapes_match_reference(cfg_file, cfg_name):
+    from core.utils import synthetic as syn
+    args, (tr, te, start, grad_vars, opt, _) = _build(cfg_file)
+    caster = te["ray_caster"]
+    cfg = syn.model_config(cfg_name)
+    ref = syn.make_state_dict(cfg, 0, 20, syn.rest_pose(cfg["rest_scale"]))   # loads strictly into the reference
+    sd = caster.network.state_dict()
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == ref[k].shape, k
+    assert max_err(sd["graph_net.axis_scale"].numpy(), ref["graph_net.axis_scale"]) == 0.0
+    assert np.array_equal(sd["graph_net.layers.0.adj"].numpy(), ref["graph_net.layers.0.adj"])
+    n_par = sum(p.numel() for p in grad_vars)
+    assert n_par == sum(v.size for k, v in ref.items() if not k.endswith(".adj"))
+    assert caster.network_fine is caster.network                # single_net
+    assert type(caster).__name__ == "GraphCaster"
+    assert caster.use_volume_near_far == ("fast" in cfg_file)
+    assert np.array_equal(caster.transforms[0].numpy(), o.bone_align_transforms(syn.rest_pose(cfg["rest_scale"])))
+
+
+def test_reference_checkpoint_layout_round_trip(tmp_path):
+    from core.utils import synthetic as syn
+    args, (tr, te, *_rest) = _build("h36m_zju/danbo_base.txt")
+    caster = te["ray_caster"]
+    ref = syn.make_state_dict(syn.model_config("danbo_base"), 5, 20, syn.rest_pose(0.48))
+    caster.network.load_state_dict({k: torch.tensor(v) for k, v in ref.items()}, strict=True)
+    ck = caster.state_dict()
+    # reference layout (raycasters.py:601-615): one dict per sub-network, single_net saved twice
+    assert set(ck) == {"network_fn_state_dict", "network_fine_state_dict"}
+    path = tmp_path / "000010.tar"
+    torch.save({"global_step": 10, **ck}, path)
+    args2, (tr2, te2, *_r) = _build("h36m_zju/danbo_base.txt")
+    c2 = te2["ray_caster"]
+    c2.load_state_dict(torch.load(path))
+    for k, v in c2.network.state_dict().items():
+        assert torch.equal(v, torch.tensor(ref[k])), k
+
+
+def test_config_files_parse_to_the_shipped_values():
+    from core.config import parse_args
+    d = os.path.join(ROOT, "danbo-pytorch_amd", "configs")
+    a = parse_args([], config=os.path.join(d, "h36m_zju/danbo_base.txt"))
+    assert (a.nerf_type, a.N_samples, a.N_importance, a.multires_voxel, a.gcn_fc_D, a.chunk) == ("danbo", 96, 48, 6, 1, 4096)
+    assert a.use_volume_near_far is False and a.opt_framecode is True and a.loss_fn == "L1"
+    b = parse_args(["--N_samples", "48"], config=os.path.join(d, "perfcap/danbo_fast.txt"))
+    assert (b.nerf_type, b.view_type, b.ray_tr_type, b.N_samples, b.vol_scale_penalty) == ("graph", "relray", "root_local", 48, 1e-4)
+    c = parse_args([], config=os.path.join(d, "h36m_zju/anerf_base.txt"))
+    assert (c.nerf_type, c.netwidth, c.use_cutoff, c.multires) == ("nerf", 448, True, 7)
+
+
+def test_cutoff_embedder_tau_schedule():
+    from core.cutoff_embedder import get_embedder
+    emb, dim = get_embedder(7, 0, input_dims=24, cutoff_kwargs=dict(cutoff=True, cutoff_dist=0.5, cutoff_dim=24,
+                                                                    cutoff_inputs=True, cut_to_cutoff=True,
+                                                                    shift_inputs=True))
+    assert dim == 360 and emb.get_tau() == 20.0
+    emb.update_tau(250000, 250, 10.0)
+    assert abs(emb.get_tau() - 200.0) < 1e-3
+    emb.update_tau(10 ** 7, 250, 10.0)
+    assert emb.get_tau() == 2000.0
+    assert set(emb.state_dict()) == {"cutoff_dist", "tau"}
+
+
+def test_forward_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    args, (tr, te, *_r) = _build("h36m_zju/danbo_base.txt")
+    caster = te["ray_caster"].eval()
+    R = 8
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        caster(torch.zeros(R, 11), N_samples=8, kp_batch=torch.zeros(R, 24, 3), skts=torch.eye(4).expand(R, 24, 4, 4),
+               cyls=torch.ones(R, 5), bones=torch.zeros(R, 24, 3), cams=None, N_importance=4)
+
+
+def test_unsupported_variants_raise_instead_of_falling_back():
+    with pytest.raises(NotImplementedError):
+        _build("h36m_zju/danbo_base.txt", extra=["--agg_type", "softmax"])
+    with pytest.raises(NotImplementedError):
+        _build("h36m_zju/danbo_base.txt", extra=["--gnn_backbone", "PNBGNN"])
