@@ -117,8 +117,11 @@ __device__ __forceinline__ float rgb_dot(const float* x /*LDS, 16-B aligned*/, c
 // ======================================================================================
 // per-ray view constants
 // ======================================================================================
-constexpr int VIEW_RPB = 8;  // rays per workgroup iteration
+constexpr int VIEW_RPB = 16;  // rays per workgroup iteration (8 per half-workgroup)
 
+// Each thread owns one of the 128 view-layer columns for 8 rays: per input i it reads ONE weight
+// (conflict-free, lane = column) and the 8 rays' v_i as two broadcast ds_read_b128, then issues
+// 8 FMAs -- 3 LDS reads per 8 FMAs instead of 2 per FMA.
 __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ rays_d, const float* __restrict__ skts,
                                                      int R, int G, int ray_mode, int normalise, int L_view,
                                                      const float* __restrict__ framecodes, int n_codes, int Cf,
@@ -132,17 +135,19 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Cpe = 3 * (1 + 2 * L_view);
     const int Cv = Cpe + Cf;
-    const int Cvp = (Cv + 3) & ~3;
-    float* s_w = smem;                       // [Cv][128]
-    float* s_v = s_w + Cv * MLP_VW;          // [RPB][Cvp]
-    float* s_x = s_v + VIEW_RPB * Cvp;       // [RPB][128]
+    float* s_w = smem;                        // [Cv][128]
+    float* s_v = s_w + Cv * MLP_VW;           // [Cv][16]   (transposed: input-major, ray-minor)
+    float* s_x = s_v + Cv * VIEW_RPB;         // [16][128]
     const int tid = threadIdx.x;
     for (int i = tid; i < Cv * MLP_VW; i += 256) s_w[i] = wt[i];
     const int rays_per_pose = R / G;
+    const int c = tid & 127, half = tid >> 7;
+    const float bias = views_b[c];
+    const float ec = empty_consts ? empty_consts[c] : 0.f;
 
     for (int r0 = blockIdx.x * VIEW_RPB; r0 < R; r0 += gridDim.x * VIEW_RPB) {
         __syncthreads();
-        // ---- build the per-ray view vectors [PE(dir) | frame code] ----
+        // ---- build the per-ray view vectors [PE(dir) | frame code], stored [i][ray] ----
         if (tid < VIEW_RPB * 3) {
             const int rl = tid / 3, k = tid % 3;
             const int r = min(r0 + rl, R - 1);
@@ -159,36 +164,43 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                 const float den = fmaxf(nrm, 1e-12f);
                 d[0] = div_rn(d[0], den); d[1] = div_rn(d[1], den); d[2] = div_rn(d[2], den);
             }
-            float* v = s_v + rl * Cvp;
-            v[k] = d[k];
+            s_v[k * VIEW_RPB + rl] = d[k];
             for (int l = 0; l < L_view; ++l) {
-                const float xf = mul_rn(d[k], (float)(1 << l));
                 float sn, cs;
-                sincosf(xf, &sn, &cs);
-                v[3 * (1 + 2 * l) + k] = sn;
-                v[3 * (2 + 2 * l) + k] = cs;
+                sincosf(mul_rn(d[k], (float)(1 << l)), &sn, &cs);
+                s_v[(3 * (1 + 2 * l) + k) * VIEW_RPB + rl] = sn;
+                s_v[(3 * (2 + 2 * l) + k) * VIEW_RPB + rl] = cs;
             }
         }
         for (int i = tid; i < VIEW_RPB * Cf; i += 256) {
             const int rl = i / Cf, k = i % Cf;
             const int r = min(r0 + rl, R - 1);
             const long idx = cam_idx ? (long)cam_idx[r] : -1;
-            float val;
-            if (idx < 0) val = mean_code[k];
-            else val = framecodes[(size_t)min(idx, (long)n_codes - 1) * Cf + k];
-            s_v[rl * Cvp + Cpe + k] = val;
+            const float val = idx < 0 ? mean_code[k] : framecodes[(size_t)min(idx, (long)n_codes - 1) * Cf + k];
+            s_v[(Cpe + k) * VIEW_RPB + rl] = val;
         }
         __syncthreads();
-        // ---- cview[r][c] = sum_i W[c][256+i] v[i] + b[c] ----
-        const int c = tid & 127;
-        for (int rl = tid >> 7; rl < VIEW_RPB; rl += 2) {
-            const float* v = s_v + rl * Cvp;
-            float acc = 0.f;
-            for (int i = 0; i < Cv; ++i) acc = fmaf(v[i], s_w[i * MLP_VW + c], acc);
-            acc += views_b[c];
-            const int r = r0 + rl;
-            if (r < R) cview[(size_t)r * MLP_VW + c] = acc;
-            if (empty_consts) s_x[rl * MLP_VW + c] = fmaxf(empty_consts[c] + acc, 0.f);
+        // ---- cview[r][c] = sum_i W[c][256+i] v[i] + b[c]   (sequential fmaf over i) ----
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        const float* vp = s_v + half * 8;
+#pragma unroll 4
+        for (int i = 0; i < Cv; ++i) {
+            const float w = s_w[i * MLP_VW + c];
+            const float4 v0 = *reinterpret_cast<const float4*>(vp + i * VIEW_RPB);
+            const float4 v1 = *reinterpret_cast<const float4*>(vp + i * VIEW_RPB + 4);
+            acc[0] = fmaf(v0.x, w, acc[0]); acc[1] = fmaf(v0.y, w, acc[1]);
+            acc[2] = fmaf(v0.z, w, acc[2]); acc[3] = fmaf(v0.w, w, acc[3]);
+            acc[4] = fmaf(v1.x, w, acc[4]); acc[5] = fmaf(v1.y, w, acc[5]);
+            acc[6] = fmaf(v1.z, w, acc[6]); acc[7] = fmaf(v1.w, w, acc[7]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rl = half * 8 + q, r = r0 + rl;
+            const float a = acc[q] + bias;
+            if (r < R) cview[(size_t)r * MLP_VW + c] = a;
+            if (empty_consts) s_x[rl * MLP_VW + c] = fmaxf(ec + a, 0.f);
         }
         if (empty_consts) {
             __syncthreads();
@@ -456,8 +468,7 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
     DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
     DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
     const int Cv = 3 * (1 + 2 * L_view) + Cf;
-    const int Cvp = (Cv + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + VIEW_RPB * Cvp + VIEW_RPB * MLP_VW);
+    const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + VIEW_RPB * Cv + VIEW_RPB * MLP_VW);
     DANBO_CHECK_ARG(lds <= 160 * 1024);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_view_consts),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
