@@ -164,7 +164,7 @@ def mlp_pack(pts_w, feature_w, views_w):
 
 
 def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code, cam_idx, wrt, views_b,
-                rgb_w, rgb_b, empty_consts=None):
+                rgb_w, rgb_b, empty_consts=None, rgb_order=0):
     rays_d = _f32(rays_d, "rays_d")
     R, G = rays_d.shape[0], skts.shape[0]
     Cf = 0 if mean_code is None else mean_code.shape[0]
@@ -175,7 +175,7 @@ def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code
         cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
     _call("danbo_view_consts", _p(rays_d), _p(_f32(skts, "skts")), R, G, int(ray_mode), int(normalise), int(L_view),
           _p(framecodes), n_codes, Cf, _p(mean_code), _p(cam_idx), _p(wrt), _p(views_b), _p(rgb_w), _p(rgb_b),
-          _p(empty_consts), _p(cview), _p(raw_empty), _stream())
+          _p(empty_consts), int(rgb_order), _p(cview), _p(raw_empty), _stream())
     return cview, raw_empty
 
 
@@ -185,6 +185,29 @@ def pe_mlp(h, S, packed, pts_b, alpha_w, alpha_b, feature_b, cview, rgb_w, rgb_b
     aux_out = torch.empty(n, VIEW_W + 1, device=h.device, dtype=torch.float32) if aux else None
     _call("danbo_pe_mlp_fwd", _p(h), _p(lst), _p(cnt), n, S, _p(packed), _ptr_array(pts_b), _p(alpha_w), _p(alpha_b),
           _p(feature_b), _p(cview), _p(rgb_w), _p(rgb_b), _p(raw_out), _p(aux_out), _stream())
+    return aux_out
+
+
+MLP16_PACKED_BYTES = 2686976
+
+
+def mlp16_pack(pts_w, feature_w, views_w):
+    """fp16 hi/lo fragment packing for pe_mlp16 -> uint8 buffer [MLP16_PACKED_BYTES]."""
+    dev = feature_w.device
+    Cv = views_w.shape[1] - 256
+    packed = torch.empty(MLP16_PACKED_BYTES, device=dev, dtype=torch.uint8)
+    pts_w = [_f32(w, "pts_w") for w in pts_w]
+    _call("danbo_mlp16_pack", _ptr_array(pts_w), _p(_f32(feature_w, "feature_w")), _p(_f32(views_w, "views_w")), Cv,
+          _p(packed), _stream())
+    return packed
+
+
+def pe_mlp16(h, S, packed16, pts_b, alpha_w, alpha_b, feature_b, cview, rgb_w, rgb_b, raw_out,
+             lst=None, cnt=None, n=None, aux=False):
+    n = h.shape[0] if n is None else n
+    aux_out = torch.empty(n, VIEW_W + 1, device=h.device, dtype=torch.float32) if aux else None
+    _call("danbo_pe_mlp16_fwd", _p(h), _p(lst), _p(cnt), n, S, _p(packed16), _ptr_array(pts_b), _p(alpha_w),
+          _p(alpha_b), _p(feature_b), _p(cview), _p(rgb_w), _p(rgb_b), _p(raw_out), _p(aux_out), _stream())
     return aux_out
 
 

@@ -15,7 +15,7 @@ from . import hip_ops as ops
 
 
 class DanboEngine:
-    def __init__(self, cfg, params, align, buffers=None):
+    def __init__(self, cfg, params, align, buffers=None, mlp_mode="f16split"):
         """cfg: dict (see core/utils/synthetic.model_config); params: name -> CUDA tensor using the
         reference's state_dict names; align: [24,4,4] bone-align transforms."""
         self.cfg = cfg
@@ -26,6 +26,9 @@ class DanboEngine:
         self.mean_code = None
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
+        # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
+        assert mlp_mode in ("f16split", "fp32")
+        self.mlp_mode = mlp_mode
 
     # ------------------------------------------------------------------ derived buffers
     def _key(self):
@@ -33,13 +36,14 @@ class DanboEngine:
 
     def refresh(self):
         key = self._key()
-        if key == self._packed_key:
+        if key == self._packed_key and getattr(self, "_built_mode", None) == self.mlp_mode:
             return
         p = self.p
         dev = p["alpha_linear.weight"].device
         self.pts_w = [p[f"pts_linears.{i}.weight"] for i in range(8)]
         self.pts_b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(8)]
         self.packed, self.wrt = ops.mlp_pack(self.pts_w, p["feature_linear.weight"], p["views_linears.0.weight"])
+        self.packed16 = ops.mlp16_pack(self.pts_w, p["feature_linear.weight"], p["views_linears.0.weight"])
         self.alpha_w = p["alpha_linear.weight"].reshape(-1).contiguous()
         self.alpha_b = p["alpha_linear.bias"].contiguous()
         self.feature_b = p["feature_linear.bias"].contiguous()
@@ -69,10 +73,16 @@ class DanboEngine:
         # empty-space constants: one zero row through the MLP without the per-ray view term
         h0 = torch.zeros(1, ops.H_STRIDE, device=dev)
         scratch_raw = torch.empty(1, 4, device=dev)
-        aux = ops.pe_mlp(h0, 1, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, None,
-                         self.rgb_w, self.rgb_b, scratch_raw, aux=True)
-        self.empty_consts = aux.reshape(-1).contiguous()
+        self.empty_consts = self._mlp(h0, 1, None, scratch_raw, aux=True).reshape(-1).contiguous()
+        self._built_mode = self.mlp_mode
         self._packed_key = key
+
+    def _mlp(self, h, S, cview, raw, lst=None, cnt=None, n=None, aux=False):
+        if self.mlp_mode == "f16split":
+            return ops.pe_mlp16(h, S, self.packed16, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
+                                self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux)
+        return ops.pe_mlp(h, S, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
+                          self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux)
 
     # ------------------------------------------------------------------ network forward
     def volumes(self, bones):
@@ -86,7 +96,7 @@ class DanboEngine:
         normalise = 1 if cfg["view_type"] == "relray" else 0
         return ops.view_consts(rays_d, skts, ray_mode, normalise, cfg["multires_views"], self.framecodes,
                                self.mean_code, cam_idx, self.wrt, self.views_b, self.rgb_w, self.rgb_b,
-                               self.empty_consts)
+                               self.empty_consts, 1 if self.mlp_mode == "f16split" else 0)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
                         want_confd=False, volumes=None, view=None):
@@ -106,8 +116,7 @@ class DanboEngine:
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        ops.pe_mlp(h, S, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
-                   self.rgb_w, self.rgb_b, raw, lst, cnt, geo.M)
+        self._mlp(h, S, cview, raw, lst, cnt, geo.M)
         if self.profile is not None:
             e1.record()
             self.profile.setdefault("k_pe_mlp", []).append((e0, e1, cnt if cnt is not None else geo.M))

@@ -114,6 +114,25 @@ __device__ __forceinline__ float rgb_dot(const float* x /*LDS, 16-B aligned*/, c
     return acc + b;
 }
 
+// the same head in the summation order of k_pe_mlp16 (csrc/k_mlp16.hip): features are split
+// between the two lane halves h (n = 32T + 8j + 4h + i), each half accumulates in (T, j, i)
+// order, then (p0 + p1) + b.
+__device__ __forceinline__ float rgb_dot_halves(const float* x, const float* __restrict__ w, float b) {
+    float p[2] = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        for (int T = 0; T < 4; ++T)
+            for (int j = 0; j < 4; ++j) {
+                const int n = 32 * T + 8 * j + 4 * h;
+                const float4 xv = *reinterpret_cast<const float4*>(x + n);
+                p[h] = fmaf(xv.x, w[n], p[h]);
+                p[h] = fmaf(xv.y, w[n + 1], p[h]);
+                p[h] = fmaf(xv.z, w[n + 2], p[h]);
+                p[h] = fmaf(xv.w, w[n + 3], p[h]);
+            }
+    return (p[0] + p[1]) + b;
+}
+
 // ======================================================================================
 // per-ray view constants
 // ======================================================================================
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                                                      const float* __restrict__ wt /*[Cv][128]*/,
                                                      const float* __restrict__ views_b, const float* __restrict__ rgb_w,
                                                      const float* __restrict__ rgb_b,
-                                                     const float* __restrict__ empty_consts,
+                                                     const float* __restrict__ empty_consts, int rgb_order,
                                                      float* __restrict__ cview, float* __restrict__ raw_empty) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Cpe = 3 * (1 + 2 * L_view);
@@ -208,7 +227,10 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                 const int rl = tid >> 2, ch = tid & 3;
                 const int r = r0 + rl;
                 if (r < R) {
-                    const float val = ch < 3 ? rgb_dot(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch]) : empty_consts[MLP_VW];
+                    float val = empty_consts[MLP_VW];
+                    if (ch < 3)
+                        val = rgb_order ? rgb_dot_halves(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch])
+                                        : rgb_dot(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch]);
                     raw_empty[(size_t)r * 4 + ch] = val;
                 }
             }
@@ -462,8 +484,8 @@ extern "C" int danbo_mlp_pack(const float* const* pts_w, const float* feature_w,
 extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise,
                                   int L_view, const float* framecodes, int n_codes, int Cf, const float* mean_code,
                                   const int64_t* cam_idx, const float* views_w_ray_t, const float* views_b,
-                                  const float* rgb_w, const float* rgb_b, const float* empty_consts, float* cview,
-                                  float* raw_empty, void* stream) {
+                                  const float* rgb_w, const float* rgb_b, const float* empty_consts, int rgb_order,
+                                  float* cview, float* raw_empty, void* stream) {
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && L_view >= 0 && Cf >= 0);
     DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
     DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
@@ -477,7 +499,7 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
     const int grid = iters < NUM_CU ? iters : NUM_CU;
     hipLaunchKernelGGL(k_view_consts, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
                        normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
-                       rgb_b, empty_consts, cview, raw_empty);
+                       rgb_b, empty_consts, rgb_order, cview, raw_empty);
     DANBO_LAUNCH_RET();
 }
 

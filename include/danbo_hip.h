@@ -150,6 +150,7 @@ int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int 
                       const float* views_w_ray_t /*[Cv,128]*/, const float* views_b /*[128]*/,
                       const float* rgb_w /*[3,128]*/, const float* rgb_b /*[3]*/,
                       const float* empty_consts /*[129] or NULL*/,
+                      int rgb_order /*0: summation order of danbo_pe_mlp_fwd, 1: of danbo_pe_mlp16_fwd*/,
                       float* cview /*[R,128]*/, float* raw_empty /*[R,4] or NULL*/, void* stream);
 
 /* rows: h [n,16] (output of K2).  Row i belongs to sample id m = list ? list[i] : i and ray
@@ -162,6 +163,19 @@ int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32_t* count, 
                      const float* feature_b /*[256]*/, const float* cview /*[R,128] or NULL*/,
                      const float* rgb_w, const float* rgb_b,
                      float* raw_out /*[R*S,4]*/, float* aux_out, void* stream);
+
+/* K3, fast variant (csrc/k_mlp16.hip): same contract as danbo_pe_mlp_fwd, products evaluated as
+ * three fp16 MFMAs on hi/lo-split operands with fp32 accumulation (<= 2e-6 relative on the raw
+ * logits vs fp64 -- the accuracy class of an fp32 GEMM).  Weights are packed by danbo_mlp16_pack
+ * into DANBO_MLP16_PACKED_BYTES bytes of fp16 fragments. */
+#define DANBO_MLP16_PACKED_BYTES 2686976
+int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* views_w, int Cv,
+                     void* packed16, void* stream);
+int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
+                       const void* packed16, const float* const* pts_b,
+                       const float* alpha_w, const float* alpha_b, const float* feature_b,
+                       const float* cview, const float* rgb_w, const float* rgb_b,
+                       float* raw_out, float* aux_out, void* stream);
 
 /* raw[r,s,:] = raw_empty[r,:] (broadcast fill before K3 scatters the in-volume rows) */
 int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream);

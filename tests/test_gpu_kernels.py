@@ -177,6 +177,7 @@ def test_view_constants_and_empty_raw(ops, stage):
 
 
 def test_pe_mlp_on_golden_features(ops, stage):
+    """both MLP kernels (exact fp32 MFMA, fp16x2-split MFMA) on the oracle's blended features"""
     g, eng, ret = stage["g"], stage["eng"], stage["ret"]
     rb = g["ray_batch"]
     S = int(g["N_samples"])
@@ -187,10 +188,38 @@ def test_pe_mlp_on_golden_features(ops, stage):
     ops.pe_mlp(T(h), S, eng.packed, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w, eng.rgb_b, raw)
     assert rel_err(N(raw), g["raw_coarse"], floor=1.0) < 1e-4      # north_star tolerance vs the reference
     assert rel_err(N(raw), ret["raw_coarse"], floor=1.0) < 1e-4
+    raw16 = torch.zeros(len(rb), S, 4, device=DEV)
+    ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w,
+                 eng.rgb_b, raw16)
+    assert rel_err(N(raw16), g["raw_coarse"], floor=1.0) < 1e-4
+    assert rel_err(N(raw16), N(raw), floor=1.0) < 2e-5             # split products ~ fp32 round-off class
 
 
-def test_forward_dense_equals_culled_bitwise(stage):
+def test_pe_mlp16_random_rows_and_tails(ops, stage):
+    """row counts that are not multiples of the 128-row tile, compacted scatter, large |h|"""
+    eng = stage["eng"]
+    rng = np.random.default_rng(5)
+    for n in (1, 31, 129, 1000):
+        h = np.zeros((n, 16), np.float32)
+        h[:, :15] = rng.normal(0, 1.5, size=(n, 15))
+        S = 4
+        R = (n + S - 1) // S
+        cview = T(rng.normal(0, 0.3, size=(R, 128)))
+        lst = T(rng.permutation(R * S)[:n], torch.int32)
+        a = torch.zeros(R * S, 4, device=DEV)
+        b = torch.zeros(R * S, 4, device=DEV)
+        ops.pe_mlp(T(h), S, eng.packed, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w, eng.rgb_b,
+                   a, lst=lst)
+        ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w,
+                     eng.rgb_b, b, lst=lst)
+        assert rel_err(N(b), N(a), floor=1.0) < 2e-5, n
+        assert float(N(a).__abs__().max()) > 0.1
+
+
+@pytest.mark.parametrize("mode", ["f16split", "fp32"])
+def test_forward_dense_equals_culled_bitwise(stage, mode):
     g, eng = stage["g"], stage["eng"]
+    eng.mlp_mode = mode
     rb = g["ray_batch"]
     args = (T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cam_idx"], torch.int64))
     raw_c, ex = eng.forward_samples(*args, z=T(g["z_coarse"]), dense=False)
@@ -199,6 +228,7 @@ def test_forward_dense_equals_culled_bitwise(stage):
     assert rel_err(N(raw_c), g["raw_coarse"], floor=1.0) < 1e-4
     n = int(N(ex["count"])[0])
     assert 0 < n < raw_c.shape[0] * raw_c.shape[1]
+    eng.mlp_mode = "f16split"
 
 
 def test_composite(ops, stage):
