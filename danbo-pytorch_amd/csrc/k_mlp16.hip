@@ -143,23 +143,41 @@ __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
     return *reinterpret_cast<const half8*>(base + piece * 1024);
 }
 
-// acc[T] += W(k-step) * B for the two k-steps of one chunk, 8 output tiles; two tiles are
-// interleaved so that dependent MFMAs on one accumulator are two issue slots apart
-#define DANBO_MFMA3(ACC, AH, AL, BH, BL)                                      \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);
+// A fragments of one output-tile pair: (hi, lo) x 2 tiles = 4 ds_read_b128
+struct APair { half8 h0, l0, h1, l1; };
 
+__device__ __forceinline__ APair load_pair(const char* base, int piece0) {
+    APair a;
+    a.h0 = lds_frag(base, piece0);
+    a.l0 = lds_frag(base, piece0 + 1);
+    a.h1 = lds_frag(base, piece0 + 2);
+    a.l1 = lds_frag(base, piece0 + 3);
+    return a;
+}
+
+__device__ __forceinline__ void mfma_pair(f32x16& c0, f32x16& c1, const APair& a, const half8& bh, const half8& bl) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h0, bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h1, bh, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h0, bl, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h1, bl, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l0, bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l1, bh, c1, 0, 0, 0);
+}
+
+// acc[T] += W(k-step) * B for one k-step of a chunk, 8 output tiles.  Software-pipelined: the four
+// ds_read_b128 of the NEXT tile pair are issued before the six MFMAs of the current pair, so their
+// LDS latency hides under 192 cycles of matrix pipe (sched_barrier pins that order).
 __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[8], const char* base, int ks_local, const half8& bh,
                                            const half8& bl) {
+    APair cur = load_pair(base, ks_local * 16);
 #pragma unroll
     for (int T = 0; T < 8; T += 2) {
-        const half8 ah0 = lds_frag(base, ks_local * 16 + T * 2), al0 = lds_frag(base, ks_local * 16 + T * 2 + 1);
-        const half8 ah1 = lds_frag(base, ks_local * 16 + T * 2 + 2), al1 = lds_frag(base, ks_local * 16 + T * 2 + 3);
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, acc[T + 1], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, acc[T + 1], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, acc[T + 1], 0, 0, 0);
+        APair nxt = cur;
+        if (T + 2 < 8) nxt = load_pair(base, ks_local * 16 + (T + 2) * 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pair(acc[T], acc[T + 1], cur, bh, bl);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
 }
 
@@ -309,17 +327,12 @@ __global__ __launch_bounds__(256, 1) void k_pe_mlp16(Mlp16Args a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int s = 4 * c + ks;
-#pragma unroll
-                for (int T = 0; T < 4; T += 2) {
-                    const half8 ah0 = lds_frag(base, ks * 8 + T * 2), al0 = lds_frag(base, ks * 8 + T * 2 + 1);
-                    const half8 ah1 = lds_frag(base, ks * 8 + T * 2 + 2), al1 = lds_frag(base, ks * 8 + T * 2 + 3);
-                    accv[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[s], accv[T], 0, 0, 0);
-                    accv[T + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[s], accv[T + 1], 0, 0, 0);
-                    accv[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[s], accv[T], 0, 0, 0);
-                    accv[T + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[s], accv[T + 1], 0, 0, 0);
-                    accv[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[s], accv[T], 0, 0, 0);
-                    accv[T + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[s], accv[T + 1], 0, 0, 0);
-                }
+                APair cur = load_pair(base, ks * 8);
+                APair nxt = load_pair(base, ks * 8 + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_pair(accv[0], accv[1], cur, bh[s], bl[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_pair(accv[2], accv[3], nxt, bh[s], bl[s]);
             }
         }
         // ------------------------------------------------------------------ colour head + output

@@ -397,20 +397,102 @@ __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ ra
 }
 
 // ======================================================================================
-// importance sampling + merge: one thread per ray, rows of the outputs double as scratch
+// importance sampling + merge
 // ======================================================================================
+// General fallback (any S): one thread per ray, the sorted_idx row doubles as cdf scratch.
 __global__ __launch_bounds__(64) void k_importance(const float* __restrict__ z, const float* __restrict__ weights,
                                                    int R, int S, int Sf, const float* __restrict__ u,
                                                    float* __restrict__ z_fine, float* __restrict__ z_sorted,
                                                    int32_t* __restrict__ sorted_idx) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-        // cdf scratch: the tail of this ray's z_sorted row is free until the final merge, but the
-        // merge writes from the front; S-1 <= S+Sf so we use a private region at the back and the
-        // merge never reads cdf.  To stay safe with any S/Sf, cdf lives in sorted_idx's row
-        // (reinterpreted), which is only written by the merge after the cdf is dead.
         float* cdf = reinterpret_cast<float*>(sorted_idx + (size_t)r * (S + Sf));
-        importance_ray(z + (size_t)r * S, weights + (size_t)r * S, S, Sf, u ? u + (size_t)r * Sf : nullptr, cdf,
-                       z_fine + (size_t)r * Sf, z_sorted + (size_t)r * (S + Sf), sorted_idx + (size_t)r * (S + Sf));
+        const float* zr = z + (size_t)r * S;
+        float* zf = z_fine + (size_t)r * Sf;
+        float* zs = z_sorted + (size_t)r * (S + Sf);
+        int32_t* si = sorted_idx + (size_t)r * (S + Sf);
+        importance_ray(zr, weights + (size_t)r * S, S, Sf, u ? u + (size_t)r * Sf : nullptr, cdf, zf, zs, si);
+        if (u != nullptr) {
+            // random u: the new samples are not ordered -> merge by rank instead of two pointers
+            for (int i = 0; i < S; ++i) {
+                int rank = i;
+                for (int k = 0; k < Sf; ++k) rank += zf[k] < zr[i];
+                zs[rank] = zr[i];
+                si[rank] = i;
+            }
+            for (int k = 0; k < Sf; ++k) {
+                int rank = 0;
+                for (int i = 0; i < S; ++i) rank += zr[i] <= zf[k];
+                for (int q = 0; q < Sf; ++q) rank += (zf[q] < zf[k]) || (zf[q] == zf[k] && q < k);
+                zs[rank] = zf[k];
+                si[rank] = S + k;
+            }
+        }
+    }
+}
+
+// S <= 64 and Sf <= 64: one wavefront per ray.  Lane i holds coarse sample i (pdf bin, cdf by
+// shuffle scan); lane k additionally draws fine sample k (binary search in the cdf through
+// shuffles); the merged order comes from ranks counted with broadcast compares -- no sort,
+// no scratch memory, every global access coalesced.
+__global__ __launch_bounds__(256) void k_importance_wave(const float* __restrict__ z, const float* __restrict__ weights,
+                                                         int R, int S, int Sf, const float* __restrict__ u,
+                                                         float* __restrict__ z_fine, float* __restrict__ z_sorted,
+                                                         int32_t* __restrict__ sorted_idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nb = S - 2, ncdf = S - 1;
+    for (int r = wave; r < R; r += nwaves) {
+        const bool cact = lane < S;
+        const float zi = cact ? z[(size_t)r * S + lane] : INFINITY;
+        const float wi = cact ? weights[(size_t)r * S + lane] : 0.f;
+        const float w1 = __shfl_down(wi, 1, 64), w2 = __shfl_down(wi, 2, 64);
+        const float z1 = __shfl_down(zi, 1, 64);
+        float dw = 0.f;
+        if (lane < nb) dw = add_rn(add_rn(mul_rn(0.5f, add_rn(fmaxf(wi, w1), fmaxf(w1, w2))), 0.01f), 1e-5f);
+        const float sum = wave_sum(dw);
+        float inc = div_rn(dw, sum);  // pdf, then inclusive scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float q = __shfl_up(inc, off, 64);
+            if (lane >= off) inc = add_rn(inc, q);
+        }
+        float cdf = __shfl_up(inc, 1, 64);  // lane i: cdf[i], i in [0, ncdf)
+        if (lane == 0) cdf = 0.f;
+        const float bin = mul_rn(0.5f, add_rn(z1, zi));  // lane i: mid-point i (valid for i < S-1)
+        // ---- inverse CDF for fine sample `lane` ----
+        const bool fact = lane < Sf;
+        const float uk = u ? (fact ? u[(size_t)r * Sf + lane] : 0.f) : linspace01(fact ? lane : 0, Sf);
+        int lo = 0, hi = ncdf;  // searchsorted(cdf, u, right=True)
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const float cm = __shfl(cdf, mid < ncdf ? mid : ncdf - 1, 64);
+            if (lo < hi) {
+                if (cm > uk) hi = mid; else lo = mid + 1;
+            }
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < ncdf - 1 ? lo : ncdf - 1;
+        const float c0 = __shfl(cdf, below, 64), c1 = __shfl(cdf, above, 64);
+        const float b0 = __shfl(bin, below, 64), b1 = __shfl(bin, above, 64);
+        float denom = sub_rn(c1, c0);
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = div_rn(sub_rn(uk, c0), denom);
+        const float zf = fact ? add_rn(b0, mul_rn(t, sub_rn(b1, b0))) : INFINITY;
+        if (fact) z_fine[(size_t)r * Sf + lane] = zf;
+        // ---- merged order by rank (stable: coarse first on ties, fine by index) ----
+        int rank_c = lane, rank_f = lane;
+        for (int k = 0; k < Sf; ++k) {
+            const float zk = __shfl(zf, k, 64);
+            rank_c += zk < zi;
+            rank_f += (zk < zf) || (zk == zf && k < lane);
+        }
+        rank_f -= lane;  // the loop counted fine predecessors only; add coarse ones below
+        for (int i = 0; i < S; ++i) rank_f += __shfl(zi, i, 64) <= zf;
+        const size_t o = (size_t)r * (S + Sf);
+        if (cact) { z_sorted[o + rank_c] = zi; sorted_idx[o + rank_c] = lane; }
+        if (fact) { z_sorted[o + rank_f] = zf; sorted_idx[o + rank_f] = S + lane; }
     }
 }
 
@@ -515,7 +597,12 @@ extern "C" int danbo_composite_fwd(const float* raw, const float* z, const float
 extern "C" int danbo_importance_samples(const float* z, const float* weights, int R, int S, int Sf, const float* u,
                                          float* z_fine, float* z_sorted, int32_t* sorted_idx, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S >= 3 && Sf > 0);
-    hipLaunchKernelGGL(k_importance, dim3(stream_grid(R, 64)), dim3(64), 0, (hipStream_t)stream, z, weights, R, S, Sf, u,
-                       z_fine, z_sorted, sorted_idx);
+    if (S <= 64 && Sf <= 64) {
+        hipLaunchKernelGGL(k_importance_wave, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream, z,
+                           weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx);
+    } else {
+        hipLaunchKernelGGL(k_importance, dim3(stream_grid(R, 64)), dim3(64), 0, (hipStream_t)stream, z, weights, R, S, Sf,
+                           u, z_fine, z_sorted, sorted_idx);
+    }
     DANBO_LAUNCH_RET();
 }

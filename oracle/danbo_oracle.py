@@ -207,13 +207,13 @@ def sample_points(rays_o, rays_d, z):
     return (rays_o[:, None, :] + (rays_d[:, None, :] * z[:, :, None]).astype(F32)).astype(F32)
 
 
-def sample_pdf_det(bins, weights, n):
-    """sample_pdf(det=True), core/utils/ray_utils.py:159-203."""
+def sample_pdf_det(bins, weights, n, u=None):
+    """sample_pdf, core/utils/ray_utils.py:159-203 (det=True: u = linspace; else caller's uniforms)."""
     w = (weights + F32(1e-5)).astype(F32)
     pdf = (w / w.sum(-1, keepdims=True, dtype=F32)).astype(F32)
     cdf = np.cumsum(pdf, -1, dtype=F32)
     cdf = np.concatenate([np.zeros_like(cdf[:, :1]), cdf], -1)
-    u = np.broadcast_to(torch_linspace01(n), (cdf.shape[0], n))
+    u = np.broadcast_to(torch_linspace01(n), (cdf.shape[0], n)) if u is None else np.asarray(u, dtype=F32)
     inds = np.stack([np.searchsorted(cdf[r], u[r], side='right') for r in range(cdf.shape[0])])
     below = np.maximum(0, inds - 1)
     above = np.minimum(cdf.shape[-1] - 1, inds)
@@ -227,14 +227,14 @@ def sample_pdf_det(bins, weights, n):
     return (bg0 + t * (bg1 - bg0)).astype(F32)
 
 
-def importance_z(z, weights, n_importance, alpha_base=0.01):
+def importance_z(z, weights, n_importance, alpha_base=0.01, u=None):
     """isample_from_lineseg(det=True, is_only=True), core/utils/ray_utils.py:257-291.
 
     Returns sorted z [R,S+Sf], z_samples [R,Sf], sorted_idxs [R,S+Sf] (stable sort)."""
     mid = (F32(.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
     w_l, w_k, w_u = weights[:, 0:-2], weights[:, 1:-1], weights[:, 2:]
     dw = (F32(0.5) * (np.maximum(w_l, w_k) + np.maximum(w_k, w_u)) + F32(alpha_base)).astype(F32)
-    zs = sample_pdf_det(mid, dw, n_importance)
+    zs = sample_pdf_det(mid, dw, n_importance, u)
     cat = np.concatenate([z, zs], -1)
     idx = np.argsort(cat, -1, kind='stable')
     return np.take_along_axis(cat, idx, -1), zs, idx

@@ -270,6 +270,25 @@ def test_importance_samples_and_merge(ops, stage):
     assert np.array_equal(N(m), want)
 
 
+@pytest.mark.parametrize("S,Sf", [(48, 16), (32, 16), (96, 48), (7, 3)])
+def test_importance_random_uniforms_and_long_rays(ops, S, Sf):
+    """wave-per-ray kernel (S <= 64) and the per-thread fallback, deterministic and random u"""
+    rng = np.random.default_rng(S)
+    R = 200
+    z = np.sort(rng.uniform(2, 5, size=(R, S)).astype(np.float32), -1)
+    w = (rng.uniform(size=(R, S)) ** 4).astype(np.float32)
+    for u in (None, rng.uniform(size=(R, Sf)).astype(np.float32)):
+        zs, zf, idx = ops.importance_samples(T(z), T(w), Sf, None if u is None else T(u))
+        z_all, z_fine, order = o.importance_z(z, w, Sf, u=u)
+        # t = (u - c0) / (c1 - c0) is ill-conditioned for the tiny bins of this w ~ U^4 test data
+        assert max_err(N(zf), z_fine) < 1e-4
+        assert np.mean(np.abs(N(zf) - z_fine)) < 2e-6
+        cat = np.concatenate([z, N(zf)], -1)
+        assert np.array_equal(N(zs), np.sort(cat, -1))                      # a permutation, sorted
+        assert np.array_equal(np.take_along_axis(cat, N(idx).astype(np.int64), -1), N(zs))
+        assert np.array_equal(N(idx).astype(np.int64), np.argsort(cat, -1, kind="stable"))
+
+
 def test_render_stage_fixture_end_to_end(stage):
     g, eng = stage["g"], stage["eng"]
     rb = g["ray_batch"]
