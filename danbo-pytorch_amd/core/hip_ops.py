@@ -151,6 +151,25 @@ def gather_assign_blend(geo, volumes, bits, aw, lst=None, cnt=None, n=None, want
     return h, confd
 
 
+ASSIGN16_PACKED_BYTES = 262144
+
+
+def assign16_pack(aw):
+    """fp16 hi/lo fragments of the assignment GNN with the adjacency folded into layer 0."""
+    packed = torch.empty(ASSIGN16_PACKED_BYTES, device=aw["w0"].device, dtype=torch.uint8)
+    _call("danbo_assign16_pack", _p(aw["w0"]), _p(aw["adjw"]), _p(aw["w1"]), _p(packed), _stream())
+    return packed
+
+
+def gather_assign_blend16(geo, volumes, bits, aw, packed16, lst=None, cnt=None, n=None, want_confd=False):
+    n = geo.M if n is None else n
+    h = torch.empty(n, H_STRIDE, device=geo.device, dtype=torch.float32)
+    confd = torch.empty(n, J, device=geo.device, dtype=torch.float32) if want_confd else None
+    _call("danbo_gather_assign_blend16_fwd", *geo.head(), _p(volumes), _p(bits), _p(lst), _p(cnt), n, _p(packed16),
+          _p(aw["b0"]), _p(aw["b1"]), _p(aw["w2"]), _p(aw["b2"]), _p(h), _p(confd), _stream())
+    return h, confd
+
+
 def mlp_pack(pts_w, feature_w, views_w):
     """pts_w: 8 tensors; views_w [128, 256+Cv] -> (packed [659456], views_w_ray_t [Cv,128])."""
     dev = feature_w.device

@@ -64,6 +64,7 @@ class DanboEngine:
             b0=p[a + "0.bias"].contiguous(), w1=p[a + "1.weight"].contiguous(),
             b1=p[a + "1.bias"].reshape(24, -1).contiguous(), w2=p[a + "2.weight"].reshape(24, -1).contiguous(),
             b2=p[a + "2.bias"].reshape(-1).contiguous())
+        self.assign16 = ops.assign16_pack(self.aw)
         self.axis_scale = p["graph_net.axis_scale"].contiguous()
         if self.cfg["use_framecode"]:
             self.framecodes = p["framecodes.codes.weight"].contiguous()
@@ -111,7 +112,10 @@ class DanboEngine:
         cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
         S = geo.S
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense)
-        h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
+        if self.mlp_mode == "f16split":
+            h, confd = ops.gather_assign_blend16(geo, vols, bits, self.aw, self.assign16, lst, cnt, geo.M, want_confd)
+        else:
+            h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
         raw = ops.fill_raw(raw_empty, S)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

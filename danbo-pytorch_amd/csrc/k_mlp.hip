@@ -114,23 +114,22 @@ __device__ __forceinline__ float rgb_dot(const float* x /*LDS, 16-B aligned*/, c
     return acc + b;
 }
 
-// the same head in the summation order of k_pe_mlp16 (csrc/k_mlp16.hip): features are split
-// between the two lane halves h (n = 32T + 8j + 4h + i), each half accumulates in (T, j, i)
-// order, then (p0 + p1) + b.
+// the same head in the summation order of k_pe_mlp16 (csrc/k_mlp16.hip): a sample's 128 features are
+// split over four lane groups q (n = 16T + 4q + i), each group accumulates in (T, i) order, then
+// ((p0 + p1) + (p2 + p3)) + b  (the xor-16 / xor-32 butterfly).
 __device__ __forceinline__ float rgb_dot_halves(const float* x, const float* __restrict__ w, float b) {
-    float p[2] = {0.f, 0.f};
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-        for (int T = 0; T < 4; ++T)
-            for (int j = 0; j < 4; ++j) {
-                const int n = 32 * T + 8 * j + 4 * h;
-                const float4 xv = *reinterpret_cast<const float4*>(x + n);
-                p[h] = fmaf(xv.x, w[n], p[h]);
-                p[h] = fmaf(xv.y, w[n + 1], p[h]);
-                p[h] = fmaf(xv.z, w[n + 2], p[h]);
-                p[h] = fmaf(xv.w, w[n + 3], p[h]);
-            }
-    return (p[0] + p[1]) + b;
+    for (int q = 0; q < 4; ++q)
+        for (int T = 0; T < 8; ++T) {
+            const int n = 16 * T + 4 * q;
+            const float4 xv = *reinterpret_cast<const float4*>(x + n);
+            p[q] = fmaf(xv.x, w[n], p[q]);
+            p[q] = fmaf(xv.y, w[n + 1], p[q]);
+            p[q] = fmaf(xv.z, w[n + 2], p[q]);
+            p[q] = fmaf(xv.w, w[n + 3], p[q]);
+        }
+    return ((p[0] + p[1]) + (p[2] + p[3])) + b;
 }
 
 // ======================================================================================

@@ -3,37 +3,39 @@
 //
 // Numerics: every fp32 operand x is split as x = hi + lo with hi = fp16(x), lo = fp16(x - hi)
 // (22 significant bits together) and a product is evaluated as hi*hi + hi*lo + lo*hi on
-// v_mfma_f32_32x32x16_f16 with fp32 accumulation -- the dropped lo*lo term is 2^-22 relative.
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation -- the dropped lo*lo term is 2^-22 relative.
 // Measured against fp64 on this network: max 2e-6 relative on the raw logits, the same class as
 // a plain fp32 GEMM (1e-6) and 50x inside the 1e-4 bound of the north-star.  Three half
 // MFMAs replace sixteen-times-slower fp32 MFMAs: 5.3x the matrix rate of k_pe_mlp.
 //
 // Dataflow (transposed chain, activations never leave registers):
 //   out^T [features x samples] = W [features x k] * act^T [k x samples]
-//   A operand = weights (shared by every wavefront -> staged once per workgroup through a 3-slot
-//               32 KB LDS ring filled by global_load_lds, pre-packed in fragment order),
-//   B operand = this wavefront's 32 samples (lane = sample + 32*half),
-//   D tile T  : lane (m, h) holds features 32T + 8j + 4h + i  (reg = 4j + i) of sample m,
-//   which is exactly the B fragment layout of the next layer when its k-steps are ordered
-//   k-step s = (T = s>>1, j in {2(s&1), 2(s&1)+1}) -- the pack kernel permutes the weight columns
-//   accordingly, so bias + ReLU + hi/lo split happen in registers and feed the next GEMM.
-// One workgroup = 4 wavefronts (1 per SIMD) x 32 samples; persistent over 128-row tiles.
+//   A operand = weights, shared by every wavefront: streamed once per workgroup through a 3-slot
+//               32 KB LDS ring filled by global_load_lds, pre-packed in fragment order;
+//   B operand = this wavefront's 16 samples: lane = sample m + 16*q, k-slots 8q..8q+7;
+//   D tile T  : lane (m, q) holds features 16T + 4q + i (i = reg 0..3) of sample m -- exactly the
+//   B-fragment layout of the next layer once its k-step s is defined to cover tiles 2s and 2s+1
+//   (the pack kernel permutes the weight columns accordingly), so bias + ReLU + hi/lo split stay
+//   in registers and feed the next GEMM.
+// One workgroup = 8 wavefronts x 16 samples = 128 rows, TWO wavefronts per SIMD (<= 256 VGPRs
+// each): while one wavefront waits on the weight ring, LDS or its epilogue VALU work, the other
+// keeps the matrix pipe busy (a one-wavefront-per-SIMD version spent half its time stalled).
 #include "common.hpp"
 
 namespace danbo {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int M16_BM = 128;            // rows per workgroup iteration
 constexpr int CHUNK_BYTES = 32768;     // 32 fragment pieces of 1 KB
 constexpr int RING_SLOTS = 3;
-constexpr int NCH_X0 = 7;              // 13 k-steps of 16 PE features (+1 zero step)
-constexpr int NCH_ACT = 8;             // 16 k-steps = 8 source tiles
-constexpr int NCH_VIEW = 4;            // 16 k-steps, 4 output tiles -> 4 k-steps per chunk
+constexpr int NCH_X0 = 7;              // 7 k-steps of 32 PE features (208 >= 195)
+constexpr int NCH_ACT = 8;             // 8 k-steps of 32 features
+constexpr int NCH_VIEW = 4;            // 8 k-steps, 8 output tiles -> 2 k-steps per chunk
 constexpr int NCH_TOTAL = NCH_X0 + 4 * NCH_ACT + (NCH_X0 + NCH_ACT) + 2 * NCH_ACT + NCH_ACT + NCH_VIEW;  // 82
 static_assert(NCH_TOTAL * CHUNK_BYTES == DANBO_MLP16_PACKED_BYTES, "header constant out of date");
-constexpr int X0_KSTEPS = 13;
+constexpr int X0_KSTEPS = 7;
 constexpr int IN_CH = 195, W_ = 256, VW_ = 128;
 
 // ---------------------------------------------------------------------------------------------
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k_mlp16_pack(Pack16Args a, _Float16* __re
         const int chunk = (int)(idx / (CHUNK_BYTES / 2));
         const int within = (int)(idx % (CHUNK_BYTES / 2));
         const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
-        const int h = lane >> 5;
+        const int q = lane >> 4;
         // which GEMM / which part does this chunk belong to
         int layer, cl, kind;  // kind 0: x0 part, 1: act part, 2: view layer
         if (chunk < 7) { layer = 0; cl = chunk; kind = 0; }
@@ -63,19 +65,19 @@ __global__ __launch_bounds__(256) void k_mlp16_pack(Pack16Args a, _Float16* __re
         else if (chunk < 78) { layer = 8; cl = chunk - 70; kind = 1; }
         else { layer = 9; cl = chunk - 78; kind = 2; }
         int s, T, hl;
-        if (kind == 2) { s = 4 * cl + (piece >> 3); T = (piece >> 1) & 3; hl = piece & 1; }
-        else { s = 2 * cl + (piece >> 4); T = (piece >> 1) & 7; hl = piece & 1; }
-        const int n = 32 * T + (lane & 31);
+        if (kind == 2) { s = 2 * cl + (piece >> 4); T = (piece >> 1) & 7; hl = piece & 1; }
+        else { s = cl; T = piece >> 1; hl = piece & 1; }
+        const int n = 16 * T + (lane & 15);
         float w = 0.f;
         if (kind == 0) {
             const int j = 8 * s + e;
-            const int c = j / 13, t = j % 13, kk = h + 2 * c;
-            if (j < 8 * X0_KSTEPS && kk < FEAT) {
+            const int c = j / 13, t = j % 13, kk = q + 4 * c;
+            if (j < 52 && kk < FEAT) {
                 const int col = FEAT * t + kk;  // [x | sin 2^0 | cos 2^0 | ...] blocks of 15
                 w = layer == 0 ? a.pts_w[0][(size_t)n * IN_CH + col] : a.pts_w[5][(size_t)n * (IN_CH + W_) + col];
             }
         } else {
-            const int f = 32 * (s >> 1) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * h + (e & 3);
+            const int f = 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3);
             if (layer == 5) w = a.pts_w[5][(size_t)n * (IN_CH + W_) + IN_CH + f];
             else if (layer <= 7) w = a.pts_w[layer][(size_t)n * W_ + f];
             else if (layer == 8) w = a.feature_w[(size_t)n * W_ + f];
@@ -107,6 +109,7 @@ struct Mlp16Args {
     float* aux_out;
 };
 
+constexpr int M16_THREADS = 512;
 constexpr int M16_TABLE_FLOATS = 9 * W_ + W_ + 3 * VW_ + 4;
 constexpr int M16_LDS_BYTES = RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4;
 
@@ -116,21 +119,22 @@ struct Pipe {
     int issue_chunk, issue_slot, cons_slot, wave, lane;
 };
 
+// every wavefront loads 4 of the 32 pieces of a chunk
 __device__ __forceinline__ void pipe_issue(Pipe& p) {
-    const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192 + p.lane * 16;
-    char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192;
+    const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 4096 + p.lane * 16;
+    char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 4096;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < 4; ++q)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
     p.issue_chunk = p.issue_chunk + 1 == NCH_TOTAL ? 0 : p.issue_chunk + 1;
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
 }
 
-// start of a chunk: my share of it has landed (<= 8 younger loads outstanding), then everybody's
+// start of a chunk: my share of it has landed (<= 4 younger loads outstanding), then everybody's
 // has (barrier) and everybody is done with the slot we are about to refill
 __device__ __forceinline__ const char* pipe_begin(Pipe& p) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     pipe_issue(p);
@@ -143,41 +147,20 @@ __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
     return *reinterpret_cast<const half8*>(base + piece * 1024);
 }
 
-// A fragments of one output-tile pair: (hi, lo) x 2 tiles = 4 ds_read_b128
-struct APair { half8 h0, l0, h1, l1; };
-
-__device__ __forceinline__ APair load_pair(const char* base, int piece0) {
-    APair a;
-    a.h0 = lds_frag(base, piece0);
-    a.l0 = lds_frag(base, piece0 + 1);
-    a.h1 = lds_frag(base, piece0 + 2);
-    a.l1 = lds_frag(base, piece0 + 3);
-    return a;
-}
-
-__device__ __forceinline__ void mfma_pair(f32x16& c0, f32x16& c1, const APair& a, const half8& bh, const half8& bl) {
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h0, bh, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h1, bh, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h0, bl, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h1, bl, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l0, bh, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l1, bh, c1, 0, 0, 0);
-}
-
-// acc[T] += W(k-step) * B for one k-step of a chunk, 8 output tiles.  Software-pipelined: the four
-// ds_read_b128 of the NEXT tile pair are issued before the six MFMAs of the current pair, so their
-// LDS latency hides under 192 cycles of matrix pipe (sched_barrier pins that order).
-__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[8], const char* base, int ks_local, const half8& bh,
-                                           const half8& bl) {
-    APair cur = load_pair(base, ks_local * 16);
+// acc[T] += W(k-step, tile T) * B for NT output tiles; pieces [p0 + 2T, p0 + 2T + 1] = (hi, lo).
+// Two tiles are interleaved so dependent MFMAs on one accumulator are two issue slots apart.
+template <int NT>
+__device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[NT], const char* base, int p0, const half8& bh, const half8& bl) {
 #pragma unroll
-    for (int T = 0; T < 8; T += 2) {
-        APair nxt = cur;
-        if (T + 2 < 8) nxt = load_pair(base, ks_local * 16 + (T + 2) * 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_pair(acc[T], acc[T + 1], cur, bh, bl);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
+    for (int T = 0; T < NT; T += 2) {
+        const half8 ah0 = lds_frag(base, p0 + 2 * T), al0 = lds_frag(base, p0 + 2 * T + 1);
+        const half8 ah1 = lds_frag(base, p0 + 2 * T + 2), al1 = lds_frag(base, p0 + 2 * T + 3);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc[T + 1], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc[T + 1], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc[T + 1], 0, 0, 0);
     }
 }
 
@@ -190,7 +173,14 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_pe_mlp16(Mlp16Args a) {
+// sum of the four lane-group partials of a sample; identical in all four groups
+__device__ __forceinline__ float quad_sum(float p) {
+    p += __shfl_xor(p, 16, 64);
+    p += __shfl_xor(p, 32, 64);
+    return p;
+}
+
+__global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);  // [9][256]
     float* s_aw = s_bias + 9 * W_;                                              // [256]
@@ -198,11 +188,10 @@ __global__ __launch_bounds__(256, 1) void k_pe_mlp16(Mlp16Args a) {
     float* s_misc = s_rgbw + 3 * VW_;                                           // alpha_b, rgb_b[3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 31, hh = lane >> 5;
-    for (int i = tid; i < 8 * W_; i += 256) s_bias[i] = a.pts_b[i >> 8][i & 255];
-    s_bias[8 * W_ + tid] = a.feature_b[tid];
-    s_aw[tid] = a.alpha_w[tid];
-    for (int i = tid; i < 3 * VW_; i += 256) s_rgbw[i] = a.rgb_w[i];
+    const int m = lane & 15, qq = lane >> 4;
+    for (int i = tid; i < 8 * W_; i += M16_THREADS) s_bias[i] = a.pts_b[i >> 8][i & 255];
+    if (tid < W_) { s_bias[8 * W_ + tid] = a.feature_b[tid]; s_aw[tid] = a.alpha_w[tid]; }
+    for (int i = tid; i < 3 * VW_; i += M16_THREADS) s_rgbw[i] = a.rgb_w[i];
     if (tid < 4) s_misc[tid] = tid == 0 ? a.alpha_b[0] : a.rgb_b[tid - 1];
     __syncthreads();
 
@@ -217,33 +206,31 @@ __global__ __launch_bounds__(256, 1) void k_pe_mlp16(Mlp16Args a) {
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ------------------------------------------------------------------ inputs
-        const int row = tile * M16_BM + wave * 32 + m;
+        const int row = tile * M16_BM + wave * 16 + m;
         const bool row_ok = row < n;
         int dst = -1;
         float4 hq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < 4; ++c) hq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row_ok) {
             const float4* hp = reinterpret_cast<const float4*>(a.h + (size_t)row * DANBO_H_STRIDE);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hq[q] = hp[q];
+            for (int c = 0; c < 4; ++c) hq[c] = hp[c];
             dst = a.list ? a.list[row] : row;
         }
         const int ray = dst >= 0 ? dst / a.S : 0;
-        // this lane's 8 channels: kk = hh + 2c
-        float hv[8];
+        // this lane's 4 channels: kk = qq + 4c  (kk = 15 is padding)
+        float hv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            hv[2 * q] = hh ? hq[q].y : hq[q].x;
-            hv[2 * q + 1] = hh ? hq[q].w : hq[q].z;
-        }
-        if (hh) hv[7] = 0.f;  // channel 15 is padding
+        for (int c = 0; c < 4; ++c)
+            hv[c] = qq == 0 ? hq[c].x : (qq == 1 ? hq[c].y : (qq == 2 ? hq[c].z : hq[c].w));
+        if (qq == 3) hv[3] = 0.f;
         // ------------------------------------------------------------------ X0 = PE(h) fragments
         half8 xh[X0_KSTEPS], xl[X0_KSTEPS];
         {
             float xv[8 * X0_KSTEPS];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < 4; ++c) {
                 const float x = hv[c];
                 xv[13 * c] = x;
 #pragma unroll
@@ -255,115 +242,100 @@ __global__ __launch_bounds__(256, 1) void k_pe_mlp16(Mlp16Args a) {
                 }
             }
 #pragma unroll
+            for (int j = 52; j < 8 * X0_KSTEPS; ++j) xv[j] = 0.f;
+#pragma unroll
             for (int s = 0; s < X0_KSTEPS; ++s) split8(xv + 8 * s, xh[s], xl[s]);
         }
 
-        half8 bh[16], bl[16];
+        half8 bh[8], bl[8];
         float alpha_part = 0.f;
-        f32x16 acc[8];
+        f32x4 acc[16];
 #pragma unroll 1
         for (int step = 0; step < 9; ++step) {
 #pragma unroll
-            for (int T = 0; T < 8; ++T)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[T][r] = 0.f;
-            if (step == 0 || step == 5) {  // input / skip connection: 13 k-steps of PE features
+            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (step == 0 || step == 5) {  // input / skip connection: 7 k-steps of PE features
 #pragma unroll
                 for (int c = 0; c < NCH_X0; ++c) {
                     const char* base = pipe_begin(p);
-                    chunk_mfma(acc, base, 0, xh[2 * c], xl[2 * c]);
-                    if (2 * c + 1 < X0_KSTEPS) chunk_mfma(acc, base, 1, xh[2 * c + 1], xl[2 * c + 1]);
+                    kstep_mfma<16>(acc, base, 0, xh[c], xl[c]);
                 }
             }
             if (step != 0) {
 #pragma unroll
                 for (int c = 0; c < NCH_ACT; ++c) {
                     const char* base = pipe_begin(p);
-                    chunk_mfma(acc, base, 0, bh[2 * c], bl[2 * c]);
-                    chunk_mfma(acc, base, 1, bh[2 * c + 1], bl[2 * c + 1]);
+                    kstep_mfma<16>(acc, base, 0, bh[c], bl[c]);
                 }
             }
             // ---- epilogue: bias (+ReLU), density-logit partial, re-split into the next B fragments
-            const float* bias = s_bias + step * W_ + 4 * hh;
-            const float* aw = s_aw + 4 * hh;
+            const float* bias = s_bias + step * W_ + 4 * qq;
+            const float* aw = s_aw + 4 * qq;
 #pragma unroll
-            for (int T = 0; T < 8; ++T) {
-                float v[16];
+            for (int s = 0; s < 8; ++s) {
+                float v[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 b = *reinterpret_cast<const float4*>(bias + 32 * T + 8 * j);
-                    v[4 * j + 0] = acc[T][4 * j + 0] + b.x;
-                    v[4 * j + 1] = acc[T][4 * j + 1] + b.y;
-                    v[4 * j + 2] = acc[T][4 * j + 2] + b.z;
-                    v[4 * j + 3] = acc[T][4 * j + 3] + b.w;
+                for (int t = 0; t < 2; ++t) {
+                    const int T = 2 * s + t;
+                    const float4 b = *reinterpret_cast<const float4*>(bias + 16 * T);
+                    v[4 * t + 0] = acc[T][0] + b.x;
+                    v[4 * t + 1] = acc[T][1] + b.y;
+                    v[4 * t + 2] = acc[T][2] + b.z;
+                    v[4 * t + 3] = acc[T][3] + b.w;
                 }
                 if (step < 8) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (step == 7) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 w = *reinterpret_cast<const float4*>(aw + 32 * T + 8 * j);
-                        alpha_part = fmaf(v[4 * j + 0], w.x, alpha_part);
-                        alpha_part = fmaf(v[4 * j + 1], w.y, alpha_part);
-                        alpha_part = fmaf(v[4 * j + 2], w.z, alpha_part);
-                        alpha_part = fmaf(v[4 * j + 3], w.w, alpha_part);
+                    for (int t = 0; t < 2; ++t) {
+                        const float4 w = *reinterpret_cast<const float4*>(aw + 16 * (2 * s + t));
+                        alpha_part = fmaf(v[4 * t + 0], w.x, alpha_part);
+                        alpha_part = fmaf(v[4 * t + 1], w.y, alpha_part);
+                        alpha_part = fmaf(v[4 * t + 2], w.z, alpha_part);
+                        alpha_part = fmaf(v[4 * t + 3], w.w, alpha_part);
                     }
                 }
-                split8(v, bh[2 * T], bl[2 * T]);
-                split8(v + 8, bh[2 * T + 1], bl[2 * T + 1]);
+                split8(v, bh[s], bl[s]);
             }
         }
         // ------------------------------------------------------------------ view layer (128 outputs)
-        f32x16 accv[4];
+        f32x4 accv[8];
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accv[T][r] = 0.f;
+        for (int T = 0; T < 8; ++T) accv[T] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NCH_VIEW; ++c) {
             const char* base = pipe_begin(p);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int s = 4 * c + ks;
-                APair cur = load_pair(base, ks * 8);
-                APair nxt = load_pair(base, ks * 8 + 4);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_pair(accv[0], accv[1], cur, bh[s], bl[s]);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_pair(accv[2], accv[3], nxt, bh[s], bl[s]);
-            }
+            kstep_mfma<8>(accv, base, 0, bh[2 * c], bl[2 * c]);
+            kstep_mfma<8>(accv, base, 16, bh[2 * c + 1], bl[2 * c + 1]);
         }
         // ------------------------------------------------------------------ colour head + output
         float pr = 0.f, pg = 0.f, pb = 0.f;
-        const float* cv = a.cview ? a.cview + (size_t)ray * VW_ + 4 * hh : nullptr;
-        float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (VW_ + 1) + 4 * hh : nullptr;
+        const float* cv = a.cview ? a.cview + (size_t)ray * VW_ + 4 * qq : nullptr;
+        float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (VW_ + 1) + 4 * qq : nullptr;
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nn = 32 * T + 8 * j;  // + 4*hh + i
-                float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cv) c4 = *reinterpret_cast<const float4*>(cv + nn);
-                const float pre[4] = {accv[T][4 * j], accv[T][4 * j + 1], accv[T][4 * j + 2], accv[T][4 * j + 3]};
-                if (aux) *reinterpret_cast<float4*>(aux + nn) = make_float4(pre[0], pre[1], pre[2], pre[3]);
-                const float x[4] = {fmaxf(pre[0] + c4.x, 0.f), fmaxf(pre[1] + c4.y, 0.f), fmaxf(pre[2] + c4.z, 0.f),
-                                    fmaxf(pre[3] + c4.w, 0.f)};
-                const float4 wr = *reinterpret_cast<const float4*>(s_rgbw + 0 * VW_ + nn + 4 * hh);
-                const float4 wg = *reinterpret_cast<const float4*>(s_rgbw + 1 * VW_ + nn + 4 * hh);
-                const float4 wb = *reinterpret_cast<const float4*>(s_rgbw + 2 * VW_ + nn + 4 * hh);
-                pr = fmaf(x[0], wr.x, pr); pr = fmaf(x[1], wr.y, pr); pr = fmaf(x[2], wr.z, pr); pr = fmaf(x[3], wr.w, pr);
-                pg = fmaf(x[0], wg.x, pg); pg = fmaf(x[1], wg.y, pg); pg = fmaf(x[2], wg.z, pg); pg = fmaf(x[3], wg.w, pg);
-                pb = fmaf(x[0], wb.x, pb); pb = fmaf(x[1], wb.y, pb); pb = fmaf(x[2], wb.z, pb); pb = fmaf(x[3], wb.w, pb);
-            }
+        for (int T = 0; T < 8; ++T) {
+            const int nn = 16 * T;  // + 4*qq + i
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cv) c4 = *reinterpret_cast<const float4*>(cv + nn);
+            const float pre[4] = {accv[T][0], accv[T][1], accv[T][2], accv[T][3]};
+            if (aux) *reinterpret_cast<float4*>(aux + nn) = make_float4(pre[0], pre[1], pre[2], pre[3]);
+            const float x[4] = {fmaxf(pre[0] + c4.x, 0.f), fmaxf(pre[1] + c4.y, 0.f), fmaxf(pre[2] + c4.z, 0.f),
+                                fmaxf(pre[3] + c4.w, 0.f)};
+            const float4 wr = *reinterpret_cast<const float4*>(s_rgbw + 0 * VW_ + nn + 4 * qq);
+            const float4 wg = *reinterpret_cast<const float4*>(s_rgbw + 1 * VW_ + nn + 4 * qq);
+            const float4 wb = *reinterpret_cast<const float4*>(s_rgbw + 2 * VW_ + nn + 4 * qq);
+            pr = fmaf(x[0], wr.x, pr); pr = fmaf(x[1], wr.y, pr); pr = fmaf(x[2], wr.z, pr); pr = fmaf(x[3], wr.w, pr);
+            pg = fmaf(x[0], wg.x, pg); pg = fmaf(x[1], wg.y, pg); pg = fmaf(x[2], wg.z, pg); pg = fmaf(x[3], wg.w, pg);
+            pb = fmaf(x[0], wb.x, pb); pb = fmaf(x[1], wb.y, pb); pb = fmaf(x[2], wb.z, pb); pb = fmaf(x[3], wb.w, pb);
         }
-        // combine the two lane halves (each holds half of a sample's features)
-        const float r_ = (pr + __shfl_xor(pr, 32, 64)) + s_misc[1];
-        const float g_ = (pg + __shfl_xor(pg, 32, 64)) + s_misc[2];
-        const float b_ = (pb + __shfl_xor(pb, 32, 64)) + s_misc[3];
-        const float al = (alpha_part + __shfl_xor(alpha_part, 32, 64)) + s_misc[0];
-        if (hh == 0 && dst >= 0) {
+        // combine the four lane groups (each holds a quarter of a sample's features)
+        const float r_ = quad_sum(pr) + s_misc[1];
+        const float g_ = quad_sum(pg) + s_misc[2];
+        const float b_ = quad_sum(pb) + s_misc[3];
+        const float al = quad_sum(alpha_part) + s_misc[0];
+        if (qq == 0 && dst >= 0) {
             reinterpret_cast<float4*>(a.raw_out)[dst] = make_float4(r_, g_, b_, al);
             if (a.aux_out) a.aux_out[(size_t)row * (VW_ + 1) + VW_] = al;
         }
@@ -409,6 +381,6 @@ extern "C" int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int
     }
     const int ntiles = ceil_div(n, M16_BM);
     const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
-    hipLaunchKernelGGL(k_pe_mlp16, dim3(grid), dim3(256), M16_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_pe_mlp16, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

@@ -124,6 +124,19 @@ int danbo_gather_assign_blend_fwd(const float* rays_o, const float* rays_d, cons
                                   const float* w1, const float* b1, const float* w2, const float* b2,
                                   float* h, float* confd, void* stream);
 
+/* K1b + K2, fast variant (csrc/k_assign16.hip): same contract as danbo_gather_assign_blend_fwd with the
+ * two per-bone GEMMs on fp16 hi/lo-split MFMAs (fp32 accumulate) and the skeleton adjacency folded
+ * into the layer-0 weights by danbo_assign16_pack (w0 [24,15,32], adjw [24,24], w1 [24,32,32]). */
+#define DANBO_ASSIGN16_PACKED_BYTES 262144
+int danbo_assign16_pack(const float* w0, const float* adjw, const float* w1, void* packed16, void* stream);
+int danbo_gather_assign_blend16_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts,
+                                    int R, int S, int G, const float* skts, const float* align,
+                                    const float* axis_scale, const float* volumes,
+                                    const uint32_t* valid_bits, const int32_t* list, const int32_t* count, int n,
+                                    const void* packed16, const float* b0, const float* b1 /*[24,32]*/,
+                                    const float* w2 /*[24,32]*/, const float* b2 /*[24]*/,
+                                    float* h, float* confd, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * K3  voxel-feature PE + density/colour MLP on fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * Embedder (core/cutoff_embedder.py:62-73), NeRF.inference / forward_density /

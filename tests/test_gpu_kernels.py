@@ -161,6 +161,16 @@ def test_assign_blend_unfused_and_fused(ops, stage):
     h2, confd2 = ops.gather_assign_blend(geo, T(g["volumes"]), bits, eng.aw, want_confd=True)
     assert max_err(N(h2)[:, :15], h_ref) < 5e-6
     assert max_err(N(confd2).reshape(g["confd"].shape), g["confd"]) < 2e-5
+    # fast variant: fp16 hi/lo split MFMA, adjacency folded into the layer-0 weights
+    h3, confd3 = ops.gather_assign_blend16(geo, T(g["volumes"]), bits, eng.aw, eng.assign16, want_confd=True)
+    assert max_err(N(h3)[:, :15], h_ref) < 5e-6
+    assert float(N(h3)[:, 15].max()) == 0.0
+    assert max_err(N(confd3).reshape(g["confd"].shape), g["confd"]) < 2e-5
+    # compacted rows, tail tile
+    _, lst, cnt = ops.bone_cull(geo, compact=True)
+    n = int(N(cnt)[0])
+    h4, _ = ops.gather_assign_blend16(geo, T(g["volumes"]), bits, eng.aw, eng.assign16, lst, cnt, geo.M)
+    assert max_err(N(h4)[:n, :15], h_ref[N(lst)[:n]]) < 5e-6
 
 
 def test_view_constants_and_empty_raw(ops, stage):
