@@ -10,7 +10,7 @@
 //
 // Dataflow (transposed chain, activations never leave registers):
 //   out^T [features x samples] = W [features x k] * act^T [k x samples]
-//   A operand = weights, shared by every wavefront: streamed once per workgroup through a 3-slot
+//   A operand = weights, shared by every wavefront: streamed once per workgroup through a 4-slot
 //               32 KB LDS ring filled by global_load_lds, pre-packed in fragment order;
 //   B operand = this wavefront's 16 samples: lane = sample m + 16*q, k-slots 8q..8q+7;
 //   D tile T  : lane (m, q) holds features 16T + 4q + i (i = reg 0..3) of sample m -- exactly the
@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int M16_BM = 128;            // rows per workgroup iteration
 constexpr int CHUNK_BYTES = 32768;     // 32 fragment pieces of 1 KB
-constexpr int RING_SLOTS = 3;
+constexpr int RING_SLOTS = 4;
 constexpr int NCH_X0 = 7;              // 7 k-steps of 32 PE features (208 >= 195)
 constexpr int NCH_ACT = 8;             // 8 k-steps of 32 features
 constexpr int NCH_VIEW = 4;            // 8 k-steps, 8 output tiles -> 2 k-steps per chunk
@@ -131,10 +131,10 @@ __device__ __forceinline__ void pipe_issue(Pipe& p) {
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
 }
 
-// start of a chunk: my share of it has landed (<= 4 younger loads outstanding), then everybody's
+// start of a chunk: my share of it has landed (<= 8 younger loads = 2 chunks outstanding), then everybody's
 // has (barrier) and everybody is done with the slot we are about to refill
 __device__ __forceinline__ const char* pipe_begin(Pipe& p) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     pipe_issue(p);
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
 
     Pipe p;
     p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave; p.lane = lane;
+    pipe_issue(p);
     pipe_issue(p);
     pipe_issue(p);
 
