@@ -43,7 +43,9 @@ class DanboEngine:
         self.pts_w = [p[f"pts_linears.{i}.weight"] for i in range(8)]
         self.pts_b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(8)]
         self.packed, self.wrt = ops.mlp_pack(self.pts_w, p["feature_linear.weight"], p["views_linears.0.weight"])
-        self.packed16 = ops.mlp16_pack(self.pts_w, p["feature_linear.weight"], p["views_linears.0.weight"])
+        self.packed16, self.views_b16 = ops.mlp16_pack(self.pts_w, p["feature_linear.weight"],
+                                                       p["feature_linear.bias"], p["views_linears.0.weight"],
+                                                       p["views_linears.0.bias"])
         self.alpha_w = p["alpha_linear.weight"].reshape(-1).contiguous()
         self.alpha_b = p["alpha_linear.bias"].contiguous()
         self.feature_b = p["feature_linear.bias"].contiguous()
@@ -80,7 +82,7 @@ class DanboEngine:
 
     def _mlp(self, h, S, cview, raw, lst=None, cnt=None, n=None, aux=False):
         if self.mlp_mode == "f16split":
-            return ops.pe_mlp16(h, S, self.packed16, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
+            return ops.pe_mlp16(h, S, self.packed16, self.pts_b, self.alpha_w, self.alpha_b, cview,
                                 self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux)
         return ops.pe_mlp(h, S, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
                           self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux)
@@ -96,8 +98,9 @@ class DanboEngine:
         ray_mode = {"world": 0, "root_local": 1}[cfg["ray_tr_type"]]
         normalise = 1 if cfg["view_type"] == "relray" else 0
         return ops.view_consts(rays_d, skts, ray_mode, normalise, cfg["multires_views"], self.framecodes,
-                               self.mean_code, cam_idx, self.wrt, self.views_b, self.rgb_w, self.rgb_b,
-                               self.empty_consts, 1 if self.mlp_mode == "f16split" else 0)
+                               self.mean_code, cam_idx, self.wrt,
+                               self.views_b16 if self.mlp_mode == "f16split" else self.views_b, self.rgb_w,
+                               self.rgb_b, self.empty_consts, 1 if self.mlp_mode == "f16split" else 0)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
                         want_confd=False, volumes=None, view=None):

@@ -179,14 +179,18 @@ int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32_t* count, 
 
 /* K3, fast variant (csrc/k_mlp16.hip): same contract as danbo_pe_mlp_fwd, products evaluated as
  * three fp16 MFMAs on hi/lo-split operands with fp32 accumulation (<= 2e-6 relative on the raw
- * logits vs fp64 -- the accuracy class of an fp32 GEMM).  Weights are packed by danbo_mlp16_pack
- * into DANBO_MLP16_PACKED_BYTES bytes of fp16 fragments. */
-#define DANBO_MLP16_PACKED_BYTES 2686976
-int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* views_w, int Cv,
-                     void* packed16, void* stream);
+ * logits vs fp64 -- the accuracy class of an fp32 GEMM).  danbo_mlp16_pack writes
+ * DANBO_MLP16_PACKED_BYTES bytes of fp16 fragments; it also merges feature_linear with the
+ * per-sample part of views_linears.0 (no activation in between, nerf.py:200-204) into one
+ * 256->128 GEMM and returns the matching view bias views_b_eff = views_b + W_v[:, :256] feature_b,
+ * which the caller passes to danbo_view_consts in place of views_b. */
+#define DANBO_MLP16_PACKED_BYTES 2424832
+int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
+                     const float* views_w, const float* views_b, int Cv,
+                     void* packed16, float* views_b_eff /*[128]*/, void* stream);
 int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
                        const void* packed16, const float* const* pts_b,
-                       const float* alpha_w, const float* alpha_b, const float* feature_b,
+                       const float* alpha_w, const float* alpha_b,
                        const float* cview, const float* rgb_w, const float* rgb_b,
                        float* raw_out, float* aux_out, void* stream);
 

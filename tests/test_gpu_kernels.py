@@ -178,7 +178,10 @@ def test_view_constants_and_empty_raw(ops, stage):
     rb = g["ray_batch"]
     cview, raw_empty = eng.view_constants(T(rb[:, 3:6]), T(g["skts"]), T(g["cam_idx"], torch.int64))
     vin = g["view_inputs"]                                   # [R,155] from the reference
-    want = vin @ sd["views_linears.0.weight"][:, 256:].T + sd["views_linears.0.bias"]
+    # in the default (fp16-split) mode the bias also carries W_v[:, :256] b_feature (merged layers)
+    vb = sd["views_linears.0.bias"] + sd["views_linears.0.weight"][:, :256] @ sd["feature_linear.bias"]
+    assert max_err(N(eng.views_b16), vb) < 2e-6
+    want = vin @ sd["views_linears.0.weight"][:, 256:].T + vb
     assert max_err(N(cview), want) < 5e-6
     # empty-space raw: MLP on PE(0) with this ray's view vector
     dens0 = o.positional_encoding(np.zeros((1, 15), np.float32), 6)
@@ -191,7 +194,9 @@ def test_pe_mlp_on_golden_features(ops, stage):
     g, eng, ret = stage["g"], stage["eng"], stage["ret"]
     rb = g["ray_batch"]
     S = int(g["N_samples"])
+    eng.mlp_mode = "fp32"
     cview, raw_empty = eng.view_constants(T(rb[:, 3:6]), T(g["skts"]), T(g["cam_idx"], torch.int64))
+    eng.mlp_mode = "f16split"
     h = np.zeros((ret["enc"]["h"].shape[0], 16), np.float32)
     h[:, :15] = ret["enc"]["h"]
     raw = torch.zeros(len(rb), S, 4, device=DEV)
@@ -199,8 +204,8 @@ def test_pe_mlp_on_golden_features(ops, stage):
     assert rel_err(N(raw), g["raw_coarse"], floor=1.0) < 1e-4      # north_star tolerance vs the reference
     assert rel_err(N(raw), ret["raw_coarse"], floor=1.0) < 1e-4
     raw16 = torch.zeros(len(rb), S, 4, device=DEV)
-    ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w,
-                 eng.rgb_b, raw16)
+    cview16 = cview + (eng.views_b16 - eng.views_b)               # merged feature+view layer: bias moves to cview
+    ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview16, eng.rgb_w, eng.rgb_b, raw16)
     assert rel_err(N(raw16), g["raw_coarse"], floor=1.0) < 1e-4
     assert rel_err(N(raw16), N(raw), floor=1.0) < 2e-5             # split products ~ fp32 round-off class
 
@@ -220,7 +225,7 @@ def test_pe_mlp16_random_rows_and_tails(ops, stage):
         b = torch.zeros(R * S, 4, device=DEV)
         ops.pe_mlp(T(h), S, eng.packed, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w, eng.rgb_b,
                    a, lst=lst)
-        ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w,
+        ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview + (eng.views_b16 - eng.views_b), eng.rgb_w,
                      eng.rgb_b, b, lst=lst)
         assert rel_err(N(b), N(a), floor=1.0) < 2e-5, n
         assert float(N(a).__abs__().max()) > 0.1
@@ -332,7 +337,7 @@ def test_render_perfcap_view_branch():
     rb = g["ray_batch"]
     cam = T(-np.ones(len(rb)), torch.int64)
     cview, _ = eng.view_constants(T(rb[:, 3:6]), T(g["skts"]), cam)
-    want = g["view_inputs"] @ sd["views_linears.0.weight"][:, 256:].T + sd["views_linears.0.bias"]
+    want = g["view_inputs"] @ sd["views_linears.0.weight"][:, 256:].T + N(eng.views_b16)
     assert max_err(N(cview), want) < 5e-6
     nf = (T(g["near"][:, 0]), T(g["far"][:, 0]))
     out = eng.render(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cyls"]), cam,
