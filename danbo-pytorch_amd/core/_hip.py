@@ -30,7 +30,8 @@ SIGNATURES = {
     "danbo_assign16_pack": [P, P, P, P, P],
     "danbo_gather_assign_blend16_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P],
     "danbo_mlp_pack": [POINTER(c_void_p), P, P, I, P, P, P],
-    "danbo_view_consts": [P, P, I, I, I, I, I, P, I, I, P, P, P, P, P, P, P, I, P, P, P],
+    "danbo_view_consts": [P, P, I, I, I, I, I, P, I, I, P, P, P, P, P, P, P, I, P, P, P, P],
+    "danbo_view_code_table": [P, P, I, I, I, P, P, P, P],
     "danbo_mlp16_pack": [POINTER(c_void_p), P, P, P, P, I, P, P, P],
     "danbo_pe_mlp16_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P],
     "danbo_pe_mlp_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P, P],

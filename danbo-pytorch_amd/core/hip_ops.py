@@ -183,7 +183,7 @@ def mlp_pack(pts_w, feature_w, views_w):
 
 
 def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code, cam_idx, wrt, views_b,
-                rgb_w, rgb_b, empty_consts=None, rgb_order=0):
+                rgb_w, rgb_b, empty_consts=None, rgb_order=0, code_table=None):
     rays_d = _f32(rays_d, "rays_d")
     R, G = rays_d.shape[0], skts.shape[0]
     Cf = 0 if mean_code is None else mean_code.shape[0]
@@ -194,8 +194,16 @@ def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code
         cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
     _call("danbo_view_consts", _p(rays_d), _p(_f32(skts, "skts")), R, G, int(ray_mode), int(normalise), int(L_view),
           _p(framecodes), n_codes, Cf, _p(mean_code), _p(cam_idx), _p(wrt), _p(views_b), _p(rgb_w), _p(rgb_b),
-          _p(empty_consts), int(rgb_order), _p(cview), _p(raw_empty), _stream())
+          _p(empty_consts), int(rgb_order), _p(code_table), _p(cview), _p(raw_empty), _stream())
     return cview, raw_empty
+
+
+def view_code_table(framecodes, mean_code, L_view, wrt, views_b):
+    n_codes, Cf = framecodes.shape
+    table = torch.empty(n_codes + 1, VIEW_W, device=framecodes.device, dtype=torch.float32)
+    _call("danbo_view_code_table", _p(framecodes), _p(mean_code), n_codes, Cf, int(L_view), _p(wrt), _p(views_b),
+          _p(table), _stream())
+    return table
 
 
 def pe_mlp(h, S, packed, pts_b, alpha_w, alpha_b, feature_b, cview, rgb_w, rgb_b, raw_out,

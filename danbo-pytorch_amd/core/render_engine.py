@@ -71,8 +71,11 @@ class DanboEngine:
         if self.cfg["use_framecode"]:
             self.framecodes = p["framecodes.codes.weight"].contiguous()
             self.mean_code = self.framecodes.mean(0).contiguous()
+            vb = self.views_b16 if self.mlp_mode == "f16split" else self.views_b
+            self.code_table = ops.view_code_table(self.framecodes, self.mean_code, self.cfg["multires_views"],
+                                                  self.wrt, vb)
         else:
-            self.framecodes = self.mean_code = None
+            self.framecodes = self.mean_code = self.code_table = None
         # empty-space constants: one zero row through the MLP without the per-ray view term
         h0 = torch.zeros(1, ops.H_STRIDE, device=dev)
         scratch_raw = torch.empty(1, 4, device=dev)
@@ -100,7 +103,8 @@ class DanboEngine:
         return ops.view_consts(rays_d, skts, ray_mode, normalise, cfg["multires_views"], self.framecodes,
                                self.mean_code, cam_idx, self.wrt,
                                self.views_b16 if self.mlp_mode == "f16split" else self.views_b, self.rgb_w,
-                               self.rgb_b, self.empty_consts, 1 if self.mlp_mode == "f16split" else 0)
+                               self.rgb_b, self.empty_consts, 1 if self.mlp_mode == "f16split" else 0,
+                               self.code_table)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
                         want_confd=False, volumes=None, view=None):

@@ -137,6 +137,20 @@ __device__ __forceinline__ float rgb_dot_halves(const float* x, const float* __r
 // ======================================================================================
 constexpr int VIEW_RPB = 16;  // rays per workgroup iteration (8 per half-workgroup)
 
+// table[c][n] = views_b[n] + sum_k W_view[n][256 + Cpe + k] * code_c[k]   for every frame code c and,
+// in row n_codes, for the mean code (Optcodes eval with idx < 0).  One workgroup per code.
+__global__ __launch_bounds__(128) void k_view_code_table(const float* __restrict__ framecodes,
+                                                         const float* __restrict__ mean_code, int n_codes, int Cf,
+                                                         const float* __restrict__ wt_code /*[Cf][128]*/,
+                                                         const float* __restrict__ views_b,
+                                                         float* __restrict__ table) {
+    const int c = blockIdx.x, n = threadIdx.x;
+    const float* code = c < n_codes ? framecodes + (size_t)c * Cf : mean_code;
+    float acc = 0.f;
+    for (int k = 0; k < Cf; ++k) acc = fmaf(code[k], wt_code[(size_t)k * MLP_VW + n], acc);
+    table[(size_t)c * MLP_VW + n] = acc + views_b[n];
+}
+
 // Each thread owns one of the 128 view-layer columns for 8 rays: per input i it reads ONE weight
 // (conflict-free, lane = column) and the 8 rays' v_i as two broadcast ds_read_b128, then issues
 // 8 FMAs -- 3 LDS reads per 8 FMAs instead of 2 per FMA.
@@ -149,10 +163,13 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                                                      const float* __restrict__ views_b, const float* __restrict__ rgb_w,
                                                      const float* __restrict__ rgb_b,
                                                      const float* __restrict__ empty_consts, int rgb_order,
+                                                     const float* __restrict__ code_table,
                                                      float* __restrict__ cview, float* __restrict__ raw_empty) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Cpe = 3 * (1 + 2 * L_view);
-    const int Cv = Cpe + Cf;
+    // with a code table the frame-code part (and the bias) is a per-camera constant: only PE(dir) is summed
+    const int Cv = code_table ? Cpe : Cpe + Cf;
+    if (code_table) Cf = 0;
     float* s_w = smem;                        // [Cv][128]
     float* s_v = s_w + Cv * MLP_VW;           // [Cv][16]   (transposed: input-major, ray-minor)
     float* s_x = s_v + Cv * VIEW_RPB;         // [16][128]
@@ -190,6 +207,11 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                 s_v[(3 * (2 + 2 * l) + k) * VIEW_RPB + rl] = cs;
             }
         }
+        if (code_table && tid < VIEW_RPB) {
+            const int r = min(r0 + tid, R - 1);
+            const long idx = cam_idx ? (long)cam_idx[r] : -1;
+            reinterpret_cast<int*>(s_x)[tid] = idx < 0 ? n_codes : (int)min(idx, (long)n_codes - 1);
+        }
         for (int i = tid; i < VIEW_RPB * Cf; i += 256) {
             const int rl = i / Cf, k = i % Cf;
             const int r = min(r0 + rl, R - 1);
@@ -202,6 +224,12 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        int trow[8];
+        if (code_table) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) trow[q] = reinterpret_cast<const int*>(s_x)[half * 8 + q];
+            __syncthreads();  // s_x is reused for the activations below
+        }
         const float* vp = s_v + half * 8;
 #pragma unroll 4
         for (int i = 0; i < Cv; ++i) {
@@ -216,7 +244,7 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int rl = half * 8 + q, r = r0 + rl;
-            const float a = acc[q] + bias;
+            const float a = code_table ? acc[q] + code_table[(size_t)trow[q] * MLP_VW + c] : acc[q] + bias;
             if (r < R) cview[(size_t)r * MLP_VW + c] = a;
             if (empty_consts) s_x[rl * MLP_VW + c] = fmaxf(ec + a, 0.f);
         }
@@ -484,11 +512,11 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
                                   int L_view, const float* framecodes, int n_codes, int Cf, const float* mean_code,
                                   const int64_t* cam_idx, const float* views_w_ray_t, const float* views_b,
                                   const float* rgb_w, const float* rgb_b, const float* empty_consts, int rgb_order,
-                                  float* cview, float* raw_empty, void* stream) {
+                                  const float* code_table, float* cview, float* raw_empty, void* stream) {
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && L_view >= 0 && Cf >= 0);
     DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
     DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
-    const int Cv = 3 * (1 + 2 * L_view) + Cf;
+    const int Cv = 3 * (1 + 2 * L_view) + (code_table ? 0 : Cf);
     const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + VIEW_RPB * Cv + VIEW_RPB * MLP_VW);
     DANBO_CHECK_ARG(lds <= 160 * 1024);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_view_consts),
@@ -498,7 +526,16 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
     const int grid = iters < NUM_CU ? iters : NUM_CU;
     hipLaunchKernelGGL(k_view_consts, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
                        normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
-                       rgb_b, empty_consts, rgb_order, cview, raw_empty);
+                       rgb_b, empty_consts, rgb_order, code_table, cview, raw_empty);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_view_code_table(const float* framecodes, const float* mean_code, int n_codes, int Cf, int L_view,
+                                      const float* views_w_ray_t, const float* views_b, float* table, void* stream) {
+    DANBO_CHECK_ARG(framecodes && mean_code && n_codes > 0 && Cf > 0 && views_w_ray_t && views_b && table);
+    const int Cpe = 3 * (1 + 2 * L_view);
+    hipLaunchKernelGGL(k_view_code_table, dim3(n_codes + 1), dim3(128), 0, (hipStream_t)stream, framecodes, mean_code,
+                       n_codes, Cf, views_w_ray_t + (size_t)Cpe * MLP_VW, views_b, table);
     DANBO_LAUNCH_RET();
 }
 

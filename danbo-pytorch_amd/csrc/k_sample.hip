@@ -162,6 +162,21 @@ __device__ __forceinline__ void load_point(const float* __restrict__ rays_o, con
 // ======================================================================================
 // K1a: transform + cull
 // ======================================================================================
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ((m0*x + m1*y) + m2*z) + m3 for two points at once; every packed op rounds each half like the
+// scalar __fmul_rn / __fadd_rn chain of affine_unfused() (contraction disabled)
+__device__ __forceinline__ void affine_pk(const float* M, v2f x, v2f y, v2f z, v2f* q) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 r = *reinterpret_cast<const float4*>(M + 4 * k);
+        v2f s = r.x * x + r.y * y;
+        s = s + r.z * z;
+        q[k] = s + r.w;
+    }
+}
+
 constexpr int CULL_BLOCK = 256;
 constexpr int CULL_SPT = 4;  // samples per thread -> 1024 consecutive samples per workgroup
 
@@ -193,30 +208,74 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int it = 0; it < CULL_SPT; ++it) {
-        const long m = base + it * CULL_BLOCK + threadIdx.x;
-        uint32_t bits = 0;
-        if (m < M) {
-            const int g = (int)min(m / spp, (long)G - 1);
-            float p[3];
-            load_point(rays_o, rays_d, z, pts, m, S, p);
-            const float* sk = s_skt + (g - g0) * J * 16;
+    // Two samples per lane and per instruction: the unfused mul/add chain runs on packed fp32
+    // (v_pk_mul_f32 / v_pk_add_f32: two IEEE-rounded results per lane-op, same values as the scalar
+    // chain), the per-bone matrices are LDS broadcasts splatted over the pair.
+    uint32_t bits4[CULL_SPT];
+#pragma unroll
+    for (int pr = 0; pr < CULL_SPT / 2; ++pr) {
+        const long ma = base + (2 * pr) * CULL_BLOCK + threadIdx.x;
+        const long mb = ma + CULL_BLOCK;
+        const long mac = min(ma, M - 1), mbc = min(mb, M - 1);
+        float pa[3], pb[3];
+        load_point(rays_o, rays_d, z, pts, mac, S, pa);
+        load_point(rays_o, rays_d, z, pts, mbc, S, pb);
+        const int ga = (int)min(mac / spp, (long)G - 1), gb = (int)min(mbc / spp, (long)G - 1);
+        uint32_t ba = 0, bb = 0;
+        if (ga == gb) {
+            const v2f px = {pa[0], pb[0]}, py = {pa[1], pb[1]}, pz = {pa[2], pb[2]};
+            const float* sk = s_skt + (ga - g0) * J * 16;
 #pragma unroll 4
             for (int j = 0; j < J; ++j) {
-                float pt[3];
-                bone_local(sk + 16 * j, s_align + 16 * j, p, pt);
-                bits |= (in_volume(pt, s_scale + 4 * j) ? 1u : 0u) << j;
+                v2f l[3], t[3];
+                affine_pk(sk + 16 * j, px, py, pz, l);
+                affine_pk(s_align + 16 * j, l[0], l[1], l[2], t);
+                const float* sc = s_scale + 4 * j;
+                const bool ina = !(fabsf(t[0].x) > sc[0] || fabsf(t[1].x) > sc[1] || fabsf(t[2].x) > sc[2]);
+                const bool inb = !(fabsf(t[0].y) > sc[0] || fabsf(t[1].y) > sc[1] || fabsf(t[2].y) > sc[2]);
+                ba |= (ina ? 1u : 0u) << j;
+                bb |= (inb ? 1u : 0u) << j;
             }
-            valid_bits[m] = bits;
+        } else {  // the pair straddles two poses (chunk boundaries only)
+            const float* ska = s_skt + (ga - g0) * J * 16;
+            const float* skb = s_skt + (gb - g0) * J * 16;
+            for (int j = 0; j < J; ++j) {
+                float pt[3];
+                bone_local(ska + 16 * j, s_align + 16 * j, pa, pt);
+                ba |= (in_volume(pt, s_scale + 4 * j) ? 1u : 0u) << j;
+                bone_local(skb + 16 * j, s_align + 16 * j, pb, pt);
+                bb |= (in_volume(pt, s_scale + 4 * j) ? 1u : 0u) << j;
+            }
         }
-        if (list != nullptr) {  // wave-aggregated append of in-volume samples
-            const unsigned long long ball = __ballot(bits != 0);
-            if (ball != 0ull) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(count, __popcll(ball));
-                wbase = __shfl(wbase, 0, 64);
-                if (bits != 0) list[wbase + __popcll(ball & ((1ull << lane) - 1ull))] = (int32_t)m;
+        bits4[2 * pr] = ma < M ? ba : 0u;
+        bits4[2 * pr + 1] = mb < M ? bb : 0u;
+        if (ma < M) valid_bits[ma] = ba;
+        if (mb < M) valid_bits[mb] = bb;
+    }
+    if (list != nullptr) {
+        // one atomic per WORKGROUP: the 1024 consecutive samples of this workgroup stay in order in the
+        // list (good locality for the per-wavefront bone skipping of K2), order across workgroups free
+        __shared__ int s_cnt[CULL_SPT * (CULL_BLOCK / 64)];
+        __shared__ int s_base;
+        const int wave = threadIdx.x >> 6;
+        unsigned long long ball[CULL_SPT];
+#pragma unroll
+        for (int it = 0; it < CULL_SPT; ++it) {
+            ball[it] = __ballot(bits4[it] != 0);
+            if (lane == 0) s_cnt[it * (CULL_BLOCK / 64) + wave] = __popcll(ball[it]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int i = 0; i < CULL_SPT * (CULL_BLOCK / 64); ++i) { const int c = s_cnt[i]; s_cnt[i] = run; run += c; }
+            s_base = run > 0 ? atomicAdd(count, run) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < CULL_SPT; ++it) {
+            if (bits4[it] != 0) {
+                const long m = base + it * CULL_BLOCK + threadIdx.x;
+                list[s_base + s_cnt[it * (CULL_BLOCK / 64) + wave] + __popcll(ball[it] & ((1ull << lane) - 1ull))] = (int32_t)m;
             }
         }
     }

@@ -164,7 +164,15 @@ int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int 
                       const float* rgb_w /*[3,128]*/, const float* rgb_b /*[3]*/,
                       const float* empty_consts /*[129] or NULL*/,
                       int rgb_order /*0: summation order of danbo_pe_mlp_fwd, 1: of danbo_pe_mlp16_fwd*/,
+                      const float* code_table /*[n_codes+1,128] from danbo_view_code_table, or NULL*/,
                       float* cview /*[R,128]*/, float* raw_empty /*[R,4] or NULL*/, void* stream);
+
+/* Per-camera part of the view constants, once per weight update: table[c] = views_b + W_view[:, code
+ * columns] . framecode[c] for c < n_codes, row n_codes = the mean code.  With it danbo_view_consts
+ * only sums the 3(1+2L) direction encodings per ray. */
+int danbo_view_code_table(const float* framecodes, const float* mean_code, int n_codes, int Cf, int L_view,
+                          const float* views_w_ray_t, const float* views_b, float* table /*[n_codes+1,128]*/,
+                          void* stream);
 
 /* rows: h [n,16] (output of K2).  Row i belongs to sample id m = list ? list[i] : i and ray
  * m / S; raw_out[m] = (rgb logits, density logit).  aux_out (optional) [n,129] receives the
