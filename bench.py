@@ -31,11 +31,15 @@ import torch  # noqa: E402
 
 H = W = 512
 N_SAMPLES, N_IMPORTANCE = 48, 16
-MAC_PER_ROW = 677376           # density trunk + alpha + feature + view + rgb
-PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md
+MAC_PER_ROW_REF = 677376       # reference network: trunk 558592 + alpha 256 + feature 65536 + view 52608 + rgb 384
+# executed by each kernel (per-ray part of the view layer is hoisted into k_view_consts in both):
+MAC_PER_ROW = {"fp32": 558592 + 256 + 65536 + 32768 + 384,      # k_pe_mlp : trunk, alpha, feature, view[:, :256], rgb
+               "f16split": 558592 + 256 + 32768 + 384}          # k_pe_mlp16: feature+view merged into one 256->128
+PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_FP16_MFMA = 2500e12       # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (2:1-sparse figures are not used)
 
 
-def build_workload(device, view):
+def build_workload(device, view, mlp_mode="f16split"):
     from core.render_engine import DanboEngine
     from core.utils import synthetic as syn
     cfg = syn.model_config("danbo_base")
@@ -46,7 +50,7 @@ def build_workload(device, view):
     T = lambda x, dt=torch.float32: torch.tensor(np.ascontiguousarray(x), dtype=dt, device=device)  # noqa: E731
     from core.utils.skeleton_utils import bone_align_transforms
     align = bone_align_transforms(rest)
-    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(align))
+    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(align), mlp_mode=mlp_mode)
     inputs = dict(rays_o=T(ro), rays_d=T(rd), skts=T(scene["skts"]), bones=T(scene["bones"]), cyls=T(scene["cyls"]),
                   cam_idx=torch.zeros(len(ro), dtype=torch.int64, device=device))
     return eng, inputs, (cfg, sd, rest, scene, ro, rd)
@@ -89,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
+                    help="f16split: fp32-accurate products as 3 fp16 MFMAs (default); fp32: exact fp32 MFMA kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,7 +109,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
-    eng, inp, extra = build_workload(device, view=rank)
+    eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
     for _ in range(args.warmup):
         render(eng, inp)
     torch.cuda.synchronize()
@@ -132,17 +138,33 @@ def main():
     eng.profile = None
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
     rows = sum(int(c.item()) if torch.is_tensor(c) else int(c) for _, _, c in prof)
-    flops = 2.0 * MAC_PER_ROW * rows
+    mac = MAC_PER_ROW[args.mlp]
+    flops = 2.0 * mac * rows                          # EXECUTED multiply-adds of in-volume rows only
     achieved = flops / (ms * 1e-3)
-    roofline = dict(bound="mfma", kernel="k_pe_mlp", achieved=achieved / 1e12, peak=PEAK_FP32_MFMA / 1e12,
-                    unit="TFLOP/s", frac=achieved / PEAK_FP32_MFMA, traffic=None, launches=len(prof),
-                    avg_launch_ms=ms / len(prof), rows_per_launch=rows / len(prof),
-                    flop_per_row=2 * MAC_PER_ROW, note="executed flops only (rows inside >=1 bone volume)")
+    if args.mlp == "f16split":
+        kernel, peak = "k_pe_mlp16", PEAK_FP16_MFMA / 3.0
+        peak_note = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: every fp32-accurate product is three half-precision "
+                     "MFMA products (hi*hi + hi*lo + lo*hi); executed MFMA rate = 3 x achieved")
+    else:
+        kernel, peak = "k_pe_mlp", PEAK_FP32_MFMA
+        peak_note = "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    if os.path.exists(pmc) and args.mlp == "f16split":
+        traffic = json.load(open(pmc))["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
+    roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+                    frac=achieved / peak, traffic=traffic, launches=len(prof), avg_launch_ms=ms / len(prof),
+                    rows_per_launch=rows / len(prof), flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF,
+                    peak_note=peak_note,
+                    note="executed flops of rows inside >=1 bone volume only; traffic = HBM bytes per launch from "
+                         "rocprofv3 PMC passes (profiles/r01_pmc_hbm.json), algorithmic bytes = 84 B per row")
 
     result = {
         "metric": "ray-samples/sec at 512x512x64 samples", "value": value, "unit": "ray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.mlp == "fp32" else "f32 (fp16x2-split MFMA products, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "H36M danbo_base network, 512x512 rays x (48 coarse + 16 importance) samples, "
                                "1 pose / 1 camera per rank, cylinder near/far, exact in-volume culling",
                    "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
@@ -161,7 +183,7 @@ def main():
             td = (time.perf_counter() - t1) / nd
             result["dense_value"] = samples_per_frame / td
             result["dense_ms_per_step"] = 1e3 * td
-            result["dense_mlp_tflops_lower_bound"] = 2.0 * MAC_PER_ROW * samples_per_frame / td / 1e12
+            result["dense_mlp_tflops_lower_bound"] = 2.0 * mac * samples_per_frame / td / 1e12
             result["dense_equals_culled"] = bool(torch.equal(out_d["rgb_map"], out["rgb_map"]))
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(extra)
