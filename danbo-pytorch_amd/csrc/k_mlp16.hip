@@ -24,6 +24,13 @@
 
 namespace danbo {
 
+// A-fragment batch (output tiles per group of ds_read_b128): 2, 4 and 8 measured within 3 % of
+// each other -- the kernel is bound by LDS read bandwidth, not by read latency
+#ifndef DANBO_M16_BT
+#define DANBO_M16_BT 4
+#define DANBO_M16_BTX 4
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -162,20 +169,58 @@ __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
 }
 
 // acc[T] += W(k-step, tile T) * B for NT output tiles; pieces [p0 + 2T, p0 + 2T + 1] = (hi, lo).
-// Two tiles are interleaved so dependent MFMAs on one accumulator are two issue slots apart.
-template <int NT>
+// The A fragments of BT tiles (2*BT ds_read_b128) are requested as one batch before their 3*BT MFMAs;
+// while this wavefront waits for them the other wavefront of the SIMD owns the matrix pipe.
+template <int NT, int BT>
 __device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[NT], const char* base, int p0, const half8& bh, const half8& bl) {
 #pragma unroll
-    for (int T = 0; T < NT; T += 2) {
-        const half8 ah0 = lds_frag(base, p0 + 2 * T), al0 = lds_frag(base, p0 + 2 * T + 1);
-        const half8 ah1 = lds_frag(base, p0 + 2 * T + 2), al1 = lds_frag(base, p0 + 2 * T + 3);
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc[T + 1], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc[T + 1], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc[T + 1], 0, 0, 0);
+    for (int T0 = 0; T0 < NT; T0 += BT) {
+        half8 ah[BT], al[BT];
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            ah[t] = lds_frag(base, p0 + 2 * (T0 + t));
+            al[t] = lds_frag(base, p0 + 2 * (T0 + t) + 1);
+        }
+#ifdef DANBO_M16_SB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int t = 0; t < BT; t += 2) {
+            acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[T0 + t], 0, 0, 0);
+            acc[T0 + t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t + 1], bh, acc[T0 + t + 1], 0, 0, 0);
+            acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[T0 + t], 0, 0, 0);
+            acc[T0 + t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t + 1], bl, acc[T0 + t + 1], 0, 0, 0);
+            acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[T0 + t], 0, 0, 0);
+            acc[T0 + t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t + 1], bh, acc[T0 + t + 1], 0, 0, 0);
+        }
+#ifdef DANBO_M16_SB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+}
+
+// sin / cos of the positional encoding: Cody-Waite reduction by pi/2 (3 constants) + degree-7/8
+// minimax polynomials; |error| < 2e-7 for |x| < 1e4, about a quarter of the code of OCML's sincosf
+// (whose Payne-Hanek slow path is inlined at every call site).
+__device__ __forceinline__ void pe_sincos(float x, float* s, float* c) {
+    const float k = rintf(x * 0.636619772367581343f);  // 2/pi
+    float r = fmaf(k, -1.57079601287841796875f, x);    // pi/2 split in three (24 + 24 + 24 bits)
+    r = fmaf(k, -3.1391647326017846353352069854736328125e-7f, r);
+    r = fmaf(k, -5.390302529957764765544681040410068817436695098876953125e-15f, r);
+    const float r2 = r * r;
+    float sp = fmaf(r2, 2.6083159809786593541502952575683593750e-6f, -1.981069071916863322258e-4f);
+    sp = fmaf(sp, r2, 8.33307858556509017944e-3f);
+    sp = fmaf(sp, r2, -1.66666597127914428711e-1f);
+    const float sn = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.44331571593647822737693786621e-5f, -1.38873163610696792602539062500e-3f);
+    cp = fmaf(cp, r2, 4.16666455566883087158203125e-2f);
+    cp = fmaf(cp, r2, -0.5f);
+    const float cs = fmaf(cp, r2, 1.0f);
+    const int q = (int)k;
+    const float s0 = (q & 1) ? cs : sn;
+    const float c0 = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -s0 : s0;
+    *c = ((q + 1) & 2) ? -c0 : c0;
 }
 
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
@@ -240,28 +285,6 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
         for (int c = 0; c < 4; ++c)
             hv[c] = qq == 0 ? hq[c].x : (qq == 1 ? hq[c].y : (qq == 2 ? hq[c].z : hq[c].w));
         if (qq == 3) hv[3] = 0.f;
-        // ------------------------------------------------------------------ X0 = PE(h) fragments
-        half8 xh[X0_KSTEPS], xl[X0_KSTEPS];
-        {
-            float xv[8 * X0_KSTEPS];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float x = hv[c];
-                xv[13 * c] = x;
-#pragma unroll
-                for (int l = 0; l < 6; ++l) {
-                    float sn, cs;
-                    sincosf(x * (float)(1 << l), &sn, &cs);
-                    xv[13 * c + 1 + 2 * l] = sn;
-                    xv[13 * c + 2 + 2 * l] = cs;
-                }
-            }
-#pragma unroll
-            for (int j = 52; j < 8 * X0_KSTEPS; ++j) xv[j] = 0.f;
-#pragma unroll
-            for (int s = 0; s < X0_KSTEPS; ++s) split8(xv + 8 * s, xh[s], xl[s]);
-        }
-
         half8 bh[8], bl[8];
         float alpha_part = 0.f;
         f32x4 acc[16];
@@ -270,17 +293,40 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
 #pragma unroll
             for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (step == 0 || step == 5) {  // input / skip connection: 7 k-steps of PE features
+                // X0 = PE(h) fragments; recomputed for the skip connection (24 sincos per lane) rather
+                // than kept in 56 VGPRs across five layers
+                half8 xh[X0_KSTEPS], xl[X0_KSTEPS];
+                {
+                    // value j = 13c + t of this lane: t = 0: x_c, t = 1+2l: sin(2^l x_c), t = 2+2l: cos(2^l x_c);
+                    // produced in order and split 8 at a time so only one k-step of fp32 values is live
+                    float v8[8], cs_keep = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8 * X0_KSTEPS; ++j) {
+                        const int c = j / 13, t = j % 13;
+                        float val = 0.f;
+                        if (j < 52) {
+                            if (t == 0) val = hv[c];
+                            else if (t & 1) {
+                                float sn;
+                                pe_sincos(hv[c] * (float)(1 << ((t - 1) >> 1)), &sn, &cs_keep);
+                                val = sn;
+                            } else val = cs_keep;
+                        }
+                        v8[j & 7] = val;
+                        if ((j & 7) == 7) split8(v8, xh[j >> 3], xl[j >> 3]);
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < NCH_X0; ++c) {
                     const char* base = pipe_begin(p);
-                    kstep_mfma<16>(acc, base, 0, xh[c], xl[c]);
+                    kstep_mfma<16, DANBO_M16_BTX>(acc, base, 0, xh[c], xl[c]);  // smaller batches: xh/xl are live here
                 }
             }
             if (step != 0) {
 #pragma unroll
                 for (int c = 0; c < NCH_ACT; ++c) {
                     const char* base = pipe_begin(p);
-                    kstep_mfma<16>(acc, base, 0, bh[c], bl[c]);
+                    kstep_mfma<16, DANBO_M16_BT>(acc, base, 0, bh[c], bl[c]);
                 }
             }
             // ---- epilogue: bias (+ReLU), density-logit partial, re-split into the next B fragments
@@ -320,8 +366,8 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
 #pragma unroll
         for (int c = 0; c < NCH_VIEW; ++c) {
             const char* base = pipe_begin(p);
-            kstep_mfma<8>(accv, base, 0, bh[2 * c], bl[2 * c]);
-            kstep_mfma<8>(accv, base, 16, bh[2 * c + 1], bl[2 * c + 1]);
+            kstep_mfma<8, DANBO_M16_BT>(accv, base, 0, bh[2 * c], bl[2 * c]);
+            kstep_mfma<8, DANBO_M16_BT>(accv, base, 16, bh[2 * c + 1], bl[2 * c + 1]);
         }
         // ------------------------------------------------------------------ colour head + output
         float pr = 0.f, pg = 0.f, pb = 0.f;
