@@ -92,7 +92,8 @@ class DANBO(NeRF):
         """inputs: pts [R,S,3], skts [R|1,24,4,4], bones [R|1,24,3], align_transforms [..,24,4,4],
         N_uniques, rays_d [R,1,3], cam_idxs [R] | None  ->  raw [R,S,4], encoded"""
         if self.training:
-            raise NotImplementedError("training forward/backward kernels: see DESIGN.md 'not yet built'")
+            from .. import train_path
+            return train_path.forward_train(self, inputs)
         pts = inputs['pts']
         R = pts.shape[0]
         G = int(inputs.get('N_uniques', 1))

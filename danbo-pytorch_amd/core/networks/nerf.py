@@ -68,6 +68,9 @@ class NeRF(nn.Module):
         noise = None
         if raw_noise_std > 0.:
             noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std * B
+        if raw.requires_grad:
+            from .. import train_path
+            return train_path.composite(raw, z_vals, rays_d, B, noise)
         return ops.composite(raw, z_vals, rays_d.reshape(-1, 3), B, noise)
 
     def update_embed_fns(self, global_step, args):

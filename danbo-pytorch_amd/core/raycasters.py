@@ -164,7 +164,7 @@ class RayCaster(nn.Module):
         if fwd_type:
             raise NotImplementedError(fwd_type)
         if self.training:
-            raise NotImplementedError("training render (backward kernels) is not built yet -- DESIGN.md")
+            return self.render_rays_train(*args, **kwargs)
         with torch.no_grad():
             return self.render_rays(*args, **kwargs)
 
@@ -201,6 +201,48 @@ class RayCaster(nn.Module):
         eng.cfg['density_scale'] = preproc_kwargs.get('density_scale', eng.cfg['density_scale'])
         return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance,
                           near_far=(near, far))
+
+    def render_rays_train(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
+                          subject_idxs=None, lindisp=False, perturb=0., N_importance=0, raw_noise_std=0.,
+                          ray_noise_std=0., N_uniques=1, preproc_kwargs={}, netchunk=1024 * 64, **kwargs):
+        """Differentiable two-pass render (reference render_rays :245-377 in training mode): sampling is
+        detached, the network and the compositing carry gradients (core/train_path.py)."""
+        if N_importance <= 0 or lindisp or ray_noise_std:
+            raise NotImplementedError("training needs N_importance > 0, lindisp=False, ray_noise_std=0")
+        eng = self._engine()
+        G = int(N_uniques)
+        R = ray_batch.shape[0]
+        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+        skts_g, bones_g, cyls_g = self._per_pose(skts, G), self._per_pose(bones, G), self._per_pose(cyls, G)
+        B = preproc_kwargs.get('density_scale', 1.0)
+        with torch.no_grad():
+            near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., R, ray_batch[:, 6], ray_batch[:, 7])
+            if eng.cfg['use_volume_near_far']:
+                ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
+            t_rand = torch.rand(R, N_samples, device=rays_o.device) if perturb > 0. else None
+            z = ops.coarse_samples(near, far, N_samples, t_rand)
+        align = self.transforms[:1, None].to(rays_o.device)
+
+        def net(zv):
+            pts = rays_o[:, None, :] + rays_d[:, None, :] * zv[:, :, None]
+            inputs = dict(pts=pts, kps=None, skts=skts_g, bones=bones_g, align_transforms=align, N_uniques=G,
+                          rays_o=rays_o[:, None], rays_d=rays_d[:, None], cam_idxs=cams)
+            return self.network(inputs)
+
+        raw, enc = net(z)
+        out0 = self.network.raw2outputs(raw, z, rays_d, raw_noise_std=raw_noise_std, B=B)
+        with torch.no_grad():
+            u = torch.rand(R, N_importance, device=rays_o.device) if perturb > 0. else None
+            z_all, z_fine, order = ops.importance_samples(z, out0['weights'], N_importance, u)
+        raw_f, enc_f = net(z_fine)
+        idx = order.long()
+        take = lambda a, b: torch.gather(torch.cat([a, b], 1), 1, idx[..., None].expand(-1, -1, a.shape[-1]))  # noqa: E731
+        raw_all = take(raw, raw_f)
+        out = self.network.raw2outputs(raw_all, z_all, rays_d, raw_noise_std=raw_noise_std, B=B)
+        return dict(rgb_map=out['rgb_map'], disp_map=out['disp_map'], acc_map=out['acc_map'], alpha=out['alpha'],
+                    T_i=out['weights'], rgb0=out0['rgb_map'], disp0=out0['disp_map'], acc0=out0['acc_map'],
+                    alpha0=out0['alpha'], confd=take(enc['confd'], enc_f['confd']),
+                    part_invalid=take(enc['part_invalid'], enc_f['part_invalid']))
 
     def render_pts_density(self, pts, kps, skts, bones, netchunk=1024 * 64, network=None):
         assert kps.shape[0] == 1, f'Assuming only one pose is provided, got {kps.shape[0]} instead'

@@ -1,0 +1,239 @@
+"""Differentiable (training) forward of DANBO on the MI355X path.
+
+Work split:
+  * hand-written HIP, forward AND backward: world->bone transform + in-volume cull (K1a, no
+    gradient), factorised gather (K1b: d volumes / d axis_scale by atomics), alpha compositing
+    (K4), sampling / importance sampling / merge order (no gradient: the reference detaches them);
+  * plain GEMMs through rocBLAS (torch.addmm / einsum) on the COMPACTED in-volume rows only:
+    the per-bone linears of the two GNNs and the 12 linear layers of the MLP, recorded by
+    autograd;
+  * small element-wise glue (PE, masked sigmoid, blend) as torch ops.
+Samples outside every bone volume share, per ray, one "empty-space" MLP evaluation (h = 0),
+which keeps the gradient path of the reference (every sample reaches the MLP weights) at a
+fraction of the rows.
+
+Gradient semantics follow the reference: `window` is detached and `invalid` is not
+differentiable (core/networks/gnn_backbone.py:802-808); sample depths are detached
+(core/utils/ray_utils.py:287); no gradient reaches pts / skts / bones (opt_pose is off).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _hip
+from . import hip_ops as ops
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+# --------------------------------------------------------------------------------------
+# custom autograd functions around the HIP kernels
+# --------------------------------------------------------------------------------------
+class GatherFn(torch.autograd.Function):
+    """part_feat [n,24,15] = factorised gather of `volumes` at the listed samples (K1b)."""
+
+    @staticmethod
+    def forward(ctx, volumes, axis_scale, geo, rows):
+        geo.axis_scale = axis_scale.detach().float().contiguous()
+        n = rows.shape[0]
+        out = ops.bone_gather(geo, volumes.detach().contiguous(), rows, None, n)
+        ctx.geo, ctx.n = geo, n
+        ctx.save_for_backward(volumes.detach(), geo.axis_scale, rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        volumes, axis_scale, rows = ctx.saved_tensors
+        geo = ctx.geo
+        # explicit shapes: zeros_like would inherit the permuted strides of an einsum output
+        d_vol = torch.zeros(volumes.shape, dtype=torch.float32, device=volumes.device)
+        d_sc = torch.zeros(axis_scale.shape, dtype=torch.float32, device=volumes.device)
+        g = g.contiguous().float()
+        if ctx.n > 0:
+            _hip.check(_hip.lib().danbo_bone_gather_bwd(
+                _p(geo.rays_o), _p(geo.rays_d), _p(geo.z), _p(geo.pts), geo.R, geo.S, geo.G, _p(geo.skts),
+                _p(geo.align), _p(axis_scale), _p(volumes.contiguous()), _p(rows), ctx.n, _p(g), _p(d_vol), _p(d_sc),
+                ops._stream()), "danbo_bone_gather_bwd")
+        return d_vol, d_sc, None, None
+
+
+class CompositeFn(torch.autograd.Function):
+    """NeRF.raw2outputs with gradients for rgb_map and acc_map (K4)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rays_d, B, noise):
+        out = ops.composite(raw.detach(), z, rays_d, B, noise)
+        ctx.B = float(B)
+        ctx.save_for_backward(raw.detach().contiguous(), z.contiguous(), rays_d.contiguous(),
+                              noise if noise is not None else torch.empty(0, device=raw.device))
+        ctx.mark_non_differentiable(out["disp_map"], out["weights"], out["alpha"])
+        return out["rgb_map"], out["disp_map"], out["acc_map"], out["weights"], out["alpha"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_alpha):
+        raw, z, rays_d, noise = ctx.saved_tensors
+        R, S = z.shape
+        d_raw = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
+        g_rgb = (g_rgb if g_rgb is not None else torch.zeros(R, 3, device=raw.device)).contiguous().float()
+        g_acc = (g_acc if g_acc is not None else torch.zeros(R, device=raw.device)).contiguous().float()
+        _hip.check(_hip.lib().danbo_composite_bwd(
+            _p(raw), _p(z), _p(rays_d), R, S, ctx.B, _p(noise if noise.numel() else None), _p(g_rgb), _p(g_acc),
+            _p(d_raw), ops._stream()), "danbo_composite_bwd")
+        return d_raw, None, None, None, None
+
+
+def composite(raw, z, rays_d, B=1.0, noise=None):
+    rgb, disp, acc, w, al = CompositeFn.apply(raw.contiguous().float(), z.contiguous().float(),
+                                              rays_d.reshape(-1, 3).contiguous().float(), B, noise)
+    return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
+
+
+# --------------------------------------------------------------------------------------
+# small differentiable pieces (GEMMs via rocBLAS, element-wise glue)
+# --------------------------------------------------------------------------------------
+def positional_encoding(x, L):
+    outs = [x]
+    for l in range(L):
+        xf = x * float(2 ** l)
+        outs += [torch.sin(xf), torch.cos(xf)]
+    return torch.cat(outs, -1)
+
+
+def axis_angle_to_rot6d(aa):
+    """pytorch3d axis_angle_to_matrix (via quaternion, Taylor branch < 1e-6) -> first two columns."""
+    ang = torch.norm(aa, p=2, dim=-1, keepdim=True)
+    half = ang * 0.5
+    small = ang.abs() < 1e-6
+    s = torch.where(small, 0.5 - (ang * ang) / 48, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    q = torch.cat([torch.cos(half), aa * s], -1)
+    r, i, j, k = q.unbind(-1)
+    two_s = 2.0 / (q * q).sum(-1)
+    return torch.stack([1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * j + k * r),
+                        1 - two_s * (i * i + k * k), two_s * (i * k - j * r), two_s * (j * k + i * r)], -1)
+
+
+def pose_volumes(model, bones_g):
+    """FactorizeGNN forward (reference gnn_backbone.py:683-704) -> [G,24,240], differentiable."""
+    gn = model.graph_net
+    n = positional_encoding(axis_angle_to_rot6d(bones_g), model.graph_pe_fn.num_freqs)
+    mask = torch.ones(1, 24, 1, device=n.device)
+    mask[:, 0] = 0.
+    n = n * mask
+    last = len(gn.layers) - 1
+    for i, l in enumerate(gn.layers):
+        if hasattr(l, "adj_w"):  # graph conv: per-bone linear, weighted adjacency, shared bias
+            out = torch.einsum("bkl,klj->bkj", n, l.lin.weight)
+            out = torch.matmul(l.get_adjw(), out) + l.bias
+        else:
+            out = torch.einsum("bkl,klj->bkj", n, l.weight) + l.bias
+        if i == 0:
+            out = out + out  # skip_gcn=False quirk: first layer doubled (gnn_backbone.py:698-699)
+        n = F.relu(out) if i < last else out
+    return n
+
+
+def assignment_logits(model, part_feat):
+    """MixGNN forward (reference gnn_backbone.py:567-629): [n,24,15] -> [n,24]."""
+    l0, l1, l2 = model.prob_linears.layers
+    y = torch.einsum("bkl,klj->bkj", part_feat, l0.lin.weight)
+    y = F.relu(torch.matmul(l0.get_adjw(), y) + l0.bias)
+    y = F.relu(torch.einsum("bkl,klj->bkj", y, l1.weight) + l1.bias)
+    return (torch.einsum("bkl,klj->bkj", y, l2.weight) + l2.bias)[..., 0]
+
+
+def mlp(model, dens_in, view_in):
+    h = dens_in
+    for i, l in enumerate(model.pts_linears):
+        h = F.relu(l(h))
+        if i in model.skips:
+            h = torch.cat([dens_in, h], -1)
+    alpha = model.alpha_linear(h)
+    feat = model.feature_linear(h)
+    hv = F.relu(model.views_linears[0](torch.cat([feat, view_in], -1)))
+    return torch.cat([model.rgb_linear(hv), alpha], -1)
+
+
+def view_inputs(model, rays_d, skts_g, cam_idxs, rays_per_pose):
+    """per-ray [PE(dir) | frame code] (reference nerf.py:252-279, encoders.py:179-189,570-578)."""
+    name = model.pts_embedder.ray_tr_fn.encoder_name
+    d = rays_d
+    if name == "RLEncoder":
+        pose = torch.arange(rays_d.shape[0], device=rays_d.device) // rays_per_pose
+        d = torch.einsum("rij,rj->ri", skts_g[pose, 0, :3, :3], rays_d)
+    if model.pts_embedder.view_input_fn.encoder_name == "VecNorm":
+        d = F.normalize(d, dim=-1, p=2)
+    v = positional_encoding(d, model.dirs_pe_fn.num_freqs)
+    if model.use_framecode:
+        idx = cam_idxs.reshape(-1).long()
+        if (not model.training) and int(idx.max()) < 0:
+            code = model.framecodes.codes.weight.mean(0, keepdim=True).expand(idx.shape[0], -1)
+        else:
+            code = model.framecodes.codes(idx)
+        v = torch.cat([v, code], -1)
+    return v
+
+
+# --------------------------------------------------------------------------------------
+# DANBO.forward in training mode
+# --------------------------------------------------------------------------------------
+def forward_train(model, inputs):
+    """-> raw [R,S,4] (differentiable), encoded {confd [R,S,24], part_invalid [R,S,24]}"""
+    pts = inputs["pts"].contiguous().float()
+    R, S = pts.shape[:2]
+    G = int(inputs.get("N_uniques", 1))
+    skts, bones = inputs["skts"], inputs["bones"]
+    skts_g = (skts if skts.shape[0] == G else skts[:: max(skts.shape[0] // G, 1)]).contiguous().float()
+    bones_g = (bones if bones.shape[0] == G else bones[:: max(bones.shape[0] // G, 1)]).contiguous().float()
+    align = inputs["align_transforms"].reshape(-1, 24, 4, 4)[0].contiguous().float().to(pts.device)
+    rays_d = inputs["rays_d"].reshape(R, 3).contiguous().float()
+    axis_scale = model.graph_net.axis_scale
+
+    geo = ops.Geometry(rays_d, rays_d, skts_g, align, axis_scale.detach(), pts=pts)
+    bits, lst, cnt = ops.bone_cull(geo, compact=True)
+    n = int(cnt.item())                      # one host sync per pass: sizes the autograd graph
+    rows = torch.sort(lst[:n]).values.contiguous()
+    vols = pose_volumes(model, bones_g)
+    part_feat = GatherFn.apply(vols, axis_scale, geo, rows)
+    logits = assignment_logits(model, part_feat)
+    shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
+    valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
+    p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid_rows
+    h = (part_feat * p[..., None]).sum(-2)
+    vin = view_inputs(model, rays_d, skts_g, inputs.get("cam_idxs"), R // G)
+    ray_of_row = (rows // S).long()
+    L = model.voxel_pe_fn.num_freqs
+    raw_rows = mlp(model, positional_encoding(h, L), vin[ray_of_row])
+    raw_empty = mlp(model, positional_encoding(torch.zeros(1, h.shape[1], device=pts.device), L).expand(R, -1), vin)
+    raw = raw_empty[:, None, :].expand(R, S, 4).reshape(R * S, 4).index_copy(0, rows.long(), raw_rows)
+    confd = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), logits)
+    # confd of samples outside every volume: the reference evaluates the assignment net there too; those
+    # logits never reach a loss (they are multiplied by part_valid = 0), so they are left at zero
+    all_valid = ((bits.unsqueeze(-1) >> shifts) & 1).float()
+    encoded = dict(confd=confd.reshape(R, S, 24), part_invalid=(1.0 - all_valid).reshape(R, S, 24))
+    return raw.reshape(R, S, 4), encoded
+
+
+# --------------------------------------------------------------------------------------
+# losses (reference core/trainer.py:396-422, 507-553)
+# --------------------------------------------------------------------------------------
+def nerf_loss(args, rgb_pred, acc_pred, target, bgs=1.0, loss_weight=1.0):
+    if args.use_background:
+        rgb_pred = rgb_pred + (1. - acc_pred)[..., None] * bgs
+    fn = {"L1": F.l1_loss, "MSE": F.mse_loss}[args.loss_fn]
+    return fn(rgb_pred, target, reduction="mean") * loss_weight * args.rgb_loss_coef
+
+
+def soft_softmax_loss(args, model, preds):
+    labels = ((preds["T_i"] * preds["alpha"]) > 0).float()
+    part_valid = 1 - preds["part_invalid"]
+    p = model.sigmoid(preds["confd"], preds["part_invalid"], mask_invalid=False, clamp=False)
+    return args.soft_softmax_loss_coef * (labels - (p * part_valid).sum(-1)).pow(2.).mean()
+
+
+def volume_scale_loss(args, model):
+    gn = model.graph_net
+    scale = gn.axis_scale.abs().clamp(min=gn.init_scale.to(gn.axis_scale.device) * 0.05)
+    return torch.prod(scale, dim=-1).sum() * args.vol_scale_penalty

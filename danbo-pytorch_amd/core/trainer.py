@@ -1,0 +1,92 @@
+"""Training step (reference: core/trainer.py `Trainer.train_batch`, losses :396-422,507-553,
+learning-rate decay :189-200) for one process per GPU.
+
+Data-parallel training = every rank renders its own shard of the ray batch (whole images, so
+`N_uniques` stays an integer per rank) and the flat fp32 gradient is summed with ONE RCCL
+all-reduce per step and divided by the world size; Adam then runs redundantly
+on every rank.  No nn.DataParallel, no DistributedDataParallel hooks.
+"""
+import torch
+import torch.distributed as dist
+
+from . import train_path
+
+
+def decay_optimizer_lrate(lrate, lrate_decay, decay_rate=0.1, optimizer=None, global_step=None, decay_unit=1000):
+    """lr = lrate * decay_rate^((step // unit) / lrate_decay)  (decay_steps = lrate_decay * unit)"""
+    decay_steps = lrate_decay * decay_unit
+    optim_step = global_step // decay_unit * decay_unit
+    new_lrate = lrate * (decay_rate ** (optim_step / decay_steps))
+    for g in optimizer.param_groups:
+        g['lr'] = new_lrate
+    return new_lrate, None
+
+
+def allreduce_gradients(params, world=None):
+    """one flat-bucket all-reduce (sum) of every gradient, then / world"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = world or dist.get_world_size()
+    if world == 1:
+        return 0
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for p, g in zip(params, grads):
+        n = g.numel()
+        p.grad = flat[off:off + n].view_as(p).clone()
+        off += n
+    return flat.numel()
+
+
+class Trainer:
+    def __init__(self, args, data_attrs, optimizer, pose_optimizer=None, render_kwargs_train=None,
+                 render_kwargs_test=None, popt_kwargs=None, device=None):
+        self.args, self.optimizer, self.device = args, optimizer, device
+        self.render_kwargs_train, self.render_kwargs_test = render_kwargs_train, render_kwargs_test
+        self.hwf, self.data_attrs = data_attrs.get('hwf'), data_attrs
+
+    def _ray_batch(self, batch):
+        ro, rd = batch['rays_o'].float(), batch['rays_d'].float()
+        vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+        near, far = torch.zeros_like(rd[..., :1]), torch.ones_like(rd[..., :1])
+        return torch.cat([ro, rd, near, far, vd], -1)
+
+    def compute_loss(self, batch, preds):
+        args = self.args
+        caster = self.render_kwargs_train['ray_caster']
+        model = caster.network
+        bgs = batch.get('bgs', 1.0)
+        loss = {'rgb_loss': train_path.nerf_loss(args, preds['rgb_map'], preds['acc_map'], batch['target_s'], bgs)}
+        if 'rgb0' in preds:
+            loss['rgb_loss0'] = train_path.nerf_loss(args, preds['rgb0'], preds['acc0'], batch['target_s'], bgs,
+                                                     loss_weight=args.coarse_weight)
+        if 'confd' in preds and args.agg_type == 'sigmoid':
+            loss['soft_softmax_loss'] = train_path.soft_softmax_loss(args, model, preds)
+        if args.opt_vol_scale:
+            loss['vol_scale_loss'] = train_path.volume_scale_loss(args, model)
+        loss['total_loss'] = sum(loss.values())
+        return loss
+
+    def train_batch(self, batch, i=0, global_step=0):
+        args = self.args
+        kw = {k: v for k, v in self.render_kwargs_train.items() if k not in ('ray_caster', 'use_viewdirs')}
+        caster = self.render_kwargs_train['ray_caster']
+        caster.train()
+        batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        preds = caster(self._ray_batch(batch), kp_batch=batch['kp3d'], skts=batch['skts'], cyls=batch['cyls'],
+                       bones=batch['bones'], cams=batch.get('cam_idxs'), N_uniques=batch['N_uniques'], **kw)
+        loss = self.compute_loss(batch, preds)
+        self.optimizer.zero_grad()
+        loss['total_loss'].backward()
+        params = [p for g in self.optimizer.param_groups for p in g['params']]
+        allreduce_gradients(params)
+        self.optimizer.step()
+        lr, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, self.optimizer,
+                                      global_step, args.decay_unit)
+        caster.update_embed_fns(global_step, args)
+        stats = {k: float(v.detach()) for k, v in loss.items()}
+        stats.update(lrate=lr, alpha=float(preds['acc_map'].mean().detach()))
+        return loss, stats

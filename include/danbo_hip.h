@@ -214,6 +214,19 @@ int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, i
                         const float* noise, float* rgb_map, float* disp, float* acc,
                         float* weights, float* alpha, void* stream);
 
+/* K4 backward: gradients of rgb_map [R,3] and acc_map [R] -> d raw [R,S,4] (S <= 256).  disp_map,
+ * weights and alpha carry no gradient in the reference's losses (core/trainer.py:396-422,507-536). */
+int danbo_composite_bwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
+                        const float* noise, const float* g_rgb, const float* g_acc, float* d_raw, void* stream);
+
+/* K1b backward: d part_feat [n,24,15] -> d volumes [G,24,240] and d axis_scale [24,3] (both ACCUMULATED
+ * with atomics: the caller zeroes them).  Same autograd semantics as the reference: the window is
+ * detached and the in-volume mask is not differentiable (gnn_backbone.py:802-808). */
+int danbo_bone_gather_bwd(const float* rays_o, const float* rays_d, const float* z, const float* pts,
+                          int R, int S, int G, const float* skts, const float* align, const float* axis_scale,
+                          const float* volumes, const int32_t* list, int n, const float* d_part_feat,
+                          float* d_volumes, float* d_axis_scale, void* stream);
+
 /* isample_from_lineseg(is_only=True) + sample_pdf (core/utils/ray_utils.py:159-203,257-291)
  * + the sort of [z, z_fine] (stable, coarse first):  u NULL = linspace(0,1,Sf) (det) else
  * caller-supplied uniforms [R,Sf].  sorted_idx int32 [R,S+Sf]. */

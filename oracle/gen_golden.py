@@ -14,6 +14,8 @@ Fixtures
                      chunk incl. rays that miss the cylinder (NaN back-fill), 32+16: final maps
   danbo_perfcap.npz  D-Perf (relray/root_local view branch, box near/far), 256 rays, 32+16,
                      mean frame code (idx -1): raw + final maps
+  danbo_train.npz    D-H36M, 128 rays = 4 poses x 32, 16+8 samples, training mode with perturb = 0 and
+                     raw_noise_std = 0: the four loss terms of Trainer.compute_loss and gradients
   pose_rot6d.npz     axis-angle -> rot6d incl. tiny angles (pytorch3d boundary, cross-checked
                      with scipy in the tests)
 """
@@ -191,6 +193,58 @@ def gen_danbo_perfcap():
     print("danbo_perfcap: acc mean", fin["acc_map"].mean())
 
 
+def gen_danbo_train():
+    """one deterministic training forward/backward (perturb = 0, raw_noise_std = 0) of the reference:
+    loss terms of Trainer.compute_loss and gradients of a representative parameter subset"""
+    seed = 14
+    cfg, args, caster, kw_test, rest = build("danbo_base", seed)
+    import types
+    import core.trainer as rtr
+    scene = syn.make_scene(n_poses=4, H=64, W=64, n_views=4, pose_seed=21)
+    n_per = 32
+    ro, rd, pose = [], [], []
+    for p in range(4):
+        o, d = body_rays(scene, p, n_per, seed=200 + p)
+        ro.append(o); rd.append(d); pose += [p] * n_per
+    ro, rd, pose = np.concatenate(ro), np.concatenate(rd), np.array(pose)
+    rb = syn.ray_batch(ro, rd)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    cam_idx = (np.arange(len(pose)) % 5).astype(np.int64)
+    rng = np.random.default_rng(7)
+    target = rng.uniform(size=(len(pose), 3)).astype(np.float32)
+    bgs = rng.uniform(size=(len(pose), 3)).astype(np.float32)
+    S, Sf = 16, 8
+    caster.train()
+    kw = {k: v for k, v in kw_test.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
+    preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                   cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+    wrap = types.SimpleNamespace(module=caster)
+    tr = rtr.Trainer(args, dict(hwf=(64, 64, 80.0)), None, None, dict(ray_caster=wrap), dict(ray_caster=caster))
+    loss_dict, stats = tr.compute_loss(dict(target_s=T(target), bgs=T(bgs)), preds, kp_opts=None, popt_detach=True)
+    caster.zero_grad()
+    loss_dict["total_loss"].backward()
+    net = caster.network
+    grads = {n: p.grad.numpy() for n, p in net.named_parameters() if p.grad is not None}
+    keep = {}
+    for n in ("graph_net.axis_scale", "pts_linears.0.weight", "pts_linears.5.bias", "alpha_linear.weight",
+              "rgb_linear.weight", "views_linears.0.bias", "framecodes.codes.weight", "prob_linears.layers.1.weight",
+              "prob_linears.layers.0.adj_w", "prob_linears.layers.2.bias", "graph_net.layers.0.adj_w",
+              "graph_net.layers.2.bias"):
+        keep["grad/" + n] = grads[n]
+    keep["grad/graph_net.layers.3.weight[:, ::16, ::8]"] = grads["graph_net.layers.3.weight"][:, ::16, ::8].copy()
+    keep["grad/graph_net.layers.0.lin.weight[:, ::8, ::16]"] = grads["graph_net.layers.0.lin.weight"][:, ::8, ::16].copy()
+    norms = {"gnorm/" + n: np.float64(np.sqrt((g.astype(np.float64) ** 2).sum())) for n, g in grads.items()}
+    np.savez_compressed(
+        os.path.join(OUT, "danbo_train.npz"),
+        cfg_name="danbo_base", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=4,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
+        pose_of_ray=pose, cam_idx=cam_idx, target=target, bgs=bgs,
+        rgb_map=preds["rgb_map"].detach().numpy(), acc_map=preds["acc_map"].detach().numpy(),
+        rgb0=preds["rgb0"].detach().numpy(), part_invalid=preds["part_invalid"].detach().numpy(),
+        **{"loss/" + k: np.float64(v.item()) for k, v in loss_dict.items()}, **keep, **norms)
+    print("danbo_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()})
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -208,7 +262,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -217,5 +271,7 @@ if __name__ == "__main__":
         gen_danbo_perfcap()
     if "rot6d" in which:
         gen_pose_rot6d()
+    if "train" in which:
+        gen_danbo_train()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
