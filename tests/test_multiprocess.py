@@ -60,3 +60,45 @@ def test_shard_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "danbo-pytorch_amd"))
+    from core.trainer import allreduce_gradients
+    torch.manual_seed(0)                                    # identical initial parameters on every rank
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    opt = torch.optim.Adam(params, lr=1e-2)
+    for step in range(3):
+        opt.zero_grad()
+        x = torch.full((3,), float(rank + 1 + step))        # a different data shard per rank
+        loss = (params[0] @ x).pow(2).sum() + (params[1] * (rank + 1)).sum()   # params[2] gets no gradient
+        loss.backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        n = allreduce_gradients(params)
+        assert n == 5 * 3 + 7 + 4
+        opt.step()
+    q.put((rank, [p.detach().numpy().copy() for p in params], local[1].numpy(), params[1].grad.numpy().copy(),
+           params[2].grad.numpy().copy()))   # numpy: torch tensors in a Queue die with the sending process
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_keeps_replicas_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, l0, g0, z0), (_, p1, l1, g1, z1) = res
+    import numpy as np
+    assert np.allclose(g0, (l0 + l1) / 2) and np.array_equal(g0, g1)       # mean of the rank gradients, on both
+    assert not z0.any() and not z1.any()                                   # missing gradient == zero contribution
+    assert all(np.array_equal(a, b) for a, b in zip(p0, p1))               # replicas stay bit-identical
