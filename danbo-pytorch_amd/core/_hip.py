@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdanbo_hip.so")
+LIB_PATH = os.environ.get("DANBO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libdanbo_hip.so")
 
 P = c_void_p  # device pointer
 I = c_int

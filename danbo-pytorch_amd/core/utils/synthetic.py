@@ -343,6 +343,8 @@ def make_state_dict(cfg, seed=0, n_framecodes=100, rest=None, lively=True):
         sd['dirs_pe_fn.cutoff_dist'] = np.full((N_JOINTS,), cfg['cutoff_dist'], np.float32)
         sd['pe_fn.tau'] = np.array(cfg['tau'], np.float32)
         sd['dirs_pe_fn.tau'] = np.array(cfg['tau'], np.float32)
+        if lively:
+            _calibrate_anerf(sd, cfg, rng)
     return sd
 
 
@@ -380,6 +382,39 @@ def _calibrate_density(sd, cfg, rng):
     w = w + (8.0 - gap) * u / float(u @ u)
     sd['alpha_linear.weight'] = w[None].astype(np.float32)
     sd['alpha_linear.bias'] = np.array([-2.0 - float(h[0] @ w)], dtype=np.float32)
+
+
+def _cutoff_pe64(v, cutoff, tau, L):
+    """A-NeRF distance encoding (cut_to_dist, cutoff_shift, cutoff_inputs) in float64: [n,24] -> [n,(1+2L)*24]."""
+    inp = cutoff - v
+    sh = inp * (2.0 / cutoff) - 1.0
+    w = 1.0 - 1.0 / (1.0 + np.exp(-tau * (v - cutoff)))
+    blocks = [inp]
+    for l in range(L):
+        blocks += [np.sin(sh * 2.0 ** l), np.cos(sh * 2.0 ** l)]
+    return (np.stack(blocks, -2) * w[..., None, :]).reshape(v.shape[0], -1)
+
+
+def _calibrate_anerf(sd, cfg, rng):
+    """The A-NeRF counterpart of `_calibrate_density`: samples far from every joint (all cutoff weights
+    ~0) get raw density -2, samples with a few joints within 5-25 cm get +6 on average."""
+    n = 256
+    unit = rng.standard_normal((2 * n, N_JOINTS, 3))
+    unit /= np.linalg.norm(unit, axis=-1, keepdims=True)
+    v_far = rng.uniform(0.9, 1.6, size=(n, N_JOINTS))
+    v_near = rng.uniform(0.45, 1.2, size=(n, N_JOINTS))
+    for i in range(n):
+        j = rng.choice(N_JOINTS, size=3, replace=False)
+        v_near[i, j] = rng.uniform(0.05, 0.25, size=3)
+    v = np.concatenate([v_far, v_near], 0)
+    x = np.concatenate([_cutoff_pe64(v, cfg['cutoff_dist'], cfg['tau'], cfg['multires']), unit.reshape(2 * n, -1)], -1)
+    h = _trunk64(sd, x, cfg['D'], cfg['skips'])
+    h_far, h_near = h[:n].mean(0), h[n:].mean(0)
+    u = h_near - h_far
+    w = sd['alpha_linear.weight'].astype(np.float64)[0] * 0.5
+    w = w + (8.0 - float(u @ w)) * u / float(u @ u)
+    sd['alpha_linear.weight'] = w[None].astype(np.float32)
+    sd['alpha_linear.bias'] = np.array([-2.0 - float(h_far @ w)], dtype=np.float32)
 
 
 # ----------------------------------------------------------------------------- scenes

@@ -24,13 +24,6 @@
 
 namespace danbo {
 
-// A-fragment batch (output tiles per group of ds_read_b128): 2, 4 and 8 measured within 3 % of
-// each other -- the kernel is bound by LDS read bandwidth, not by read latency
-#ifndef DANBO_M16_BT
-#define DANBO_M16_BT 4
-#define DANBO_M16_BTX 4
-#endif
-
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -138,64 +131,85 @@ struct Pipe {
     const char* packed;
     char* ring;
     int issue_chunk, issue_slot, cons_slot, wave, lane;
+    bool early;
 };
 
 // every wavefront loads 4 of the 32 pieces of a chunk
 __device__ __forceinline__ void pipe_issue(Pipe& p) {
     const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 4096 + p.lane * 16;
     char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 4096;
+#ifndef DANBO_DBG_NOSTREAM
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+#endif
     p.issue_chunk = p.issue_chunk + 1 == NCH_TOTAL ? 0 : p.issue_chunk + 1;
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
 }
 
-// start of a chunk: my share of it has landed (<= 8 younger loads = 2 chunks outstanding), then everybody's
-// has (barrier) and everybody is done with the slot we are about to refill
-__device__ __forceinline__ const char* pipe_begin(Pipe& p) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+// Ring hand-over #c, executed once per chunk c by every wavefront -- by the "early" wavefronts (0-3) in the
+// middle of chunk c, by the "late" ones (4-7, their SIMD partners) before they start it, so the two
+// wavefronts of a SIMD run half a chunk apart and one's VALU epilogue work and LDS latencies fall under
+// the other's MFMAs instead of both stalling at the same program point:
+//   wait: my share of chunk c+1 has landed (<= 4 younger loads = chunk c+2 outstanding);
+//   barrier: everybody's has, and everybody is past chunk c-1;  then refill that slot with chunk c+3.
+__device__ __forceinline__ void pipe_handover(Pipe& p) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     pipe_issue(p);
-    const char* base = p.ring + p.cons_slot * CHUNK_BYTES + p.lane * 16;
-    p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
-    return base;
 }
 
 __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
+#ifdef DANBO_DBG_NOLDS
+    half8 r; for (int e = 0; e < 8; ++e) r[e] = (_Float16)(float)(((size_t)base >> 4) + piece + e); return r;
+#endif
     return *reinterpret_cast<const half8*>(base + piece * 1024);
 }
 
-// acc[T] += W(k-step, tile T) * B for NT output tiles; pieces [p0 + 2T, p0 + 2T + 1] = (hi, lo).
-// The A fragments of BT tiles (2*BT ds_read_b128) are requested as one batch before their 3*BT MFMAs;
-// while this wavefront waits for them the other wavefront of the SIMD owns the matrix pipe.
-template <int NT, int BT>
-__device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[NT], const char* base, int p0, const half8& bh, const half8& bl) {
-#pragma unroll
-    for (int T0 = 0; T0 < NT; T0 += BT) {
-        half8 ah[BT], al[BT];
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            ah[t] = lds_frag(base, p0 + 2 * (T0 + t));
-            al[t] = lds_frag(base, p0 + 2 * (T0 + t) + 1);
-        }
-#ifdef DANBO_M16_SB
-        __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ void mfma3(f32x4& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
+#ifdef DANBO_DBG_NOMFMA
+    acc[0] += (float)ah[0] + (float)al[1]; acc[1] += (float)bh[0]; acc[2] += (float)bl[0]; return;
 #endif
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+}
+
+// One 32 KB chunk = 16 (tile, hi/lo) fragment pairs.  DENSE layers: one k-step, output tiles 0..15, B = (b0h, b0l).
+// VIEW layer: two k-steps of 8 output tiles, B = b0 for pairs 0..7 and b1 for pairs 8..15.
+// The A fragments are read two tiles ahead of their MFMAs (double-buffered in registers).
+template <int NACC, bool VIEW>
+__device__ __forceinline__ void chunk_mfma(f32x4 (&acc)[NACC], Pipe& p, const half8& b0h, const half8& b0l,
+                                           const half8& b1h, const half8& b1l) {
+    if (!p.early) pipe_handover(p);
+    const char* base = p.ring + p.cons_slot * CHUNK_BYTES + p.lane * 16;
+    p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
+    half8 ah[2][2], al[2][2];
 #pragma unroll
-        for (int t = 0; t < BT; t += 2) {
-            acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[T0 + t], 0, 0, 0);
-            acc[T0 + t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t + 1], bh, acc[T0 + t + 1], 0, 0, 0);
-            acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[T0 + t], 0, 0, 0);
-            acc[T0 + t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t + 1], bl, acc[T0 + t + 1], 0, 0, 0);
-            acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[T0 + t], 0, 0, 0);
-            acc[T0 + t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t + 1], bh, acc[T0 + t + 1], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) {
+        ah[0][t] = lds_frag(base, 2 * t);
+        al[0][t] = lds_frag(base, 2 * t + 1);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (b + 1 < 8) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[(b + 1) & 1][t] = lds_frag(base, 4 * (b + 1) + 2 * t);
+                al[(b + 1) & 1][t] = lds_frag(base, 4 * (b + 1) + 2 * t + 1);
+            }
         }
-#ifdef DANBO_M16_SB
+        if (b == 4 && p.early) pipe_handover(p);
         __builtin_amdgcn_sched_barrier(0);
-#endif
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int T = 2 * b + t;
+            if (VIEW && T >= 8) mfma3(acc[T - 8], ah[b & 1][t], al[b & 1][t], b1h, b1l);
+            else mfma3(acc[VIEW ? T : T], ah[b & 1][t], al[b & 1][t], b0h, b0l);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -239,6 +253,29 @@ __device__ __forceinline__ float quad_sum(float p) {
     return p;
 }
 
+// B fragments of k-step s of the next GEMM from the previous layer's accumulators: tiles 2s and 2s+1,
+// bias + ReLU, hi/lo split.  ALPHA: also accumulate this lane's part of the density logit.
+template <bool ALPHA>
+__device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, const float* bias /* + 4qq + 32s */,
+                                             const float* aw, float& alpha_part, half8& bh, half8& bl) {
+    float v[8];
+    const float4 b0 = *reinterpret_cast<const float4*>(bias);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + 16);
+    v[0] = fmaxf(a0[0] + b0.x, 0.f); v[1] = fmaxf(a0[1] + b0.y, 0.f);
+    v[2] = fmaxf(a0[2] + b0.z, 0.f); v[3] = fmaxf(a0[3] + b0.w, 0.f);
+    v[4] = fmaxf(a1[0] + b1.x, 0.f); v[5] = fmaxf(a1[1] + b1.y, 0.f);
+    v[6] = fmaxf(a1[2] + b1.z, 0.f); v[7] = fmaxf(a1[3] + b1.w, 0.f);
+    if (ALPHA) {
+        const float4 w0 = *reinterpret_cast<const float4*>(aw);
+        const float4 w1 = *reinterpret_cast<const float4*>(aw + 16);
+        alpha_part = fmaf(v[0], w0.x, alpha_part); alpha_part = fmaf(v[1], w0.y, alpha_part);
+        alpha_part = fmaf(v[2], w0.z, alpha_part); alpha_part = fmaf(v[3], w0.w, alpha_part);
+        alpha_part = fmaf(v[4], w1.x, alpha_part); alpha_part = fmaf(v[5], w1.y, alpha_part);
+        alpha_part = fmaf(v[6], w1.z, alpha_part); alpha_part = fmaf(v[7], w1.w, alpha_part);
+    }
+    split8(v, bh, bl);
+}
+
 __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);  // [8][256]
@@ -246,13 +283,12 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     float* s_rgbw = s_aw + W_;                                                  // [3][128]
     float* s_misc = s_rgbw + 3 * VW_;                                           // alpha_b, rgb_b[3]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, qq = lane >> 4;
     for (int i = tid; i < 8 * W_; i += M16_THREADS) s_bias[i] = a.pts_b[i >> 8][i & 255];
     if (tid < W_) s_aw[tid] = a.alpha_w[tid];
     for (int i = tid; i < 3 * VW_; i += M16_THREADS) s_rgbw[i] = a.rgb_w[i];
     if (tid < 4) s_misc[tid] = tid == 0 ? a.alpha_b[0] : a.rgb_b[tid - 1];
-    __syncthreads();
 
     const int n = resolve_count(a.count, a.n_cap);
     const int ntiles = (n + M16_BM - 1) / M16_BM;
@@ -260,9 +296,12 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
 
     Pipe p;
     p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave; p.lane = lane;
+    p.early = wave < 4;  // wavefronts w and w+4 of a workgroup share a SIMD
     pipe_issue(p);
     pipe_issue(p);
     pipe_issue(p);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk 0 landed (tables: the same barrier)
+    __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ------------------------------------------------------------------ inputs
@@ -285,89 +324,66 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
         for (int c = 0; c < 4; ++c)
             hv[c] = qq == 0 ? hq[c].x : (qq == 1 ? hq[c].y : (qq == 2 ? hq[c].z : hq[c].w));
         if (qq == 3) hv[3] = 0.f;
-        half8 bh[8], bl[8];
         float alpha_part = 0.f;
-        f32x4 acc[16];
+        f32x4 prev[16];  // pre-bias outputs of the previous layer
+#pragma unroll
+        for (int T = 0; T < 16; ++T) prev[T] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int step = 0; step < 8; ++step) {
+            f32x4 acc[16];
 #pragma unroll
             for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (step == 0 || step == 5) {  // input / skip connection: 7 k-steps of PE features
-                // X0 = PE(h) fragments; recomputed for the skip connection (24 sincos per lane) rather
-                // than kept in 56 VGPRs across five layers
-                half8 xh[X0_KSTEPS], xl[X0_KSTEPS];
-                {
-                    // value j = 13c + t of this lane: t = 0: x_c, t = 1+2l: sin(2^l x_c), t = 2+2l: cos(2^l x_c);
-                    // produced in order and split 8 at a time so only one k-step of fp32 values is live
-                    float v8[8], cs_keep = 0.f;
+                // value j = 13c + t of this lane: t = 0: x_c, t = 1+2l: sin(2^l x_c), t = 2+2l: cos(2^l x_c);
+                // produced 8 at a time right before the k-step that consumes them (and recomputed for the
+                // skip connection rather than kept in 56 VGPRs across five layers)
+                float v8[8], cs_keep = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8 * X0_KSTEPS; ++j) {
-                        const int c = j / 13, t = j % 13;
-                        float val = 0.f;
-                        if (j < 52) {
-                            if (t == 0) val = hv[c];
-                            else if (t & 1) {
-                                float sn;
-                                pe_sincos(hv[c] * (float)(1 << ((t - 1) >> 1)), &sn, &cs_keep);
-                                val = sn;
-                            } else val = cs_keep;
-                        }
-                        v8[j & 7] = val;
-                        if ((j & 7) == 7) split8(v8, xh[j >> 3], xl[j >> 3]);
+                for (int j = 0; j < 8 * X0_KSTEPS; ++j) {
+                    const int c = j / 13, t = j % 13;
+                    float val = 0.f;
+                    if (j < 52) {
+                        if (t == 0) val = hv[c];
+                        else if (t & 1) {
+                            float sn;
+                            pe_sincos(hv[c] * (float)(1 << ((t - 1) >> 1)), &sn, &cs_keep);
+                            val = sn;
+                        } else val = cs_keep;
                     }
-                }
-#pragma unroll
-                for (int c = 0; c < NCH_X0; ++c) {
-                    const char* base = pipe_begin(p);
-                    kstep_mfma<16, DANBO_M16_BTX>(acc, base, 0, xh[c], xl[c]);  // smaller batches: xh/xl are live here
+                    v8[j & 7] = val;
+                    if ((j & 7) == 7) {
+                        half8 xh, xl;
+                        split8(v8, xh, xl);
+                        chunk_mfma<16, false>(acc, p, xh, xl, xh, xl);
+                    }
                 }
             }
             if (step != 0) {
+                const float* bias = s_bias + (step - 1) * W_ + 4 * qq;
 #pragma unroll
-                for (int c = 0; c < NCH_ACT; ++c) {
-                    const char* base = pipe_begin(p);
-                    kstep_mfma<16, DANBO_M16_BT>(acc, base, 0, bh[c], bl[c]);
+                for (int s = 0; s < NCH_ACT; ++s) {
+                    half8 bh, bl;
+                    act_fragment<false>(prev[2 * s], prev[2 * s + 1], bias + 32 * s, nullptr, alpha_part, bh, bl);
+                    chunk_mfma<16, false>(acc, p, bh, bl, bh, bl);
                 }
             }
-            // ---- epilogue: bias (+ReLU), density-logit partial, re-split into the next B fragments
-            const float* bias = s_bias + step * W_ + 4 * qq;
-            const float* aw = s_aw + 4 * qq;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                float v[8];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int T = 2 * s + t;
-                    const float4 b = *reinterpret_cast<const float4*>(bias + 16 * T);
-                    v[4 * t + 0] = acc[T][0] + b.x;
-                    v[4 * t + 1] = acc[T][1] + b.y;
-                    v[4 * t + 2] = acc[T][2] + b.z;
-                    v[4 * t + 3] = acc[T][3] + b.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                if (step == 7) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const float4 w = *reinterpret_cast<const float4*>(aw + 16 * (2 * s + t));
-                        alpha_part = fmaf(v[4 * t + 0], w.x, alpha_part);
-                        alpha_part = fmaf(v[4 * t + 1], w.y, alpha_part);
-                        alpha_part = fmaf(v[4 * t + 2], w.z, alpha_part);
-                        alpha_part = fmaf(v[4 * t + 3], w.w, alpha_part);
-                    }
-                }
-                split8(v, bh[s], bl[s]);
-            }
+            for (int T = 0; T < 16; ++T) prev[T] = acc[T];
         }
         // ------------------------------------------------------------------ view layer (128 outputs)
         f32x4 accv[8];
 #pragma unroll
         for (int T = 0; T < 8; ++T) accv[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* bias = s_bias + 7 * W_ + 4 * qq;
+            const float* aw = s_aw + 4 * qq;
 #pragma unroll
-        for (int c = 0; c < NCH_VIEW; ++c) {
-            const char* base = pipe_begin(p);
-            kstep_mfma<8, DANBO_M16_BT>(accv, base, 0, bh[2 * c], bl[2 * c]);
-            kstep_mfma<8, DANBO_M16_BT>(accv, base, 16, bh[2 * c + 1], bl[2 * c + 1]);
+            for (int c = 0; c < NCH_VIEW; ++c) {
+                half8 b0h, b0l, b1h, b1l;
+                act_fragment<true>(prev[4 * c], prev[4 * c + 1], bias + 64 * c, aw + 64 * c, alpha_part, b0h, b0l);
+                act_fragment<true>(prev[4 * c + 2], prev[4 * c + 3], bias + 64 * c + 32, aw + 64 * c + 32, alpha_part, b1h, b1l);
+                chunk_mfma<8, true>(accv, p, b0h, b0l, b1h, b1l);
+            }
         }
         // ------------------------------------------------------------------ colour head + output
         float pr = 0.f, pg = 0.f, pb = 0.f;
@@ -399,6 +415,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
             if (a.aux_out) a.aux_out[(size_t)row * (VW_ + 1) + VW_] = al;
         }
     }
+    // every wavefront executed the same number of hand-overs; drain the ring before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }

@@ -502,17 +502,88 @@ def cutoff_pe_dist(v, cutoff, tau, L=7):
 
 
 def cutoff_pe_view(d, v, cutoff, tau, L=4):
-    """view variant (dist_inputs=True): d [M,72] per-bone unit dirs, weights from v [M,24]
-    repeated x3; the raw input block is NOT weighted (cutoff_inputs applies... see ref :192-197)."""
+    """view variant (dist_inputs=True, cutoff_inputs=True; core/cutoff_embedder.py:156-166,176-197):
+    d [M,72] per-bone unit directions, cutoff weights from the joint distances v [M,24] repeated x3;
+    -> [M,(1+2L)*72] block-major [d, sin(2^0 d), cos(2^0 d), ...], EVERY block times the weight."""
     vr = np.repeat(v, 3, -1)
     cr = np.repeat(cutoff, 3, -1)
     w = (F32(1.) - sigmoid((F32(tau) * (vr - cr)).astype(F32))).astype(F32)
-    blocks = []
+    blocks = [d.astype(F32)]
     for l in range(L):
         f = (d * F32(2.0 ** l)).astype(F32)
         blocks += [np.sin(f).astype(F32), np.cos(f).astype(F32)]
-    e = np.stack(blocks, -2)
-    return e, w
+    e = np.stack(blocks, -2)  # [M,1+2L,72]
+    return (e * w[..., None, :]).astype(F32).reshape(d.shape[0], -1), w
+
+
+def unit_vectors(x):
+    """F.normalize(x, dim=-1, p=2): x / max(|x|, 1e-12)  (VecNormEncoder, core/encoders.py:774-795)."""
+    n = np.sqrt((x * x).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    return (x / np.maximum(n, F32(1e-12))).astype(F32)
+
+
+def bone_local_rays(rays_d, skts):
+    """transform_batch_rays (core/encoders.py:305-317): rotation part of every bone transform -> [R,24,3]."""
+    return (skts[:, :, :3, :3] @ rays_d[:, None, :, None])[..., 0].astype(F32)
+
+
+class AnerfOracle:
+    """Eval-mode forward of A-NeRF (nerf_type=nerf; core/networks/nerf.py:107-122,222-279): joint-distance
+    cutoff PE + unit bone-local directions -> density trunk; cutoff-weighted PE of the bone-local ray
+    directions + frame code -> colour head.  No skeleton GNN, no culling."""
+
+    def __init__(self, cfg, sd, rest_pose):
+        self.cfg = cfg
+        self.sd = {k: np.asarray(v, dtype=F32) if np.asarray(v).dtype != np.int64 else v for k, v in sd.items()}
+        self.align = bone_align_transforms(rest_pose)
+
+    def forward(self, pts, rays_d, skts, bones=None, cam_idxs=None, n_uniques=1, stages=False):
+        cfg, sd = self.cfg, self.sd
+        R, S = pts.shape[:2]
+        M = R * S
+        pts_t = bone_local(pts, skts, self.align)
+        v = np.sqrt((pts_t * pts_t).sum(-1, dtype=F32)).astype(F32)                       # RelDist
+        r = unit_vectors(pts_t).reshape(R, S, -1)                                          # VecNorm, [R,S,72]
+        tau = float(sd['pe_fn.tau'])
+        v_pe, w = cutoff_pe_dist(v.reshape(M, J), sd['pe_fn.cutoff_dist'], tau, cfg['multires'])
+        dens_in = np.concatenate([v_pe, r.reshape(M, -1)], -1).astype(F32)
+        d = unit_vectors(bone_local_rays(rays_d, skts)).reshape(R, -1)                     # [R,72]
+        d_pe, _ = cutoff_pe_view(np.repeat(d, S, axis=0), v.reshape(M, J), sd['dirs_pe_fn.cutoff_dist'],
+                                 float(sd['dirs_pe_fn.tau']), cfg['multires_views'])
+        vin = d_pe
+        if cfg['use_framecode']:
+            vin = np.concatenate([vin, np.repeat(frame_codes(sd, cam_idxs, R), S, axis=0)], -1)
+        raw = mlp(sd, dens_in, vin, cfg['D'], cfg['skips']).reshape(R, S, 4)
+        enc = dict(v=v, r=r)
+        if stages:
+            enc.update(density_inputs=dens_in, view_inputs=vin, view_dirs=d, w=w)
+        return raw, enc
+
+    def render(self, ray_batch, skts, bones, cyls, cam_idxs=None, n_uniques=1, N_samples=None, N_importance=None,
+               chunk=None, stages=False, near_far=None):
+        cfg = self.cfg
+        S = N_samples or cfg['N_samples']
+        Sf = N_importance or cfg['N_importance']
+        rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+        if near_far is None:
+            near, far = near_far_cylinder(rays_o, rays_d, cyls, ray_batch[:, 6:7], ray_batch[:, 7:8], chunk)
+        else:
+            near, far = near_far
+        z = coarse_z(near, far, S)
+        raw, enc = self.forward(sample_points(rays_o, rays_d, z), rays_d, skts, bones, cam_idxs, n_uniques, stages)
+        B = cfg['density_scale']
+        out0 = composite(raw, z, rays_d, B)
+        z_all, z_fine, order = importance_z(z, out0['weights'], Sf)
+        raw_f, _ = self.forward(sample_points(rays_o, rays_d, z_fine), rays_d, skts, bones, cam_idxs, n_uniques)
+        raw_all = np.take_along_axis(np.concatenate([raw, raw_f], 1), order[..., None], 1)
+        out = composite(raw_all, z_all, rays_d, B)
+        ret = dict(rgb_map=out['rgb_map'], disp_map=out['disp_map'], acc_map=out['acc_map'], alpha=out['alpha'],
+                   T_i=out['weights'], rgb0=out0['rgb_map'], disp0=out0['disp_map'], acc0=out0['acc_map'],
+                   alpha0=out0['alpha'])
+        if stages:
+            ret.update(near=near, far=far, z_coarse=z, raw_coarse=raw, weights_coarse=out0['weights'], z_fine=z_fine,
+                       z_sorted=z_all, sorted_idxs=order, raw_fine=raw_f, raw_sorted=raw_all, enc=enc)
+        return ret
 
 
 # =============================================================================

@@ -16,6 +16,8 @@ Fixtures
                      mean frame code (idx -1): raw + final maps
   danbo_train.npz    D-H36M, 128 rays = 4 poses x 32, 16+8 samples, training mode with perturb = 0 and
                      raw_noise_std = 0: the four loss terms of Trainer.compute_loss and gradients
+  anerf_stages.npz   A-H36M (anerf_base net: cutoff PE, W = 448), 48 rays = 2 poses x 24, 12+6 samples, at
+                     tau = 20 (step 0) with every stage tensor, and raw + final maps again at tau = 2000
   pose_rot6d.npz     axis-angle -> rot6d incl. tiny angles (pytorch3d boundary, cross-checked
                      with scipy in the tests)
 """
@@ -245,6 +247,51 @@ def gen_danbo_train():
     print("danbo_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()})
 
 
+def gen_anerf_stages():
+    seed = 15
+    cfg, args, caster, kw_test, rest = build("anerf_base", seed)
+    net = caster.network
+    scene = syn.make_scene(n_poses=2, H=64, W=64, n_views=2, pose_seed=9)
+    n_per = 24
+    ro, rd, pose = [], [], []
+    for p in range(2):
+        o, d = body_rays(scene, p, n_per, seed=300 + p)
+        ro.append(o); rd.append(d); pose += [p] * n_per
+    ro, rd, pose = np.concatenate(ro), np.concatenate(rd), np.array(pose)
+    rb = syn.ray_batch(ro, rd)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    cam_idx = (np.arange(len(pose)) % 7).astype(np.int64)
+    S, Sf = 12, 6
+    keep = {}
+    for tag, tau in (("", 20.0), ("tau2000_", 2000.0)):
+        for fn in (net.pe_fn, net.dirs_pe_fn):
+            fn.tau.fill_(tau)
+        fin = call_caster(caster, kw_test, rb, kps, skts, cyls, bones, T(cam_idx, torch.long), S, Sf, 2)
+        with torch.no_grad():
+            rays_o, rays_d = T(ro), T(rd)
+            near, far = caster.get_near_far(rays_o, rays_d, T(cyls), near=T(rb[:, 6:7]), far=T(rb[:, 7:8]), skts=T(skts))
+            pts, z = caster.sample_pts(rays_o, rays_d, near, far, len(pose), S, 0., False)
+            inputs = caster.get_nerf_inputs(pts, [rays_o[:, None, :], rays_d[:, None, :]], T(kps), T(skts), T(bones),
+                                            cam_idxs=T(cam_idx, torch.long), N_uniques=2)
+            dens_in, enc = net.encode_pts(inputs)
+            view_in, enc_v = net.encode_views(inputs, refs=enc["pts_t"], encoded_pts=enc)
+            raw, _ = net(inputs)
+        keep.update({tag + "raw_coarse": raw.numpy(), **{tag + "final_" + k: v for k, v in fin.items()}})
+        if not tag:
+            keep.update(near=near.numpy(), far=far.numpy(), z_coarse=z.numpy(), pts=pts.numpy(),
+                        v=enc["v"].numpy(), r=enc["r"].numpy(), density_inputs=dens_in.numpy(),
+                        view_dirs=enc_v["d"].numpy()[:, 0].copy(), view_inputs=view_in.numpy()[::5].copy())
+            print("anerf has align:", inputs["align_transforms"] is not None)
+    np.savez_compressed(
+        os.path.join(OUT, "anerf_stages.npz"),
+        cfg_name="anerf_base", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=2,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
+        pose_of_ray=pose, cam_idx=cam_idx, rest_pose=rest, **keep)
+    print("anerf_stages: acc mean", keep["final_acc_map"].mean(), keep["tau2000_final_acc_map"].mean(),
+          "raw alpha range", keep["raw_coarse"][..., 3].min(), keep["raw_coarse"][..., 3].max(),
+          "rgb spread", keep["final_rgb_map"].std(0))
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -262,7 +309,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -273,5 +320,7 @@ if __name__ == "__main__":
         gen_pose_rot6d()
     if "train" in which:
         gen_danbo_train()
+    if "anerf" in which:
+        gen_anerf_stages()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -23,7 +23,8 @@ def oracle_for(g):
     cfg = syn.model_config(str(g["cfg_name"]))
     rest = syn.rest_pose(cfg["rest_scale"])
     sd = syn.make_state_dict(cfg, seed=int(g["weight_seed"]), n_framecodes=int(g["n_framecodes"]), rest=rest)
-    return o.DanboOracle(cfg, sd, rest), cfg, sd, rest
+    cls = o.DanboOracle if cfg["nerf_type"] == "danbo" else o.AnerfOracle
+    return cls(cfg, sd, rest), cfg, sd, rest
 
 
 def max_err(a, b):
