@@ -6,7 +6,7 @@ tensor is not a CUDA(HIP) tensor.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_void_p, POINTER
+from ctypes import c_long, c_char_p, c_float, c_int, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DANBO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libdanbo_hip.so")
@@ -41,6 +41,9 @@ SIGNATURES = {
     "danbo_bone_gather_bwd": [P, P, P, P, I, I, I, P, P, P, P, P, I, P, P, P, P],
     "danbo_importance_samples": [P, P, I, I, I, P, P, P, P, P],
     "danbo_merge_samples": [P, P, P, I, I, I, I, P, P],
+    "danbo_anerf_encode_fwd": [P, P, P, P, I, I, I, P, P, P, F, I, c_long, I, P, P, P],
+    "danbo_anerf_view_pe_fwd": [P, P, I, I, I, P, P],
+    "danbo_anerf_color_fwd": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P],
 }
 
 _lib = None

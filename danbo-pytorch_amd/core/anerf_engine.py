@@ -1,0 +1,158 @@
+"""Orchestration of the A-NeRF render path (nerf_type = nerf: joint-distance cutoff PE, W = 448 trunk).
+
+Per chunk of whole rays:  k_anerf_encode (HIP) -> 8 dense trunk layers + alpha + merged feature/view
+layer (plain library GEMMs with fused bias+ReLU epilogues, fp32) -> k_anerf_color (HIP).  Sampling,
+compositing and importance resampling are the kernels the DANBO path uses.  A-NeRF has no in-volume mask:
+every sample is evaluated, exactly as in the reference (core/networks/nerf.py:107-122).
+"""
+import torch
+
+from . import hip_ops as ops
+
+
+def _linear_relu(x, w_t, b, add=None):
+    """relu(x @ w_t + b [+ add]) with the bias/ReLU in the GEMM epilogue where hipBLASLt provides it."""
+    if add is None:
+        try:
+            return torch._addmm_activation(b, x, w_t, use_gelu=False)
+        except (RuntimeError, AttributeError):
+            return torch.relu_(torch.addmm(b, x, w_t))
+    return torch.relu_(torch.addmm(add, x, w_t))
+
+
+class AnerfEngine:
+    def __init__(self, cfg, params, align, rows_per_chunk=1 << 18):
+        self.cfg, self.p = cfg, params
+        self.align = align.float().contiguous()
+        self.rows_per_chunk = rows_per_chunk
+        self._key_built = None
+
+    def _key(self):
+        return tuple((k, v.data_ptr(), v._version) for k, v in sorted(self.p.items()))
+
+    def refresh(self):
+        key = self._key()
+        if key == self._key_built:
+            return
+        p, cfg = self.p, self.cfg
+        W, VW = cfg["W"], cfg["view_W"]
+        self.L, self.Lv = cfg["multires"], cfg["multires_views"]
+        self.in_ch = (1 + 2 * self.L) * 24 + 72
+        self.w_t = [p[f"pts_linears.{i}.weight"].t().contiguous() for i in range(cfg["D"])]
+        self.b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(cfg["D"])]
+        self.skip_after = set(cfg["skips"])
+        # layer after a skip: input = [x0 | h]  -> two GEMMs instead of a concatenated copy
+        self.w_skip = {i + 1: (self.w_t[i + 1][:self.in_ch].contiguous(), self.w_t[i + 1][self.in_ch:].contiguous())
+                       for i in self.skip_after}
+        self.alpha_w_t = p["alpha_linear.weight"].t().contiguous()
+        self.alpha_b = p["alpha_linear.bias"].contiguous()
+        wv = p["views_linears.0.weight"].double()                       # [VW, W + view_ch + code]
+        wf, bf = p["feature_linear.weight"].double(), p["feature_linear.bias"].double()
+        view_ch = (1 + 2 * self.Lv) * 72
+        # feature_linear (no activation) folded into the view layer: one W -> VW GEMM per sample
+        self.w_fv_t = (wv[:, :W] @ wf).float().t().contiguous()        # [W, VW]
+        b_eff = wv[:, :W] @ bf + p["views_linears.0.bias"].double()
+        # per-joint slices of the view weights: [24, 27, VW] with k = block*3 + axis
+        nb = 1 + 2 * self.Lv
+        self.w_view_j = wv[:, W:W + view_ch].float().reshape(VW, nb, 24, 3).permute(2, 1, 3, 0).reshape(24, nb * 3, VW).contiguous()
+        if cfg["use_framecode"]:
+            codes = p["framecodes.codes.weight"].double()
+            codes = torch.cat([codes, codes.mean(0, keepdim=True)], 0)  # last row: mean code (eval, idx < 0)
+            self.table = (codes @ wv[:, W + view_ch:].t() + b_eff).float().contiguous()
+        else:
+            self.table = b_eff.float().reshape(1, VW).contiguous()
+        self.rgb_w = p["rgb_linear.weight"].contiguous()
+        self.rgb_b = p["rgb_linear.bias"].contiguous()
+        self.cutoff = p["pe_fn.cutoff_dist"].contiguous()
+        self.cutoff_v = p["dirs_pe_fn.cutoff_dist"].contiguous()
+        if not torch.equal(self.cutoff, self.cutoff_v):
+            raise NotImplementedError("distance and view cutoffs differ: the shared cutoff weight no longer applies")
+        self._key_built = key
+
+    def taus(self):
+        t, tv = float(self.p["pe_fn.tau"]), float(self.p["dirs_pe_fn.tau"])
+        if t != tv:
+            raise NotImplementedError("pe_fn.tau != dirs_pe_fn.tau")
+        return t
+
+    # ------------------------------------------------------------------ network forward
+    def view_constants(self, rays_d, skts):
+        """C [24, R, VW]: per-ray, per-joint part of the view layer (before the per-sample cutoff weight)."""
+        self.refresh()
+        E = ops.anerf_view_pe(rays_d, skts, self.Lv)                    # [R, nb*72], block-major
+        R = E.shape[0]
+        nb = 1 + 2 * self.Lv
+        Ej = E.reshape(R, nb, 24, 3).permute(2, 0, 1, 3).reshape(24, R, nb * 3)
+        return torch.bmm(Ej, self.w_view_j)
+
+    def _trunk(self, x0):
+        h = _linear_relu(x0, self.w_t[0], self.b[0])
+        for i in range(1, self.cfg["D"]):
+            if i in self.w_skip:
+                wa, wb = self.w_skip[i]
+                h = _linear_relu(h, wb, None, add=torch.addmm(self.b[i], x0, wa))
+            else:
+                h = _linear_relu(h, self.w_t[i], self.b[i])
+        return h
+
+    def forward_samples(self, rays_o, rays_d, skts, cam_idx=None, z=None, pts=None, view=None, density_only=False):
+        """NeRF.forward on R x S samples -> raw [R,S,4] (density_only: [R*S,1])."""
+        self.refresh()
+        tau = self.taus()
+        if pts is not None:
+            R, S = pts.shape[:2]
+            dev = pts.device
+        else:
+            R, S = z.shape
+            dev = z.device
+        raw = torch.empty(R, S, 4, device=dev, dtype=torch.float32)
+        dens = torch.empty(R * S, 1, device=dev, dtype=torch.float32) if density_only else None
+        C = None if density_only else (self.view_constants(rays_d, skts) if view is None else view)
+        rays_per_chunk = max(1, self.rows_per_chunk // S)
+        n_max = min(R, rays_per_chunk) * S
+        buf = (torch.empty(n_max, self.in_ch, device=dev), torch.empty(n_max, 24, device=dev))
+        for r0 in range(0, R, rays_per_chunk):
+            nr = min(rays_per_chunk, R - r0)
+            n = nr * S
+            x0, w = ops.anerf_encode(rays_o, rays_d, skts, self.align, self.cutoff, tau, self.L, r0 * S, n, z=z, pts=pts,
+                                     out=buf)
+            h = self._trunk(x0)
+            alpha = torch.addmm(self.alpha_b, h, self.alpha_w_t)
+            if density_only:
+                dens[r0 * S:r0 * S + n] = alpha
+                continue
+            featv = h @ self.w_fv_t
+            ops.anerf_color(featv, w, C, self.table, cam_idx if self.cfg["use_framecode"] else None, r0, nr, S,
+                            self.rgb_w, self.rgb_b, alpha.reshape(-1), raw)
+        return dens if density_only else raw
+
+    def density(self, pts, skts, bones=None):
+        return self.forward_samples(None, None, skts, pts=pts.reshape(-1, 1, 3), density_only=True)
+
+    # ------------------------------------------------------------------ RayCaster.render_rays (eval)
+    def near_far(self, rays_o, rays_d, cyls, skts=None, near0=0.0, far0=1.0, chunk=4096):
+        return ops.near_far_cylinder(rays_o, rays_d, cyls, near0, far0, chunk)
+
+    def render(self, rays_o, rays_d, skts, bones, cyls, cam_idx=None, N_samples=None, N_importance=None, chunk=4096,
+               near_far=None, keep=False, **_):
+        cfg = self.cfg
+        S = N_samples or cfg["N_samples"]
+        Sf = N_importance or cfg["N_importance"]
+        B = cfg["density_scale"]
+        self.refresh()
+        near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
+        z = ops.coarse_samples(near, far, S)
+        C = self.view_constants(rays_d, skts)
+        raw = self.forward_samples(rays_o, rays_d, skts, cam_idx, z=z, view=C)
+        out0 = ops.composite(raw, z, rays_d, B)
+        z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
+        raw_f = self.forward_samples(rays_o, rays_d, skts, cam_idx, z=z_fine, view=C)
+        raw_all = ops.merge_samples(raw, raw_f, order)
+        out = ops.composite(raw_all, z_all, rays_d, B)
+        ret = dict(rgb_map=out["rgb_map"], disp_map=out["disp_map"], acc_map=out["acc_map"], alpha=out["alpha"],
+                   T_i=out["weights"], rgb0=out0["rgb_map"], disp0=out0["disp_map"], acc0=out0["acc_map"],
+                   alpha0=out0["alpha"])
+        if keep:
+            ret.update(near=near, far=far, z_coarse=z, raw_coarse=raw, weights_coarse=out0["weights"], z_fine=z_fine,
+                       z_sorted=z_all, sorted_idxs=order, raw_fine=raw_f, raw_sorted=raw_all)
+        return ret

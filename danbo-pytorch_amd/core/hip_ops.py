@@ -279,3 +279,50 @@ def merge_samples(a, b, idx):
     out = torch.empty((R, S + Sf) + tuple(a.shape[2:]), device=a.device, dtype=torch.float32)
     _call("danbo_merge_samples", _p(_f32(a, "a")), _p(_f32(b, "b")), _p(idx), R, S, Sf, C, _p(out), _stream())
     return out
+
+
+# -------------------------------------------------------------------------------------- A-NeRF
+def anerf_encode(rays_o, rays_d, skts, align, cutoff, tau, L, row0, nrows, z=None, pts=None, out=None):
+    """-> x0 [nrows, (1+2L)*24+72], w [nrows,24] for samples [row0, row0+nrows) of the R x S grid."""
+    skts = _f32(skts, "skts")
+    G = skts.shape[0]
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        R, S = pts.shape[0], pts.shape[1]
+        dev = pts.device
+        rays_o = rays_d = z = None
+    else:
+        rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
+        R, S = z.shape
+        dev = z.device
+    in_ch = (1 + 2 * L) * J + 3 * J
+    if out is None:
+        x0 = torch.empty(nrows, in_ch, device=dev, dtype=torch.float32)
+        w = torch.empty(nrows, J, device=dev, dtype=torch.float32)
+    else:
+        x0, w = out[0][:nrows], out[1][:nrows]
+    _call("danbo_anerf_encode_fwd", _p(rays_o), _p(rays_d), _p(z), _p(pts), R, S, G, _p(skts), _p(_f32(align, "align")),
+          _p(_f32(cutoff, "cutoff")), float(tau), int(L), int(row0), int(nrows), _p(x0), _p(w), _stream())
+    return x0, w
+
+
+def anerf_view_pe(rays_d, skts, L):
+    rays_d, skts = _f32(rays_d, "rays_d"), _f32(skts, "skts")
+    R, G = rays_d.shape[0], skts.shape[0]
+    E = torch.empty(R, (1 + 2 * L) * 3 * J, device=rays_d.device, dtype=torch.float32)
+    _call("danbo_anerf_view_pe_fwd", _p(rays_d), _p(skts), R, G, int(L), _p(E), _stream())
+    return E
+
+
+def anerf_color(featv, w, C, table, cam_idx, ray0, nrays, S, rgb_w, rgb_b, alpha, raw_out):
+    """raw_out [R_total,S,4] rows of rays [ray0, ray0+nrays) are written."""
+    VW = featv.shape[1]
+    R_total = C.shape[1]
+    if cam_idx is not None:
+        cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
+        if not cam_idx.is_cuda:
+            raise RuntimeError("cam_idx: expected a CUDA/HIP tensor")
+    _call("danbo_anerf_color_fwd", _p(_f32(featv, "featv")), _p(_f32(w, "w")), _p(_f32(C, "C")), _p(_f32(table, "table")),
+          _p(cam_idx), table.shape[0] - 1, R_total, int(ray0), int(nrays), int(S), VW, _p(_f32(rgb_w, "rgb_w")),
+          _p(_f32(rgb_b, "rgb_b")), _p(_f32(alpha, "alpha")), _p(raw_out), _stream())
+    return raw_out

@@ -82,6 +82,53 @@ class NeRF(nn.Module):
     def collect_encoded(self, encoded_pts, encoded_views):
         return {}
 
+    # ---- A-NeRF (cutoff PE) engine plumbing ----
+    def engine_config(self):
+        emb = self.pts_embedder
+        names = (emb.pts_tr_fn.encoder_name, emb.kp_input_fn.encoder_name, emb.bone_input_fn.encoder_name,
+                 emb.view_input_fn.encoder_name, getattr(emb.ray_tr_fn, 'encoder_name', 'local'))
+        pe, dpe, bpe = self.pe_fn, self.dirs_pe_fn, self.bones_pe_fn
+        ok = (names == ('W2LEncoder', 'RelDist', 'VecNorm', 'VecNorm', 'local')
+              and type(pe).__name__ == 'CutoffEmbedder' and type(dpe).__name__ == 'CutoffEmbedder'
+              and pe.cut_to_cutoff and pe.shift_inputs and pe.cutoff_inputs and not pe.dist_inputs
+              and dpe.dist_inputs and dpe.cutoff_inputs and getattr(bpe, 'num_freqs', 0) == 0
+              and type(bpe).__name__ != 'CutoffEmbedder' and tuple(self.skips) == (4,) and self.view_W <= 256)
+        if not ok:
+            raise NotImplementedError(f"NeRF variant {names}: the HIP path implements the shipped A-NeRF configuration "
+                                      "(reldist + reldir + relray, local rays, use_cutoff, cutoff_viewdir, cutoff_inputs, "
+                                      "cut_to_dist, cutoff_shift)")
+        return dict(nerf_type='nerf', W=self.W, D=self.D, skips=tuple(self.skips), view_W=self.view_W,
+                    multires=pe.num_freqs, multires_views=dpe.num_freqs, use_framecode=self.use_framecode,
+                    density_scale=self.density_scale, use_volume_near_far=False, N_samples=None, N_importance=None)
+
+    def engine(self, align):
+        from ..anerf_engine import AnerfEngine
+        params = {**dict(self.named_parameters()), **dict(self.named_buffers())}
+        key = (next(self.parameters()).device, align.data_ptr())
+        if self._engine is None or self._engine_key != key:
+            self._engine = AnerfEngine(self.engine_config(), {k: v.detach() for k, v in params.items()}, align.to(key[0]))
+            self._engine_key = key
+        else:
+            self._engine.p = {k: v.detach() for k, v in params.items()}
+        return self._engine
+
     def forward(self, inputs, netchunk=1024 * 64):
-        raise NotImplementedError("plain NeRF / A-NeRF forward: the cutoff-PE kernel is not built yet "
-                                  "(DESIGN.md, 'not yet built'); DANBO configs are supported")
+        """inputs: the reference's nerf_inputs dict (core/raycasters.py:399-413) -> raw [R,S,4], encoded"""
+        if self.training:
+            raise NotImplementedError("A-NeRF training (backward of the cutoff-PE kernels) is not built; "
+                                      "the DANBO configs train (core/train_path.py)")
+        pts = inputs['pts']
+        R = pts.shape[0]
+        G = int(inputs.get('N_uniques', 1))
+        skts = inputs['skts']
+        if skts.shape[0] != R:
+            G = skts.shape[0]
+        skts_g = skts if skts.shape[0] == G else skts[::max(skts.shape[0] // G, 1)].contiguous()
+        eng = self.engine(inputs['align_transforms'].reshape(-1, 24, 4, 4)[0])
+        raw = eng.forward_samples(None, inputs['rays_d'].reshape(R, 3), skts_g, inputs.get('cam_idxs'), pts=pts)
+        return raw, {}
+
+    def forward_pts(self, inputs, **kwargs):
+        """density of arbitrary points (reference nerf.py:150-154)"""
+        eng = self.engine(inputs['align_transforms'].reshape(-1, 24, 4, 4)[0])
+        return eng.density(inputs['pts'], inputs['skts'][:1])

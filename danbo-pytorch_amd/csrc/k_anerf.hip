@@ -1,0 +1,228 @@
+// A-NeRF (nerf_type = nerf): the per-sample encoders on either side of the W = 448
+// trunk.  gfx950 only.  The trunk itself is eight plain dense layers and runs as library GEMMs on the
+// rows these kernels produce (core/anerf_engine.py); what is specific to A-NeRF lives here:
+//   k_anerf_encode    bone-local distance + unit direction per joint, joint-distance cutoff PE  -> [n,432]
+//   k_anerf_view_pe   per-RAY positional encoding of the 24 bone-local unit ray directions      -> [R,648]
+//   k_anerf_color     cutoff-weighted view term + frame code + ReLU + rgb head                  -> raw [n,4]
+// The view layer's 648 per-sample inputs are PE(dir)[ray, joint] * w[sample, joint]: the product with
+// views_linears.0 factorises into per-ray, per-joint vectors C[ray, j, :] (24 x 224 floats, made once
+// per ray) and a 24-term weighted sum per sample -- 5 376 MACs instead of 145 152 per sample.
+#include "common.hpp"
+
+namespace danbo {
+
+constexpr int AN_TS = 8;                      // samples per workgroup iteration
+constexpr int AN_BLOCK = AN_TS * J;           // 192 threads: (sample, joint)
+constexpr int AN_MAXL = 8;
+
+// reference: SamplePointsEmbedder.encode_pts (encoders.py:424-450) -> RelDistEncoder / VecNormEncoder
+// (:630-651, :774-795) -> CutoffEmbedder._embed (cutoff_embedder.py:151-214; cut_to_dist, cutoff_shift,
+// cutoff_inputs) -> NeRF.encode_pts cat (nerf.py:222-250)
+__global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d,
+                                                           const float* __restrict__ z, const float* __restrict__ pts,
+                                                           int R, int S, int G, const float* __restrict__ skts,
+                                                           const float* __restrict__ align,
+                                                           const float* __restrict__ cutoff, float tau, int L,
+                                                           long row0, int nrows, float* __restrict__ x0,
+                                                           float* __restrict__ wout) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];  // [AN_TS][in_ch]
+    __shared__ float s_align[J * 16];
+    const int in_ch = (1 + 2 * L) * J + 3 * J;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < J * 16; i += AN_BLOCK) s_align[i] = align[i];
+    const long spp = (long)(R / G) * S;
+    const int sl = tid / J, j = tid % J;
+    const float c = cutoff[j];
+    const float two_over_c = div_rn(2.0f, c);
+    const int ntiles = (nrows + AN_TS - 1) / AN_TS;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        const int row = tile * AN_TS + sl;
+        if (row < nrows) {
+            const long m = row0 + row;
+            const int g = (int)min(m / spp, (long)G - 1);
+            float p[3], pt[3], sk[12];
+            if (pts) { p[0] = pts[3 * m]; p[1] = pts[3 * m + 1]; p[2] = pts[3 * m + 2]; }
+            else {
+                const long r = m / S;
+                const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+                const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+                sample_point(o, d, z[m], p);
+            }
+            const float* src = skts + ((size_t)g * J + j) * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) sk[i] = src[i];
+            bone_local(sk, s_align + 16 * j, p, pt);
+            const float v = sqrtf(add_rn(add_rn(mul_rn(pt[0], pt[0]), mul_rn(pt[1], pt[1])), mul_rn(pt[2], pt[2])));
+            const float den = fmaxf(v, 1e-12f);
+            float* out = s_row + sl * in_ch;
+            const float w = sub_rn(1.0f, sigmoidf_(mul_rn(tau, sub_rn(v, c))));
+            const float inp = sub_rn(c, v);
+            const float sh = sub_rn(mul_rn(inp, two_over_c), 1.0f);
+            out[j] = mul_rn(inp, w);
+            for (int l = 0; l < L; ++l) {
+                float sn, cs;
+                sincosf(mul_rn(sh, (float)(1 << l)), &sn, &cs);
+                out[(1 + 2 * l) * J + j] = mul_rn(sn, w);
+                out[(2 + 2 * l) * J + j] = mul_rn(cs, w);
+            }
+            float* dir = out + (1 + 2 * L) * J + 3 * j;
+            dir[0] = div_rn(pt[0], den);
+            dir[1] = div_rn(pt[1], den);
+            dir[2] = div_rn(pt[2], den);
+            wout[(size_t)row * J + j] = w;
+        }
+        __syncthreads();
+        // coalesced copy-out of the finished rows
+        const int base = tile * AN_TS;
+        const int live = min(AN_TS, nrows - base) * in_ch;
+        float* dst = x0 + (size_t)base * in_ch;
+        for (int i = tid; i < live; i += AN_BLOCK) dst[i] = s_row[i];
+    }
+}
+
+// reference: transform_batch_rays (encoders.py:305-317) -> VecNormEncoder -> the frequency part of
+// CutoffEmbedder._embed with dist_inputs (cutoff_embedder.py:156-166); the cutoff weight is applied per
+// sample in k_anerf_color.  E[ray][b*72 + 3j + k], b = 0: d, 1+2l: sin(2^l d), 2+2l: cos(2^l d)
+__global__ __launch_bounds__(256) void k_anerf_view_pe(const float* __restrict__ rays_d, const float* __restrict__ skts,
+                                                       int R, int G, int L, float* __restrict__ E) {
+    const int rays_per_pose = R / G;
+    const int stride = (1 + 2 * L) * 3 * J;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * J; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / J), j = (int)(i % J);
+        const float* M = skts + ((size_t)min(r / rays_per_pose, G - 1) * J + j) * 16;
+        const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        float q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            q[a] = add_rn(add_rn(mul_rn(M[4 * a], d[0]), mul_rn(M[4 * a + 1], d[1])), mul_rn(M[4 * a + 2], d[2]));
+        const float nrm = sqrtf(add_rn(add_rn(mul_rn(q[0], q[0]), mul_rn(q[1], q[1])), mul_rn(q[2], q[2])));
+        const float den = fmaxf(nrm, 1e-12f);
+        float* out = E + (size_t)r * stride + 3 * j;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float u = div_rn(q[k], den);
+            out[k] = u;
+            for (int l = 0; l < L; ++l) {
+                float sn, cs;
+                sincosf(mul_rn(u, (float)(1 << l)), &sn, &cs);
+                out[(1 + 2 * l) * 3 * J + k] = sn;
+                out[(2 + 2 * l) * 3 * J + k] = cs;
+            }
+        }
+    }
+}
+
+// reference: the view branch of NeRF.inference (nerf.py:196-209) on encode_views' output (nerf.py:252-279).
+// One wavefront per ray: the ray's 24 x VW joint vectors stay in registers while its S samples stream by.
+//   x[c]   = relu(featv[row][c] + table[cam][c] + sum_j w[row][j] * C[j][ray][c])
+//   raw    = (rgb_w x + rgb_b, alpha[row])
+constexpr int AN_VW_MAX = 256;  // 4 columns per lane
+__global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ featv, const float* __restrict__ w,
+                                                     const float* __restrict__ C, const float* __restrict__ table,
+                                                     const int64_t* __restrict__ cam_idx, int n_codes, int R_total,
+                                                     int ray0, int nrays, int S, int VW,
+                                                     const float* __restrict__ rgb_w, const float* __restrict__ rgb_b,
+                                                     const float* __restrict__ alpha, float* __restrict__ raw_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float rw[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) rw[ch][i] = c < VW ? rgb_w[ch * VW + c] : 0.f;
+    }
+    const float rb0 = rgb_b[0], rb1 = rgb_b[1], rb2 = rgb_b[2];
+    for (int rl = wave_global; rl < nrays; rl += nwaves) {
+        const int ray = ray0 + rl;
+        float cj[J][4];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                cj[j][i] = c < VW ? C[((size_t)j * R_total + ray) * VW + c] : 0.f;
+            }
+        long code = n_codes;  // the mean code (Optcodes eval with idx < 0)
+        if (cam_idx) {
+            const long idx = cam_idx[ray];
+            if (idx >= 0) code = idx < n_codes ? idx : n_codes - 1;
+        }
+        float tb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            tb[i] = c < VW ? table[(size_t)code * VW + c] : 0.f;
+        }
+        for (int s = 0; s < S; ++s) {
+            const size_t row = (size_t)rl * S + s;
+            const float* wr = w + row * J;
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                x[i] = c < VW ? featv[row * VW + c] + tb[i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float wj = wr[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = fmaf(wj, cj[j][i], x[i]);
+            }
+            float pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xr = fmaxf(x[i], 0.f);
+                pr = fmaf(xr, rw[0][i], pr);
+                pg = fmaf(xr, rw[1][i], pg);
+                pb = fmaf(xr, rw[2][i], pb);
+            }
+            pr = wave_sum(pr); pg = wave_sum(pg); pb = wave_sum(pb);
+            if (lane == 0)
+                reinterpret_cast<float4*>(raw_out)[(size_t)ray * S + s] = make_float4(pr + rb0, pg + rb1, pb + rb2, alpha[row]);
+        }
+    }
+}
+
+}  // namespace danbo
+
+using namespace danbo;
+
+extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
+                                 int S, int G, const float* skts, const float* align, const float* cutoff, float tau,
+                                 int L, long row0, int nrows, float* x0, float* w_out, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0 && L >= 0 && L <= AN_MAXL && nrows >= 0 && row0 >= 0);
+    DANBO_CHECK_ARG(row0 + nrows <= (long)R * S && skts && align && cutoff && x0 && w_out);
+    DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr) && (pts || (rays_o && rays_d)));
+    if (nrows == 0) return 0;
+    const int in_ch = (1 + 2 * L) * J + 3 * J;
+    const int ntiles = ceil_div(nrows, AN_TS);
+    const int grid = ntiles < NUM_CU * 8 ? ntiles : NUM_CU * 8;
+    hipLaunchKernelGGL(k_anerf_encode, dim3(grid), dim3(AN_BLOCK), AN_TS * in_ch * sizeof(float), (hipStream_t)stream,
+                       rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, L, row0, nrows, x0, w_out);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_anerf_view_pe_fwd(const float* rays_d, const float* skts, int R, int G, int L, float* E, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && L >= 0 && L <= AN_MAXL && rays_d && skts && E);
+    hipLaunchKernelGGL(k_anerf_view_pe, dim3(stream_grid((long)R * J, 256)), dim3(256), 0, (hipStream_t)stream, rays_d,
+                       skts, R, G, L, E);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_anerf_color_fwd(const float* featv, const float* w, const float* C, const float* table,
+                                const int64_t* cam_idx, int n_codes, int R_total, int ray0, int nrays, int S, int VW,
+                                const float* rgb_w, const float* rgb_b, const float* alpha, float* raw_out,
+                                void* stream) {
+    DANBO_CHECK_ARG(featv && w && C && table && rgb_w && rgb_b && alpha && raw_out);
+    DANBO_CHECK_ARG(VW > 0 && VW <= AN_VW_MAX && S > 0 && nrays >= 0 && ray0 >= 0 && ray0 + nrays <= R_total && n_codes >= 0);
+    if (nrays == 0) return 0;
+    const int blocks = ceil_div(nrays, 4);
+    const int grid = blocks < NUM_CU * 8 ? blocks : NUM_CU * 8;
+    hipLaunchKernelGGL(k_anerf_color, dim3(grid), dim3(256), 0, (hipStream_t)stream, featv, w, C, table, cam_idx, n_codes,
+                       R_total, ray0, nrays, S, VW, rgb_w, rgb_b, alpha, raw_out);
+    DANBO_LAUNCH_RET();
+}

@@ -238,6 +238,35 @@ int danbo_importance_samples(const float* z, const float* weights, int R, int S,
 int danbo_merge_samples(const float* a /*[R,S,C]*/, const float* b /*[R,Sf,C]*/, const int32_t* sorted_idx,
                         int R, int S, int Sf, int C, float* out /*[R,S+Sf,C]*/, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A-NeRF (nerf_type = nerf): the per-sample encoders around the W = 448 trunk.
+ * The trunk's dense layers are plain GEMMs on the rows produced here (core/anerf_engine.py).
+ * ------------------------------------------------------------------------------------------- */
+
+/* SamplePointsEmbedder.encode_pts (core/encoders.py:424-450) with RelDistEncoder (:630-651) and
+ * VecNormEncoder (:774-795), then CutoffEmbedder._embed (core/cutoff_embedder.py:151-214; cut_to_dist,
+ * cutoff_shift, cutoff_inputs) and the cat of NeRF.encode_pts (core/networks/nerf.py:222-250), for the
+ * samples [row0, row0 + nrows) of the R x S grid (either z [R,S] + rays, or pts [R*S,3]):
+ *   x0   [nrows, (1+2L)*24 + 72] = [ (c-v)w | sin(2^l sh)w | cos(2^l sh)w ... (block-major, joint-minor) | unit dirs ]
+ *   w_out[nrows, 24]             = 1 - sigmoid(tau (v - c))     (re-used by danbo_anerf_color_fwd) */
+int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                     const float* skts /*[G,24,4,4]*/, const float* align /*[24,4,4]*/, const float* cutoff /*[24]*/,
+                     float tau, int L, long row0, int nrows, float* x0, float* w_out, void* stream);
+
+/* transform_batch_rays (core/encoders.py:305-317) + VecNormEncoder + the sin/cos part of the view
+ * CutoffEmbedder (dist_inputs; core/cutoff_embedder.py:156-166): E [R, (1+2L)*72], block-major. */
+int danbo_anerf_view_pe_fwd(const float* rays_d, const float* skts, int R, int G, int L, float* E, void* stream);
+
+/* view branch of NeRF.inference (core/networks/nerf.py:196-209) for the rays [ray0, ray0+nrays) whose
+ * S samples are rows [0, nrays*S) of featv / w / alpha:
+ *   x = relu(featv[row] + table[code(ray)] + sum_j w[row,j] C[j,ray,:]);  raw[ray,s] = (rgb_w x + rgb_b, alpha[row])
+ * featv = (views_linears.0[:, :W] feature_linear) h  [rows,VW];  C [24,R_total,VW] = per-ray, per-joint
+ * products of views_linears.0 with E;  table [n_codes+1,VW] = frame-code part + folded biases, last row =
+ * mean code (Optcodes eval, core/networks/embedding.py:22-23);  cam_idx int64 [R_total] or NULL. */
+int danbo_anerf_color_fwd(const float* featv, const float* w, const float* C, const float* table, const int64_t* cam_idx,
+                    int n_codes, int R_total, int ray0, int nrays, int S, int VW, const float* rgb_w,
+                    const float* rgb_b, const float* alpha, float* raw_out /*[R_total,S,4]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

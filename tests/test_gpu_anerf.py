@@ -1,0 +1,143 @@
+"""GPU parity tests of the A-NeRF path (cutoff PE kernels + W = 448 trunk + colour head) against the numpy
+oracle and against the reference's own outputs (tests/golden/anerf_stages.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import danbo_oracle as o
+from helpers import ROOT, golden, oracle_for, max_err, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(x, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device=DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def env():
+    from core.config import parse_args
+    from core.raycasters import create_raycaster
+    from core.utils import synthetic as syn
+    from core.utils.skeleton_utils import SMPLSkeleton
+    g = golden("anerf_stages")
+    args = parse_args(["--no_reload"], config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", "h36m_zju", "anerf_base.txt"))
+    n_codes = int(g["n_framecodes"])
+    da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=n_codes, rest_pose=syn.rest_pose(0.48), hwf=(64, 64, 80.))
+    tr, te, *_ = create_raycaster(args, da, device=DEV)
+    caster = te["ray_caster"].eval()
+    orc, cfg, sd, rest = oracle_for(g)
+    caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    kw = {k: v for k, v in te.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
+    return g, caster, kw, orc
+
+
+def call(caster, kw, g):
+    pose = g["pose_of_ray"]
+    return caster(T(g["ray_batch"]), N_samples=int(g["N_samples"]), kp_batch=T(g["kps"][pose]), skts=T(g["skts"][pose]),
+                  cyls=T(g["cyls"][pose]), bones=T(g["bones"][pose]), cams=T(g["cam_idx"], torch.int64),
+                  N_importance=int(g["N_importance"]), N_uniques=2, **kw)
+
+
+def test_encode_kernel_matches_reference_density_inputs(env):
+    from core import hip_ops as ops
+    g, caster, kw, orc = env
+    eng = caster._engine()
+    rb = g["ray_batch"]
+    R, S = g["z_coarse"].shape
+    x0, w = ops.anerf_encode(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), eng.align, eng.cutoff, 20.0, 7, 0, R * S,
+                             z=T(g["z_coarse"]))
+    assert x0.shape == (R * S, 432)
+    # sin(64 sh) with sh = (c - v) 2/c - 1 amplifies 1e-6 of distance round-off 256x
+    assert max_err(N(x0), g["density_inputs"]) < 2e-4
+    assert max_err(N(x0)[:, 360:], g["r"].reshape(-1, 72)) < 3e-6
+    wo = 1.0 - 1.0 / (1.0 + np.exp(-20.0 * (g["v"].reshape(-1, 24).astype(np.float64) - 0.5)))
+    assert max_err(N(w), wo) < 2e-5
+    # a window of rows, and explicit points instead of (rays, z), give the same rows bit for bit
+    x1, w1 = ops.anerf_encode(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), eng.align, eng.cutoff, 20.0, 7, 5 * S, 3 * S + 1,
+                              z=T(g["z_coarse"]))
+    assert torch.equal(x1, x0[5 * S:8 * S + 1]) and torch.equal(w1, w[5 * S:8 * S + 1])
+    x2, _ = ops.anerf_encode(None, None, T(g["skts"]), eng.align, eng.cutoff, 20.0, 7, 0, R * S, pts=T(g["pts"]))
+    assert max_err(N(x2), N(x0)) < 2e-4
+
+
+def test_view_direction_encoding(env):
+    from core import hip_ops as ops
+    g, caster, kw, orc = env
+    E = N(ops.anerf_view_pe(T(g["ray_batch"][:, 3:6]), T(g["skts"]), 4))
+    assert E.shape == (48, 648)
+    assert max_err(E[:, :72], g["view_dirs"]) < 1e-6
+    d = g["view_dirs"].astype(np.float64)
+    for l in range(4):
+        assert max_err(E[:, 72 * (1 + 2 * l):72 * (2 + 2 * l)], np.sin(d * 2 ** l)) < 2e-6
+        assert max_err(E[:, 72 * (2 + 2 * l):72 * (3 + 2 * l)], np.cos(d * 2 ** l)) < 2e-6
+
+
+def test_model_forward_matches_reference_raw(env):
+    g, caster, kw, orc = env
+    pose = g["pose_of_ray"]
+    rb = g["ray_batch"]
+    inputs = dict(pts=T(g["pts"]), kps=T(g["kps"][pose]), skts=T(g["skts"][pose]), bones=T(g["bones"][pose]),
+                  rest_pose=T(g["rest_pose"]).reshape(1, 1, 24, 3), align_transforms=caster.transforms[:1, None].to(DEV),
+                  N_uniques=2, rays_o=T(rb[:, None, 0:3]), rays_d=T(rb[:, None, 3:6]), cam_idxs=T(g["cam_idx"], torch.int64))
+    raw, enc = caster.network(inputs)
+    assert raw.shape == (48, 12, 4)
+    assert rel_err(N(raw), g["raw_coarse"], floor=1.0) < 2e-4
+    # small row chunks (whole rays per chunk) give the same result
+    caster._engine().rows_per_chunk = 5 * 12
+    raw2, _ = caster.network(inputs)
+    caster._engine().rows_per_chunk = 1 << 18
+    assert rel_err(N(raw2), N(raw), floor=1.0) < 1e-5
+
+
+def test_caster_call_matches_reference_maps_tau20_and_tau2000(env):
+    g, caster, kw, orc = env
+    out = call(caster, kw, g)
+    assert set(out) == {"rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0"}
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
+        assert max_err(N(out[k]), g["final_" + k]) < 1e-3, k
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 65.0
+    net = caster.network
+    with torch.no_grad():
+        net.pe_fn.tau.fill_(2000.0)
+        net.dirs_pe_fn.tau.fill_(2000.0)
+    try:
+        out = call(caster, kw, g)
+        assert max_err(N(out["rgb_map"]), g["tau2000_final_rgb_map"]) < 5e-3
+        assert o.psnr(N(out["rgb_map"]), g["tau2000_final_rgb_map"]) > 55.0
+    finally:
+        with torch.no_grad():
+            net.pe_fn.tau.fill_(20.0)
+            net.dirs_pe_fn.tau.fill_(20.0)
+
+
+def test_full_render_against_oracle_and_density_query(env):
+    """more rays than one chunk, mean frame code (cams = -1), and forward_pts density"""
+    from core.utils import synthetic as syn
+    g, caster, kw, orc = env
+    scene = syn.make_scene(n_poses=1, H=24, W=24, n_views=1, pose_seed=3)
+    ro, rd = scene["rays"][0]
+    rb = syn.ray_batch(ro, rd)
+    R = len(ro)
+    z = np.zeros(R, np.int64)
+    caster._engine().rows_per_chunk = 100 * 16
+    out = caster(T(rb), N_samples=16, kp_batch=T(scene["kps"][z]), skts=T(scene["skts"][z]), cyls=T(scene["cyls"][z]),
+                 bones=T(scene["bones"][z]), cams=T(-np.ones(R), torch.int64), N_importance=8, N_uniques=1, **kw)
+    caster._engine().rows_per_chunk = 1 << 18
+    ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], cam_idxs=-np.ones(R, np.int64),
+                     n_uniques=1, N_samples=16, N_importance=8, chunk=R)
+    assert max_err(N(out["rgb_map"]), ref["rgb_map"]) < 2e-3
+    assert o.psnr(N(out["rgb_map"]), ref["rgb_map"]) > 60.0
+    assert max_err(N(out["acc_map"]), ref["acc_map"]) < 2e-3
+    pts = np.random.default_rng(0).uniform(-0.6, 0.6, size=(500, 3)).astype(np.float32) + scene["kps"][0, 0]
+    dens = caster(T(pts).reshape(-1, 1, 3), T(scene["kps"]), T(scene["skts"]), T(scene["bones"]), fwd_type="density")
+    raw, _ = orc.forward(pts.reshape(-1, 1, 3), np.zeros((500, 3), np.float32) + [0, 0, 1],
+                         np.repeat(scene["skts"], 500, 0), cam_idxs=None)
+    assert rel_err(N(dens).reshape(-1), raw[:, 0, 3], floor=1.0) < 2e-4
