@@ -138,12 +138,10 @@ struct Pipe {
 __device__ __forceinline__ void pipe_issue(Pipe& p) {
     const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 4096 + p.lane * 16;
     char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 4096;
-#ifndef DANBO_DBG_NOSTREAM
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-#endif
     p.issue_chunk = p.issue_chunk + 1 == NCH_TOTAL ? 0 : p.issue_chunk + 1;
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
 }
@@ -162,16 +160,10 @@ __device__ __forceinline__ void pipe_handover(Pipe& p) {
 }
 
 __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
-#ifdef DANBO_DBG_NOLDS
-    half8 r; for (int e = 0; e < 8; ++e) r[e] = (_Float16)(float)(((size_t)base >> 4) + piece + e); return r;
-#endif
     return *reinterpret_cast<const half8*>(base + piece * 1024);
 }
 
 __device__ __forceinline__ void mfma3(f32x4& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
-#ifdef DANBO_DBG_NOMFMA
-    acc[0] += (float)ah[0] + (float)al[1]; acc[1] += (float)bh[0]; acc[2] += (float)bl[0]; return;
-#endif
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
