@@ -271,6 +271,48 @@ def importance_samples(z, weights, Sf, u=None):
     return zs, zf, idx
 
 
+def composite_importance(raw, z, rays_d, Sf, B=1.0, noise=None, u=None, bits=None, raw_empty=None, want_weights=True):
+    """coarse composite + importance resampling in one launch (S, Sf <= 64) ->
+    (out0 dict, z_sorted, z_fine, sorted_idx); bits/raw_empty: un-filled raw (see danbo_hip.h)."""
+    raw, z, rays_d = _f32(raw, "raw"), _f32(z, "z"), _f32(rays_d, "rays_d")
+    R, S = z.shape
+    dev = raw.device
+    rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+    disp = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    w = torch.empty(R, S, device=dev, dtype=torch.float32) if want_weights else None
+    al = torch.empty(R, S, device=dev, dtype=torch.float32)
+    zf = torch.empty(R, Sf, device=dev, dtype=torch.float32)
+    zs = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
+    idx = torch.empty(R, S + Sf, device=dev, dtype=torch.int32)
+    _call("danbo_composite_importance_fwd", _p(raw), _p(_f32(raw_empty, "raw_empty")), _p(bits), _p(z), _p(rays_d), R, S,
+          int(Sf), float(B), _p(_f32(noise, "noise")), _p(_f32(u, "u")), _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _p(zf),
+          _p(zs), _p(idx), _stream())
+    return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al), zs, zf, idx
+
+
+def composite_merged(raw_a, raw_b, idx, z_sorted, rays_d, B=1.0, noise=None, bits_a=None, bits_b=None, raw_empty=None,
+                     want_raw=False):
+    """final composite reading the coarse / importance raw through the sorted order (no merged copy)"""
+    raw_a, raw_b, rays_d = _f32(raw_a, "raw_a"), _f32(raw_b, "raw_b"), _f32(rays_d, "rays_d")
+    R, S = raw_a.shape[:2]
+    Sf = raw_b.shape[1]
+    dev = raw_a.device
+    rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+    disp = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    w = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
+    al = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
+    rs = torch.empty(R, S + Sf, 4, device=dev, dtype=torch.float32) if want_raw else None
+    _call("danbo_composite_merged_fwd", _p(raw_a), _p(raw_b), _p(_f32(raw_empty, "raw_empty")), _p(bits_a), _p(bits_b),
+          _p(idx), _p(_f32(z_sorted, "z_sorted")), _p(rays_d), R, S, Sf, float(B), _p(_f32(noise, "noise")), _p(rgb),
+          _p(disp), _p(acc), _p(w), _p(al), _p(rs), _stream())
+    out = dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
+    if want_raw:
+        out["raw_sorted"] = rs
+    return out
+
+
 def merge_samples(a, b, idx):
     """a [R,S,C], b [R,Sf,C], idx int32 [R,S+Sf] -> [R,S+Sf,C]"""
     R, S = a.shape[:2]

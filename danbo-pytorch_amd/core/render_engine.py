@@ -107,7 +107,7 @@ class DanboEngine:
                                self.code_table)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None):
+                        want_confd=False, volumes=None, view=None, fill=True):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
@@ -123,7 +123,8 @@ class DanboEngine:
             h, confd = ops.gather_assign_blend16(geo, vols, bits, self.aw, self.assign16, lst, cnt, geo.M, want_confd)
         else:
             h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
-        raw = ops.fill_raw(raw_empty, S)
+        # fill=False: rows outside every volume stay unwritten; the consumer reads raw_empty for them (valid_bits == 0)
+        raw = ops.fill_raw(raw_empty, S) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -164,13 +165,23 @@ class DanboEngine:
         z = ops.coarse_samples(near, far, S)
         vols = self.volumes(bones)
         view = self.view_constants(rays_d, skts, cam_idx)
-        raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view)
-        out0 = ops.composite(raw, z, rays_d, B)
-        z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
+        fused = S <= 64 and Sf <= 64
+        lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
+        raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
+                                       fill=not lazy)
+        if fused:
+            out0, z_all, z_fine, order = ops.composite_importance(
+                raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
+                want_weights=keep)
+        else:
+            out0 = ops.composite(raw, z, rays_d, B)
+            z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
         raw_f, ex_f = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z_fine, dense=dense,
-                                           volumes=vols, view=view)
-        raw_all = ops.merge_samples(raw, raw_f, order)
-        out = ops.composite(raw_all, z_all, rays_d, B)
+                                           volumes=vols, view=view, fill=not lazy)
+        out = ops.composite_merged(raw, raw_f, order, z_all, rays_d, B, bits_a=ex["valid_bits"] if lazy else None,
+                                   bits_b=ex_f["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
+                                   want_raw=keep)
+        raw_all = out.get("raw_sorted")
         ret = dict(rgb_map=out["rgb_map"], disp_map=out["disp_map"], acc_map=out["acc_map"], alpha=out["alpha"],
                    T_i=out["weights"], rgb0=out0["rgb_map"], disp0=out0["disp_map"], acc0=out0["acc_map"],
                    alpha0=out0["alpha"])

@@ -30,6 +30,35 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- wave64 scans on the DPP cross-lane paths of the VALU (no LDS crossbar traffic) ----
+// inclusive scan: row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast15 / row_bcast31 carry the row
+// totals across rows (gfx9 DPP controls; lanes without a source keep the identity)
+#define DANBO_DPP_STEP(OP, IDENT, CTRL, ROWMASK)                                                              \
+    {                                                                                                          \
+        const int t_ = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(IDENT)),                    \
+                                                   __builtin_bit_cast(int, x), CTRL, ROWMASK, 0xf, false);     \
+        x = OP(x, __builtin_bit_cast(float, t_));                                                              \
+    }
+__device__ __forceinline__ float dpp_add_(float a, float b) { return add_rn(a, b); }
+__device__ __forceinline__ float dpp_mul_(float a, float b) { return mul_rn(a, b); }
+
+__device__ __forceinline__ float wave_scan_add(float x) {
+    DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
+    DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x118, 0xf)
+    DANBO_DPP_STEP(dpp_add_, 0.f, 0x142, 0xa) DANBO_DPP_STEP(dpp_add_, 0.f, 0x143, 0xc)
+    return x;
+}
+__device__ __forceinline__ float wave_scan_mul(float x) {
+    DANBO_DPP_STEP(dpp_mul_, 1.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_mul_, 1.f, 0x112, 0xf)
+    DANBO_DPP_STEP(dpp_mul_, 1.f, 0x114, 0xf) DANBO_DPP_STEP(dpp_mul_, 1.f, 0x118, 0xf)
+    DANBO_DPP_STEP(dpp_mul_, 1.f, 0x142, 0xa) DANBO_DPP_STEP(dpp_mul_, 1.f, 0x143, 0xc)
+    return x;
+}
+// total of the wave in every lane (summation order = the scan's tree)
+__device__ __forceinline__ float wave_total(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_add(x)), 63));
+}
+
 // number of rows a kernel has to process: device-side count (clamped to capacity) or host n
 __device__ __forceinline__ int resolve_count(const int32_t* count, int n_cap) {
     if (count == nullptr) return n_cap;

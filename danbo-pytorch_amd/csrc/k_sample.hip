@@ -390,8 +390,56 @@ __global__ __launch_bounds__(256) void k_merge_samples(const float* __restrict__
 }
 
 // ======================================================================================
-// K4: alpha compositing, one wavefront per ray, exclusive cumprod by wave scan
+// K4: alpha compositing, one wavefront per ray (lane = sample), scans on the DPP paths
 // ======================================================================================
+struct CompositeState {
+    float carry, sr, sg, sb, sd, sa;
+};
+
+// one 64-sample chunk of a ray: rw = raw of this lane's sample, zs its depth, gap = z[s+1] - z[s] (1e10 for the
+// last sample of the ray), nz = optional density noise.  Returns the sample's weight; al = its alpha.
+__device__ __forceinline__ float composite_chunk(CompositeState& st, const float4 rw, float zs, float gap, float dn,
+                                                 float B, bool has_noise, float nz, bool act, int lane, float& al) {
+    const float dist = mul_rn(gap, dn);
+    float sig = div_rn(rw.w, B);
+    if (has_noise) sig = add_rn(sig, nz);
+    sig = fmaxf(sig, 0.f);
+    al = sub_rn(1.0f, expf(-mul_rn(sig, dist)));
+    if (!act) al = 0.f;
+    const float t = act ? add_rn(sub_rn(1.0f, al), 1e-10f) : 1.0f;
+    const float p = wave_scan_mul(t);  // inclusive product
+    float excl = __shfl_up(p, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float T = mul_rn(st.carry, excl);
+    st.carry = mul_rn(st.carry, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 63)));
+    const float w = mul_rn(al, T);
+    const float cr = sub_rn(mul_rn(sigmoidf_(rw.x), 1.002f), 0.001f);
+    const float cg = sub_rn(mul_rn(sigmoidf_(rw.y), 1.002f), 0.001f);
+    const float cb = sub_rn(mul_rn(sigmoidf_(rw.z), 1.002f), 0.001f);
+    st.sr += wave_total(w * cr);
+    st.sg += wave_total(w * cg);
+    st.sb += wave_total(w * cb);
+    st.sd += wave_total(w * zs);
+    st.sa += wave_total(w);
+    return w;
+}
+
+__device__ __forceinline__ void composite_finish(const CompositeState& st, int r, float* __restrict__ rgb_map,
+                                                 float* __restrict__ disp, float* __restrict__ acc_out) {
+    rgb_map[3 * r] = st.sr;
+    rgb_map[3 * r + 1] = st.sg;
+    rgb_map[3 * r + 2] = st.sb;
+    float dsp = div_rn(1.0f, fmaxf(1e-10f, div_rn(st.sd, add_rn(st.sa, 1e-10f))));
+    if (fabsf(st.sa) <= 1e-8f) dsp = 0.f;
+    disp[r] = dsp;
+    acc_out[r] = fminf(st.sa, 1.0f);
+}
+
+__device__ __forceinline__ float ray_norm(const float* __restrict__ rays_d, int r) {
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
+    return sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz_, dz_)));
+}
+
 __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ raw, const float* __restrict__ z,
                                                    const float* __restrict__ rays_d, int R, int S, float B,
                                                    const float* __restrict__ noise, float* __restrict__ rgb_map,
@@ -401,57 +449,70 @@ __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ ra
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int r = wave; r < R; r += nwaves) {
-        const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
-        const float dn = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz_, dz_)));
-        float carry = 1.0f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+        const float dn = ray_norm(rays_d, r);
+        CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int s = c0 + lane;
             const bool act = s < S;
             const size_t m = (size_t)r * S + (act ? s : S - 1);
-            const float4 rw = raw[m];
             const float zs = z[m];
-            const float zn = (s + 1 < S) ? z[m + 1] : zs;
-            const float dist = mul_rn((s + 1 < S) ? sub_rn(zn, zs) : 1e10f, dn);
-            float sig = div_rn(rw.w, B);
-            if (noise) sig = add_rn(sig, noise[m]);
-            sig = fmaxf(sig, 0.f);
-            float al = sub_rn(1.0f, expf(-mul_rn(sig, dist)));
-            if (!act) al = 0.f;
-            const float t = act ? add_rn(sub_rn(1.0f, al), 1e-10f) : 1.0f;
-            // inclusive product scan across the wave
-            float p = t;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float q = __shfl_up(p, off, 64);
-                if (lane >= off) p = mul_rn(p, q);
-            }
-            float excl = __shfl_up(p, 1, 64);
-            if (lane == 0) excl = 1.0f;
-            const float T = mul_rn(carry, excl);
-            carry = mul_rn(carry, __shfl(p, 63, 64));
-            const float w = mul_rn(al, T);
+            const float gap = (s + 1 < S) ? sub_rn(z[m + 1], zs) : 1e10f;
+            float al;
+            const float w = composite_chunk(st, raw[m], zs, gap, dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
             if (act) {
                 if (weights) weights[m] = w;
                 if (alpha_out) alpha_out[m] = al;
             }
-            const float cr = sub_rn(mul_rn(sigmoidf_(rw.x), 1.002f), 0.001f);
-            const float cg = sub_rn(mul_rn(sigmoidf_(rw.y), 1.002f), 0.001f);
-            const float cb = sub_rn(mul_rn(sigmoidf_(rw.z), 1.002f), 0.001f);
-            sr += wave_sum(w * cr);
-            sg += wave_sum(w * cg);
-            sb += wave_sum(w * cb);
-            sd += wave_sum(w * zs);
-            sa += wave_sum(w);
         }
-        if (lane == 0) {
-            rgb_map[3 * r] = sr;
-            rgb_map[3 * r + 1] = sg;
-            rgb_map[3 * r + 2] = sb;
-            float dsp = div_rn(1.0f, fmaxf(1e-10f, div_rn(sd, add_rn(sa, 1e-10f))));
-            if (fabsf(sa) <= 1e-8f) dsp = 0.f;
-            disp[r] = dsp;
-            acc_out[r] = fminf(sa, 1.0f);
+        if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
+    }
+}
+
+// The last composite of the two-pass render without materialising the merged raw tensor: sample i of the sorted
+// order is fetched from the coarse (src < S) or the importance (src >= S) pass through sorted_idx
+// (merge_samples, core/raycasters.py:745-761, folded into raw2outputs).  bits_* / raw_empty (optional): samples
+// whose in-volume word is 0 were never written by K3 and take the ray's empty-space raw instead.
+__global__ __launch_bounds__(256) void k_composite_merged(const float4* __restrict__ raw_a, const float4* __restrict__ raw_b,
+                                                          const float4* __restrict__ raw_empty,
+                                                          const uint32_t* __restrict__ bits_a,
+                                                          const uint32_t* __restrict__ bits_b,
+                                                          const int32_t* __restrict__ sorted_idx,
+                                                          const float* __restrict__ z, const float* __restrict__ rays_d,
+                                                          int R, int S, int Sf, float B, const float* __restrict__ noise,
+                                                          float* __restrict__ rgb_map, float* __restrict__ disp,
+                                                          float* __restrict__ acc_out, float* __restrict__ weights,
+                                                          float* __restrict__ alpha_out, float4* __restrict__ raw_sorted) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int St = S + Sf;
+    for (int r = wave; r < R; r += nwaves) {
+        const float dn = ray_norm(rays_d, r);
+        CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < St; c0 += 64) {
+            const int s = c0 + lane;
+            const bool act = s < St;
+            const size_t m = (size_t)r * St + (act ? s : St - 1);
+            const int src = sorted_idx[m];
+            float4 rw;
+            if (src < S) {
+                const size_t q = (size_t)r * S + src;
+                rw = (bits_a && bits_a[q] == 0u) ? raw_empty[r] : raw_a[q];
+            } else {
+                const size_t q = (size_t)r * Sf + (src - S);
+                rw = (bits_b && bits_b[q] == 0u) ? raw_empty[r] : raw_b[q];
+            }
+            const float zs = z[m];
+            const float gap = (s + 1 < St) ? sub_rn(z[m + 1], zs) : 1e10f;
+            float al;
+            const float w = composite_chunk(st, rw, zs, gap, dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+            if (act) {
+                if (weights) weights[m] = w;
+                if (alpha_out) alpha_out[m] = al;
+                if (raw_sorted) raw_sorted[m] = rw;
+            }
         }
+        if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
     }
 }
 
@@ -489,59 +550,63 @@ __global__ __launch_bounds__(64) void k_importance(const float* __restrict__ z, 
     }
 }
 
-// S <= 64 and Sf <= 64: one wavefront per ray.  Lane i holds coarse sample i (pdf bin, cdf by
-// shuffle scan); lane k additionally draws fine sample k (binary search in the cdf through
-// shuffles); the merged order comes from ranks counted with broadcast compares -- no sort,
-// no scratch memory, every global access coalesced.
-__global__ __launch_bounds__(256) void k_importance_wave(const float* __restrict__ z, const float* __restrict__ weights,
-                                                         int R, int S, int Sf, const float* __restrict__ u,
-                                                         float* __restrict__ z_fine, float* __restrict__ z_sorted,
-                                                         int32_t* __restrict__ sorted_idx) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+// S <= 64 and Sf <= 64: one wavefront per ray.  Lane i holds coarse sample i (pdf bin, cdf by a DPP scan);
+// lane k additionally draws fine sample k (binary search in the cdf through shuffles); the merged order comes
+// from ranks -- two more binary searches when the draws are the sorted linspace (eval), broadcast compares for
+// random draws -- no sort, no scratch memory, every global access coalesced.
+//   zi / wi: this lane's coarse depth (INFINITY beyond S) and weight (0 beyond S)
+template <bool DET>
+__device__ __forceinline__ void importance_wave(float zi, float wi, int r, int S, int Sf, const float* __restrict__ u,
+                                                int lane, float* __restrict__ z_fine, float* __restrict__ z_sorted,
+                                                int32_t* __restrict__ sorted_idx) {
     const int nb = S - 2, ncdf = S - 1;
-    for (int r = wave; r < R; r += nwaves) {
-        const bool cact = lane < S;
-        const float zi = cact ? z[(size_t)r * S + lane] : INFINITY;
-        const float wi = cact ? weights[(size_t)r * S + lane] : 0.f;
-        const float w1 = __shfl_down(wi, 1, 64), w2 = __shfl_down(wi, 2, 64);
-        const float z1 = __shfl_down(zi, 1, 64);
-        float dw = 0.f;
-        if (lane < nb) dw = add_rn(add_rn(mul_rn(0.5f, add_rn(fmaxf(wi, w1), fmaxf(w1, w2))), 0.01f), 1e-5f);
-        const float sum = wave_sum(dw);
-        float inc = div_rn(dw, sum);  // pdf, then inclusive scan
+    const bool cact = lane < S;
+    const float w1 = __shfl_down(wi, 1, 64), w2 = __shfl_down(wi, 2, 64);
+    const float z1 = __shfl_down(zi, 1, 64);
+    float dw = 0.f;
+    if (lane < nb) dw = add_rn(add_rn(mul_rn(0.5f, add_rn(fmaxf(wi, w1), fmaxf(w1, w2))), 0.01f), 1e-5f);
+    const float sum = wave_total(dw);
+    const float inc = wave_scan_add(div_rn(dw, sum));  // pdf -> inclusive scan
+    float cdf = __shfl_up(inc, 1, 64);                 // lane i: cdf[i], i in [0, ncdf)
+    if (lane == 0) cdf = 0.f;
+    const float bin = mul_rn(0.5f, add_rn(z1, zi));    // lane i: mid-point i (valid for i < S-1)
+    // ---- inverse CDF for fine sample `lane` ----
+    const bool fact = lane < Sf;
+    const float uk = DET ? linspace01(fact ? lane : 0, Sf) : (fact ? u[(size_t)r * Sf + lane] : 0.f);
+    int lo = 0, hi = ncdf;  // searchsorted(cdf, u, right=True)
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float q = __shfl_up(inc, off, 64);
-            if (lane >= off) inc = add_rn(inc, q);
+    for (int it = 0; it < 7; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const float cm = __shfl(cdf, mid < ncdf ? mid : ncdf - 1, 64);
+        if (lo < hi) {
+            if (cm > uk) hi = mid; else lo = mid + 1;
         }
-        float cdf = __shfl_up(inc, 1, 64);  // lane i: cdf[i], i in [0, ncdf)
-        if (lane == 0) cdf = 0.f;
-        const float bin = mul_rn(0.5f, add_rn(z1, zi));  // lane i: mid-point i (valid for i < S-1)
-        // ---- inverse CDF for fine sample `lane` ----
-        const bool fact = lane < Sf;
-        const float uk = u ? (fact ? u[(size_t)r * Sf + lane] : 0.f) : linspace01(fact ? lane : 0, Sf);
-        int lo = 0, hi = ncdf;  // searchsorted(cdf, u, right=True)
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < ncdf - 1 ? lo : ncdf - 1;
+    const float c0 = __shfl(cdf, below, 64), c1 = __shfl(cdf, above, 64);
+    const float b0 = __shfl(bin, below, 64), b1 = __shfl(bin, above, 64);
+    float denom = sub_rn(c1, c0);
+    if (denom < 1e-5f) denom = 1.0f;
+    const float t = div_rn(sub_rn(uk, c0), denom);
+    const float zf = fact ? add_rn(b0, mul_rn(t, sub_rn(b1, b0))) : INFINITY;
+    if (fact) z_fine[(size_t)r * Sf + lane] = zf;
+    // ---- merged order by rank (stable: coarse first on ties, fine by index) ----
+    int rank_c = lane, rank_f = lane;
+    if (DET) {
+        // both sequences are non-decreasing: #fine < zi and #coarse <= zf by binary search
+        int l0 = 0, h0 = Sf, l1 = 0, h1 = S;
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const float cm = __shfl(cdf, mid < ncdf ? mid : ncdf - 1, 64);
-            if (lo < hi) {
-                if (cm > uk) hi = mid; else lo = mid + 1;
-            }
+            const int m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;
+            const float f = __shfl(zf, m0 < 63 ? m0 : 63, 64);
+            const float c = __shfl(zi, m1 < 63 ? m1 : 63, 64);
+            if (l0 < h0) { if (f < zi) l0 = m0 + 1; else h0 = m0; }
+            if (l1 < h1) { if (c <= zf) l1 = m1 + 1; else h1 = m1; }
         }
-        const int below = lo - 1 > 0 ? lo - 1 : 0;
-        const int above = lo < ncdf - 1 ? lo : ncdf - 1;
-        const float c0 = __shfl(cdf, below, 64), c1 = __shfl(cdf, above, 64);
-        const float b0 = __shfl(bin, below, 64), b1 = __shfl(bin, above, 64);
-        float denom = sub_rn(c1, c0);
-        if (denom < 1e-5f) denom = 1.0f;
-        const float t = div_rn(sub_rn(uk, c0), denom);
-        const float zf = fact ? add_rn(b0, mul_rn(t, sub_rn(b1, b0))) : INFINITY;
-        if (fact) z_fine[(size_t)r * Sf + lane] = zf;
-        // ---- merged order by rank (stable: coarse first on ties, fine by index) ----
-        int rank_c = lane, rank_f = lane;
+        rank_c += l0;
+        rank_f += l1;
+    } else {
         for (int k = 0; k < Sf; ++k) {
             const float zk = __shfl(zf, k, 64);
             rank_c += zk < zi;
@@ -549,9 +614,60 @@ __global__ __launch_bounds__(256) void k_importance_wave(const float* __restrict
         }
         rank_f -= lane;  // the loop counted fine predecessors only; add coarse ones below
         for (int i = 0; i < S; ++i) rank_f += __shfl(zi, i, 64) <= zf;
-        const size_t o = (size_t)r * (S + Sf);
-        if (cact) { z_sorted[o + rank_c] = zi; sorted_idx[o + rank_c] = lane; }
-        if (fact) { z_sorted[o + rank_f] = zf; sorted_idx[o + rank_f] = S + lane; }
+    }
+    const size_t o = (size_t)r * (S + Sf);
+    if (cact) { z_sorted[o + rank_c] = zi; sorted_idx[o + rank_c] = lane; }
+    if (fact) { z_sorted[o + rank_f] = zf; sorted_idx[o + rank_f] = S + lane; }
+}
+
+template <bool DET>
+__global__ __launch_bounds__(256) void k_importance_wave(const float* __restrict__ z, const float* __restrict__ weights,
+                                                         int R, int S, int Sf, const float* __restrict__ u,
+                                                         float* __restrict__ z_fine, float* __restrict__ z_sorted,
+                                                         int32_t* __restrict__ sorted_idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < R; r += nwaves) {
+        const bool cact = lane < S;
+        const float zi = cact ? z[(size_t)r * S + lane] : INFINITY;
+        const float wi = cact ? weights[(size_t)r * S + lane] : 0.f;
+        importance_wave<DET>(zi, wi, r, S, Sf, u, lane, z_fine, z_sorted, sorted_idx);
+    }
+}
+
+// coarse composite + importance resampling of a ray in one pass (S, Sf <= 64): the weights never leave the
+// wavefront's registers unless the caller asks for them
+template <bool DET>
+__global__ __launch_bounds__(256) void k_composite_importance(const float4* __restrict__ raw,
+                                                              const float4* __restrict__ raw_empty,
+                                                              const uint32_t* __restrict__ bits,
+                                                              const float* __restrict__ z, const float* __restrict__ rays_d,
+                                                              int R, int S, int Sf, float B, const float* __restrict__ noise,
+                                                              const float* __restrict__ u, float* __restrict__ rgb_map,
+                                                              float* __restrict__ disp, float* __restrict__ acc_out,
+                                                              float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                              float* __restrict__ z_fine, float* __restrict__ z_sorted,
+                                                              int32_t* __restrict__ sorted_idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < R; r += nwaves) {
+        const float dn = ray_norm(rays_d, r);
+        CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool act = lane < S;
+        const size_t m = (size_t)r * S + (act ? lane : S - 1);
+        const float4 rw = (bits && bits[m] == 0u) ? raw_empty[r] : raw[m];
+        const float zs = z[m];
+        const float gap = (lane + 1 < S) ? sub_rn(z[m + 1], zs) : 1e10f;
+        float al;
+        const float w = composite_chunk(st, rw, zs, gap, dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+        if (act) {
+            if (weights) weights[m] = w;
+            if (alpha_out) alpha_out[m] = al;
+        }
+        if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
+        importance_wave<DET>(act ? zs : INFINITY, act ? w : 0.f, r, S, Sf, u, lane, z_fine, z_sorted, sorted_idx);
     }
 }
 
@@ -657,11 +773,49 @@ extern "C" int danbo_importance_samples(const float* z, const float* weights, in
                                          float* z_fine, float* z_sorted, int32_t* sorted_idx, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S >= 3 && Sf > 0);
     if (S <= 64 && Sf <= 64) {
-        hipLaunchKernelGGL(k_importance_wave, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream, z,
-                           weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx);
+        if (u)
+            hipLaunchKernelGGL(k_importance_wave<false>, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0,
+                               (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx);
+        else
+            hipLaunchKernelGGL(k_importance_wave<true>, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0,
+                               (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx);
     } else {
         hipLaunchKernelGGL(k_importance, dim3(stream_grid(R, 64)), dim3(64), 0, (hipStream_t)stream, z, weights, R, S, Sf,
                            u, z_fine, z_sorted, sorted_idx);
     }
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_composite_importance_fwd(const float* raw, const float* raw_empty, const uint32_t* valid_bits,
+                                               const float* z, const float* rays_d, int R, int S, int Sf, float B,
+                                               const float* noise, const float* u, float* rgb_map, float* disp,
+                                               float* acc, float* weights, float* alpha, float* z_fine, float* z_sorted,
+                                               int32_t* sorted_idx, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64 && B > 0.f);
+    DANBO_CHECK_ARG(raw && z && rays_d && rgb_map && disp && acc && z_fine && z_sorted && sorted_idx);
+    DANBO_CHECK_ARG((valid_bits == nullptr) || (raw_empty != nullptr));
+    const dim3 grid(stream_grid((long)R * 64, 256)), block(256);
+    const float4* r4 = reinterpret_cast<const float4*>(raw);
+    const float4* e4 = reinterpret_cast<const float4*>(raw_empty);
+    if (u)
+        hipLaunchKernelGGL(k_composite_importance<false>, grid, block, 0, (hipStream_t)stream, r4, e4, valid_bits, z, rays_d,
+                           R, S, Sf, B, noise, u, rgb_map, disp, acc, weights, alpha, z_fine, z_sorted, sorted_idx);
+    else
+        hipLaunchKernelGGL(k_composite_importance<true>, grid, block, 0, (hipStream_t)stream, r4, e4, valid_bits, z, rays_d,
+                           R, S, Sf, B, noise, u, rgb_map, disp, acc, weights, alpha, z_fine, z_sorted, sorted_idx);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_composite_merged_fwd(const float* raw_a, const float* raw_b, const float* raw_empty,
+                                           const uint32_t* bits_a, const uint32_t* bits_b, const int32_t* sorted_idx,
+                                           const float* z_sorted, const float* rays_d, int R, int S, int Sf, float B,
+                                           const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
+                                           float* alpha, float* raw_sorted, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && Sf > 0 && B > 0.f && raw_a && raw_b && sorted_idx && z_sorted && rays_d);
+    DANBO_CHECK_ARG(rgb_map && disp && acc && ((bits_a == nullptr && bits_b == nullptr) || raw_empty != nullptr));
+    hipLaunchKernelGGL(k_composite_merged, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(raw_a), reinterpret_cast<const float4*>(raw_b),
+                       reinterpret_cast<const float4*>(raw_empty), bits_a, bits_b, sorted_idx, z_sorted, rays_d, R, S, Sf, B,
+                       noise, rgb_map, disp, acc, weights, alpha, reinterpret_cast<float4*>(raw_sorted));
     DANBO_LAUNCH_RET();
 }

@@ -238,6 +238,24 @@ int danbo_importance_samples(const float* z, const float* weights, int R, int S,
 int danbo_merge_samples(const float* a /*[R,S,C]*/, const float* b /*[R,Sf,C]*/, const int32_t* sorted_idx,
                         int R, int S, int Sf, int C, float* out /*[R,S+Sf,C]*/, void* stream);
 
+/* raw2outputs of the coarse pass + isample_from_lineseg in one launch (S, Sf <= 64; same arithmetic as
+ * danbo_composite_fwd followed by danbo_importance_samples).  valid_bits / raw_empty (optional, together):
+ * samples whose in-volume word is 0 were not written to raw and take raw_empty[ray] instead.
+ * weights / alpha may be NULL. */
+int danbo_composite_importance_fwd(const float* raw /*[R,S,4]*/, const float* raw_empty /*[R,4]*/,
+                                   const uint32_t* valid_bits /*[R,S]*/, const float* z, const float* rays_d, int R, int S,
+                                   int Sf, float B, const float* noise, const float* u, float* rgb_map, float* disp,
+                                   float* acc, float* weights, float* alpha, float* z_fine, float* z_sorted,
+                                   int32_t* sorted_idx, void* stream);
+
+/* merge_samples (core/raycasters.py:745-761) folded into raw2outputs of the merged samples: sample i of the sorted
+ * order is read from raw_a (sorted_idx < S) or raw_b; raw_sorted (optional) receives the merged raw tensor. */
+int danbo_composite_merged_fwd(const float* raw_a /*[R,S,4]*/, const float* raw_b /*[R,Sf,4]*/, const float* raw_empty,
+                               const uint32_t* bits_a, const uint32_t* bits_b, const int32_t* sorted_idx,
+                               const float* z_sorted /*[R,S+Sf]*/, const float* rays_d, int R, int S, int Sf, float B,
+                               const float* noise, float* rgb_map, float* disp, float* acc, float* weights /*[R,S+Sf]*/,
+                               float* alpha, float* raw_sorted /*[R,S+Sf,4] or NULL*/, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A-NeRF (nerf_type = nerf): the per-sample encoders around the W = 448 trunk.
  * The trunk's dense layers are plain GEMMs on the rows produced here (core/anerf_engine.py).

@@ -376,3 +376,59 @@ def test_large_random_batch_against_oracle(ops):
     n = int(N(ex["count"])[0])
     rows = N(ex["list"])[:n]
     assert max_err(N(ex["confd_rows"])[:n], enc["confd"].reshape(-1, 24)[rows]) < 5e-5
+
+
+@pytest.mark.parametrize("S,Sf,rand_u", [(48, 16, False), (12, 6, False), (64, 64, False), (32, 16, True), (5, 3, True)])
+def test_fused_composite_importance_and_merged_composite_equal_the_separate_kernels(ops, S, Sf, rand_u):
+    """one-launch coarse composite + resampling, and the final composite reading through the sorted order,
+    are bit-identical to composite -> importance_samples -> merge_samples -> composite"""
+    rng = np.random.default_rng(S * 100 + Sf)
+    R = 777
+    raw = T(rng.normal(0, 2.0, size=(R, S, 4)))
+    raw_f = T(rng.normal(0, 2.0, size=(R, Sf, 4)))
+    near = rng.uniform(1, 3, size=(R, 1))
+    z = T(near + np.sort(rng.uniform(0, 2, size=(R, S)), -1))
+    d = T(rng.normal(size=(R, 3)))
+    u = T(rng.uniform(size=(R, Sf))) if rand_u else None
+    noise = T(rng.normal(0, 0.2, size=(R, S))) if rand_u else None
+    a = ops.composite(raw, z, d, 0.8, noise)
+    z_all, z_fine, order = ops.importance_samples(z, a["weights"], Sf, u)
+    b, z_all2, z_fine2, order2 = ops.composite_importance(raw, z, d, Sf, 0.8, noise, u)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(z_all, z_all2) and torch.equal(z_fine, z_fine2) and torch.equal(order, order2)
+    srt = torch.sort(order.long(), -1).values
+    assert bool((srt == torch.arange(S + Sf, device=DEV)).all()) and bool((z_all[:, 1:] >= z_all[:, :-1]).all())
+    merged = ops.merge_samples(raw, raw_f, order)
+    c = ops.composite(merged, z_all, d, 0.8)
+    e = ops.composite_merged(raw, raw_f, order, z_all, d, 0.8, want_raw=True)
+    for k in c:
+        assert torch.equal(c[k], e[k]), k
+    assert torch.equal(e["raw_sorted"], merged)
+    # un-filled raw: rows whose in-volume word is 0 hold garbage and must be replaced by the ray's empty-space raw
+    bits = T(rng.integers(0, 2, size=(R, S)) * rng.integers(1, 1 << 24, size=(R, S)), torch.int32)
+    bits_f = T(rng.integers(0, 2, size=(R, Sf)) * 5, torch.int32)
+    empty = T(rng.normal(size=(R, 4)))
+    filled = torch.where((bits != 0)[..., None], raw, empty[:, None, :].expand(R, S, 4)).contiguous()
+    filled_f = torch.where((bits_f != 0)[..., None], raw_f, empty[:, None, :].expand(R, Sf, 4)).contiguous()
+    junk = torch.where((bits != 0)[..., None], raw, torch.full_like(raw, float("nan")))
+    junk_f = torch.where((bits_f != 0)[..., None], raw_f, torch.full_like(raw_f, float("nan")))
+    f1, zs1, zf1, o1 = ops.composite_importance(filled, z, d, Sf, 0.8, noise, u)
+    f2, zs2, zf2, o2 = ops.composite_importance(junk, z, d, Sf, 0.8, noise, u, bits=bits, raw_empty=empty)
+    assert all(torch.equal(f1[k], f2[k]) for k in f1) and torch.equal(zs1, zs2) and torch.equal(o1, o2)
+    g1 = ops.composite_merged(filled, filled_f, o1, zs1, d, 0.8)
+    g2 = ops.composite_merged(junk, junk_f, o1, zs1, d, 0.8, bits_a=bits, bits_b=bits_f, raw_empty=empty)
+    assert all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
+def test_render_lazy_fill_equals_filled(ops, stage):
+    """engine.render (no raw pre-fill, fused kernels) == the keep=True path that materialises everything"""
+    g = golden("danbo_stages")
+    eng = stage["eng"]
+    pose = g["pose_of_ray"]
+    rb = g["ray_batch"]
+    args = (T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cyls"]), T(g["cam_idx"], torch.int64))
+    a = eng.render(*args, N_samples=12, N_importance=6, keep=False)
+    b = eng.render(*args, N_samples=12, N_importance=6, keep=True)
+    for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0"):
+        assert torch.equal(a[k], b[k]), k
