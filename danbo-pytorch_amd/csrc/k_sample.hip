@@ -179,6 +179,7 @@ __device__ __forceinline__ void affine_pk(const float* M, v2f x, v2f y, v2f z, v
 
 constexpr int CULL_BLOCK = 256;
 constexpr int CULL_SPT = 4;  // samples per thread -> 1024 consecutive samples per workgroup
+constexpr int CULL_MAX_RAYS = 130;  // rays a workgroup may span (S >= 8) for the ray-level bone rejection
 
 __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d,
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
     float* s_align = smem;                 // [24][16]
     float* s_scale = smem + J * 16;        // [24][4]
     float* s_skt = smem + J * 16 + J * 4;  // [np_lds][24][16]
+    __shared__ float s_zlo[CULL_MAX_RAYS], s_zhi[CULL_MAX_RAYS];
+    __shared__ uint32_t s_mask[CULL_MAX_RAYS];
 
     const long M = (long)R * S;
     const long spp = (long)(R / G) * S;  // samples per pose
@@ -208,6 +211,53 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
+    // ---- ray-level rejection (z mode): a bone whose slightly inflated box the ray's sampled segment misses
+    // cannot contain any of the ray's samples, so whole wavefronts skip it.  Conservative (margins far above
+    // fp32 round-off of the transform chain); the per-sample test below is unchanged, so the mask stays exact.
+    const int r_first = (int)(base / S), r_last = (int)(last / S);
+    const int nrays = r_last - r_first + 1;
+    const bool prefilter = pts == nullptr && nrays <= CULL_MAX_RAYS;
+    if (prefilter) {
+        for (int i = threadIdx.x; i < nrays; i += CULL_BLOCK) {
+            const size_t m0 = (size_t)(r_first + i) * S;
+            // the samples of a ray are either sorted (coarse / deterministic importance) or not (random draws):
+            // take the true min / max of the row
+            float lo = z[m0], hi = lo;
+            for (int k = 1; k < S; ++k) { const float v = z[m0 + k]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+            s_zlo[i] = lo; s_zhi[i] = hi; s_mask[i] = 0u;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < nrays * J; q += CULL_BLOCK) {
+            const int i = q / J, j = q % J, r = r_first + i;
+            const int g = (int)min((long)r * S / spp, (long)G - 1);
+            const float* sk = s_skt + (g - g0) * J * 16 + 16 * j;
+            const float* al = s_align + 16 * j;
+            const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+            const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+            float ol[3], dl[3], t[3];
+            bone_local(sk, al, o, ol);
+            for (int k = 0; k < 3; ++k) t[k] = sk[4 * k] * d[0] + sk[4 * k + 1] * d[1] + sk[4 * k + 2] * d[2];
+            for (int k = 0; k < 3; ++k) dl[k] = al[4 * k] * t[0] + al[4 * k + 1] * t[1] + al[4 * k + 2] * t[2];
+            const float zl = s_zlo[i], zh = s_zhi[i];
+            const float pad = 1e-4f * fmaxf(fabsf(zl), fabsf(zh)) + 1e-5f;
+            float tmin = zl - pad, tmax = zh + pad;
+            bool miss = false;
+            for (int k = 0; k < 3; ++k) {
+                const float sc = s_scale[4 * j + k] * 1.001f + 1e-4f;
+                if (fabsf(dl[k]) < 1e-12f) {
+                    miss = miss || fabsf(ol[k]) > sc;
+                } else {
+                    const float inv = 1.0f / dl[k];
+                    const float t1 = (-sc - ol[k]) * inv, t2 = (sc - ol[k]) * inv;
+                    tmin = fmaxf(tmin, fminf(t1, t2));
+                    tmax = fminf(tmax, fmaxf(t1, t2));
+                }
+            }
+            miss = miss || tmin > tmax;   // NaN anywhere -> not provably missed -> keep the bone
+            if (!miss) atomicOr(&s_mask[i], 1u << j);
+        }
+        __syncthreads();
+    }
     // Two samples per lane and per instruction: the unfused mul/add chain runs on packed fp32
     // (v_pk_mul_f32 / v_pk_add_f32: two IEEE-rounded results per lane-op, same values as the scalar
     // chain), the per-bone matrices are LDS broadcasts splatted over the pair.
@@ -222,11 +272,20 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
         load_point(rays_o, rays_d, z, pts, mbc, S, pb);
         const int ga = (int)min(mac / spp, (long)G - 1), gb = (int)min(mbc / spp, (long)G - 1);
         uint32_t ba = 0, bb = 0;
-        if (ga == gb) {
+        // bones any lane of this wavefront may be inside (wave-uniform)
+        uint32_t need = (1u << J) - 1u;
+        if (prefilter) {
+            uint32_t mine = s_mask[(int)(mac / S) - r_first] | s_mask[(int)(mbc / S) - r_first];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mine |= (uint32_t)__shfl_xor((int)mine, off, 64);
+            need = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+        }
+        if (__builtin_amdgcn_readfirstlane((int)__all(ga == gb))) {
             const v2f px = {pa[0], pb[0]}, py = {pa[1], pb[1]}, pz = {pa[2], pb[2]};
             const float* sk = s_skt + (ga - g0) * J * 16;
-#pragma unroll 4
-            for (int j = 0; j < J; ++j) {
+            while (need) {
+                const int j = __builtin_ctz(need);
+                need &= need - 1u;
                 v2f l[3], t[3];
                 affine_pk(sk + 16 * j, px, py, pz, l);
                 affine_pk(s_align + 16 * j, l[0], l[1], l[2], t);
@@ -236,7 +295,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
                 ba |= (ina ? 1u : 0u) << j;
                 bb |= (inb ? 1u : 0u) << j;
             }
-        } else {  // the pair straddles two poses (chunk boundaries only)
+        } else {  // some pair of the wavefront straddles two poses (chunk boundaries only)
             const float* ska = s_skt + (ga - g0) * J * 16;
             const float* skb = s_skt + (gb - g0) * J * 16;
             for (int j = 0; j < J; ++j) {
