@@ -200,12 +200,15 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                 d[0] = div_rn(d[0], den); d[1] = div_rn(d[1], den); d[2] = div_rn(d[2], den);
             }
             s_v[k * VIEW_RPB + rl] = d[k];
-            for (int l = 0; l < L_view; ++l) {
-                float sn, cs;
-                sincosf(mul_rn(d[k], (float)(1 << l)), &sn, &cs);
-                s_v[(3 * (1 + 2 * l) + k) * VIEW_RPB + rl] = sn;
-                s_v[(3 * (2 + 2 * l) + k) * VIEW_RPB + rl] = cs;
-            }
+        }
+        __syncthreads();
+        // one (ray, axis, level) per thread: sin / cos of 2^l d
+        for (int q = tid; q < VIEW_RPB * 3 * L_view; q += 256) {
+            const int rl = q % VIEW_RPB, k = (q / VIEW_RPB) % 3, l = q / (VIEW_RPB * 3);
+            float sn, cs;
+            pe_sincos(mul_rn(s_v[k * VIEW_RPB + rl], (float)(1 << l)), &sn, &cs);
+            s_v[(3 * (1 + 2 * l) + k) * VIEW_RPB + rl] = sn;
+            s_v[(3 * (2 + 2 * l) + k) * VIEW_RPB + rl] = cs;
         }
         if (code_table && tid < VIEW_RPB) {
             const int r = min(r0 + tid, R - 1);
@@ -250,14 +253,36 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
         }
         if (empty_consts) {
             __syncthreads();
-            if (tid < VIEW_RPB * 4) {
+            if (rgb_order) {
+                // the summation order of k_pe_mlp16: four lane-group partials per (ray, channel), then
+                // ((p0 + p1) + (p2 + p3)) + b -- one partial chain per thread (192 threads busy instead of 48)
+                float part = 0.f;
+                const int rl = tid >> 4, ch = (tid >> 2) & 3, q = tid & 3;
+                if (ch < 3) {
+                    const float* x = s_x + rl * MLP_VW;
+                    const float* wv = rgb_w + ch * MLP_VW;
+#pragma unroll
+                    for (int T = 0; T < 8; ++T) {
+                        const int n = 16 * T + 4 * q;
+                        const float4 xv = *reinterpret_cast<const float4*>(x + n);
+                        part = fmaf(xv.x, wv[n], part);
+                        part = fmaf(xv.y, wv[n + 1], part);
+                        part = fmaf(xv.z, wv[n + 2], part);
+                        part = fmaf(xv.w, wv[n + 3], part);
+                    }
+                }
+                // lanes 4k..4k+3 hold p0..p3 of one (ray, channel)
+                const float p1 = __shfl_xor(part, 1, 64);
+                const float pair = (q & 1) ? p1 + part : part + p1;      // p0+p1 in lanes q=0,1 ; p2+p3 in lanes q=2,3
+                const float other = __shfl_xor(pair, 2, 64);
+                const int r = r0 + rl;
+                if (q == 0 && r < R) raw_empty[(size_t)r * 4 + ch] = ch < 3 ? (pair + other) + rgb_b[ch] : empty_consts[MLP_VW];
+            } else if (tid < VIEW_RPB * 4) {
                 const int rl = tid >> 2, ch = tid & 3;
                 const int r = r0 + rl;
                 if (r < R) {
                     float val = empty_consts[MLP_VW];
-                    if (ch < 3)
-                        val = rgb_order ? rgb_dot_halves(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch])
-                                        : rgb_dot(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch]);
+                    if (ch < 3) val = rgb_dot(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch]);
                     raw_empty[(size_t)r * 4 + ch] = val;
                 }
             }
@@ -523,7 +548,8 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int iters = ceil_div(R, VIEW_RPB);
-    const int grid = iters < NUM_CU ? iters : NUM_CU;
+    const int per_cu = (int)((160 * 1024) / (lds + 1024)) < 8 ? (int)((160 * 1024) / (lds + 1024)) : 8;  // latency-bound phases: fill the CU
+    const int grid = iters < NUM_CU * per_cu ? iters : NUM_CU * (per_cu > 0 ? per_cu : 1);
     hipLaunchKernelGGL(k_view_consts, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
                        normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
                        rgb_b, empty_consts, rgb_order, code_table, cview, raw_empty);

@@ -205,30 +205,6 @@ __device__ __forceinline__ void chunk_mfma(f32x4 (&acc)[NACC], Pipe& p, const ha
     }
 }
 
-// sin / cos of the positional encoding: Cody-Waite reduction by pi/2 (3 constants) + degree-7/8
-// minimax polynomials; |error| < 2e-7 for |x| < 1e4, about a quarter of the code of OCML's sincosf
-// (whose Payne-Hanek slow path is inlined at every call site).
-__device__ __forceinline__ void pe_sincos(float x, float* s, float* c) {
-    const float k = rintf(x * 0.636619772367581343f);  // 2/pi
-    float r = fmaf(k, -1.57079601287841796875f, x);    // pi/2 split in three (24 + 24 + 24 bits)
-    r = fmaf(k, -3.1391647326017846353352069854736328125e-7f, r);
-    r = fmaf(k, -5.390302529957764765544681040410068817436695098876953125e-15f, r);
-    const float r2 = r * r;
-    float sp = fmaf(r2, 2.6083159809786593541502952575683593750e-6f, -1.981069071916863322258e-4f);
-    sp = fmaf(sp, r2, 8.33307858556509017944e-3f);
-    sp = fmaf(sp, r2, -1.66666597127914428711e-1f);
-    const float sn = fmaf(sp * r2, r, r);
-    float cp = fmaf(r2, 2.44331571593647822737693786621e-5f, -1.38873163610696792602539062500e-3f);
-    cp = fmaf(cp, r2, 4.16666455566883087158203125e-2f);
-    cp = fmaf(cp, r2, -0.5f);
-    const float cs = fmaf(cp, r2, 1.0f);
-    const int q = (int)k;
-    const float s0 = (q & 1) ? cs : sn;
-    const float c0 = (q & 1) ? sn : cs;
-    *s = (q & 2) ? -s0 : s0;
-    *c = ((q + 1) & 2) ? -c0 : c0;
-}
-
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
