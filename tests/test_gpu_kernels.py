@@ -39,6 +39,7 @@ def stage():
     orc, cfg, sd, rest = oracle_for(g)
     params = {k: T(v) for k, v in sd.items()}
     eng = DanboEngine(cfg, params, T(orc.align))
+    eng.refresh()   # packed weights / tables exist even when a test uses the engine's buffers directly
     pose = g["pose_of_ray"]
     ret = orc.render(g["ray_batch"], g["skts"][pose], g["bones"][pose], g["cyls"][pose], cam_idxs=g["cam_idx"],
                      n_uniques=2, N_samples=int(g["N_samples"]), N_importance=int(g["N_importance"]), stages=True)
