@@ -87,15 +87,19 @@ def cpu_baseline(extra, n_rays=4096):
 
 
 def main():
+    global N_SAMPLES, N_IMPORTANCE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--coarse", type=int, default=N_SAMPLES, help="dev: coarse samples per ray (metric: 48)")
+    ap.add_argument("--fine", type=int, default=N_IMPORTANCE, help="dev: importance samples per ray (metric: 16)")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
                     help="f16split: fp32-accurate products as 3 fp16 MFMAs (default); fp32: exact fp32 MFMA kernels")
     args = ap.parse_args()
+    N_SAMPLES, N_IMPORTANCE = args.coarse, args.fine
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +153,7 @@ def main():
         kernel, peak = "k_pe_mlp", PEAK_FP32_MFMA
         peak_note = "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    pmc = os.path.join(ROOT, "profiles", "r01r_pmc_hbm.json")
     if os.path.exists(pmc) and args.mlp == "f16split":
         traffic = json.load(open(pmc))["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
     roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s",
@@ -157,7 +161,7 @@ def main():
                     rows_per_launch=rows / len(prof), flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF,
                     peak_note=peak_note,
                     note="executed flops of rows inside >=1 bone volume only; traffic = HBM bytes per launch from "
-                         "rocprofv3 PMC passes (profiles/r01_pmc_hbm.json), algorithmic bytes = 84 B per row")
+                         "rocprofv3 PMC passes (profiles/r01r_pmc_hbm.json, tools/pmc_hbm.sh), algorithmic bytes = 84 B per row")
 
     result = {
         "metric": "ray-samples/sec at 512x512x64 samples", "value": value, "unit": "ray-samples/s",
@@ -165,7 +169,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.mlp == "fp32" else "f32 (fp16x2-split MFMA products, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "H36M danbo_base network, 512x512 rays x (48 coarse + 16 importance) samples, "
+        "config": {"workload": f"H36M danbo_base network, 512x512 rays x ({N_SAMPLES} coarse + {N_IMPORTANCE} importance) samples, "
                                "1 pose / 1 camera per rank, cylinder near/far, exact in-volume culling",
                    "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
         "in_volume_fraction": rows / (args.steps * samples_per_frame),

@@ -24,6 +24,10 @@
 
 namespace danbo {
 
+#ifndef DANBO_M16_BT
+#define DANBO_M16_BT 2   // output tiles per batch of A-fragment reads (2 / 4 / 8 measured within 2 %)
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -125,7 +129,7 @@ struct Mlp16Args {
 
 constexpr int M16_THREADS = 512;
 constexpr int M16_TABLE_FLOATS = 8 * W_ + W_ + 3 * VW_ + 4;
-constexpr int M16_LDS_BYTES = RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4;
+constexpr int M16_LDS_BYTES = RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4 + 8 * (1024 + 256);  // + staging, see TileSrc
 
 struct Pipe {
     const char* packed;
@@ -133,6 +137,43 @@ struct Pipe {
     int issue_chunk, issue_slot, cons_slot, wave, lane;
     bool early;
 };
+
+// Tile-boundary prefetch, so that no wavefront waits on HBM between two row tiles:
+//   * the NEXT tile's rows (blended features h and list entries) are fetched by two LDS-DMA loads per wavefront
+//     into a 1.25 KB staging area while the view layer of the current tile runs;
+//   * the CURRENT tile's per-ray view constants are fetched by eight inline-asm loads one chunk before the
+//     colour head needs them (inline asm: a compiler-tracked load would make the compiler wait with
+//     s_waitcnt vmcnt(0), which also drains the weight ring).
+// Both ride on the ring's in-order vmcnt accounting: see pipe_handover.
+constexpr int STAGE_H_BYTES = 1024, STAGE_BYTES = 1024 + 256;  // per wavefront: h [16][16] floats, list [64] ints
+struct TileSrc {
+    const float* h;        // a.h
+    const int32_t* list;   // a.list or nullptr
+    const char* dummy;     // any readable 256 bytes (the packed weights)
+    int next_row0;         // first row of this wavefront in the next tile
+    int n;
+    char* stage;           // this wavefront's staging area (wave-uniform)
+};
+
+__device__ __forceinline__ void prefetch_rows(const TileSrc& t, int lane) {
+    int row0 = t.next_row0;
+    asm volatile("" : "+s"(row0));  // addresses are formed here, not hoisted out of the layer loop and spilled
+    const int rh = min(row0 + (lane >> 2), t.n - 1);
+    const float* src_h = t.h + (size_t)rh * DANBO_H_STRIDE + 4 * (lane & 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_h,
+                                     (__attribute__((address_space(3))) void*)t.stage, 16, 0, 0);
+    const int rl = min(row0 + (lane & 15), t.n - 1);
+    const void* src_l = t.list ? (const void*)(t.list + rl) : (const void*)(t.dummy + 4 * lane);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_l,
+                                     (__attribute__((address_space(3))) void*)(t.stage + STAGE_H_BYTES), 4, 0, 0);
+}
+// one base address + instruction offsets: no per-load address registers.  Four column tiles per call.
+template <int HALF>
+__device__ __forceinline__ void prefetch_cv(const float* base, f32x4 (&cv)[8]) {
+#define DANBO_CV_LOAD(T) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(cv[T]) : "v"(base), "i"((T) * 64) : "memory")
+    DANBO_CV_LOAD(4 * HALF); DANBO_CV_LOAD(4 * HALF + 1); DANBO_CV_LOAD(4 * HALF + 2); DANBO_CV_LOAD(4 * HALF + 3);
+#undef DANBO_CV_LOAD
+}
 
 // every wavefront loads 4 of the 32 pieces of a chunk
 __device__ __forceinline__ void pipe_issue(Pipe& p) {
@@ -152,10 +193,21 @@ __device__ __forceinline__ void pipe_issue(Pipe& p) {
 // the other's MFMAs instead of both stalling at the same program point:
 //   wait: my share of chunk c+1 has landed (<= 4 younger loads = chunk c+2 outstanding);
 //   barrier: everybody's has, and everybody is past chunk c-1;  then refill that slot with chunk c+3.
-__device__ __forceinline__ void pipe_handover(Pipe& p) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+// WAIT / extra (view layer only): `extra()` issues additional loads between the barrier and the ring refill, so
+// they are OLDER than that refill and YOUNGER than the chunk the next hand-over waits for; that next hand-over
+// therefore allows WAIT = 4 + (number of extra loads) operations to stay in flight.
+struct NoExtra {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int WAIT, class Extra>
+__device__ __forceinline__ void pipe_handover(Pipe& p, const Extra& extra) {
+    static_assert(WAIT == 4 || WAIT == 6 || WAIT == 8, "add the s_waitcnt immediate");
+    if (WAIT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    extra();
     pipe_issue(p);
 }
 
@@ -163,43 +215,41 @@ __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
     return *reinterpret_cast<const half8*>(base + piece * 1024);
 }
 
+// hi*hi + hi*lo + lo*hi into acc; FIRST: the accumulator starts from zero (no separate clear)
+template <bool FIRST>
 __device__ __forceinline__ void mfma3(f32x4& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
 }
 
 // One 32 KB chunk = 16 (tile, hi/lo) fragment pairs.  DENSE layers: one k-step, output tiles 0..15, B = (b0h, b0l).
 // VIEW layer: two k-steps of 8 output tiles, B = b0 for pairs 0..7 and b1 for pairs 8..15.
-// The A fragments are read two tiles ahead of their MFMAs (double-buffered in registers).
-template <int NACC, bool VIEW>
+template <int NACC, bool VIEW, bool FIRST, int WAIT = 4, class Extra = NoExtra>
 __device__ __forceinline__ void chunk_mfma(f32x4 (&acc)[NACC], Pipe& p, const half8& b0h, const half8& b0l,
-                                           const half8& b1h, const half8& b1l) {
-    if (!p.early) pipe_handover(p);
+                                           const half8& b1h, const half8& b1l, const Extra& extra = Extra()) {
+    if (!p.early) pipe_handover<WAIT>(p, extra);
     const char* base = p.ring + p.cons_slot * CHUNK_BYTES + p.lane * 16;
     p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
-    half8 ah[2][2], al[2][2];
+    // batches of BT tiles: 2 BT ds_read_b128, then their 3 BT MFMAs.  (Reading a batch ahead buys nothing with
+    // compiler-tracked LDS loads -- the compiler waits with lgkmcnt(0), i.e. for the look-ahead batch too; the other
+    // wavefront of the SIMD covers the read latency.)
+    constexpr int BT = DANBO_M16_BT;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        ah[0][t] = lds_frag(base, 2 * t);
-        al[0][t] = lds_frag(base, 2 * t + 1);
-    }
+    for (int b = 0; b < 16 / BT; ++b) {
+        half8 ah[BT], al[BT];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        if (b + 1 < 8) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                ah[(b + 1) & 1][t] = lds_frag(base, 4 * (b + 1) + 2 * t);
-                al[(b + 1) & 1][t] = lds_frag(base, 4 * (b + 1) + 2 * t + 1);
-            }
+        for (int t = 0; t < BT; ++t) {
+            ah[t] = lds_frag(base, 2 * (BT * b + t));
+            al[t] = lds_frag(base, 2 * (BT * b + t) + 1);
         }
-        if (b == 4 && p.early) pipe_handover(p);
+        if (BT * b == 8 && p.early) pipe_handover<WAIT>(p, extra);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int T = 2 * b + t;
-            if (VIEW && T >= 8) mfma3(acc[T - 8], ah[b & 1][t], al[b & 1][t], b1h, b1l);
-            else mfma3(acc[VIEW ? T : T], ah[b & 1][t], al[b & 1][t], b0h, b0l);
+        for (int t = 0; t < BT; ++t) {
+            const int T = BT * b + t;
+            if (VIEW && T >= 8) mfma3<false>(acc[T - 8], ah[t], al[t], b1h, b1l);
+            else mfma3<FIRST>(acc[T], ah[t], al[t], b0h, b0l);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -244,6 +294,28 @@ __device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, c
     split8(v, bh, bl);
 }
 
+// the 8 positional-encoding values of k-step KS held by this lane: value j = 8 KS + e = 13 c + t of channel c
+// (hv[c]): t = 0: x_c, t = 1 + 2l: sin(2^l x_c), t = 2 + 2l: cos(2^l x_c); j >= 52 is padding.  cs_keep carries the
+// cosine of a sine / cosine pair across a k-step boundary.  (Deriving odd levels from the level below by the
+// double-angle identities is 40 % cheaper but its 4e-7 input error is amplified past the 1e-4 bound by this MLP.)
+template <int KS>
+__device__ __forceinline__ void pe_kstep(const float (&hv)[4], float& cs_keep, float (&v8)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = 8 * KS + e, c = j / 13, t = j % 13;
+        float val = 0.f;
+        if (j < 52) {
+            if (t == 0) val = hv[c];
+            else if (t & 1) {
+                float sn;
+                pe_sincos(hv[c] * (float)(1 << ((t - 1) >> 1)), &sn, &cs_keep);
+                val = sn;
+            } else val = cs_keep;
+        }
+        v8[e] = val;
+    }
+}
+
 __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);  // [8][256]
@@ -268,104 +340,134 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     pipe_issue(p);
     pipe_issue(p);
     pipe_issue(p);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk 0 landed (tables: the same barrier)
+    // first tile of this workgroup: the same two staging loads (later tiles: issued during the previous view layer)
+    TileSrc src;
+    src.h = a.h; src.list = a.list; src.dummy = a.packed; src.n = n;
+    src.stage = smem + RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4 + wave * STAGE_BYTES;
+    src.next_row0 = blockIdx.x * M16_BM + wave * 16;
+    prefetch_rows(src, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ring chunks 0-2 and the first rows (tables: the same barrier)
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // ------------------------------------------------------------------ inputs
+        // ------------------------------------------------------------------ inputs (staged during the previous tile)
         const int row = tile * M16_BM + wave * 16 + m;
         const bool row_ok = row < n;
-        int dst = -1;
-        float4 hq[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) hq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row_ok) {
-            const float4* hp = reinterpret_cast<const float4*>(a.h + (size_t)row * DANBO_H_STRIDE);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) hq[c] = hp[c];
-            dst = a.list ? a.list[row] : row;
-        }
+        const float* sh = reinterpret_cast<const float*>(src.stage) + m * DANBO_H_STRIDE + qq;
+        const int staged_dst = reinterpret_cast<const int*>(src.stage + STAGE_H_BYTES)[m];
+        int dst = row_ok ? (a.list ? staged_dst : row) : -1;
+        asm volatile("" : "+v"(dst));  // materialised now: the staging area is overwritten during this tile's view layer
         const int ray = dst >= 0 ? dst / a.S : 0;
         // this lane's 4 channels: kk = qq + 4c  (kk = 15 is padding)
         float hv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            hv[c] = qq == 0 ? hq[c].x : (qq == 1 ? hq[c].y : (qq == 2 ? hq[c].z : hq[c].w));
+        for (int c = 0; c < 4; ++c) hv[c] = row_ok ? sh[4 * c] : 0.f;
         if (qq == 3) hv[3] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(hv[c]));
         float alpha_part = 0.f;
         f32x4 prev[16];  // pre-bias outputs of the previous layer
-#pragma unroll
-        for (int T = 0; T < 16; ++T) prev[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        src.next_row0 = (tile + (int)gridDim.x) * M16_BM + wave * 16;
+        // steps 0..7: the density trunk; step 8: the merged feature + view layer (128 outputs, tiles 0..7 of acc)
 #pragma unroll 1
-        for (int step = 0; step < 8; ++step) {
+        for (int step = 0; step < 9; ++step) {
             f32x4 acc[16];
-#pragma unroll
-            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (step == 0 || step == 5) {  // input / skip connection: 7 k-steps of PE features
-                // value j = 13c + t of this lane: t = 0: x_c, t = 1+2l: sin(2^l x_c), t = 2+2l: cos(2^l x_c);
-                // produced 8 at a time right before the k-step that consumes them (and recomputed for the
-                // skip connection rather than kept in 56 VGPRs across five layers)
-                float v8[8], cs_keep = 0.f;
+                // produced 8 values at a time right before the k-step that consumes them (and recomputed for the
+                // skip connection rather than kept in 56 VGPRs across five layers).  Explicit k-steps: a single
+                // `#pragma unroll` loop over the 56 values exceeds the unroll budget and turns into a runtime loop
+                // with dynamically indexed registers.
+                float cs_keep = 0.f;
+#define DANBO_X0_STEP(KS, FIRST_)                                                  \
+                {                                                                  \
+                    float v8[8], hk[4] = {hv[0], hv[1], hv[2], hv[3]};             \
+                    /* re-defined after the previous chunk: the sincos of later k-steps must not be hoisted (and spilled) */ \
+                    asm volatile("" : "+v"(hk[0]), "+v"(hk[1]), "+v"(hk[2]), "+v"(hk[3]));                            \
+                    pe_kstep<KS>(hk, cs_keep, v8);                                 \
+                    half8 xh, xl;                                                  \
+                    split8(v8, xh, xl);                                            \
+                    chunk_mfma<16, false, FIRST_>(acc, p, xh, xl, xh, xl);         \
+                }
+                DANBO_X0_STEP(0, true)
+                DANBO_X0_STEP(1, false)
+                DANBO_X0_STEP(2, false)
+                DANBO_X0_STEP(3, false)
+                DANBO_X0_STEP(4, false)
+                DANBO_X0_STEP(5, false)
+                DANBO_X0_STEP(6, false)
+#undef DANBO_X0_STEP
+            }
+            // lane constants are re-derived here instead of living in (or being spilled from) registers across
+            // the layer loop: a scratch reload is a VMEM op and its wait would drain the weight ring
+            int zero = 0;
+            asm volatile("" : "+s"(zero));  // keeps the two mbcnt ops inside the loop (no hoist + spill)
+            const int q4 = (int)((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) >> 4) & 3) * 4;
+            if (step != 0 && step != 8) {
+                const float* bias = s_bias + (step - 1) * W_ + q4;
+                {
+                    half8 bh, bl;
+                    act_fragment<false>(prev[0], prev[1], bias, nullptr, alpha_part, bh, bl);
+                    if (step == 5) chunk_mfma<16, false, false>(acc, p, bh, bl, bh, bl);
+                    else chunk_mfma<16, false, true>(acc, p, bh, bl, bh, bl);
+                }
 #pragma unroll
-                for (int j = 0; j < 8 * X0_KSTEPS; ++j) {
-                    const int c = j / 13, t = j % 13;
-                    float val = 0.f;
-                    if (j < 52) {
-                        if (t == 0) val = hv[c];
-                        else if (t & 1) {
-                            float sn;
-                            pe_sincos(hv[c] * (float)(1 << ((t - 1) >> 1)), &sn, &cs_keep);
-                            val = sn;
-                        } else val = cs_keep;
-                    }
-                    v8[j & 7] = val;
-                    if ((j & 7) == 7) {
-                        half8 xh, xl;
-                        split8(v8, xh, xl);
-                        chunk_mfma<16, false>(acc, p, xh, xl, xh, xl);
-                    }
+                for (int s = 1; s < NCH_ACT; ++s) {
+                    half8 bh, bl;
+                    int off_s = 32 * s;
+                    asm volatile("" : "+v"(off_s));   // no hoisting of all eight bias loads (the offset, not the pointer:
+                    const float* bias_s = bias + off_s;  // the pointer must stay an LDS pointer)
+                    act_fragment<false>(prev[2 * s], prev[2 * s + 1], bias_s, nullptr, alpha_part, bh, bl);
+                    chunk_mfma<16, false, false>(acc, p, bh, bl, bh, bl);
                 }
             }
-            if (step != 0) {
-                const float* bias = s_bias + (step - 1) * W_ + 4 * qq;
+            if (step == 8) {
+                // view layer; while it runs: stage the next tile's rows (chunk 0)
+                const float* bias = s_bias + 7 * W_ + q4;
+                const float* aw = s_aw + q4;
+                f32x4 (&accv)[8] = *reinterpret_cast<f32x4 (*)[8]>(&acc[0]);
 #pragma unroll
-                for (int s = 0; s < NCH_ACT; ++s) {
-                    half8 bh, bl;
-                    act_fragment<false>(prev[2 * s], prev[2 * s + 1], bias + 32 * s, nullptr, alpha_part, bh, bl);
-                    chunk_mfma<16, false>(acc, p, bh, bl, bh, bl);
+                for (int c = 0; c < NCH_VIEW; ++c) {
+                    half8 b0h, b0l, b1h, b1l;
+                    int off_c = 64 * c;
+                    asm volatile("" : "+v"(off_c));
+                    const float* bias_c = bias + off_c;
+                    const float* aw_c = aw + off_c;
+                    act_fragment<true>(prev[4 * c], prev[4 * c + 1], bias_c, aw_c, alpha_part, b0h, b0l);
+                    act_fragment<true>(prev[4 * c + 2], prev[4 * c + 3], bias_c + 32, aw_c + 32, alpha_part, b1h, b1l);
+                    if (c == 0) chunk_mfma<8, true, true, 4>(accv, p, b0h, b0l, b1h, b1l, [&]() { prefetch_rows(src, lane); });
+                    else if (c == 1) chunk_mfma<8, true, false, 6>(accv, p, b0h, b0l, b1h, b1l);
+                    else chunk_mfma<8, true, false, 4>(accv, p, b0h, b0l, b1h, b1l);
                 }
+#pragma unroll
+                for (int T = 8; T < 16; ++T) acc[T] = acc[T - 8];  // defined values for the copy below (never read)
             }
 #pragma unroll
             for (int T = 0; T < 16; ++T) prev[T] = acc[T];
         }
-        // ------------------------------------------------------------------ view layer (128 outputs)
-        f32x4 accv[8];
-#pragma unroll
-        for (int T = 0; T < 8; ++T) accv[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 (&accv)[8] = *reinterpret_cast<f32x4 (*)[8]>(&prev[0]);
+        // this tile's per-ray view constants: eight untracked loads and ONE wait (a compiler-tracked load per column tile
+        // would each wait with vmcnt(0)); the trunk's registers are free here
+        f32x4 cvq[8];
         {
-            const float* bias = s_bias + 7 * W_ + 4 * qq;
-            const float* aw = s_aw + 4 * qq;
+            const float* cvb = a.cview ? a.cview + (size_t)ray * VW_ + 4 * qq : reinterpret_cast<const float*>(a.packed);
+            prefetch_cv<0>(cvb, cvq);
+            prefetch_cv<1>(cvb, cvq);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int c = 0; c < NCH_VIEW; ++c) {
-                half8 b0h, b0l, b1h, b1l;
-                act_fragment<true>(prev[4 * c], prev[4 * c + 1], bias + 64 * c, aw + 64 * c, alpha_part, b0h, b0l);
-                act_fragment<true>(prev[4 * c + 2], prev[4 * c + 3], bias + 64 * c + 32, aw + 64 * c + 32, alpha_part, b1h, b1l);
-                chunk_mfma<8, true>(accv, p, b0h, b0l, b1h, b1l);
-            }
+            for (int T = 0; T < 8; ++T) asm volatile("" : "+v"(cvq[T]));
         }
         // ------------------------------------------------------------------ colour head + output
         float pr = 0.f, pg = 0.f, pb = 0.f;
-        const float* cv = a.cview ? a.cview + (size_t)ray * VW_ + 4 * qq : nullptr;
         float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (VW_ + 1) + 4 * qq : nullptr;
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             const int nn = 16 * T;  // + 4*qq + i
-            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cv) c4 = *reinterpret_cast<const float4*>(cv + nn);
+            f32x4 c4 = cvq[T];
+            if (!a.cview) c4 = f32x4{0.f, 0.f, 0.f, 0.f};
             const float pre[4] = {accv[T][0], accv[T][1], accv[T][2], accv[T][3]};
             if (aux) *reinterpret_cast<float4*>(aux + nn) = make_float4(pre[0], pre[1], pre[2], pre[3]);
-            const float x[4] = {fmaxf(pre[0] + c4.x, 0.f), fmaxf(pre[1] + c4.y, 0.f), fmaxf(pre[2] + c4.z, 0.f),
-                                fmaxf(pre[3] + c4.w, 0.f)};
+            const float x[4] = {fmaxf(pre[0] + c4[0], 0.f), fmaxf(pre[1] + c4[1], 0.f), fmaxf(pre[2] + c4[2], 0.f),
+                                fmaxf(pre[3] + c4[3], 0.f)};
             const float4 wr = *reinterpret_cast<const float4*>(s_rgbw + 0 * VW_ + nn + 4 * qq);
             const float4 wg = *reinterpret_cast<const float4*>(s_rgbw + 1 * VW_ + nn + 4 * qq);
             const float4 wb = *reinterpret_cast<const float4*>(s_rgbw + 2 * VW_ + nn + 4 * qq);

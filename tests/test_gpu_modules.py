@@ -91,3 +91,22 @@ def test_density_query_for_mesh_extraction():
     dens = caster(T(pts), T(g["kps"][:1]), T(g["skts"][:1]), T(g["bones"][:1]), fwd_type="density")
     want = g["raw_coarse"][:24].reshape(-1, 4)[:, 3:4]
     assert rel_err(N(dens), want, floor=1.0) < 1e-4
+
+
+def test_long_rays_96_plus_48_samples_against_oracle():
+    """SURVEY 8(d) config 3 (danbo_base recipe: 96 coarse + 48 importance samples): more than 64 samples per ray
+    takes the chunked composite and the general importance kernel"""
+    from helpers import oracle_for
+    g = golden("danbo_stages")
+    caster, kw = build("h36m_zju/danbo_base.txt", g)
+    orc, cfg, sd, rest = oracle_for(g)
+    pose = g["pose_of_ray"]
+    out = caster(T(g["ray_batch"]), N_samples=96, kp_batch=T(g["kps"][pose]), skts=T(g["skts"][pose]),
+                 cyls=T(g["cyls"][pose]), bones=T(g["bones"][pose]), cams=T(g["cam_idx"], torch.int64),
+                 N_importance=48, N_uniques=2, **kw)
+    ref = orc.render(g["ray_batch"], g["skts"][pose], g["bones"][pose], g["cyls"][pose], cam_idxs=g["cam_idx"],
+                     n_uniques=2, N_samples=96, N_importance=48)
+    assert out["T_i"].shape == (len(pose), 144)
+    for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
+        assert max_err(N(out[k]), ref[k]) < 1e-3, k
+    assert o.psnr(N(out["rgb_map"]), ref["rgb_map"]) > 65.0
