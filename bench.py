@@ -164,7 +164,7 @@ def main():
                          "rocprofv3 PMC passes (profiles/r01r_pmc_hbm.json, tools/pmc_hbm.sh), algorithmic bytes = 84 B per row")
 
     result = {
-        "metric": "ray-samples/sec at 512x512x64 samples", "value": value, "unit": "ray-samples/s",
+        "metric": f"ray-samples/sec at 512x512x{N_SAMPLES + N_IMPORTANCE} samples", "value": value, "unit": "ray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.mlp == "fp32" else "f32 (fp16x2-split MFMA products, fp32 accumulate)",
