@@ -63,7 +63,32 @@ __global__ __launch_bounds__(512, 2) void k_probe(const char* packed, const floa
         const char* base = smem + slot * CHUNK + lane * 16;
         slot = slot + 1 == SLOTS ? 0 : slot + 1;
         auto frag = [&](int piece) { return *reinterpret_cast<const half8*>(base + piece * 1024); };
-        if (ORDER == 3) {
+        if (ORDER == 4 || ORDER == 5) {
+#define MFI(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+            half8 ah[2][2], al[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { ah[0][t] = frag(2 * t); al[0][t] = frag(2 * t + 1); }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b + 1 < 8) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) { ah[(b + 1) & 1][t] = frag(4 * (b + 1) + 2 * t); al[(b + 1) & 1][t] = frag(4 * (b + 1) + 2 * t + 1); }
+                }
+                if (b == 4 && early) handover();
+                f32x4& a0 = acc[2 * b];
+                f32x4& a1 = acc[2 * b + 1];
+                asm volatile("s_nop 1");
+                if (ORDER == 4) {
+                    MFI(a0, ah[b & 1][0], bh); MFI(a0, ah[b & 1][0], bl); MFI(a0, al[b & 1][0], bh);
+                    MFI(a1, ah[b & 1][1], bh); MFI(a1, ah[b & 1][1], bl); MFI(a1, al[b & 1][1], bh);
+                } else {
+                    MFI(a0, ah[b & 1][0], bh); MFI(a1, ah[b & 1][1], bh);
+                    MFI(a0, ah[b & 1][0], bl); MFI(a1, ah[b & 1][1], bl);
+                    MFI(a0, al[b & 1][0], bh); MFI(a1, al[b & 1][1], bh);
+                }
+            }
+            if (s == 7) asm volatile("s_nop 7\n s_nop 7");
+        } else if (ORDER == 3) {
             half8 ah[2][2], al[2][2];
             const unsigned laddr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)base;
             auto rd = [&](half8& dst, int piece) {
@@ -188,6 +213,8 @@ int main() {
     run<2, 1, true>("4 tiles hh/hl/lh, no fences, epilogue", packed, bias, out, iters);
     run<1, 2, true>("two tiles interleaved, sched_group_barrier mix, epilogue", packed, bias, out, iters);
     run<2, 2, true>("4 tiles hh/hl/lh, sched_group_barrier mix, epilogue", packed, bias, out, iters);
+    run<4, 0, true>("asm in-place MFMA, dep x3 per tile, epilogue", packed, bias, out, iters);
+    run<5, 0, true>("asm in-place MFMA, two tiles interleaved, epilogue", packed, bias, out, iters);
     run<3, 0, true>("asm ds_read + manual lgkmcnt, interleaved, fenced, epilogue", packed, bias, out, iters);
     run<3, 1, true>("asm ds_read + manual lgkmcnt, interleaved, no fences, epilogue", packed, bias, out, iters);
     run<0, 0, false>("dep x3 per tile, fenced, no epilogue", packed, bias, out, iters);
