@@ -115,8 +115,9 @@ class NeRF(nn.Module):
     def forward(self, inputs, netchunk=1024 * 64):
         """inputs: the reference's nerf_inputs dict (core/raycasters.py:399-413) -> raw [R,S,4], encoded"""
         if self.training:
-            raise NotImplementedError("A-NeRF training (backward of the cutoff-PE kernels) is not built; "
-                                      "the DANBO configs train (core/train_path.py)")
+            from .. import train_path
+            self.engine_config()   # raises for unsupported encoder combinations
+            return train_path.forward_train_anerf(self, inputs)
         pts = inputs['pts']
         R = pts.shape[0]
         G = int(inputs.get('N_uniques', 1))

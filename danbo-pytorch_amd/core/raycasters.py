@@ -217,7 +217,7 @@ class RayCaster(nn.Module):
         B = preproc_kwargs.get('density_scale', 1.0)
         with torch.no_grad():
             near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., R, ray_batch[:, 6], ray_batch[:, 7])
-            if eng.cfg['use_volume_near_far']:
+            if eng.cfg.get('use_volume_near_far'):
                 ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
             t_rand = torch.rand(R, N_samples, device=rays_o.device) if perturb > 0. else None
             z = ops.coarse_samples(near, far, N_samples, t_rand)
@@ -239,10 +239,12 @@ class RayCaster(nn.Module):
         take = lambda a, b: torch.gather(torch.cat([a, b], 1), 1, idx[..., None].expand(-1, -1, a.shape[-1]))  # noqa: E731
         raw_all = take(raw, raw_f)
         out = self.network.raw2outputs(raw_all, z_all, rays_d, raw_noise_std=raw_noise_std, B=B)
-        return dict(rgb_map=out['rgb_map'], disp_map=out['disp_map'], acc_map=out['acc_map'], alpha=out['alpha'],
-                    T_i=out['weights'], rgb0=out0['rgb_map'], disp0=out0['disp_map'], acc0=out0['acc_map'],
-                    alpha0=out0['alpha'], confd=take(enc['confd'], enc_f['confd']),
-                    part_invalid=take(enc['part_invalid'], enc_f['part_invalid']))
+        ret = dict(rgb_map=out['rgb_map'], disp_map=out['disp_map'], acc_map=out['acc_map'], alpha=out['alpha'],
+                   T_i=out['weights'], rgb0=out0['rgb_map'], disp0=out0['disp_map'], acc0=out0['acc_map'],
+                   alpha0=out0['alpha'])
+        if 'confd' in enc:   # DANBO: the assignment logits feed the soft-softmax loss (reference :710-716)
+            ret.update(confd=take(enc['confd'], enc_f['confd']), part_invalid=take(enc['part_invalid'], enc_f['part_invalid']))
+        return ret
 
     def render_pts_density(self, pts, kps, skts, bones, netchunk=1024 * 64, network=None):
         assert kps.shape[0] == 1, f'Assuming only one pose is provided, got {kps.shape[0]} instead'

@@ -216,6 +216,48 @@ def forward_train(model, inputs):
     return raw.reshape(R, S, 4), encoded
 
 
+def forward_train_anerf(model, inputs):
+    """A-NeRF (nerf_type = nerf) training forward -> raw [R,S,4] (differentiable), {}.
+
+    The encoders have no trainable parameter (`cutoff_dist` is `requires_grad=False`, core/cutoff_embedder.py:139) and
+    no gradient flows to the sample positions (`z_samples` detached, core/utils/ray_utils.py:287), so the HIP encode
+    kernels run as they do in evaluation; the trunk, the view layer and the colour head are dense layers recorded by
+    autograd.  The view layer uses the same factorisation as the eval kernel: per-ray, per-joint products of
+    views_linears.0 with the direction encoding, then a 24-term cutoff-weighted sum per sample (a batched matmul)."""
+    pts = inputs["pts"].contiguous().float()
+    R, S = pts.shape[:2]
+    G = int(inputs.get("N_uniques", 1))
+    skts = inputs["skts"]
+    skts_g = (skts if skts.shape[0] == G else skts[:: max(skts.shape[0] // G, 1)]).contiguous().float()
+    align = inputs["align_transforms"].reshape(-1, 24, 4, 4)[0].contiguous().float().to(pts.device)
+    rays_d = inputs["rays_d"].reshape(R, 3).contiguous().float()
+    L, Lv = model.pe_fn.num_freqs, model.dirs_pe_fn.num_freqs
+    tau = float(model.pe_fn.tau)
+    with torch.no_grad():
+        x0, w = ops.anerf_encode(None, None, skts_g, align, model.pe_fn.cutoff_dist.detach(), tau, L, 0, R * S, pts=pts)
+        E = ops.anerf_view_pe(rays_d, skts_g, Lv)                                  # [R, nb*72], block-major
+    h = x0
+    for i, l in enumerate(model.pts_linears):
+        h = F.relu(l(h))
+        if i in model.skips:
+            h = torch.cat([x0, h], -1)
+    alpha = model.alpha_linear(h)
+    feat = model.feature_linear(h)
+    W, nb = model.W, 1 + 2 * Lv
+    wv, bv = model.views_linears[0].weight, model.views_linears[0].bias           # [VW, W + nb*72 + code]
+    view_ch = nb * 72
+    wj = wv[:, W:W + view_ch].reshape(-1, nb, 24, 3).permute(2, 1, 3, 0).reshape(24, nb * 3, -1)   # [24, 27, VW]
+    Ej = E.reshape(R, nb, 24, 3).permute(2, 0, 1, 3).reshape(24, R, nb * 3)
+    C = torch.bmm(Ej, wj).permute(1, 0, 2)                                         # [R, 24, VW]
+    pre = feat @ wv[:, :W].t() + torch.bmm(w.reshape(R, S, 24), C).reshape(R * S, -1) + bv
+    if model.use_framecode:
+        idx = inputs.get("cam_idxs").reshape(-1).long()
+        code = model.framecodes.codes(idx) @ wv[:, W + view_ch:].t()               # [R, VW]
+        pre = pre + code.repeat_interleave(S, 0)
+    rgb = model.rgb_linear(F.relu(pre))
+    return torch.cat([rgb, alpha], -1).reshape(R, S, 4), {}
+
+
 # --------------------------------------------------------------------------------------
 # losses (reference core/trainer.py:396-422, 507-553)
 # --------------------------------------------------------------------------------------

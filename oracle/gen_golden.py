@@ -18,6 +18,8 @@ Fixtures
                      raw_noise_std = 0: the four loss terms of Trainer.compute_loss and gradients
   anerf_stages.npz   A-H36M (anerf_base net: cutoff PE, W = 448), 48 rays = 2 poses x 24, 12+6 samples, at
                      tau = 20 (step 0) with every stage tensor, and raw + final maps again at tau = 2000
+  anerf_train.npz    A-H36M, 96 rays = 4 poses x 24, 12+6 samples, training mode (perturb = 0, noise = 0): loss terms and
+                     gradients of the reference's autograd
   pose_rot6d.npz     axis-angle -> rot6d incl. tiny angles (pytorch3d boundary, cross-checked
                      with scipy in the tests)
 """
@@ -292,6 +294,51 @@ def gen_anerf_stages():
           "rgb spread", keep["final_rgb_map"].std(0))
 
 
+def gen_anerf_train():
+    """A-NeRF: one deterministic training forward/backward of the reference (perturb = 0, raw_noise_std = 0)"""
+    import types
+    seed = 16
+    cfg, args, caster, kw_test, rest = build("anerf_base", seed)
+    import core.trainer as rtr
+    scene = syn.make_scene(n_poses=4, H=64, W=64, n_views=4, pose_seed=23)
+    n_per = 24
+    ro, rd, pose = [], [], []
+    for p in range(4):
+        o, d = body_rays(scene, p, n_per, seed=400 + p)
+        ro.append(o); rd.append(d); pose += [p] * n_per
+    ro, rd, pose = np.concatenate(ro), np.concatenate(rd), np.array(pose)
+    rb = syn.ray_batch(ro, rd)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    cam_idx = (np.arange(len(pose)) % 5).astype(np.int64)
+    rng = np.random.default_rng(8)
+    target = rng.uniform(size=(len(pose), 3)).astype(np.float32)
+    bgs = rng.uniform(size=(len(pose), 3)).astype(np.float32)
+    S, Sf = 12, 6
+    caster.train()
+    kw = {k: v for k, v in kw_test.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
+    preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                   cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+    wrap = types.SimpleNamespace(module=caster)
+    tr = rtr.Trainer(args, dict(hwf=(64, 64, 80.0)), None, None, dict(ray_caster=wrap), dict(ray_caster=caster))
+    loss_dict, stats = tr.compute_loss(dict(target_s=T(target), bgs=T(bgs)), preds, kp_opts=None, popt_detach=True)
+    caster.zero_grad()
+    loss_dict["total_loss"].backward()
+    grads = {n: p.grad.numpy() for n, p in caster.network.named_parameters() if p.grad is not None}
+    keep = {"grad/" + n: grads[n] for n in ("alpha_linear.weight", "rgb_linear.weight", "views_linears.0.bias",
+                                            "framecodes.codes.weight", "pts_linears.7.bias")}
+    keep["grad/views_linears.0.weight[::8, ::16]"] = grads["views_linears.0.weight"][::8, ::16].copy()
+    keep["grad/pts_linears.0.weight[::16, ::8]"] = grads["pts_linears.0.weight"][::16, ::8].copy()
+    norms = {"gnorm/" + n: np.float64(np.sqrt((g.astype(np.float64) ** 2).sum())) for n, g in grads.items()}
+    np.savez_compressed(
+        os.path.join(OUT, "anerf_train.npz"),
+        cfg_name="anerf_base", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=4,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
+        pose_of_ray=pose, cam_idx=cam_idx, target=target, bgs=bgs,
+        rgb_map=preds["rgb_map"].detach().numpy(), acc_map=preds["acc_map"].detach().numpy(),
+        **{"loss/" + k: np.float64(v.item()) for k, v in loss_dict.items()}, **keep, **norms)
+    print("anerf_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()}, "params with grad", len(grads))
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -309,7 +356,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -322,5 +369,7 @@ if __name__ == "__main__":
         gen_danbo_train()
     if "anerf" in which:
         gen_anerf_stages()
+    if "anerf_train" in which:
+        gen_anerf_train()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -161,3 +161,57 @@ def test_one_optimiser_step_changes_parameters_and_stays_finite():
     out = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"],
                  cams=b["cam_idxs"], N_uniques=b["N_uniques"], **kw)
     assert torch.isfinite(out["rgb_map"]).all()
+
+
+def test_anerf_losses_and_gradients_match_reference_autograd():
+    """A-NeRF (cutoff PE, W = 448): loss terms and gradients of every parameter against the reference's autograd"""
+    from core.config import parse_args
+    from core.raycasters import create_raycaster
+    from core.trainer import Trainer
+    from core.utils import synthetic as syn
+    from core.utils.skeleton_utils import SMPLSkeleton
+    g = golden("anerf_train")
+    args = parse_args(["--no_reload", "--N_samples", str(int(g["N_samples"])), "--N_importance", str(int(g["N_importance"])),
+                       "--perturb", "0", "--raw_noise_std", "0"],
+                      config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", "h36m_zju", "anerf_base.txt"))
+    n_codes = int(g["n_framecodes"])
+    da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=n_codes, rest_pose=syn.rest_pose(0.48), hwf=(64, 64, 80.))
+    tr_kw, te_kw, start, grad_vars, opt, _ = create_raycaster(args, da, device=DEV)
+    caster = tr_kw["ray_caster"]
+    sd = syn.make_state_dict(syn.model_config("anerf_base"), int(g["weight_seed"]), n_codes, syn.rest_pose(0.48))
+    caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    trainer = Trainer(args, da, opt, None, tr_kw, te_kw, device=DEV)
+    caster.train()
+    batch = batch_of(g)
+    kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs")}
+    preds = caster(trainer._ray_batch(batch), kp_batch=batch["kp3d"], skts=batch["skts"], cyls=batch["cyls"],
+                   bones=batch["bones"], cams=batch["cam_idxs"], N_uniques=batch["N_uniques"], **kw)
+    assert "confd" not in preds
+    assert np.abs(preds["rgb_map"].detach().cpu().numpy() - g["rgb_map"]).max() < 1e-3
+    loss = trainer.compute_loss(batch, preds)
+    assert set(loss) == {"rgb_loss", "rgb_loss0", "total_loss"}
+    for k in loss:
+        ref = float(g["loss/" + k])
+        assert abs(float(loss[k].detach()) - ref) <= 5e-4 * abs(ref), (k, float(loss[k].detach()), ref)
+    caster.zero_grad()
+    loss["total_loss"].backward()
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in caster.network.named_parameters() if p.grad is not None}
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            n = key[len("gnorm/"):]
+            ours, ref = float(np.sqrt((grads[n].astype(np.float64) ** 2).sum())), float(g[key])
+            assert abs(ours - ref) <= 2e-2 * ref + 1e-9, (n, ours, ref)
+    for key in g.files:
+        if not key.startswith("grad/"):
+            continue
+        n = key[len("grad/"):]
+        if "[" in n:
+            base, sl = n.split("[", 1)
+            ours = eval("grads[base][" + sl)
+        else:
+            ours = grads[n]
+        ref = g[key]
+        assert np.abs(ours - ref).max() <= 2e-2 * (np.abs(ref).max() + 1e-12), (n, np.abs(ours - ref).max(), np.abs(ref).max())
+    # and one optimiser step runs
+    l2, stats = trainer.train_batch(batch, i=0, global_step=0)
+    assert np.isfinite(stats["total_loss"])
