@@ -339,6 +339,20 @@ def gen_anerf_train():
     print("anerf_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()}, "params with grad", len(grads))
 
 
+def gen_ckpt_manifest():
+    """wire format of the reference's checkpoints (trainer.py:597-618, raycasters.py:601-637): top-level keys of the
+    saved dict and name -> shape of every tensor, for a DANBO and an A-NeRF caster"""
+    import json
+    out = {}
+    for name in ("danbo_base", "anerf_base"):
+        cfg, args, caster, kw_test, rest = build(name, 1)
+        ck = caster.state_dict()
+        out[name] = {top: {k: list(v.shape) for k, v in sub.items()} for top, sub in ck.items()}
+    with open(os.path.join(OUT, "ckpt_manifest.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("ckpt_manifest:", {k: {t: len(v) for t, v in d.items()} for k, d in out.items()})
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -356,7 +370,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -371,5 +385,7 @@ if __name__ == "__main__":
         gen_anerf_stages()
     if "anerf_train" in which:
         gen_anerf_train()
+    if "ckpt" in which:
+        gen_ckpt_manifest()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -222,3 +222,24 @@ def test_unsupported_variants_raise_instead_of_falling_back():
         _build("h36m_zju/danbo_base.txt", extra=["--agg_type", "softmax"])
     with pytest.raises(NotImplementedError):
         _build("h36m_zju/danbo_base.txt", extra=["--gnn_backbone", "PNBGNN"])
+
+
+@pytest.mark.parametrize("cfg_file,name", [("h36m_zju/danbo_base.txt", "danbo_base"), ("h36m_zju/anerf_base.txt", "anerf_base")])
+def test_checkpoint_wire_format_equals_the_reference_manifest(cfg_file, name):
+    """tests/golden/ckpt_manifest.json = top-level keys and name -> shape of `caster.state_dict()` of the REFERENCE
+    (what trainer.py:597-618 saves): our caster must produce and accept exactly that dictionary"""
+    import json
+    manifest = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ckpt_manifest.json")))[name]
+    args, (tr, te, *_rest) = _build(cfg_file)
+    caster = te["ray_caster"]
+    ck = caster.state_dict()
+    assert set(ck) == set(manifest)
+    for top, sub in manifest.items():
+        ours = {k: list(v.shape) for k, v in ck[top].items()}
+        assert ours == sub, (top, set(ours) ^ set(sub))
+    # a checkpoint with the reference's layout (random tensors of the manifest's shapes) loads strictly
+    one = {k: torch.randn(*shape) if shape else torch.tensor(1.5) for k, shape in manifest["network_fn_state_dict"].items()}
+    fake = {top: dict(one) for top in manifest}       # single_net: the reference saves the same network twice
+    caster.load_state_dict(fake)
+    for k, v in caster.network.state_dict().items():
+        assert torch.equal(v, fake["network_fn_state_dict"][k]), k
