@@ -85,7 +85,33 @@ def parse_args(argv=None, config=None):
     return args
 
 
-def txt_to_argstring(path):
-    """`args.txt` written by the trainer (one `key = value` per line) -> argv list
-    (reference core/utils/evaluation_helpers.py:221-255)."""
-    return config_file_to_argv(path)
+def txt_to_argstring(path, ignore_config=False):
+    """`args.txt` written by the trainer (`key = value` per line, every argparse attribute, Python reprs) -> argv
+    (reference core/utils/evaluation_helpers.py:221-255).  `None` values are dropped, `True` becomes a bare flag,
+    `False` nothing, lists -- real ones or the bracketed strings of config files -- one token per element."""
+    import ast
+    argv = []
+    with open(path, 'r') as f:
+        for line in f:
+            parts = line.strip().split(' = ')
+            if len(parts) != 2:          # no ' = ' (or one inside the value): not a key/value line
+                continue
+            key, text = parts
+            try:
+                value = ast.literal_eval(text)
+            except (ValueError, SyntaxError):
+                value = text
+            if value is None or (key == 'config' and ignore_config):
+                continue
+            if isinstance(value, bool):
+                if value:
+                    argv.append(f'--{key}')
+                continue
+            argv.append(f'--{key}')
+            if isinstance(value, list):
+                argv.extend(str(v) for v in value)
+            elif isinstance(value, str) and value[:1] == '[' and value[-1:] == ']':
+                argv.extend(t.strip() for t in value[1:-1].split(','))
+            else:
+                argv.append(text)
+    return argv

@@ -353,6 +353,28 @@ def gen_ckpt_manifest():
     print("ckpt_manifest:", {k: {t: len(v) for t, v in d.items()} for k, d in out.items()})
 
 
+def gen_args_txt():
+    """`args.txt` exactly as run_nerf.py:590-594 writes it for the danbo_base config, and the argv the reference's
+    txt_to_argstring (core/utils/evaluation_helpers.py:221-255, lifted with ast: the module itself needs cv2 / imageio)
+    turns it back into"""
+    import ast as _ast
+    import json
+    args = rh.parse_reference_config(CONFIGS["danbo_base"])
+    args.basedir, args.expname = "./logs", "danbo_base"
+    text = "".join("{} = {}\n".format(k, getattr(args, k)) for k in sorted(vars(args)))
+    src = open(os.path.join(rh.REF_ROOT, "core", "utils", "evaluation_helpers.py")).read()
+    fn = next(n for n in _ast.parse(src).body if isinstance(n, _ast.FunctionDef) and n.name == "txt_to_argstring")
+    ns = {}
+    exec(compile(_ast.Module(body=[fn], type_ignores=[]), "txt_to_argstring", "exec"), ns)
+    path = os.path.join(tempfile.mkdtemp(), "args.txt")
+    open(path, "w").write(text)
+    argv = ns["txt_to_argstring"](path)
+    argv_noconf = ns["txt_to_argstring"](path, ignore_config=True)
+    with open(os.path.join(OUT, "args_txt.json"), "w") as f:
+        json.dump(dict(args_txt=text, argv=argv, argv_ignore_config=argv_noconf), f, indent=0)
+    print("args_txt:", len(text.splitlines()), "lines ->", len(argv), "argv tokens")
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -370,7 +392,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt", "args"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -387,5 +409,7 @@ if __name__ == "__main__":
         gen_anerf_train()
     if "ckpt" in which:
         gen_ckpt_manifest()
+    if "args" in which:
+        gen_args_txt()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -243,3 +243,18 @@ def test_checkpoint_wire_format_equals_the_reference_manifest(cfg_file, name):
     caster.load_state_dict(fake)
     for k, v in caster.network.state_dict().items():
         assert torch.equal(v, fake["network_fn_state_dict"][k]), k
+
+
+def test_args_txt_round_trip_matches_the_reference_reader(tmp_path):
+    """tests/golden/args_txt.json: an args.txt as the reference trainer writes it (run_nerf.py:590-594) and the argv
+    the reference's own txt_to_argstring makes of it"""
+    import json
+    from core.config import parse_args, txt_to_argstring
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "args_txt.json")))
+    path = tmp_path / "args.txt"
+    path.write_text(g["args_txt"])
+    assert txt_to_argstring(str(path)) == g["argv"]
+    assert txt_to_argstring(str(path), ignore_config=True) == g["argv_ignore_config"]
+    args = parse_args(txt_to_argstring(str(path), ignore_config=True))
+    assert (args.nerf_type, args.netwidth, args.N_samples, args.N_importance, args.voxel_res, args.agg_backbone,
+            args.opt_framecode, args.use_volume_near_far, args.loss_fn) == ("danbo", 256, 96, 48, 16, "vox_MIXGNN", True, False, "L1")
