@@ -46,3 +46,31 @@ def isample_from_lineseg(z_vals, weights, N_importance, det=False, pytest=False,
     u = None if det else torch.rand(z_vals.shape[0], N_importance, device=z_vals.device)
     z_all, z_fine, idx = ops.importance_samples(z_vals, weights.detach(), N_importance, u)
     return z_all, z_fine, idx
+
+
+def kp_to_valid_rays(poses, H, W, focal, kps=None, cylinder_params=None, skts=None, centers=None, ext_scale=0.00035):
+    """Rays of the pixels inside the image-space box of each pose's bounding cylinder (reference :84-138): render-time
+    ray selection, so that only pixels that can see the body are cast.  poses: camera-to-world matrices, one per image
+    (images of the same pose consecutive, `cyl_idx = i % n_poses`).  -> rays [(o, d)], flat pixel indices, cylinders, boxes"""
+    from .skeleton_utils import cylinder_to_box_2d, get_kp_bounding_cylinder, nerf_c2w_to_extrinsic
+    if cylinder_params is None:
+        assert kps is not None
+        cyl = get_kp_bounding_cylinder(kps.cpu().numpy(), ext_scale=ext_scale, extend_mm=250, top_expand_ratio=1.60,
+                                       bot_expand_ratio=1.10, head='-y')
+        cylinder_params = torch.tensor(cyl, dtype=torch.float32, device=kps.device)
+    rays, valid_idxs, bboxes = [], [], []
+    for i, c2w in enumerate(poses):
+        cyl = cylinder_params[i % kps.shape[0]]
+        f = focal if isinstance(focal, float) else focal[i]
+        center = None if centers is None else centers[i]
+        h = H if isinstance(H, int) else H[i]
+        w = W if isinstance(W, int) else W[i]
+        ray_o, ray_d = get_rays(h, w, f, c2w, center=center)
+        ray_o, ray_d = ray_o.cpu(), ray_d.cpu()
+        tl, br, _ = cylinder_to_box_2d(cyl.cpu().numpy(), [h, w, f], nerf_c2w_to_extrinsic(c2w.cpu().numpy()), center=center)
+        vh, vw = torch.meshgrid(torch.arange(tl[1], br[1]), torch.arange(tl[0], br[0]), indexing='ij')
+        idx = (vh * w + vw).reshape(-1)
+        rays.append((ray_o.reshape(-1, 3)[idx], ray_d.reshape(-1, 3)[idx]))
+        valid_idxs.append(idx)
+        bboxes.append((tl, br))
+    return rays, valid_idxs, cylinder_params, bboxes

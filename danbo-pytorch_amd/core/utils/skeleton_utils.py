@@ -133,3 +133,49 @@ def get_kp_bounding_cylinder(kp, skel_type=None, ext_scale=0.001, extend_mm=250,
     cyl = np.stack([root[:, g_axes[0]], root[:, g_axes[1]], dist + ext,
                     flip * (hi + ext * top_expand_ratio), flip * (lo - ext * bot_expand_ratio)], -1)
     return cyl if batched else cyl[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# camera helpers of the render-time ray selection (reference :445-446, 633-707, 1431-1450)
+# ---------------------------------------------------------------------------------------------
+def swap_mat(mat):
+    """NeRF camera convention [right, up, back] <-> [right, -up, -forward]: negate columns 1 and 2."""
+    return np.concatenate([mat[..., 0:1], -mat[..., 1:2], -mat[..., 2:3], mat[..., 3:]], axis=-1)
+
+
+def nerf_c2w_to_extrinsic(c2w):
+    return np.linalg.inv(swap_mat(c2w))
+
+
+def focal_to_intrinsic_np(focal):
+    fx, fy = (focal, focal) if isinstance(focal, float) or np.asarray(focal).size < 2 else focal
+    return np.array([[fx, 0, 0, 0], [0, fy, 0, 0], [0, 0, 1, 0]], dtype=np.float32)
+
+
+def cylinder_to_box_2d(cylinder_params, hwf, w2c=None, scale=1.0, center=None, make_int=True):
+    """image-space bounding box of a bounding cylinder: project 50 points on each cap rim and take the extrema
+    -> (top-left [N,2], bottom-right [N,2], projected points)."""
+    H, W, focal = hwf
+    cyl = np.asarray(cylinder_params)
+    cyl = cyl[None] if cyl.ndim == 1 else cyl
+    root, radius, top, bot = cyl[:, :2], cyl[:, 2:3], cyl[:, 3:4], cyl[:, 4:5]
+    rads = np.linspace(0., 2 * np.pi, 50)
+    x = root[:, 0:1] + np.cos(rads)[None] * radius
+    z = root[:, 1:2] + np.sin(rads)[None] * radius
+    ones = np.ones_like(x)
+    caps = np.concatenate([np.stack([x, top * ones, z, ones], -1), np.stack([x, bot * ones, z, ones], -1)], axis=-2)
+    pts = caps.reshape(-1, 4)
+    if w2c is not None:
+        pts = pts @ w2c.T
+    pts = (pts @ focal_to_intrinsic_np(focal).T).reshape(cyl.shape[0], -1, 3)
+    p2 = pts[..., :2] / pts[..., 2:3]
+    lo, hi = p2.min(1), p2.max(1)
+    if make_int:
+        lo, hi = np.floor(lo).astype(np.int32), np.ceil(hi).astype(np.int32)
+    off = np.array([int(W * .5), int(H * .5)] if center is None else [int(center[0]), int(center[1])])
+    tl, br = lo + off, hi + off
+    if scale != 1.0:
+        raise NotImplementedError("box scaling is not used on the render path")
+    tl[:, 0], br[:, 0] = np.clip(tl[:, 0], 0, W - 1), np.clip(br[:, 0], 0, W - 1)
+    tl[:, 1], br[:, 1] = np.clip(tl[:, 1], 0, H - 1), np.clip(br[:, 1], 0, H - 1)
+    return (tl[0], br[0], p2[0]) if cyl.shape[0] == 1 else (tl, br, p2)

@@ -375,6 +375,22 @@ def gen_args_txt():
     print("args_txt:", len(text.splitlines()), "lines ->", len(argv), "argv tokens")
 
 
+def gen_valid_rays():
+    """kp_to_valid_rays of the reference (core/utils/ray_utils.py:84-138) on a synthetic scene: 2 poses x 2 cameras"""
+    rh.install_stubs()
+    from core.utils.ray_utils import kp_to_valid_rays
+    scene = syn.make_scene(n_poses=2, H=48, W=64, n_views=2, pose_seed=31, cam_dist=6.5)
+    cams = np.stack([scene["cams"][0], scene["cams"][0], scene["cams"][1], scene["cams"][1]]).astype(np.float32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rays, idxs, cyl, boxes = kp_to_valid_rays(T(cams), 48, 64, float(scene["focal"]), kps=T(scene["kps"]), ext_scale=0.001)
+    np.savez_compressed(
+        os.path.join(OUT, "valid_rays.npz"), kps=scene["kps"], cams=cams, H=48, W=64, focal=scene["focal"],
+        cyl=cyl.numpy(), boxes=np.array([[b[0], b[1]] for b in boxes]),
+        n_valid=np.array([len(i) for i in idxs]), idx0=idxs[0].numpy(), idx3=idxs[3].numpy(),
+        rays_o3=rays[3][0].numpy(), rays_d3=rays[3][1].numpy())
+    print("valid_rays: boxes", [(tuple(b[0]), tuple(b[1])) for b in boxes], "n", [len(i) for i in idxs])
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -392,7 +408,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt", "args"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt", "args", "valid_rays"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -411,5 +427,7 @@ if __name__ == "__main__":
         gen_ckpt_manifest()
     if "args" in which:
         gen_args_txt()
+    if "valid_rays" in which:
+        gen_valid_rays()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

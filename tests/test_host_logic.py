@@ -258,3 +258,19 @@ def test_args_txt_round_trip_matches_the_reference_reader(tmp_path):
     args = parse_args(txt_to_argstring(str(path), ignore_config=True))
     assert (args.nerf_type, args.netwidth, args.N_samples, args.N_importance, args.voxel_res, args.agg_backbone,
             args.opt_framecode, args.use_volume_near_far, args.loss_fn) == ("danbo", 256, 96, 48, 16, "vox_MIXGNN", True, False, "L1")
+
+
+def test_kp_to_valid_rays_matches_reference():
+    """render-time ray selection: image box of the bounding cylinder, flat pixel indices and the rays
+    of those pixels, against the reference's kp_to_valid_rays (tests/golden/valid_rays.npz)"""
+    from core.utils.ray_utils import kp_to_valid_rays
+    g = golden("valid_rays")
+    rays, idxs, cyl, boxes = kp_to_valid_rays(torch.tensor(g["cams"]), int(g["H"]), int(g["W"]), float(g["focal"]),
+                                              kps=torch.tensor(g["kps"]), ext_scale=0.001)
+    assert max_err(cyl.numpy(), g["cyl"]) < 1e-6
+    assert np.array_equal(np.array([[b[0], b[1]] for b in boxes]), g["boxes"])
+    assert [len(i) for i in idxs] == list(g["n_valid"])
+    assert np.array_equal(idxs[0].numpy(), g["idx0"]) and np.array_equal(idxs[3].numpy(), g["idx3"])
+    assert max_err(rays[3][0].numpy(), g["rays_o3"]) < 1e-6 and max_err(rays[3][1].numpy(), g["rays_d3"]) < 1e-6
+    tl, br = boxes[0]
+    assert 0 < tl[0] < br[0] < int(g["W"]) - 1 and 0 < tl[1] < br[1] < int(g["H"]) - 1   # an interior box, not the frame
