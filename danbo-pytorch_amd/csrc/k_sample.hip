@@ -414,9 +414,11 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __res
         // coalesced 16-B stores of the 16 x 1440 B tile
         const int rows_here = min(GATHER_TS, n - row0);
         const int nvec = rows_here * (J * FEAT / 4);
-        float4* dst = reinterpret_cast<float4*>(part_feat + (size_t)row0 * J * FEAT);
-        const float4* src = reinterpret_cast<const float4*>(s_out);
-        for (int i = tid; i < nvec; i += GATHER_BLOCK) dst[i] = src[i];
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t* dst = reinterpret_cast<f32x4_t*>(part_feat + (size_t)row0 * J * FEAT);
+        const f32x4_t* src = reinterpret_cast<const f32x4_t*>(s_out);
+        // write-once stream: non-temporal, it is 1 440 B per sample and must not evict the volumes / transforms
+        for (int i = tid; i < nvec; i += GATHER_BLOCK) __builtin_nontemporal_store(src[i], dst + i);
     }
 }
 
