@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--coarse", type=int, default=N_SAMPLES, help="dev: coarse samples per ray (metric: 48)")
     ap.add_argument("--fine", type=int, default=N_IMPORTANCE, help="dev: importance samples per ray (metric: 16)")
+    ap.add_argument("--debug-single-device", action="store_true",
+                    help="dev: every rank uses cuda:0 and the gloo backend (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
                     help="f16split: fp32-accurate products as 3 fp16 MFMAs (default); fp32: exact fp32 MFMA kernels")
     args = ap.parse_args()
@@ -106,12 +108,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libdanbo_hip has no CPU path")
+    if args.debug_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.debug_single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
 
     eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
     for _ in range(args.warmup):
@@ -130,7 +137,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.debug_single_device else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
