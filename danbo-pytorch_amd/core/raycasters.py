@@ -235,7 +235,7 @@ class RayCaster(nn.Module):
             u = torch.rand(R, N_importance, device=rays_o.device) if perturb > 0. else None
             z_all, z_fine, order = ops.importance_samples(z, out0['weights'], N_importance, u)
         raw_f, enc_f = net(z_fine)
-        idx = order.long()
+        idx = order.long().clamp_(0, N_samples + N_importance - 1)   # a permutation unless depths are NaN
         take = lambda a, b: torch.gather(torch.cat([a, b], 1), 1, idx[..., None].expand(-1, -1, a.shape[-1]))  # noqa: E731
         raw_all = take(raw, raw_f)
         out = self.network.raw2outputs(raw_all, z_all, rays_d, raw_noise_std=raw_noise_std, B=B)

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_merge_samples(const float* __restrict__
     const long N = (long)R * St;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / St);
-        const int src = idx[i];
+        const int src = min(max(idx[i], 0), St - 1);
         const float* s = src < S ? a + ((size_t)r * S + src) * C : b + ((size_t)r * Sf + (src - S)) * C;
         float* o = out + (size_t)i * C;
         if (C == 4) {
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
             const int s = c0 + lane;
             const bool act = s < St;
             const size_t m = (size_t)r * St + (act ? s : St - 1);
-            const int src = sorted_idx[m];
+            const int src = min(max(sorted_idx[m], 0), St - 1);   // NaN depths must not become an out-of-bounds read
             float4 rw;
             if (src < S) {
                 const size_t q = (size_t)r * S + src;
@@ -592,11 +592,15 @@ __global__ __launch_bounds__(64) void k_importance(const float* __restrict__ z, 
         float* zs = z_sorted + (size_t)r * (S + Sf);
         int32_t* si = sorted_idx + (size_t)r * (S + Sf);
         importance_ray(zr, weights + (size_t)r * S, S, Sf, u ? u + (size_t)r * Sf : nullptr, cdf, zf, zs, si);
-        if (u != nullptr) {
-            // random u: the new samples are not ordered -> merge by rank instead of two pointers
+        bool ascending = true;
+        for (int i = 0; i + 1 < S; ++i) ascending = ascending && zr[i + 1] >= zr[i];
+        if (u != nullptr || !ascending) {
+            // random draws or descending depths (far bound before the near bound): the two-pointer merge above is not a
+            // sort -> place every sample by its rank in (value, coarse-before-fine, index) order
             for (int i = 0; i < S; ++i) {
-                int rank = i;
+                int rank = 0;
                 for (int k = 0; k < Sf; ++k) rank += zf[k] < zr[i];
+                for (int q = 0; q < S; ++q) rank += (zr[q] < zr[i]) || (zr[q] == zr[i] && q < i);
                 zs[rank] = zr[i];
                 si[rank] = i;
             }
@@ -654,7 +658,10 @@ __device__ __forceinline__ void importance_wave(float zi, float wi, int r, int S
     if (fact) z_fine[(size_t)r * Sf + lane] = zf;
     // ---- merged order by rank (stable: coarse first on ties, fine by index) ----
     int rank_c = lane, rank_f = lane;
-    if (DET) {
+    // the binary searches need non-decreasing depths; a ray whose far bound lies before its near bound (looking away
+    // from the body) has descending samples -> count ranks the general way (wave-uniform choice)
+    const bool ascending = __all(!(lane < S - 1) || z1 >= zi);
+    if (DET && ascending) {
         // both sequences are non-decreasing: #fine < zi and #coarse <= zf by binary search
         int l0 = 0, h0 = Sf, l1 = 0, h1 = S;
 #pragma unroll
@@ -668,13 +675,21 @@ __device__ __forceinline__ void importance_wave(float zi, float wi, int r, int S
         rank_c += l0;
         rank_f += l1;
     } else {
+        // general case: rank = number of predecessors in (value, coarse-before-fine, index) order -- a permutation for
+        // any input order, equal to torch.sort(cat([z, z_fine])) (stable)
+        rank_c = 0;
+        rank_f = 0;
         for (int k = 0; k < Sf; ++k) {
             const float zk = __shfl(zf, k, 64);
             rank_c += zk < zi;
             rank_f += (zk < zf) || (zk == zf && k < lane);
         }
-        rank_f -= lane;  // the loop counted fine predecessors only; add coarse ones below
-        for (int i = 0; i < S; ++i) rank_f += __shfl(zi, i, 64) <= zf;
+        if (ascending) rank_c += lane;
+        for (int i = 0; i < S; ++i) {
+            const float zc = __shfl(zi, i, 64);
+            rank_f += zc <= zf;
+            if (!ascending) rank_c += (zc < zi) || (zc == zi && i < lane);
+        }
     }
     const size_t o = (size_t)r * (S + Sf);
     if (cact) { z_sorted[o + rank_c] = zi; sorted_idx[o + rank_c] = lane; }

@@ -433,3 +433,36 @@ def test_render_lazy_fill_equals_filled(ops, stage):
     b = eng.render(*args, N_samples=12, N_importance=6, keep=True)
     for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("S,Sf", [(16, 8), (48, 16), (96, 32)])
+def test_importance_with_descending_and_mixed_depth_order(ops, S, Sf):
+    """a ray looking away from the body has its far bound before its near bound: descending coarse depths.  The merged
+    order must still be the stable sort of cat([z, z_fine]) (torch.sort in the reference), for the wavefront kernel,
+    the fused composite kernel and the general (S > 64) kernel"""
+    rng = np.random.default_rng(S)
+    R = 300
+    near = rng.uniform(2, 4, size=(R, 1))
+    far = near + rng.uniform(0.5, 2, size=(R, 1)) * np.where(np.arange(R)[:, None] % 3 == 0, -1.0, 1.0)   # every third ray descends
+    t = np.linspace(0, 1, S)[None]
+    z = (near * (1 - t) + far * t).astype(np.float32)
+    w = rng.uniform(size=(R, S)).astype(np.float32)
+    zs, zf, idx = ops.importance_samples(T(z), T(w), Sf)
+    z_all, z_fine, order = o.importance_z(z, w, Sf)
+    assert max_err(N(zf), z_fine) < 1e-4
+    srt = np.sort(N(idx).astype(np.int64), -1)
+    assert np.array_equal(srt, np.broadcast_to(np.arange(S + Sf), srt.shape))          # a permutation, always
+    assert bool((N(zs)[:, 1:] >= N(zs)[:, :-1]).all())                                 # and sorted
+    both = np.concatenate([z, N(zf)], 1)
+    assert np.array_equal(np.take_along_axis(both, N(idx).astype(np.int64), 1), N(zs))
+    asc = np.arange(R) % 3 != 0
+    assert np.array_equal(N(idx)[asc], order[asc])
+    if S <= 64:
+        raw = T(rng.normal(0, 1, size=(R, S, 4)))
+        d = T(rng.normal(size=(R, 3)))
+        a = ops.composite(raw, T(z), d, 1.0)
+        zs2, zf2, idx2 = ops.importance_samples(T(z), a["weights"], Sf)
+        b, zs3, zf3, idx3 = ops.composite_importance(raw, T(z), d, Sf, 1.0)
+        assert torch.equal(idx2, idx3) and torch.equal(zs2, zs3)
+        srt = torch.sort(idx3.long(), -1).values
+        assert bool((srt == torch.arange(S + Sf, device=DEV)).all())

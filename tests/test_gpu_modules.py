@@ -110,3 +110,35 @@ def test_long_rays_96_plus_48_samples_against_oracle():
     for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
         assert max_err(N(out[k]), ref[k]) < 1e-3, k
     assert o.psnr(N(out["rgb_map"]), ref["rgb_map"]) > 65.0
+
+
+def test_edge_cases_no_body_hit_single_ray_and_ragged_counts():
+    """rays that never enter a bone volume (count = 0 everywhere), a single ray, and ray counts that are not multiples
+    of any tile size: the compacted-row kernels must cope with 0 and ragged row counts"""
+    from helpers import oracle_for
+    from core.utils import synthetic as syn
+    g = golden("danbo_stages")
+    caster, kw = build("h36m_zju/danbo_base.txt", g)
+    orc, cfg, sd, rest = oracle_for(g)
+    scene = syn.make_scene(n_poses=1, H=16, W=16, n_views=1, pose_seed=4)
+    ro, rd = scene["rays"][0]
+    # (a) look away from the body: same origins, directions mirrored -> cylinder missed, no sample in any volume
+    for R in (1, 7, 130):
+        rb = syn.ray_batch(ro[:R], -rd[:R])
+        z = np.zeros(R, np.int64)
+        out = caster(T(rb), N_samples=16, kp_batch=T(scene["kps"][z]), skts=T(scene["skts"][z]), cyls=T(scene["cyls"][z]),
+                     bones=T(scene["bones"][z]), cams=T(np.zeros(R), torch.int64), N_importance=8, N_uniques=1, **kw)
+        ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], cam_idxs=np.zeros(R, np.int64),
+                         n_uniques=1, N_samples=16, N_importance=8, chunk=R)
+        assert out["rgb_map"].shape == (R, 3) and bool(torch.isfinite(out["rgb_map"]).all())
+        assert max_err(N(out["acc_map"]), ref["acc_map"]) < 1e-5 and max_err(N(out["rgb_map"]), ref["rgb_map"]) < 1e-5
+    # (b) ragged counts through the body
+    for R in (1, 3, 65, 200):
+        sel = (np.arange(R) + 16 * 4) % len(ro)   # starts in the rows through the torso
+        rb = syn.ray_batch(ro[sel], rd[sel])
+        z = np.zeros(R, np.int64)
+        out = caster(T(rb), N_samples=16, kp_batch=T(scene["kps"][z]), skts=T(scene["skts"][z]), cyls=T(scene["cyls"][z]),
+                     bones=T(scene["bones"][z]), cams=T(np.zeros(R), torch.int64), N_importance=8, N_uniques=1, **kw)
+        ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], cam_idxs=np.zeros(R, np.int64),
+                         n_uniques=1, N_samples=16, N_importance=8, chunk=R)
+        assert max_err(N(out["rgb_map"]), ref["rgb_map"]) < 2e-3 and max_err(N(out["acc_map"]), ref["acc_map"]) < 2e-3, R
