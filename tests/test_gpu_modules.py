@@ -142,3 +142,28 @@ def test_edge_cases_no_body_hit_single_ray_and_ragged_counts():
         ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], cam_idxs=np.zeros(R, np.int64),
                          n_uniques=1, N_samples=16, N_importance=8, chunk=R)
         assert max_err(N(out["rgb_map"]), ref["rgb_map"]) < 2e-3 and max_err(N(out["acc_map"]), ref["acc_map"]) < 2e-3, R
+
+
+def test_whole_chunk_misses_the_cylinder_falls_back_to_the_placeholder_bounds():
+    """every ray of the chunk misses the bounding cylinder (here: rays parallel to its axis, for which the 2-D
+    intersection is 0/0): the nan-mean back-fill has nothing to average and the placeholder bounds (0, 1) stay
+    (reference ray_utils.py:294-346 as restated by the oracle) -- no NaN, no out-of-bounds access on the way"""
+    from helpers import oracle_for
+    from core.utils import synthetic as syn
+    g = golden("danbo_stages")
+    caster, kw = build("h36m_zju/danbo_base.txt", g)
+    orc, cfg, sd, rest = oracle_for(g)
+    scene = syn.make_scene(n_poses=1, H=8, W=8, n_views=1, pose_seed=4)
+    ro, rd = scene["rays"][0]
+    R = 37
+    up = np.zeros((R, 3), np.float32)
+    up[:, 1] = 1.0
+    rb = syn.ray_batch(ro[:R], up)
+    z = np.zeros(R, np.int64)
+    out = caster(T(rb), N_samples=16, kp_batch=T(scene["kps"][z]), skts=T(scene["skts"][z]), cyls=T(scene["cyls"][z]),
+                 bones=T(scene["bones"][z]), cams=T(np.zeros(R), torch.int64), N_importance=8, N_uniques=1, **kw)
+    ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], cam_idxs=np.zeros(R, np.int64), n_uniques=1,
+                     N_samples=16, N_importance=8, chunk=R)
+    assert out["rgb_map"].shape == (R, 3) and out["T_i"].shape == (R, 24)
+    assert bool(torch.isfinite(out["rgb_map"]).all())
+    assert max_err(N(out["rgb_map"]), ref["rgb_map"]) < 1e-5 and max_err(N(out["acc_map"]), ref["acc_map"]) < 1e-5
