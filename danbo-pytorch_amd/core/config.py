@@ -42,6 +42,9 @@ _FLAGS = [
     ("init_freq", float, 0.0), ("freq_schedule_step", int, 0), ("N_sample_images", int, 8),
     ("n_iters", int, 150000), ("i_weights", int, 10000), ("i_testset", int, 50000), ("debug", bool, False),
     ("input_coords", bool, False), ("cat_coords", bool, False), ("cat_all", bool, False),
+    ("i_print", int, 100), ("dataset_type", str, "synthetic"),
+    # this build's array sources (core/load_data.py): the reference's HDF5 dataset types are not readable here
+    ("syn_poses", int, 8), ("syn_cams", int, 4), ("syn_res", int, 64), ("syn_seed", int, 0), ("syn_rest_scale", float, 0.48),
 ]
 
 

@@ -48,8 +48,27 @@ def load_ckpt_from_path(ray_caster, optimizer, ckpt_path, finetune=False):
 
 
 def filter_state_dict(model_sd, ckpt_sd):
-    """keep checkpoint entries whose name and shape match the model (non-strict reload)"""
-    return {k: v for k, v in ckpt_sd.items() if k in model_sd and tuple(v.shape) == tuple(model_sd[k].shape)}
+    """Non-strict reload rules (reference core/utils/run_nerf_helpers.py:23-50): an entry is taken from the checkpoint when
+    name and shape match; a cutoff-embedder entry (`*pe_fn*`) missing from an older checkpoint keeps the model's value, except
+    `tau`, which is set to 1000 (a converged, hard cutoff); frame codes of a different count are replaced by the mean code in
+    every row; any other mismatch is left out (the model keeps its initialisation)."""
+    out = {}
+    for k, cur in model_sd.items():
+        if k in ckpt_sd:
+            v = ckpt_sd[k]
+        elif 'pe_fn' in k:
+            v = torch.tensor(1000.) if 'tau' in k else cur
+            print(f'checkpoint has no {k}: using {v}')
+        else:
+            continue
+        if tuple(v.shape) == tuple(cur.shape):
+            out[k] = v
+        elif 'framecodes' in k:
+            print(f'{k}: {tuple(v.shape)} in the checkpoint, {tuple(cur.shape)} in the model -- loading the mean code')
+            out[k] = v.mean(dim=0, keepdim=True).repeat(cur.shape[0], 1)
+        else:
+            print(f'{k}: {tuple(v.shape)} in the checkpoint, {tuple(cur.shape)} in the model -- not loaded')
+    return out
 
 
 def create_raycaster(args, data_attrs, device=None):

@@ -12,6 +12,34 @@ import torch.distributed as dist
 from . import train_path
 
 
+def batchify_rays(rays_flat, chunk=1024 * 64, ray_caster=None, **kwargs):
+    """Cast rays chunk by chunk and concatenate every returned tensor (reference :75-90).  Per-ray tensors in `kwargs` are
+    sliced with the rays; everything else is passed through."""
+    parts = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        kw = {k: (v[i:i + chunk] if torch.is_tensor(v) else v) for k, v in kwargs.items()}
+        for k, v in ray_caster(rays_flat[i:i + chunk], **kw).items():
+            parts.setdefault(k, []).append(v)
+    return {k: torch.cat(v, 0) for k, v in parts.items()}
+
+
+def render(H, W, focal, chunk=1024 * 64, rays=None, c2w=None, near=0., far=1., center=None, use_viewdirs=False, **kwargs):
+    """Rays (given, or the full image of camera `c2w`) -> dict of per-ray maps shaped like the ray grid (reference :96-161).
+    near / far are the 0 / 1 placeholders the caster replaces by the cylinder (or per-bone box) bounds."""
+    from .utils.ray_utils import get_rays
+    if rays is None:
+        rays_o, rays_d = get_rays(H, W, focal, c2w, center=None if center is None else center.ravel())
+    else:
+        rays_o, rays_d = rays
+    sh = rays_d.shape
+    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    cols = [rays_o, rays_d, near * torch.ones_like(rays_d[:, :1]), far * torch.ones_like(rays_d[:, :1])]
+    if use_viewdirs:
+        cols.append(rays_d / torch.norm(rays_d, dim=-1, keepdim=True))
+    out = batchify_rays(torch.cat(cols, -1), chunk, **kwargs)
+    return {k: (v if v.dim() >= 4 else v.reshape(list(sh[:-1]) + list(v.shape[1:]))) for k, v in out.items()}
+
+
 def decay_optimizer_lrate(lrate, lrate_decay, decay_rate=0.1, optimizer=None, global_step=None, decay_unit=1000):
     """lr = lrate * decay_rate^((step // unit) / lrate_decay)  (decay_steps = lrate_decay * unit)"""
     decay_steps = lrate_decay * decay_unit
@@ -88,5 +116,16 @@ class Trainer:
                                       global_step, args.decay_unit)
         caster.update_embed_fns(global_step, args)
         stats = {k: float(v.detach()) for k, v in loss.items()}
-        stats.update(lrate=lr, alpha=float(preds['acc_map'].mean().detach()))
+        with torch.no_grad():
+            mse = torch.mean((preds['rgb_map'] + (1. - preds['acc_map'][..., None]) * batch.get('bgs', 1.0) - batch['target_s']) ** 2)
+        stats.update(lrate=lr, alpha=float(preds['acc_map'].mean().detach()), psnr=float(-10. * torch.log10(mse)))
         return loss, stats
+
+    def save_nerf(self, path, global_step):
+        """checkpoint in the reference's layout (:597-618): step, optimizer and one state dict per caster sub-module; the
+        pose-optimisation entries the reference writes as None are kept so its loader finds every key"""
+        caster = self.render_kwargs_train['ray_caster']
+        torch.save({'global_step': global_step, 'optimizer_state_dict': self.optimizer.state_dict(),
+                    'poseopt_layer_state_dict': None, 'pose_optimizer_state_dict': None, 'poseopt_anchors': None,
+                    **caster.state_dict()}, path)
+        print('Saved checkpoints at', path)

@@ -179,3 +179,41 @@ def cylinder_to_box_2d(cylinder_params, hwf, w2c=None, scale=1.0, center=None, m
     tl[:, 0], br[:, 0] = np.clip(tl[:, 0], 0, W - 1), np.clip(br[:, 0], 0, W - 1)
     tl[:, 1], br[:, 1] = np.clip(tl[:, 1], 0, H - 1), np.clip(br[:, 1], 0, H - 1)
     return (tl[0], br[0], p2[0]) if cyl.shape[0] == 1 else (tl, br, p2)
+
+
+def _axis_rotation(axis, angle):
+    """float32 4x4 rotation about a coordinate axis (reference :20-42; the y rotation has the sign of sin flipped,
+    i.e. it turns the camera ring clockwise seen from +y)."""
+    c, s = np.cos(angle), np.sin(angle)
+    m = np.eye(4, dtype=np.float32)
+    a, b = {'x': (1, 2), 'y': (0, 2), 'z': (0, 1)}[axis]
+    m[a, a] = m[b, b] = c
+    m[a, b], m[b, a] = -s, s
+    return m
+
+
+def rotate_x(phi):
+    return _axis_rotation('x', phi)
+
+
+def rotate_y(theta):
+    return _axis_rotation('y', theta)
+
+
+def rotate_z(psi):
+    return _axis_rotation('z', psi)
+
+
+def get_smpl_l2ws(pose, rest_pose=None, scale=1., skel_type=SMPLSkeleton):
+    """Forward kinematics of ONE pose: axis-angle [24,3] -> joint-local-to-world matrices [24,4,4] (reference :334-376):
+    root at rest_pose[0], every other joint = parent . [R_j | rest_j - rest_parent]."""
+    from .synthetic import rodrigues
+    rest = (smpl_rest_pose if rest_pose is None else np.asarray(rest_pose)) * scale
+    rots = rodrigues(np.asarray(pose).reshape(-1, 3))
+    l2ws = []
+    for j, parent in enumerate(skel_type.joint_trees):
+        m = np.eye(4, dtype=np.result_type(rest.dtype, np.float32))
+        m[:3, :3] = rots[j]
+        m[:3, 3] = rest[j] if j == 0 else rest[j] - rest[parent]
+        l2ws.append(m if j == 0 else l2ws[parent] @ m)
+    return np.array(l2ws)

@@ -20,6 +20,8 @@ Fixtures
                      tau = 20 (step 0) with every stage tensor, and raw + final maps again at tau = 2000
   anerf_train.npz    A-H36M, 96 rays = 4 poses x 24, 12+6 samples, training mode (perturb = 0, noise = 0): loss terms and
                      gradients of the reference's autograd
+  sequences.npz      bullet-time / interpolation / selected-frame camera and pose sequences of run_render.py
+  render_path.npz    run_nerf.render_path end to end (valid-ray boxes, background blend), D-Surr, 4 images of 40 x 32
   pose_rot6d.npz     axis-angle -> rot6d incl. tiny angles (pytorch3d boundary, cross-checked
                      with scipy in the tests)
 """
@@ -391,6 +393,79 @@ def gen_valid_rays():
     print("valid_rays: boxes", [(tuple(b[0]), tuple(b[1])) for b in boxes], "n", [len(i) for i in idxs])
 
 
+def _sequence_inputs():
+    """4 poses / 4 cameras with off-axis camera translations and non-zero roots, so that every centring branch does something"""
+    rest = syn.rest_pose(0.48)
+    bones = syn.random_bones(4, seed=41).astype(np.float32)
+    _, _, kps = syn.forward_kinematics(bones, rest)
+    rng = np.random.default_rng(7)
+    kps = (kps + rng.normal(0, 0.3, size=(4, 1, 3))).astype(np.float32)
+    c2ws = syn.bullet_cameras(4, dist=3.0).astype(np.float32)
+    c2ws[:, :3, 3] += rng.normal(0, 0.2, size=(4, 3)).astype(np.float32)
+    focals = np.array([80., 82., 84., 86.], dtype=np.float32)
+    centers = rng.uniform(28, 36, size=(4, 2)).astype(np.float32)
+    return rest, bones, kps, c2ws, focals, centers
+
+
+def gen_sequences():
+    """Camera / pose sequence generators of the reference's run_render.py (:838-999) and load_data.py (:56-71), run from the
+    reference source with the `refined=(kps, bones)` in-memory branch (the HDF5 branch needs deepdish)."""
+    import math
+    rh.install_stubs()
+    from core.utils.skeleton_utils import get_smpl_l2ws, rotate_x, rotate_y, rotate_z
+    (gbt,) = rh.lift_functions("core/load_data.py", ["generate_bullet_time"],
+                               dict(np=np, math=math, rotate_x=rotate_x, rotate_y=rotate_y, rotate_z=rotate_z))
+    _, bullet, interp, selected = rh.lift_functions(
+        "run_render.py", ["find_idxs_with_map", "load_bullettime", "load_interpolate", "load_selected"],
+        dict(np=np, get_smpl_l2ws=get_smpl_l2ws, generate_bullet_time=gbt))
+    rest, bones, kps, c2ws, focals, centers = _sequence_inputs()
+    sel = np.array([2, 0, 3])
+    out = dict(rest=rest, bones=bones, kps=kps, c2ws=c2ws, focals=focals, centers=centers, sel=sel,
+               ring_x=gbt(c2ws[1], 5, 'x'), ring_y=gbt(c2ws[1], 5, 'y'), ring_z=gbt(c2ws[1], 5, 'z'))
+    fresh = lambda: dict(refined=(kps.copy(), bones.copy()))  # noqa: E731  (the loaders edit their inputs in place)
+    names = ("kps", "skts", "c2ws", "cam_idxs", "focals", "bones", "centers")
+    for tag, kw in (("bt", dict()), ("bt_nokp", dict(center_kps=False)), ("bt_raw", dict(center_kps=False, center_cam=False, undo_rot=True))):
+        r = bullet(None, c2ws.copy(), focals.copy(), rest, None, sel, n_bullet=3, centers=centers.copy(), **kw, **fresh())
+        out.update({f"{tag}_{n}": v for n, v in zip(names, r)})
+    for tag, kw in (("ip", dict()), ("ip_c", dict(center_cam=True)), ("ip_k", dict(center_kps=True))):
+        r = interp(None, c2ws.copy(), focals.copy(), rest, None, sel, n_step=4, **kw, **fresh())
+        out.update({f"{tag}_{n}": v for n, v in zip(names[:5], r)})
+    r = selected(None, c2ws.copy(), focals.copy(), rest, None, sel, centers=centers.copy(), **fresh())
+    out.update({f"sel_{n}": v for n, v in zip(names, r)})
+    np.savez_compressed(os.path.join(OUT, "sequences.npz"), **out)
+    print("sequences:", {k: v.shape for k, v in out.items() if k.startswith("bt_") and "raw" not in k and "nokp" not in k})
+
+
+def gen_render_path():
+    """`render_path` of the reference (run_nerf.py:29-147) end to end on CPU: D-Surr network, 2 poses x 2 cameras at 40 x 32,
+    valid-ray boxes, background images blended by (1 - acc); and once more with a white background"""
+    import torch.nn.functional as F
+    seed = 17
+    cfg, args, caster, kw_test, rest = build("danbo_surreal", seed, n_framecodes=4)
+    from core.trainer import render
+    from core.utils.ray_utils import kp_to_valid_rays
+    (rp,) = rh.lift_functions("run_nerf.py", ["render_path"],
+                              dict(np=np, torch=torch, F=F, time=__import__("time"), tqdm=lambda x: x, render=render,
+                                   kp_to_valid_rays=kp_to_valid_rays))
+    scene = syn.make_scene(n_poses=2, H=40, W=32, n_views=2, pose_seed=23, rest_scale=cfg["rest_scale"], cam_dist=7.0)
+    cams = np.stack([scene["cams"][0], scene["cams"][1], scene["cams"][1], scene["cams"][0]]).astype(np.float32)
+    rng = np.random.default_rng(3)
+    bg_imgs = rng.uniform(size=(2, 20, 16, 3)).astype(np.float32)          # half resolution: exercises the bilinear resize
+    bg_indices = np.array([1, 0, 0, 1])
+    kw = dict(kw_test, N_samples=16, N_importance=8)
+    res = {}
+    for tag, extra in (("bg", dict(bg_imgs=bg_imgs, bg_indices=bg_indices)), ("white", dict(white_bkgd=True))):
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            rgbs, disps, accs, idxs, boxes = rp(T(cams), (40, 32, float(scene["focal"])), 4096, kw, kp=T(scene["kps"]),
+                                                skts=T(scene["skts"]), bones=T(scene["bones"]), ret_acc=True, ext_scale=0.001, **extra)
+        res.update({f"{tag}_rgbs": rgbs, f"{tag}_disps": disps, f"{tag}_accs": accs})
+    np.savez_compressed(os.path.join(OUT, "render_path.npz"), cfg_name="danbo_surreal", weight_seed=seed, n_framecodes=4,
+                        N_samples=16, N_importance=8, pose_seed=23, cam_dist=7.0, H=40, W=32, focal=scene["focal"], cams=cams,
+                        kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], bg_imgs=bg_imgs, bg_indices=bg_indices,
+                        boxes=np.array([[b[0], b[1]] for b in boxes]), n_valid=np.array([len(i) for i in idxs]), **res)
+    print("render_path: boxes", [(tuple(b[0]), tuple(b[1])) for b in boxes], "acc mean", res["bg_accs"].mean())
+
+
 def gen_pose_rot6d():
     rh.install_stubs()
     from core.utils.skeleton_utils import axisang_to_rot6d
@@ -408,7 +483,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt", "args", "valid_rays"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -429,5 +504,9 @@ if __name__ == "__main__":
         gen_args_txt()
     if "valid_rays" in which:
         gen_valid_rays()
+    if "sequences" in which:
+        gen_sequences()
+    if "render_path" in which:
+        gen_render_path()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

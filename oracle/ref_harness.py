@@ -128,6 +128,17 @@ def _lift_config_parser():
     return parser
 
 
+def lift_functions(rel_path, names, namespace):
+    """Compile the named top-level functions of a reference script (whose module-level imports need packages this
+    image lacks: h5py, deepdish, imageio, tensorboard ...) into `namespace` and return them.  The source is read
+    from /root/reference at run time; nothing is copied into this repo."""
+    tree = ast.parse(open(os.path.join(REF_ROOT, rel_path)).read())
+    found = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    mod = ast.Module(body=[found[n] for n in names], type_ignores=[])
+    exec(compile(mod, f"<{rel_path}>", "exec"), namespace)
+    return [namespace[n] for n in names]
+
+
 def config_file_to_argv(path):
     """`key = value` lines -> argv; booleans are store_true flags; lists are `[a, b]`."""
     argv = []
