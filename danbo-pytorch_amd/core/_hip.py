@@ -45,7 +45,11 @@ SIGNATURES = {
     "danbo_composite_merged_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P],
     "danbo_anerf_encode_fwd": [P, P, P, P, I, I, I, P, P, P, F, I, c_long, I, P, P, P],
     "danbo_anerf_view_pe_fwd": [P, P, I, I, I, P, P],
-    "danbo_anerf_color_fwd": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P],
+    "danbo_anerf_color_fwd": [P, I, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P, P],
+    "danbo_linear16_set_trace": [P],
+    "danbo_linear16_packed_bytes": [I, I, I],
+    "danbo_linear16_pack": [P, c_long, c_long, I, I, I, P, P],
+    "danbo_linear16_fwd": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P],
 }
 
 _lib = None

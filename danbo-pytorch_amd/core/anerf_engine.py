@@ -1,23 +1,14 @@
 """Orchestration of the A-NeRF render path (nerf_type = nerf: joint-distance cutoff PE, W = 448 trunk).
 
-Per chunk of whole rays:  k_anerf_encode (HIP) -> 8 dense trunk layers + alpha + merged feature/view
-layer (plain library GEMMs with fused bias+ReLU epilogues, fp32) -> k_anerf_color (HIP).  Sampling,
+Per chunk of whole rays:  k_anerf_encode (HIP) -> 8 dense trunk layers, then alpha + merged feature/view layer as one
+225-wide layer (k_linear16: fp32-accurate hi/lo-split products on the fp16 matrix cores, bias + ReLU in the epilogue, skip
+layer fed from two buffers without a concatenated copy) -> k_anerf_color (HIP).  Sampling,
 compositing and importance resampling are the kernels the DANBO path uses.  A-NeRF has no in-volume mask:
 every sample is evaluated, exactly as in the reference (core/networks/nerf.py:107-122).
 """
 import torch
 
 from . import hip_ops as ops
-
-
-def _linear_relu(x, w_t, b, add=None):
-    """relu(x @ w_t + b [+ add]) with the bias/ReLU in the GEMM epilogue where hipBLASLt provides it."""
-    if add is None:
-        try:
-            return torch._addmm_activation(b, x, w_t, use_gelu=False)
-        except (RuntimeError, AttributeError):
-            return torch.relu_(torch.addmm(b, x, w_t))
-    return torch.relu_(torch.addmm(add, x, w_t))
 
 
 class AnerfEngine:
@@ -38,19 +29,20 @@ class AnerfEngine:
         W, VW = cfg["W"], cfg["view_W"]
         self.L, self.Lv = cfg["multires"], cfg["multires_views"]
         self.in_ch = (1 + 2 * self.L) * 24 + 72
-        self.w_t = [p[f"pts_linears.{i}.weight"].t().contiguous() for i in range(cfg["D"])]
         self.b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(cfg["D"])]
-        self.skip_after = set(cfg["skips"])
-        # layer after a skip: input = [x0 | h]  -> two GEMMs instead of a concatenated copy
-        self.w_skip = {i + 1: (self.w_t[i + 1][:self.in_ch].contiguous(), self.w_t[i + 1][self.in_ch:].contiguous())
-                       for i in self.skip_after}
-        self.alpha_w_t = p["alpha_linear.weight"].t().contiguous()
-        self.alpha_b = p["alpha_linear.bias"].contiguous()
+        # layer after a skip: input = [x0 | h], read from the two buffers (no concatenated copy)
+        self.skip_into = {i + 1 for i in cfg["skips"]}
+        self.layers = [ops.linear16_pack(p[f"pts_linears.{i}.weight"], K1=self.in_ch if i in self.skip_into else None)
+                       for i in range(cfg["D"])]
         wv = p["views_linears.0.weight"].double()                       # [VW, W + view_ch + code]
         wf, bf = p["feature_linear.weight"].double(), p["feature_linear.bias"].double()
         view_ch = (1 + 2 * self.Lv) * 72
         # feature_linear (no activation) folded into the view layer: one W -> VW GEMM per sample
-        self.w_fv_t = (wv[:, :W] @ wf).float().t().contiguous()        # [W, VW]
+        # ... and stacked on alpha_linear: rows [0, VW) = view features, row VW = density logit
+        head_w = torch.cat([(wv[:, :W] @ wf).float(), p["alpha_linear.weight"].float()], 0).contiguous()
+        self.head = ops.linear16_pack(head_w)
+        self.head_b = torch.cat([torch.zeros(VW, device=head_w.device), p["alpha_linear.bias"].float()]).contiguous()
+        self.VW = VW
         b_eff = wv[:, :W] @ bf + p["views_linears.0.bias"].double()
         # per-joint slices of the view weights: [24, 27, VW] with k = block*3 + axis
         nb = 1 + 2 * self.Lv
@@ -86,13 +78,14 @@ class AnerfEngine:
         return torch.bmm(Ej, self.w_view_j)
 
     def _trunk(self, x0):
-        h = _linear_relu(x0, self.w_t[0], self.b[0])
-        for i in range(1, self.cfg["D"]):
-            if i in self.w_skip:
-                wa, wb = self.w_skip[i]
-                h = _linear_relu(h, wb, None, add=torch.addmm(self.b[i], x0, wa))
+        h = None
+        for i, (packed, shape) in enumerate(self.layers):
+            if i == 0:
+                h = ops.linear16(x0, packed, shape, self.b[i], relu=True)
+            elif i in self.skip_into:
+                h = ops.linear16(x0, packed, shape, self.b[i], relu=True, x2=h)
             else:
-                h = _linear_relu(h, self.w_t[i], self.b[i])
+                h = ops.linear16(h, packed, shape, self.b[i], relu=True)
         return h
 
     def forward_samples(self, rays_o, rays_d, skts, cam_idx=None, z=None, pts=None, view=None, density_only=False):
@@ -111,19 +104,19 @@ class AnerfEngine:
         rays_per_chunk = max(1, self.rows_per_chunk // S)
         n_max = min(R, rays_per_chunk) * S
         buf = (torch.empty(n_max, self.in_ch, device=dev), torch.empty(n_max, 24, device=dev))
+        head_buf = torch.empty(n_max, (self.VW + 4) // 4 * 4, device=dev)     # [view features | density logit | pad to 16 B]
         for r0 in range(0, R, rays_per_chunk):
             nr = min(rays_per_chunk, R - r0)
             n = nr * S
             x0, w = ops.anerf_encode(rays_o, rays_d, skts, self.align, self.cutoff, tau, self.L, r0 * S, n, z=z, pts=pts,
                                      out=buf)
             h = self._trunk(x0)
-            alpha = torch.addmm(self.alpha_b, h, self.alpha_w_t)
+            head = ops.linear16(h, self.head[0], self.head[1], self.head_b, out=head_buf[:n, :self.VW + 1])
             if density_only:
-                dens[r0 * S:r0 * S + n] = alpha
+                dens[r0 * S:r0 * S + n] = head[:, self.VW:]
                 continue
-            featv = h @ self.w_fv_t
-            ops.anerf_color(featv, w, C, self.table, cam_idx if self.cfg["use_framecode"] else None, r0, nr, S,
-                            self.rgb_w, self.rgb_b, alpha.reshape(-1), raw)
+            ops.anerf_color(head[:, :self.VW], w, C, self.table, cam_idx if self.cfg["use_framecode"] else None, r0, nr, S,
+                            self.rgb_w, self.rgb_b, head[:, self.VW], raw)
         return dens if density_only else raw
 
     def density(self, pts, skts, bones=None):

@@ -356,15 +356,80 @@ def anerf_view_pe(rays_d, skts, L):
     return E
 
 
+def _rows(t, name):
+    """fp32 CUDA matrix whose rows may be strided (a column slice of a wider buffer) -> (tensor, row stride in floats)"""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected a float32 CUDA/HIP tensor -- libdanbo_hip has no CPU fallback")
+    if t.dim() == 1:
+        t = t.unsqueeze(1)
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
 def anerf_color(featv, w, C, table, cam_idx, ray0, nrays, S, rgb_w, rgb_b, alpha, raw_out):
-    """raw_out [R_total,S,4] rows of rays [ray0, ray0+nrays) are written."""
+    """raw_out [R_total,S,4] rows of rays [ray0, ray0+nrays) are written.  featv [rows,VW] and alpha [rows] may be column
+    slices of one wider buffer."""
     VW = featv.shape[1]
     R_total = C.shape[1]
     if cam_idx is not None:
         cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
         if not cam_idx.is_cuda:
             raise RuntimeError("cam_idx: expected a CUDA/HIP tensor")
-    _call("danbo_anerf_color_fwd", _p(_f32(featv, "featv")), _p(_f32(w, "w")), _p(_f32(C, "C")), _p(_f32(table, "table")),
+    featv, ldf = _rows(featv, "featv")
+    alpha, lda = _rows(alpha, "alpha")
+    _call("danbo_anerf_color_fwd", _p(featv), ldf, _p(_f32(w, "w")), _p(_f32(C, "C")), _p(_f32(table, "table")),
           _p(cam_idx), table.shape[0] - 1, R_total, int(ray0), int(nrays), int(S), VW, _p(_f32(rgb_w, "rgb_w")),
-          _p(_f32(rgb_b, "rgb_b")), _p(_f32(alpha, "alpha")), _p(raw_out), _stream())
+          _p(_f32(rgb_b, "rgb_b")), _p(alpha), lda, _p(raw_out), _stream())
     return raw_out
+
+
+# -------------------------------------------------------------------------------------- dense layer (fp16-split MFMA)
+def linear16_pack(weight, K1=None, transposed=False):
+    """nn.Linear weight [N, K] (or, `transposed`, a [K, N] matrix used as W^T) -> packed fragment buffer.
+    K1: columns that multiply the first input of a two-input (skip) layer; the rest multiply the second."""
+    w = _f32(weight, "weight")
+    N, K = (w.shape[1], w.shape[0]) if transposed else w.shape
+    K1 = K if K1 is None else int(K1)
+    nbytes = _hip.lib().danbo_linear16_packed_bytes(N, K1, K - K1)
+    if nbytes < 0:
+        raise ValueError(f"linear16: unsupported layer shape N={N}, K={K}")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    sn, sk = (1, w.stride(0)) if transposed else (w.stride(0), 1)
+    _call("danbo_linear16_pack", _p(w), sn, sk, N, K1, K - K1, _p(packed), _stream())
+    return packed, (N, K1, K - K1)
+
+
+def _aligned_rows(t, name):
+    """input of linear16: row stride a multiple of 4 floats covering round_up(K, 4) readable, finite columns, 16-byte aligned
+    base.  Anything else (e.g. DANBO's 195-wide first layer) is staged through a zero-padded copy."""
+    t, ld = _rows(t, name)
+    K = t.shape[1]
+    if ld % 4 == 0 and ld >= (K + 3) // 4 * 4 and t.data_ptr() % 16 == 0:
+        return t, ld
+    buf = torch.zeros(t.shape[0], (K + 3) // 4 * 4, device=t.device, dtype=torch.float32)
+    buf[:, :K] = t
+    return buf[:, :K], buf.stride(0)
+
+
+def linear16(x1, packed, shape, bias=None, relu=False, x2=None, out=None, count=None):
+    """y = act([x1 | x2] W^T + bias) for the rows of x1 (/ x2); `out` may be a column slice of a wider buffer whose row
+    stride is a multiple of 4 floats."""
+    N, K1, K2 = shape
+    if x1.shape[1] != K1 or (K2 > 0) != (x2 is not None):
+        raise ValueError(f"linear16: inputs do not match the packed layer ({K1} + {K2} columns)")
+    x1, ld1 = _aligned_rows(x1, "x1")
+    M = x1.shape[0]
+    ld2 = 0
+    if x2 is not None:
+        if tuple(x2.shape) != (M, K2):
+            raise ValueError("linear16: x2 shape")
+        x2, ld2 = _aligned_rows(x2, "x2")
+    if out is None:
+        out = torch.empty(M, (N + 3) // 4 * 4, device=x1.device, dtype=torch.float32)[:, :N]
+    y, ldy = _rows(out, "out")
+    if y.data_ptr() != out.data_ptr() or tuple(y.shape) != (M, N) or ldy % 4 or y.data_ptr() % 16:
+        raise ValueError("linear16: out must be a [M, N] float32 matrix, unit column stride, rows 16-byte aligned")
+    _call("danbo_linear16_fwd", _p(x1), ld1, K1, _p(x2), ld2, K2, _p(packed), _p(_f32(bias, "bias")), N, 1 if relu else 0,
+          _p(y), ldy, M, _p(count), _stream())
+    return out

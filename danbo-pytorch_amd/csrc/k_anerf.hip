@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void k_anerf_view_pe(const float* __restrict__
 //   x[c]   = relu(featv[row][c] + table[cam][c] + sum_j w[row][j] * C[j][ray][c])
 //   raw    = (rgb_w x + rgb_b, alpha[row])
 constexpr int AN_VW_MAX = 256;  // 4 columns per lane
-__global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ featv, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ featv, int ldf, const float* __restrict__ w,
                                                      const float* __restrict__ C, const float* __restrict__ table,
                                                      const int64_t* __restrict__ cam_idx, int n_codes, int R_total,
                                                      int ray0, int nrays, int S, int VW,
                                                      const float* __restrict__ rgb_w, const float* __restrict__ rgb_b,
-                                                     const float* __restrict__ alpha, float* __restrict__ raw_out) {
+                                                     const float* __restrict__ alpha, int lda, float* __restrict__ raw_out) {
     const int lane = threadIdx.x & 63;
     const int wave_global = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ f
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = lane + 64 * i;
-                x[i] = c < VW ? featv[row * VW + c] + tb[i] : 0.f;
+                x[i] = c < VW ? featv[row * ldf + c] + tb[i] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ f
             }
             pr = wave_sum(pr); pg = wave_sum(pg); pb = wave_sum(pb);
             if (lane == 0)
-                reinterpret_cast<float4*>(raw_out)[(size_t)ray * S + s] = make_float4(pr + rb0, pg + rb1, pb + rb2, alpha[row]);
+                reinterpret_cast<float4*>(raw_out)[(size_t)ray * S + s] = make_float4(pr + rb0, pg + rb1, pb + rb2, alpha[row * lda]);
         }
     }
 }
@@ -213,16 +213,16 @@ extern "C" int danbo_anerf_view_pe_fwd(const float* rays_d, const float* skts, i
     DANBO_LAUNCH_RET();
 }
 
-extern "C" int danbo_anerf_color_fwd(const float* featv, const float* w, const float* C, const float* table,
+extern "C" int danbo_anerf_color_fwd(const float* featv, int ld_featv, const float* w, const float* C, const float* table,
                                 const int64_t* cam_idx, int n_codes, int R_total, int ray0, int nrays, int S, int VW,
-                                const float* rgb_w, const float* rgb_b, const float* alpha, float* raw_out,
+                                const float* rgb_w, const float* rgb_b, const float* alpha, int ld_alpha, float* raw_out,
                                 void* stream) {
-    DANBO_CHECK_ARG(featv && w && C && table && rgb_w && rgb_b && alpha && raw_out);
+    DANBO_CHECK_ARG(featv && w && C && table && rgb_w && rgb_b && alpha && raw_out && ld_featv >= VW && ld_alpha >= 1);
     DANBO_CHECK_ARG(VW > 0 && VW <= AN_VW_MAX && S > 0 && nrays >= 0 && ray0 >= 0 && ray0 + nrays <= R_total && n_codes >= 0);
     if (nrays == 0) return 0;
     const int blocks = ceil_div(nrays, 4);
     const int grid = blocks < NUM_CU * 8 ? blocks : NUM_CU * 8;
-    hipLaunchKernelGGL(k_anerf_color, dim3(grid), dim3(256), 0, (hipStream_t)stream, featv, w, C, table, cam_idx, n_codes,
-                       R_total, ray0, nrays, S, VW, rgb_w, rgb_b, alpha, raw_out);
+    hipLaunchKernelGGL(k_anerf_color, dim3(grid), dim3(256), 0, (hipStream_t)stream, featv, ld_featv, w, C, table, cam_idx,
+                       n_codes, R_total, ray0, nrays, S, VW, rgb_w, rgb_b, alpha, ld_alpha, raw_out);
     DANBO_LAUNCH_RET();
 }

@@ -1,0 +1,363 @@
+// One dense layer  Y = act([X1 | X2] W^T + b)  with fp32-accurate products on the half-precision matrix cores
+// (the hi/lo split of k_mlp16.hip: x = fp16(x) + fp16(x - fp16(x)), product = hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// gfx950 only.  Used where activations have to exist in HBM anyway: the A-NeRF trunk (W = 448, inputs 432 / 880) and
+// the GEMMs of the training step.
+//
+// Dataflow (the transposed formulation of k_mlp16.hip, one layer per launch):
+//   Y^T [N x rows] = W [N x K] * X^T [K x rows]
+//   A operand = weights: pre-packed in MFMA fragment order (danbo_linear16_pack), streamed once per 128-row tile through
+//               a 4-slot x 32 KB LDS ring by global_load_lds; one chunk = one k-step of 32 inputs x 16 output tiles;
+//               fragments are read from LDS one batch (two tiles) ahead of the MFMAs that use them;
+//   B operand = this wavefront's 16 rows: lane (n, q) loads the 8 inputs 32 s + 8 q .. + 7 of row n straight from HBM
+//               (32 B per lane, 128 B contiguous per row and k-step), two k-steps ahead, and splits them in registers;
+//   D         = up to 32 output tiles of 16 features x 16 rows in registers (128 VGPRs); lane (n, q) owns features
+//               16 T + 4 q + i of row n, i.e. 16-byte pieces of the output row: bias + activation + one dwordx4 store.
+// Everything that is not an MFMA -- ring refill, hi/lo split of the next k-step's rows, their next request -- is spread over
+// the eight MFMA batches of a chunk, so that the matrix pipe only idles at the barrier of the ring hand-over.
+// Algorithmic HBM bytes per row: 4 (K + N); flops 2 K N (x3 half-precision MFMA products).
+// Measured (tools/micro_linear16.py, MI355X): 448 -> 448 on 262 144 rows 0.45 ms = 233 TFLOP/s fp32-equivalent (the fp32
+// library GEMM + ReLU: 1.07 ms); s_memtime trace of a k-step (--trace): 2 x ~1 700 cycles of MFMA batches, 2 x ~500 at the
+// hand-over barrier (the two wavefronts of a SIMD finish their halves of a chunk one after the other), ~450 loop / tile
+// bookkeeping; the end of a row tile (drain + 28 stores per lane) costs ~15 000 cycles per 80 000.
+#include <type_traits>
+#include "common.hpp"
+
+namespace danbo {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int L16_CHUNK = 32768, L16_SLOTS = 4, L16_BM = 128, L16_THREADS = 512, L16_MAX_N = 512;
+constexpr int L16_LDS_BYTES = L16_SLOTS * L16_CHUNK + L16_MAX_N * 4;
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing: chunk c = s * NH + hf holds k-step s of output tiles 16 hf .. 16 hf + 15:
+//   [tile t][hi | lo][lane 64][8 halves],  lane (m, q) = W[16 T + m][col(s, 8 q + e)]
+// k-steps 0 .. KS1-1 cover the K1 columns of X1, the rest the K2 columns of X2 (each part zero-padded to 32)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__ w, long sn, long sk, int N, int K1, int K2, int NH,
+                                                       _Float16* __restrict__ packed) {
+    const int KS1 = (K1 + 31) / 32, KS = KS1 + (K2 + 31) / 32;
+    const long total = (long)KS * NH * (L16_CHUNK / 2);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int chunk = (int)(idx / (L16_CHUNK / 2)), within = (int)(idx % (L16_CHUNK / 2));
+        const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
+        const int s = chunk / NH, hf = chunk % NH;
+        const int n = 16 * (16 * hf + (piece >> 1)) + (lane & 15);
+        const int kk = 8 * (lane >> 4) + e;
+        int col = -1;
+        if (s < KS1) { if (32 * s + kk < K1) col = 32 * s + kk; }
+        else if (32 * (s - KS1) + kk < K2) col = K1 + 32 * (s - KS1) + kk;
+        const float v = (n < N && col >= 0) ? w[n * sn + col * sk] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        packed[idx] = (piece & 1) ? (_Float16)(v - (float)hi) : hi;
+    }
+}
+
+struct Lin16Args {
+    const float* x1;
+    const float* x2;
+    int ld1, ld2, K1, K2;
+    const char* packed;
+    const float* bias;
+    float* y;
+    int ldy, N, act, M;
+    const int32_t* count;
+    long long* trace;  // dev tool (tools/micro_linear16.py --trace): s_memtime stamps of one wavefront, or nullptr
+};
+
+struct LinPipe {
+    const char* src_lane;   // packed + wave * 4096 + lane * 16: this lane's 16 bytes of piece 4 * wave of chunk 0
+    char* dst_wave;         // ring + wave * 4096
+    int issue_chunk, issue_slot, cons_slot, nch, skip;
+};
+
+// every wavefront loads 4 of the 32 pieces of a chunk; the instruction offset advances the global and the LDS address alike
+__device__ __forceinline__ void lin_issue(LinPipe& p) {
+    const auto* src = (const __attribute__((address_space(1))) char*)(p.src_lane + (size_t)p.issue_chunk * L16_CHUNK);
+    auto* dst = (__attribute__((address_space(3))) char*)(p.dst_wave + p.issue_slot * L16_CHUNK);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+    p.issue_chunk = p.issue_chunk + 1 == p.nch ? 0 : p.issue_chunk + 1;
+    p.issue_slot = p.issue_slot + 1 == L16_SLOTS ? 0 : p.issue_slot + 1;
+}
+
+// Ring hand-over before chunk c: my share of chunk c+1 has landed, then (barrier) everybody's has and everybody is done
+// with chunk c-1, whose slot is refilled with chunk c+3 a little later, under chunk c's MFMAs (lin_issue).  vmcnt is an in-order counter for loads; the loads younger than
+// those of chunk c+1 are the 4 of chunk c+2 plus the 2 input-row loads of one k-step, at every hand-over (the kernel
+// issues the same loads in every k-step, past the end too), so "at most 6 outstanding" means chunk c+1 is in LDS -- and
+// so are the input rows of the k-step that starts here, which were requested two k-steps ago (NH = 1: exactly the 6
+// youngest loads are younger than them).  Stores in flight do not break this: the wait allows no more outstanding
+// operations than there are younger LOADS.
+template <class Stamp>
+__device__ __forceinline__ void lin_handover(LinPipe& p, const Stamp& stamp) {
+    if (p.skip > 0) --p.skip;                    // chunk c+1 is known to be there (prologue / end of a row tile)
+    else __builtin_amdgcn_s_waitcnt(0xF76);      // vmcnt(6); expcnt, lgkmcnt: no wait
+    stamp();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp();
+}
+
+__device__ __forceinline__ void lin_split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)(v[e] - (float)hh);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input rows.  Lane (n, q) needs the 8 inputs 32 s + 8 q .. + 7 of its row in every k-step; they are requested two k-steps
+// ahead.  A register that is the target of a load in flight must never be copied or spilled by the compiler, and across a
+// loop back-edge it does exactly that with ordinary (even inline-asm "+v") values.  So the two row sets live in fixed
+// physical registers v[240:247] / v[248:255] that only the inline asm below names: the compiler, which needs ~215
+// registers for this kernel and allocates from v0 upwards, never touches them (tests/test_host_logic.py checks the ISA), and
+// it adds no waits of its own because it does not see the loads.  The ring hand-over's wait covers them (lin_handover).
+// Columns past the end of a part are read from the clamped address, i.e. they repeat earlier columns of the same row:
+// their packed weights are zero, so the (finite) values do not matter, nothing outside the row is touched, and every
+// load instruction is issued for every lane in every k-step, which the vmcnt accounting relies on.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SET>
+__device__ __forceinline__ void lin_request_rows(const float* pa, const float* pb) {
+    if (SET == 0) {
+        asm volatile("global_load_dwordx4 v[240:243], %0, off\n\tglobal_load_dwordx4 v[244:247], %1, off" ::"v"(pa), "v"(pb)
+                     : "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+    } else {
+        asm volatile("global_load_dwordx4 v[248:251], %0, off\n\tglobal_load_dwordx4 v[252:255], %1, off" ::"v"(pa), "v"(pb)
+                     : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+    }
+}
+template <int SET>
+__device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
+    if (SET == 0)
+        asm volatile("v_mov_b32 %0, v240\n\tv_mov_b32 %1, v241\n\tv_mov_b32 %2, v242\n\tv_mov_b32 %3, v243\n\t"
+                     "v_mov_b32 %4, v244\n\tv_mov_b32 %5, v245\n\tv_mov_b32 %6, v246\n\tv_mov_b32 %7, v247"
+                     : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
+    else
+        asm volatile("v_mov_b32 %0, v248\n\tv_mov_b32 %1, v249\n\tv_mov_b32 %2, v250\n\tv_mov_b32 %3, v251\n\t"
+                     "v_mov_b32 %4, v252\n\tv_mov_b32 %5, v253\n\tv_mov_b32 %6, v254\n\tv_mov_b32 %7, v255"
+                     : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
+}
+
+template <int NH>
+__global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_bias = reinterpret_cast<float*>(smem + L16_SLOTS * L16_CHUNK);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int M = resolve_count(a.count, a.M);
+    const int n_tiles = (M + L16_BM - 1) / L16_BM;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int KS1 = (a.K1 + 31) / 32, KS = KS1 + (a.K2 + 31) / 32, nt = (a.N + 15) / 16;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = my_tiles * KS;  // k-steps this workgroup runs
+
+    for (int i = tid; i < L16_MAX_N; i += L16_THREADS) s_bias[i] = (a.bias != nullptr && i < a.N) ? a.bias[i] : 0.f;
+
+    LinPipe p{a.packed + wave * 4096 + lane * 16, smem + wave * 4096, 0, 0, 0, KS * NH, 2};
+    lin_issue(p);
+    lin_issue(p);
+    lin_issue(p);
+
+    // request the rows of the next k-step of this workgroup's stream (k-steps of its row tiles one after the other; past
+    // the end the last k-step is requested again: the vmcnt pattern stays uniform)
+    int rq_s = 0, rq_it = 0;
+    auto request = [&](auto set) {
+        long row = (long)(blockIdx.x + rq_it * gridDim.x) * L16_BM + wave * 16 + n;
+        row = row < M ? row : M - 1;
+        const bool second = rq_s >= KS1;
+        const float* base = second ? a.x2 + row * a.ld2 : a.x1 + row * a.ld1;
+        const int Kp = ((second ? a.K2 : a.K1) + 3) & ~3;   // rows are readable (and finite) up to a multiple of 4 columns
+        const int col = 32 * (second ? rq_s - KS1 : rq_s) + 8 * q;
+        lin_request_rows<decltype(set)::value>(base + min(col, Kp - 4), base + min(col + 4, Kp - 4));
+        if (rq_s + 1 < KS) ++rq_s;
+        else if (rq_it + 1 < my_tiles) rq_s = 0, ++rq_it;
+    };
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_waitcnt(0xF70);  // vmcnt(0): chunks 0-2 and the first rows are here (p.skip = 2 relies on it)
+    __syncthreads();
+    half8 bh, bl;   // B fragments of the current k-step; those of the next one are prepared under this one's MFMAs
+    {
+        float x[8];
+        lin_take_rows<0>(x);
+        lin_split8(x, bh, bl);
+        request(std::integral_constant<int, 0>{});
+    }
+
+    f32x4 acc[16 * NH];
+    int s = 0, it = 0, tr = 0;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u;
+    const bool tracing = a.trace != nullptr && blockIdx.x == 0 && wave == 1;
+    auto stamp = [&]() {
+        if (tracing && it == 2 && lane == 0 && tr < 256) a.trace[tr++] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    // one k-step (`set`: the register set holding the rows of k-step g + 1)
+    auto kstep = [&](auto set, int g) {
+        if (s == 0) {
+#pragma unroll
+            for (int T = 0; T < 16 * NH; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        stamp();
+        half8 nbh, nbl;
+        float nx[8];
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            stamp();
+            lin_handover(p, stamp);
+            stamp();
+            const int slot = p.cons_slot;
+            p.cons_slot = p.cons_slot + 1 == L16_SLOTS ? 0 : p.cons_slot + 1;
+            // A fragments one batch (two tiles = 4 reads) ahead of the MFMAs that use them.  The reads are inline asm with a
+            // manual s_waitcnt: LDS reads return in order, so "at most 4 outstanding" means batch b has arrived while the
+            // reads of batch b + 1 stay in flight under batch b's six MFMAs.  (Reads the compiler tracks are always waited
+            // for with lgkmcnt(0), which exposes the full LDS latency once per batch: 38 % -> measured below.)
+            half8 fr[2][4];
+            const unsigned la = lds_base + (unsigned)(slot * L16_CHUNK);
+#define DANBO_L16_READ(B, F)                                                                                              \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                                      \
+                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                                           \
+                 : "=v"(F[0]), "=v"(F[1]), "=v"(F[2]), "=v"(F[3])                                                           \
+                 : "v"(la), "i"((4 * (B)) * 1024), "i"((4 * (B) + 1) * 1024), "i"((4 * (B) + 2) * 1024), "i"((4 * (B) + 3) * 1024))
+            DANBO_L16_READ(0, fr[0]);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                half8 (&f)[4] = fr[b & 1];   // hi, lo of tile 2b; hi, lo of tile 2b + 1
+                half8 (&fn)[4] = fr[(b + 1) & 1];
+                switch (b) {                 // the offsets are instruction immediates
+                    case 0: DANBO_L16_READ(1, fn); break;
+                    case 1: DANBO_L16_READ(2, fn); break;
+                    case 2: DANBO_L16_READ(3, fn); break;
+                    case 3: DANBO_L16_READ(4, fn); break;
+                    case 4: DANBO_L16_READ(5, fn); break;
+                    case 5: DANBO_L16_READ(6, fn); break;
+                    case 6: DANBO_L16_READ(7, fn); break;
+                    default: break;
+                }
+                // Work that is not MFMA is spread over the batches, a few VALU / scalar instructions under each batch's six
+                // MFMAs: the ring refill (the slot of chunk c-1 is free once the barrier has been passed), and in the first
+                // chunk of a k-step the next k-step's rows (requested two k-steps ago, arrived: see lin_handover) become B
+                // fragments and their registers are re-used for the request after next.
+                if (b == 1) lin_issue(p);
+                if (hf == 0 && b == 2) lin_take_rows<decltype(set)::value>(nx);
+                if (hf == 0 && b >= 3 && b <= 6) {
+#pragma unroll
+                    for (int e = 2 * (b - 3); e < 2 * (b - 3) + 2; ++e) {
+                        const _Float16 hh = (_Float16)nx[e];
+                        nbh[e] = hh;
+                        nbl[e] = (_Float16)(nx[e] - (float)hh);
+                    }
+                }
+                if (hf == 0 && b == 7) request(set);
+                if (b < 7) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+                if (16 * hf + 2 * b < nt) {  // uniform: whole pairs of tiles past N are skipped
+                    f32x4& c0 = acc[16 * hf + 2 * b];
+                    f32x4& c1 = acc[16 * hf + 2 * b + 1];
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], bh, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[2], bh, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], bl, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[2], bl, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[1], bh, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[3], bh, c1, 0, 0, 0);
+                }
+            }
+#undef DANBO_L16_READ
+        }
+        bh = nbh;
+        bl = nbl;
+        stamp();
+        if (++s < KS) return;
+        // End of a row tile.  Everything requested so far -- chunks c+1, c+2 of the ring and the rows of the next two
+        // k-steps, all at least a chunk old -- is waited for BEFORE the stores are issued, and the next two hand-overs then
+        // skip their wait: a vmcnt wait right behind 28 stores per lane would stall every wavefront until the stores have
+        // reached memory; this way they have two chunks of MFMA work to drain under.
+        __builtin_amdgcn_s_waitcnt(0xF70);
+        p.skip = 2;
+        const long row = (long)(blockIdx.x + it * gridDim.x) * L16_BM + wave * 16 + n;
+        if (row < M) {
+            float* yrow = a.y + row * a.ldy;
+#pragma unroll
+            for (int T = 0; T < 16 * NH; ++T) {
+                const int col = 16 * T + 4 * q;
+                if (col < a.N) {
+                    f32x4 v = acc[T] + *reinterpret_cast<const f32x4*>(s_bias + col);
+                    if (a.act == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    // inline asm like the loads: no compiler-inserted waits.  The hand-over waits stay valid with stores in
+                    // flight even if stores and loads complete out of order with respect to each other: they allow no more
+                    // outstanding operations than there are younger LOADS, and loads return in order.
+                    if (col + 4 <= a.N) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yrow + col), "v"(v) : "memory");
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (col + i < a.N) asm volatile("global_store_dword %0, %1, off" ::"v"(yrow + col + i), "v"(v[i]) : "memory");
+                    }
+                }
+            }
+        }
+        stamp();
+        s = 0;
+        ++it;
+    };
+    // k-step g prepares the rows of k-step g + 1, which live in register set (g + 1) & 1
+    for (int g = 0; g < G; g += 2) {
+        kstep(std::integral_constant<int, 1>{}, g);
+        if (g + 1 < G) kstep(std::integral_constant<int, 0>{}, g + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA still in flight must not outlive the workgroup's LDS
+}
+
+static inline int lin16_nh(int N) { return N <= 256 ? 1 : 2; }
+
+}  // namespace danbo
+
+using namespace danbo;
+
+static long long* g_lin16_trace = nullptr;
+/* dev tool: buffer of 256 int64 that receives s_memtime stamps of wavefront 1 of workgroup 0 during its third row tile */
+extern "C" int danbo_linear16_set_trace(void* buf) {
+    g_lin16_trace = (long long*)buf;
+    return 0;
+}
+
+extern "C" int danbo_linear16_packed_bytes(int N, int K1, int K2) {
+    if (N < 1 || N > L16_MAX_N || K1 < 1 || K2 < 0) return -1;
+    return ((K1 + 31) / 32 + (K2 + 31) / 32) * lin16_nh(N) * L16_CHUNK;
+}
+
+extern "C" int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int K1, int K2, void* packed, void* stream) {
+    DANBO_CHECK_ARG(w && packed && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0);
+    const long total = (long)danbo_linear16_packed_bytes(N, K1, K2) / 2;
+    hipLaunchKernelGGL(k_linear16_pack, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, stride_n, stride_k, N, K1,
+                       K2, lin16_nh(N), (_Float16*)packed);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
+                                  const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, void* stream) {
+    DANBO_CHECK_ARG(x1 && packed && y && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0 && (K2 == 0 || x2) && M >= 0);
+    DANBO_CHECK_ARG(ldy >= N && (act == 0 || act == 1));
+    // 16-byte accesses: row strides multiples of 4 floats, rows readable up to a multiple of 4 columns, aligned bases
+    DANBO_CHECK_ARG(ld1 % 4 == 0 && ld1 >= ((K1 + 3) & ~3) && (K2 == 0 || (ld2 % 4 == 0 && ld2 >= ((K2 + 3) & ~3))) && ldy % 4 == 0);
+    DANBO_CHECK_ARG((uintptr_t)x1 % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
+    if (M == 0) return 0;
+    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, g_lin16_trace};
+    const int tiles = (M + L16_BM - 1) / L16_BM;
+    const dim3 grid(tiles < NUM_CU ? tiles : NUM_CU), block(L16_THREADS);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES);
+        once = true;
+    }
+    if (lin16_nh(N) == 1) hipLaunchKernelGGL(k_linear16<1>, grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_linear16<2>, grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}

@@ -281,9 +281,27 @@ int danbo_anerf_view_pe_fwd(const float* rays_d, const float* skts, int R, int G
  * featv = (views_linears.0[:, :W] feature_linear) h  [rows,VW];  C [24,R_total,VW] = per-ray, per-joint
  * products of views_linears.0 with E;  table [n_codes+1,VW] = frame-code part + folded biases, last row =
  * mean code (Optcodes eval, core/networks/embedding.py:22-23);  cam_idx int64 [R_total] or NULL. */
-int danbo_anerf_color_fwd(const float* featv, const float* w, const float* C, const float* table, const int64_t* cam_idx,
-                    int n_codes, int R_total, int ray0, int nrays, int S, int VW, const float* rgb_w,
-                    const float* rgb_b, const float* alpha, float* raw_out /*[R_total,S,4]*/, void* stream);
+int danbo_anerf_color_fwd(const float* featv, int ld_featv, const float* w, const float* C, const float* table,
+                    const int64_t* cam_idx, int n_codes, int R_total, int ray0, int nrays, int S, int VW, const float* rgb_w,
+                    const float* rgb_b, const float* alpha, int ld_alpha, float* raw_out /*[R_total,S,4]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One dense layer on rows that live in HBM:  y = act([x1 | x2] W^T + bias)  -- nn.Linear (+ ReLU) as the reference's
+ * trunks apply it (core/networks/nerf.py:176-195: `h = relu(l(h))`, skip layers `cat([input, h])`), with fp32-accurate
+ * products on the fp16 matrix cores (hi/lo split, see csrc/k_linear16.hip).  Used by the A-NeRF trunk (W = 448).
+ * ------------------------------------------------------------------------------------------- */
+
+/* dev tool (tools/micro_linear16.py --trace): int64[256] device buffer for s_memtime stamps of one wavefront, NULL = off */
+int danbo_linear16_set_trace(void* buf);
+/* size of the packed weight buffer of an N x (K1 + K2) layer; -1 if unsupported (N > 512) */
+int danbo_linear16_packed_bytes(int N, int K1, int K2);
+/* W[n, k] = w[n * stride_n + k * stride_k]  (strides in floats: (K, 1) for nn.Linear.weight, (1, N) for its transpose);
+ * columns [0, K1) multiply x1, [K1, K1 + K2) multiply x2 */
+int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int K1, int K2, void* packed, void* stream);
+/* y [M, ldy] (first N columns written); x1 [M, ld1], x2 [M, ld2] or NULL (K2 = 0); bias [N] or NULL; act 0 = none,
+ * 1 = ReLU; rows = min(*count, M) if count != NULL (device-side row count of a compacted list) */
+int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
+                       const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, void* stream);
 
 #ifdef __cplusplus
 }

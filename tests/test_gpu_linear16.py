@@ -1,0 +1,101 @@
+"""k_linear16 (one dense layer, fp32-accurate hi/lo-split products on the fp16 matrix cores) against a float64 reference of
+the same nn.Linear (+ ReLU): the tolerance is that of a plain fp32 GEMM (relative 2e-6 of the row's |x| . |w| bound)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, w, b, relu):
+    y = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+    return torch.relu(y) if relu else y
+
+
+def _check(y, x, w, b, relu, tol=3e-6):
+    ref = _ref(x, w, b, relu)
+    bound = x.double().abs() @ w.double().abs().t() + 1e-30          # magnitude of the accumulated products
+    err = ((y.double() - ref).abs() / bound).max().item()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(1000, 448, 448, True), (129, 432, 448, True), (5000, 448, 225, False), (77, 64, 16, False),
+                                         (300, 256, 256, True), (4096, 448, 1, False), (257, 36, 40, True)])
+def test_linear16_matches_float64(M, K, N, relu):
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    packed, shape = ops.linear16_pack(w)
+    y = ops.linear16(x, packed, shape, b, relu=relu)
+    assert y.shape == (M, N)
+    _check(y, x, w, b, relu)
+
+
+def test_linear16_skip_layer_two_inputs_strided_views_and_device_count():
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, K1, K2, N = 3000, 432, 448, 448
+    xa, xb = torch.randn(M, K1, generator=g).to(DEV), torch.randn(M, K2, generator=g).to(DEV)
+    w = (torch.randn(N, K1 + K2, generator=g) / 30).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    packed, shape = ops.linear16_pack(w, K1=K1)
+    y = ops.linear16(xa, packed, shape, b, relu=True, x2=xb)
+    _check(y, torch.cat([xa, xb], 1), w, b, True)
+    # output into a column slice of a wider buffer; the neighbouring columns stay untouched
+    wide = torch.full((M, 456), 7.0, device=DEV)
+    ops.linear16(xa, packed, shape, b, relu=True, x2=xb, out=wide[:, :448])
+    assert torch.equal(wide[:, :448], y) and bool((wide[:, 448:] == 7.0).all())
+    # inputs that are column slices of wider buffers
+    big = torch.randn(M, 900, generator=g).to(DEV)
+    y2 = ops.linear16(big[:, :432], packed, shape, b, relu=True, x2=big[:, 440:888])
+    _check(y2, torch.cat([big[:, :432], big[:, 440:888]], 1), w, b, True)
+    # device-side row count (compacted lists): rows past the count are not written
+    cnt = torch.tensor([1234], dtype=torch.int32, device=DEV)
+    out = torch.full((M, N), -1.0, device=DEV)
+    ops.linear16(xa, packed, shape, b, relu=True, x2=xb, out=out, count=cnt)
+    assert torch.equal(out[:1234], y[:1234]) and bool((out[1234:] == -1.0).all())
+
+
+def test_linear16_transposed_weight_is_the_backward_data_gemm():
+    """dX = dY W: the same kernel with the weight read through its transpose"""
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(9)
+    M, K, N = 700, 256, 451
+    dy = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(K, N, generator=g) / 16).to(DEV)          # nn.Linear(N -> K).weight
+    packed, shape = ops.linear16_pack(w, transposed=True)
+    assert shape == (N, K, 0)
+    buf = torch.empty(M, 452, device=DEV)
+    dx = ops.linear16(dy, packed, shape, None, out=buf[:, :N])
+    _check(dx, dy, w.t().contiguous(), None, False)
+
+
+def test_linear16_unaligned_rows_take_the_scalar_path():
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, K, N = 500, 195, 256                                     # DANBO's first layer: 195 inputs, rows not 16-byte aligned
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / 14).to(DEV)
+    packed, shape = ops.linear16_pack(w)
+    _check(ops.linear16(x, packed, shape, None, relu=True), x, w, None, True)
+
+
+def test_linear16_large_is_deterministic_and_rejects_bad_shapes():
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(13)
+    M = 1 << 17
+    x = torch.randn(M, 448, generator=g).to(DEV)
+    w = (torch.randn(448, 448, generator=g) / 21).to(DEV)
+    packed, shape = ops.linear16_pack(w)
+    a, b = ops.linear16(x, packed, shape, None, relu=True), ops.linear16(x, packed, shape, None, relu=True)
+    assert torch.equal(a, b)
+    _check(a[::97], x[::97], w, None, True)
+    with pytest.raises(ValueError):
+        ops.linear16_pack(torch.zeros(600, 64, device=DEV))
+    with pytest.raises(ValueError):
+        ops.linear16(x[:, :100], packed, shape)
+    with pytest.raises(RuntimeError):
+        ops.linear16(x.cpu(), packed, shape)

@@ -274,3 +274,34 @@ def test_kp_to_valid_rays_matches_reference():
     assert max_err(rays[3][0].numpy(), g["rays_o3"]) < 1e-6 and max_err(rays[3][1].numpy(), g["rays_d3"]) < 1e-6
     tl, br = boxes[0]
     assert 0 < tl[0] < br[0] < int(g["W"]) - 1 and 0 < tl[1] < br[1] < int(g["H"]) - 1   # an interior box, not the frame
+
+
+def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
+    """k_linear16 requests its input rows two k-steps ahead into fixed physical registers v[240:255] that only its inline asm
+    names; nothing the compiler generates may touch them (a copy or spill of a register whose load is in flight reads stale
+    data), and the compiler must not add vmcnt waits of its own inside the k-step loop (they would drain the weight ring).
+    Checked on the gfx950 ISA of both instantiations."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "danbo-pytorch_amd", "csrc", "k_linear16.hip")
+    out = str(tmp_path / "k_linear16.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out, src],
+                   check=True, capture_output=True)
+    text = open(out).read()
+    high = re.compile(r"\bv(24\d|25[0-5])\b|v\[(24\d|25[0-5]):")
+    for nh, handovers in ((1, 2), (2, 4)):
+        name = f"_ZN5danbo10k_linear16ILi{nh}EEEvNS_9Lin16ArgsE"
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")].split("\n")
+        assert not any("scratch_" in l for l in body), "register spills"
+        touching = [l.strip() for l in body if high.search(l)]
+        loads = [l for l in touching if l.startswith("global_load_dwordx4 v[2")]
+        takes = [l for l in touching if re.match(r"v_mov_b32 v\d+, v2[45]\d$", l)]
+        # requests: three in the prologue + one per unrolled k-step, 2 loads each; takes: 8 registers in the prologue and in
+        # each of the two k-steps
+        assert len(loads) == 10 and len(takes) == 24 and len(touching) == 34, touching
+        waits = sorted(re.search(r"vmcnt\(\d+\)", l).group(0) for l in body if "s_waitcnt" in l and "vmcnt" in l)
+        # bias table, prologue, one per row-tile end in each of the two unrolled k-steps, final drain; one per hand-over
+        assert waits == sorted(["vmcnt(0)"] * 5 + ["vmcnt(6)"] * handovers), waits

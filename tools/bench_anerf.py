@@ -55,7 +55,7 @@ def main():
     print(json.dumps(dict(metric="ray-samples/s", value=n / ms * 1e3, ms_per_frame=ms, rays=len(ro), samples_per_ray=S + Sf,
                           tau=a.tau, executed_mac_per_sample=mac, reference_mac_per_sample=2268000,
                           tflops_executed=n * mac * 2 / ms / 1e9, acc_mean=float(out["acc_map"].mean()),
-                          config="h36m_zju/anerf_base (SURVEY 8d config 5), fp32 library GEMM trunk")))
+                          config="h36m_zju/anerf_base (SURVEY 8d config 5), k_linear16 trunk (fp16-split MFMA)")))
 
 
 if __name__ == "__main__":
