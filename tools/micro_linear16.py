@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=262144)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--zeros", action="store_true", help="all-zero inputs and weights: no operand toggling (power probe)")
     ap.add_argument("--trace", action="store_true", help="s_memtime stamps of one wavefront over one row tile (448 x 448)")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -48,6 +49,8 @@ def main():
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)
+        if a.zeros:
+            x.zero_(), w.zero_(), b.zero_()
         packed, shape = ops.linear16_pack(w)
         y = torch.empty(M, N, device=dev)
         for _ in range(3):

@@ -1,4 +1,5 @@
-"""micro-benchmark of the f16-split MLP kernel on the bench workload's coarse pass (dev tool)"""
+"""micro-benchmark of the f16-split MLP kernel on the bench workload's coarse pass (dev tool)
+    python tools/micro_mlp16.py [reps] [--zeros]     --zeros: same rows, all-zero weights and inputs (no operand toggling: power probe)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "danbo-pytorch_amd"))
@@ -6,7 +7,9 @@ import torch
 import bench
 from core import hip_ops as ops
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+zeros = "--zeros" in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+reps = int(args[0]) if args else 10
 eng, inp, _ = bench.build_workload(torch.device("cuda:0"), 0)
 eng.refresh()
 near, far = eng.near_far(inp["rays_o"], inp["rays_d"], inp["cyls"], inp["skts"])
@@ -18,6 +21,12 @@ n = int(cnt.item())
 h = ops.gather_assign_blend16(geo, vols, bits, eng.aw, eng.assign16, lst, cnt, geo.M)[0]
 raw = torch.zeros(geo.M, 4, device="cuda")
 cview, raw_empty = eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"])
+if zeros:
+    with torch.no_grad():
+        for prm in eng.p.values():
+            prm.zero_()
+    eng.refresh()
+    h.zero_(), cview.zero_()
 fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n)
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
