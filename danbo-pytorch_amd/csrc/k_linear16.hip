@@ -15,7 +15,7 @@
 // Everything that is not an MFMA -- ring refill, hi/lo split of the next k-step's rows, their next request -- is spread over
 // the eight MFMA batches of a chunk, so that the matrix pipe only idles at the barrier of the ring hand-over.
 // Algorithmic HBM bytes per row: 4 (K + N); flops 2 K N (x3 half-precision MFMA products).
-// Measured (tools/micro_linear16.py, MI355X): 448 -> 448 on 262 144 rows 0.45 ms = 233 TFLOP/s fp32-equivalent (the fp32
+// Measured (tools/micro_linear16.py, MI355X): 448 -> 448 on 262 144 rows 0.43 ms = 248 TFLOP/s fp32-equivalent (the fp32
 // library GEMM + ReLU: 1.07 ms); s_memtime trace of a k-step (--trace): 2 x ~1 700 cycles of MFMA batches, 2 x ~500 at the
 // hand-over barrier (the two wavefronts of a SIMD finish their halves of a chunk one after the other), ~450 loop / tile
 // bookkeeping; the end of a row tile (drain + 28 stores per lane) costs ~15 000 cycles per 80 000.
@@ -143,7 +143,8 @@ __device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
                      : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
 }
 
-template <int NH>
+// NP: tile pairs in the last chunk of a k-step known at compile time (no branches in the batch loop), 0 = taken from N
+template <int NH, int NP, bool TRACE>
 __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + L16_SLOTS * L16_CHUNK);
@@ -192,9 +193,8 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     f32x4 acc[16 * NH];
     int s = 0, it = 0, tr = 0;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u;
-    const bool tracing = a.trace != nullptr && blockIdx.x == 0 && wave == 1;
-    auto stamp = [&]() {
-        if (tracing && it == 2 && lane == 0 && tr < 256) a.trace[tr++] = (long long)__builtin_amdgcn_s_memtime();
+    auto stamp = [&]() {   // compiled out unless the trace buffer is set (danbo_linear16_set_trace)
+        if (TRACE && blockIdx.x == 0 && wave == 1 && it == 2 && lane == 0 && tr < 256) a.trace[tr++] = (long long)__builtin_amdgcn_s_memtime();
     };
     // one k-step (`set`: the register set holding the rows of k-step g + 1)
     auto kstep = [&](auto set, int g) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                 if (hf == 0 && b == 7) request(set);
                 if (b < 7) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-                if (16 * hf + 2 * b < nt) {  // uniform: whole pairs of tiles past N are skipped
+                if (NP ? (hf < NH - 1 || b < NP) : (16 * hf + 2 * b < nt)) {  // whole pairs of tiles past N are skipped
                     f32x4& c0 = acc[16 * hf + 2 * b];
                     f32x4& c1 = acc[16 * hf + 2 * b + 1];
                     c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], bh, c0, 0, 0, 0);
@@ -351,13 +351,23 @@ extern "C" int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float*
     Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, g_lin16_trace};
     const int tiles = (M + L16_BM - 1) / L16_BM;
     const dim3 grid(tiles < NUM_CU ? tiles : NUM_CU), block(L16_THREADS);
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES);
-        once = true;
+    const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;   // tile pairs in the last chunk of a k-step
+#define DANBO_L16_GO(NH_, NP_, TR_)                                                                                        \
+    {                                                                                                                      \
+        static bool once = false;                                                                                          \
+        if (!once) {                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear16<NH_, NP_, TR_>),                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES);                          \
+            once = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((k_linear16<NH_, NP_, TR_>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);               \
     }
-    if (lin16_nh(N) == 1) hipLaunchKernelGGL(k_linear16<1>, grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_linear16<2>, grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);
+    if (a.trace && nh == 2) DANBO_L16_GO(2, 0, true)
+    else if (nh == 2 && np == 8) DANBO_L16_GO(2, 8, false)
+    else if (nh == 2 && np == 6) DANBO_L16_GO(2, 6, false)   // N = 448: the A-NeRF trunk
+    else if (nh == 2) DANBO_L16_GO(2, 0, false)
+    else if (np == 8) DANBO_L16_GO(1, 8, false)              // N in 225 .. 256
+    else DANBO_L16_GO(1, 0, false)
+#undef DANBO_L16_GO
     DANBO_LAUNCH_RET();
 }

@@ -291,8 +291,8 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
                    check=True, capture_output=True)
     text = open(out).read()
     high = re.compile(r"\bv(24\d|25[0-5])\b|v\[(24\d|25[0-5]):")
-    for nh, handovers in ((1, 2), (2, 4)):
-        name = f"_ZN5danbo10k_linear16ILi{nh}EEEvNS_9Lin16ArgsE"
+    for nh, np_, handovers in ((1, 0, 2), (2, 0, 4), (1, 8, 2), (2, 6, 4), (2, 8, 4)):
+        name = f"_ZN5danbo10k_linear16ILi{nh}ELi{np_}ELb0EEEvNS_9Lin16ArgsE"
         body = text[text.index(name + ":"):]
         body = body[:body.index(".Lfunc_end")].split("\n")
         assert not any("scratch_" in l for l in body), "register spills"
