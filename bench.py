@@ -61,7 +61,7 @@ def render(eng, inp, dense=False):
                       N_SAMPLES, N_IMPORTANCE, chunk=4096, dense=dense)
 
 
-def cpu_baseline(extra, n_rays=4096):
+def cpu_baseline(extra, n_rays=4096, frame=None):
     """The numpy oracle (a CPU port of the reference path) on one 4096-ray chunk of the frame."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import danbo_oracle as o
@@ -73,9 +73,15 @@ def cpu_baseline(extra, n_rays=4096):
     z = np.zeros(n_rays, dtype=np.int64)
     orc = o.DanboOracle(cfg, sd, rest)
     t0 = time.perf_counter()
-    orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], np.zeros(n_rays, np.int64), 1,
-               N_SAMPLES, N_IMPORTANCE)
+    ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], np.zeros(n_rays, np.int64), 1,
+                     N_SAMPLES, N_IMPORTANCE)
     dt = time.perf_counter() - t0
+    parity = None
+    if frame is not None:   # the timed HIP path's image on the same rays (checker only: nothing here is timed or shipped)
+        rgb, acc = frame["rgb_map"][sl].cpu().numpy(), frame["acc_map"][sl].cpu().numpy()
+        parity = dict(against="oracle/danbo_oracle.py on the cpu_baseline sample", rays=n_rays,
+                      psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])), max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()),
+                      max_abs_acc=float(np.abs(acc - ref["acc_map"]).max()))
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
@@ -83,7 +89,7 @@ def cpu_baseline(extra, n_rays=4096):
         cores = os.cpu_count() or 1
     return dict(value=n_rays * (N_SAMPLES + N_IMPORTANCE) / dt, unit="ray-samples/s", cores=int(cores), kind="port",
                 sample=f"{n_rays} centre rays x {N_SAMPLES}+{N_IMPORTANCE} samples of the same frame through "
-                       f"oracle/danbo_oracle.py (numpy, BLAS threads), {dt:.1f} s")
+                       f"oracle/danbo_oracle.py (numpy, BLAS threads), {dt:.1f} s"), parity
 
 
 def main():
@@ -197,7 +203,9 @@ def main():
             result["dense_mlp_tflops_lower_bound"] = 2.0 * mac * samples_per_frame / td / 1e12
             result["dense_equals_culled"] = bool(torch.equal(out_d["rgb_map"], out["rgb_map"]))
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(extra)
+            result["cpu_baseline"], parity = cpu_baseline(extra, frame=out)
+            if parity is not None:
+                result["parity"] = parity
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
