@@ -157,32 +157,43 @@ __global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ f
             const int c = lane + 64 * i;
             tb[i] = c < VW ? table[(size_t)code * VW + c] : 0.f;
         }
-        for (int s = 0; s < S; ++s) {
-            const size_t row = (size_t)rl * S + s;
-            const float* wr = w + row * J;
-            float x[4];
+        // four samples per trip: all their loads (16 feature values and 4 x 24 cutoff weights) are issued before the first
+        // FMA, so one memory latency is paid per four samples instead of per sample (a wavefront walks its ray alone)
+        constexpr int U = 4;
+        for (int s0 = 0; s0 < S; s0 += U) {
+            float x[U][4], wj[U][J], al[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = lane + 64 * i;
-                x[i] = c < VW ? featv[row * ldf + c] + tb[i] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const size_t row = (size_t)rl * S + min(s0 + u, S - 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + 64 * i;
+                    x[u][i] = c < VW ? featv[row * ldf + c] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < J; ++j) wj[u][j] = w[row * J + j];
+                al[u] = alpha[row * lda];
             }
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const float wj = wr[j];
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) x[i] = fmaf(wj, cj[j][i], x[i]);
-            }
-            float pr = 0.f, pg = 0.f, pb = 0.f;
+                for (int i = 0; i < 4; ++i) x[u][i] = (lane + 64 * i) < VW ? x[u][i] + tb[i] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float xr = fmaxf(x[i], 0.f);
-                pr = fmaf(xr, rw[0][i], pr);
-                pg = fmaf(xr, rw[1][i], pg);
-                pb = fmaf(xr, rw[2][i], pb);
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[u][i] = fmaf(wj[u][j], cj[j][i], x[u][i]);
+                float pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xr = fmaxf(x[u][i], 0.f);
+                    pr = fmaf(xr, rw[0][i], pr);
+                    pg = fmaf(xr, rw[1][i], pg);
+                    pb = fmaf(xr, rw[2][i], pb);
+                }
+                pr = wave_total(pr); pg = wave_total(pg); pb = wave_total(pb);   // DPP scan: no LDS-crossbar shuffles
+                if (lane == 0 && s0 + u < S)
+                    reinterpret_cast<float4*>(raw_out)[(size_t)ray * S + s0 + u] = make_float4(pr + rb0, pg + rb1, pb + rb2, al[u]);
             }
-            pr = wave_sum(pr); pg = wave_sum(pg); pb = wave_sum(pb);
-            if (lane == 0)
-                reinterpret_cast<float4*>(raw_out)[(size_t)ray * S + s] = make_float4(pr + rb0, pg + rb1, pb + rb2, alpha[row * lda]);
         }
     }
 }
