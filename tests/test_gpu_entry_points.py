@@ -86,6 +86,11 @@ def test_train_checkpoint_render_round_trip(tmp_path):
     assert rgbs.shape == (6, 48, 48, 3) and accs.shape == (6, 48, 48, 1) and len(boxes) == 6
     assert np.isfinite(rgbs).all() and accs.max() > 0.05
     assert np.load(tmp_path / "out" / "bt" / "image.npy").shape == (6, 48, 48, 3)
+    # pose interpolation between two frames: n_step blends per interval + the last pose, all from the first camera
+    rgbs, accs, boxes, _ = run_render.run_render(base + ["--render_type", "interpolate", "--n_step", "3", "--selected_idxs", "0", "2",
+                                                         "--runname", "ip", "--render_res", "32", "32", "--no_save"])
+    assert rgbs.shape == (4, 32, 32, 3) and np.isfinite(rgbs).all() and not (tmp_path / "out" / "ip" / "image.npy").exists()
+    assert np.abs(rgbs[0] - rgbs[-1]).max() > 1e-3          # the pose really changes along the sequence
     rgbs, _, _, scores = run_render.run_render(base + ["--render_type", "val", "--runname", "val", "--render_res", "32", "32", "--eval"])
     assert rgbs.shape[0] == 4 and len(scores["psnr"]) == 4 and np.isfinite(scores["psnr"]).all()
     assert (tmp_path / "out" / "val" / "score_final.txt").exists()
