@@ -74,14 +74,13 @@ class DANBO(NeRF):
 
     def engine(self, align):
         """The kernel orchestrator bound to this module's parameters (rebuilt if they move)."""
-        params = {**dict(self.named_parameters()), **dict(self.named_buffers())}
+        params = self._engine_params()
         key = (next(self.parameters()).device, align.data_ptr())
         if self._engine is None or self._engine_key != key:
-            self._engine = DanboEngine(self.engine_config(), {k: v.detach() for k, v in params.items()},
-                                       align.to(key[0]))
+            self._engine = DanboEngine(self.engine_config(), params, align.to(key[0]))
             self._engine_key = key
         else:
-            self._engine.p = {k: v.detach() for k, v in params.items()}
+            self._engine.p = params
         return self._engine
 
     @staticmethod

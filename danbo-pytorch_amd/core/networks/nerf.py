@@ -101,15 +101,37 @@ class NeRF(nn.Module):
                     multires=pe.num_freqs, multires_views=dpe.num_freqs, use_framecode=self.use_framecode,
                     density_scale=self.density_scale, use_volume_near_far=False, N_samples=None, N_importance=None)
 
+    # ---- parameters as the engines see them: detached views, rebuilt only when storage moved ----
+    def _engine_params(self):
+        """{name: detached tensor} of every parameter and buffer.  Walking the module tree costs ~0.3 ms, which is most of the
+        host time of a 512-ray validation chunk, so the walk is cached; in-place updates (optimizer steps, load_state_dict)
+        keep the storage and are seen through the shared version counters, moves (`.to()`) change the pointers."""
+        cache = self.__dict__.get('_engine_params_cache')
+        if cache is None:
+            named = list(self.named_parameters()) + list(self.named_buffers())
+            cache = self.__dict__['_engine_params_cache'] = [named, None, None]
+        ptrs = tuple(v.data_ptr() for _, v in cache[0])
+        if ptrs != cache[1]:
+            cache[1], cache[2] = ptrs, {k: v.detach() for k, v in cache[0]}
+        return cache[2]
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): buffers are replaced by new tensors
+        self.__dict__.pop('_engine_params_cache', None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop('_engine_params_cache', None)
+        return super().load_state_dict(*args, **kwargs)
+
     def engine(self, align):
         from ..anerf_engine import AnerfEngine
-        params = {**dict(self.named_parameters()), **dict(self.named_buffers())}
+        params = self._engine_params()
         key = (next(self.parameters()).device, align.data_ptr())
         if self._engine is None or self._engine_key != key:
-            self._engine = AnerfEngine(self.engine_config(), {k: v.detach() for k, v in params.items()}, align.to(key[0]))
+            self._engine = AnerfEngine(self.engine_config(), params, align.to(key[0]))
             self._engine_key = key
         else:
-            self._engine.p = {k: v.detach() for k, v in params.items()}
+            self._engine.p = params
         return self._engine
 
     def forward(self, inputs, netchunk=1024 * 64):

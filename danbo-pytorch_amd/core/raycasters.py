@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 from . import hip_ops as ops
 from .encoders import get_pe_embedder, get_pts_embedder
+from .render_engine import DanboEngine
 from .networks import create_nerf
 from .utils.skeleton_utils import SMPLSkeleton, bone_align_transforms, get_skel_profile_from_rest_pose
 
@@ -135,6 +136,16 @@ class RayCaster(nn.Module):
         if align_bones is not None:
             self.init_bone_align_transforms()
 
+    # ---- HIP-graph replay of the eval chain for small chunks (see render_rays) ----
+    use_graphs = True
+    graph_max_rays = 8192
+
+    @property
+    def _graphs(self):
+        if '_graph_cache' not in self.__dict__:
+            self.__dict__['_graph_cache'] = _GraphCache()
+        return self.__dict__['_graph_cache']
+
     def init_bone_align_transforms(self):
         if self.align_bones != 'align':
             raise NotImplementedError("align_bones must be 'align'")
@@ -211,15 +222,24 @@ class RayCaster(nn.Module):
             raise NotImplementedError("stochastic sampling belongs to the training path")
         eng = self._engine()
         G = int(N_uniques)
-        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
         skts_g, bones_g, cyls_g = self._per_pose(skts, G), self._per_pose(bones, G), self._per_pose(cyls, G)
-        R = rays_o.shape[0]
-        near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., R, ray_batch[:, 6], ray_batch[:, 7])
-        if eng.cfg['use_volume_near_far']:
-            ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
         eng.cfg['density_scale'] = preproc_kwargs.get('density_scale', eng.cfg['density_scale'])
-        return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance,
-                          near_far=(near, far))
+        R = ray_batch.shape[0]
+
+        def chain(rb, skts_g, bones_g, cyls_g, cams):
+            rays_o, rays_d = rb[:, 0:3].contiguous(), rb[:, 3:6].contiguous()
+            near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., R, rb[:, 6], rb[:, 7])
+            if eng.cfg['use_volume_near_far']:
+                ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
+            return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance, near_far=(near, far))
+
+        # Small ray chunks (the reference casts `chunk // 8` = 512 rays at a time during validation) are launch-bound: the
+        # ~25 kernels of the chain are captured once per chunk shape as a HIP graph and replayed.
+        if self.use_graphs and R <= self.graph_max_rays and isinstance(eng, DanboEngine):
+            key = (R, G, int(N_samples), int(N_importance), cams is not None, eng.cfg['use_volume_near_far'],
+                   float(eng.cfg['density_scale']))
+            return self._graphs.run(eng, key, chain, ray_batch, skts_g, bones_g, cyls_g, cams)
+        return chain(ray_batch, skts_g, bones_g, cyls_g, cams)
 
     def render_rays_train(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
                           subject_idxs=None, lindisp=False, perturb=0., N_importance=0, raw_noise_std=0.,
@@ -278,6 +298,60 @@ class RayCaster(nn.Module):
         grid = torch.stack([gx, gy, gz], -1)
         dens = self.render_pts_density(grid.reshape(-1, 1, 3) + kps[0, 0], kps, skts, bones)[..., :1]
         return dens.reshape(*grid.shape[:-1]).transpose(1, 0)
+
+
+class _GraphCache:
+    """One captured HIP graph per (chunk shape, sampling, engine state).  The engine's packed weights are part of the
+    captured pointers, so every graph is dropped when the engine has been refreshed with new parameter versions."""
+
+    def __init__(self, max_graphs=8):
+        self.max_graphs, self.engine_key, self.graphs = max_graphs, None, {}
+
+    def run(self, eng, key, chain, rb, skts_g, bones_g, cyls_g, cams):
+        state = (eng._packed_key, eng.mlp_mode)
+        if self.engine_key != state:
+            self.graphs.clear()
+            self.engine_key = state
+        g = self.graphs.get(key)
+        if g is None:
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+            g = self.graphs[key] = _ChainGraph(chain, rb, skts_g, bones_g, cyls_g, cams)
+        return g(rb, skts_g, bones_g, cyls_g, cams)
+
+
+class _ChainGraph:
+    def __init__(self, chain, rb, skts_g, bones_g, cyls_g, cams):
+        self.inputs = [x.clone().contiguous() if x is not None else None for x in (rb.float(), skts_g.float(), bones_g.float(),
+                                                                                   cyls_g.float(), cams)]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):       # eager warm-up off the capture: lazy initialisations, allocator pools
+            chain(*self.inputs)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out = chain(*self.inputs)
+            self.keys = list(out)
+            self.shapes = [tuple(out[k].shape) for k in self.keys]
+            R = rb.shape[0]
+            self.packed = torch.cat([out[k].reshape(R, -1) for k in self.keys], 1)   # one buffer to copy out per replay
+
+    def __call__(self, rb, skts_g, bones_g, cyls_g, cams):
+        for dst, src in zip(self.inputs, (rb, skts_g, bones_g, cyls_g, cams)):
+            if dst is not None:
+                dst.copy_(src)
+        self.graph.replay()
+        flat = self.packed.clone()
+        out, c = {}, 0
+        for k, shp in zip(self.keys, self.shapes):
+            w = 1
+            for d in shp[1:]:
+                w *= d
+            out[k] = flat[:, c:c + w].reshape(shp)
+            c += w
+        return out
 
 
 class GraphCaster(RayCaster):

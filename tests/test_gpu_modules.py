@@ -167,3 +167,38 @@ def test_whole_chunk_misses_the_cylinder_falls_back_to_the_placeholder_bounds():
     assert out["rgb_map"].shape == (R, 3) and out["T_i"].shape == (R, 24)
     assert bool(torch.isfinite(out["rgb_map"]).all())
     assert max_err(N(out["rgb_map"]), ref["rgb_map"]) < 1e-5 and max_err(N(out["acc_map"]), ref["acc_map"]) < 1e-5
+
+
+def test_small_chunks_replay_a_hip_graph_and_equal_the_eager_chain():
+    """chunks of <= 8192 rays (the reference validates with 512-ray chunks) go through a captured HIP graph: same kernels,
+    bit-identical outputs; a parameter update drops the graphs"""
+    g = golden("danbo_stages")
+    caster, kw = build("h36m_zju/danbo_base.txt", g)
+    pose = g["pose_of_ray"]
+    args = (T(g["ray_batch"]),)
+    kwargs = dict(N_samples=int(g["N_samples"]), kp_batch=T(g["kps"][pose]), skts=T(g["skts"][pose]), cyls=T(g["cyls"][pose]),
+                  bones=T(g["bones"][pose]), cams=T(g["cam_idx"], torch.int64), N_importance=int(g["N_importance"]), N_uniques=2, **kw)
+    caster.use_graphs = False
+    eager = {k: v.clone() for k, v in caster(*args, **kwargs).items()}
+    caster.use_graphs = True
+    first = {k: v.clone() for k, v in caster(*args, **kwargs).items()}          # captures
+    again = caster(*args, **kwargs)                                              # replays
+    assert len(caster._graphs.graphs) == 1
+    for k in eager:
+        assert torch.equal(eager[k], first[k]) and torch.equal(eager[k], again[k]), k
+    # different inputs through the same graph
+    rb2 = args[0].clone()
+    rb2[:, 3:6] *= 1.01
+    caster.use_graphs = False
+    want = {k: v.clone() for k, v in caster(rb2, **kwargs).items()}
+    caster.use_graphs = True
+    got = caster(rb2, **kwargs)
+    assert len(caster._graphs.graphs) == 1 and all(torch.equal(want[k], got[k]) for k in want)
+    # a weight update invalidates the captured pointers
+    with torch.no_grad():
+        caster.network.alpha_linear.bias.add_(0.5)
+    caster.use_graphs = False
+    want = {k: v.clone() for k, v in caster(*args, **kwargs).items()}
+    caster.use_graphs = True
+    got = caster(*args, **kwargs)
+    assert all(torch.equal(want[k], got[k]) for k in want) and not torch.equal(want["acc_map"], eager["acc_map"])
