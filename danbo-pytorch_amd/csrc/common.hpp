@@ -83,6 +83,19 @@ __device__ __forceinline__ float wave_total(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_add(x)), 63));
 }
 
+// x of lane ^ 32 / lane ^ 16 on the VALU (gfx950 v_permlane32_swap / v_permlane16_swap + one select) instead of the
+// LDS-crossbar ds_bpermute that __shfl_xor compiles to
+__device__ __forceinline__ float lane_xor32(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0]: upper half = my lower half; r[1]: lower = my upper
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor16(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // r[0]: odd rows = my even rows; r[1]: even = my odd
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+
 // number of rows a kernel has to process: device-side count (clamped to capacity) or host n
 __device__ __forceinline__ int resolve_count(const int32_t* count, int n_cap) {
     if (count == nullptr) return n_cap;

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 keep[e] = hh ? f[8 + e] : f[e];                       // my half of my own bone
-                recv[e] = __shfl_xor(hh ? f[e] : f[8 + e], 32, 64);   // my half of the partner's bone
+                recv[e] = lane_xor32(hh ? f[e] : f[8 + e]);           // my half of the partner's bone
             }
             // bone 2i: half 0 keeps, half 1 receives; bone 2i+1: the other way round
             float even[8], odd[8];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
                 part = fmaf(fmaxf(acc[4 * jj + 2], 0.f), w.z, part);
                 part = fmaf(fmaxf(acc[4 * jj + 3], 0.f), w.w, part);
             }
-            const float logit = (part + __shfl_xor(part, 32, 64)) + s_b2[j];
+            const float logit = (part + lane_xor32(part)) + s_b2[j];
             if (a.confd != nullptr && row_ok && hh == 0) a.confd[(size_t)row * J + j] = logit;
             // ---- masked sigmoid + blend of this lane's 8 features ----
             const float valid = ((bits >> j) & 1u) ? 1.0f : 0.0f;

@@ -266,8 +266,8 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 
 // sum of the four lane-group partials of a sample; identical in all four groups
 __device__ __forceinline__ float quad_sum(float p) {
-    p += __shfl_xor(p, 16, 64);
-    p += __shfl_xor(p, 32, 64);
+    p += lane_xor16(p);
+    p += lane_xor32(p);
     return p;
 }
 
