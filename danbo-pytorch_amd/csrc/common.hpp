@@ -78,6 +78,14 @@ __device__ __forceinline__ float wave_scan_mul(float x) {
     DANBO_DPP_STEP(dpp_mul_, 1.f, 0x142, 0xa) DANBO_DPP_STEP(dpp_mul_, 1.f, 0x143, 0xc)
     return x;
 }
+// bitwise OR over the wave, in every lane (same DPP tree)
+__device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+#define DANBO_DPP_OR(CTRL, ROWMASK) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xf, false);
+    DANBO_DPP_OR(0x111, 0xf) DANBO_DPP_OR(0x112, 0xf) DANBO_DPP_OR(0x114, 0xf) DANBO_DPP_OR(0x118, 0xf)
+    DANBO_DPP_OR(0x142, 0xa) DANBO_DPP_OR(0x143, 0xc)
+#undef DANBO_DPP_OR
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 // total of the wave in every lane (summation order = the scan's tree)
 __device__ __forceinline__ float wave_total(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_add(x)), 63));

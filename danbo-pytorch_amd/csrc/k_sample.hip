@@ -276,9 +276,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
         uint32_t need = (1u << J) - 1u;
         if (prefilter) {
             uint32_t mine = s_mask[(int)(mac / S) - r_first] | s_mask[(int)(mbc / S) - r_first];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mine |= (uint32_t)__shfl_xor((int)mine, off, 64);
-            need = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+            need = wave_or(mine);
         }
         if (__builtin_amdgcn_readfirstlane((int)__all(ga == gb))) {
             const v2f px = {pa[0], pb[0]}, py = {pa[1], pb[1]}, pz = {pa[2], pb[2]};
