@@ -5,7 +5,8 @@
         --dataset synthetic --entry val --render_type bullet --runname demo_bullet --render_res 256 256 [--eval]
 
 A trained model (the reference's `args.txt` + `.tar` checkpoint formats) is rendered along a generated camera / pose
-sequence -- `bullet` (camera ring around selected poses), `interpolate` (axis-angle blend between selected poses), `val` /
+sequence -- `bullet` (camera ring around selected poses), `interpolate` (axis-angle blend between selected poses), `bubble`
+(camera wobbling around its position), `val` /
 `selected` (the data's own cameras) -- or sampled on a density grid (`--render_mesh`).  The sequence generators take arrays
 instead of the reference's HDF5 paths (no h5py / deepdish here); `--dataset synthetic` builds them from seeded poses, `--dataset
 npz --entry file.npz` reads them.  Outputs: `image/`, `acc/` as .npy stacks (no imageio here), `bboxes.npy`, and with
@@ -35,7 +36,7 @@ def config_parser():
     p.add_argument('--dataset', type=str, required=True, help="'synthetic' or 'npz'")
     p.add_argument('--entry', type=str, required=True, help='catalog entry: a split name (synthetic) or an .npz path')
     p.add_argument('--white_bkgd', action='store_true')
-    p.add_argument('--render_type', type=str, default='bullet', help='bullet | interpolate | selected | val')
+    p.add_argument('--render_type', type=str, default='bullet', help='bullet | interpolate | bubble | selected | val')
     p.add_argument('--render_mesh', action='store_true', help='sample the density grid instead of rendering images')
     p.add_argument('--mesh_res', type=int, default=255)
     p.add_argument('--mesh_radius', type=float, default=1.8)
@@ -122,6 +123,32 @@ def load_selected(kps, bones, c2ws, focals, rest_pose, selected_idxs, centers=No
     return kps, skts, c2ws, selected_idxs, focals, bones, (centers[selected_idxs] if centers is not None else None)
 
 
+def load_bubble(kps, bones, c2ws, focals, rest_pose, selected_idxs, x_deg=15., y_deg=25., z_t=0.1, centers=None, n_step=5):
+    """Every selected pose seen from a camera that wobbles around its own position: `n_step` points of a closed curve, rotation
+    about x by (cos t - 1) x_deg and about y by sin t y_deg, pushed back along z by (sin t + 1) z_t x (distance of the first
+    camera) (reference :1001-1073).  Poses are centred on their root.  Like the reference, `bones` comes back once per selected
+    pose (NOT repeated per step; `render_path` cycles shorter tensors), everything else once per (pose, step)."""
+    from core.utils.skeleton_utils import rotate_x, rotate_y
+    selected_idxs = np.asarray(selected_idxs)
+    c2ws, focals = _select_cameras(c2ws, focals, selected_idxs)
+    z_t = z_t * c2ws[0, 2, -1]
+    t = np.linspace(0., 2 * np.pi, n_step, endpoint=True)
+    motions = [rotate_x(xm) @ rotate_y(ym) for xm, ym in zip((np.cos(t) - 1.) * np.deg2rad(x_deg), np.sin(t) * np.deg2rad(y_deg))]
+    z_trans = (np.sin(t) + 1.) * z_t
+    out = []
+    for c2w in c2ws:
+        for m, dz in zip(motions, z_trans):
+            c = c2w.copy()
+            c[2, -1] += dz
+            out.append(m @ c)
+    rep = lambda x: np.repeat(x, n_step, axis=0)  # noqa: E731
+    kps, bones = kps[selected_idxs].copy(), bones[selected_idxs].copy()
+    kps -= kps[..., :1, :].copy()
+    kps, skts = _pose_chain(bones, rest_pose, kps[..., :1, :])
+    centers = rep(centers[selected_idxs]) if centers is not None else None
+    return rep(kps), rep(skts), np.array(out).reshape(-1, 4, 4), rep(selected_idxs), rep(focals), bones, centers
+
+
 # ---------------------------------------------------------------------------------------------------- model / data
 def load_nerf(args, nerf_args, device):
     """Network of `nerf_args` with the checkpoint's weights, frozen, in eval mode; the frame-code table takes its size from the
@@ -166,6 +193,9 @@ def load_render_data(args, nerf_args, dataset):
     elif args.render_type == 'interpolate':
         kps, skts, c2ws, cam_idxs, focals, bones = load_interpolate(*src, n_step=args.n_step)
         centers = None
+    elif args.render_type == 'bubble':
+        kps, skts, c2ws, cam_idxs, focals, bones, centers = load_bubble(*src, centers=centers, n_step=args.n_step)
+        bones = np.repeat(bones, args.n_step, axis=0)     # the pose GNN needs the bones of every frame, in frame order
     elif args.render_type in ('selected', 'val'):
         kps, skts, c2ws, cam_idxs, focals, bones, centers = load_selected(*src, centers=centers)
         if scale == 1.0:

@@ -415,9 +415,9 @@ def gen_sequences():
     from core.utils.skeleton_utils import get_smpl_l2ws, rotate_x, rotate_y, rotate_z
     (gbt,) = rh.lift_functions("core/load_data.py", ["generate_bullet_time"],
                                dict(np=np, math=math, rotate_x=rotate_x, rotate_y=rotate_y, rotate_z=rotate_z))
-    _, bullet, interp, selected = rh.lift_functions(
-        "run_render.py", ["find_idxs_with_map", "load_bullettime", "load_interpolate", "load_selected"],
-        dict(np=np, get_smpl_l2ws=get_smpl_l2ws, generate_bullet_time=gbt))
+    _, bullet, interp, selected, bubble = rh.lift_functions(
+        "run_render.py", ["find_idxs_with_map", "load_bullettime", "load_interpolate", "load_selected", "load_bubble"],
+        dict(np=np, get_smpl_l2ws=get_smpl_l2ws, generate_bullet_time=gbt, rotate_x=rotate_x, rotate_y=rotate_y))
     rest, bones, kps, c2ws, focals, centers = _sequence_inputs()
     sel = np.array([2, 0, 3])
     out = dict(rest=rest, bones=bones, kps=kps, c2ws=c2ws, focals=focals, centers=centers, sel=sel,
@@ -432,6 +432,8 @@ def gen_sequences():
         out.update({f"{tag}_{n}": v for n, v in zip(names[:5], r)})
     r = selected(None, c2ws.copy(), focals.copy(), rest, None, sel, centers=centers.copy(), **fresh())
     out.update({f"sel_{n}": v for n, v in zip(names, r)})
+    r = bubble(None, c2ws.copy(), focals.copy(), rest, None, sel, centers=centers.copy(), n_step=4, **fresh())
+    out.update({f"bb_{n}": v for n, v in zip(names, r)})
     np.savez_compressed(os.path.join(OUT, "sequences.npz"), **out)
     print("sequences:", {k: v.shape for k, v in out.items() if k.startswith("bt_") and "raw" not in k and "nokp" not in k})
 

@@ -52,6 +52,15 @@ def test_load_selected_matches_reference(seq):
         np.testing.assert_allclose(v, seq[f"sel_{n}"], atol=2e-6, err_msg=n)
 
 
+def test_load_bubble_matches_reference(seq):
+    import run_render
+    out = run_render.load_bubble(seq["kps"].copy(), seq["bones"].copy(), seq["c2ws"].copy(), seq["focals"].copy(), seq["rest"],
+                                 seq["sel"], centers=seq["centers"].copy(), n_step=4)
+    for n, v in zip(NAMES, out):
+        np.testing.assert_allclose(v, seq[f"bb_{n}"], atol=2e-6, err_msg=n)
+    assert out[2].shape == (12, 4, 4) and out[5].shape == (3, 24, 3)        # bones: once per pose, as in the reference
+
+
 def test_sequence_loaders_leave_inputs_untouched(seq):
     import run_render
     kps, bones, c2ws = seq["kps"].copy(), seq["bones"].copy(), seq["c2ws"].copy()

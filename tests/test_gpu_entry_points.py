@@ -91,6 +91,10 @@ def test_train_checkpoint_render_round_trip(tmp_path):
                                                          "--runname", "ip", "--render_res", "32", "32", "--no_save"])
     assert rgbs.shape == (4, 32, 32, 3) and np.isfinite(rgbs).all() and not (tmp_path / "out" / "ip" / "image.npy").exists()
     assert np.abs(rgbs[0] - rgbs[-1]).max() > 1e-3          # the pose really changes along the sequence
+    rgbs, _, boxes, _ = run_render.run_render(base + ["--render_type", "bubble", "--n_step", "3", "--selected_idxs", "1", "--runname", "bb",
+                                                      "--render_res", "32", "32", "--no_save"])
+    assert rgbs.shape == (3, 32, 32, 3) and np.isfinite(rgbs).all()
+    assert np.abs(rgbs[0] - rgbs[2]).max() < 1e-5 and np.abs(rgbs[0] - rgbs[1]).max() > 1e-3   # closed curve: last = first camera
     rgbs, _, _, scores = run_render.run_render(base + ["--render_type", "val", "--runname", "val", "--render_res", "32", "32", "--eval"])
     assert rgbs.shape[0] == 4 and len(scores["psnr"]) == 4 and np.isfinite(scores["psnr"]).all()
     assert (tmp_path / "out" / "val" / "score_final.txt").exists()
