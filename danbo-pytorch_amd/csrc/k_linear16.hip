@@ -1,5 +1,7 @@
 // One dense layer  Y = act([X1 | X2] W^T + b)  with fp32-accurate products on the half-precision matrix cores
 // (the hi/lo split of k_mlp16.hip: x = fp16(x) + fp16(x - fp16(x)), product = hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// (Accuracy: 2^-22 relative per product, plus an absolute floor of 2^-25 per operand -- the lo part of |x| < 1/8 is an fp16
+// subnormal.  Against float64, 200 random layer shapes: <= 3e-6 of sum |x||w| per output, 6e-6 for a K = 4 layer.)
 // gfx950 only.  Used where activations have to exist in HBM anyway: the A-NeRF trunk (W = 448, inputs 432 / 880) and
 // the GEMMs of the training step.
 //
