@@ -99,3 +99,20 @@ def test_linear16_large_is_deterministic_and_rejects_bad_shapes():
         ops.linear16(x[:, :100], packed, shape)
     with pytest.raises(RuntimeError):
         ops.linear16(x.cpu(), packed, shape)
+
+
+def test_linear16_random_layer_shapes():
+    """rows 1 .. 70 000, inputs 4 .. 708, outputs 1 .. 512: every tile-pair count, both ring widths, ragged last tiles"""
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(123)
+    for trial in range(40):
+        M = int(torch.randint(1, 70000, (1,), generator=g))
+        K = int(torch.randint(1, 60, (1,), generator=g)) * 4 * (1 + trial % 3)
+        N = int(torch.randint(1, 513, (1,), generator=g))
+        x = torch.randn(M, K, generator=g).to(DEV)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+        b = torch.randn(N, generator=g).to(DEV)
+        packed, shape = ops.linear16_pack(w)
+        y = ops.linear16(x, packed, shape, b, relu=bool(trial & 1))
+        # 2^-22 per product plus the fp16-subnormal floor of the lo parts (k_linear16.hip): visible only for K of a few columns
+        _check(y, x, w, b, bool(trial & 1), tol=3e-6 if K >= 32 else 2e-5)
