@@ -36,7 +36,7 @@ def config_parser():
     p.add_argument('--dataset', type=str, required=True, help="'synthetic' or 'npz'")
     p.add_argument('--entry', type=str, required=True, help='catalog entry: a split name (synthetic) or an .npz path')
     p.add_argument('--white_bkgd', action='store_true')
-    p.add_argument('--render_type', type=str, default='bullet', help='bullet | interpolate | bubble | selected | val')
+    p.add_argument('--render_type', type=str, default='bullet', help='bullet | interpolate | bubble | pose_rotate | selected | val')
     p.add_argument('--render_mesh', action='store_true', help='sample the density grid instead of rendering images')
     p.add_argument('--mesh_res', type=int, default=255)
     p.add_argument('--mesh_radius', type=float, default=1.8)
@@ -149,6 +149,26 @@ def load_bubble(kps, bones, c2ws, focals, rest_pose, selected_idxs, x_deg=15., y
     return rep(kps), rep(skts), np.array(out).reshape(-1, 4, 4), rep(selected_idxs), rep(focals), bones, centers
 
 
+def load_pose_rotate(kps, bones, c2ws, focals, rest_pose, selected_idxs, n_bullet=30):
+    """ONE selected pose whose root joint is turned through full circles about the world y, x and z axes (`n_bullet // 3` steps
+    each) in front of its fixed camera (reference :800-836; axis-angle <-> matrix there is pytorch3d, here scipy's Rotation).
+    -> kps, skts, bones, c2ws, cam_idxs, focals (the reference's order for this loader)"""
+    from scipy.spatial.transform import Rotation
+    selected_idxs = np.asarray(selected_idxs)
+    if len(selected_idxs) != 1:
+        raise ValueError("pose_rotate renders one selected pose (the reference's array shapes only fit one)")
+    kps, bones = kps[selected_idxs], bones[selected_idxs].copy()
+    root = np.eye(4, dtype=np.float32)
+    root[:3, :3] = Rotation.from_rotvec(bones[0, 0].astype(np.float64)).as_matrix()
+    rots = np.concatenate([generate_bullet_time(root, n_bullet // 3, axis) for axis in 'yxz'], 0)
+    n = len(rots)
+    bones = bones.repeat(n, 0)
+    bones[:, 0, :] = Rotation.from_matrix(rots[:, :3, :3].astype(np.float64)).as_rotvec().astype(bones.dtype)
+    c2ws, focals = _select_cameras(c2ws, focals, selected_idxs)
+    kps_out, skts = _pose_chain(bones, rest_pose, kps[..., :1, :])
+    return kps_out, skts, bones, c2ws.repeat(n, 0), selected_idxs.repeat(n, 0), focals.repeat(n, 0)
+
+
 # ---------------------------------------------------------------------------------------------------- model / data
 def load_nerf(args, nerf_args, device):
     """Network of `nerf_args` with the checkpoint's weights, frozen, in eval mode; the frame-code table takes its size from the
@@ -192,6 +212,9 @@ def load_render_data(args, nerf_args, dataset):
         kps, skts, c2ws, cam_idxs, focals, bones, centers = load_bullettime(*src, n_bullet=args.n_bullet, centers=centers)
     elif args.render_type == 'interpolate':
         kps, skts, c2ws, cam_idxs, focals, bones = load_interpolate(*src, n_step=args.n_step)
+        centers = None
+    elif args.render_type == 'pose_rotate':
+        kps, skts, bones, c2ws, cam_idxs, focals = load_pose_rotate(*src, n_bullet=args.n_bullet)
         centers = None
     elif args.render_type == 'bubble':
         kps, skts, c2ws, cam_idxs, focals, bones, centers = load_bubble(*src, centers=centers, n_step=args.n_step)

@@ -432,6 +432,13 @@ def gen_sequences():
         out.update({f"{tag}_{n}": v for n, v in zip(names[:5], r)})
     r = selected(None, c2ws.copy(), focals.copy(), rest, None, sel, centers=centers.copy(), **fresh())
     out.update({f"sel_{n}": v for n, v in zip(names, r)})
+    from core.utils.skeleton_utils import axisang_to_rot, rot_to_axisang
+    (pose_rotate,) = rh.lift_functions("run_render.py", ["load_pose_rotate"],
+                                       dict(np=np, torch=torch, get_smpl_l2ws=get_smpl_l2ws, generate_bullet_time=gbt,
+                                            axisang_to_rot=axisang_to_rot, rot_to_axisang=rot_to_axisang,
+                                            find_idxs_with_map=lambda s_, m_: s_))
+    r = pose_rotate(None, c2ws.copy(), focals.copy(), rest, None, np.array([2]), n_bullet=9, **fresh())
+    out.update({f"pr_{n}": v for n, v in zip(("kps", "skts", "bones", "c2ws", "cam_idxs", "focals"), r)})
     r = bubble(None, c2ws.copy(), focals.copy(), rest, None, sel, centers=centers.copy(), n_step=4, **fresh())
     out.update({f"bb_{n}": v for n, v in zip(names, r)})
     np.savez_compressed(os.path.join(OUT, "sequences.npz"), **out)

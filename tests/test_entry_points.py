@@ -61,6 +61,26 @@ def test_load_bubble_matches_reference(seq):
     assert out[2].shape == (12, 4, 4) and out[5].shape == (3, 24, 3)        # bones: once per pose, as in the reference
 
 
+def test_load_pose_rotate_matches_reference(seq):
+    """root-rotation sweep; the reference converts through pytorch3d (restated in oracle/ref_harness.py), here scipy: rotation
+    vectors agree as ROTATIONS (a turn by pi has two axis-angle forms), so the matrices derived from them are compared"""
+    import run_render
+    from scipy.spatial.transform import Rotation
+    out = run_render.load_pose_rotate(seq["kps"].copy(), seq["bones"].copy(), seq["c2ws"].copy(), seq["focals"].copy(), seq["rest"],
+                                      np.array([2]), n_bullet=9)
+    names = ("kps", "skts", "bones", "c2ws", "cam_idxs", "focals")
+    for n, v in zip(names, out):
+        if n == "bones":
+            a = Rotation.from_rotvec(v.reshape(-1, 3).astype(np.float64)).as_matrix()
+            b = Rotation.from_rotvec(seq["pr_bones"].reshape(-1, 3).astype(np.float64)).as_matrix()
+            np.testing.assert_allclose(a, b, atol=2e-6)
+        else:
+            np.testing.assert_allclose(v, seq[f"pr_{n}"], atol=5e-6, err_msg=n)
+    assert out[0].shape == (9, 24, 3)
+    with pytest.raises(ValueError):
+        run_render.load_pose_rotate(seq["kps"], seq["bones"], seq["c2ws"], seq["focals"], seq["rest"], np.array([0, 1]))
+
+
 def test_sequence_loaders_leave_inputs_untouched(seq):
     import run_render
     kps, bones, c2ws = seq["kps"].copy(), seq["bones"].copy(), seq["c2ws"].copy()

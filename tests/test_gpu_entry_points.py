@@ -91,6 +91,9 @@ def test_train_checkpoint_render_round_trip(tmp_path):
                                                          "--runname", "ip", "--render_res", "32", "32", "--no_save"])
     assert rgbs.shape == (4, 32, 32, 3) and np.isfinite(rgbs).all() and not (tmp_path / "out" / "ip" / "image.npy").exists()
     assert np.abs(rgbs[0] - rgbs[-1]).max() > 1e-3          # the pose really changes along the sequence
+    rgbs, _, _, _ = run_render.run_render(base + ["--render_type", "pose_rotate", "--n_bullet", "6", "--selected_idxs", "2", "--runname", "pr",
+                                                  "--render_res", "32", "32", "--no_save"])
+    assert rgbs.shape == (6, 32, 32, 3) and np.isfinite(rgbs).all() and np.abs(rgbs[0] - rgbs[1]).max() > 1e-3
     rgbs, _, boxes, _ = run_render.run_render(base + ["--render_type", "bubble", "--n_step", "3", "--selected_idxs", "1", "--runname", "bb",
                                                       "--render_res", "32", "32", "--no_save"])
     assert rgbs.shape == (3, 32, 32, 3) and np.isfinite(rgbs).all()
