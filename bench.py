@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--coarse", type=int, default=N_SAMPLES, help="dev: coarse samples per ray (metric: 48)")
     ap.add_argument("--fine", type=int, default=N_IMPORTANCE, help="dev: importance samples per ray (metric: 16)")
+    ap.add_argument("--box-near-far", action="store_true",
+                    help="dev: per-bone box near/far as in the danbo_fast configs (SURVEY 8d config 2: with --coarse 32 --fine 16)")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="dev: every rank uses cuda:0 and the gloo backend (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
@@ -127,6 +129,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
 
     eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
+    eng.cfg["use_volume_near_far"] = bool(args.box_near_far)
     for _ in range(args.warmup):
         render(eng, inp)
     torch.cuda.synchronize()
@@ -183,7 +186,8 @@ def main():
         "dtype": "f32" if args.mlp == "fp32" else "f32 (fp16x2-split MFMA products, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"H36M danbo_base network, 512x512 rays x ({N_SAMPLES} coarse + {N_IMPORTANCE} importance) samples, "
-                               "1 pose / 1 camera per rank, cylinder near/far, exact in-volume culling",
+                               f"1 pose / 1 camera per rank, {'per-bone box' if args.box_near_far else 'cylinder'} near/far, "
+                               "exact in-volume culling",
                    "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
         "in_volume_fraction": rows / (args.steps * samples_per_frame),
         "roofline": roofline,
