@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tau", type=float, default=20.0)
     ap.add_argument("--hw", type=int, default=512)
-    ap.add_argument("--rows-per-chunk", type=int, default=1 << 18)
+    ap.add_argument("--rows-per-chunk", type=int, default=1 << 20)
     a = ap.parse_args()
     from core.anerf_engine import AnerfEngine
     from core.utils import synthetic as syn
