@@ -305,3 +305,25 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
         waits = sorted(re.search(r"vmcnt\(\d+\)", l).group(0) for l in body if "s_waitcnt" in l and "vmcnt" in l)
         # bias table, prologue, one per row-tile end in each of the two unrolled k-steps, final drain; one per hand-over
         assert waits == sorted(["vmcnt(0)"] * 5 + ["vmcnt(6)"] * handovers), waits
+
+
+def test_ring_kernels_do_not_spill(tmp_path):
+    """The kernels that stream weights through an LDS ring with hand-counted vmcnt waits must not spill: a scratch access is a
+    VMEM operation the compiler waits for with vmcnt(0), which drains the ring (k_pe_mlp16 with 196 B of spills moved 10x the HBM
+    traffic).  Checked on the gfx950 ISA."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    for src, kernels in (("k_mlp16.hip", ["k_pe_mlp16"]), ("k_assign16.hip", ["k_assign16E"])):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(ROOT, "danbo-pytorch_amd", "csrc", src)], check=True, capture_output=True)
+        text = open(out).read()
+        for k in kernels:
+            meta = re.search(r"\.name:\s+\S*" + k + r"\S*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
+            assert meta is not None, k
+            assert int(meta.group(1)) == 0, (k, meta.group(1))
+            body = text[text.index(re.search(r"^(_ZN5danbo\S*" + k + r"\S*):", text, re.M).group(1) + ":"):]
+            body = body[:body.index(".Lfunc_end")]
+            assert "scratch_" not in body and "buffer_store" not in body, k
