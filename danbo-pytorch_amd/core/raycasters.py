@@ -262,10 +262,12 @@ class RayCaster(nn.Module):
             z = ops.coarse_samples(near, far, N_samples, t_rand)
         align = self.transforms[:1, None].to(rays_o.device)
 
+        shared = {}   # per-pose volumes, per-ray view inputs and the empty-space evaluation are the same in both passes
+
         def net(zv):
             pts = rays_o[:, None, :] + rays_d[:, None, :] * zv[:, :, None]
             inputs = dict(pts=pts, kps=None, skts=skts_g, bones=bones_g, align_transforms=align, N_uniques=G,
-                          rays_o=rays_o[:, None], rays_d=rays_d[:, None], cam_idxs=cams)
+                          rays_o=rays_o[:, None], rays_d=rays_d[:, None], cam_idxs=cams, shared=shared)
             return self.network(inputs)
 
         raw, enc = net(z)

@@ -195,18 +195,32 @@ def forward_train(model, inputs):
     bits, lst, cnt = ops.bone_cull(geo, compact=True)
     n = int(cnt.item())                      # one host sync per pass: sizes the autograd graph
     rows = torch.sort(lst[:n]).values.contiguous()
-    vols = pose_volumes(model, bones_g)
+    shared = inputs.get("shared")
+    shared = shared if shared is not None else {}
+    if "vols" not in shared:
+        shared["vols"] = pose_volumes(model, bones_g)
+    vols = shared["vols"]
     part_feat = GatherFn.apply(vols, axis_scale, geo, rows)
     logits = assignment_logits(model, part_feat)
     shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
     valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
     p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid_rows
     h = (part_feat * p[..., None]).sum(-2)
-    vin = view_inputs(model, rays_d, skts_g, inputs.get("cam_idxs"), R // G)
+    if "vin" not in shared:
+        shared["vin"] = view_inputs(model, rays_d, skts_g, inputs.get("cam_idxs"), R // G)
+    vin = shared["vin"]
     ray_of_row = (rows // S).long()
     L = model.voxel_pe_fn.num_freqs
-    raw_rows = mlp(model, positional_encoding(h, L), vin[ray_of_row])
-    raw_empty = mlp(model, positional_encoding(torch.zeros(1, h.shape[1], device=pts.device), L).expand(R, -1), vin)
+    # in-volume rows and the one empty-space row per ray through the MLP in ONE batch: half the GEMM launches and half the
+    # gradient accumulations of two separate calls
+    # (a caller that runs several passes over the same rays -- coarse and importance samples -- shares the empty-space rows)
+    if "raw_empty" in shared:
+        raw_rows, raw_empty = mlp(model, positional_encoding(h, L), vin[ray_of_row]), shared["raw_empty"]
+    else:
+        pe_empty = positional_encoding(torch.zeros(1, h.shape[1], device=pts.device), L).expand(R, -1)
+        raw_both = mlp(model, torch.cat([positional_encoding(h, L), pe_empty], 0), torch.cat([vin[ray_of_row], vin], 0))
+        raw_rows, raw_empty = raw_both[:n], raw_both[n:]
+        shared["raw_empty"] = raw_empty
     raw = raw_empty[:, None, :].expand(R, S, 4).reshape(R * S, 4).index_copy(0, rows.long(), raw_rows)
     confd = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), logits)
     # confd of samples outside every volume: the reference evaluates the assignment net there too; those
