@@ -85,6 +85,42 @@ class CompositeFn(torch.autograd.Function):
         return d_raw, None, None, None, None
 
 
+class LinearFn(torch.autograd.Function):
+    """nn.Linear whose weight gradient dW = dY^T X is computed split-K: the library's single GEMM with K = 70 000 rows and a
+    256 x 256 output fills a fraction of the GPU (measured 239 us; 683 us for the 451-wide skip layer), 64 row slices as one
+    batched GEMM plus a sum take 93 / 165 us.  Forward and dX are the plain library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            n, N, K = g.shape[0], g.shape[1], x.shape[1]
+            slices = min(64, n // 512)
+            if slices >= 2:
+                xc = x.contiguous()
+                ch = (n // slices) * slices
+                dw = torch.bmm(g[:ch].view(slices, -1, N).transpose(1, 2), xc[:ch].view(slices, -1, K)).sum(0)
+                if ch < n:
+                    dw = dw + g[ch:].t() @ xc[ch:]
+            else:
+                dw = g.t() @ x
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(layer, x):
+    return LinearFn.apply(x, layer.weight, layer.bias)
+
+
 def composite(raw, z, rays_d, B=1.0, noise=None):
     rgb, disp, acc, w, al = CompositeFn.apply(raw.contiguous().float(), z.contiguous().float(),
                                               rays_d.reshape(-1, 3).contiguous().float(), B, noise)
@@ -147,13 +183,13 @@ def assignment_logits(model, part_feat):
 def mlp(model, dens_in, view_in):
     h = dens_in
     for i, l in enumerate(model.pts_linears):
-        h = F.relu(l(h))
+        h = F.relu(linear(l, h))
         if i in model.skips:
             h = torch.cat([dens_in, h], -1)
-    alpha = model.alpha_linear(h)
-    feat = model.feature_linear(h)
-    hv = F.relu(model.views_linears[0](torch.cat([feat, view_in], -1)))
-    return torch.cat([model.rgb_linear(hv), alpha], -1)
+    alpha = linear(model.alpha_linear, h)
+    feat = linear(model.feature_linear, h)
+    hv = F.relu(linear(model.views_linears[0], torch.cat([feat, view_in], -1)))
+    return torch.cat([linear(model.rgb_linear, hv), alpha], -1)
 
 
 def view_inputs(model, rays_d, skts_g, cam_idxs, rays_per_pose):
@@ -252,11 +288,11 @@ def forward_train_anerf(model, inputs):
         E = ops.anerf_view_pe(rays_d, skts_g, Lv)                                  # [R, nb*72], block-major
     h = x0
     for i, l in enumerate(model.pts_linears):
-        h = F.relu(l(h))
+        h = F.relu(linear(l, h))
         if i in model.skips:
             h = torch.cat([x0, h], -1)
-    alpha = model.alpha_linear(h)
-    feat = model.feature_linear(h)
+    alpha = linear(model.alpha_linear, h)
+    feat = linear(model.feature_linear, h)
     W, nb = model.W, 1 + 2 * Lv
     wv, bv = model.views_linears[0].weight, model.views_linears[0].bias           # [VW, W + nb*72 + code]
     view_ch = nb * 72
@@ -268,7 +304,7 @@ def forward_train_anerf(model, inputs):
         idx = inputs.get("cam_idxs").reshape(-1).long()
         code = model.framecodes.codes(idx) @ wv[:, W + view_ch:].t()               # [R, VW]
         pre = pre + code.repeat_interleave(S, 0)
-    rgb = model.rgb_linear(F.relu(pre))
+    rgb = linear(model.rgb_linear, F.relu(pre))
     return torch.cat([rgb, alpha], -1).reshape(R, S, 4), {}
 
 
