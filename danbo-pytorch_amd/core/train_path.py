@@ -130,12 +130,21 @@ def composite(raw, z, rays_d, B=1.0, noise=None):
 # --------------------------------------------------------------------------------------
 # small differentiable pieces (GEMMs via rocBLAS, element-wise glue)
 # --------------------------------------------------------------------------------------
+_PE_FREQS = {}
+
+
 def positional_encoding(x, L):
-    outs = [x]
-    for l in range(L):
-        xf = x * float(2 ** l)
-        outs += [torch.sin(xf), torch.cos(xf)]
-    return torch.cat(outs, -1)
+    """[x, sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ...] (reference cutoff_embedder.py:62-73) in five tensor ops instead
+    of 3 L + 1: the training step is launch-bound, and the scaling by powers of two is exact either way"""
+    if L == 0:
+        return x
+    key = (L, x.device, x.dtype)
+    if key not in _PE_FREQS:
+        _PE_FREQS[key] = torch.tensor([float(2 ** l) for l in range(L)], device=x.device, dtype=x.dtype)
+    freqs = _PE_FREQS[key]
+    xf = x.unsqueeze(-2) * freqs[:, None]                                   # [..., L, d]
+    sc = torch.stack([torch.sin(xf), torch.cos(xf)], -2)                   # [..., L, 2, d]
+    return torch.cat([x, sc.flatten(-3)], -1)
 
 
 def axis_angle_to_rot6d(aa):
