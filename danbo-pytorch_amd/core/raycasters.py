@@ -198,13 +198,14 @@ class RayCaster(nn.Module):
         with torch.no_grad():
             return self.render_rays(*args, **kwargs)
 
-    def _engine(self):
+    def _engine(self, refresh=True):
         dev = next(self.network.parameters()).device
         if self.transforms.device != dev:
             self.transforms = self.transforms.to(dev)
         eng = self.network.engine(self.transforms[0])
         eng.cfg['use_volume_near_far'] = bool(getattr(self, 'use_volume_near_far', False))
-        eng.refresh()
+        if refresh:      # re-packs the kernels' weight buffers when a parameter version changed: the eval path needs that
+            eng.refresh()
         return eng
 
     @staticmethod
@@ -248,7 +249,8 @@ class RayCaster(nn.Module):
         detached, the network and the compositing carry gradients (core/train_path.py)."""
         if N_importance <= 0 or lindisp or ray_noise_std:
             raise NotImplementedError("training needs N_importance > 0, lindisp=False, ray_noise_std=0")
-        eng = self._engine()
+        # the training forward reads the parameters themselves: no re-pack of the eval kernels' buffers after every optimizer step
+        eng = self._engine(refresh=False)
         G = int(N_uniques)
         R = ray_batch.shape[0]
         rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
@@ -257,7 +259,8 @@ class RayCaster(nn.Module):
         with torch.no_grad():
             near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., R, ray_batch[:, 6], ray_batch[:, 7])
             if eng.cfg.get('use_volume_near_far'):
-                ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
+                ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, self.network.graph_net.axis_scale.detach().contiguous(),
+                                   near, far)
             t_rand = torch.rand(R, N_samples, device=rays_o.device) if perturb > 0. else None
             z = ops.coarse_samples(near, far, N_samples, t_rand)
         align = self.transforms[:1, None].to(rays_o.device)
