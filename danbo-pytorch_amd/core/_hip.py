@@ -6,7 +6,7 @@ tensor is not a CUDA(HIP) tensor.
 """
 import ctypes
 import os
-from ctypes import c_long, c_char_p, c_float, c_int, c_void_p, POINTER
+from ctypes import c_long, c_char_p, c_float, c_int, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DANBO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libdanbo_hip.so")
@@ -50,7 +50,30 @@ SIGNATURES = {
     "danbo_linear16_packed_bytes": [I, I, I],
     "danbo_linear16_pack": [P, c_long, c_long, I, I, I, P, P],
     "danbo_linear16_fwd": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P],
+    "danbo_render_frame_workspace": [I, I, I, I, I, I],
+    "danbo_render_frame": [P, P, I, I, P, P, c_size_t, P],
 }
+RESTYPES = {"danbo_render_frame_workspace": c_size_t}   # everything else returns int (0 = ok)
+
+
+class DanboModel(ctypes.Structure):
+    """mirror of `struct DanboModel` in include/danbo_hip.h"""
+    _fields_ = ([(n, P) for n in ("g_w0", "g_adjw0", "g_b0", "g_w1", "g_adjw1", "g_b1", "g_w2", "g_b2", "g_w3", "g_b3")]
+                + [("L_graph", I), ("graph_width", I), ("align", P), ("axis_scale", P), ("assign16", P)]
+                + [(n, P) for n in ("a_b0", "a_b1", "a_w2", "a_b2")] + [("mlp16", P), ("pts_b", P * 8)]
+                + [(n, P) for n in ("alpha_w", "alpha_b", "rgb_w", "rgb_b", "views_w_ray_t", "views_b_eff", "framecodes",
+                                    "mean_code", "code_table", "empty_consts")]
+                + [(n, I) for n in ("n_codes", "code_size", "L_view", "ray_mode", "normalise")]
+                + [("density_scale", F), ("use_volume_near_far", I)])
+
+
+class DanboRays(ctypes.Structure):
+    _fields_ = ([(n, P) for n in ("rays_o", "rays_d", "skts", "bones", "cyls", "cam_idx", "near_in", "far_in")]
+                + [("R", I), ("G", I), ("chunk", I)])
+
+
+class DanboFrameOut(ctypes.Structure):
+    _fields_ = [(n, P) for n in ("rgb_map", "disp_map", "acc_map", "alpha", "weights", "rgb0", "disp0", "acc0", "alpha0")]
 
 _lib = None
 
@@ -67,7 +90,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = RESTYPES.get(name, c_int)
         _lib = l
     return _lib
 

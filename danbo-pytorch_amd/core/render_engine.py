@@ -146,6 +146,53 @@ class DanboEngine:
         raw, _ = self.forward_samples(dummy, dummy, skts, bones, pts=pts, view=(cview, raw_empty))
         return raw[..., 3:4].reshape(M, 1)
 
+    # ------------------------------------------------------------------ the same chain behind ONE C call
+    def render_frame_c(self, rays_o, rays_d, skts, bones, cyls, cam_idx=None, N_samples=None, N_importance=None, chunk=4096):
+        """`render()` through `danbo_render_frame` (include/danbo_hip.h): the library enqueues the whole chain itself, out of
+        one workspace buffer -- the entry point a C host binds.  Same kernels, same order: bit-identical outputs."""
+        import ctypes
+        from . import _hip
+        assert self.mlp_mode == "f16split"
+        self.refresh()
+        cfg = self.cfg
+        S, Sf = N_samples or cfg["N_samples"], N_importance or cfg["N_importance"]
+        f32 = lambda t: None if t is None else t.float().contiguous()  # noqa: E731
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        rays_o, rays_d, skts, bones, cyls = (f32(t) for t in (rays_o, rays_d, skts, bones, cyls))
+        cam = None if (cam_idx is None or not cfg["use_framecode"]) else cam_idx.reshape(-1).to(torch.int64).contiguous()
+        R, G, dev = rays_o.shape[0], skts.shape[0], rays_o.device
+        gw, aw = self.gw, self.aw
+        m = _hip.DanboModel()
+        for k in ("w0", "adjw0", "b0", "w1", "adjw1", "b1", "w2", "b2", "w3", "b3"):
+            setattr(m, "g_" + k, gw[k].data_ptr())
+        m.L_graph, m.graph_width = cfg["multires_graph"], gw["w1"].shape[-1]
+        m.align, m.axis_scale, m.assign16 = self.align.data_ptr(), self.axis_scale.data_ptr(), self.assign16.data_ptr()
+        m.a_b0, m.a_b1, m.a_w2, m.a_b2 = (aw[k].data_ptr() for k in ("b0", "b1", "w2", "b2"))
+        m.mlp16 = self.packed16.data_ptr()
+        for i in range(8):
+            m.pts_b[i] = self.pts_b[i].data_ptr()
+        m.alpha_w, m.alpha_b, m.rgb_w, m.rgb_b = (t.data_ptr() for t in (self.alpha_w, self.alpha_b, self.rgb_w, self.rgb_b))
+        m.views_w_ray_t, m.views_b_eff, m.empty_consts = self.wrt.data_ptr(), self.views_b16.data_ptr(), self.empty_consts.data_ptr()
+        if self.framecodes is not None:
+            m.framecodes, m.mean_code, m.code_table = (t.data_ptr() for t in (self.framecodes, self.mean_code, self.code_table))
+            m.n_codes, m.code_size = self.framecodes.shape
+        m.L_view = cfg["multires_views"]
+        m.ray_mode, m.normalise = {"world": 0, "root_local": 1}[cfg["ray_tr_type"]], 1 if cfg["view_type"] == "relray" else 0
+        m.density_scale, m.use_volume_near_far = float(cfg["density_scale"]), int(bool(cfg["use_volume_near_far"]))
+        r = _hip.DanboRays(rays_o=rays_o.data_ptr(), rays_d=rays_d.data_ptr(), skts=skts.data_ptr(), bones=bones.data_ptr(),
+                           cyls=cyls.data_ptr(), cam_idx=None if cam is None else cam.data_ptr(), near_in=None, far_in=None,
+                           R=R, G=G, chunk=int(chunk))
+        shapes = dict(rgb_map=(R, 3), disp_map=(R,), acc_map=(R,), alpha=(R, S + Sf), weights=(R, S + Sf), rgb0=(R, 3),
+                      disp0=(R,), acc0=(R,), alpha0=(R, S))
+        out = {k: torch.empty(v, device=dev, dtype=torch.float32) for k, v in shapes.items()}
+        o = _hip.DanboFrameOut(**{k: v.data_ptr() for k, v in out.items()})
+        nbytes = _hip.lib().danbo_render_frame_workspace(R, G, S, Sf, int(chunk), m.graph_width)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _hip.check(_hip.lib().danbo_render_frame(ctypes.byref(m), ctypes.byref(r), S, Sf, ctypes.byref(o), ptr(ws), nbytes,
+                                                 ops._stream()), "danbo_render_frame")
+        out["T_i"] = out.pop("weights")
+        return out
+
     # ------------------------------------------------------------------ RayCaster.render_rays (eval)
     def near_far(self, rays_o, rays_d, cyls, skts, near0=0.0, far0=1.0, chunk=4096):
         self.refresh()

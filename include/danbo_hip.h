@@ -15,6 +15,7 @@
 #ifndef DANBO_HIP_H
 #define DANBO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -302,6 +303,48 @@ int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int
  * 1 = ReLU; rows = min(*count, M) if count != NULL (device-side row count of a compacted list) */
 int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
                        const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The whole eval chain of one ray batch behind one call: RayCaster.render_rays (core/raycasters.py:245-377) with the DANBO
+ * network (core/networks/danbo.py) -- what a C host binds instead of the reference's caster(ray_batch, ...) call.
+ * Every pointer is a device pointer; the weight buffers are the ones the *_pack entry points above produce.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct DanboModel {
+    /* FactorizeGNN (danbo_pose_volumes_fwd) */
+    const float *g_w0, *g_adjw0, *g_b0, *g_w1, *g_adjw1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3;
+    int L_graph, graph_width;
+    /* geometry */
+    const float *align /*[24,4,4]*/, *axis_scale /*[24,3]*/;
+    /* assignment net (danbo_assign16_pack) */
+    const void* assign16;
+    const float *a_b0, *a_b1, *a_w2, *a_b2;
+    /* density / colour MLP (danbo_mlp16_pack) */
+    const void* mlp16;
+    const float* pts_b[8];
+    const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+    /* view branch (danbo_mlp_pack -> views_w_ray_t, danbo_mlp16_pack -> views_b_eff, danbo_view_code_table) */
+    const float *views_w_ray_t, *views_b_eff, *framecodes, *mean_code, *code_table, *empty_consts;
+    int n_codes, code_size, L_view, ray_mode, normalise;
+    float density_scale;
+    int use_volume_near_far;
+} DanboModel;
+
+typedef struct DanboRays {
+    const float *rays_o, *rays_d /*[R,3]*/, *skts /*[G,24,4,4]*/, *bones /*[G,24,3]*/, *cyls /*[G,5]*/;
+    const int64_t* cam_idx /*[R] or NULL*/;
+    const float *near_in, *far_in /*[R] placeholders or NULL (0 / 1)*/;
+    int R, G, chunk /*rays per nan-mean chunk of the cylinder bounds (the reference: 4096)*/;
+} DanboRays;
+
+typedef struct DanboFrameOut {   /* the dict of render_rays: final maps, then the coarse pass' */
+    float *rgb_map /*[R,3]*/, *disp_map, *acc_map /*[R]*/, *alpha, *weights /*[R,S+Sf]: alpha, T_i*/;
+    float *rgb0, *disp0, *acc0, *alpha0 /*[R,S]*/;
+} DanboFrameOut;
+
+size_t danbo_render_frame_workspace(int R, int G, int S, int Sf, int chunk, int graph_width);
+/* S, Sf <= 64.  Enqueues ~25 kernels on `stream`; workspace: danbo_render_frame_workspace bytes of device memory. */
+int danbo_render_frame(const DanboModel* model, const DanboRays* rays, int S, int Sf, const DanboFrameOut* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

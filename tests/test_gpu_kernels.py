@@ -466,3 +466,26 @@ def test_importance_with_descending_and_mixed_depth_order(ops, S, Sf):
         assert torch.equal(idx2, idx3) and torch.equal(zs2, zs3)
         srt = torch.sort(idx3.long(), -1).values
         assert bool((srt == torch.arange(S + Sf, device=DEV)).all())
+
+
+def test_render_frame_c_entry_point_equals_the_python_chain():
+    """danbo_render_frame (one C call, caller-provided workspace) enqueues the same kernels in the same order as
+    DanboEngine.render: bit-identical maps; a workspace that is too small is refused"""
+    import ctypes
+    from core import _hip
+    import bench
+    eng, inp, _ = bench.build_workload(torch.device(DEV), 0)
+    sl = slice(100 * 512, 100 * 512 + 6000)                       # 6000 rays across the body: ragged last chunk of 4096
+    args = (inp["rays_o"][sl], inp["rays_d"][sl], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"][sl])
+    want = eng.render(*args, 48, 16, chunk=4096)
+    got = eng.render_frame_c(*args, 48, 16, chunk=4096)
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    assert float(want["acc_map"].max()) > 0.5
+    eng.cfg["use_volume_near_far"] = True
+    want, got = eng.render(*args, 32, 16, chunk=4096), eng.render_frame_c(*args, 32, 16, chunk=4096)
+    assert all(torch.equal(want[k], got[k]) for k in want)
+    eng.cfg["use_volume_near_far"] = False
+    assert _hip.lib().danbo_render_frame_workspace(6000, 1, 48, 16, 4096, 128) > 6000 * 64 * 16
+    assert _hip.lib().danbo_render_frame(None, None, 48, 16, None, None, 0, None) == -22

@@ -28,7 +28,7 @@ def fp(a):
 def test_library_exports_every_declared_symbol():
     from core import _hip
     hdr = open(os.path.join(ROOT, "include", "danbo_hip.h")).read()
-    declared = set(re.findall(r"^int\s+(danbo_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t)\s+(danbo_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 16
     lib = _hip.lib()                                  # loads without a GPU
     for name in declared:
@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.danbo_abi_version() == 1
     # argument counts of the ctypes table match the header
     for name in declared:
-        m = re.search(r"int\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
+        m = re.search(r"(?:int|size_t)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
         body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S).strip()
         n_args = 0 if body in ("void", "") else body.count(",") + 1
         assert n_args == len(_hip.SIGNATURES[name]), (name, n_args, len(_hip.SIGNATURES[name]))
