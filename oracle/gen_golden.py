@@ -16,6 +16,8 @@ Fixtures
                      mean frame code (idx -1): raw + final maps
   danbo_train.npz    D-H36M, 128 rays = 4 poses x 32, 16+8 samples, training mode with perturb = 0 and
                      raw_noise_std = 0: the four loss terms of Trainer.compute_loss and gradients
+  danbo_perfcap_train.npz  D-Perf (relray/root_local, box near/far), 192 rays = 4 poses x 48, 16+8 samples, training
+                     mode (perturb = 0, noise = 0): loss terms, gradient norms and gradients of the reference's autograd
   anerf_stages.npz   A-H36M (anerf_base net: cutoff PE, W = 448), 48 rays = 2 poses x 24, 12+6 samples, at
                      tau = 20 (step 0) with every stage tensor, and raw + final maps again at tau = 2000
   anerf_train.npz    A-H36M, 96 rays = 4 poses x 24, 12+6 samples, training mode (perturb = 0, noise = 0): loss terms and
@@ -249,6 +251,69 @@ def gen_danbo_train():
         rgb0=preds["rgb0"].detach().numpy(), part_invalid=preds["part_invalid"].detach().numpy(),
         **{"loss/" + k: np.float64(v.item()) for k, v in loss_dict.items()}, **keep, **norms)
     print("danbo_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()})
+
+
+def gen_danbo_perfcap_train():
+    """BASELINE config 4 in miniature: PerfCap danbo_fast (view_type relray + ray_tr_type root_local, per-bone box near/far,
+    vol_scale_penalty as configured), one deterministic training forward/backward (perturb = 0, raw_noise_std = 0) of the
+    reference: loss terms of Trainer.compute_loss, gradient norms of every parameter and a representative set of gradients"""
+    seed = 17
+    cfg, args, caster, kw_test, rest = build("danbo_perfcap", seed)
+    import types
+    import core.trainer as rtr
+    scene = syn.make_scene(n_poses=4, H=64, W=64, n_views=4, pose_seed=31)
+    n_per = 48
+    ro, rd, pose = [], [], []
+    for p in range(4):
+        o, d = body_rays(scene, p, n_per, seed=300 + p)
+        ro.append(o); rd.append(d); pose += [p] * n_per
+    ro, rd, pose = np.concatenate(ro), np.concatenate(rd), np.array(pose)
+    rb = syn.ray_batch(ro, rd)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    cam_idx = (np.arange(len(pose)) // n_per * 3 % 7).astype(np.int64)       # one camera per image, as the dataset hands over
+    rng = np.random.default_rng(8)
+    target = rng.uniform(size=(len(pose), 3)).astype(np.float32)
+    bgs = rng.uniform(size=(len(pose), 3)).astype(np.float32)
+    S, Sf = 16, 8
+    caster.train()
+    kw = {k: v for k, v in kw_test.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
+    preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                   cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+    wrap = types.SimpleNamespace(module=caster)
+    tr = rtr.Trainer(args, dict(hwf=(64, 64, 80.0)), None, None, dict(ray_caster=wrap), dict(ray_caster=caster))
+    loss_dict, stats = tr.compute_loss(dict(target_s=T(target), bgs=T(bgs)), preds, kp_opts=None, popt_detach=True)
+    caster.zero_grad()
+    loss_dict["total_loss"].backward()
+    net = caster.network
+    grads = {n: p.grad.numpy() for n, p in net.named_parameters() if p.grad is not None}
+    keep = {}
+    for n in ("graph_net.axis_scale", "pts_linears.0.weight", "pts_linears.5.bias", "pts_linears.7.bias", "alpha_linear.weight",
+              "alpha_linear.bias", "feature_linear.bias", "rgb_linear.weight", "rgb_linear.bias", "views_linears.0.bias",
+              "framecodes.codes.weight", "prob_linears.layers.0.bias", "prob_linears.layers.1.weight",
+              "prob_linears.layers.1.bias", "prob_linears.layers.2.weight", "prob_linears.layers.0.adj_w",
+              "prob_linears.layers.2.bias", "graph_net.layers.0.adj_w", "graph_net.layers.1.adj_w", "graph_net.layers.0.bias",
+              "graph_net.layers.1.bias", "graph_net.layers.2.bias", "graph_net.layers.3.bias"):
+        keep["grad/" + n] = grads[n]
+    keep["grad/graph_net.layers.3.weight[:, ::16, ::8]"] = grads["graph_net.layers.3.weight"][:, ::16, ::8].copy()
+    keep["grad/graph_net.layers.2.weight[:, ::16, ::16]"] = grads["graph_net.layers.2.weight"][:, ::16, ::16].copy()
+    keep["grad/graph_net.layers.1.lin.weight[:, ::16, ::16]"] = grads["graph_net.layers.1.lin.weight"][:, ::16, ::16].copy()
+    keep["grad/graph_net.layers.0.lin.weight[:, ::8, ::16]"] = grads["graph_net.layers.0.lin.weight"][:, ::8, ::16].copy()
+    keep["grad/prob_linears.layers.0.lin.weight[:, ::3, ::4]"] = grads["prob_linears.layers.0.lin.weight"][:, ::3, ::4].copy()
+    keep["grad/views_linears.0.weight[::4, ::8]"] = grads["views_linears.0.weight"][::4, ::8].copy()
+    keep["grad/pts_linears.5.weight[::8, ::8]"] = grads["pts_linears.5.weight"][::8, ::8].copy()
+    keep["grad/feature_linear.weight[::8, ::8]"] = grads["feature_linear.weight"][::8, ::8].copy()
+    norms = {"gnorm/" + n: np.float64(np.sqrt((g.astype(np.float64) ** 2).sum())) for n, g in grads.items()}
+    np.savez_compressed(
+        os.path.join(OUT, "danbo_perfcap_train.npz"),
+        cfg_name="danbo_perfcap", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=4,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
+        pose_of_ray=pose, cam_idx=cam_idx, target=target, bgs=bgs,
+        rgb_map=preds["rgb_map"].detach().numpy(), acc_map=preds["acc_map"].detach().numpy(),
+        rgb0=preds["rgb0"].detach().numpy(), acc0=preds["acc0"].detach().numpy(),
+        part_invalid=preds["part_invalid"].detach().numpy(),
+        **{"loss/" + k: np.float64(v.item()) for k, v in loss_dict.items()}, **keep, **norms)
+    print("danbo_perfcap_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()},
+          "in-volume fraction", 1.0 - float(preds["part_invalid"].detach().numpy().all(-1).mean()))
 
 
 def gen_anerf_stages():
@@ -492,7 +557,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -507,6 +572,8 @@ if __name__ == "__main__":
         gen_anerf_stages()
     if "anerf_train" in which:
         gen_anerf_train()
+    if "perfcap_train" in which:
+        gen_danbo_perfcap_train()
     if "ckpt" in which:
         gen_ckpt_manifest()
     if "args" in which:

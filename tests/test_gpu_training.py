@@ -17,6 +17,9 @@ def T(x, dtype=torch.float32):
     return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device=DEV)
 
 
+CONFIG_OF = {"danbo_base": ("h36m_zju", "danbo_base.txt"), "danbo_perfcap": ("perfcap", "danbo_fast.txt")}
+
+
 def build_trainer(g, extra=()):
     from core.config import parse_args
     from core.raycasters import create_raycaster
@@ -25,12 +28,12 @@ def build_trainer(g, extra=()):
     from core.utils.skeleton_utils import SMPLSkeleton
     args = parse_args(["--no_reload", "--N_samples", str(int(g["N_samples"])), "--N_importance", str(int(g["N_importance"])),
                        "--perturb", "0", "--raw_noise_std", "0", *extra],
-                      config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", "h36m_zju", "danbo_base.txt"))
+                      config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", *CONFIG_OF[str(g["cfg_name"])]))
     n_codes = int(g["n_framecodes"])
     da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=n_codes, rest_pose=syn.rest_pose(0.48), hwf=(64, 64, 80.))
     tr_kw, te_kw, start, grad_vars, opt, _ = create_raycaster(args, da, device=DEV)
     caster = tr_kw["ray_caster"]
-    cfg = syn.model_config("danbo_base")
+    cfg = syn.model_config(str(g["cfg_name"]))
     sd = syn.make_state_dict(cfg, int(g["weight_seed"]), n_codes, syn.rest_pose(0.48))
     caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
     return args, caster, Trainer(args, da, opt, None, tr_kw, te_kw, device=DEV), opt
@@ -44,8 +47,11 @@ def batch_of(g):
                 cam_idxs=T(g["cam_idx"], torch.int64), N_uniques=int(g["n_uniques"]))
 
 
-def test_losses_and_gradients_match_reference_autograd():
-    g = golden("danbo_train")
+@pytest.mark.parametrize("fixture", ["danbo_train", "danbo_perfcap_train"])
+def test_losses_and_gradients_match_reference_autograd(fixture):
+    """danbo_train: D-H36M (world rays, identity view, cylinder near/far); danbo_perfcap_train: BASELINE config 4's network
+    (root_local rays, relray view, per-bone box near/far, its vol_scale_penalty)"""
+    g = golden(fixture)
     args, caster, trainer, opt = build_trainer(g)
     caster.train()
     batch = batch_of(g)
