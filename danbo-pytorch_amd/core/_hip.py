@@ -52,8 +52,32 @@ SIGNATURES = {
     "danbo_linear16_fwd": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P],
     "danbo_render_frame_workspace": [I, I, I, I, I, I],
     "danbo_render_frame": [P, P, I, I, P, P, c_size_t, P],
+    # ---- training step
+    "danbo_composite_bwd_lazy": [P, P, P, P, P, I, I, F, P, P, P, P, P],
+    "danbo_linear16_ex": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P, P],
+    "danbo_linear16_group_bytes": [P, I],
+    "danbo_linear16_pack_group": [P, I, P, P, P, P, P],
+    "danbo_dw16_scratch_floats": [P, I, I],
+    "danbo_dw16": [P, I, I, P, I, P, P],
+    "danbo_gather_assign_blend16_train": [P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P],
+    "danbo_train_view_inputs": [P, P, I, I, I, I, I, P, I, I, P, P, I, P],
+    "danbo_train_rows_fwd": [P, P, P, I, I, I, I, I, P, I, P, I, P, P, P],
+    "danbo_train_rgb_head_fwd": [P, P, I, P, P, P, P, I, I, I, P, P, P, P],
+    "danbo_train_loss_grad": [P, P, P, P, P, P, I, I, I, F, F, P, P, P, P, P, P],
+    "danbo_train_draw_unmerge": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P],
+    "danbo_train_rgb_head_bwd": [P, P, P, P, P, P, I, I, P, P, P, P, P, P],
+    "danbo_train_code_grad": [P, I, I, I, P, P, P, I, I, P, P],
+    "danbo_train_pe_bwd": [P, I, P, I, I, P, P, I, I, I, P, P],
+    "danbo_train_bone_lists": [P, P, P, P, I, I, P, P, P],
+    "danbo_assign_blend_bwd": [P, P],
+    "danbo_pose_volumes_bwd": [P, I, I, I] + [P] * 24,
+    "danbo_adam_step": [P, P, P, P, c_long, P, F, F, F, P],
+    "danbo_train_workspace": [P, I, I, I, I, I],
+    "danbo_train_step": [P, P, P, P, c_size_t, P],
 }
-RESTYPES = {"danbo_render_frame_workspace": c_size_t}   # everything else returns int (0 = ok)
+# everything else returns int (0 = ok)
+RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t, "danbo_linear16_group_bytes": c_long,
+            "danbo_dw16_scratch_floats": c_long}
 
 
 class DanboModel(ctypes.Structure):
@@ -74,6 +98,63 @@ class DanboRays(ctypes.Structure):
 
 class DanboFrameOut(ctypes.Structure):
     _fields_ = [(n, P) for n in ("rgb_map", "disp_map", "acc_map", "alpha", "weights", "rgb0", "disp0", "acc0", "alpha0")]
+
+
+
+# ---- training step (include/danbo_hip.h: enum DanboTrainTensor and the Danbo{LinearEx,PackDesc,DwLayer,AssignBwd,Train*} structs)
+TRAIN_TENSORS = (
+    ["graph_net.layers.0.lin.weight", "graph_net.layers.0.adj_w", "graph_net.layers.0.bias", "graph_net.layers.1.lin.weight",
+     "graph_net.layers.1.adj_w", "graph_net.layers.1.bias", "graph_net.layers.2.weight", "graph_net.layers.2.bias",
+     "graph_net.layers.3.weight", "graph_net.layers.3.bias", "graph_net.axis_scale",
+     "prob_linears.layers.0.lin.weight", "prob_linears.layers.0.adj_w", "prob_linears.layers.0.bias", "prob_linears.layers.1.weight",
+     "prob_linears.layers.1.bias", "prob_linears.layers.2.weight", "prob_linears.layers.2.bias"]
+    + [f"pts_linears.{i}.weight" for i in range(8)] + [f"pts_linears.{i}.bias" for i in range(8)]
+    + ["alpha_linear.weight", "alpha_linear.bias", "feature_linear.weight", "feature_linear.bias", "views_linears.0.weight",
+       "views_linears.0.bias", "rgb_linear.weight", "rgb_linear.bias", "framecodes.codes.weight"])
+N_TRAIN_TENSORS = len(TRAIN_TENSORS)   # DANBO_T_COUNT
+
+
+class DanboLinearEx(ctypes.Structure):
+    _fields_ = [("first", P), ("relu_in", P), ("relu_out", P), ("mask_cols", I), ("in_maxabs", P), ("out_maxabs", P), ("wscale_inv", P)]
+
+
+class DanboPackDesc(ctypes.Structure):
+    _fields_ = ([("w", P), ("w2", P)] + [(n, c_long) for n in ("sn", "sk", "sn2", "sk2")]
+                + [(n, I) for n in ("N", "K1", "K2", "n_shift", "split_n", "split_k")])
+
+
+class DanboDwLayer(ctypes.Structure):
+    _fields_ = ([(n, P) for n in ("dy", "x1", "x2", "dy_maxabs", "gw", "gw2", "gb", "gb2")]
+                + [(n, I) for n in ("ldy", "ld1", "ld2", "N", "K1", "K2", "split_n")])
+
+
+class DanboAssignBwd(ctypes.Structure):
+    _fields_ = ([(n, P) for n in ("rays_o", "rays_d", "z_c", "z_f", "skts", "align", "axis_scale", "volumes")]
+                + [(n, I) for n in ("R", "S", "Sf", "G", "rows_cap")]
+                + [(n, P) for n in ("row_sample", "row_ray", "cnt", "lists", "cntb", "h_rows", "d_h", "label_c", "label_f", "bits_c",
+                                    "bits_f", "w0", "adj_w", "adj", "b0", "w1", "b1", "w2", "b2", "g_w0", "g_adj_w", "g_b0", "g_w1",
+                                    "g_b1", "g_w2", "g_b2", "g_vol", "g_scale")]
+                + [("c_ss", F), ("loss", P)])
+
+
+class DanboTrainModel(ctypes.Structure):
+    _fields_ = ([("p", P * N_TRAIN_TENSORS), ("g", P * N_TRAIN_TENSORS), ("g_flat", P), ("n_flat", c_long)]
+                + [(n, P) for n in ("g_adj0", "g_adj1", "a_adj", "align", "init_scale")]
+                + [(n, I) for n in ("L_graph", "graph_width", "L_view", "L_voxel", "ray_mode", "normalise", "n_codes", "code_size",
+                                    "view_ch", "use_volume_near_far", "loss_mse", "use_background")]
+                + [(n, F) for n in ("density_scale", "rgb_loss_coef", "coarse_weight", "soft_softmax_coef", "vol_scale_penalty")])
+
+
+class DanboTrainBatch(ctypes.Structure):
+    _fields_ = ([(n, P) for n in ("rays_o", "rays_d", "skts", "bones", "cyls", "near_in", "far_in", "cam_idx", "target", "bgs",
+                                  "t_rand", "u_rand", "noise_c", "noise_f")]
+                + [(n, I) for n in ("R", "G", "S", "Sf", "chunk")])
+
+
+class DanboTrainOut(ctypes.Structure):
+    _fields_ = [(n, P) for n in ("rgb_map", "disp_map", "acc_map", "alpha", "weights", "rgb0", "disp0", "acc0", "alpha0", "loss",
+                                 "counts")]
+
 
 _lib = None
 

@@ -1,0 +1,251 @@
+"""The training step on the HIP path: `danbo_train_step` (forward + losses + backward of one batch behind one C call,
+csrc/k_train.hip) and `danbo_adam_step` on flat parameter / gradient buffers.
+
+Reference: Trainer.train_batch (core/trainer.py:257-302) -- render, compute_loss (:348-394), loss.backward() and
+optimizer.step() (:563-576) -- for the shipped DANBO structure.  What PyTorch does here: it owns the device memory
+(the flat buffers every nn.Parameter / .grad / Adam moment is a VIEW of), draws the step's random numbers and provides the
+stream; there is no autograd graph and no torch kernel on the hot path.
+
+Flat layout: all trainable tensors back to back in the order of `_hip.TRAIN_TENSORS` (alpha_linear.bias moved right behind
+feature_linear.bias: the two layers are evaluated as one 257-wide layer).  The gradient all-reduce of data-parallel training is
+ONE collective on `flat_grad` with no packing copies.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _hip
+
+_P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+
+
+def supported(args, caster):
+    """-> None if the fused step covers this configuration, else the reason (the caller then uses the autograd path)"""
+    net = caster.network
+    if type(net).__name__ != 'DANBO':
+        return f'network {type(net).__name__}'
+    if args.loss_fn not in ('L1', 'MSE'):
+        return f'loss_fn {args.loss_fn}'
+    if getattr(args, 'reg_fn', None) not in (None, 'None') or getattr(args, 'weight_decay', None) is not None:
+        return 'regulariser / weight decay'
+    if getattr(args, 'finetune_light', False) or getattr(args, 'opt_pose', False):
+        return 'finetune_light / opt_pose'
+    if args.agg_type != 'sigmoid' or args.N_importance <= 0 or args.N_samples + args.N_importance > 256 or args.N_samples < 3:
+        return 'sampling / aggregation settings'
+    if net.voxel_pe_fn.num_freqs != 6 or net.W != 256 or net.D != 8 or list(net.skips) != [4]:
+        return 'MLP shape'
+    sd = dict(net.named_parameters())
+    for n in _hip.TRAIN_TENSORS:
+        if n not in sd and not (n.startswith('framecodes') and not net.use_framecode):
+            return f'missing parameter {n}'
+        if n in sd and not sd[n].requires_grad and n != 'graph_net.axis_scale':
+            return f'{n} is frozen'
+    extra = set(sd) - set(_hip.TRAIN_TENSORS)
+    if extra:
+        return f'parameters outside the fused step: {sorted(extra)}'
+    return None
+
+
+class DanboTrainEngine:
+    def __init__(self, args, caster, optimizer):
+        self.args, self.caster, self.opt = args, caster, optimizer
+        net = self.net = caster.network
+        dev = self.device = next(net.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError("the training step runs on the HIP path only: move the caster to a GPU first")
+        params = dict(net.named_parameters())
+        names = [n for n in _hip.TRAIN_TENSORS if n in params]
+        order = list(names)
+        order.remove('alpha_linear.bias')
+        order.insert(order.index('feature_linear.bias') + 1, 'alpha_linear.bias')
+        trainable = [n for n in order if params[n].requires_grad]
+        frozen = [n for n in order if not params[n].requires_grad]
+        # every tensor starts on a 16-byte boundary (vector loads in the kernels) except alpha_linear.bias, which must follow
+        # feature_linear.bias immediately
+        self.offsets, off = {}, 0
+        for n in trainable + frozen:
+            if n != 'alpha_linear.bias':
+                off = (off + 3) // 4 * 4
+            self.offsets[n] = off
+            off += params[n].numel()
+            if n == trainable[-1]:
+                self.n_train = off
+        total = off
+        self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(self.n_train, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(self.n_train, device=dev, dtype=torch.float32)
+        self.params = {n: params[n] for n in order}
+        with torch.no_grad():
+            for n, p in self.params.items():
+                o, k = self.offsets[n], p.numel()
+                self.flat_p[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + k].view(p.shape)
+                p.grad = self.flat_g[o:o + k].view(p.shape)
+        self.trainable = trainable
+        self._adopt_optimizer_state()
+        self.t = self._optimizer_step_count()
+        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self._buffers = {}
+        self._ws = None
+        self._model_struct = None
+        self.graph = None           # (key, CUDAGraph, static inputs, outputs)
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ optimizer state as views of the flat moments
+    def _optimizer_step_count(self):
+        for p in self.params.values():
+            st = self.opt.state.get(p)
+            if st and 'step' in st:
+                return int(float(st['step']))
+        return 0
+
+    def _adopt_optimizer_state(self):
+        """torch.optim.Adam's per-parameter state (what the checkpoint stores) becomes views of flat_m / flat_v; a state that
+        was loaded from a checkpoint is copied in first."""
+        for n in self.trainable:
+            p = self.params[n]
+            o, k = self.offsets[n], p.numel()
+            m, v = self.flat_m[o:o + k].view(p.shape), self.flat_v[o:o + k].view(p.shape)
+            st = self.opt.state.get(p)
+            step = torch.tensor(0.)
+            if st:
+                if st['exp_avg'].data_ptr() == m.data_ptr():
+                    continue
+                m.copy_(st['exp_avg'])
+                v.copy_(st['exp_avg_sq'])
+                step = st['step'].detach().clone().cpu().float() if torch.is_tensor(st['step']) else torch.tensor(float(st['step']))
+            self.opt.state[p] = dict(step=step, exp_avg=m, exp_avg_sq=v)
+
+    # ------------------------------------------------------------------ model description for the C side
+    def _model(self):
+        if self._model_struct is not None:
+            return self._model_struct
+        net, args = self.net, self.args
+        m = _hip.DanboTrainModel()
+        for i, n in enumerate(_hip.TRAIN_TENSORS):
+            if n in self.params:
+                o = self.offsets[n]
+                m.p[i] = self.flat_p.data_ptr() + 4 * o
+                m.g[i] = self.flat_g.data_ptr() + 4 * o
+        m.g_flat, m.n_flat = self.flat_g.data_ptr(), self.flat_g.numel()
+        gl, pl = net.graph_net.layers, net.prob_linears.layers
+        keep = self._buffers
+        keep['adj0'] = gl[0].adj.detach().float().reshape(24, 24).contiguous()
+        keep['adj1'] = gl[1].adj.detach().float().reshape(24, 24).contiguous()
+        keep['adja'] = pl[0].adj.detach().float().reshape(24, 24).contiguous()
+        if max(int((keep[k] != 0).sum(1).max()) for k in ('adja',)) > 6:
+            raise NotImplementedError("assignment-net adjacency with more than 5 neighbours per bone")
+        keep['align'] = self.caster.transforms[0].to(self.device).float().contiguous()
+        keep['init_scale'] = net.graph_net.init_scale.to(self.device).float().contiguous()
+        m.g_adj0, m.g_adj1, m.a_adj = (keep[k].data_ptr() for k in ('adj0', 'adj1', 'adja'))
+        m.align, m.init_scale = keep['align'].data_ptr(), keep['init_scale'].data_ptr()
+        m.L_graph, m.graph_width = net.graph_pe_fn.num_freqs, gl[0].lin.weight.shape[-1]
+        m.L_view, m.L_voxel = net.dirs_pe_fn.num_freqs, net.voxel_pe_fn.num_freqs
+        m.ray_mode = 1 if net.pts_embedder.ray_tr_fn.encoder_name == "RLEncoder" else 0
+        m.normalise = 1 if net.pts_embedder.view_input_fn.encoder_name == "VecNorm" else 0
+        if net.use_framecode:
+            m.n_codes, m.code_size = net.framecodes.codes.weight.shape
+        m.view_ch = 3 * (1 + 2 * m.L_view) + (m.code_size if net.use_framecode else 0)
+        m.use_volume_near_far = int(bool(getattr(self.caster, 'use_volume_near_far', False)))
+        m.loss_mse, m.use_background = int(args.loss_fn == 'MSE'), int(bool(args.use_background))
+        m.density_scale = float(args.density_scale)
+        m.rgb_loss_coef, m.coarse_weight = float(args.rgb_loss_coef), float(args.coarse_weight)
+        m.soft_softmax_coef = float(args.soft_softmax_loss_coef)
+        m.vol_scale_penalty = float(args.vol_scale_penalty) if args.opt_vol_scale else 0.0
+        self._model_struct = m
+        return m
+
+    # ------------------------------------------------------------------ one forward + backward
+    def _launch(self, t, S, Sf, perturb, raw_noise_std):
+        """t: dict of static input tensors; -> dict of outputs (device tensors)"""
+        m = self._model()
+        R, G = t['rays_o'].shape[0], t['skts'].shape[0]
+        dev = self.device
+        B = m.density_scale
+        rnd = {}
+        if perturb > 0.:
+            rnd['t_rand'] = torch.rand(R, S, device=dev)
+            rnd['u_rand'] = torch.rand(R, Sf, device=dev)
+        if raw_noise_std > 0.:
+            rnd['noise_c'] = torch.randn(R, S, device=dev) * (raw_noise_std * B)
+            rnd['noise_f'] = torch.randn(R, S + Sf, device=dev) * (raw_noise_std * B)
+        out = dict(rgb_map=(R, 3), disp_map=(R,), acc_map=(R,), alpha=(R, S + Sf), weights=(R, S + Sf), rgb0=(R, 3), disp0=(R,),
+                   acc0=(R,), alpha0=(R, S), loss=(4,))
+        out = {k: torch.empty(v, device=dev, dtype=torch.float32) for k, v in out.items()}
+        out['counts'] = torch.empty(8, device=dev, dtype=torch.int32)
+        chunk = R
+        nbytes = _hip.lib().danbo_train_workspace(ctypes.byref(m), R, G, S, Sf, chunk)
+        if nbytes == 0:
+            raise RuntimeError("danbo_train_workspace rejected the model / batch shape")
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        bt = _hip.DanboTrainBatch(
+            rays_o=_P(t['rays_o']), rays_d=_P(t['rays_d']), skts=_P(t['skts']), bones=_P(t['bones']), cyls=_P(t['cyls']),
+            near_in=_P(t.get('near_in')), far_in=_P(t.get('far_in')), cam_idx=_P(t.get('cam_idx')), target=_P(t['target']),
+            bgs=_P(t.get('bgs')), t_rand=_P(rnd.get('t_rand')), u_rand=_P(rnd.get('u_rand')), noise_c=_P(rnd.get('noise_c')),
+            noise_f=_P(rnd.get('noise_f')), R=R, G=G, S=S, Sf=Sf, chunk=chunk)
+        o = _hip.DanboTrainOut(**{k: _P(v) for k, v in out.items()})
+        _hip.check(_hip.lib().danbo_train_step(ctypes.byref(m), ctypes.byref(bt), ctypes.byref(o), _P(self._ws), self._ws.numel(),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_train_step")
+        out['_keep'] = rnd
+        return out
+
+    @staticmethod
+    def _static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx, target, bgs, near_in, far_in):
+        f = lambda x: None if x is None else x.detach().float().contiguous()  # noqa: E731
+        t = dict(rays_o=f(rays_o), rays_d=f(rays_d), skts=f(skts), bones=f(bones), cyls=f(cyls), target=f(target), bgs=f(bgs),
+                 near_in=f(near_in), far_in=f(far_in))
+        t['cam_idx'] = None if cam_idx is None else cam_idx.reshape(-1).to(torch.int64).contiguous()
+        return {k: v for k, v in t.items() if v is not None}
+
+    def forward_backward(self, rays_o, rays_d, skts, bones, cyls, cam_idx, target, bgs, S, Sf, perturb=0., raw_noise_std=0.,
+                         near_in=None, far_in=None):
+        """One batch: per-pose skts [G,24,4,4] / bones [G,24,3] / cyls [G,5]; per-ray everything else.  Gradients land in
+        `flat_grad` (the parameters' .grad views); -> dict(rgb_map, ..., loss [4], counts [8])."""
+        t = self._static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx if self.net.use_framecode else None, target, bgs,
+                                near_in, far_in)
+        if t.get('bgs') is not None and t['bgs'].numel() != t['target'].numel():
+            t['bgs'] = t['bgs'].expand_as(t['target']).contiguous()
+        if not self.use_graph:
+            return self._launch(t, S, Sf, perturb, raw_noise_std)
+        key = (tuple((k, tuple(v.shape)) for k, v in sorted(t.items())), S, Sf, float(perturb), float(raw_noise_std))
+        if self.graph is None or self.graph[0] != key:
+            static = {k: v.clone() for k, v in t.items()}
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):        # eager warm-up off the capture: lazy initialisations, workspace allocation
+                self._launch(static, S, Sf, perturb, raw_noise_std)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self._launch(static, S, Sf, perturb, raw_noise_std)
+            self.graph = (key, g, static, outs)
+        _, g, static, outs = self.graph
+        for k, v in t.items():
+            static[k].copy_(v)
+        g.replay()
+        return outs
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, lr, grad_scale=1.0):
+        """torch.optim.Adam's update with the group's betas / eps on the flat buffers (core/raycasters.py:75)"""
+        grp = self.opt.param_groups[0]
+        b1, b2 = grp['betas']
+        self.t += 1
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3] = float(lr), 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t), float(grad_scale)
+        self.hyper.copy_(h, non_blocking=True)
+        _hip.check(_hip.lib().danbo_adam_step(_P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), self.n_train,
+                                              _P(self.hyper), float(b1), float(b2), float(grp['eps']),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_adam_step")
+        for p in self.params.values():
+            st = self.opt.state.get(p)
+            if st is not None:
+                st['step'] = st['step'] + 1
+            # the kernel wrote the parameter behind torch's back: bump its version counter, which the eval engine's packed
+            # weight buffers (and their HIP graphs) are keyed on
+            torch._C._increment_version(p)

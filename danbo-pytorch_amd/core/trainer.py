@@ -5,7 +5,16 @@ Data-parallel training = every rank renders its own shard of the ray batch (whol
 `N_uniques` stays an integer per rank) and the flat fp32 gradient is summed with ONE RCCL
 all-reduce per step and divided by the world size; Adam then runs redundantly
 on every rank.  No nn.DataParallel, no DistributedDataParallel hooks.
+
+Two step implementations:
+  * fused (default for the shipped DANBO configurations): core/train_engine.py -- forward, losses and backward of a batch are
+    ONE C call (`danbo_train_step`, ~75 hand-written HIP kernels, captured in a HIP graph), parameters / gradients / Adam
+    moments are views of flat buffers, the all-reduce runs on the flat gradient in place, Adam is one kernel;
+  * autograd (A-NeRF, exotic flags, or DANBO_TRAIN_PATH=autograd): the caster's differentiable forward (core/train_path.py)
+    with torch.autograd and torch.optim.Adam.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -41,10 +50,12 @@ def render(H, W, focal, chunk=1024 * 64, rays=None, c2w=None, near=0., far=1., c
 
 
 def decay_optimizer_lrate(lrate, lrate_decay, decay_rate=0.1, optimizer=None, global_step=None, decay_unit=1000):
-    """lr = lrate * decay_rate^((step // unit) / lrate_decay)  (decay_steps = lrate_decay * unit)"""
-    decay_steps = lrate_decay * decay_unit
-    optim_step = global_step // decay_unit * decay_unit
-    new_lrate = lrate * (decay_rate ** (optim_step / decay_steps))
+    """lr = lrate * decay_rate^((optimizer step // unit) / lrate_decay), the step read from the optimizer's state as the
+    reference does (core/trainer.py:189-200): it counts the update that has just been made, survives a resume and starts from 0
+    after --finetune; `global_step` is only the fall-back before the first update."""
+    state = optimizer.state.get(optimizer.param_groups[0]['params'][0], {}) if optimizer is not None else {}
+    step = float(state['step']) if 'step' in state else float(global_step or 0)
+    new_lrate = lrate * (decay_rate ** ((step // decay_unit) / lrate_decay))
     for g in optimizer.param_groups:
         g['lr'] = new_lrate
     return new_lrate, None
@@ -75,6 +86,55 @@ class Trainer:
         self.args, self.optimizer, self.device = args, optimizer, device
         self.render_kwargs_train, self.render_kwargs_test = render_kwargs_train, render_kwargs_test
         self.hwf, self.data_attrs = data_attrs.get('hwf'), data_attrs
+        self.engine, self.fused_reason = None, None
+
+    def fused_engine(self):
+        """the HIP training engine for this caster / optimizer, or None with `self.fused_reason` saying why not"""
+        if self.engine is None and self.fused_reason is None:
+            from . import train_engine
+            caster = self.render_kwargs_train['ray_caster']
+            self.fused_reason = ('DANBO_TRAIN_PATH=autograd' if os.environ.get('DANBO_TRAIN_PATH') == 'autograd'
+                                 else train_engine.supported(self.args, caster))
+            if self.fused_reason is None:
+                self.engine = train_engine.DanboTrainEngine(self.args, caster, self.optimizer)
+        return self.engine
+
+    def train_batch_fused(self, batch, i=0, global_step=0, sync_stats=True):
+        """Trainer.train_batch through danbo_train_step + danbo_adam_step (core/train_engine.py)"""
+        args, eng = self.args, self.engine
+        caster = self.render_kwargs_train['ray_caster']
+        kw = self.render_kwargs_train
+        batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        G = int(batch['N_uniques'])
+        pp = caster._per_pose
+        S, Sf = int(kw['N_samples']), int(kw['N_importance'])
+        out = eng.forward_backward(batch['rays_o'], batch['rays_d'], pp(batch['skts'], G), pp(batch['bones'], G), pp(batch['cyls'], G),
+                                   batch.get('cam_idxs'), batch['target_s'], batch.get('bgs'), S, Sf,
+                                   perturb=float(kw['perturb']), raw_noise_std=float(kw['raw_noise_std']))
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            dist.all_reduce(eng.flat_g[:eng.n_train], op=dist.ReduceOp.SUM)     # in place on the flat gradient: no packing
+        lr = self.optimizer.param_groups[0]['lr']
+        eng.adam_step(lr, 1.0 / world)
+        lr, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, self.optimizer, global_step, args.decay_unit)
+        caster.update_embed_fns(global_step, args)
+        R = out['rgb_map'].shape[0]
+        ls = out['loss']
+        loss = {'rgb_loss': ls[0], 'rgb_loss0': ls[1]}
+        if args.agg_type == 'sigmoid':
+            loss['soft_softmax_loss'] = ls[2] * (args.soft_softmax_loss_coef / (R * (S + Sf)))
+        if args.opt_vol_scale:
+            loss['vol_scale_loss'] = ls[3]
+        loss['total_loss'] = sum(loss.values())
+        stats = dict(lrate=lr)
+        if sync_stats:      # one device-to-host copy; the loop asks for it only when it prints
+            bgs = batch.get('bgs', 1.0)
+            mse = torch.mean((out['rgb_map'] + (1. - out['acc_map'][..., None]) * bgs - batch['target_s']) ** 2)
+            keys = list(loss)
+            vals = torch.stack([loss[k] for k in keys] + [out['acc_map'].mean(), mse]).cpu().tolist()
+            stats.update({k: v for k, v in zip(keys, vals)}, alpha=vals[-2], psnr=float(-10. * torch.log10(torch.tensor(vals[-1]))))
+        self.last_preds = out
+        return loss, stats
 
     def _ray_batch(self, batch):
         ro, rd = batch['rays_o'].float(), batch['rays_d'].float()
@@ -98,7 +158,9 @@ class Trainer:
         loss['total_loss'] = sum(loss.values())
         return loss
 
-    def train_batch(self, batch, i=0, global_step=0):
+    def train_batch(self, batch, i=0, global_step=0, sync_stats=True):
+        if self.fused_engine() is not None:
+            return self.train_batch_fused(batch, i, global_step, sync_stats)
         args = self.args
         kw = {k: v for k, v in self.render_kwargs_train.items() if k not in ('ray_caster', 'use_viewdirs')}
         caster = self.render_kwargs_train['ray_caster']

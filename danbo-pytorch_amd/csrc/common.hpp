@@ -2,11 +2,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/danbo_hip.h"
 #include "sample_math.hpp"
 
 #define DANBO_CHECK_ARG(cond) do { if (!(cond)) return DANBO_EINVAL; } while (0)
 #define DANBO_LAUNCH_RET() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 0 : (int)e_; } while (0)
+
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is per DEVICE: the "done" mask is keyed by the calling
+// thread's current device (a host that drives several GPUs from one process opts in on each), and it is an atomic so that
+// concurrent host threads agree on it.  Returns the HIP error from the enclosing C-ABI function on failure.
+#define DANBO_ENSURE_LDS(func, bytes)                                                                              \
+    do {                                                                                                           \
+        static std::atomic<unsigned long long> done_{0};                                                           \
+        int dev_ = 0;                                                                                              \
+        if (hipGetDevice(&dev_) != hipSuccess) return (int)hipGetLastError();                                      \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                       \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                                                     \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(func),                         \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));   \
+            if (e_ != hipSuccess) return (int)e_;                                                                  \
+            done_.fetch_or(bit_, std::memory_order_release);                                                       \
+        }                                                                                                          \
+    } while (0)
 
 namespace danbo {
 

@@ -258,13 +258,7 @@ static int launch_assign(const GatherArgs& ga, const float* part_feat, const uin
                          const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* confd,
                          void* stream) {
     const size_t lds = sizeof(float) * ASSIGN_LDS_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_blend<FUSED>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DANBO_ENSURE_LDS(k_assign_blend<FUSED>, lds);
     const int tiles = ceil_div(n, ASSIGN_SPB);
     const int grid = tiles < NUM_CU ? tiles : NUM_CU;
     hipLaunchKernelGGL(k_assign_blend<FUSED>, dim3(grid), dim3(ASSIGN_BLOCK), lds, (hipStream_t)stream, ga, part_feat,

@@ -103,6 +103,8 @@ struct A16Args {
     const float* b2;  // [24]
     float* h_out;     // [n][16]
     float* confd;     // [n][24] or NULL
+    // TRAIN instantiation only (danbo_gather_assign_blend16_train):
+    const int32_t* first;   // device scalar: rows [*first, count) of list / h_out / confd are processed, or nullptr (0)
 };
 
 constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16;  // + one pose's volumes and transforms
@@ -148,6 +150,9 @@ __device__ __forceinline__ half8 a16_frag(const char* base, int piece_in_chunk) 
     return *reinterpret_cast<const half8*>(base + piece_in_chunk * 1024);
 }
 
+// TRAIN: device-side first row, and the pad slot h[15] receives q = sum_j p_j valid_j (the row's assignment mass, which the
+// soft-softmax loss compares with its label -- reference core/trainer.py:507-536)
+template <bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_b0 = reinterpret_cast<float*>(smem + A16_SLOTS * A16_CHUNK);  // [32]
@@ -168,7 +173,14 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
     for (int i = tid; i < J * 4; i += 256) s_scale[i] = (i & 3) < 3 ? fabsf(a.axis_scale[(i >> 2) * 3 + (i & 3)]) : 1.f;
     __syncthreads();
 
-    const int n = resolve_count(a.count, a.n_cap);
+    int n = resolve_count(a.count, a.n_cap);
+    if (TRAIN && a.first != nullptr) {
+        const int f0 = *a.first;
+        n = n > f0 ? n - f0 : 0;
+        a.list += f0;
+        a.h_out += (size_t)f0 * DANBO_H_STRIDE;
+        if (a.confd != nullptr) a.confd += (size_t)f0 * J;
+    }
     const int ntiles = (n + A16_BM - 1) / A16_BM;
     if ((int)blockIdx.x >= ntiles) return;
 
@@ -293,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
         }
         // ---------------------------------------------------------------- assignment GNN + blend
         float hacc[8];
+        float qsum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) hacc[e] = 0.f;
         const char* base = nullptr;
@@ -365,12 +378,13 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
             const float pj = (sigmoidf_(logit) * 1.002f - 0.001f) * valid;
 #pragma unroll
             for (int e = 0; e < 8; ++e) hacc[e] = fmaf(pj, (float)fh[j][e] + (float)fl[j][e], hacc[e]);
+            if (TRAIN) qsum += pj;
             __builtin_amdgcn_sched_barrier(0);
         }
         if (row_ok) {
             float4* dst = reinterpret_cast<float4*>(a.h_out + (size_t)row * DANBO_H_STRIDE + 8 * hh);
             dst[0] = make_float4(hacc[0], hacc[1], hacc[2], hacc[3]);
-            dst[1] = make_float4(hacc[4], hacc[5], hacc[6], hh ? 0.f : hacc[7]);
+            dst[1] = make_float4(hacc[4], hacc[5], hacc[6], hh ? (TRAIN ? qsum : 0.f) : hacc[7]);
         }
         cur = nxt;
     }
@@ -400,16 +414,27 @@ extern "C" int danbo_gather_assign_blend16_fwd(const float* rays_o, const float*
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, pts, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd};
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign16),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, A16_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr};
+    DANBO_ENSURE_LDS(k_assign16<false>, A16_LDS_BYTES);
     const int ntiles = ceil_div(n, A16_BM);
     const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
-    hipLaunchKernelGGL(k_assign16, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_assign16<false>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_gather_assign_blend16_train(const float* rays_o, const float* rays_d, const float* z, int R, int S, int G,
+                                                 const float* skts, const float* align, const float* axis_scale,
+                                                 const float* volumes, const uint32_t* valid_bits, const int32_t* list,
+                                                 const int32_t* count, const int32_t* first, int n, const void* packed16,
+                                                 const float* b0, const float* b1, const float* w2, const float* b2, float* h,
+                                                 void* stream) {
+    DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && list && count && z && R > 0 && S > 0 && G > 0 && R % G == 0);
+    if (n == 0) return 0;
+    A16Args a = {rays_o, rays_d, z, nullptr, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first};
+    DANBO_ENSURE_LDS(k_assign16<true>, A16_LDS_BYTES);
+    const int ntiles = ceil_div(n, A16_BM);
+    const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
+    hipLaunchKernelGGL(k_assign16<true>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

@@ -1,0 +1,348 @@
+// Backward of K1b + K2 (factorised gather -> assignment GNN -> masked sigmoid -> blend) for the training step.
+// Reference forward: core/networks/gnn_backbone.py:567-629 (MixGNN), :787-828 (sample_from_volume), core/networks/misc.py:331-351,
+// core/networks/danbo.py:299-300,406-415; gradients = what loss.backward() (core/trainer.py:563-576) sends to
+// prob_linears.*, graph_net.axis_scale and the per-pose volumes (and from there into the pose GNN, k_pose_bwd.hip).  gfx950 only.
+//
+// Nothing of the forward is stored: the 1 440 B / row part_feat tensor the unfused forward would have to write is
+// RECOMPUTED here from the 23 KB pose volumes (L2-resident), in exact fp32.
+//
+// Work decomposition: a bone's logit only reaches a loss where the bone is valid for the sample (p_j = s(a_j) valid_j, and the
+// soft-softmax term multiplies by valid_j too), so the unit of work is a PAIR (row, valid bone j) -- on average 1.6 per
+// in-volume row instead of 24.  Pairs are grouped by bone (k_train_bone_lists): a workgroup serves one bone j, keeps the
+// weights that bone touches in LDS (layer 0 of j's tree neighbours, its own layers 1 and 2: 14 KB) and their GRADIENTS in
+// registers for its whole chunk of pairs -- one flush of atomics per workgroup instead of per pair.
+// A wavefront works on two pairs at a time, one per 32-lane half; lane c of a half owns hidden unit c.
+//   forward (recompute)    f_k = gather(vol[g,k], x_k) for k in N(j);  y_k = f_k W0_k;  z0 = sum_k A_jk y_k + b0;  a0 = relu z0
+//                          z1 = a0 W1_j + b1_j;  a1 = relu z1;  logit = a1 . w2_j + b2_j;  p = 1.002 s(logit) - 0.001
+//   upstream               d h [15] (from the MLP through the PE adjoint),  q = sum_j p_j (forward, h[15]),  label (T_i alpha > 0)
+//   d logit = (d h . f_j + c_ss (q - label)) 1.002 s (1 - s),   c_ss = 2 coef / (R (S + Sf))
+//   ... d w2, d b2, d W1, d b1, d b0, d A_jk, d W0_k, d f_k = A_jk (dz0 W0_k^T) (+ p d h for k = j)
+//   d vol[g,k], d axis_scale[k] from d f_k by the adjoint of the interpolation (window detached, mask not differentiable:
+//   gnn_backbone.py:804,808)
+#include "common.hpp"
+
+namespace danbo {
+
+constexpr int AB_MAXNB = 6;          // bone + at most 5 tree neighbours (SMPL: 5)
+constexpr int AB_W = 32;             // hidden width of the assignment net
+constexpr int AB_STRIDE = AB_W + 1;  // padded rows: row-wise and column-wise reads are both conflict-free
+constexpr int AB_THREADS = 256;
+constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefronts x 2 halves)
+
+struct ABArgs {
+    // geometry
+    const float *rays_o, *rays_d, *z_c, *z_f, *skts, *align, *axis_scale, *volumes;
+    int R, S, Sf, G;
+    // rows
+    const int32_t *row_sample, *row_ray, *cnt, *lists, *cntb;
+    int cap;
+    const float *h_rows, *d_h;
+    const uint8_t *label_c, *label_f;
+    const uint32_t *bits_c, *bits_f;
+    // assignment net (reference parameter layouts)
+    const float *w0 /*[24,15,32]*/, *adj_w /*[24,24]*/, *adj /*[24,24]*/, *b0 /*[32]*/, *w1 /*[24,32,32]*/, *b1 /*[24,32]*/, *w2 /*[24,32]*/,
+        *b2 /*[24]*/;
+    // gradients (accumulated with atomics: the caller zeroes them)
+    float *g_w0, *g_adj_w, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2, *g_vol /*[G,24,240]*/, *g_scale /*[24,3]*/;
+    float c_ss;          // 2 coef / (R (S + Sf))
+    float* loss;         // loss[2] += (label - q)^2 of in-volume rows
+    int pairs_per_wg;    // pairs one workgroup serves (workgroups are dealt to the bones in proportion to their pair counts)
+};
+
+__device__ __forceinline__ float half_sum32(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
+    __shared__ float s_w0[AB_MAXNB][FEAT][AB_STRIDE];
+    __shared__ float s_w1[AB_W][AB_STRIDE];
+    __shared__ float s_b0[AB_W], s_b1[AB_W], s_w2[AB_W];
+    __shared__ float s_adj[AB_MAXNB], s_align[AB_MAXNB][12], s_scale[AB_MAXNB][4];
+    __shared__ int s_nb[AB_MAXNB];
+    __shared__ int s_nq;
+    __shared__ float s_gvol[AB_MAXNB][VOL];
+    // per-pair scratch (one per wave half)
+    __shared__ __attribute__((aligned(16))) float s_f[AB_PAIRS][AB_MAXNB][16];
+    __shared__ __attribute__((aligned(16))) float s_df[AB_PAIRS][AB_MAXNB][16];
+    __shared__ __attribute__((aligned(16))) float s_a0[AB_PAIRS][AB_W], s_dz1[AB_PAIRS][AB_W], s_dz0[AB_PAIRS][AB_W], s_dh[AB_PAIRS][16];
+
+    // workgroup -> (bone j, chunk of its pair list): bones get ceil(pairs / pairs_per_wg) workgroups each, in bone order
+    int j = 0, wg = blockIdx.x, npairs = 0;
+    for (; j < J; ++j) {
+        npairs = min(a.cntb[j], a.cap);
+        const int need = (npairs + a.pairs_per_wg - 1) / a.pairs_per_wg;
+        if (wg < need) break;
+        wg -= need;
+    }
+    if (j == J) return;
+    const int p_begin = wg * a.pairs_per_wg, p_end = min(p_begin + a.pairs_per_wg, npairs);
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, slot = tid >> 5;   // slot: which pair of the 8 in flight
+
+    // ---- neighbourhood of bone j from the adjacency buffer (self first) and its weights
+    if (tid == 0) {
+        int nq = 0;
+        s_nb[nq++] = j;
+        for (int k = 0; k < J && nq < AB_MAXNB; ++k)
+            if (k != j && a.adj[j * J + k] != 0.f) s_nb[nq++] = k;
+        s_nq = nq;
+    }
+    __syncthreads();
+    const int nq = s_nq;
+    for (int i = tid; i < nq * FEAT * AB_W; i += AB_THREADS) {
+        const int q = i / (FEAT * AB_W), t = (i / AB_W) % FEAT, cc = i % AB_W;
+        s_w0[q][t][cc] = a.w0[((size_t)s_nb[q] * FEAT + t) * AB_W + cc];
+    }
+    for (int i = tid; i < AB_W * AB_W; i += AB_THREADS) s_w1[i / AB_W][i % AB_W] = a.w1[(size_t)j * AB_W * AB_W + i];
+    if (tid < AB_W) { s_b0[tid] = a.b0[tid]; s_b1[tid] = a.b1[j * AB_W + tid]; s_w2[tid] = a.w2[j * AB_W + tid]; }
+    if (tid < nq) s_adj[tid] = a.adj_w[j * J + s_nb[tid]] * a.adj[j * J + s_nb[tid]];
+    for (int i = tid; i < nq * 12; i += AB_THREADS) s_align[i / 12][i % 12] = a.align[s_nb[i / 12] * 16 + i % 12];
+    for (int i = tid; i < nq * 4; i += AB_THREADS) s_scale[i / 4][i % 4] = (i % 4) < 3 ? a.axis_scale[s_nb[i / 4] * 3 + i % 4] : 1.f;
+    for (int i = tid; i < AB_MAXNB * VOL; i += AB_THREADS) (&s_gvol[0][0])[i] = 0.f;
+    __syncthreads();
+    const float b2 = a.b2[j];
+    const int first_f = a.cnt[2];
+    const int rays_per_pose = a.R / a.G;
+    // pose whose volume gradient is gathered in LDS: the pose of this chunk's first pair (rows are ray-ordered, so most pairs
+    // of a chunk share it); pairs of other poses go to global memory directly
+    int g0;
+    {
+        const int i0 = a.lists[(size_t)j * a.cap + p_begin];
+        g0 = min(a.row_ray[i0] / rays_per_pose, a.G - 1);
+    }
+
+    // ---- gradient accumulators of this lane (hidden unit c of half `slot & 1`)
+    float gw1[AB_W];                 // d W1[j][cc][c], cc = 0..31
+    float gw0[AB_MAXNB][FEAT];       // d W0[nb q][t][c]
+    float gb1 = 0.f, gw2 = 0.f, gb0 = 0.f, gb2 = 0.f, gadj[AB_MAXNB], gsc = 0.f, lss = 0.f;
+#pragma unroll
+    for (int i = 0; i < AB_W; ++i) gw1[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < AB_MAXNB; ++q) {
+        gadj[q] = 0.f;
+#pragma unroll
+        for (int t = 0; t < FEAT; ++t) gw0[q][t] = 0.f;
+    }
+    // lanes 0 .. 3 nq - 1 of a half: (neighbour gq, axis gk) of the gather and of its adjoint
+    const int gq = c / 3, gk = c % 3;
+    const bool glane = c < 3 * nq;
+
+    const int iters = (p_end - p_begin + AB_PAIRS - 1) / AB_PAIRS;
+    for (int it = 0; it < iters; ++it) {
+        const int pi = p_begin + it * AB_PAIRS + slot;
+        const bool live = pi < p_end;            // uniform per half
+        const int i = a.lists[(size_t)j * a.cap + (live ? pi : p_begin)];
+        const bool coarse = i < first_f;
+        const int m = a.row_sample[i], ray = a.row_ray[i];
+        const int g = min(ray / rays_per_pose, a.G - 1);
+        const float zv = coarse ? a.z_c[m] : a.z_f[m];
+        const float lab = (float)(coarse ? a.label_c[m] : a.label_f[m]);
+        const uint32_t bits = coarse ? a.bits_c[m] : a.bits_f[m];
+        const float qrow = a.h_rows[(size_t)i * 16 + 15];
+        if (c < 16) s_dh[slot][c] = c < FEAT ? a.d_h[(size_t)i * 16 + c] : 0.f;
+
+        // ---- recompute the gather: lane (gq, gk) evaluates neighbour gq completely and keeps axis gk
+        float x_k = 0.f, win = 0.f, w0t = 0.f, w1t = 0.f, sck = 1.f;
+        int y0 = 0, y1 = 0;
+        bool ok0 = false, ok1 = false;
+        const float* vol = nullptr;
+        if (glane) {
+            const int k = s_nb[gq];
+            const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
+            const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
+            float p[3], pl[3], pt[3], x[3], skt[12];
+            sample_point(o, d, zv, p);
+            const float* src = a.skts + ((size_t)g * J + k) * 16;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) skt[e] = src[e];
+            affine_unfused(skt, p, pl);
+            affine_unfused(s_align[gq], pl, pt);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) x[e] = div_rn(pt[e], fabsf(s_scale[gq][e]));
+            win = coord_window(x);
+            x_k = x[gk];
+            sck = s_scale[gq][gk];
+            const float iy = div_rn(sub_rn(mul_rn(add_rn(x_k, 1.0f), (float)VRES), 1.0f), 2.0f);
+            const float fl = floorf(iy);
+            w1t = sub_rn(iy, fl);
+            w0t = sub_rn(1.0f, w1t);
+            y0 = (int)fminf(fmaxf(fl, -2.0f), (float)VRES + 1.0f);
+            y1 = y0 + 1;
+            ok0 = y0 >= 0 && y0 < VRES;
+            ok1 = y1 >= 0 && y1 < VRES;
+            vol = a.volumes + ((size_t)g * J + k) * VOL;
+#pragma unroll
+            for (int f = 0; f < VOXF; ++f) {
+                const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
+                const float v1 = ok1 ? vol[f * (VRES * 3) + y1 * 3 + gk] : 0.f;
+                s_f[slot][gq][f * 3 + gk] = mul_rn(add_rn(mul_rn(v0, w0t), mul_rn(v1, w1t)), win);
+            }
+            if (gk == 0) s_f[slot][gq][15] = 0.f;
+        }
+        __syncthreads();
+
+        // ---- layer 0: y_q[c], z0[c]
+        float y[AB_MAXNB];
+        float z0 = s_b0[c];
+#pragma unroll
+        for (int q = 0; q < AB_MAXNB; ++q) {
+            y[q] = 0.f;
+            if (q < nq) {
+#pragma unroll
+                for (int t = 0; t < FEAT; ++t) y[q] = fmaf(s_f[slot][q][t], s_w0[q][t][c], y[q]);
+                z0 = fmaf(s_adj[q], y[q], z0);
+            }
+        }
+        const float a0 = fmaxf(z0, 0.f);
+        s_a0[slot][c] = a0;
+        __syncthreads();
+        // ---- layer 1, 2
+        float z1 = s_b1[c];
+#pragma unroll
+        for (int cc = 0; cc < AB_W; ++cc) z1 = fmaf(s_a0[slot][cc], s_w1[cc][c], z1);
+        const float a1 = fmaxf(z1, 0.f);
+        const float logit = half_sum32(a1 * s_w2[c]) + b2;
+        const float sg = sigmoidf_(logit);
+        const float pj = sg * 1.002f - 0.001f;
+        // ---- upstream
+        float dp = c < FEAT ? s_dh[slot][c] * s_f[slot][0][c] : 0.f;   // neighbour 0 is the bone itself
+        dp = half_sum32(dp);
+        float dlogit = (dp + a.c_ss * (qrow - lab)) * 1.002f * sg * (1.0f - sg);
+        if (!live) dlogit = 0.f;
+        if (live && c == 0 && j == __builtin_ctz(bits)) lss += (lab - qrow) * (lab - qrow);   // once per row
+        // ---- layer 2, 1 adjoints
+        gw2 = fmaf(dlogit, a1, gw2);
+        gb2 += dlogit;
+        const float dz1 = z1 > 0.f ? dlogit * s_w2[c] : 0.f;
+        gb1 += dz1;
+        s_dz1[slot][c] = dz1;
+#pragma unroll
+        for (int cc = 0; cc < AB_W; ++cc) gw1[cc] = fmaf(s_a0[slot][cc], dz1, gw1[cc]);
+        __syncthreads();
+        float da0 = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < AB_W; ++cc) da0 = fmaf(s_w1[c][cc], s_dz1[slot][cc], da0);
+        const float dz0 = z0 > 0.f ? da0 : 0.f;
+        gb0 += dz0;
+        s_dz0[slot][c] = dz0;
+        // ---- layer 0 adjoints: adjacency, W0
+#pragma unroll
+        for (int q = 0; q < AB_MAXNB; ++q) {
+            if (q < nq) {
+                gadj[q] += half_sum32(dz0 * y[q]);
+                const float dy = s_adj[q] * dz0;
+#pragma unroll
+                for (int t = 0; t < FEAT; ++t) gw0[q][t] = fmaf(s_f[slot][q][t], dy, gw0[q][t]);
+            }
+        }
+        __syncthreads();
+        // ---- d f_q[t] = A_jq sum_cc dz0[cc] W0_q[t][cc]  (+ p d h[t] for the bone itself): (q, t) pairs spread over the half
+        for (int e = c; e < nq * FEAT; e += 32) {
+            const int q = e / FEAT, t = e % FEAT;
+            float acc = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < AB_W; ++cc) acc = fmaf(s_dz0[slot][cc], s_w0[q][t][cc], acc);
+            acc *= s_adj[q];
+            if (q == 0) acc = fmaf(pj, s_dh[slot][t], acc);
+            s_df[slot][q][t] = live ? acc : 0.f;
+        }
+        __syncthreads();
+        // ---- adjoint of the gather (k_backward.hip's arithmetic): lane (gq, gk)
+        if (glane && live && win != 0.f) {
+            const int k = s_nb[gq];
+            float* gv = g == g0 ? &s_gvol[gq][0] : a.g_vol + ((size_t)g * J + k) * VOL;
+            float dx = 0.f;
+#pragma unroll
+            for (int f = 0; f < VOXF; ++f) {
+                const float gqv = s_df[slot][gq][f * 3 + gk] * win;
+                const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
+                const float v1 = ok1 ? vol[f * (VRES * 3) + y1 * 3 + gk] : 0.f;
+                if (ok0) atomicAdd(gv + f * (VRES * 3) + y0 * 3 + gk, gqv * w0t);
+                if (ok1) atomicAdd(gv + f * (VRES * 3) + y1 * 3 + gk, gqv * w1t);
+                dx += gqv * (v1 - v0);
+            }
+            dx *= 0.5f * (float)VRES;
+            gsc += dx * (-x_k / fabsf(sck)) * (sck < 0.f ? -1.f : 1.f);
+        }
+        // (the next iteration's first barrier orders its scratch writes after these reads)
+    }
+
+    // ---- flush: the 8 pair slots of the workgroup first add up in LDS (the weight tables are dead by now and become the
+    // accumulators), then every entry goes to global memory with one atomic
+    __syncthreads();
+    for (int i = tid; i < AB_MAXNB * FEAT * AB_STRIDE; i += AB_THREADS) (&s_w0[0][0][0])[i] = 0.f;
+    for (int i = tid; i < AB_W * AB_STRIDE; i += AB_THREADS) (&s_w1[0][0])[i] = 0.f;
+    if (tid < AB_W) { s_b0[tid] = 0.f; s_b1[tid] = 0.f; s_w2[tid] = 0.f; }
+    if (tid < AB_MAXNB) { s_adj[tid] = 0.f; }
+    if (tid < AB_MAXNB * 4) (&s_scale[0][0])[tid] = 0.f;
+    if (tid < 16) s_dh[0][tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < AB_W; ++cc) atomicAdd(&s_w1[cc][c], gw1[cc]);
+#pragma unroll
+    for (int q = 0; q < AB_MAXNB; ++q) {
+        if (q < nq) {
+#pragma unroll
+            for (int t = 0; t < FEAT; ++t) atomicAdd(&s_w0[q][t][c], gw0[q][t]);
+            if (c == 0) atomicAdd(&s_adj[q], gadj[q]);
+        }
+    }
+    atomicAdd(&s_b1[c], gb1);
+    atomicAdd(&s_w2[c], gw2);
+    atomicAdd(&s_b0[c], gb0);
+    if (c == 0) { atomicAdd(&s_dh[0][0], gb2); atomicAdd(&s_dh[0][1], lss); }
+    if (glane) atomicAdd(&s_scale[gq][gk], gsc);
+    __syncthreads();
+    float* gw1p = a.g_w1 + (size_t)j * AB_W * AB_W;
+    for (int i = tid; i < AB_W * AB_W; i += AB_THREADS) {
+        const float v = s_w1[i / AB_W][i % AB_W];
+        if (v != 0.f) atomicAdd(gw1p + i, v);
+    }
+    for (int i = tid; i < nq * FEAT * AB_W; i += AB_THREADS) {
+        const int q = i / (FEAT * AB_W), t = (i / AB_W) % FEAT, cc = i % AB_W;
+        const float v = s_w0[q][t][cc];
+        if (v != 0.f) atomicAdd(a.g_w0 + ((size_t)s_nb[q] * FEAT + t) * AB_W + cc, v);
+    }
+    if (tid < AB_W) {
+        if (s_b1[tid] != 0.f) atomicAdd(a.g_b1 + j * AB_W + tid, s_b1[tid]);
+        if (s_w2[tid] != 0.f) atomicAdd(a.g_w2 + j * AB_W + tid, s_w2[tid]);
+        if (s_b0[tid] != 0.f) atomicAdd(a.g_b0 + tid, s_b0[tid]);
+    }
+    if (tid < nq && s_adj[tid] != 0.f) atomicAdd(a.g_adj_w + j * J + s_nb[tid], s_adj[tid] * a.adj[j * J + s_nb[tid]]);
+    if (tid < nq * 3 && s_scale[tid / 3][tid % 3] != 0.f) atomicAdd(a.g_scale + s_nb[tid / 3] * 3 + tid % 3, s_scale[tid / 3][tid % 3]);
+    if (tid == 0) {
+        if (s_dh[0][0] != 0.f) atomicAdd(a.g_b2 + j, s_dh[0][0]);
+        if (s_dh[0][1] != 0.f) atomicAdd(a.loss + 2, s_dh[0][1]);
+    }
+    for (int i = tid; i < nq * VOL; i += AB_THREADS) {
+        const float v = s_gvol[i / VOL][i % VOL];
+        if (v != 0.f) atomicAdd(a.g_vol + ((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL, v);
+    }
+}
+
+}  // namespace danbo
+
+using namespace danbo;
+
+extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
+    DANBO_CHECK_ARG(p && p->rays_o && p->rays_d && p->z_c && p->z_f && p->skts && p->align && p->axis_scale && p->volumes);
+    DANBO_CHECK_ARG(p->R > 0 && p->S > 0 && p->Sf > 0 && p->G > 0 && p->R % p->G == 0 && p->rows_cap > 0);
+    DANBO_CHECK_ARG(p->row_sample && p->row_ray && p->cnt && p->lists && p->cntb && p->h_rows && p->d_h && p->label_c && p->label_f);
+    DANBO_CHECK_ARG(p->bits_c && p->bits_f && p->w0 && p->adj_w && p->adj && p->b0 && p->w1 && p->b1 && p->w2 && p->b2);
+    DANBO_CHECK_ARG(p->g_w0 && p->g_adj_w && p->g_b0 && p->g_w1 && p->g_b1 && p->g_w2 && p->g_b2 && p->g_vol && p->g_scale && p->loss);
+    ABArgs a;
+    a.rays_o = p->rays_o; a.rays_d = p->rays_d; a.z_c = p->z_c; a.z_f = p->z_f; a.skts = p->skts; a.align = p->align;
+    a.axis_scale = p->axis_scale; a.volumes = p->volumes; a.R = p->R; a.S = p->S; a.Sf = p->Sf; a.G = p->G;
+    a.row_sample = p->row_sample; a.row_ray = p->row_ray; a.cnt = p->cnt; a.lists = p->lists; a.cntb = p->cntb; a.cap = p->rows_cap;
+    a.h_rows = p->h_rows; a.d_h = p->d_h; a.label_c = p->label_c; a.label_f = p->label_f; a.bits_c = p->bits_c; a.bits_f = p->bits_f;
+    a.w0 = p->w0; a.adj_w = p->adj_w; a.adj = p->adj; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
+    a.g_w0 = p->g_w0; a.g_adj_w = p->g_adj_w; a.g_b0 = p->g_b0; a.g_w1 = p->g_w1; a.g_b1 = p->g_b1; a.g_w2 = p->g_w2; a.g_b2 = p->g_b2;
+    a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
+    // 256 pairs (32 iterations of 8) per workgroup amortise its weight staging and its flush; a sample lies in at most a few
+    // volumes, so 4 pairs per row of capacity is far above what geometry allows -- and workgroups without pairs exit at once
+    a.pairs_per_wg = 256;
+    const long wgs = ((long)p->rows_cap * 4 + a.pairs_per_wg - 1) / a.pairs_per_wg + J;
+    hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < 65535 ? wgs : 65535)), dim3(AB_THREADS), 0, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}

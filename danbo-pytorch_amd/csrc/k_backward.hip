@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
                                                        const float* __restrict__ rays_d, int R, int S, float B,
                                                        const float* __restrict__ noise,
                                                        const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
-                                                       float4* __restrict__ d_raw) {
+                                                       float4* __restrict__ d_raw, const float4* __restrict__ raw_empty,
+                                                       const uint32_t* __restrict__ bits) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
             const int s = c * 64 + lane;
             const bool act = s < S;
             const size_t m = (size_t)r * S + (act ? s : S - 1);
-            const float4 rw = raw[m];
+            // lazily filled raw: samples outside every volume were never written and take the ray's empty-space raw
+            const float4 rw = (bits != nullptr && bits[m] == 0u) ? raw_empty[r] : raw[m];
             const float zs = z[m];
             const float zn = (s + 1 < S) ? z[m + 1] : zs;
             dist[c] = mul_rn((s + 1 < S) ? sub_rn(zn, zs) : 1e10f, dn);
@@ -199,12 +201,19 @@ extern "C" int danbo_bone_gather_bwd(const float* rays_o, const float* rays_d, c
     DANBO_LAUNCH_RET();
 }
 
+extern "C" int danbo_composite_bwd_lazy(const float* raw, const float* raw_empty, const uint32_t* valid_bits, const float* z,
+                                         const float* rays_d, int R, int S, float B, const float* noise, const float* g_rgb,
+                                         const float* g_acc, float* d_raw, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && S <= 256 && B > 0.f && raw && z && rays_d && g_rgb && g_acc && d_raw);
+    DANBO_CHECK_ARG(valid_bits == nullptr || raw_empty != nullptr);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(raw), z, rays_d, R, S, B, noise, g_rgb, g_acc,
+                       reinterpret_cast<float4*>(d_raw), reinterpret_cast<const float4*>(raw_empty), valid_bits);
+    DANBO_LAUNCH_RET();
+}
+
 extern "C" int danbo_composite_bwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
                                     const float* noise, const float* g_rgb, const float* g_acc, float* d_raw,
                                     void* stream) {
-    DANBO_CHECK_ARG(R > 0 && S > 0 && S <= 256 && B > 0.f && g_rgb && g_acc && d_raw);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(raw), z, rays_d, R, S, B, noise, g_rgb, g_acc,
-                       reinterpret_cast<float4*>(d_raw));
-    DANBO_LAUNCH_RET();
+    return danbo_composite_bwd_lazy(raw, nullptr, nullptr, z, rays_d, R, S, B, noise, g_rgb, g_acc, d_raw, stream);
 }

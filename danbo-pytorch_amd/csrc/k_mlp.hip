@@ -577,13 +577,7 @@ extern "C" int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32
     a.alpha_w = alpha_w; a.alpha_b = alpha_b; a.feature_b = feature_b; a.cview = cview;
     a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.raw_out = raw_out; a.aux_out = aux_out;
     const size_t lds = sizeof(float) * MLP_LDS_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pe_mlp),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DANBO_ENSURE_LDS(k_pe_mlp, lds);
     const int ntiles = ceil_div(n, MLP_BM);
     const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
     hipLaunchKernelGGL(k_pe_mlp, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);

@@ -521,13 +521,7 @@ extern "C" int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int
     for (int i = 0; i < 8; ++i) a.pts_b[i] = pts_b[i];
     a.alpha_w = alpha_w; a.alpha_b = alpha_b; a.cview = cview;
     a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.raw_out = raw_out; a.aux_out = aux_out;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pe_mlp16),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, M16_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    DANBO_ENSURE_LDS(k_pe_mlp16, M16_LDS_BYTES);
     const int ntiles = ceil_div(n, M16_BM);
     const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
     hipLaunchKernelGGL(k_pe_mlp16, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a);

@@ -1,0 +1,487 @@
+// Row-wise glue kernels of the training step (everything between the hand-written stages that is not a GEMM):
+// per-ray view inputs, positional encoding of the blended features and its adjoint, the colour head and its adjoint,
+// the loss gradients, un-merging of the composite gradients, frame-code gradients, per-bone pair lists, Adam.
+// Reference: core/networks/nerf.py:176-209,252-279 (inference / encode_views), core/cutoff_embedder.py:62-73 (Embedder),
+// core/trainer.py:396-422,507-536 (losses), torch.optim.Adam as configured by core/raycasters.py:75.  gfx950 only.
+//
+// Row layout of a step (R rays, S coarse + Sf importance samples):
+//   rows [0, R)                     one "empty-space" row per ray: blended feature h = 0; every sample of the ray that lies in
+//                                   no bone volume shares its raw output (exact: see DESIGN.md "Exact sparsity")
+//   rows [R, R + n_c)               coarse samples inside >= 1 volume, in the order K1a compacted them
+//   rows [R + n_c, R + n_c + n_f)   importance samples inside >= 1 volume
+// cnt[] (device int32): [0] running compaction counter (n_c after the coarse cull, n_c + n_f after the second),
+//   [1] n_c, [2] R + n_c, [3] n_f, [4] R + n_c + n_f, [5] n_c + n_f
+#include "common.hpp"
+
+namespace danbo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void atomic_max_abs(float* slot, float v) {
+    if (v > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, v));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-ray view inputs  vin[r] = [ PE_L(dir) | frame code | 0 ]   (reference nerf.py:252-279, encoders.py:179-189,570-578)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_view_inputs(const float* __restrict__ rays_d, const float* __restrict__ skts, int R, int G,
+                                                           int ray_mode, int normalise, int L, const float* __restrict__ codes,
+                                                           int n_codes, int Cf, const int64_t* __restrict__ cam_idx,
+                                                           float* __restrict__ vin, int ldv) {
+    const int nd = 3 * (1 + 2 * L);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)R * ldv; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / ldv), c = (int)(idx % ldv);
+        float out = 0.f;
+        if (c < nd) {
+            float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+            if (ray_mode == 1) {   // root_local: skts[g, 0, :3, :3] d   (sequential-k sum like torch.matmul)
+                const float* m = skts + (size_t)(r / (R / G)) * J * 16;
+                float t[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t[k] = add_rn(add_rn(mul_rn(m[4 * k], d[0]), mul_rn(m[4 * k + 1], d[1])), mul_rn(m[4 * k + 2], d[2]));
+                d[0] = t[0]; d[1] = t[1]; d[2] = t[2];
+            }
+            if (normalise) {       // F.normalize(p = 2, eps = 1e-12)
+                const float nrm = fmaxf(sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2]))), 1e-12f);
+                d[0] = div_rn(d[0], nrm); d[1] = div_rn(d[1], nrm); d[2] = div_rn(d[2], nrm);
+            }
+            if (c < 3) out = d[c];
+            else {
+                const int b = (c - 3) / 3, k = (c - 3) % 3, l = b >> 1;
+                float sn, cs;
+                pe_sincos(mul_rn(d[k], (float)(1 << l)), &sn, &cs);
+                out = (b & 1) ? cs : sn;
+            }
+        } else if (c < nd + Cf && codes != nullptr) {
+            long ci = cam_idx ? cam_idx[r] : 0;
+            ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
+            out = codes[ci * Cf + (c - nd)];
+        }
+        vin[idx] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// rows of one pass: positional encoding of h, the ray's view inputs, ray of the row, derived counters
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_rows_fwd(const float* __restrict__ h_rows, const int32_t* __restrict__ row_sample,
+                                                        int32_t* __restrict__ cnt, int pass, int R, int S_pass, int L,
+                                                        const float* __restrict__ vin, int ldv, float* __restrict__ pe, int ldp,
+                                                        float* __restrict__ vinr, int32_t* __restrict__ row_ray) {
+    const int n_run = cnt[0];
+    const int first = pass == 0 ? 0 : R + cnt[1];
+    const int rows = pass == 0 ? R + n_run : n_run - cnt[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (pass == 0) { cnt[1] = n_run; cnt[2] = R + n_run; }
+        else { cnt[3] = rows; cnt[4] = first + rows; cnt[5] = n_run; }
+    }
+    const int npe = FEAT * (1 + 2 * L);
+    // one thread per (row, 4-column group) of [pe | vinr]
+    const int gp = ldp / 4, gv = ldv / 4, gpr = gp + gv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)rows * gpr; idx += (long)gridDim.x * blockDim.x) {
+        const int i = first + (int)(idx / gpr), gq = (int)(idx % gpr);
+        const bool empty = i < R;
+        const int ray = empty ? i : row_sample[i] / S_pass;
+        if (gq == 0) row_ray[i] = ray;
+        if (gq < gp) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * gq + e;
+                float v = 0.f;
+                if (c < npe) {
+                    if (c < FEAT) v = empty ? 0.f : h_rows[(size_t)i * 16 + c];
+                    else {
+                        const int b = (c - FEAT) / FEAT, k = (c - FEAT) % FEAT, l = b >> 1;
+                        const float x = empty ? 0.f : h_rows[(size_t)i * 16 + k];
+                        float sn, cs;
+                        pe_sincos(mul_rn(x, (float)(1 << l)), &sn, &cs);
+                        v = (b & 1) ? cs : sn;
+                    }
+                }
+                o[e] = v;
+            }
+            *reinterpret_cast<f32x4*>(pe + (size_t)i * ldp + 4 * gq) = o;
+        } else {
+            const int c = 4 * (gq - gp);
+            *reinterpret_cast<f32x4*>(vinr + (size_t)i * ldv + c) = *reinterpret_cast<const f32x4*>(vin + (size_t)ray * ldv + c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// colour head: raw = (rgb_linear(hv), alpha) per row, scattered to the dense raw tensor of the pass / the ray's empty raw
+// 32 lanes per row (4 columns of hv each)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a wave half
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_train_rgb_head_fwd(const float* __restrict__ hv, const float* __restrict__ fa, int ldfa,
+                                                            const float* __restrict__ rgb_w, const float* __restrict__ rgb_b,
+                                                            const int32_t* __restrict__ row_sample, const int32_t* __restrict__ cnt,
+                                                            int pass, int R, float* __restrict__ raw_rows,
+                                                            float* __restrict__ raw_dense, float* __restrict__ raw_empty) {
+    const int first = pass == 0 ? 0 : cnt[2];
+    const int rows = pass == 0 ? cnt[2] : cnt[3];
+    const int sub = threadIdx.x & 31;
+    const long slot = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5, nslots = ((long)gridDim.x * blockDim.x) >> 5;
+    f32x4 w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w[c] = *reinterpret_cast<const f32x4*>(rgb_w + c * 128 + 4 * sub);
+    for (long k = slot; k < rows; k += nslots) {
+        const int i = first + (int)k;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(hv + (size_t)i * 128 + 4 * sub);
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = half_wave_sum(x[0] * w[c][0] + x[1] * w[c][1] + x[2] * w[c][2] + x[3] * w[c][3]) + rgb_b[c];
+        if (sub == 0) {
+            const f32x4 r4 = {o[0], o[1], o[2], fa[(size_t)i * ldfa + 256]};
+            *reinterpret_cast<f32x4*>(raw_rows + (size_t)i * 4) = r4;
+            float* dst = i < R ? raw_empty + (size_t)i * 4 : raw_dense + (size_t)row_sample[i] * 4;
+            *reinterpret_cast<f32x4*>(dst) = r4;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// loss gradients with respect to the composited maps of both passes (reference trainer.py:396-422: L1 / MSE on
+// rgb + (1 - acc) * bg, mean over R x 3 entries), and the loss values (atomically summed into loss[0] fine, loss[1] coarse)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_loss_grad(const float* __restrict__ rgb, const float* __restrict__ acc,
+                                                         const float* __restrict__ rgb0, const float* __restrict__ acc0,
+                                                         const float* __restrict__ target, const float* __restrict__ bgs, int use_bg,
+                                                         int R, int mse, float w_fine, float w_coarse, float* __restrict__ g_rgb,
+                                                         float* __restrict__ g_acc, float* __restrict__ g_rgb0,
+                                                         float* __restrict__ g_acc0, float* __restrict__ loss) {
+    float l_f = 0.f, l_c = 0.f;
+    const float inv = 1.0f / (3.0f * (float)R);
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* c = p ? rgb0 : rgb;
+            const float a = p ? acc0[r] : acc[r];
+            const float wgt = p ? w_coarse : w_fine;
+            float ga = 0.f, ls = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float bg = use_bg ? (bgs ? bgs[3 * r + k] : 1.0f) : 0.f;
+                const float e = c[3 * r + k] + (use_bg ? (1.0f - a) * bg : 0.f) - target[3 * r + k];
+                const float g = (mse ? 2.0f * e : (e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.f))) * inv * wgt;
+                ls += mse ? e * e : fabsf(e);
+                (p ? g_rgb0 : g_rgb)[3 * r + k] = g;
+                ga -= g * bg;
+            }
+            (p ? g_acc0 : g_acc)[r] = ga;
+            if (p) l_c += ls * inv * wgt; else l_f += ls * inv * wgt;
+        }
+    }
+    l_f = wave_total(l_f);
+    l_c = wave_total(l_c);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(loss + 0, l_f); atomicAdd(loss + 1, l_c); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Un-merge the gradient of the final composite (sorted order) onto the coarse / importance samples, add the coarse
+// composite's own gradient, sum the samples outside every volume into the ray's empty-space row, and derive the
+// soft-softmax labels (T_i alpha > 0, reference trainer.py:507-536) in un-sorted order.  One wavefront per ray.
+// loss[2] += sum of label^2 over samples outside every volume (their assignment probability mass is 0).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_draw_unmerge(float4* __restrict__ d_raw_c /*in: coarse composite's, out: combined*/,
+                                                            const float4* __restrict__ d_raw_sorted, const int32_t* __restrict__ order,
+                                                            const uint32_t* __restrict__ bits_c, const uint32_t* __restrict__ bits_f,
+                                                            const float* __restrict__ weights, const float* __restrict__ alpha, int R,
+                                                            int S, int Sf, float4* __restrict__ d_raw_f, float4* __restrict__ d_raw_rows,
+                                                            uint8_t* __restrict__ label_c, uint8_t* __restrict__ label_f,
+                                                            float* __restrict__ loss, float* __restrict__ maxabs) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int St = S + Sf;
+    float lsum = 0.f, mx = 0.f;
+    for (int r = wave; r < R; r += nwaves) {
+        float ex = 0.f, ey = 0.f, ez = 0.f, ew = 0.f;
+        for (int i = lane; i < St; i += 64) {
+            const size_t ms = (size_t)r * St + i;
+            const int src = min(max(order[ms], 0), St - 1);
+            float4 d = d_raw_sorted[ms];
+            const uint8_t lab = (weights[ms] * alpha[ms] > 0.f) ? 1 : 0;
+            bool inside;
+            if (src < S) {
+                const size_t q = (size_t)r * S + src;
+                const float4 c = d_raw_c[q];
+                d.x += c.x; d.y += c.y; d.z += c.z; d.w += c.w;
+                d_raw_c[q] = d;
+                label_c[q] = lab;
+                inside = bits_c[q] != 0u;
+            } else {
+                const size_t q = (size_t)r * Sf + (src - S);
+                d_raw_f[q] = d;
+                label_f[q] = lab;
+                inside = bits_f[q] != 0u;
+            }
+            if (!inside) { ex += d.x; ey += d.y; ez += d.z; ew += d.w; lsum += (float)lab; }
+            else mx = fmaxf(mx, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+        }
+        ex = wave_total(ex); ey = wave_total(ey); ez = wave_total(ez); ew = wave_total(ew);
+        if (lane == 0) d_raw_rows[r] = make_float4(ex, ey, ez, ew);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fmaxf(fabsf(ez), fabsf(ew))));
+    }
+    lsum = wave_total(lsum);
+    mx = wave_max(mx);
+    if (lane == 0) {
+        if (lsum != 0.f) atomicAdd(loss + 2, lsum);
+        atomic_max_abs(maxabs, mx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// adjoint of the colour head, per row (32 lanes per row):  d raw (gathered from the dense gradients; rows < R already
+// hold the ray sums) -> d_raw_rows (kept: dy of rgb_linear), dpre_v = (d_rgb rgb_w) * [hv > 0], d_alpha4[row] = (d alpha, 0, 0, 0)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_rgb_head_bwd(const float* __restrict__ hv, const float* __restrict__ rgb_w,
+                                                            const float4* __restrict__ d_raw_c, const float4* __restrict__ d_raw_f,
+                                                            const int32_t* __restrict__ row_sample, const int32_t* __restrict__ cnt, int R,
+                                                            float4* __restrict__ d_raw_rows, float* __restrict__ dpre_v,
+                                                            float4* __restrict__ d_alpha4, float* __restrict__ max_v,
+                                                            float* __restrict__ max_a) {
+    const int rows = cnt[4], first_f = cnt[2];
+    const int sub = threadIdx.x & 31;
+    const long slot = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5, nslots = ((long)gridDim.x * blockDim.x) >> 5;
+    f32x4 w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w[c] = *reinterpret_cast<const f32x4*>(rgb_w + c * 128 + 4 * sub);
+    float mv = 0.f, ma = 0.f;
+    for (long k = slot; k < rows; k += nslots) {
+        const int i = (int)k;
+        float4 d;
+        if (i < R) d = d_raw_rows[i];
+        else d = i < first_f ? d_raw_c[row_sample[i]] : d_raw_f[row_sample[i]];
+        const f32x4 x = *reinterpret_cast<const f32x4*>(hv + (size_t)i * 128 + 4 * sub);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e];
+            o[e] = x[e] > 0.f ? g : 0.f;
+            mv = fmaxf(mv, fabsf(o[e]));
+        }
+        *reinterpret_cast<f32x4*>(dpre_v + (size_t)i * 128 + 4 * sub) = o;
+        if (sub == 0) {
+            if (i >= R) d_raw_rows[i] = d;
+            d_alpha4[i] = make_float4(d.w, 0.f, 0.f, 0.f);
+            ma = fmaxf(ma, fabsf(d.w));
+        }
+    }
+    mv = wave_max(mv);
+    ma = wave_max(ma);
+    if ((threadIdx.x & 63) == 0) { atomic_max_abs(max_v, mv); atomic_max_abs(max_a, ma); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// frame-code gradient: g_codes[cam(ray(row)), :] += d_vin[row, code columns]   (embedding backward).  128-thread workgroups
+// own a chunk of consecutive rows (rows of one image are consecutive: the running sum is flushed when the camera changes)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CODE_CHUNK = 64;
+__global__ __launch_bounds__(128) void k_train_code_grad(const float* __restrict__ d_vfeat, int ldvf, int col0, int Cf,
+                                                         const int32_t* __restrict__ row_ray, const int64_t* __restrict__ cam_idx,
+                                                         const int32_t* __restrict__ cnt, int n_codes, float* __restrict__ g_codes) {
+    const int rows = cnt[4];
+    const int c = threadIdx.x;
+    for (int base = blockIdx.x * CODE_CHUNK; base < rows; base += gridDim.x * CODE_CHUNK) {
+        float acc = 0.f;
+        long cur = -1;
+        const int end = min(base + CODE_CHUNK, rows);
+        for (int i = base; i < end; ++i) {
+            long ci = cam_idx ? cam_idx[row_ray[i]] : 0;
+            ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
+            if (ci != cur) {
+                if (cur >= 0 && c < Cf && acc != 0.f) atomicAdd(g_codes + cur * Cf + c, acc);
+                cur = ci;
+                acc = 0.f;
+            }
+            if (c < Cf) acc += d_vfeat[(size_t)i * ldvf + col0 + c];
+        }
+        if (cur >= 0 && c < Cf && acc != 0.f) atomicAdd(g_codes + cur * Cf + c, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// adjoint of the positional encoding: d h[c] = d pe[c] + sum_l 2^l (cos(2^l h_c) d pe[sin_l c] - sin(2^l h_c) d pe[cos_l c]),
+// d pe = (layer-0 input gradient) + (skip layer's input gradient); in-volume rows only
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_pe_bwd(const float* __restrict__ d_x0, int ld0, const float* __restrict__ d_x5, int ld5,
+                                                      int col5, const float* __restrict__ h_rows, const int32_t* __restrict__ cnt, int R,
+                                                      int L, float* __restrict__ d_h) {
+    const int rows = cnt[5];
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)rows * 16; idx += (long)gridDim.x * blockDim.x) {
+        const int i = R + (int)(idx >> 4), c = (int)(idx & 15);
+        float g = 0.f;
+        if (c < FEAT) {
+            const float* a = d_x0 + (size_t)i * ld0;
+            const float* b = d_x5 + (size_t)i * ld5 + col5;
+            const float x = h_rows[(size_t)i * 16 + c];
+            g = a[c] + b[c];
+            for (int l = 0; l < L; ++l) {
+                const float f = (float)(1 << l);
+                float sn, cs;
+                pe_sincos(mul_rn(x, f), &sn, &cs);
+                const int is = FEAT + 2 * FEAT * l + c, ic = is + FEAT;
+                g += f * (cs * (a[is] + b[is]) - sn * (a[ic] + b[ic]));
+            }
+        }
+        d_h[(size_t)i * 16 + c] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-bone lists of (row) pairs: bone j's list holds every in-volume row whose sample lies inside bone j's volume
+// (wave-aggregated appends: one atomic per wavefront and bone)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_train_bone_lists(const uint32_t* __restrict__ bits_c, const uint32_t* __restrict__ bits_f,
+                                                          const int32_t* __restrict__ row_sample, const int32_t* __restrict__ cnt, int R,
+                                                          int cap, int32_t* __restrict__ lists, int32_t* __restrict__ cntb) {
+    const int rows = cnt[5], first_f = cnt[2];
+    const int lane = threadIdx.x & 63;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long k0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; k0 < rows; k0 += nthreads) {
+        const long k = k0 + lane;
+        const int i = R + (int)k;
+        uint32_t b = 0;
+        if (k < rows) b = i < first_f ? bits_c[row_sample[i]] : bits_f[row_sample[i]];
+        uint32_t any = wave_or(b);
+        while (any) {
+            const int j = __builtin_ctz(any);
+            any &= any - 1;
+            const bool mine = (b >> j) & 1u;
+            const unsigned long long bal = __ballot(mine);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(cntb + j, (int)__popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (mine) lists[(size_t)j * cap + base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Adam on the flat parameter buffer, exactly the update torch.optim.Adam (amsgrad = False, weight_decay = 0) performs:
+//   m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// hyper (device): [lr, bc1 = 1 - b1^t, sqrt(bc2) = sqrt(1 - b2^t), grad_scale]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long n, const float* __restrict__ hyper, float b1, float b2,
+                                              float eps) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
+    const float step = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);      // torch lerp_: start + weight * (end - start) for weight < 0.5
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+}
+
+}  // namespace danbo
+
+using namespace danbo;
+
+extern "C" int danbo_train_view_inputs(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise, int L_view,
+                                       const float* codes, int n_codes, int Cf, const int64_t* cam_idx, float* vin, int ldv,
+                                       void* stream) {
+    DANBO_CHECK_ARG(rays_d && vin && R > 0 && G > 0 && R % G == 0 && L_view >= 0 && ldv % 4 == 0);
+    DANBO_CHECK_ARG(ldv >= 3 * (1 + 2 * L_view) + (codes ? Cf : 0) && (ray_mode == 0 || skts));
+    hipLaunchKernelGGL(k_train_view_inputs, dim3(stream_grid((long)R * ldv, 256)), dim3(256), 0, (hipStream_t)stream, rays_d, skts, R, G,
+                       ray_mode, normalise, L_view, codes, n_codes, Cf, cam_idx, vin, ldv);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_rows_fwd(const float* h_rows, const int32_t* row_sample, int32_t* cnt, int pass, int R, int S_pass,
+                                    int rows_cap, int L_voxel, const float* vin, int ldv, float* pe, int ldp, float* vinr,
+                                    int32_t* row_ray, void* stream) {
+    DANBO_CHECK_ARG(h_rows && row_sample && cnt && vin && pe && vinr && row_ray && (pass == 0 || pass == 1) && R > 0 && S_pass > 0);
+    DANBO_CHECK_ARG(ldv % 4 == 0 && ldp % 4 == 0 && ldp >= FEAT * (1 + 2 * L_voxel) && rows_cap > 0);
+    hipLaunchKernelGGL(k_train_rows_fwd, dim3(stream_grid((long)rows_cap * ((ldp + ldv) / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       h_rows, row_sample, cnt, pass, R, S_pass, L_voxel, vin, ldv, pe, ldp, vinr, row_ray);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_rgb_head_fwd(const float* hv, const float* fa, int ldfa, const float* rgb_w, const float* rgb_b,
+                                        const int32_t* row_sample, const int32_t* cnt, int pass, int R, int rows_cap, float* raw_rows,
+                                        float* raw_dense, float* raw_empty, void* stream) {
+    DANBO_CHECK_ARG(hv && fa && rgb_w && rgb_b && row_sample && cnt && raw_rows && raw_dense && raw_empty && ldfa > 256);
+    hipLaunchKernelGGL(k_train_rgb_head_fwd, dim3(stream_grid((long)rows_cap * 32, 256)), dim3(256), 0, (hipStream_t)stream, hv, fa, ldfa,
+                       rgb_w, rgb_b, row_sample, cnt, pass, R, raw_rows, raw_dense, raw_empty);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_loss_grad(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
+                                     const float* bgs, int use_bg, int R, int mse, float w_fine, float w_coarse, float* g_rgb,
+                                     float* g_acc, float* g_rgb0, float* g_acc0, float* loss, void* stream) {
+    DANBO_CHECK_ARG(rgb && acc && rgb0 && acc0 && target && g_rgb && g_acc && g_rgb0 && g_acc0 && loss && R > 0);
+    hipLaunchKernelGGL(k_train_loss_grad, dim3(stream_grid(R, 256)), dim3(256), 0, (hipStream_t)stream, rgb, acc, rgb0, acc0, target, bgs,
+                       use_bg, R, mse, w_fine, w_coarse, g_rgb, g_acc, g_rgb0, g_acc0, loss);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorted, const int32_t* order, const uint32_t* bits_c,
+                                        const uint32_t* bits_f, const float* weights, const float* alpha, int R, int S, int Sf,
+                                        float* d_raw_f, float* d_raw_rows, uint8_t* label_c, uint8_t* label_f, float* loss,
+                                        float* maxabs, void* stream) {
+    DANBO_CHECK_ARG(d_raw_c && d_raw_sorted && order && bits_c && bits_f && weights && alpha && d_raw_f && d_raw_rows && label_c && label_f);
+    DANBO_CHECK_ARG(loss && maxabs && R > 0 && S > 0 && Sf > 0);
+    hipLaunchKernelGGL(k_train_draw_unmerge, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_sorted), order, bits_c, bits_f, weights,
+                       alpha, R, S, Sf, reinterpret_cast<float4*>(d_raw_f), reinterpret_cast<float4*>(d_raw_rows), label_c, label_f, loss,
+                       maxabs);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_rgb_head_bwd(const float* hv, const float* rgb_w, const float* d_raw_c, const float* d_raw_f,
+                                        const int32_t* row_sample, const int32_t* cnt, int R, int rows_cap, float* d_raw_rows,
+                                        float* dpre_v, float* d_alpha4, float* max_v, float* max_a, void* stream) {
+    DANBO_CHECK_ARG(hv && rgb_w && d_raw_c && d_raw_f && row_sample && cnt && d_raw_rows && dpre_v && d_alpha4 && max_v && max_a);
+    hipLaunchKernelGGL(k_train_rgb_head_bwd, dim3(stream_grid((long)rows_cap * 32, 256)), dim3(256), 0, (hipStream_t)stream, hv, rgb_w,
+                       reinterpret_cast<const float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_f), row_sample, cnt, R,
+                       reinterpret_cast<float4*>(d_raw_rows), dpre_v, reinterpret_cast<float4*>(d_alpha4), max_v, max_a);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_code_grad(const float* d_vfeat, int ldvf, int col0, int Cf, const int32_t* row_ray, const int64_t* cam_idx,
+                                     const int32_t* cnt, int rows_cap, int n_codes, float* g_codes, void* stream) {
+    DANBO_CHECK_ARG(d_vfeat && row_ray && cnt && g_codes && Cf >= 1 && Cf <= 128 && n_codes >= 1 && col0 >= 0 && ldvf >= col0 + Cf);
+    const int chunks = (rows_cap + CODE_CHUNK - 1) / CODE_CHUNK;
+    hipLaunchKernelGGL(k_train_code_grad, dim3(chunks < NUM_CU * 8 ? chunks : NUM_CU * 8), dim3(128), 0, (hipStream_t)stream, d_vfeat, ldvf,
+                       col0, Cf, row_ray, cam_idx, cnt, n_codes, g_codes);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_pe_bwd(const float* d_x0, int ld0, const float* d_x5, int ld5, int col5, const float* h_rows,
+                                  const int32_t* cnt, int R, int rows_cap, int L_voxel, float* d_h, void* stream) {
+    DANBO_CHECK_ARG(d_x0 && d_x5 && h_rows && cnt && d_h && R > 0 && L_voxel >= 0);
+    hipLaunchKernelGGL(k_train_pe_bwd, dim3(stream_grid((long)rows_cap * 16, 256)), dim3(256), 0, (hipStream_t)stream, d_x0, ld0, d_x5, ld5,
+                       col5, h_rows, cnt, R, L_voxel, d_h);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_bone_lists(const uint32_t* bits_c, const uint32_t* bits_f, const int32_t* row_sample, const int32_t* cnt,
+                                      int R, int rows_cap, int32_t* lists, int32_t* cntb, void* stream) {
+    DANBO_CHECK_ARG(bits_c && bits_f && row_sample && cnt && lists && cntb && R > 0 && rows_cap > 0);
+    hipLaunchKernelGGL(k_train_bone_lists, dim3(stream_grid(rows_cap, 256)), dim3(256), 0, (hipStream_t)stream, bits_c, bits_f, row_sample,
+                       cnt, R, rows_cap, lists, cntb);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const float* hyper,
+                               float beta1, float beta2, float eps, void* stream) {
+    DANBO_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && hyper && n > 0);
+    hipLaunchKernelGGL(k_adam, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, hyper,
+                       beta1, beta2, eps);
+    DANBO_LAUNCH_RET();
+}

@@ -219,6 +219,11 @@ int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, i
  * weights and alpha carry no gradient in the reference's losses (core/trainer.py:396-422,507-536). */
 int danbo_composite_bwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
                         const float* noise, const float* g_rgb, const float* g_acc, float* d_raw, void* stream);
+/* the same on a lazily filled raw tensor (danbo_composite_importance_fwd's convention): samples whose in-volume word is 0
+ * take raw_empty[ray] */
+int danbo_composite_bwd_lazy(const float* raw, const float* raw_empty /*[R,4]*/, const uint32_t* valid_bits /*[R,S] or NULL*/,
+                             const float* z, const float* rays_d, int R, int S, float B, const float* noise,
+                             const float* g_rgb, const float* g_acc, float* d_raw, void* stream);
 
 /* K1b backward: d part_feat [n,24,15] -> d volumes [G,24,240] and d axis_scale [24,3] (both ACCUMULATED
  * with atomics: the caller zeroes them).  Same autograd semantics as the reference: the window is
@@ -303,6 +308,185 @@ int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int
  * 1 = ReLU; rows = min(*count, M) if count != NULL (device-side row count of a compacted list) */
 int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
                        const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Training step (SURVEY 8b "+ _bwd"; reference core/trainer.py:257-302,563-576 = forward, loss, loss.backward(), Adam).
+ * The dense layers of the density / colour MLP run layer by layer on the compacted in-volume rows:
+ *   forward   y_l   = relu(x_l W_l^T + b_l)                       danbo_linear16_ex (activations kept for the backward)
+ *   backward  dz_l-1 = (dz_l W_l) * [y_l-1 > 0]                    danbo_linear16_ex on the transposed packing, mask epilogue
+ *             dW_l  = dz_l^T x_l,  db_l = sum_rows dz_l            danbo_dw16 (all layers in one launch, split over row slices)
+ * all with fp32-accurate products on the fp16 matrix cores (hi/lo split).  Gradients are ~1e-6: every backward
+ * GEMM pre-scales its gradient operand by a power of two taken from the running max |.| the producing kernel recorded
+ * (in_maxabs / out_maxabs) and scales the result back -- exact, and it keeps the lo halves out of fp16's subnormals.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct DanboLinearEx {
+    const int32_t* first;     /* device scalar: first row (x1, x2, y, mask are shifted by it), or NULL = 0 */
+    const void* relu_in;      /* [M, 4] x 64 bits recorded by the forward layer (relu_out): y[row, c] = 0 where the recorded
+                                 activation was <= 0, for c < mask_cols (<= 256, multiple of 4); or NULL */
+    void* relu_out;           /* [M, 4] x 64 bits: receives [y > 0] of columns < 256 (bit 4 T + i of word pair q <-> column
+                                 16 T + 4 q + i); or NULL */
+    int mask_cols;
+    const float* in_maxabs;   /* device scalar: max |x| over the inputs (power-of-two pre-scale), or NULL */
+    float* out_maxabs;        /* device scalar, atomically raised to max |y| (caller zeroes it), or NULL */
+    const float* wscale_inv;  /* device scalar written by danbo_linear16_pack_group for this matrix, or NULL (unscaled packing) */
+} DanboLinearEx;
+int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
+                      const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count,
+                      const DanboLinearEx* ex, void* stream);
+
+/* One matrix of a grouped packing: W[n, k] (n < N output features, k < K1 + K2 inputs) is read as
+ *   nn = (n + n_shift) mod N;  nn >= split_n ? w2[(nn - split_n) sn2 + k sk2] : k >= split_k ? w2[nn sn2 + (k - split_k) sk2]
+ *                                                                             : w[nn sn + k sk]
+ * (two source tensors: feature_linear + alpha_linear evaluated as one 257-wide layer, and its transpose; n_shift: the
+ * adjoint of the skip layer writes [d h | d input] instead of [d input | d h] so that both halves start 16-byte aligned).
+ * Unused splits: INT32_MAX. */
+typedef struct DanboPackDesc {
+    const float *w, *w2;
+    long sn, sk, sn2, sk2;
+    int N, K1, K2, n_shift, split_n, split_k;
+} DanboPackDesc;
+long danbo_linear16_group_bytes(const DanboPackDesc* descs, int n);
+/* packs n <= 28 matrices back to back into `packed` (offsets[i] = byte offset of matrix i, host array or NULL), each
+ * multiplied by the power of two that puts its largest |w| into [2^13, 2^14); wscale_inv[i] (device) receives the inverse;
+ * wmax [n] is device scratch.  Two launches. */
+int danbo_linear16_pack_group(const DanboPackDesc* descs, int n, void* packed, long* offsets, float* wmax,
+                              float* wscale_inv, void* stream);
+
+/* dW / db of up to 12 dense layers in one launch pair (csrc/k_dw16.hip).  dy [rows, ldy]: gradient with respect to the layer's
+ * pre-activation; x1 | x2: the layer's input(s); gw [N, K1 + K2] and gb [N] in nn.Linear layout are OVERWRITTEN.  A layer
+ * evaluated for two parameters at once (feature_linear + alpha_linear) writes rows >= split_n to gw2 / gb2.  16-byte aligned
+ * bases, row strides multiples of 4 floats, x1 readable up to a multiple of 4 columns.  rows = min(*count, M). */
+typedef struct DanboDwLayer {
+    const float *dy, *x1, *x2, *dy_maxabs /* device scalar max |dy| recorded by the producer, or NULL */;
+    float *gw, *gw2, *gb, *gb2;
+    int ldy, ld1, ld2, N, K1, K2, split_n;
+} DanboDwLayer;
+long danbo_dw16_scratch_floats(const DanboDwLayer* layers, int n_layers, int slices);
+int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const int32_t* count, int slices, float* scratch, void* stream);
+
+/* ---- building blocks of the training step (csrc/k_train_rows.hip, k_assign_bwd.hip, k_pose_bwd.hip); danbo_train_step
+ * below enqueues all of them.  Row layout and the device counters cnt[] are described at the top of k_train_rows.hip. ---- */
+
+/* K1b + K2 forward for the training step: as danbo_gather_assign_blend16_fwd on rows [*first, *count) of list / h, and
+ * h[row][15] = q = sum_j p_j valid_j instead of the zero pad (the row's assignment mass of the soft-softmax loss) */
+int danbo_gather_assign_blend16_train(const float* rays_o, const float* rays_d, const float* z, int R, int S, int G,
+                                      const float* skts, const float* align, const float* axis_scale, const float* volumes,
+                                      const uint32_t* valid_bits, const int32_t* list, const int32_t* count, const int32_t* first,
+                                      int n, const void* packed16, const float* b0, const float* b1, const float* w2,
+                                      const float* b2, float* h, void* stream);
+/* per-ray view inputs [PE(dir) | frame code | 0] (nerf.py:252-279); ray_mode / normalise as danbo_view_consts */
+int danbo_train_view_inputs(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise, int L_view,
+                            const float* codes, int n_codes, int Cf, const int64_t* cam_idx, float* vin, int ldv, void* stream);
+/* rows of one pass (0 coarse incl. the R empty rows, 1 importance): pe = PE_L(h) (cutoff_embedder.py:62-73), vinr = the ray's view inputs */
+int danbo_train_rows_fwd(const float* h_rows, const int32_t* row_sample, int32_t* cnt, int pass, int R, int S_pass, int rows_cap,
+                         int L_voxel, const float* vin, int ldv, float* pe, int ldp, float* vinr, int32_t* row_ray, void* stream);
+/* rgb_linear + assembly of raw = (rgb, alpha), scattered to the pass' dense raw / the rays' empty-space raw (nerf.py:200-209) */
+int danbo_train_rgb_head_fwd(const float* hv, const float* fa, int ldfa, const float* rgb_w, const float* rgb_b,
+                             const int32_t* row_sample, const int32_t* cnt, int pass, int R, int rows_cap, float* raw_rows,
+                             float* raw_dense, float* raw_empty, void* stream);
+/* d loss / d (rgb_map, acc_map) of both passes for L1 (mse = 0) or MSE on rgb + (1 - acc) bg (trainer.py:396-422);
+ * loss[0] += fine term, loss[1] += coarse term */
+int danbo_train_loss_grad(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
+                          const float* bgs /*[R,3] or NULL (1)*/, int use_bg, int R, int mse, float w_fine, float w_coarse,
+                          float* g_rgb, float* g_acc, float* g_rgb0, float* g_acc0, float* loss, void* stream);
+/* un-merge d raw of the final composite onto the two passes' samples (+ the coarse composite's own gradient), ray sums of the
+ * samples outside every volume -> d_raw_rows[ray], soft-softmax labels (trainer.py:507-536), loss[2] += labels outside */
+int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorted, const int32_t* order, const uint32_t* bits_c,
+                             const uint32_t* bits_f, const float* weights, const float* alpha, int R, int S, int Sf,
+                             float* d_raw_f, float* d_raw_rows, uint8_t* label_c, uint8_t* label_f, float* loss, float* maxabs,
+                             void* stream);
+int danbo_train_rgb_head_bwd(const float* hv, const float* rgb_w, const float* d_raw_c, const float* d_raw_f,
+                             const int32_t* row_sample, const int32_t* cnt, int R, int rows_cap, float* d_raw_rows, float* dpre_v,
+                             float* d_alpha4, float* max_v, float* max_a, void* stream);
+/* framecodes.codes.weight.grad[cam] += d vin[row, code columns] (embedding backward, core/networks/embedding.py:17-39) */
+int danbo_train_code_grad(const float* d_vfeat, int ldvf, int col0, int Cf, const int32_t* row_ray, const int64_t* cam_idx,
+                          const int32_t* cnt, int rows_cap, int n_codes, float* g_codes, void* stream);
+int danbo_train_pe_bwd(const float* d_x0, int ld0, const float* d_x5, int ld5, int col5, const float* h_rows, const int32_t* cnt,
+                       int R, int rows_cap, int L_voxel, float* d_h, void* stream);
+int danbo_train_bone_lists(const uint32_t* bits_c, const uint32_t* bits_f, const int32_t* row_sample, const int32_t* cnt, int R,
+                           int rows_cap, int32_t* lists /*[24, rows_cap]*/, int32_t* cntb /*[24], zeroed by the caller*/, void* stream);
+
+/* backward of K1b + K2 with the forward recomputed from the pose volumes (csrc/k_assign_bwd.hip) */
+typedef struct DanboAssignBwd {
+    const float *rays_o, *rays_d, *z_c /*[R,S]*/, *z_f /*[R,Sf]*/, *skts, *align, *axis_scale, *volumes;
+    int R, S, Sf, G, rows_cap;
+    const int32_t *row_sample, *row_ray, *cnt, *lists, *cntb;
+    const float *h_rows /*[rows,16], [15] = q*/, *d_h /*[rows,16]*/;
+    const uint8_t *label_c, *label_f;
+    const uint32_t *bits_c, *bits_f;
+    const float *w0, *adj_w, *adj, *b0, *w1, *b1, *w2, *b2;          /* prob_linears.* in the reference's layouts */
+    float *g_w0, *g_adj_w, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2;       /* accumulated: the caller zeroes them */
+    float *g_vol /*[G,24,240]*/, *g_scale /*[24,3]*/;
+    float c_ss;        /* 2 soft_softmax_loss_coef / (R (S + Sf)) */
+    float* loss;       /* loss[2] += (label - q)^2 of the in-volume rows */
+} DanboAssignBwd;
+int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream);
+
+/* backward of danbo_pose_volumes_fwd (csrc/k_pose_bwd.hip).  adj_w / adj: the raw parameter and the 0/1 buffer [24,24];
+ * fwd_scratch: what the forward left in its scratch; g_w*, g_b2, g_b3 are overwritten, g_adj_w*, g_b0, g_b1 accumulated. */
+int danbo_pose_volumes_bwd(const float* bones, int G, int L_graph, int W, const float* w0, const float* adj_w0, const float* adj0,
+                           const float* b0, const float* w1, const float* adj_w1, const float* adj1, const float* b1,
+                           const float* w2, const float* w3, const float* fwd_scratch, const float* d_volumes, float* g_w0,
+                           float* g_adj_w0, float* g_b0, float* g_w1, float* g_adj_w1, float* g_b1, float* g_w2, float* g_b2,
+                           float* g_w3, float* g_b3, float* bwd_scratch /*>= 2 G 24 W floats*/, void* stream);
+
+/* torch.optim.Adam's update (amsgrad = False, weight_decay = 0; core/raycasters.py:75) on a flat parameter buffer.
+ * hyper (device, 4 floats): lr, 1 - beta1^t, sqrt(1 - beta2^t), gradient scale (1 / world size) */
+int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const float* hyper,
+                    float beta1, float beta2, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One training batch behind one call: forward, losses, backward (csrc/k_train.hip) -- what Trainer.train_batch
+ * (core/trainer.py:257-302) does between dict_to_device and optimizer.step(), for the shipped DANBO structure
+ * (FGNNcat + vox_MIXGNN + sigmoid, D = 8, W = 256, skip after layer 4, view_W = 128, single_net).
+ * Parameters and gradients are handed over as pointers into two flat fp32 buffers (g_flat is zeroed by the call).
+ * ------------------------------------------------------------------------------------------- */
+enum DanboTrainTensor {
+    DANBO_T_G_W0 = 0, DANBO_T_G_ADJW0, DANBO_T_G_B0, DANBO_T_G_W1, DANBO_T_G_ADJW1, DANBO_T_G_B1, DANBO_T_G_W2, DANBO_T_G_B2,
+    DANBO_T_G_W3, DANBO_T_G_B3, DANBO_T_AXIS_SCALE,                       /* graph_net.layers.{0..3}.*, graph_net.axis_scale */
+    DANBO_T_A_W0, DANBO_T_A_ADJW, DANBO_T_A_B0, DANBO_T_A_W1, DANBO_T_A_B1, DANBO_T_A_W2, DANBO_T_A_B2,   /* prob_linears.layers.* */
+    DANBO_T_PTS_W0, DANBO_T_PTS_B0 = DANBO_T_PTS_W0 + 8,                  /* pts_linears.{0..7}.{weight, bias} */
+    DANBO_T_ALPHA_W = DANBO_T_PTS_B0 + 8, DANBO_T_ALPHA_B, DANBO_T_FEAT_W, DANBO_T_FEAT_B, DANBO_T_VIEWS_W, DANBO_T_VIEWS_B,
+    DANBO_T_RGB_W, DANBO_T_RGB_B, DANBO_T_CODES,                          /* framecodes.codes.weight (unused when n_codes = 0) */
+    DANBO_T_COUNT
+};
+
+typedef struct DanboTrainModel {
+    const float* p[DANBO_T_COUNT];     /* parameters, the reference's layouts */
+    float* g[DANBO_T_COUNT];           /* their gradients (inside g_flat); alpha_linear.bias must follow feature_linear.bias */
+    float* g_flat;                     /* the flat gradient buffer, zeroed at the start of the step */
+    long n_flat;
+    const float *g_adj0, *g_adj1, *a_adj;   /* the 0/1 adjacency buffers [24,24] of the three graph-conv layers */
+    const float *align /*[24,4,4]*/, *init_scale /*[24,3]: graph_net.init_scale*/;
+    int L_graph, graph_width, L_view, L_voxel, ray_mode, normalise, n_codes, code_size;
+    int view_ch;                       /* 3 (1 + 2 L_view) + code_size: per-sample view inputs of views_linears.0 */
+    int use_volume_near_far, loss_mse /*0: L1*/, use_background;
+    float density_scale, rgb_loss_coef, coarse_weight, soft_softmax_coef, vol_scale_penalty /*0 unless opt_vol_scale*/;
+} DanboTrainModel;
+
+typedef struct DanboTrainBatch {
+    const float *rays_o, *rays_d /*[R,3]*/, *skts /*[G,24,4,4]*/, *bones /*[G,24,3]*/, *cyls /*[G,5]*/;
+    const float *near_in, *far_in /*[R] placeholders or NULL (0 / 1)*/;
+    const int64_t* cam_idx /*[R]*/;
+    const float *target /*[R,3]*/, *bgs /*[R,3] or NULL (white)*/;
+    /* the step's random draws (NULL = the deterministic eval choice): stratified offsets [R,S], inverse-CDF uniforms [R,Sf],
+     * density noise of the two composites [R,S] / [R,S+Sf], already multiplied by raw_noise_std * B (nerf.py:316) */
+    const float *t_rand, *u_rand, *noise_c, *noise_f;
+    int R, G, S, Sf, chunk;
+} DanboTrainBatch;
+
+typedef struct DanboTrainOut {
+    float *rgb_map /*[R,3]*/, *disp_map, *acc_map /*[R]*/, *alpha, *weights /*[R,S+Sf]*/, *rgb0, *disp0, *acc0, *alpha0 /*[R,S]*/;
+    float* loss;      /* [4]: rgb loss, coarse rgb loss, sum over ALL samples of (label - q)^2 (x coef / (R (S+Sf)) = soft-softmax
+                         loss), volume-scale loss */
+    int32_t* counts;  /* [8] or NULL: row counters of the step ([1] coarse in-volume samples, [3] importance ones) */
+} DanboTrainOut;
+
+size_t danbo_train_workspace(const DanboTrainModel* model, int R, int G, int S, int Sf, int chunk);
+/* S >= 3, S + Sf <= 256.  Enqueues ~75 kernels on `stream`; nothing synchronises, every data-dependent size stays on the device. */
+int danbo_train_step(const DanboTrainModel* model, const DanboTrainBatch* batch, const DanboTrainOut* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The whole eval chain of one ray batch behind one call: RayCaster.render_rays (core/raycasters.py:245-377) with the DANBO

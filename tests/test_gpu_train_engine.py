@@ -1,0 +1,260 @@
+"""GPU tests of the hand-written training step (csrc/k_train.hip and its building blocks):
+  * the dense-layer kernels of the step against torch (forward with recorded ReLU bits, input gradients through the transposed
+    packing with the ReLU adjoint and power-of-two pre-scales at gradient magnitudes ~1e-7, grouped weight / bias gradients),
+  * the whole step -- losses and the gradient of EVERY parameter -- against the reference's own autograd on both training
+    fixtures (danbo_train: D-H36M; danbo_perfcap_train: BASELINE config 4's network),
+  * the fused step against this package's autograd path on the same batch, Adam against torch.optim.Adam, HIP-graph replay.
+All through the C ABI (ctypes)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+from test_gpu_training import batch_of, build_trainer, T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_group(descs):
+    from core import _hip
+    arr = (_hip.DanboPackDesc * len(descs))(*descs)
+    nbytes = _hip.lib().danbo_linear16_group_bytes(arr, len(descs))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    offs = (ctypes.c_long * len(descs))()
+    wmax = torch.empty(len(descs), device=DEV)
+    winv = torch.empty(len(descs), device=DEV)
+    _hip.check(_hip.lib().danbo_linear16_pack_group(arr, len(descs), P(packed), offs, P(wmax), P(winv), stream()), "pack_group")
+    return packed, list(offs), winv
+
+
+def desc(w, N, K1, K2=0, transposed=False, n_shift=0):
+    from core import _hip
+    NONE = 2 ** 31 - 1
+    ldw = w.shape[1]
+    sn, sk = (1, ldw) if transposed else (ldw, 1)
+    return _hip.DanboPackDesc(w=P(w), w2=None, sn=sn, sk=sk, sn2=0, sk2=0, N=N, K1=K1, K2=K2, n_shift=n_shift, split_n=NONE, split_k=NONE)
+
+
+def linear_ex(x1, K1, packed, off, N, bias=None, act=0, x2=None, K2=0, count=None, **ex):
+    from core import _hip
+    M = x1.shape[0]
+    ldy = (N + 3) // 4 * 4
+    y = torch.zeros(M, ldy, device=DEV)
+    e = _hip.DanboLinearEx(**{k: P(v) if torch.is_tensor(v) else v for k, v in ex.items()})
+    _hip.check(_hip.lib().danbo_linear16_ex(P(x1), x1.stride(0), K1, P(x2), 0 if x2 is None else x2.stride(0), K2,
+                                            ctypes.c_void_p(packed.data_ptr() + off), P(bias), N, act, P(y), ldy, M, P(count),
+                                            ctypes.byref(e), stream()), "linear16_ex")
+    return y[:, :N]
+
+
+def test_dense_layer_forward_backward_and_weight_gradients_match_torch():
+    from core import _hip
+    g = torch.Generator(device="cpu").manual_seed(0)
+    M, first, live = 1000, 37, 700
+    W5 = (torch.randn(256, 451, generator=g) * 0.05).to(DEV)       # the skip layer: inputs [pe 195 | y 256]
+    b5 = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    pe = torch.zeros(M, 196, device=DEV)
+    pe[:, :195] = torch.randn(M, 195, generator=g).to(DEV)
+    y4 = torch.relu(torch.randn(M, 256, generator=g)).to(DEV)
+    packed, offs, winv = pack_group([desc(W5, 256, 195, 256), desc(W5, 451, 256, transposed=True, n_shift=195)])
+    cnt = torch.tensor([first, live], dtype=torch.int32, device=DEV)
+    bits = torch.zeros(M, 4, 2, dtype=torch.int32, device=DEV)
+    y = linear_ex(pe, 195, packed, offs[0], 256, bias=b5, act=1, x2=y4, K2=256, count=cnt[1:], first=cnt[:1], relu_out=bits,
+                  wscale_inv=winv[:1])
+    ref = torch.relu(torch.cat([pe[:, :195], y4], 1).double() @ W5.double().t() + b5.double()).float()
+    sl = slice(first, first + live)
+    assert float((y[sl] - ref[sl]).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float(y[:first].abs().max()) == 0.0 and float(y[first + live:].abs().max()) == 0.0     # rows outside [first, first + count)
+    # recorded ReLU bits: bit 4 T + i of word pair q <-> column 16 T + 4 q + i
+    words = bits.cpu().numpy().astype(np.uint32)
+    cols = np.arange(256)
+    Tt, qq, ii = cols // 16, (cols % 16) // 4, cols % 4
+    rec = (words[:, qq, Tt // 8] >> (4 * (Tt % 8) + ii)) & 1
+    assert np.array_equal(rec[sl].astype(bool), (y[sl] > 0).cpu().numpy())
+    # ---- input gradient at gradient magnitudes (~1e-7): dX = (dz W5) reordered [d y4 | d pe], ReLU adjoint on the first 256 columns
+    dz = (torch.randn(M, 256, generator=g) * 1e-7).to(DEV)
+    mx_in = dz[sl].abs().max().reshape(1).clone()
+    mx_out = torch.zeros(1, device=DEV)
+    y4_bits = torch.zeros(M, 4, 2, dtype=torch.int32, device=DEV)      # bits of y4 itself (as layer 4's forward would record them)
+    y4w = (y4 > 0).cpu().numpy()
+    w = np.zeros((M, 4, 2), np.uint32)
+    for c in range(256):
+        w[:, (c % 16) // 4, (c // 16) // 8] |= (y4w[:, c].astype(np.uint32) << np.uint32(4 * ((c // 16) % 8) + c % 4))
+    y4_bits.copy_(torch.from_numpy(w.view(np.int32)))
+    dx = linear_ex(dz, 256, packed, offs[1], 451, count=cnt[1:], first=cnt[:1], relu_in=y4_bits, mask_cols=256, in_maxabs=mx_in,
+                   out_maxabs=mx_out, wscale_inv=winv[1:])
+    full = dz.double() @ W5.double()
+    ref_dx = torch.cat([full[:, 195:] * (y4 > 0), full[:, :195]], 1).float()
+    scale = float(ref_dx[sl].abs().max())
+    assert float((dx[sl] - ref_dx[sl]).abs().max()) <= 2e-5 * scale, (float((dx[sl] - ref_dx[sl]).abs().max()), scale)
+    assert abs(float(mx_out) - float(dx[sl].abs().max())) <= 1e-12
+    # ---- weight / bias gradients: dW [256, 451] = dz^T [pe | y4], plus a 3-wide and a 1-wide layer in the same launch
+    d3 = torch.zeros(M, 4, device=DEV)
+    d3[:, :3] = (torch.randn(M, 3, generator=g) * 1e-6).to(DEV)
+    hv = torch.relu(torch.randn(M, 128, generator=g)).to(DEV)
+    d1 = torch.zeros(M, 4, device=DEV)
+    d1[:, 0] = (torch.randn(M, generator=g) * 1e-6).to(DEV)
+    gw5, gb5 = torch.full((256, 451), 7., device=DEV), torch.full((256,), 7., device=DEV)
+    gw3, gb3 = torch.full((3, 128), 7., device=DEV), torch.full((3,), 7., device=DEV)
+    gw1, gb1 = torch.full((1, 256), 7., device=DEV), torch.full((1,), 7., device=DEV)
+    mx3 = d3.abs().max().reshape(1).clone()
+    # the grouped kernel has no first-row argument: hand it the live rows directly
+    L = (_hip.DanboDwLayer * 3)(
+        _hip.DanboDwLayer(dy=P(dz[sl]), x1=P(pe[sl]), x2=P(y4[sl]), dy_maxabs=P(mx_in), gw=P(gw5), gb=P(gb5), ldy=256, ld1=196, ld2=256,
+                          N=256, K1=195, K2=256),
+        _hip.DanboDwLayer(dy=P(d3[sl]), x1=P(hv[sl]), dy_maxabs=P(mx3), gw=P(gw3), gb=P(gb3), ldy=4, ld1=128, N=3, K1=128),
+        _hip.DanboDwLayer(dy=P(d1[sl]), x1=P(y4[sl]), dy_maxabs=P(mx3), gw=P(gw1), gb=P(gb1), ldy=4, ld1=256, N=1, K1=256))
+    slices = 5
+    scratch = torch.empty(_hip.lib().danbo_dw16_scratch_floats(L, 3, slices), device=DEV)
+    n_live = torch.tensor([live - 13], dtype=torch.int32, device=DEV)       # device-side row count below the capacity
+    _hip.check(_hip.lib().danbo_dw16(L, 3, live, P(n_live), slices, P(scratch), stream()), "dw16")
+    rows = slice(first, first + live - 13)
+    for gw, gb, dy, x in ((gw5, gb5, dz[rows], torch.cat([pe[rows, :195], y4[rows]], 1)), (gw3, gb3, d3[rows, :3], hv[rows]),
+                          (gw1, gb1, d1[rows, :1], y4[rows])):
+        ref_w = (dy.double().t() @ x.double()).float()
+        ref_b = dy.double().sum(0).float()
+        assert float((gw - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max()), (tuple(gw.shape), float((gw - ref_w).abs().max()), float(ref_w.abs().max()))
+        assert float((gb - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()) + 1e-12
+
+
+def fused_step(fixture, graph=False):
+    g = golden(fixture)
+    args, caster, trainer, opt = build_trainer(g)
+    eng = trainer.fused_engine()
+    assert eng is not None, trainer.fused_reason
+    eng.use_graph = graph
+    b = batch_of(g)
+    G = b["N_uniques"]
+    pp = caster._per_pose
+    out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G), b["cam_idxs"],
+                               b["target_s"], b["bgs"], int(g["N_samples"]), int(g["N_importance"]))
+    torch.cuda.synchronize()
+    return g, args, caster, trainer, eng, out
+
+
+@pytest.mark.parametrize("fixture", ["danbo_train", "danbo_perfcap_train"])
+def test_fused_step_matches_reference_autograd(fixture):
+    g, args, caster, trainer, eng, out = fused_step(fixture)
+    R, St = out["rgb_map"].shape[0], out["alpha"].shape[1]
+    assert np.abs(out["rgb_map"].cpu().numpy() - g["rgb_map"]).max() < 5e-4
+    assert np.abs(out["rgb0"].cpu().numpy() - g["rgb0"]).max() < 5e-5
+    ls = out["loss"].cpu().numpy().astype(np.float64)
+    ours = {"rgb_loss": ls[0], "rgb_loss0": ls[1], "soft_softmax_loss": ls[2] * args.soft_softmax_loss_coef / (R * St),
+            "vol_scale_loss": ls[3]}
+    ours["total_loss"] = sum(ours.values())
+    for k, v in ours.items():
+        ref = float(g["loss/" + k])
+        assert abs(v - ref) <= 2e-4 * max(abs(ref), 1e-3), (k, v, ref)
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in caster.network.named_parameters()}
+    worst = 0.0
+    for key in g.files:
+        if key.startswith("gnorm/"):
+            n = key[len("gnorm/"):]
+            o, ref = float(np.sqrt((grads[n].astype(np.float64) ** 2).sum())), float(g[key])
+            worst = max(worst, abs(o - ref) / (ref + 1e-12))
+            assert abs(o - ref) <= 5e-3 * ref + 1e-9, (n, o, ref)
+    for key in g.files:
+        if not key.startswith("grad/"):
+            continue
+        n = key[len("grad/"):]
+        if "[" in n:
+            base, sl = n.split("[", 1)
+            o = eval("grads[base][" + sl)
+        else:
+            o = grads[n]
+        ref = g[key]
+        scale = np.abs(ref).max() + 1e-12
+        assert np.abs(o - ref).max() <= 5e-3 * scale, (n, np.abs(o - ref).max(), scale)
+    print(f"{fixture}: worst gradient-norm deviation {worst:.2e}")
+
+
+def test_fused_step_equals_autograd_path_on_every_parameter():
+    """same batch through core/train_path.py (torch autograd + rocBLAS) and through danbo_train_step"""
+    g = golden("danbo_perfcap_train")
+    args, caster, trainer, opt = build_trainer(g)
+    caster.train()
+    b = batch_of(g)
+    kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs")}
+    preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                   N_uniques=b["N_uniques"], **kw)
+    loss = trainer.compute_loss(b, preds)
+    caster.zero_grad()
+    loss["total_loss"].backward()
+    ref = {n: p.grad.detach().clone() for n, p in caster.network.named_parameters()}
+    _, _, caster2, _, eng, out = fused_step("danbo_perfcap_train")
+    for n, p in caster2.network.named_parameters():
+        a, r = p.grad, ref[n]
+        assert float((a - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-10, (n, float((a - r).abs().max()), float(r.abs().max()))
+    assert float((out["rgb_map"] - preds["rgb_map"]).abs().max()) < 1e-4
+
+
+def test_adam_kernel_matches_torch_adam_and_graph_replay_matches_eager():
+    g = golden("danbo_train")
+    args, caster, trainer, opt = build_trainer(g)
+    eng = trainer.fused_engine()
+    eng.use_graph = False
+    b = batch_of(g)
+    G = b["N_uniques"]
+    pp = caster._per_pose
+    run = lambda: eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G),  # noqa: E731
+                                       b["cam_idxs"], b["target_s"], b["bgs"], int(g["N_samples"]), int(g["N_importance"]))
+    run()
+    # a torch.optim.Adam on copies of the parameters, fed the same gradients for three steps
+    names = list(eng.params)
+    shadow = [torch.nn.Parameter(eng.params[n].detach().clone()) for n in names]
+    ref_opt = torch.optim.Adam(shadow, lr=args.lrate, betas=(0.9, 0.999))
+    for step in range(3):
+        for s, n in zip(shadow, names):
+            s.grad = eng.params[n].grad.detach().clone()
+        ref_opt.step()
+        eng.adam_step(args.lrate)
+        for s, n in zip(shadow, names):
+            if eng.params[n].requires_grad:
+                d = float((s.detach() - eng.params[n].detach()).abs().max())
+                assert d <= 2e-7 + 1e-6 * float(s.detach().abs().max()), (step, n, d)
+        run()
+    assert int(float(opt.state[eng.params[names[0]]]["step"])) == 3
+    # HIP-graph capture of the step: replays give the eager gradients (deterministic batch: perturb = 0, noise = 0)
+    eager = eng.flat_g.clone()
+    eng.use_graph = True
+    run()
+    run()
+    torch.cuda.synchronize()
+    d = float((eng.flat_g - eager).abs().max())
+    assert d <= 1e-5 * float(eager.abs().max()), d      # atomics: summation order differs between runs
+
+
+def test_train_batch_runs_fused_with_noise_and_updates_eval_weights():
+    g = golden("danbo_perfcap_train")
+    args, caster, trainer, opt = build_trainer(g, extra=["--raw_noise_std", "1.0", "--perturb", "1.0"])
+    before = {n: p.detach().clone() for n, p in caster.network.named_parameters()}
+    torch.manual_seed(0)
+    loss, stats = trainer.train_batch(batch_of(g), i=0, global_step=0)
+    assert trainer.engine is not None and np.isfinite(stats["total_loss"]) and stats["lrate"] == pytest.approx(5e-4, rel=1e-5)
+    moved = [n for n, p in caster.network.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert len(moved) == 43, sorted(set(before) - set(moved))
+    for i in range(1, 4):
+        loss, stats = trainer.train_batch(batch_of(g), i=i, global_step=i)
+        assert np.isfinite(stats["total_loss"])
+    # the eval path renders with the updated weights (parameter versions are bumped by the Adam kernel's wrapper)
+    caster.eval()
+    kw = {k: v for k, v in trainer.render_kwargs_test.items() if k not in ("ray_caster", "use_viewdirs")}
+    b = batch_of(g)
+    out1 = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                  N_uniques=b["N_uniques"], **kw)
+    trainer.train_batch(batch_of(g), i=4, global_step=4)
+    caster.eval()
+    out2 = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                  N_uniques=b["N_uniques"], **kw)
+    assert torch.isfinite(out2["rgb_map"]).all() and not torch.equal(out1["rgb_map"], out2["rgb_map"])

@@ -28,7 +28,7 @@ def fp(a):
 def test_library_exports_every_declared_symbol():
     from core import _hip
     hdr = open(os.path.join(ROOT, "include", "danbo_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|size_t)\s+(danbo_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|long)\s+(danbo_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 16
     lib = _hip.lib()                                  # loads without a GPU
     for name in declared:
@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.danbo_abi_version() == 1
     # argument counts of the ctypes table match the header
     for name in declared:
-        m = re.search(r"(?:int|size_t)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
+        m = re.search(r"(?:int|size_t|long)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
         body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S).strip()
         n_args = 0 if body in ("void", "") else body.count(",") + 1
         assert n_args == len(_hip.SIGNATURES[name]), (name, n_args, len(_hip.SIGNATURES[name]))
@@ -188,7 +188,7 @@ def test_config_files_parse_to_the_shipped_values():
     assert (a.nerf_type, a.N_samples, a.N_importance, a.multires_voxel, a.gcn_fc_D, a.chunk) == ("danbo", 96, 48, 6, 1, 4096)
     assert a.use_volume_near_far is False and a.opt_framecode is True and a.loss_fn == "L1"
     b = parse_args(["--N_samples", "48"], config=os.path.join(d, "perfcap/danbo_fast.txt"))
-    assert (b.nerf_type, b.view_type, b.ray_tr_type, b.N_samples, b.vol_scale_penalty) == ("graph", "relray", "root_local", 48, 1e-4)
+    assert (b.nerf_type, b.view_type, b.ray_tr_type, b.N_samples, b.vol_scale_penalty) == ("graph", "relray", "root_local", 48, 1e-3)   # the reference file's value (its README trains PerfCap with --vol_scale_penalty 0.0001)
     c = parse_args([], config=os.path.join(d, "h36m_zju/anerf_base.txt"))
     assert (c.nerf_type, c.netwidth, c.use_cutoff, c.multires) == ("nerf", 448, True, 7)
 
@@ -291,8 +291,11 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
                    check=True, capture_output=True)
     text = open(out).read()
     high = re.compile(r"\bv(24\d|25[0-5])\b|v\[(24\d|25[0-5]):")
-    for nh, np_, handovers in ((1, 0, 2), (2, 0, 4), (1, 8, 2), (2, 6, 4), (2, 8, 4)):
-        name = f"_ZN5danbo10k_linear16ILi{nh}ELi{np_}ELb0EEEvNS_9Lin16ArgsE"
+    # (NH, NP, EXT): EXT = the training step's variant (danbo_linear16_ex), whose recorded-ReLU load is one more asm load
+    # waited for together with everything else at the end of a row tile (one in each of the two unrolled k-steps)
+    for nh, np_, ext, handovers in ((1, 0, 0, 2), (2, 0, 0, 4), (1, 8, 0, 2), (2, 6, 0, 4), (2, 8, 0, 4),
+                                    (1, 0, 1, 2), (1, 8, 1, 2), (2, 0, 1, 4)):
+        name = f"_ZN5danbo10k_linear16ILi{nh}ELi{np_}ELb0ELb{ext}EEEvNS_9Lin16ArgsE"
         body = text[text.index(name + ":"):]
         body = body[:body.index(".Lfunc_end")].split("\n")
         assert not any("scratch_" in l for l in body), "register spills"
@@ -304,7 +307,7 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
         assert len(loads) == 10 and len(takes) == 24 and len(touching) == 34, touching
         waits = sorted(re.search(r"vmcnt\(\d+\)", l).group(0) for l in body if "s_waitcnt" in l and "vmcnt" in l)
         # bias table, prologue, one per row-tile end in each of the two unrolled k-steps, final drain; one per hand-over
-        assert waits == sorted(["vmcnt(0)"] * 5 + ["vmcnt(6)"] * handovers), waits
+        assert waits == sorted(["vmcnt(0)"] * (7 if ext else 5) + ["vmcnt(6)"] * handovers), waits
 
 
 def test_ring_kernels_do_not_spill(tmp_path):
@@ -315,7 +318,7 @@ def test_ring_kernels_do_not_spill(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    for src, kernels in (("k_mlp16.hip", ["k_pe_mlp16"]), ("k_assign16.hip", ["k_assign16E"])):
+    for src, kernels in (("k_mlp16.hip", ["k_pe_mlp16"]), ("k_assign16.hip", ["k_assign16ILb0E", "k_assign16ILb1E"])):
         out = str(tmp_path / (src + ".s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out,
                         os.path.join(ROOT, "danbo-pytorch_amd", "csrc", src)], check=True, capture_output=True)
