@@ -28,6 +28,7 @@ constexpr int AB_W = 32;             // hidden width of the assignment net
 constexpr int AB_STRIDE = AB_W + 1;  // padded rows: row-wise and column-wise reads are both conflict-free
 constexpr int AB_THREADS = 256;
 constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefronts x 2 halves)
+constexpr int AB_PPW = 128;          // pairs per workgroup (16 iterations of 8): amortises the weight staging and the flush
 
 struct ABArgs {
     // geometry
@@ -55,7 +56,7 @@ __device__ __forceinline__ float half_sum32(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
+__global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
     __shared__ float s_w0[AB_MAXNB][FEAT][AB_STRIDE];
     __shared__ float s_w1[AB_W][AB_STRIDE];
     __shared__ float s_b0[AB_W], s_b1[AB_W], s_w2[AB_W];
@@ -69,23 +70,31 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
     __shared__ __attribute__((aligned(16))) float s_a0[AB_PAIRS][AB_W], s_dz1[AB_PAIRS][AB_W], s_dz0[AB_PAIRS][AB_W], s_dh[AB_PAIRS][16];
 
     // workgroup -> (bone j, chunk of its pair list): bones get ceil(pairs / pairs_per_wg) workgroups each, in bone order
+    // (the 24 counters and the bone's adjacency row are fetched by 24 lanes at once: a serial loop of dependent global loads
+    //  cost ~50 us per workgroup)
+    __shared__ int s_cnt[J];
+    __shared__ float s_adjrow[J];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, slot = tid >> 5;   // slot: which pair of the 8 in flight
+    if (tid < J) s_cnt[tid] = min(a.cntb[tid], a.cap);
+    __syncthreads();
     int j = 0, wg = blockIdx.x, npairs = 0;
     for (; j < J; ++j) {
-        npairs = min(a.cntb[j], a.cap);
+        npairs = s_cnt[j];
         const int need = (npairs + a.pairs_per_wg - 1) / a.pairs_per_wg;
         if (wg < need) break;
         wg -= need;
     }
     if (j == J) return;
     const int p_begin = wg * a.pairs_per_wg, p_end = min(p_begin + a.pairs_per_wg, npairs);
-    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, slot = tid >> 5;   // slot: which pair of the 8 in flight
 
     // ---- neighbourhood of bone j from the adjacency buffer (self first) and its weights
+    if (tid < J) s_adjrow[tid] = a.adj[j * J + tid];
+    __syncthreads();
     if (tid == 0) {
         int nq = 0;
         s_nb[nq++] = j;
         for (int k = 0; k < J && nq < AB_MAXNB; ++k)
-            if (k != j && a.adj[j * J + k] != 0.f) s_nb[nq++] = k;
+            if (k != j && s_adjrow[k] != 0.f) s_nb[nq++] = k;
         s_nq = nq;
     }
     __syncthreads();
@@ -106,11 +115,33 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
     const int rays_per_pose = a.R / a.G;
     // pose whose volume gradient is gathered in LDS: the pose of this chunk's first pair (rows are ray-ordered, so most pairs
     // of a chunk share it); pairs of other poses go to global memory directly
-    int g0;
-    {
-        const int i0 = a.lists[(size_t)j * a.cap + p_begin];
-        g0 = min(a.row_ray[i0] / rays_per_pose, a.G - 1);
+    // Everything a pair needs from the row tables is fetched ONCE per workgroup, one pair per thread, into LDS: as a chain of
+    // three dependent global loads at the top of every iteration it cost ~5 us x 32 iterations with nothing to hide it behind.
+    __shared__ int s_pi[AB_PPW], s_pm[AB_PPW], s_pray[AB_PPW];
+    __shared__ float s_pz[AB_PPW], s_plab[AB_PPW], s_pq[AB_PPW];
+    __shared__ uint32_t s_pbits[AB_PPW];
+    __shared__ __attribute__((aligned(16))) float s_pdh[AB_PPW][16];
+    __shared__ float s_skt0[AB_MAXNB][12];
+    __shared__ float s_vol0[AB_MAXNB][VOL];
+    if (tid < p_end - p_begin) {
+        const int i = a.lists[(size_t)j * a.cap + p_begin + tid];
+        const bool coarse = i < first_f;
+        const int m = a.row_sample[i];
+        s_pi[tid] = i; s_pm[tid] = m; s_pray[tid] = a.row_ray[i];
+        s_pz[tid] = coarse ? a.z_c[m] : a.z_f[m];
+        s_plab[tid] = (float)(coarse ? a.label_c[m] : a.label_f[m]);
+        s_pbits[tid] = coarse ? a.bits_c[m] : a.bits_f[m];
+        s_pq[tid] = a.h_rows[(size_t)i * 16 + 15];
+        const float4* dh = reinterpret_cast<const float4*>(a.d_h + (size_t)i * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(s_pdh[tid])[e] = dh[e];
     }
+    __syncthreads();
+    const int g0 = min(s_pray[0] / rays_per_pose, a.G - 1);
+    // pose g0's bone transforms and volumes of the neighbourhood: LDS instead of two more dependent global round trips per pair
+    for (int i = tid; i < nq * 12; i += AB_THREADS) s_skt0[i / 12][i % 12] = a.skts[((size_t)g0 * J + s_nb[i / 12]) * 16 + i % 12];
+    for (int i = tid; i < nq * VOL; i += AB_THREADS) s_vol0[i / VOL][i % VOL] = a.volumes[((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL];
+    __syncthreads();
 
     // ---- gradient accumulators of this lane (hidden unit c of half `slot & 1`)
     float gw1[AB_W];                 // d W1[j][cc][c], cc = 0..31
@@ -130,17 +161,14 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
 
     const int iters = (p_end - p_begin + AB_PAIRS - 1) / AB_PAIRS;
     for (int it = 0; it < iters; ++it) {
-        const int pi = p_begin + it * AB_PAIRS + slot;
-        const bool live = pi < p_end;            // uniform per half
-        const int i = a.lists[(size_t)j * a.cap + (live ? pi : p_begin)];
-        const bool coarse = i < first_f;
-        const int m = a.row_sample[i], ray = a.row_ray[i];
+        const int pl_ = it * AB_PAIRS + slot;
+        const bool live = p_begin + pl_ < p_end;            // uniform per half
+        const int pl = live ? pl_ : 0;
+        const int ray = s_pray[pl];
         const int g = min(ray / rays_per_pose, a.G - 1);
-        const float zv = coarse ? a.z_c[m] : a.z_f[m];
-        const float lab = (float)(coarse ? a.label_c[m] : a.label_f[m]);
-        const uint32_t bits = coarse ? a.bits_c[m] : a.bits_f[m];
-        const float qrow = a.h_rows[(size_t)i * 16 + 15];
-        if (c < 16) s_dh[slot][c] = c < FEAT ? a.d_h[(size_t)i * 16 + c] : 0.f;
+        const float zv = s_pz[pl], lab = s_plab[pl], qrow = s_pq[pl];
+        const uint32_t bits = s_pbits[pl];
+        if (c < 16) s_dh[slot][c] = c < FEAT ? s_pdh[pl][c] : 0.f;
 
         // ---- recompute the gather: lane (gq, gk) evaluates neighbour gq completely and keeps axis gk
         float x_k = 0.f, win = 0.f, w0t = 0.f, w1t = 0.f, sck = 1.f;
@@ -153,7 +181,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
             const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
             float p[3], pl[3], pt[3], x[3], skt[12];
             sample_point(o, d, zv, p);
-            const float* src = a.skts + ((size_t)g * J + k) * 16;
+            const float* src = g == g0 ? s_skt0[gq] : a.skts + ((size_t)g * J + k) * 16;
 #pragma unroll
             for (int e = 0; e < 12; ++e) skt[e] = src[e];
             affine_unfused(skt, p, pl);
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assign_bwd(ABArgs a) {
             y1 = y0 + 1;
             ok0 = y0 >= 0 && y0 < VRES;
             ok1 = y1 >= 0 && y1 < VRES;
-            vol = a.volumes + ((size_t)g * J + k) * VOL;
+            vol = g == g0 ? s_vol0[gq] : a.volumes + ((size_t)g * J + k) * VOL;
 #pragma unroll
             for (int f = 0; f < VOXF; ++f) {
                 const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
@@ -341,7 +369,7 @@ extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
     a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
     // 256 pairs (32 iterations of 8) per workgroup amortise its weight staging and its flush; a sample lies in at most a few
     // volumes, so 4 pairs per row of capacity is far above what geometry allows -- and workgroups without pairs exit at once
-    a.pairs_per_wg = 256;
+    a.pairs_per_wg = AB_PPW;
     const long wgs = ((long)p->rows_cap * 4 + a.pairs_per_wg - 1) / a.pairs_per_wg + J;
     hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < 65535 ? wgs : 65535)), dim3(AB_THREADS), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();

@@ -137,11 +137,17 @@ __global__ __launch_bounds__(256) void k_pose_mix_bwd(const float* __restrict__ 
                                                       const float* __restrict__ bias, float scale, int C, float* __restrict__ dYp,
                                                       float* __restrict__ g_bias, float* __restrict__ g_adj_w) {
     __shared__ float s_A[J * J], s_dA[J * J], s_edge[J * J];
+    __shared__ float s_dm[J][256], s_y[J][256];     // this pose's dM and Yp, channel-minor (C <= 256)
     const int g = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < J * J; i += 256) { s_A[i] = adj_w[i] * adj[i]; s_edge[i] = adj[i]; s_dA[i] = 0.f; }
     __syncthreads();
-    for (int k = tid; k < C; k += 256) {
+    for (int k = tid; k < 256; k += 256) {
         float y[J], dm[J];
+        if (k >= C) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) { s_dm[j][tid] = 0.f; s_y[j][tid] = 0.f; }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < J; ++j) y[j] = Yp[((size_t)g * J + j) * C + k];
         float db = 0.f;
@@ -163,13 +169,21 @@ __global__ __launch_bounds__(256) void k_pose_mix_bwd(const float* __restrict__ 
         }
         if (db != 0.f) atomicAdd(g_bias + k, db);
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-#pragma unroll
-            for (int jp = 0; jp < J; ++jp)
-                if (s_edge[j * J + jp] != 0.f) {
-                    const float v = dm[j] * y[jp];
-                    if (v != 0.f) atomicAdd(&s_dA[j * J + jp], v);
-                }
+        for (int j = 0; j < J; ++j) { s_dm[j][tid] = dm[j]; s_y[j][tid] = y[j]; }
+    }
+    __syncthreads();
+    // d A[j][j'] = sum_k dM[j][k] Yp[j'][k]: one wavefront per edge (lanes over channels), not 128 threads adding into the same
+    // LDS word (that version spent 100 us serialising 9 000 same-address atomics)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int e = wave; e < J * J; e += 4) {
+            if (s_edge[e] == 0.f) continue;
+            const int j = e / J, jp = e % J;
+            float v = 0.f;
+            for (int k = lane; k < C; k += 64) v += s_dm[j][k] * s_y[jp][k];
+            v = wave_total(v);
+            if (lane == 0) s_dA[e] = v;
+        }
     }
     __syncthreads();
     for (int i = tid; i < J * J; i += 256)

@@ -25,6 +25,25 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+// Workgroup-wide max / sum of per-thread values, then ONE atomic per workgroup: thousands of wavefronts raising the same word
+// serialise in the L2 (k_train_rgb_head_bwd spent 190 us on two such words before this).  256-thread workgroups.
+__device__ __forceinline__ void block_atomic_max(float* slot, float v, float* s_red /*[4]*/) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_max_abs(slot, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
+}
+__device__ __forceinline__ void block_atomic_add(float* slot, float v, float* s_red /*[4]*/) {
+    v = wave_total(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (t != 0.f) atomicAdd(slot, t);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // per-ray view inputs  vin[r] = [ PE_L(dir) | frame code | 0 ]   (reference nerf.py:252-279, encoders.py:179-189,570-578)
@@ -183,9 +202,9 @@ __global__ __launch_bounds__(256) void k_train_loss_grad(const float* __restrict
             if (p) l_c += ls * inv * wgt; else l_f += ls * inv * wgt;
         }
     }
-    l_f = wave_total(l_f);
-    l_c = wave_total(l_c);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(loss + 0, l_f); atomicAdd(loss + 1, l_c); }
+    __shared__ float s_red[4];
+    block_atomic_add(loss + 0, l_f, s_red);
+    block_atomic_add(loss + 1, l_c, s_red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -233,12 +252,9 @@ __global__ __launch_bounds__(256) void k_train_draw_unmerge(float4* __restrict__
         if (lane == 0) d_raw_rows[r] = make_float4(ex, ey, ez, ew);
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fmaxf(fabsf(ez), fabsf(ew))));
     }
-    lsum = wave_total(lsum);
-    mx = wave_max(mx);
-    if (lane == 0) {
-        if (lsum != 0.f) atomicAdd(loss + 2, lsum);
-        atomic_max_abs(maxabs, mx);
-    }
+    __shared__ float s_red[4];
+    block_atomic_add(loss + 2, lsum, s_red);
+    block_atomic_max(maxabs, mx, s_red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -278,9 +294,9 @@ __global__ __launch_bounds__(256) void k_train_rgb_head_bwd(const float* __restr
             ma = fmaxf(ma, fabsf(d.w));
         }
     }
-    mv = wave_max(mv);
-    ma = wave_max(ma);
-    if ((threadIdx.x & 63) == 0) { atomic_max_abs(max_v, mv); atomic_max_abs(max_a, ma); }
+    __shared__ float s_red[4];
+    block_atomic_max(max_v, mv, s_red);
+    block_atomic_max(max_a, ma, s_red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -392,6 +408,12 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 
 using namespace danbo;
 
+// grid of a kernel whose workgroups each end in atomics on the same few words: two workgroups per CU instead of eight
+static inline int few_grid(long items, int block) {
+    const int g = stream_grid(items, block);
+    return g < 2 * NUM_CU ? g : 2 * NUM_CU;
+}
+
 extern "C" int danbo_train_view_inputs(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise, int L_view,
                                        const float* codes, int n_codes, int Cf, const int64_t* cam_idx, float* vin, int ldv,
                                        void* stream) {
@@ -425,7 +447,7 @@ extern "C" int danbo_train_loss_grad(const float* rgb, const float* acc, const f
                                      const float* bgs, int use_bg, int R, int mse, float w_fine, float w_coarse, float* g_rgb,
                                      float* g_acc, float* g_rgb0, float* g_acc0, float* loss, void* stream) {
     DANBO_CHECK_ARG(rgb && acc && rgb0 && acc0 && target && g_rgb && g_acc && g_rgb0 && g_acc0 && loss && R > 0);
-    hipLaunchKernelGGL(k_train_loss_grad, dim3(stream_grid(R, 256)), dim3(256), 0, (hipStream_t)stream, rgb, acc, rgb0, acc0, target, bgs,
+    hipLaunchKernelGGL(k_train_loss_grad, dim3(few_grid(R, 256)), dim3(256), 0, (hipStream_t)stream, rgb, acc, rgb0, acc0, target, bgs,
                        use_bg, R, mse, w_fine, w_coarse, g_rgb, g_acc, g_rgb0, g_acc0, loss);
     DANBO_LAUNCH_RET();
 }
@@ -436,7 +458,7 @@ extern "C" int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorte
                                         float* maxabs, void* stream) {
     DANBO_CHECK_ARG(d_raw_c && d_raw_sorted && order && bits_c && bits_f && weights && alpha && d_raw_f && d_raw_rows && label_c && label_f);
     DANBO_CHECK_ARG(loss && maxabs && R > 0 && S > 0 && Sf > 0);
-    hipLaunchKernelGGL(k_train_draw_unmerge, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_train_draw_unmerge, dim3(few_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_sorted), order, bits_c, bits_f, weights,
                        alpha, R, S, Sf, reinterpret_cast<float4*>(d_raw_f), reinterpret_cast<float4*>(d_raw_rows), label_c, label_f, loss,
                        maxabs);
@@ -447,7 +469,7 @@ extern "C" int danbo_train_rgb_head_bwd(const float* hv, const float* rgb_w, con
                                         const int32_t* row_sample, const int32_t* cnt, int R, int rows_cap, float* d_raw_rows,
                                         float* dpre_v, float* d_alpha4, float* max_v, float* max_a, void* stream) {
     DANBO_CHECK_ARG(hv && rgb_w && d_raw_c && d_raw_f && row_sample && cnt && d_raw_rows && dpre_v && d_alpha4 && max_v && max_a);
-    hipLaunchKernelGGL(k_train_rgb_head_bwd, dim3(stream_grid((long)rows_cap * 32, 256)), dim3(256), 0, (hipStream_t)stream, hv, rgb_w,
+    hipLaunchKernelGGL(k_train_rgb_head_bwd, dim3(few_grid((long)rows_cap * 32, 256)), dim3(256), 0, (hipStream_t)stream, hv, rgb_w,
                        reinterpret_cast<const float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_f), row_sample, cnt, R,
                        reinterpret_cast<float4*>(d_raw_rows), dpre_v, reinterpret_cast<float4*>(d_alpha4), max_v, max_a);
     DANBO_LAUNCH_RET();

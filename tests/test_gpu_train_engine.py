@@ -241,7 +241,7 @@ def test_train_batch_runs_fused_with_noise_and_updates_eval_weights():
     before = {n: p.detach().clone() for n, p in caster.network.named_parameters()}
     torch.manual_seed(0)
     loss, stats = trainer.train_batch(batch_of(g), i=0, global_step=0)
-    assert trainer.engine is not None and np.isfinite(stats["total_loss"]) and stats["lrate"] == pytest.approx(5e-4, rel=1e-5)
+    assert trainer.engine is not None and np.isfinite(stats["total_loss"]) and stats["lrate"] == pytest.approx(5e-4 * 0.1 ** (1 / 500000), rel=1e-9)
     moved = [n for n, p in caster.network.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert len(moved) == 43, sorted(set(before) - set(moved))
     for i in range(1, 4):

@@ -155,7 +155,8 @@ def test_one_optimiser_step_changes_parameters_and_stays_finite():
     before = {n: p.detach().clone() for n, p in caster.network.named_parameters()}
     torch.manual_seed(0)
     loss, stats = trainer.train_batch(batch_of(g), i=0, global_step=0)
-    assert np.isfinite(stats["total_loss"]) and stats["lrate"] == pytest.approx(5e-4)
+    assert np.isfinite(stats["total_loss"])
+    assert stats["lrate"] == pytest.approx(5e-4 * 0.1 ** (1 / 500000), rel=1e-9)   # the reference decays from the optimizer step just made
     moved = [n for n, p in caster.network.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert len(moved) >= 40 and "graph_net.axis_scale" in moved and "framecodes.codes.weight" in moved
     loss2, stats2 = trainer.train_batch(batch_of(g), i=1, global_step=1)

@@ -21,7 +21,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--poses", type=int, default=16)
     ap.add_argument("--rays-per-pose", type=int, default=192)
+    ap.add_argument("--path", choices=["fused", "autograd"], default="fused",
+                    help="fused: danbo_train_step + danbo_adam_step (HIP); autograd: core/train_path.py (torch autograd + rocBLAS)")
+    ap.add_argument("--no-graph", action="store_true", help="fused path without HIP-graph capture of the step")
+    ap.add_argument("--sync-stats", action="store_true", help="copy the loss terms to the host after every step (as the reference does)")
     a = ap.parse_args()
+    if a.path == "autograd":
+        os.environ["DANBO_TRAIN_PATH"] = "autograd"
     from core.config import parse_args
     from core.raycasters import create_raycaster
     from core.trainer import Trainer
@@ -52,19 +58,28 @@ def main():
                  bgs=t(rng.uniform(size=(R, 3))), kp3d=t(scene["kps"][pose]), skts=t(scene["skts"][pose]),
                  bones=t(scene["bones"][pose]), cyls=t(scene["cyls"][pose]), cam_idxs=t(pose % 20, torch.int64),
                  N_uniques=a.poses)
+    if a.path == "fused":
+        assert trainer.fused_engine() is not None, trainer.fused_reason
+        trainer.engine.use_graph = not a.no_graph
+    sync = a.sync_stats or a.path == "autograd"
     for i in range(a.warmup):
         trainer.train_batch(batch, i=i, global_step=i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(a.steps):
-        loss, stats = trainer.train_batch(batch, i=i, global_step=a.warmup + i)
+        loss, stats = trainer.train_batch(batch, i=i, global_step=a.warmup + i, sync_stats=sync)
     e1.record()
     torch.cuda.synchronize()
+    if "total_loss" not in stats:
+        stats["total_loss"] = float(loss["total_loss"])
+    counts = trainer.last_preds["counts"].cpu().tolist() if a.path == "fused" else None
     ms = e0.elapsed_time(e1) / a.steps
     S = args.N_samples + args.N_importance
     print(json.dumps(dict(metric="training ray-samples/s", value=R * S / ms * 1e3, ms_per_step=ms, rays=R, samples_per_ray=S,
-                          poses=a.poses, loss=stats["total_loss"], config="perfcap/danbo_fast (SURVEY 8d config 4)")))
+                          poses=a.poses, loss=stats["total_loss"], path=a.path, hip_graph=a.path == "fused" and not a.no_graph,
+                          in_volume_rows=None if counts is None else counts[5], rows=None if counts is None else counts[4],
+                          config="perfcap/danbo_fast (SURVEY 8d config 4)")))
 
 
 if __name__ == "__main__":
