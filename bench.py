@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: ray-samples/s of the DANBO render path at 512x512 rays x 64 samples.
+"""Benchmark of the MI355X DANBO path.  `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1
-the driver launches one rank per GPU with torch.distributed.run.  A *step* is one full frame:
-262 144 rays x (48 coarse + 16 importance) network evaluations = 16.78 M ray-samples through
-near/far -> sampling -> transform+cull -> gather/assign/blend -> PE+MLP -> composite ->
-importance resampling -> fine pass -> composite, with rays / pose / weights already in HBM.
-Ranks render different camera views of the same pose (rays shard data-parallel, no collective
-on the data path) => weak scaling; value = N * K * samples_per_frame / max-over-ranks time.
+Default workload = BASELINE.json's metric: ray-samples/s of the render path at 512 x 512 rays x 64 samples (48 coarse + 16
+importance: the reference cannot run N_importance = 0), H36M `danbo_base` network, seeded synthetic weights / pose /
+camera, everything resident in HBM.  A *step* is one full frame: bounds -> depths -> cull -> gather / assignment / blend ->
+PE + MLP -> composite -> importance resampling -> second network pass -> composite.  For N > 1 the driver launches one rank per
+GPU; ranks render different camera views (rays shard data-parallel, no collective on the data path) => weak scaling;
+value = N * K * units / max-over-ranks time.
 
-Workload (BASELINE.json configs[2] network at the metric's 64 samples):
-D-H36M `danbo_base` network (FGNNcat + vox_MIXGNN, W=256, D=8, 128-d frame codes), seeded
-synthetic weights / SMPL pose / bullet-time camera.  `value` is measured with exact in-volume
-culling (identical raw to evaluating every sample -- tests/test_gpu_kernels.py checks bitwise);
-`dense_value` is the same frame with every sample pushed through every kernel (the reference's
-executed work).  `roofline` is for the dominant kernel (k_pe_mlp, fp32 MFMA) with EXECUTED
-flops only.
+--config selects the other BASELINE configurations, each with its own `roofline` and `cpu_baseline`:
+  2  H36M danbo_fast: 512^2 x (32 + 16), per-bone box near/far           (render)
+  3  H36M danbo_base: 512^2 x (96 + 32) = 128 samples per ray              (render)
+  4  PerfCap danbo_fast TRAINING step: 3072 rays = 16 poses x 192, 32 + 16, perturb, noise, L1, Adam; danbo_train_step +
+     danbo_adam_step (one C call each), RCCL all-reduce of the flat gradient for N > 1 (every rank its own 3072 rays: weak)
+  5  A-NeRF anerf_base: 512^2 x (48 + 16), cutoff PE, W = 448             (render)
+
+`value` of the render configs is measured with exact in-volume culling (bit-identical raw to evaluating every sample:
+`dense_equals_culled`); `dense_value` pushes every sample through every kernel (the reference's executed work).
+`roofline` is for the dominant kernel, EXECUTED flops only, its launch durations taken from HIP events inside the timed region.
+`roofline.traffic` is filled from profiles/r02_pmc_hbm.json only if that file was measured on the kernel sources being timed
+(sha recorded by tools/pmc_hbm.sh), else null.  `cpu_baseline`: oracle/torch_cpu.py (a multi-threaded torch-CPU restatement
+doing the reference's executed work) on a bounded sample of the same workload, best of 3.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,22 +43,28 @@ MAC_PER_ROW = {"fp32": 558592 + 256 + 65536 + 32768 + 384,      # k_pe_mlp : tru
                "f16split": 558592 + 256 + 32768 + 384}          # k_pe_mlp16: feature+view merged into one 256->128
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_FP16_MFMA = 2500e12       # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (2:1-sparse figures are not used)
+SPLIT_NOTE = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: every fp32-accurate product is three half-precision MFMA products "
+              "(hi*hi + hi*lo + lo*hi); executed MFMA rate = 3 x achieved")
+CONFIGS = {1: (48, 16, False), 2: (32, 16, True), 3: (96, 32, False)}      # (coarse, importance, per-bone box bounds)
 
 
-def build_workload(device, view, mlp_mode="f16split"):
+def T(x, device, dt=torch.float32):
+    return torch.tensor(np.ascontiguousarray(x), dtype=dt, device=device)
+
+
+def build_workload(device, view, mlp_mode="f16split", cam_dist=3.0):
     from core.render_engine import DanboEngine
     from core.utils import synthetic as syn
+    from core.utils.skeleton_utils import bone_align_transforms
     cfg = syn.model_config("danbo_base")
     rest = syn.rest_pose(cfg["rest_scale"])
     sd = syn.make_state_dict(cfg, seed=0, n_framecodes=100, rest=rest)
-    scene = syn.make_scene(n_poses=1, H=H, W=W, n_views=8, pose_seed=0, min_radius=1.25)
+    scene = syn.make_scene(n_poses=1, H=H, W=W, n_views=8, pose_seed=0, min_radius=1.25, cam_dist=cam_dist)
     ro, rd = scene["rays"][view % 8]
-    T = lambda x, dt=torch.float32: torch.tensor(np.ascontiguousarray(x), dtype=dt, device=device)  # noqa: E731
-    from core.utils.skeleton_utils import bone_align_transforms
     align = bone_align_transforms(rest)
-    eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(align), mlp_mode=mlp_mode)
-    inputs = dict(rays_o=T(ro), rays_d=T(rd), skts=T(scene["skts"]), bones=T(scene["bones"]), cyls=T(scene["cyls"]),
-                  cam_idx=torch.zeros(len(ro), dtype=torch.int64, device=device))
+    eng = DanboEngine(cfg, {k: T(v, device) for k, v in sd.items()}, T(align, device), mlp_mode=mlp_mode)
+    inputs = dict(rays_o=T(ro, device), rays_d=T(rd, device), skts=T(scene["skts"], device), bones=T(scene["bones"], device),
+                  cyls=T(scene["cyls"], device), cam_idx=torch.zeros(len(ro), dtype=torch.int64, device=device))
     return eng, inputs, (cfg, sd, rest, scene, ro, rd)
 
 
@@ -61,35 +73,324 @@ def render(eng, inp, dense=False):
                       N_SAMPLES, N_IMPORTANCE, chunk=4096, dense=dense)
 
 
-def cpu_baseline(extra, n_rays=4096, frame=None):
-    """The numpy oracle (a CPU port of the reference path) on one 4096-ray chunk of the frame."""
+def sha16(*files):
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "danbo-pytorch_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------- CPU baselines (checker code)
+def best_of(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, out
+
+
+def cpu_baseline_render(extra, box_bounds, frame=None, budget_s=6.0):
+    """oracle/torch_cpu.py on centre rays of the same frame; the sample is grown until one repetition takes ~budget_s"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import danbo_oracle as o
+    import torch_cpu
     cfg, sd, rest, scene, ro, rd = extra
     from core.utils import synthetic as syn
-    r0 = (H // 2) * W - n_rays // 2          # rows around the image centre (body pixels)
-    sl = slice(r0, r0 + n_rays)
-    rb = syn.ray_batch(ro[sl], rd[sl])
-    z = np.zeros(n_rays, dtype=np.int64)
-    orc = o.DanboOracle(cfg, sd, rest)
+    cfg = dict(cfg, use_volume_near_far=box_bounds)
+    model = torch_cpu.DanboTorchCPU(cfg, sd, rest)
+
+    def run(n_rays):
+        r0 = (H // 2) * W - n_rays // 2
+        sl = slice(r0, r0 + n_rays)
+        z = np.zeros(n_rays, dtype=np.int64)
+        rb = syn.ray_batch(ro[sl], rd[sl])
+        return sl, model.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], np.zeros(n_rays, np.int64), 1, N_SAMPLES,
+                                N_IMPORTANCE)
+    n = 4096
+    run(512)                                                    # thread pools, allocator
+    # torch's default of one thread per hardware thread is far from the fastest setting for 4096-ray chunks on a 128-core
+    # host: use the thread count that is fastest on a probe, and report it
+    best_t, best_dt = torch.get_num_threads(), None
+    for nt in sorted({8, 16, 32, 64, torch.get_num_threads()}):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        run(1024)
+        dt = time.perf_counter() - t0
+        if best_dt is None or dt < best_dt:
+            best_t, best_dt = nt, dt
+    torch.set_num_threads(best_t)
     t0 = time.perf_counter()
-    ref = orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], np.zeros(n_rays, np.int64), 1,
-                     N_SAMPLES, N_IMPORTANCE)
-    dt = time.perf_counter() - t0
+    run(n)                                                      # a first estimate at the full chunk size
+    est = time.perf_counter() - t0
+    while est * 2 < budget_s and n * 2 <= 65536:
+        n, est = n * 2, est * 2
+    dt, (sl, ref) = best_of(lambda: run(n))
     parity = None
     if frame is not None:   # the timed HIP path's image on the same rays (checker only: nothing here is timed or shipped)
         rgb, acc = frame["rgb_map"][sl].cpu().numpy(), frame["acc_map"][sl].cpu().numpy()
-        parity = dict(against="oracle/danbo_oracle.py on the cpu_baseline sample", rays=n_rays,
-                      psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])), max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()),
-                      max_abs_acc=float(np.abs(acc - ref["acc_map"]).max()))
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return dict(value=n_rays * (N_SAMPLES + N_IMPORTANCE) / dt, unit="ray-samples/s", cores=int(cores), kind="port",
-                sample=f"{n_rays} centre rays x {N_SAMPLES}+{N_IMPORTANCE} samples of the same frame through "
-                       f"oracle/danbo_oracle.py (numpy, BLAS threads), {dt:.1f} s"), parity
+        parity = dict(against="oracle/torch_cpu.py on the cpu_baseline sample", rays=n, psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])),
+                      max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()), max_abs_acc=float(np.abs(acc - ref["acc_map"]).max()))
+    return dict(value=n * (N_SAMPLES + N_IMPORTANCE) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()), kind="port",
+                sample=f"{n} centre rays x {N_SAMPLES}+{N_IMPORTANCE} samples of the same frame, every sample through every bone and "
+                       f"the full MLP (the reference's executed work), oracle/torch_cpu.py (torch CPU kernels, "
+                       f"{torch.get_num_threads()} threads), 4096-ray chunks, best of 3: {dt:.2f} s"), parity
+
+
+# ---------------------------------------------------------------------------------------------- timing harness
+def timed(fn, steps, warmup, dist, device, cpu_dist):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cpu" if cpu_dist else device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+# ---------------------------------------------------------------------------------------------- render configs 1-3
+def bench_render(args, rank, world, device, dist):
+    eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
+    eng.cfg["use_volume_near_far"] = bool(args.box_near_far)
+    for _ in range(args.warmup):
+        render(eng, inp)
+    eng.profile = {}
+    elapsed, out = timed(lambda: render(eng, inp), args.steps, 0, dist, device, args.debug_single_device)
+    samples_per_frame = H * W * (N_SAMPLES + N_IMPORTANCE)
+    value = world * args.steps * samples_per_frame / elapsed
+
+    # ---- roofline of the dominant kernel from the HIP events recorded inside the timed region
+    prof = eng.profile["k_pe_mlp"]
+    eng.profile = None
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+    rows = sum(int(c.item()) if torch.is_tensor(c) else int(c) for _, _, c in prof)
+    mac = MAC_PER_ROW[args.mlp]
+    achieved = 2.0 * mac * rows / (ms * 1e-3)                # EXECUTED multiply-adds of in-volume rows only
+    if args.mlp == "f16split":
+        kernel, peak, peak_note = "k_pe_mlp16", PEAK_FP16_MFMA / 3.0, SPLIT_NOTE
+    else:
+        kernel, peak, peak_note = "k_pe_mlp", PEAK_FP32_MFMA, "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
+    traffic, traffic_note = None, "no PMC profile of this build of the kernel under profiles/ (tools/pmc_hbm.sh)"
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
+    if os.path.exists(pmc) and args.mlp == "f16split" and args.config == 1:
+        rec = json.load(open(pmc))
+        if rec.get("kernel_src_sha16") == sha16("k_mlp16.hip", "common.hpp"):
+            traffic = rec["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
+            traffic_note = "HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source (profiles/r02_pmc_hbm.json)"
+    roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak,
+                    traffic=traffic, launches=len(prof), avg_launch_ms=ms / len(prof), rows_per_launch=rows / len(prof),
+                    flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF, peak_note=peak_note,
+                    note="executed flops of rows inside >=1 bone volume only; algorithmic bytes = 84 B per row; " + traffic_note)
+    names = {1: "H36M danbo_base network", 2: "H36M danbo_fast (BASELINE config 2)", 3: "H36M danbo_base (BASELINE config 3)"}
+    result = {
+        "metric": f"ray-samples/sec at 512x512x{N_SAMPLES + N_IMPORTANCE} samples", "value": value, "unit": "ray-samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.mlp == "fp32" else "f32 (fp16x2-split MFMA products, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": f"{names.get(args.config, names[1])}, 512x512 rays x ({N_SAMPLES} coarse + {N_IMPORTANCE} importance) "
+                               f"samples, 1 pose / 1 camera per rank, {'per-bone box' if args.box_near_far else 'cylinder'} near/far, "
+                               "exact in-volume culling",
+                   "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
+        "in_volume_fraction": rows / (args.steps * samples_per_frame),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1:
+        if not args.no_dense:
+            render(eng, inp, dense=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nd = 2
+            for _ in range(nd):
+                out_d = render(eng, inp, dense=True)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - t1) / nd
+            result["dense_value"] = samples_per_frame / td
+            result["dense_ms_per_step"] = 1e3 * td
+            result["dense_mlp_tflops_lower_bound"] = 2.0 * mac * samples_per_frame / td / 1e12
+            result["dense_equals_culled"] = bool(torch.equal(out_d["rgb_map"], out["rgb_map"]))
+        if not args.no_sweep:
+            # the headline rides on how much of the frame the body fills: the same frame from nearer / farther cameras
+            sweep = []
+            for dist_ in (2.0, 3.0, 4.5):
+                e2, i2, _ = build_workload(device, view=0, mlp_mode=args.mlp, cam_dist=dist_)
+                e2.cfg["use_volume_near_far"] = bool(args.box_near_far)
+                for _ in range(3):
+                    render(e2, i2)
+                e2.profile = {}
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    render(e2, i2)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 10
+                r2 = sum(int(c.item()) for _, _, c in e2.profile["k_pe_mlp"]) / 10
+                sweep.append(dict(camera_distance=dist_, in_volume_fraction=r2 / samples_per_frame, value=samples_per_frame / dt,
+                                  ms_per_step=1e3 * dt))
+                del e2, i2
+            result["occupancy_sweep"] = sweep
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"], parity = cpu_baseline_render(extra, bool(args.box_near_far), frame=out)
+            if parity is not None:
+                result["parity"] = parity
+    return result
+
+
+# ---------------------------------------------------------------------------------------------- config 4: training step
+def bench_train(args, rank, world, device, dist):
+    from core.config import parse_args
+    from core.raycasters import create_raycaster
+    from core.trainer import Trainer
+    from core.utils import synthetic as syn
+    from core.utils.skeleton_utils import SMPLSkeleton
+    targs = parse_args(["--no_reload"], config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", "perfcap", "danbo_fast.txt"))
+    rest = syn.rest_pose(0.48)
+    da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=20, rest_pose=rest, hwf=(128, 128, 160.))
+    torch.manual_seed(0)
+    tr_kw, te_kw, start, grad_vars, opt, _ = create_raycaster(targs, da, device=device)
+    caster = tr_kw["ray_caster"]
+    sd = syn.make_state_dict(syn.model_config("danbo_perfcap"), 3, 20, rest)
+    caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    trainer = Trainer(targs, da, opt, None, tr_kw, te_kw, device=device)
+    poses, rpp = 16, 192
+    scene = syn.make_scene(n_poses=poses, H=128, W=128, n_views=poses, pose_seed=5 + rank)
+    rng = np.random.default_rng(rank)
+    js, is_ = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
+    sel = np.nonzero(((np.abs(is_ - 64) < 128 * 0.22) & (np.abs(js - 64) < 128 * 0.40)).reshape(-1))[0]
+    ro, rd, pose = [], [], []
+    for p in range(poses):
+        idx = np.sort(rng.choice(sel, size=rpp, replace=False))
+        ro.append(scene["rays"][p][0][idx]); rd.append(scene["rays"][p][1][idx]); pose += [p] * rpp
+    pose = np.array(pose)
+    R = len(pose)
+    batch = dict(rays_o=T(np.concatenate(ro), device), rays_d=T(np.concatenate(rd), device), target_s=T(rng.uniform(size=(R, 3)), device),
+                 bgs=T(rng.uniform(size=(R, 3)), device), kp3d=T(scene["kps"][pose], device), skts=T(scene["skts"][pose], device),
+                 bones=T(scene["bones"][pose], device), cyls=T(scene["cyls"][pose], device), cam_idxs=T(pose % 20, device, torch.int64),
+                 N_uniques=poses)
+    if trainer.fused_engine() is None:
+        raise SystemExit(f"the fused training step does not cover this configuration: {trainer.fused_reason}")
+    torch.manual_seed(1 + rank)
+    step = [0]
+
+    def one():
+        out = trainer.train_batch(batch, i=step[0], global_step=step[0], sync_stats=False)
+        step[0] += 1
+        return out
+    elapsed, (loss, stats) = timed(one, args.steps, args.warmup, dist, device, args.debug_single_device)
+    S = targs.N_samples + targs.N_importance
+    counts = trainer.last_preds["counts"].cpu().tolist()
+    rows, in_vol = counts[4], counts[5]
+    # dense-layer work of a step: forward (pts 0..7, feature+alpha, view[411 in], rgb) + input gradients + weight gradients
+    mac_fwd = 195 * 256 + 4 * 256 * 256 + 451 * 256 + 2 * 256 * 256 + 257 * 256 + 411 * 128 + 128 * 3
+    mac_dx = 256 * 411 + 257 * 256 + 6 * 256 * 256 + 256 * 451 + 256 * 195          # view^T, fa^T, trunk 7..1 (5: 451 out), layer 0
+    flops = 2.0 * rows * (2 * mac_fwd + mac_dx)
+    ms = 1e3 * elapsed / args.steps
+    achieved = flops / (ms * 1e-3)
+    peak = PEAK_FP16_MFMA / 3.0
+    result = {
+        "metric": "training ray-samples/sec (PerfCap danbo_fast step: forward + losses + backward + Adam)", "value": world * R * S / (ms * 1e-3),
+        "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16x2-split MFMA products, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: PerfCap danbo_fast training step, 3072 rays = 16 poses x 192 per rank, 32 + 16 samples, "
+                               "perturb = 1, raw_noise_std = 1, L1 + soft-softmax + volume-scale losses, Adam; danbo_train_step + "
+                               "danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
+                   "rays": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
+        "rows_per_step": rows, "in_volume_fraction": in_vol / (R * S), "loss": float(loss["total_loss"]),
+        "roofline": dict(bound="mfma", kernel="k_linear16<EXT> x 30 + k_dw16 (whole step)", achieved=achieved / 1e12, peak=peak / 1e12,
+                         unit="TFLOP/s", frac=achieved / peak, traffic=None, flop_per_row=2 * (2 * mac_fwd + mac_dx),
+                         peak_note=SPLIT_NOTE,
+                         note="STEP-level lower bound: executed dense-layer flops of the step (forward + input gradients + weight "
+                              "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
+                              "per-kernel durations: profiles/r02*_train_kernel_stats.csv"),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_train(targs, caster, batch, poses)
+    return result
+
+
+def cpu_baseline_train(targs, caster, batch, poses, n_poses=2):
+    """the same step (forward, L1 losses of both passes, backward, Adam) as a torch-CPU restatement with autograd, on a shard of
+    n_poses x 192 rays, dense like the reference"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_cpu_train
+    R = n_poses * 192
+    b = {k: (v[:R].cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    sd = {k: v.detach().cpu() for k, v in caster.network.state_dict().items()}
+    from core.utils import synthetic as syn
+    step = torch_cpu_train.make_step(targs, syn.model_config("danbo_perfcap"), sd, caster.transforms[0].cpu(), b, n_poses)
+    step()
+    dt, _ = best_of(step)
+    S = targs.N_samples + targs.N_importance
+    return dict(value=R * S / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()), kind="port",
+                sample=f"{R} rays = {n_poses} poses x 192 of the same batch, forward + L1 losses + backward + Adam with torch autograd on "
+                       f"CPU kernels ({torch.get_num_threads()} threads), every sample through every bone and the full MLP, best of 3: "
+                       f"{dt:.2f} s per step")
+
+
+# ---------------------------------------------------------------------------------------------- config 5: A-NeRF frame
+def bench_anerf(args, rank, world, device, dist):
+    from core.anerf_engine import AnerfEngine
+    from core.utils import synthetic as syn
+    from core.utils.skeleton_utils import bone_align_transforms
+    cfg = syn.model_config("anerf_base")
+    rest = syn.rest_pose(cfg["rest_scale"])
+    sd = syn.make_state_dict(cfg, seed=0, n_framecodes=100, rest=rest)
+    scene = syn.make_scene(n_poses=1, H=H, W=W, n_views=8, pose_seed=0, min_radius=1.25)
+    ro, rd = scene["rays"][rank % 8]
+    eng = AnerfEngine(cfg, {k: T(v, device) for k, v in sd.items()}, T(bone_align_transforms(rest), device))
+    inp = dict(rays_o=T(ro, device), rays_d=T(rd, device), skts=T(scene["skts"], device), bones=T(scene["bones"], device),
+               cyls=T(scene["cyls"], device), cam_idx=torch.zeros(len(ro), dtype=torch.int64, device=device))
+    S, Sf = 48, 16
+    run = lambda: eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"], S, Sf)  # noqa: E731
+    elapsed, out = timed(run, args.steps, args.warmup, dist, device, args.debug_single_device)
+    n = len(ro) * (S + Sf)
+    Wd, inc, VW = cfg["W"], 432, cfg["view_W"]
+    mac = inc * Wd + 4 * Wd * Wd + (inc + Wd) * Wd + 2 * Wd * Wd + Wd + Wd * VW + 24 * VW + 3 * VW
+    ms = 1e3 * elapsed / args.steps
+    achieved = 2.0 * n * mac / (ms * 1e-3)
+    peak = PEAK_FP16_MFMA / 3.0
+    result = {
+        "metric": "ray-samples/sec at 512x512x64 samples (A-NeRF)", "value": world * n / (ms * 1e-3), "unit": "ray-samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (fp16x2-split MFMA products, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": "BASELINE config 5: A-NeRF anerf_base (cutoff PE, W = 448), 512x512 rays x (48 + 16) samples, tau = 20, "
+                               "every sample evaluated (A-NeRF has no in-volume mask)",
+                   "rays": len(ro), "samples_per_ray": S + Sf, "parallelism": f"rays-dp{world}"},
+        "roofline": dict(bound="mfma", kernel="A-NeRF trunk (whole frame)", achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+                         frac=achieved / peak, traffic=None, flop_per_row=2 * mac, flop_per_row_reference=2 * 2268000, peak_note=SPLIT_NOTE,
+                         note="FRAME-level lower bound: executed flops per sample x samples / whole frame time"),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import danbo_oracle as o
+        n_rays = 2048
+        r0 = (H // 2) * W - n_rays // 2
+        rb = syn.ray_batch(ro[r0:r0 + n_rays], rd[r0:r0 + n_rays])
+        z = np.zeros(n_rays, dtype=np.int64)
+        orc = o.AnerfOracle(cfg, sd, rest)
+        dt, ref = best_of(lambda: orc.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], np.zeros(n_rays, np.int64), 1, S, Sf),
+                          reps=2)
+        rgb = out["rgb_map"][r0:r0 + n_rays].cpu().numpy()
+        result["cpu_baseline"] = dict(value=n_rays * (S + Sf) / dt, unit="ray-samples/s", cores=int(os.cpu_count() or 1), kind="port",
+                                      sample=f"{n_rays} centre rays x {S}+{Sf} samples through oracle/danbo_oracle.AnerfOracle (numpy, BLAS "
+                                             f"threads), best of 2: {dt:.1f} s")
+        result["parity"] = dict(against="oracle AnerfOracle on the cpu_baseline sample", rays=n_rays,
+                                psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])), max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()))
+    return result
 
 
 def main():
@@ -98,18 +399,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4, 5],
+                    help="1: BASELINE metric (default); 2: danbo_fast 32+16 box bounds; 3: danbo_base 96+32; 4: training step; 5: A-NeRF")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
-    ap.add_argument("--coarse", type=int, default=N_SAMPLES, help="dev: coarse samples per ray (metric: 48)")
-    ap.add_argument("--fine", type=int, default=N_IMPORTANCE, help="dev: importance samples per ray (metric: 16)")
-    ap.add_argument("--box-near-far", action="store_true",
-                    help="dev: per-bone box near/far as in the danbo_fast configs (SURVEY 8d config 2: with --coarse 32 --fine 16)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the occupancy sweep (camera distance) of the render configs")
+    ap.add_argument("--coarse", type=int, default=None, help="dev: coarse samples per ray")
+    ap.add_argument("--fine", type=int, default=None, help="dev: importance samples per ray")
+    ap.add_argument("--box-near-far", action="store_true", help="dev: per-bone box near/far (config 2 sets it)")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="dev: every rank uses cuda:0 and the gloo backend (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
                     help="f16split: fp32-accurate products as 3 fp16 MFMAs (default); fp32: exact fp32 MFMA kernels")
     args = ap.parse_args()
-    N_SAMPLES, N_IMPORTANCE = args.coarse, args.fine
+    if args.config in CONFIGS:
+        N_SAMPLES, N_IMPORTANCE, box = CONFIGS[args.config]
+        args.box_near_far = args.box_near_far or box
+    N_SAMPLES = args.coarse or N_SAMPLES
+    N_IMPORTANCE = args.fine or N_IMPORTANCE
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,88 +435,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
 
-    eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
-    eng.cfg["use_volume_near_far"] = bool(args.box_near_far)
-    for _ in range(args.warmup):
-        render(eng, inp)
-    torch.cuda.synchronize()
-
-    eng.profile = {}
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = render(eng, inp)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if args.debug_single_device else device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    samples_per_frame = H * W * (N_SAMPLES + N_IMPORTANCE)
-    value = world * args.steps * samples_per_frame / elapsed
-
-    # ---- roofline of the dominant kernel from the HIP events recorded inside the timed region
-    prof = eng.profile["k_pe_mlp"]
-    eng.profile = None
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-    rows = sum(int(c.item()) if torch.is_tensor(c) else int(c) for _, _, c in prof)
-    mac = MAC_PER_ROW[args.mlp]
-    flops = 2.0 * mac * rows                          # EXECUTED multiply-adds of in-volume rows only
-    achieved = flops / (ms * 1e-3)
-    if args.mlp == "f16split":
-        kernel, peak = "k_pe_mlp16", PEAK_FP16_MFMA / 3.0
-        peak_note = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: every fp32-accurate product is three half-precision "
-                     "MFMA products (hi*hi + hi*lo + lo*hi); executed MFMA rate = 3 x achieved")
-    else:
-        kernel, peak = "k_pe_mlp", PEAK_FP32_MFMA
-        peak_note = "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01r_pmc_hbm.json")
-    if os.path.exists(pmc) and args.mlp == "f16split":
-        traffic = json.load(open(pmc))["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
-    roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s",
-                    frac=achieved / peak, traffic=traffic, launches=len(prof), avg_launch_ms=ms / len(prof),
-                    rows_per_launch=rows / len(prof), flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF,
-                    peak_note=peak_note,
-                    note="executed flops of rows inside >=1 bone volume only; traffic = HBM bytes per launch from "
-                         "rocprofv3 PMC passes (profiles/r01r_pmc_hbm.json, tools/pmc_hbm.sh), algorithmic bytes = 84 B per row")
-
-    result = {
-        "metric": f"ray-samples/sec at 512x512x{N_SAMPLES + N_IMPORTANCE} samples", "value": value, "unit": "ray-samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.mlp == "fp32" else "f32 (fp16x2-split MFMA products, fp32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": f"H36M danbo_base network, 512x512 rays x ({N_SAMPLES} coarse + {N_IMPORTANCE} importance) samples, "
-                               f"1 pose / 1 camera per rank, {'per-bone box' if args.box_near_far else 'cylinder'} near/far, "
-                               "exact in-volume culling",
-                   "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
-        "in_volume_fraction": rows / (args.steps * samples_per_frame),
-        "roofline": roofline,
-    }
+    fn = {4: bench_train, 5: bench_anerf}.get(args.config, bench_render)
+    result = fn(args, rank, world, device, dist)
     if rank == 0:
-        if not args.no_dense and world == 1:
-            render(eng, inp, dense=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            nd = 2
-            for _ in range(nd):
-                out_d = render(eng, inp, dense=True)
-            torch.cuda.synchronize()
-            td = (time.perf_counter() - t1) / nd
-            result["dense_value"] = samples_per_frame / td
-            result["dense_ms_per_step"] = 1e3 * td
-            result["dense_mlp_tflops_lower_bound"] = 2.0 * mac * samples_per_frame / td / 1e12
-            result["dense_equals_culled"] = bool(torch.equal(out_d["rgb_map"], out["rgb_map"]))
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"], parity = cpu_baseline(extra, frame=out)
-            if parity is not None:
-                result["parity"] = parity
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

@@ -119,8 +119,10 @@ class AnerfEngine:
                             self.rgb_w, self.rgb_b, head[:, self.VW], raw)
         return dens if density_only else raw
 
-    def density(self, pts, skts, bones=None):
-        return self.forward_samples(None, None, skts, pts=pts.reshape(-1, 1, 3), density_only=True)
+    def density(self, pts, skts, bones=None, netchunk=1024 * 64):
+        pts = pts.reshape(-1, 1, 3)
+        return torch.cat([self.forward_samples(None, None, skts, pts=pts[a:a + netchunk], density_only=True)
+                          for a in range(0, pts.shape[0], netchunk)], 0)
 
     # ------------------------------------------------------------------ RayCaster.render_rays (eval)
     def near_far(self, rays_o, rays_d, cyls, skts=None, near0=0.0, far0=1.0, chunk=4096):

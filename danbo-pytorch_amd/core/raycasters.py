@@ -221,6 +221,10 @@ class RayCaster(nn.Module):
             raise NotImplementedError("N_importance=0 raises in the reference too (raycasters.py:377)")
         if perturb or raw_noise_std or ray_noise_std or lindisp:
             raise NotImplementedError("stochastic sampling belongs to the training path")
+        if render_confd or render_entropy:
+            # the reference swaps the colours for get_confidence_rgb / get_entropy_rgb (nerf.py:306-311, misc.py:620-673): a
+            # visualisation outside the hot path -- refuse instead of handing back ordinary RGB under that name
+            raise NotImplementedError("render_confd / render_entropy colourings are not implemented")
         eng = self._engine()
         G = int(N_uniques)
         skts_g, bones_g, cyls_g = self._per_pose(skts, G), self._per_pose(bones, G), self._per_pose(cyls, G)
@@ -293,16 +297,16 @@ class RayCaster(nn.Module):
     def render_pts_density(self, pts, kps, skts, bones, netchunk=1024 * 64, network=None):
         assert kps.shape[0] == 1, f'Assuming only one pose is provided, got {kps.shape[0]} instead'
         eng = self._engine()
-        return eng.density(pts.reshape(-1, 1, 3), skts[:1], bones[:1])
+        return eng.density(pts.reshape(-1, 1, 3), skts[:1], bones[:1], netchunk=int(netchunk))
 
     @torch.no_grad()
     def render_mesh_density(self, kps, skts, bones, subject_idxs=None, radius=1.0, res=64, render_kwargs=None,
                             netchunk=1024 * 64, v=None):
-        t = torch.linspace(-radius, radius, res + 1, device=kps.device)
-        gx, gy, gz = torch.meshgrid(t, t, t, indexing='xy')
-        grid = torch.stack([gx, gy, gz], -1)
-        dens = self.render_pts_density(grid.reshape(-1, 1, 3) + kps[0, 0], kps, skts, bones)[..., :1]
-        return dens.reshape(*grid.shape[:-1]).transpose(1, 0)
+        # the reference's grid (raycasters.py:425-429): float64 linspace rounded to float32, 'xy' meshgrid, + the root joint
+        t = np.linspace(-radius, radius, res + 1)
+        grid = torch.tensor(np.stack(np.meshgrid(t, t, t), axis=-1).astype(np.float32), device=kps.device)
+        dens = self.render_pts_density(grid.reshape(-1, 3) + kps[0, 0], kps, skts, bones, netchunk)[..., :1]
+        return dens.reshape(*grid.shape[:-1]).transpose(1, 0)      # x-y swapped, as the mesh extraction expects
 
 
 class _GraphCache:

@@ -40,18 +40,21 @@ class DanboEngine:
             return
         p = self.p
         dev = p["alpha_linear.weight"].device
-        self.pts_w = [p[f"pts_linears.{i}.weight"] for i in range(8)]
-        self.pts_b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(8)]
-        self.packed, self.wrt = ops.mlp_pack(self.pts_w, p["feature_linear.weight"], p["views_linears.0.weight"])
-        self.packed16, self.views_b16 = ops.mlp16_pack(self.pts_w, p["feature_linear.weight"],
-                                                       p["feature_linear.bias"], p["views_linears.0.weight"],
-                                                       p["views_linears.0.bias"])
-        self.alpha_w = p["alpha_linear.weight"].reshape(-1).contiguous()
-        self.alpha_b = p["alpha_linear.bias"].contiguous()
-        self.feature_b = p["feature_linear.bias"].contiguous()
-        self.views_b = p["views_linears.0.bias"].contiguous()
-        self.rgb_w = p["rgb_linear.weight"].contiguous()
-        self.rgb_b = p["rgb_linear.bias"].contiguous()
+        q = self._equalized(p) if self.mlp_mode == "f16split" else p
+        self.pts_w = [q[f"pts_linears.{i}.weight"] for i in range(8)]
+        self.pts_b = [q[f"pts_linears.{i}.bias"].contiguous() for i in range(8)]
+        self.packed, self.wrt = ops.mlp_pack(self.pts_w, q["feature_linear.weight"], q["views_linears.0.weight"])
+        self.packed16, self.views_b16 = ops.mlp16_pack(self.pts_w, q["feature_linear.weight"],
+                                                       q["feature_linear.bias"], q["views_linears.0.weight"],
+                                                       q["views_linears.0.bias"])
+        self.alpha_w = q["alpha_linear.weight"].reshape(-1).contiguous()
+        self.alpha_b = q["alpha_linear.bias"].contiguous()
+        self.feature_b = q["feature_linear.bias"].contiguous()
+        self.views_b = q["views_linears.0.bias"].contiguous()
+        self.rgb_w = q["rgb_linear.weight"].contiguous()
+        self.rgb_b = q["rgb_linear.bias"].contiguous()
+        # power of two the view layer's pre-activations (cview, empty_consts[:128]) are multiplied by, see _equalized
+        self.view_scale = q.get("_view_scale", torch.ones((), device=dev))
         g = "graph_net.layers."
         self.gw = dict(
             w0=p[g + "0.lin.weight"].contiguous(), adjw0=(p[g + "0.adj_w"] * p[g + "0.adj"])[0].contiguous(),
@@ -82,6 +85,54 @@ class DanboEngine:
         self.empty_consts = self._mlp(h0, 1, None, scratch_raw, aux=True).reshape(-1).contiguous()
         self._built_mode = self.mlp_mode
         self._packed_key = key
+
+    @staticmethod
+    def _equalized(p):
+        """Range guard of the fp16 hi/lo-split kernels (k_pe_mlp16): an EXACT re-parametrisation of the MLP by powers of two.
+
+        A ReLU layer commutes with positive scaling, relu(r (W x + b)) = r relu(W x + b), so with per-layer factors r_l = 2^k:
+            W'_l = r_l W_l / r_{l-1},  b'_l = r_l b_l   =>   y'_l = r_l y_l,
+        and the heads divide the factor out again (alpha_linear, feature_linear by r_7; rgb_linear by the view layer's r_v).
+        Powers of two commute with every fp32 rounding and with the hi/lo split, so as long as nothing leaves fp16's range the
+        kernel's result is bit-identical; what changes is WHERE the numbers sit: r_l is chosen so that a layer's gain on its
+        scaled input (RMS row norm x 0.7 for the ReLU) is ~1 and its largest bias stays below 2^10, which keeps activations near
+        the size of the positional encoding whatever the checkpoint's scale is (weights of 1e-3 or 1e3 times the usual size would
+        otherwise run the activations out of fp16's 6e-5 .. 65504).  Everything stays on the device (no host sync); the
+        exact-fp32 kernels (mlp_mode = 'fp32') take the parameters as they are."""
+        q = dict(p)
+        one = torch.ones((), device=p["alpha_linear.weight"].device)
+        tiny = torch.finfo(torch.float32).tiny
+
+        def pow2(x):   # power of two nearest to x (> 0) in log scale, clamped to 2^+-100 (fp32 itself ends at 2^+-126)
+            return torch.exp2(torch.clamp(torch.round(torch.log2(torch.clamp(x, min=tiny))), -100, 100))
+
+        def factor(w_eff, b):
+            gain = torch.sqrt((w_eff.double() ** 2).sum(1).mean()).float() * 0.7
+            r = pow2(1.0 / torch.clamp(gain, min=tiny))
+            cap = torch.exp2(torch.clamp(torch.floor(torch.log2(1024.0 / torch.clamp(b.abs().max(), min=tiny))), -100, 100))
+            return torch.minimum(r, cap)
+
+        r_prev = one
+        n_in = p["pts_linears.0.weight"].shape[1]
+        for l in range(8):
+            w, b = p[f"pts_linears.{l}.weight"], p[f"pts_linears.{l}.bias"]
+            if l == 0:
+                w_eff = w
+            elif w.shape[1] > p["pts_linears.1.weight"].shape[1]:      # the skip layer: [input | h]
+                w_eff = torch.cat([w[:, :n_in], w[:, n_in:] / r_prev], 1)
+            else:
+                w_eff = w / r_prev
+            r = factor(w_eff, b)
+            q[f"pts_linears.{l}.weight"], q[f"pts_linears.{l}.bias"] = (w_eff * r).contiguous(), (b * r).contiguous()
+            r_prev = r
+        q["alpha_linear.weight"] = (p["alpha_linear.weight"] / r_prev).contiguous()
+        q["feature_linear.weight"] = (p["feature_linear.weight"] / r_prev).contiguous()
+        wv, bv = p["views_linears.0.weight"], p["views_linears.0.bias"]
+        rv = factor(wv, bv)
+        q["views_linears.0.weight"], q["views_linears.0.bias"] = (wv * rv).contiguous(), (bv * rv).contiguous()
+        q["rgb_linear.weight"] = (p["rgb_linear.weight"] / rv).contiguous()
+        q["_view_scale"] = rv
+        return q
 
     def _mlp(self, h, S, cview, raw, lst=None, cnt=None, n=None, aux=False):
         if self.mlp_mode == "f16split":
@@ -135,16 +186,24 @@ class DanboEngine:
         extras = dict(valid_bits=bits, list=lst, count=cnt, confd_rows=confd, h_rows=h, volumes=vols)
         return raw, extras
 
-    def density(self, pts, skts, bones):
+    def density(self, pts, skts, bones, netchunk=1024 * 64):
         """NeRF.forward_pts (reference nerf.py:150-154): raw density of arbitrary points [M,1,3]."""
         self.refresh()
         M = pts.shape[0]
-        dummy = torch.zeros(M, 3, device=pts.device)
-        raw_empty = torch.zeros(M, 4, device=pts.device)
-        raw_empty[:, 3] = self.empty_consts[128]
-        cview = torch.zeros(M, ops.VIEW_W, device=pts.device)
-        raw, _ = self.forward_samples(dummy, dummy, skts, bones, pts=pts, view=(cview, raw_empty))
-        return raw[..., 3:4].reshape(M, 1)
+        out = torch.empty(M, 1, device=pts.device, dtype=torch.float32)
+        vols = self.volumes(bones)
+        # netchunk points at a time, as the reference (raycasters.py:421-453): a 256^3 grid in one piece would need > 10 GB of
+        # per-point buffers.  The colour head's per-ray inputs are irrelevant for the density: zero rows, allocated per chunk.
+        for a in range(0, M, netchunk):
+            p = pts[a:a + netchunk].contiguous()
+            n = p.shape[0]
+            dummy = torch.zeros(n, 3, device=pts.device)
+            raw_empty = torch.zeros(n, 4, device=pts.device)
+            raw_empty[:, 3] = self.empty_consts[128]
+            cview = torch.zeros(n, ops.VIEW_W, device=pts.device)
+            raw, _ = self.forward_samples(dummy, dummy, skts, bones, pts=p, volumes=vols, view=(cview, raw_empty))
+            out[a:a + n] = raw[..., 3:4].reshape(n, 1)
+        return out
 
     # ------------------------------------------------------------------ the same chain behind ONE C call
     def render_frame_c(self, rays_o, rays_d, skts, bones, cyls, cam_idx=None, N_samples=None, N_importance=None, chunk=4096):

@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _hip
+from . import custom_ops  # noqa: F401  (registers torch.ops.danbo.*)
 from . import hip_ops as ops
 
 
@@ -58,31 +59,6 @@ class GatherFn(torch.autograd.Function):
                 _p(geo.align), _p(axis_scale), _p(volumes.contiguous()), _p(rows), ctx.n, _p(g), _p(d_vol), _p(d_sc),
                 ops._stream()), "danbo_bone_gather_bwd")
         return d_vol, d_sc, None, None
-
-
-class CompositeFn(torch.autograd.Function):
-    """NeRF.raw2outputs with gradients for rgb_map and acc_map (K4)."""
-
-    @staticmethod
-    def forward(ctx, raw, z, rays_d, B, noise):
-        out = ops.composite(raw.detach(), z, rays_d, B, noise)
-        ctx.B = float(B)
-        ctx.save_for_backward(raw.detach().contiguous(), z.contiguous(), rays_d.contiguous(),
-                              noise if noise is not None else torch.empty(0, device=raw.device))
-        ctx.mark_non_differentiable(out["disp_map"], out["weights"], out["alpha"])
-        return out["rgb_map"], out["disp_map"], out["acc_map"], out["weights"], out["alpha"]
-
-    @staticmethod
-    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_alpha):
-        raw, z, rays_d, noise = ctx.saved_tensors
-        R, S = z.shape
-        d_raw = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
-        g_rgb = (g_rgb if g_rgb is not None else torch.zeros(R, 3, device=raw.device)).contiguous().float()
-        g_acc = (g_acc if g_acc is not None else torch.zeros(R, device=raw.device)).contiguous().float()
-        _hip.check(_hip.lib().danbo_composite_bwd(
-            _p(raw), _p(z), _p(rays_d), R, S, ctx.B, _p(noise if noise.numel() else None), _p(g_rgb), _p(g_acc),
-            _p(d_raw), ops._stream()), "danbo_composite_bwd")
-        return d_raw, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -122,8 +98,9 @@ def linear(layer, x):
 
 
 def composite(raw, z, rays_d, B=1.0, noise=None):
-    rgb, disp, acc, w, al = CompositeFn.apply(raw.contiguous().float(), z.contiguous().float(),
-                                              rays_d.reshape(-1, 3).contiguous().float(), B, noise)
+    """NeRF.raw2outputs with gradients for rgb_map and acc_map (K4): torch.ops.danbo.composite (core/custom_ops.py)"""
+    rgb, disp, acc, w, al = torch.ops.danbo.composite(raw.contiguous().float(), z.contiguous().float(),
+                                                      rays_d.reshape(-1, 3).contiguous().float(), float(B), noise)
     return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
 
 
@@ -277,7 +254,7 @@ def forward_train(model, inputs):
     if "vols" not in shared:
         shared["vols"] = pose_volumes(model, bones_g)
     vols = shared["vols"]
-    part_feat = GatherFn.apply(vols, axis_scale, geo, rows)
+    part_feat = torch.ops.danbo.bone_gather(vols, axis_scale, pts, skts_g, align, rows)
     logits = assignment_logits(model, part_feat)
     shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
     valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()

@@ -104,6 +104,15 @@ def _dist_env():
     return rank, world, local
 
 
+def sync_replicas(module, src=0):
+    """parameters and buffers of every rank := rank `src`'s (no-op without a process group)"""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            torch.distributed.broadcast(t.data, src=src)
+
+
 def validate(args, render_data, render_kwargs_test, device, vid_base):
     t = lambda x: torch.tensor(np.ascontiguousarray(x)).to(device)  # noqa: E731
     gt, fg, bgs, bg_idx = render_data["imgs"], render_data["fgs"], render_data["bgs"], render_data.get("bg_idxs")
@@ -124,7 +133,10 @@ def train(argv=None):
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     np.random.seed(0)
-    torch.manual_seed(rank)
+    # every rank builds the SAME network: replicas are kept identical by averaging gradients only (core/trainer.py), so the
+    # initial weights must agree -- one seed while the model is created, a broadcast from rank 0 for good measure, and only
+    # then per-rank streams for the stratified offsets / density noise
+    torch.manual_seed(0)
 
     train_iter, render_data, data_attrs = load_data(args, device=device, rank=rank, world=world)
     logdir = os.path.join(args.basedir, args.expname)
@@ -138,6 +150,8 @@ def train(argv=None):
                 f.write(open(args.config).read())
 
     kw_train, kw_test, start, grad_vars, optimizer, _ = create_raycaster(args, data_attrs, device=device)
+    sync_replicas(kw_train['ray_caster'])
+    torch.manual_seed(rank + 1)
     trainer = Trainer(args, data_attrs, optimizer, None, kw_train, kw_test, None, device=device)
     global_step = start
     log = open(os.path.join(logdir, 'scalars.jsonl'), 'a') if rank == 0 else None

@@ -18,6 +18,9 @@ Fixtures
                      raw_noise_std = 0: the four loss terms of Trainer.compute_loss and gradients
   danbo_perfcap_train.npz  D-Perf (relray/root_local, box near/far), 192 rays = 4 poses x 48, 16+8 samples, training
                      mode (perturb = 0, noise = 0): loss terms, gradient norms and gradients of the reference's autograd
+  danbo_h36m_fast.npz  BASELINE config 2: H36M danbo_fast (box near/far, 32 + 16, frame codes), 256 rays of 2 poses: bounds,
+                     coarse raw, final maps
+  danbo_mesh.npz     D-H36M, RayCaster.render_mesh_density at res = 16 (17^3 raw densities around the root joint)
   anerf_stages.npz   A-H36M (anerf_base net: cutoff PE, W = 448), 48 rays = 2 poses x 24, 12+6 samples, at
                      tau = 20 (step 0) with every stage tensor, and raw + final maps again at tau = 2000
   anerf_train.npz    A-H36M, 96 rays = 4 poses x 24, 12+6 samples, training mode (perturb = 0, noise = 0): loss terms and
@@ -316,6 +319,57 @@ def gen_danbo_perfcap_train():
           "in-volume fraction", 1.0 - float(preds["part_invalid"].detach().numpy().all(-1).mean()))
 
 
+def gen_danbo_mesh():
+    """mesh-density path (reference raycasters.py:421-453): raw density on a (res+1)^3 grid around the root joint, res = 16,
+    H36M danbo_base network; netchunk 1000 so that the chunked evaluation is exercised"""
+    seed = 19
+    cfg, args, caster, kw_test, rest = build("danbo_base", seed)
+    scene = syn.make_scene(n_poses=1, H=32, W=32, n_views=1, pose_seed=41)
+    kps, skts, bones = T(scene["kps"][:1]), T(scene["skts"][:1]), T(scene["bones"][:1])
+    with torch.no_grad():
+        dens = caster(kps, skts, bones, fwd_type='mesh', radius=0.9, res=16, netchunk=1000)
+    np.savez_compressed(os.path.join(OUT, "danbo_mesh.npz"), cfg_name="danbo_base", weight_seed=seed, n_framecodes=20, res=16,
+                        radius=0.9, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], density=dens.numpy())
+    print("danbo_mesh:", dens.shape, "non-constant fraction", float((dens != dens.flatten()[0]).float().mean()))
+
+
+def gen_danbo_h36m_fast():
+    """BASELINE config 2: H36M danbo_fast (world rays + identity view + frame codes, per-bone box near/far, 32 + 16 samples):
+    bounds, coarse raw and the final maps of the reference's caster on 256 body rays of 2 poses"""
+    seed = 21
+    cfg, args, caster, kw_test, rest = build("danbo_fast", seed)
+    scene = syn.make_scene(n_poses=2, H=96, W=96, n_views=4, pose_seed=51)
+    ro, rd, pose = [], [], []
+    for p_ in range(2):
+        o, d = body_rays(scene, p_ + 1, 128, seed=400 + p_)
+        ro.append(o); rd.append(d); pose += [p_] * 128
+    ro, rd, pose = np.concatenate(ro), np.concatenate(rd), np.array(pose)
+    rb = syn.ray_batch(ro, rd)
+    kps, skts, bones, cyls = per_ray(scene, pose)
+    S, Sf = 32, 16
+    cam_idx = (np.arange(len(pose)) // 128 * 5 + 2).astype(np.int64)
+    cams = T(cam_idx, torch.long)
+    fin = call_caster(caster, kw_test, rb, kps, skts, cyls, bones, cams, S, Sf, 2)
+    net = caster.network
+    with torch.no_grad():
+        rays_o, rays_d = T(ro), T(rd)
+        near, far = caster.get_near_far(rays_o, rays_d, T(cyls), near=T(rb[:, 6:7]), far=T(rb[:, 7:8]), skts=T(skts))
+        pts, z = caster.sample_pts(rays_o, rays_d, near, far, len(ro), S, 0., False)
+        inputs = caster.get_nerf_inputs(pts, [rays_o[:, None, :], rays_d[:, None, :]], T(kps), T(skts), T(bones),
+                                        cam_idxs=cams, N_uniques=2)
+        raw, enc = net(inputs)
+    invalid = enc["part_invalid"].numpy() if "part_invalid" in enc else None
+    np.savez_compressed(
+        os.path.join(OUT, "danbo_h36m_fast.npz"),
+        cfg_name="danbo_fast", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=2,
+        ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"], pose_of_ray=pose,
+        cam_idx=cam_idx, rest_pose=rest, near=near.numpy(), far=far.numpy(), raw_coarse=raw.numpy(),
+        **({} if invalid is None else {"in_volume_fraction": np.float64(1.0 - invalid.all(-1).mean())}),
+        **{"final_" + k: v for k, v in fin.items()})
+    print("danbo_h36m_fast: acc mean", fin["acc_map"].mean(), "rays hitting a box",
+          float((np.abs(near.numpy() - near.numpy().mean()) > 0).mean()))
+
+
 def gen_anerf_stages():
     seed = 15
     cfg, args, caster, kw_test, rest = build("anerf_base", seed)
@@ -557,7 +611,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "mesh", "h36m_fast", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -574,6 +628,10 @@ if __name__ == "__main__":
         gen_anerf_train()
     if "perfcap_train" in which:
         gen_danbo_perfcap_train()
+    if "mesh" in which:
+        gen_danbo_mesh()
+    if "h36m_fast" in which:
+        gen_danbo_h36m_fast()
     if "ckpt" in which:
         gen_ckpt_manifest()
     if "args" in which:

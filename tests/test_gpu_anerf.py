@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import danbo_oracle as o
-from helpers import ROOT, golden, oracle_for, max_err, rel_err
+from helpers import ROOT, golden, oracle_for, max_err, rel_err, raw_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -89,12 +89,12 @@ def test_model_forward_matches_reference_raw(env):
                   N_uniques=2, rays_o=T(rb[:, None, 0:3]), rays_d=T(rb[:, None, 3:6]), cam_idxs=T(g["cam_idx"], torch.int64))
     raw, enc = caster.network(inputs)
     assert raw.shape == (48, 12, 4)
-    assert rel_err(N(raw), g["raw_coarse"], floor=1.0) < 2e-4
+    assert raw_err(N(raw), g["raw_coarse"]) < 2e-4
     # small row chunks (whole rays per chunk) give the same result
     caster._engine().rows_per_chunk = 5 * 12
     raw2, _ = caster.network(inputs)
     caster._engine().rows_per_chunk = 1 << 18
-    assert rel_err(N(raw2), N(raw), floor=1.0) < 1e-5
+    assert raw_err(N(raw2), N(raw)) < 1e-5
 
 
 def test_caster_call_matches_reference_maps_tau20_and_tau2000(env):
@@ -140,4 +140,4 @@ def test_full_render_against_oracle_and_density_query(env):
     dens = caster(T(pts).reshape(-1, 1, 3), T(scene["kps"]), T(scene["skts"]), T(scene["bones"]), fwd_type="density")
     raw, _ = orc.forward(pts.reshape(-1, 1, 3), np.zeros((500, 3), np.float32) + [0, 0, 1],
                          np.repeat(scene["skts"], 500, 0), cam_idxs=None)
-    assert rel_err(N(dens).reshape(-1), raw[:, 0, 3], floor=1.0) < 2e-4
+    assert raw_err(N(dens).reshape(-1), raw[:, 0, 3]) < 2e-4

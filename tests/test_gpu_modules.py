@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import danbo_oracle as o
-from helpers import ROOT, golden, max_err, rel_err
+from helpers import ROOT, golden, max_err, rel_err, raw_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -65,7 +65,7 @@ def test_model_forward_on_reference_nerf_inputs():
                   N_uniques=2, rays_o=T(rb[:, None, 0:3]), rays_d=T(rb[:, None, 3:6]), cam_idxs=T(g["cam_idx"], torch.int64))
     raw, enc = caster.network(inputs)
     assert raw.shape == (R, int(g["N_samples"]), 4)
-    assert rel_err(N(raw), g["raw_coarse"], floor=1.0) < 1e-4
+    assert raw_err(N(raw), g["raw_coarse"]) < 1e-4
     out = caster.network.raw2outputs(raw, T(g["z_coarse"]), T(rb[:, 3:6]), B=1.0)
     assert max_err(N(out["weights"]), g["weights_coarse"]) < 2e-5
     assert max_err(N(out["rgb_map"]), g["rgb_coarse"]) < 2e-5
@@ -90,7 +90,7 @@ def test_density_query_for_mesh_extraction():
     pts = g["pts"][:24].reshape(-1, 1, 3)                       # samples of pose 0
     dens = caster(T(pts), T(g["kps"][:1]), T(g["skts"][:1]), T(g["bones"][:1]), fwd_type="density")
     want = g["raw_coarse"][:24].reshape(-1, 4)[:, 3:4]
-    assert rel_err(N(dens), want, floor=1.0) < 1e-4
+    assert raw_err(N(dens), want) < 1e-4
 
 
 def test_long_rays_96_plus_48_samples_against_oracle():

@@ -102,3 +102,80 @@ def test_gradient_allreduce_world2_keeps_replicas_identical():
     assert np.allclose(g0, (l0 + l1) / 2) and np.array_equal(g0, g1)       # mean of the rank gradients, on both
     assert not z0.any() and not z1.any()                                   # missing gradient == zero contribution
     assert all(np.array_equal(a, b) for a, b in zip(p0, p1))               # replicas stay bit-identical
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "danbo-pytorch_amd"))
+    from run_nerf import sync_replicas
+    torch.manual_seed(100 + rank)                           # ranks that (wrongly) built their networks from different streams
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5))
+    net[1].running_mean.add_(float(rank))
+    sync_replicas(net)
+    q.put((rank, [t.detach().numpy().copy() for t in list(net.parameters()) + list(net.buffers())]))
+    dist.destroy_process_group()
+
+
+def test_replicas_start_identical_world2():
+    """run_nerf.train seeds every rank alike while the model is built and broadcasts rank 0's parameters and buffers: without
+    that, averaging gradients alone would train N different models (the advisor's finding on round 1)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+
+
+def _fused_worker(rank, world, port, q):
+    """two ranks on ONE GPU (gloo carries the collectives): the real Trainer.train_batch, fused HIP step, flat-gradient all-reduce"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(os.path.dirname(here), "danbo-pytorch_amd"), os.path.join(os.path.dirname(here), "oracle"), here):
+        sys.path.insert(0, p)
+    from helpers import golden
+    from test_gpu_training import batch_of, build_trainer
+    g = golden("danbo_perfcap_train")
+    args, caster, trainer, opt = build_trainer(g, extra=["--raw_noise_std", "1.0", "--perturb", "1.0"])
+    full = batch_of(g)
+    n = full["rays_o"].shape[0] // world                     # whole poses per rank (4 poses, 2 ranks)
+    sl = slice(rank * n, (rank + 1) * n)
+    mine = {k: (v[sl] if torch.is_tensor(v) else v) for k, v in full.items()}
+    mine["N_uniques"] = full["N_uniques"] // world
+    torch.manual_seed(1 + rank)                              # different noise per rank, as in run_nerf.train
+    losses = []
+    for i in range(3):
+        loss, stats = trainer.train_batch(mine, i=i, global_step=i)
+        losses.append(stats["total_loss"])
+    assert trainer.engine is not None, trainer.fused_reason
+    torch.cuda.synchronize()
+    q.put((rank, trainer.engine.flat_p.detach().cpu().numpy().copy(), losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fused_training_world2_on_one_gpu_keeps_replicas_bit_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import numpy as np
+    assert np.array_equal(res[0][1], res[1][1])              # every parameter, bit for bit, after 3 steps
+    assert all(np.isfinite(l) for r in res for l in r[2]) and res[0][2] != res[1][2]    # the shards (and their losses) differ

@@ -6,10 +6,10 @@ TAG=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmchbm_$TAG
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense > $OUT.$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense --no-sweep > $OUT.$c.log 2>&1
 done
 python3 - <<PY
-import csv, glob, json, os, collections
+import csv, glob, hashlib, json, os, collections
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmchbm_$TAG"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -20,6 +20,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1; hbm_bytes = "
                "(2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md; averages over "
                "the coarse and fine launches of a frame", "kernels": {}}
+# bench.py only quotes these numbers for the kernel sources they were measured on
+h = hashlib.sha256()
+for f in ("k_mlp16.hip", "common.hpp"):
+    h.update(open(os.environ["GRAFT_REPO_ROOT"] + "/danbo-pytorch_amd/csrc/" + f, "rb").read())
+out["kernel_src_sha16"] = h.hexdigest()[:16]
 for k, d in acc.items():
     if not k.startswith("danbo::") and "danbo" not in k:
         continue
