@@ -192,10 +192,19 @@ def bench_render(args, rank, world, device, dist):
         if rec.get("kernel_src_sha16") == sha16("k_mlp16.hip", "common.hpp"):
             traffic = rec["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
             traffic_note = "HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source (profiles/r02_pmc_hbm.json)"
+    # algorithmic HBM bytes of a launch: 84 B per row (64 B h + 4 B list entry + 16 B raw) + the 512-byte per-ray view constants of
+    # every ray that owns >= 1 row (counted on the coarse pass of one extra, untimed frame)
+    keep = eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"], N_SAMPLES, N_IMPORTANCE,
+                      chunk=4096, keep=True)
+    rays_hit = int((keep["valid_bits"].view(H * W, N_SAMPLES) != 0).any(1).sum())
+    algo_bytes = 84.0 * rows / len(prof) + 512.0 * rays_hit
+    del keep
     roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak,
-                    traffic=traffic, launches=len(prof), avg_launch_ms=ms / len(prof), rows_per_launch=rows / len(prof),
-                    flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF, peak_note=peak_note,
-                    note="executed flops of rows inside >=1 bone volume only; algorithmic bytes = 84 B per row; " + traffic_note)
+                    traffic=traffic, algorithmic_bytes=algo_bytes, launches=len(prof), avg_launch_ms=ms / len(prof),
+                    rows_per_launch=rows / len(prof), flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF,
+                    peak_note=peak_note,
+                    note="executed flops of rows inside >=1 bone volume only; algorithmic bytes per launch = 84 B per row + 512 B of "
+                         "per-ray view constants for every ray with >= 1 row; " + traffic_note)
     names = {1: "H36M danbo_base network", 2: "H36M danbo_fast (BASELINE config 2)", 3: "H36M danbo_base (BASELINE config 3)"}
     result = {
         "metric": f"ray-samples/sec at 512x512x{N_SAMPLES + N_IMPORTANCE} samples", "value": value, "unit": "ray-samples/s",

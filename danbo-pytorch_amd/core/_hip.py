@@ -74,6 +74,7 @@ SIGNATURES = {
     "danbo_adam_step": [P, P, P, P, c_long, P, F, F, F, P],
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],
+    "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
 }
 # everything else returns int (0 = ok)
 RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t, "danbo_linear16_group_bytes": c_long,

@@ -154,6 +154,26 @@ def gather_assign_blend(geo, volumes, bits, aw, lst=None, cnt=None, n=None, want
 ASSIGN16_PACKED_BYTES = 262144
 
 
+_SMPL_PARENTS = [0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+_ADJ_CHECKED = set()
+
+
+def check_smpl_adjacency(adj):
+    """k_assign16 (the fp16-split K2 kernel) walks the SMPL tree's neighbour table, compiled in (csrc/k_assign16.hip a16_nb): a
+    checkpoint whose `adj` buffer describes another graph must not be evaluated with it silently.  Checked once per buffer."""
+    key = (adj.data_ptr(), adj._version)
+    if key in _ADJ_CHECKED:
+        return
+    want = torch.eye(J)
+    for i, p_ in enumerate(_SMPL_PARENTS):
+        if i != p_:
+            want[i, p_] = want[p_, i] = 1.0
+    if not torch.equal((adj.detach().reshape(J, J) != 0).cpu(), want != 0):
+        raise NotImplementedError("the assignment net's adjacency is not the SMPL tree: the fast K2 kernel (k_assign16) has that "
+                                  "tree compiled in -- use mlp_mode='fp32' (k_assign_blend reads the adjacency it is given)")
+    _ADJ_CHECKED.add(key)
+
+
 def assign16_pack(aw):
     """fp16 hi/lo fragments of the assignment GNN with the adjacency folded into layer 0."""
     packed = torch.empty(ASSIGN16_PACKED_BYTES, device=aw["w0"].device, dtype=torch.uint8)

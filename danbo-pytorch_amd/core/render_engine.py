@@ -69,6 +69,8 @@ class DanboEngine:
             b0=p[a + "0.bias"].contiguous(), w1=p[a + "1.weight"].contiguous(),
             b1=p[a + "1.bias"].reshape(24, -1).contiguous(), w2=p[a + "2.weight"].reshape(24, -1).contiguous(),
             b2=p[a + "2.bias"].reshape(-1).contiguous())
+        if self.mlp_mode == "f16split":
+            ops.check_smpl_adjacency(p[a + "0.adj"])
         self.assign16 = ops.assign16_pack(self.aw)
         self.axis_scale = p["graph_net.axis_scale"].contiguous()
         if self.cfg["use_framecode"]:

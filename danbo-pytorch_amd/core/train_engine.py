@@ -136,8 +136,8 @@ class DanboTrainEngine:
         keep['adj0'] = gl[0].adj.detach().float().reshape(24, 24).contiguous()
         keep['adj1'] = gl[1].adj.detach().float().reshape(24, 24).contiguous()
         keep['adja'] = pl[0].adj.detach().float().reshape(24, 24).contiguous()
-        if max(int((keep[k] != 0).sum(1).max()) for k in ('adja',)) > 6:
-            raise NotImplementedError("assignment-net adjacency with more than 5 neighbours per bone")
+        from . import hip_ops
+        hip_ops.check_smpl_adjacency(pl[0].adj)      # the forward of the step runs k_assign16 (SMPL neighbour table compiled in)
         keep['align'] = self.caster.transforms[0].to(self.device).float().contiguous()
         keep['init_scale'] = net.graph_net.init_scale.to(self.device).float().contiguous()
         m.g_adj0, m.g_adj1, m.a_adj = (keep[k].data_ptr() for k in ('adj0', 'adj1', 'adja'))
@@ -159,19 +159,23 @@ class DanboTrainEngine:
         return m
 
     # ------------------------------------------------------------------ one forward + backward
-    def _launch(self, t, S, Sf, perturb, raw_noise_std):
-        """t: dict of static input tensors; -> dict of outputs (device tensors)"""
+    def _launch(self, t, S, Sf, perturb, raw_noise_std, split=False):
+        """t: dict of static input tensors; -> dict of outputs (device tensors).  split: only phase 1 (see _step_phase)"""
         m = self._model()
         R, G = t['rays_o'].shape[0], t['skts'].shape[0]
         dev = self.device
         B = m.density_scale
+        # the step's random draws: ONE uniform and ONE normal generator launch (+ one scaling), carved into the four tensors the
+        # C side wants contiguous: stratified offsets [R,S], inverse-CDF uniforms [R,Sf], density noise [R,S] and [R,S+Sf]
         rnd = {}
         if perturb > 0.:
-            rnd['t_rand'] = torch.rand(R, S, device=dev)
-            rnd['u_rand'] = torch.rand(R, Sf, device=dev)
+            u = torch.rand(R * (S + Sf), device=dev)
+            rnd['_u'] = u
+            rnd['t_rand'], rnd['u_rand'] = u[:R * S].view(R, S), u[R * S:].view(R, Sf)
         if raw_noise_std > 0.:
-            rnd['noise_c'] = torch.randn(R, S, device=dev) * (raw_noise_std * B)
-            rnd['noise_f'] = torch.randn(R, S + Sf, device=dev) * (raw_noise_std * B)
+            nz = torch.randn(R * (2 * S + Sf), device=dev).mul_(raw_noise_std * B)
+            rnd['_n'] = nz
+            rnd['noise_c'], rnd['noise_f'] = nz[:R * S].view(R, S), nz[R * S:].view(R, S + Sf)
         out = dict(rgb_map=(R, 3), disp_map=(R,), acc_map=(R,), alpha=(R, S + Sf), weights=(R, S + Sf), rgb0=(R, 3), disp0=(R,),
                    acc0=(R,), alpha0=(R, S), loss=(4,))
         out = {k: torch.empty(v, device=dev, dtype=torch.float32) for k, v in out.items()}
@@ -188,10 +192,16 @@ class DanboTrainEngine:
             bgs=_P(t.get('bgs')), t_rand=_P(rnd.get('t_rand')), u_rand=_P(rnd.get('u_rand')), noise_c=_P(rnd.get('noise_c')),
             noise_f=_P(rnd.get('noise_f')), R=R, G=G, S=S, Sf=Sf, chunk=chunk)
         o = _hip.DanboTrainOut(**{k: _P(v) for k, v in out.items()})
-        _hip.check(_hip.lib().danbo_train_step(ctypes.byref(m), ctypes.byref(bt), ctypes.byref(o), _P(self._ws), self._ws.numel(),
-                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_train_step")
-        out['_keep'] = rnd
+        out['_keep'] = (rnd, bt, o)
+        self._step_phase(out, 1 if split else 0)
         return out
+
+    def _step_phase(self, out, phase):
+        """phase 0: the whole step; 1: up to the K2 / K1b adjoint (every gradient but graph_net.layers.* final); 2: the rest"""
+        _, bt, o = out['_keep']
+        _hip.check(_hip.lib().danbo_train_step_phase(ctypes.byref(self._model()), ctypes.byref(bt), ctypes.byref(o), _P(self._ws),
+                                                     self._ws.numel(), int(phase),
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_train_step")
 
     @staticmethod
     def _static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx, target, bgs, near_in, far_in):
@@ -202,7 +212,7 @@ class DanboTrainEngine:
         return {k: v for k, v in t.items() if v is not None}
 
     def forward_backward(self, rays_o, rays_d, skts, bones, cyls, cam_idx, target, bgs, S, Sf, perturb=0., raw_noise_std=0.,
-                         near_in=None, far_in=None):
+                         near_in=None, far_in=None, split=False):
         """One batch: per-pose skts [G,24,4,4] / bones [G,24,3] / cyls [G,5]; per-ray everything else.  Gradients land in
         `flat_grad` (the parameters' .grad views); -> dict(rgb_map, ..., loss [4], counts [8])."""
         t = self._static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx if self.net.use_framecode else None, target, bgs,
@@ -210,25 +220,51 @@ class DanboTrainEngine:
         if t.get('bgs') is not None and t['bgs'].numel() != t['target'].numel():
             t['bgs'] = t['bgs'].expand_as(t['target']).contiguous()
         if not self.use_graph:
-            return self._launch(t, S, Sf, perturb, raw_noise_std)
-        key = (tuple((k, tuple(v.shape)) for k, v in sorted(t.items())), S, Sf, float(perturb), float(raw_noise_std))
+            out = self._launch(t, S, Sf, perturb, raw_noise_std, split)
+            self._pending = (out, None) if split else None
+            return out
+        key = (tuple((k, tuple(v.shape)) for k, v in sorted(t.items())), S, Sf, float(perturb), float(raw_noise_std), bool(split))
         if self.graph is None or self.graph[0] != key:
             static = {k: v.clone() for k, v in t.items()}
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):        # eager warm-up off the capture: lazy initialisations, workspace allocation
-                self._launch(static, S, Sf, perturb, raw_noise_std)
+                w = self._launch(static, S, Sf, perturb, raw_noise_std, split)
+                if split:
+                    self._step_phase(w, 2)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                outs = self._launch(static, S, Sf, perturb, raw_noise_std)
-            self.graph = (key, g, static, outs)
-        _, g, static, outs = self.graph
+                outs = self._launch(static, S, Sf, perturb, raw_noise_std, split)
+            g2 = None
+            if split:                             # the pose-GNN adjoint as its own graph: the all-reduce of the finished
+                g2 = torch.cuda.CUDAGraph()       # gradients is launched between the two replays
+                with torch.cuda.graph(g2):
+                    self._step_phase(outs, 2)
+            self.graph = (key, g, static, outs, g2)
+        _, g, static, outs, g2 = self.graph
         for k, v in t.items():
             static[k].copy_(v)
         g.replay()
+        self._pending = (outs, g2) if split else None
         return outs
+
+    def finish_backward(self):
+        """second half of a split step (forward_backward(..., split=True)): the pose-GNN adjoint"""
+        outs, g2 = self._pending
+        if g2 is not None:
+            g2.replay()
+        else:
+            self._step_phase(outs, 2)
+        self._pending = None
+
+    def grad_buckets(self):
+        """(finished after phase 1, finished after phase 2): the flat gradient of everything but the pose GNN, and the pose GNN's
+        (graph_net.layers.* are the first tensors of the flat layout)"""
+        cut = self.offsets['graph_net.axis_scale'] if 'graph_net.axis_scale' in self.trainable else \
+            self.offsets['prob_linears.layers.0.lin.weight']
+        return self.flat_g[cut:self.n_train], self.flat_g[:cut]
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, lr, grad_scale=1.0):

@@ -86,7 +86,7 @@ class Trainer:
         self.args, self.optimizer, self.device = args, optimizer, device
         self.render_kwargs_train, self.render_kwargs_test = render_kwargs_train, render_kwargs_test
         self.hwf, self.data_attrs = data_attrs.get('hwf'), data_attrs
-        self.engine, self.fused_reason = None, None
+        self.engine, self.fused_reason, self._comm_stream = None, None, None
 
     def fused_engine(self):
         """the HIP training engine for this caster / optimizer, or None with `self.fused_reason` saying why not"""
@@ -108,12 +108,24 @@ class Trainer:
         G = int(batch['N_uniques'])
         pp = caster._per_pose
         S, Sf = int(kw['N_samples']), int(kw['N_importance'])
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         out = eng.forward_backward(batch['rays_o'], batch['rays_d'], pp(batch['skts'], G), pp(batch['bones'], G), pp(batch['cyls'], G),
                                    batch.get('cam_idxs'), batch['target_s'], batch.get('bgs'), S, Sf,
-                                   perturb=float(kw['perturb']), raw_noise_std=float(kw['raw_noise_std']))
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+                                   perturb=float(kw['perturb']), raw_noise_std=float(kw['raw_noise_std']), split=world > 1)
         if world > 1:
-            dist.all_reduce(eng.flat_g[:eng.n_train], op=dist.ReduceOp.SUM)     # in place on the flat gradient: no packing
+            # Two in-place all-reduces on the flat gradient (no packing, no copies).  The first -- everything but the pose GNN,
+            # final once the K2 / K1b adjoint has run -- is launched on a side stream and overlaps the pose-GNN adjoint, whose
+            # 1.7 M gradients follow as the second ("overlapped with the tail of backward").
+            early, late = eng.grad_buckets()
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                dist.all_reduce(early, op=dist.ReduceOp.SUM)
+            eng.finish_backward()
+            dist.all_reduce(late, op=dist.ReduceOp.SUM)
+            cur.wait_stream(self._comm_stream)
         lr = self.optimizer.param_groups[0]['lr']
         eng.adam_step(lr, 1.0 / world)
         lr, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, self.optimizer, global_step, args.decay_unit)

@@ -279,9 +279,12 @@ extern "C" size_t danbo_train_workspace(const DanboTrainModel* m, int R, int G, 
     return c2.used + 512;
 }
 
-extern "C" int danbo_train_step(const DanboTrainModel* m, const DanboTrainBatch* bt, const DanboTrainOut* o, void* workspace,
-                                size_t workspace_bytes, void* stream) {
-    DANBO_CHECK_ARG(model_ok(m) && bt && o && workspace);
+// phase 0: the whole step; 1: everything up to and including the K2 / K1b adjoint -- from then on every gradient except the
+// pose GNN's (graph_net.layers.*, the first tensors of the flat buffer) is final; 2: the pose GNN adjoint and the loss copy.
+// Data-parallel training launches the all-reduce of the finished part on a side stream between phases 1 and 2.
+static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, const DanboTrainOut* o, void* workspace,
+                           size_t workspace_bytes, void* stream, int phase) {
+    DANBO_CHECK_ARG(model_ok(m) && bt && o && workspace && phase >= 0 && phase <= 2);
     const int R = bt->R, G = bt->G, S = bt->S, Sf = bt->Sf;
     DANBO_CHECK_ARG(R >= 1 && G >= 1 && R % G == 0 && S >= 3 && Sf >= 1 && S <= 256 && S + Sf <= 256 && bt->chunk >= 1);
     DANBO_CHECK_ARG(bt->rays_o && bt->rays_d && bt->skts && bt->bones && bt->cyls && bt->target);
@@ -307,6 +310,7 @@ extern "C" int danbo_train_step(const DanboTrainModel* m, const DanboTrainBatch*
     const int ncap = (int)sh.rows_cap;
     const float B = m->density_scale;
 
+    if (phase != 2) {
     // ---- zero: counters, running maxima, loss terms, volume gradients; the flat parameter gradient
     if (hipMemsetAsync(b.zero_begin, 0, (size_t)(b.zero_end - b.zero_begin), st) != hipSuccess) return (int)hipGetLastError();
     if (hipMemsetAsync(m->g_flat, 0, sizeof(float) * (size_t)m->n_flat, st) != hipSuccess) return (int)hipGetLastError();
@@ -445,6 +449,8 @@ extern "C" int danbo_train_step(const DanboTrainModel* m, const DanboTrainBatch*
     ab.c_ss = 2.0f * m->soft_softmax_coef / ((float)R * (float)(S + Sf));
     ab.loss = b.loss;
     DANBO_TRY(danbo_assign_blend_bwd(&ab, stream));
+    }   // phase != 2
+    if (phase == 1) { DANBO_LAUNCH_RET(); }
     DANBO_TRY(danbo_pose_volumes_bwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], m->p[DANBO_T_G_ADJW0], m->g_adj0,
                                      m->p[DANBO_T_G_B0], m->p[DANBO_T_G_W1], m->p[DANBO_T_G_ADJW1], m->g_adj1, m->p[DANBO_T_G_B1],
                                      m->p[DANBO_T_G_W2], m->p[DANBO_T_G_W3], b.vol_scratch, b.g_vol, m->g[DANBO_T_G_W0], m->g[DANBO_T_G_ADJW0],
@@ -455,4 +461,14 @@ extern "C" int danbo_train_step(const DanboTrainModel* m, const DanboTrainBatch*
     if (o->counts != nullptr && hipMemcpyAsync(o->counts, b.cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return (int)hipGetLastError();
     DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_step(const DanboTrainModel* m, const DanboTrainBatch* bt, const DanboTrainOut* o, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return train_step_impl(m, bt, o, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int danbo_train_step_phase(const DanboTrainModel* m, const DanboTrainBatch* bt, const DanboTrainOut* o, void* workspace,
+                                      size_t workspace_bytes, int phase, void* stream) {
+    return train_step_impl(m, bt, o, workspace, workspace_bytes, stream, phase);
 }
