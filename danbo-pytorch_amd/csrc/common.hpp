@@ -122,6 +122,26 @@ __device__ __forceinline__ float lane_xor16(float x) {
     return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
 }
 
+// Zeroing / small copies as KERNELS, not hipMemsetAsync / hipMemcpyAsync: inside a captured HIP graph (torch.cuda.graph around the
+// training step) a byte-granular memset node of an odd-sized region was replayed wrongly on this ROCm (the second replay left
+// the step's device counters non-zero and the next kernel wrote out of bounds: "Memory access fault"); eager launches were fine.
+// Kernels replay like every other node.  One copy per translation unit (static).
+static __global__ __launch_bounds__(256) void k_zero_words_(uint32_t* __restrict__ p0, long n0, uint32_t* __restrict__ p1, long n1) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) p0[i] = 0u;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) p1[i] = 0u;
+}
+static inline void zero_words(void* p0, long n0, void* p1, long n1, hipStream_t st) {
+    const long n = n0 > n1 ? n0 : n1;
+    hipLaunchKernelGGL(k_zero_words_, dim3(stream_grid(n, 256)), dim3(256), 0, st, static_cast<uint32_t*>(p0), n0,
+                       static_cast<uint32_t*>(p1), p1 ? n1 : 0);
+}
+static __global__ __launch_bounds__(64) void k_copy_words_(const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0, int n0,
+                                                           const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1, int n1) {
+    for (int i = threadIdx.x; i < n0; i += 64) d0[i] = s0[i];
+    for (int i = threadIdx.x; i < n1; i += 64) d1[i] = s1[i];
+}
+
 // number of rows a kernel has to process: device-side count (clamped to capacity) or host n
 __device__ __forceinline__ int resolve_count(const int32_t* count, int n_cap) {
     if (count == nullptr) return n_cap;

@@ -4,11 +4,12 @@
 // with fp32-accurate products on the fp16 matrix cores (hi/lo split as in k_linear16.hip, fp32 accumulate).  gfx950 only.
 //
 // The reduction index of this GEMM is the ROW of both operands, i.e. the slow index of both row-major buffers, while an MFMA
-// fragment wants 8 consecutive reduction indices per lane.  So a workgroup stages 32 rows of its 128 gradient columns and
-// 256 input columns through LDS *transposed*: every thread loads the same 4 columns of two consecutive rows (2 x 16 B),
+// fragment wants 8 consecutive reduction indices per lane.  So a workgroup stages 32 rows of its 256 gradient columns and
+// 256 input columns through LDS *transposed* (a whole 256 x 256 layer per workgroup: every operand row is read from HBM ONCE
+// per layer -- with 128-column tiles the kernel re-read the inputs per tile and sat on the HBM roof at 3.4 TB/s): every thread loads the same 4 columns of two consecutive rows (2 x 16 B),
 // splits them into fp16 hi / lo and writes row PAIRS as 32-bit words at [column][row] (column stride 80 B: 2-way bank
-// conflicts at most for the writes and for the 16-byte fragment reads).  Four wavefronts then own 64 x 128 of the
-// 128 x 256 output tile each (32 accumulator tiles = 128 VGPRs): per 32-row step 24 fragment reads feed 96 MFMAs.
+// conflicts at most for the writes and for the 16-byte fragment reads).  Eight wavefronts then own 64 x 128 of the
+// 256 x 256 output tile each (32 accumulator tiles = 128 VGPRs): per 32-row step 24 fragment reads feed 96 MFMAs.
 // Rows are split over `slices` workgroups per tile; partial tiles go to a scratch buffer and a second kernel sums the
 // slices in a fixed order (deterministic, no float atomics), undoes the power-of-two pre-scale of the gradient operand
 // (in_maxabs of danbo_linear16_ex) and writes the gradients in nn.Linear layout.
@@ -21,7 +22,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DW_TN = 128, DW_TK = 256, DW_ROWS = 32, DW_THREADS = 256;
+constexpr int DW_TN = 256, DW_TK = 256, DW_ROWS = 32, DW_THREADS = 512;
 constexpr int DW_CSTRIDE = 80;                           // bytes per column in LDS: 32 rows x 2 B + 16 B padding
 constexpr int DW_A_BYTES = DW_TN * DW_CSTRIDE;           // one of hi / lo
 constexpr int DW_B_BYTES = DW_TK * DW_CSTRIDE;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void dw_store4(char* hi_base, char* lo_base, int col,
     }
 }
 
-__global__ __launch_bounds__(DW_THREADS, 2) void k_dw16(DwArgs a) {
+__global__ __launch_bounds__(DW_THREADS, 1) void k_dw16(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_ah = smem;
     char* s_al = smem + DW_A_BYTES;
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(DW_THREADS, 2) void k_dw16(DwArgs a) {
 
     // loader mapping: lanes run over row pairs first (16 pairs = 32 rows), then over groups of 4 columns
     const int rp = tid & 15;
-    const int ga = tid >> 4;                     // gradient columns 4 ga .. + 3 and 4 (ga + 16) .. + 3
-    f32x4 ra[2][2], rb[4][2];                    // [group][row of the pair]
+    const int ga = tid >> 4;                     // columns 4 ga .. + 3 and 4 (ga + 32) .. + 3 of both operands
+    f32x4 ra[2][2], rb[2][2];                    // [group][row of the pair]
     // 32-bit byte offsets from the (uniform) buffer bases: 12 loads in flight would otherwise pin 24 address registers
     const char* const dy_b = reinterpret_cast<const char*>(L.dy);
     const char* const x1_b = reinterpret_cast<const char*>(L.x1);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void k_dw16(DwArgs a) {
     auto load_step = [&](int r) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int col = n0 + 4 * (ga + 16 * u);
+            const int col = n0 + 4 * (ga + 32 * u);
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
                 const int row = r + 2 * rp + w;
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(DW_THREADS, 2) void k_dw16(DwArgs a) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int vc = v0 + 4 * (ga + 16 * u);       // virtual column: [x1 padded to K1p | x2]
+        for (int u = 0; u < 2; ++u) {
+            const int vc = v0 + 4 * (ga + 32 * u);       // virtual column: [x1 padded to K1p | x2]
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
                 const int row = r + 2 * rp + w;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void k_dw16(DwArgs a) {
         }
     };
 
-    // wave tile: 64 gradient columns x 128 input columns
+    // wave tile: 64 gradient columns x 128 input columns (8 wavefronts: 4 x 2)
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
     const int m = lane & 15, q = lane >> 4;
     const bool wave_live = (n0 + wn < L.N) && (v0 + wk < L.Kv);
@@ -175,19 +176,19 @@ __global__ __launch_bounds__(DW_THREADS, 2) void k_dw16(DwArgs a) {
         // registers -> LDS (transposed, split)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            dw_store4(s_ah, s_al, 4 * (ga + 16 * u), rp, ra[u][0], ra[u][1], sc);
+            dw_store4(s_ah, s_al, 4 * (ga + 32 * u), rp, ra[u][0], ra[u][1], sc);
             if (tk == 0) {   // bias gradient: the 16 lanes of a DPP row hold the 32 rows of the same 4 columns
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = ra[u][0][j] + ra[u][1][j];
                     DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
                     DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x118, 0xf)
-                    if (rp == 15) s_db[4 * (ga + 16 * u) + j] += x;      // this lane is the only writer of the entry
+                    if (rp == 15) s_db[4 * (ga + 32 * u) + j] += x;      // this lane is the only writer of the entry
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dw_store4(s_bh, s_bl, 4 * (ga + 16 * u), rp, rb[u][0], rb[u][1], 1.f);
+        for (int u = 0; u < 2; ++u) dw_store4(s_bh, s_bl, 4 * (ga + 32 * u), rp, rb[u][0], rb[u][1], 1.f);
         __syncthreads();
         if (r + DW_ROWS < row_end) load_step(r + DW_ROWS);     // next step's rows fly under this step's MFMAs
         if (wave_live) {

@@ -590,7 +590,7 @@ extern "C" int danbo_linear16_pack_group(const DanboPackDesc* descs, int n, void
     }
     a.chunk0[n] = chunk;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(wmax, 0, sizeof(float) * n, st) != hipSuccess) return (int)hipGetLastError();
+    zero_words(wmax, n, nullptr, 0, st);
     hipLaunchKernelGGL(k_linear16_group_max, dim3(16, n), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_linear16_group_pack, dim3(32, n), dim3(256), 0, st, a);
     DANBO_LAUNCH_RET();

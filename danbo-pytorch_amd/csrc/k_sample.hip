@@ -758,8 +758,7 @@ extern "C" int danbo_near_far_cylinder(const float* rays_o, const float* rays_d,
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && chunk > 0 && scratch != nullptr);
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(R, chunk);
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 4 * nchunk, st);
-    if (e != hipSuccess) return (int)e;
+    zero_words(scratch, 8L * nchunk, nullptr, 0, st);
     const int grid = stream_grid(R, 256);
     hipLaunchKernelGGL(k_cylinder_pass1, dim3(grid), dim3(256), 0, st, rays_o, rays_d, cyl, R, G, near0, far0, near_in,
                        far_in, chunk, reinterpret_cast<double*>(scratch), near_out, far_out);

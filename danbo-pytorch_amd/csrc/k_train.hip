@@ -16,6 +16,7 @@
 //                the forward), all weight gradients in one grouped launch, frame-code gradients, PE adjoint,
 //                K2/K1b adjoint by (row, valid bone) pairs with the forward recomputed, pose GNN adjoint, volume-scale term
 #include <limits.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 using namespace danbo;
@@ -169,7 +170,7 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long pa
     return b;
 }
 
-constexpr int DW_SLICES = 20;
+constexpr int DW_SLICES = 18;      // 14 tiles of 256 x 256 x 18 row slices = 252 workgroups: one per CU
 
 void describe_dw(const DanboTrainModel* m, const TrainBuffers& b, DanboDwLayer* L) {
     const int mx_of_dz[8] = {MX_Z0, MX_Z1, MX_Z2, MX_Z3, MX_Z4, MX_Z5, MX_Z6, MX_Z7};
@@ -310,10 +311,13 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     const int ncap = (int)sh.rows_cap;
     const float B = m->density_scale;
 
+    // dev aid: DANBO_TRAIN_STOP_AFTER=<stage> makes the call return after that stage (bisecting a fault inside a captured graph)
+    const char* stop_env = getenv("DANBO_TRAIN_STOP_AFTER");
+    const int stop_after = stop_env ? atoi(stop_env) : 1000;
+#define DANBO_STAGE(n) do { if (stop_after <= (n)) { DANBO_LAUNCH_RET(); } } while (0)
     if (phase != 2) {
     // ---- zero: counters, running maxima, loss terms, volume gradients; the flat parameter gradient
-    if (hipMemsetAsync(b.zero_begin, 0, (size_t)(b.zero_end - b.zero_begin), st) != hipSuccess) return (int)hipGetLastError();
-    if (hipMemsetAsync(m->g_flat, 0, sizeof(float) * (size_t)m->n_flat, st) != hipSuccess) return (int)hipGetLastError();
+    zero_words(b.zero_begin, (long)((b.zero_end - b.zero_begin) / 4), m->g_flat, (long)m->n_flat, st);
 
     // ---- packings of the current weights; adjacency products; volume-scale loss
     long off[N_MAT];
@@ -325,6 +329,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     const float* adjw1 = b.adj_prod + J * J;
     const float* adjw_a = b.adj_prod + 2 * J * J;
     DANBO_TRY(danbo_assign16_pack(m->p[DANBO_T_A_W0], adjw_a, m->p[DANBO_T_A_W1], b.assign16, stream));
+    DANBO_STAGE(1);
 
     // ---- bounds, depths (reference raycasters.py:310-311), pose volumes, per-ray view inputs
     const float* axis_scale = m->p[DANBO_T_AXIS_SCALE];
@@ -338,8 +343,11 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                      m->p[DANBO_T_G_W3], m->p[DANBO_T_G_B3], b.vol_scratch, b.volumes, stream));
     DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
                                       m->code_size, bt->cam_idx, b.vin, LD_VIN, stream));
+    DANBO_STAGE(2);
 
     // ---- one network pass over the compacted rows
+    bool stopped = false;
+#define NET_STAGE(n) do { if (stop_after <= (n)) { stopped = true; return 0; } } while (0)
     auto network = [&](int pass) -> int {
         const float* zz = pass == 0 ? b.z_c : b.z_f;
         const int s = pass == 0 ? S : Sf;
@@ -348,12 +356,15 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         const int32_t* count = pass == 0 ? b.cnt + 2 : b.cnt + 3;     // its number of rows
         DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, bits, b.row_sample + R, b.cnt,
                                   stream));
+        NET_STAGE(21);
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,
                                                     b.row_sample + R, b.cnt, pass == 0 ? nullptr : b.cnt + 1, ncap - R, b.assign16,
                                                     m->p[DANBO_T_A_B0], m->p[DANBO_T_A_B1], m->p[DANBO_T_A_W2], m->p[DANBO_T_A_B2],
                                                     b.h_rows + (size_t)R * 16, stream));
+        NET_STAGE(22);
         DANBO_TRY(danbo_train_rows_fwd(b.h_rows, b.row_sample, b.cnt, pass, R, s, ncap, m->L_voxel, b.vin, LD_VIN, b.pe, LD_PE, b.vinr,
                                        b.row_ray, stream));
+        NET_STAGE(23);
         DanboLinearEx ex{};
         ex.first = first;
         for (int l = 0; l < 8; ++l) {
@@ -363,6 +374,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
             const int ld1 = l == 0 || l == 5 ? LD_PE : 256, K1 = l == 0 || l == 5 ? 195 : 256;
             DANBO_TRY(danbo_linear16_ex(x1, ld1, K1, l == 5 ? b.y[4] : nullptr, 256, l == 5 ? 256 : 0, b.packed + off[l],
                                         m->p[DANBO_T_PTS_B0 + l], 256, 1, b.y[l], 256, ncap, count, &ex, stream));
+            NET_STAGE(24 + l);
         }
         ex.relu_out = nullptr;
         ex.wscale_inv = b.wscale_inv + 8;
@@ -375,6 +387,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                         b.raw_rows, pass == 0 ? b.raw_c : b.raw_f, b.raw_empty, stream);
     };
     DANBO_TRY(network(0));
+    if (stopped) { DANBO_LAUNCH_RET(); }
+    DANBO_STAGE(3);
     if (S <= 64 && Sf <= 64) {
         DANBO_TRY(danbo_composite_importance_fwd(b.raw_c, b.raw_empty, b.bits_c, b.z_c, bt->rays_d, R, S, Sf, B, bt->noise_c, bt->u_rand, o->rgb0,
                                                  o->disp0, o->acc0, b.weights0, o->alpha0, b.z_f, b.z_sorted, b.order, stream));
@@ -384,10 +398,13 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         DANBO_TRY(danbo_composite_fwd(b.raw_c, b.z_c, bt->rays_d, R, S, B, bt->noise_c, o->rgb0, o->disp0, o->acc0, b.weights0, o->alpha0, stream));
         DANBO_TRY(danbo_importance_samples(b.z_c, b.weights0, R, S, Sf, bt->u_rand, b.z_f, b.z_sorted, b.order, stream));
     }
+    DANBO_STAGE(4);
     DANBO_TRY(network(1));
+    DANBO_STAGE(5);
     DANBO_TRY(danbo_composite_merged_fwd(b.raw_c, b.raw_f, b.raw_empty, b.bits_c, b.bits_f, b.order, b.z_sorted, bt->rays_d, R, S, Sf, B,
                                          bt->noise_f, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, b.raw_sorted, stream));
 
+    DANBO_STAGE(6);
     // ---- losses and the adjoints of the two composites
     DANBO_TRY(danbo_train_loss_grad(o->rgb_map, o->acc_map, o->rgb0, o->acc0, bt->target, bt->bgs, m->use_background, R, m->loss_mse,
                                     m->rgb_loss_coef, m->rgb_loss_coef * m->coarse_weight, b.g_rgb, b.g_acc, b.g_rgb0, b.g_acc0, b.loss, stream));
@@ -400,6 +417,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_TRY(danbo_train_rgb_head_bwd(b.hv, m->p[DANBO_T_RGB_W], b.d_raw_c, b.d_raw_f, b.row_sample, b.cnt, R, ncap, b.d_raw_rows, b.dpre_v,
                                        b.d_alpha4, b.maxabs + MX_V, b.maxabs + MX_VF, stream));
 
+    DANBO_STAGE(7);
     // ---- input-gradient GEMMs over the rows of both passes
     const int32_t* all_rows = b.cnt + 4;
     {
@@ -428,14 +446,17 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         ex.relu_in = nullptr; ex.mask_cols = 0;
         DANBO_TRY(danbo_linear16_ex(b.dz[0], 256, 256, nullptr, 0, 0, b.packed + off[19], nullptr, 195, 0, b.d_x0, LD_PE, ncap, all_rows, &ex, stream));
     }
+    DANBO_STAGE(8);
     // ---- weight / bias gradients of all 12 layers, frame codes
     DANBO_TRY(danbo_dw16(dwl, 12, ncap, all_rows, DW_SLICES, b.dw_scratch, stream));
+    DANBO_STAGE(9);
     if (m->n_codes > 0)
         DANBO_TRY(danbo_train_code_grad(b.d_vfeat, LD_VF, 256 + 3 * (1 + 2 * m->L_view), m->code_size, b.row_ray, bt->cam_idx, b.cnt, ncap,
                                         m->n_codes, m->g[DANBO_T_CODES], stream));
     // ---- PE adjoint, K2 / K1b adjoint, pose GNN adjoint
     DANBO_TRY(danbo_train_pe_bwd(b.d_x0, LD_PE, b.d_x5, LD_X5, 256, b.h_rows, b.cnt, R, ncap, m->L_voxel, b.d_h, stream));
     DANBO_TRY(danbo_train_bone_lists(b.bits_c, b.bits_f, b.row_sample, b.cnt, R, ncap, b.lists, b.cntb, stream));
+    DANBO_STAGE(10);
     DanboAssignBwd ab{};
     ab.rays_o = bt->rays_o; ab.rays_d = bt->rays_d; ab.z_c = b.z_c; ab.z_f = b.z_f; ab.skts = bt->skts; ab.align = m->align;
     ab.axis_scale = axis_scale; ab.volumes = b.volumes; ab.R = R; ab.S = S; ab.Sf = Sf; ab.G = G; ab.rows_cap = ncap;
@@ -449,6 +470,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     ab.c_ss = 2.0f * m->soft_softmax_coef / ((float)R * (float)(S + Sf));
     ab.loss = b.loss;
     DANBO_TRY(danbo_assign_blend_bwd(&ab, stream));
+    DANBO_STAGE(11);
     }   // phase != 2
     if (phase == 1) { DANBO_LAUNCH_RET(); }
     DANBO_TRY(danbo_pose_volumes_bwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], m->p[DANBO_T_G_ADJW0], m->g_adj0,
@@ -457,9 +479,9 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                      m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
                                      m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, stream));
     // ---- loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
-    if (hipMemcpyAsync(o->loss, b.loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
-    if (o->counts != nullptr && hipMemcpyAsync(o->counts, b.cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return (int)hipGetLastError();
+    hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),
+                       reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),
+                       reinterpret_cast<uint32_t*>(o->counts), o->counts ? 8 : 0);
     DANBO_LAUNCH_RET();
 }
 
