@@ -225,7 +225,17 @@ class DanboTrainEngine:
             return out
         key = (tuple((k, tuple(v.shape)) for k, v in sorted(t.items())), S, Sf, float(perturb), float(raw_noise_std), bool(split))
         if self.graph is None or self.graph[0] != key:
-            static = {k: v.clone() for k, v in t.items()}
+            # the graph's static inputs are views of ONE flat buffer: a replay is preceded by a single gather of the caller's
+            # tensors (torch.cat, one launch; cam_idx travels as raw 32-bit words) instead of one copy per tensor
+            words = {k: v.reshape(-1).view(torch.float32).numel() for k, v in t.items()}
+            flat = torch.empty(sum((n + 63) // 64 * 64 for n in words.values()), device=self.device, dtype=torch.float32)
+            static, spans, o = {}, [], 0
+            for k, v in t.items():
+                static[k] = flat[o:o + words[k]].view(v.dtype).view(v.shape)
+                spans.append((k, o, words[k]))
+                o += (words[k] + 63) // 64 * 64
+            static['_flat'], static['_spans'], static['_pad'] = flat, spans, torch.zeros(64, device=self.device)
+            self._gather_inputs(static, t)
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
@@ -244,11 +254,23 @@ class DanboTrainEngine:
                     self._step_phase(outs, 2)
             self.graph = (key, g, static, outs, g2)
         _, g, static, outs, g2 = self.graph
-        for k, v in t.items():
-            static[k].copy_(v)
+        self._gather_inputs(static, t)
         g.replay()
         self._pending = (outs, g2) if split else None
         return outs
+
+    @staticmethod
+    def _gather_inputs(static, t):
+        flat, spans = static['_flat'], static['_spans']
+        parts, o = [], 0
+        for k, off, n in spans:
+            if off > o:
+                parts.append(static['_pad'][:off - o])            # alignment gap
+            parts.append(t[k].reshape(-1).view(torch.float32))
+            o = off + n
+        if o < flat.numel():
+            parts.append(static['_pad'][:flat.numel() - o])
+        torch.cat(parts, out=flat)
 
     def finish_backward(self):
         """second half of a split step (forward_backward(..., split=True)): the pose-GNN adjoint"""

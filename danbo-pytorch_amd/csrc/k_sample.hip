@@ -98,27 +98,37 @@ __global__ __launch_bounds__(256) void k_box_bounds(const float* __restrict__ ra
     for (int i = threadIdx.x; i < J * 3; i += blockDim.x) s_scale[i] = fabsf(axis_scale[i]);
     __syncthreads();
     const int rays_per_pose = R / G;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+    // one lane per (ray, bone): 32 lanes per ray (24 active), min / max over the bones by half-wave shuffles -- the same values
+    // as the sequential loop (min / max do not depend on the order); a thread per ray walking 24 fp64 slab tests was
+    // latency-bound (33 us for 3 072 rays)
+    const int j = threadIdx.x & 31;
+    const long slots = ((long)gridDim.x * blockDim.x) >> 5;
+    for (long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5; r0 < ((R + 1) & ~1L); r0 += slots) {   // both halves of a wave iterate together
+        const int r = (int)(r0 < R ? r0 : R - 1);
         const int g = min(r / rays_per_pose, G - 1);
-        float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
-        float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-        float vnear = 100000.0f, vfar = -100000.0f;
-        bool any = false;
-        for (int j = 0; j < J; ++j) {
+        float lo = 100000.0f, hi = -100000.0f;
+        bool ok = false;
+        if (j < J && r0 < R) {
+            const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+            const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
             float sk[12];
             const float* src = skts + ((size_t)g * J + j) * 16;
 #pragma unroll
             for (int i = 0; i < 12; ++i) sk[i] = src[i];
-            float lo, hi;
-            if (bone_box_steps(sk, s_align + 16 * j, s_scale + 3 * j, o, d, &lo, &hi)) {
-                any = true;
-                vnear = fminf(vnear, lo);
-                vfar = fmaxf(vfar, hi);
-            }
+            float l_, h_;
+            ok = bone_box_steps(sk, s_align + 16 * j, s_scale + 3 * j, o, d, &l_, &h_);
+            if (ok) { lo = l_; hi = h_; }
         }
-        if (any) {
-            near_io[r] = vnear;
-            far_io[r] = vfar;
+        int any = ok ? 1 : 0;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+            any |= __shfl_xor(any, off, 64);
+        }
+        if (j == 0 && r0 < R && any) {
+            near_io[r] = lo;
+            far_io[r] = hi;
         }
     }
 }
@@ -771,7 +781,7 @@ extern "C" int danbo_near_far_boxes(const float* rays_o, const float* rays_d, co
                                      const float* axis_scale, int R, int G, float* near_io, float* far_io,
                                      void* stream) {
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0);
-    hipLaunchKernelGGL(k_box_bounds, dim3(stream_grid(R, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, skts,
+    hipLaunchKernelGGL(k_box_bounds, dim3(stream_grid((long)R * 32, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, skts,
                        align, axis_scale, R, G, near_io, far_io);
     DANBO_LAUNCH_RET();
 }

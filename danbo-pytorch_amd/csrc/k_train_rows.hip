@@ -362,25 +362,37 @@ __global__ __launch_bounds__(256) void k_train_pe_bwd(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_train_bone_lists(const uint32_t* __restrict__ bits_c, const uint32_t* __restrict__ bits_f,
                                                           const int32_t* __restrict__ row_sample, const int32_t* __restrict__ cnt, int R,
                                                           int cap, int32_t* __restrict__ lists, int32_t* __restrict__ cntb) {
+    // per 256 rows: wave-level ballots -> per-wave counts in LDS -> ONE global atomic per bone for the workgroup (the 24 list
+    // counters are hot words: one atomic per wavefront and bone serialised 4 000 of them, 50 us)
+    __shared__ int s_cnt[J][4];
+    __shared__ int s_base[J];
     const int rows = cnt[5], first_f = cnt[2];
-    const int lane = threadIdx.x & 63;
-    const long nthreads = (long)gridDim.x * blockDim.x;
-    for (long k0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; k0 < rows; k0 += nthreads) {
-        const long k = k0 + lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long k0 = (long)blockIdx.x * blockDim.x; k0 < rows; k0 += (long)gridDim.x * blockDim.x) {
+        const long k = k0 + threadIdx.x;
         const int i = R + (int)k;
         uint32_t b = 0;
         if (k < rows) b = i < first_f ? bits_c[row_sample[i]] : bits_f[row_sample[i]];
-        uint32_t any = wave_or(b);
-        while (any) {
-            const int j = __builtin_ctz(any);
-            any &= any - 1;
-            const bool mine = (b >> j) & 1u;
-            const unsigned long long bal = __ballot(mine);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(cntb + j, (int)__popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (mine) lists[(size_t)j * cap + base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = i;
+        unsigned long long bal[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            bal[j] = __ballot((b >> j) & 1u);
+            if (lane == 0) s_cnt[j][wave] = (int)__popcll(bal[j]);
         }
+        __syncthreads();
+        if (threadIdx.x < J) {
+            const int j = threadIdx.x;
+            int run = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = s_cnt[j][w]; s_cnt[j][w] = run; run += c; }
+            s_base[j] = run > 0 ? atomicAdd(cntb + j, run) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if ((b >> j) & 1u)
+                lists[(size_t)j * cap + s_base[j] + s_cnt[j][wave] + (int)__popcll(bal[j] & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
     }
 }
 
