@@ -50,6 +50,8 @@ SIGNATURES = {
     "danbo_linear16_packed_bytes": [I, I, I],
     "danbo_linear16_pack": [P, c_long, c_long, I, I, I, P, P],
     "danbo_linear16_fwd": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P],
+    "danbo_linear16_pack_frag": [P, c_long, c_long, I, I, I, I, P, P],
+    "danbo_linear16_fwd_frag": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, I, P],
     "danbo_render_frame_workspace": [I, I, I, I, I, I],
     "danbo_render_frame": [P, P, I, I, P, P, c_size_t, P],
     # ---- training step

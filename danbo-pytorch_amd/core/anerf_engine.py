@@ -32,15 +32,20 @@ class AnerfEngine:
         self.b = [p[f"pts_linears.{i}.bias"].contiguous() for i in range(cfg["D"])]
         # layer after a skip: input = [x0 | h], read from the two buffers (no concatenated copy)
         self.skip_into = {i + 1 for i in cfg["skips"]}
-        self.layers = [ops.linear16_pack(p[f"pts_linears.{i}.weight"], K1=self.in_ch if i in self.skip_into else None)
+        # activations between the layers in k_linear16's fragment order (every load / store instruction one contiguous KB) when
+        # the widths allow it; the first layer reads the encoder's rows, the head writes rows for k_anerf_color
+        self.frag = W % 32 == 0 and VW + 1 <= 256
+        self.layers = [ops.linear16_pack(p[f"pts_linears.{i}.weight"], K1=self.in_ch if i in self.skip_into else None,
+                                         frag_in=(self.frag and i > 0 and i not in self.skip_into, self.frag and i in self.skip_into))
                        for i in range(cfg["D"])]
+        self._frag_store = None
         wv = p["views_linears.0.weight"].double()                       # [VW, W + view_ch + code]
         wf, bf = p["feature_linear.weight"].double(), p["feature_linear.bias"].double()
         view_ch = (1 + 2 * self.Lv) * 72
         # feature_linear (no activation) folded into the view layer: one W -> VW GEMM per sample
         # ... and stacked on alpha_linear: rows [0, VW) = view features, row VW = density logit
         head_w = torch.cat([(wv[:, :W] @ wf).float(), p["alpha_linear.weight"].float()], 0).contiguous()
-        self.head = ops.linear16_pack(head_w)
+        self.head = ops.linear16_pack(head_w, frag_in=(self.frag, False))
         self.head_b = torch.cat([torch.zeros(VW, device=head_w.device), p["alpha_linear.bias"].float()]).contiguous()
         self.VW = VW
         b_eff = wv[:, :W] @ bf + p["views_linears.0.bias"].double()
@@ -78,6 +83,8 @@ class AnerfEngine:
         return torch.bmm(Ej, self.w_view_j)
 
     def _trunk(self, x0):
+        if self.frag:
+            return self._trunk_frag(x0)
         h = None
         for i, (packed, shape) in enumerate(self.layers):
             if i == 0:
@@ -86,6 +93,23 @@ class AnerfEngine:
                 h = ops.linear16(x0, packed, shape, self.b[i], relu=True, x2=h)
             else:
                 h = ops.linear16(h, packed, shape, self.b[i], relu=True)
+        return h
+
+    def _trunk_frag(self, x0):
+        n, W = x0.shape[0], self.cfg["W"]
+        need = (n + 127) // 128 * 128 * W
+        if self._frag_store is None or self._frag_store[0].numel() < need or self._frag_store[0].device != x0.device:
+            self._frag_store = tuple(torch.empty(need, device=x0.device, dtype=torch.float32) for _ in range(2))
+        h = None
+        for i, (packed, shape) in enumerate(self.layers):
+            out = ops.FragBuffer(n, W, x0.device, storage=self._frag_store[i & 1])
+            if i == 0:
+                ops.linear16(x0, packed, shape, self.b[i], relu=True, out=out)
+            elif i in self.skip_into:
+                ops.linear16(x0, packed, shape, self.b[i], relu=True, x2=h, out=out)
+            else:
+                ops.linear16(h, packed, shape, self.b[i], relu=True, out=out)
+            h = out
         return h
 
     def forward_samples(self, rays_o, rays_d, skts, cam_idx=None, z=None, pts=None, view=None, density_only=False):

@@ -405,9 +405,10 @@ def anerf_color(featv, w, C, table, cam_idx, ray0, nrays, S, rgb_w, rgb_b, alpha
 
 
 # -------------------------------------------------------------------------------------- dense layer (fp16-split MFMA)
-def linear16_pack(weight, K1=None, transposed=False):
+def linear16_pack(weight, K1=None, transposed=False, frag_in=(False, False)):
     """nn.Linear weight [N, K] (or, `transposed`, a [K, N] matrix used as W^T) -> packed fragment buffer.
-    K1: columns that multiply the first input of a two-input (skip) layer; the rest multiply the second."""
+    K1: columns that multiply the first input of a two-input (skip) layer; the rest multiply the second.
+    frag_in: which of the two inputs arrive in fragment order (FragBuffer) -- the k-slots of that part are packed to match."""
     w = _f32(weight, "weight")
     N, K = (w.shape[1], w.shape[0]) if transposed else w.shape
     K1 = K if K1 is None else int(K1)
@@ -416,8 +417,39 @@ def linear16_pack(weight, K1=None, transposed=False):
         raise ValueError(f"linear16: unsupported layer shape N={N}, K={K}")
     packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     sn, sk = (1, w.stride(0)) if transposed else (w.stride(0), 1)
-    _call("danbo_linear16_pack", _p(w), sn, sk, N, K1, K - K1, _p(packed), _stream())
+    fr = (1 if frag_in[0] else 0) | (2 if frag_in[1] else 0)
+    _call("danbo_linear16_pack_frag", _p(w), sn, sk, N, K1, K - K1, fr, _p(packed), _stream())
     return packed, (N, K1, K - K1)
+
+
+class FragBuffer:
+    """A [rows, C] activation in the fragment order of k_linear16 (include/danbo_hip.h, danbo_linear16_fwd_frag): C % 32 == 0,
+    rows padded to the 128-row tile, element (16 g + n, 32 s + 16 h + 4 q + i) at [g][s][h][q][n][i].  Lives between the layers
+    of a trunk only; `rows()` un-permutes (tests, debugging)."""
+
+    def __init__(self, rows, C, device, storage=None):
+        if C % 32:
+            raise ValueError("FragBuffer: the width must be a multiple of 32")
+        self.M, self.C = int(rows), int(C)
+        n = (self.M + 127) // 128 * 128 * self.C
+        if storage is not None and storage.numel() < n:
+            raise ValueError("FragBuffer: storage too small")
+        self.data = torch.empty(n, device=device, dtype=torch.float32) if storage is None else storage
+
+    def rows(self):
+        G = (self.M + 127) // 128 * 8
+        t = self.data[:G * 16 * self.C].view(G, self.C // 32, 2, 4, 16, 4).permute(0, 4, 1, 2, 3, 5)
+        return t.reshape(G * 16, self.C)[:self.M]
+
+    @staticmethod
+    def from_rows(x):
+        M, C = x.shape
+        fb = FragBuffer(M, C, x.device)
+        G = (M + 127) // 128 * 8
+        pad = torch.zeros(G * 16, C, device=x.device, dtype=torch.float32)
+        pad[:M] = x
+        fb.data[:G * 16 * C] = pad.view(G, 16, C // 32, 2, 4, 4).permute(0, 2, 3, 4, 1, 5).reshape(-1)
+        return fb
 
 
 def _aligned_rows(t, name):
@@ -434,8 +466,13 @@ def _aligned_rows(t, name):
 
 def linear16(x1, packed, shape, bias=None, relu=False, x2=None, out=None, count=None):
     """y = act([x1 | x2] W^T + bias) for the rows of x1 (/ x2); `out` may be a column slice of a wider buffer whose row
-    stride is a multiple of 4 floats."""
+    stride is a multiple of 4 floats.  x1 / x2 / out may be FragBuffers (the layer must have been packed with the matching
+    `frag_in`); supported combinations: rows -> fragments, fragments -> fragments, [rows | fragments] -> fragments, and
+    fragments -> rows for N <= 256."""
     N, K1, K2 = shape
+    fr = (1 if isinstance(x1, FragBuffer) else 0) | (2 if isinstance(x2, FragBuffer) else 0) | (4 if isinstance(out, FragBuffer) else 0)
+    if fr:
+        return _linear16_frag(x1, packed, shape, bias, relu, x2, out, count, fr)
     if x1.shape[1] != K1 or (K2 > 0) != (x2 is not None):
         raise ValueError(f"linear16: inputs do not match the packed layer ({K1} + {K2} columns)")
     x1, ld1 = _aligned_rows(x1, "x1")
@@ -452,4 +489,41 @@ def linear16(x1, packed, shape, bias=None, relu=False, x2=None, out=None, count=
         raise ValueError("linear16: out must be a [M, N] float32 matrix, unit column stride, rows 16-byte aligned")
     _call("danbo_linear16_fwd", _p(x1), ld1, K1, _p(x2), ld2, K2, _p(packed), _p(_f32(bias, "bias")), N, 1 if relu else 0,
           _p(y), ldy, M, _p(count), _stream())
+    return out
+
+
+def _linear16_frag(x1, packed, shape, bias, relu, x2, out, count, fr):
+    N, K1, K2 = shape
+    if fr not in (1, 4, 5, 6) or (fr == 1 and N > 256):
+        raise ValueError("linear16: unsupported combination of fragment-order inputs / output")
+    if (K2 > 0) != (x2 is not None):
+        raise ValueError(f"linear16: inputs do not match the packed layer ({K1} + {K2} columns)")
+
+    def operand(x, K, name):
+        if isinstance(x, FragBuffer):
+            if x.C != K:
+                raise ValueError(f"linear16: {name} has {x.C} columns, the packed layer wants {K}")
+            return x.data, 0, x.M
+        if x.shape[1] != K:
+            raise ValueError(f"linear16: {name} has {x.shape[1]} columns, the packed layer wants {K}")
+        t, ld = _aligned_rows(x, name)
+        return t, ld, t.shape[0]
+    a1, ld1, M = operand(x1, K1, "x1")
+    a2, ld2 = None, 0
+    if x2 is not None:
+        a2, ld2, M2 = operand(x2, K2, "x2")
+        if M2 != M:
+            raise ValueError("linear16: x2 rows")
+    if isinstance(out, FragBuffer):
+        if out.C != N or out.M != M:
+            raise ValueError("linear16: fragment-order out does not match [rows, N]")
+        y, ldy = out.data, 0
+    else:
+        if out is None:
+            out = torch.empty(M, (N + 3) // 4 * 4, device=a1.device, dtype=torch.float32)[:, :N]
+        y, ldy = _rows(out, "out")
+        if y.data_ptr() != out.data_ptr() or tuple(y.shape) != (M, N) or ldy % 4 or y.data_ptr() % 16:
+            raise ValueError("linear16: out must be a [M, N] float32 matrix, unit column stride, rows 16-byte aligned")
+    _call("danbo_linear16_fwd_frag", _p(a1), ld1, K1, _p(a2), ld2, K2, _p(packed), _p(_f32(bias, "bias")), N, 1 if relu else 0,
+          _p(y), ldy, M, _p(count), fr, _stream())
     return out

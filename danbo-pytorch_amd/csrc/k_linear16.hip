@@ -37,8 +37,10 @@ constexpr int L16_LDS_BYTES = L16_SLOTS * L16_CHUNK + L16_MAX_N * 4;
 //   [tile t][hi | lo][lane 64][8 halves],  lane (m, q) = W[16 T + m][col(s, 8 q + e)]
 // k-steps 0 .. KS1-1 cover the K1 columns of X1, the rest the K2 columns of X2 (each part zero-padded to 32)
 // ---------------------------------------------------------------------------------------------------------------
+// frag (bit 0: the K1 part, bit 1: the K2 part): that input arrives in FRAGMENT ORDER (see Lin16Args::frag) -- k-slot 8 q + e of
+// k-step s then carries input column 32 s + 16 (e / 4) + 4 q + e % 4 instead of 32 s + 8 q + e
 __global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__ w, long sn, long sk, int N, int K1, int K2, int NH,
-                                                       _Float16* __restrict__ packed) {
+                                                       int frag, _Float16* __restrict__ packed) {
     const int KS1 = (K1 + 31) / 32, KS = KS1 + (K2 + 31) / 32;
     const long total = (long)KS * NH * (L16_CHUNK / 2);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -46,10 +48,15 @@ __global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__
         const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
         const int s = chunk / NH, hf = chunk % NH;
         const int n = 16 * (16 * hf + (piece >> 1)) + (lane & 15);
-        const int kk = 8 * (lane >> 4) + e;
+        const int kk_rows = 8 * (lane >> 4) + e, kk_frag = 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
         int col = -1;
-        if (s < KS1) { if (32 * s + kk < K1) col = 32 * s + kk; }
-        else if (32 * (s - KS1) + kk < K2) col = K1 + 32 * (s - KS1) + kk;
+        if (s < KS1) {
+            const int kk = (frag & 1) ? kk_frag : kk_rows;
+            if (32 * s + kk < K1) col = 32 * s + kk;
+        } else {
+            const int kk = (frag & 2) ? kk_frag : kk_rows;
+            if (32 * (s - KS1) + kk < K2) col = K1 + 32 * (s - KS1) + kk;
+        }
         const float v = (n < N && col >= 0) ? w[n * sn + col * sk] : 0.f;
         const _Float16 hi = (_Float16)v;
         packed[idx] = (piece & 1) ? (_Float16)(v - (float)hi) : hi;
@@ -135,6 +142,13 @@ struct Lin16Args {
     float* y;
     int ldy, N, act, M;
     const int32_t* count;
+    // Activations in FRAGMENT ORDER (inference instantiations; bit 0: x1, bit 1: x2, bit 2: y).  A [rows, C] activation, C a
+    // multiple of 32 and rows padded to the 128-row tile, is stored as [rows / 16][C / 32][2][64 lanes][4 floats]: lane (n, q)
+    // of row group g finds the 8 inputs of k-step s in two contiguous 16-byte pieces, (g, s, 0, lane) and (g, s, 1, lane), which
+    // are exactly what it holds of output tiles 2 s and 2 s + 1 of the layer that produced them (features 32 s + 16 h + 4 q + i).
+    // Every load and store instruction of a wavefront then moves one contiguous KB (8 full cache lines) instead of sixteen
+    // 64-byte pieces of sixteen rows -- the row-major epilogue drains at 16 B/clk per CU (s_memtime: 14 000 cycles per tile).
+    int frag;
     long long* trace;  // dev tool (tools/micro_linear16.py --trace): s_memtime stamps of one wavefront, or nullptr
     // ---- EXT instantiations only (training step, danbo_linear16_ex) ----
     const int32_t* first;      // device scalar: first row of x1 / x2 / y / mask this call works on, or nullptr (0)
@@ -236,7 +250,8 @@ __device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
 }
 
 // NP: tile pairs in the last chunk of a k-step known at compile time (no branches in the batch loop), 0 = taken from N
-template <int NH, int NP, bool TRACE, bool EXT>
+// FRAG: Lin16Args::frag as a compile-time constant (a run-time choice costs the registers this kernel does not have)
+template <int NH, int NP, bool TRACE, bool EXT, int FRAG = 0>
 __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + L16_SLOTS * L16_CHUNK);
@@ -276,10 +291,18 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         long row = (long)(blockIdx.x + rq_it * gridDim.x) * L16_BM + wave * 16 + n;
         row = row < M ? row : M - 1;
         const bool second = rq_s >= KS1;
+        if (FRAG & (second ? 2 : 1)) {
+            // fragment order: [row group][k-step][half][lane][4]
+            const long g16 = (long)(blockIdx.x + rq_it * gridDim.x) * (L16_BM / 16) + wave;
+            const int sp = second ? rq_s - KS1 : rq_s, ksp = (second ? a.K2 : a.K1) >> 5;
+            const float* fb = (second ? a.x2 : a.x1) + ((g16 * ksp + sp) * 2) * 256 + lane * 4;
+            lin_request_rows<decltype(set)::value>(fb, fb + 256);
+        } else {
         const float* base = second ? a.x2 + row * a.ld2 : a.x1 + row * a.ld1;
         const int Kp = ((second ? a.K2 : a.K1) + 3) & ~3;   // rows are readable (and finite) up to a multiple of 4 columns
         const int col = 32 * (second ? rq_s - KS1 : rq_s) + 8 * q;
         lin_request_rows<decltype(set)::value>(base + min(col, Kp - 4), base + min(col + 4, Kp - 4));
+        }
         if (rq_s + 1 < KS) ++rq_s;
         else if (rq_it + 1 < my_tiles) rq_s = 0, ++rq_it;
     };
@@ -400,6 +423,22 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         }
         const unsigned relu_lo = (unsigned)relu_w, relu_hi = (unsigned)(relu_w >> 32);
         p.skip = 2;
+        if (FRAG & 4) {
+            // fragment-order output: tile T of this wavefront's 16 rows is one contiguous KB (rows past M: padding of the buffer)
+            const long g16 = (long)(blockIdx.x + it * gridDim.x) * (L16_BM / 16) + wave;
+            float* yf = a.y + g16 * (a.N >> 5) * 512 + lane * 4;
+#pragma unroll
+            for (int T = 0; T < 16 * NH; ++T) {
+                if (16 * T < a.N) {
+                    f32x4 v = acc[T] + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q);
+                    if (a.act == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yf + 256 * T), "v"(v) : "memory");
+                }
+            }
+        } else
         if (row < M) {
             float* yrow = a.y + row * a.ldy;
 #pragma unroll
@@ -495,38 +534,69 @@ extern "C" int danbo_linear16_packed_bytes(int N, int K1, int K2) {
     return ((K1 + 31) / 32 + (K2 + 31) / 32) * lin16_nh(N) * L16_CHUNK;
 }
 
-extern "C" int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int K1, int K2, void* packed, void* stream) {
-    DANBO_CHECK_ARG(w && packed && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0);
+extern "C" int danbo_linear16_pack_frag(const float* w, long stride_n, long stride_k, int N, int K1, int K2, int frag_in, void* packed,
+                                        void* stream) {
+    DANBO_CHECK_ARG(w && packed && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0 && frag_in >= 0 && frag_in <= 3);
+    DANBO_CHECK_ARG(!(frag_in & 1) || K1 % 32 == 0);
+    DANBO_CHECK_ARG(!(frag_in & 2) || (K2 > 0 && K2 % 32 == 0));
     const long total = (long)danbo_linear16_packed_bytes(N, K1, K2) / 2;
     hipLaunchKernelGGL(k_linear16_pack, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, stride_n, stride_k, N, K1,
-                       K2, lin16_nh(N), (_Float16*)packed);
+                       K2, lin16_nh(N), frag_in, (_Float16*)packed);
     DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int K1, int K2, void* packed, void* stream) {
+    return danbo_linear16_pack_frag(w, stride_n, stride_k, N, K1, K2, 0, packed, stream);
 }
 
 extern "C" int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
                                   const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, void* stream) {
+    return danbo_linear16_fwd_frag(x1, ld1, K1, x2, ld2, K2, packed, bias, N, act, y, ldy, M, count, 0, stream);
+}
+
+extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
+                                       const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, int frag,
+                                       void* stream) {
     DANBO_CHECK_ARG(x1 && packed && y && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0 && (K2 == 0 || x2) && M >= 0);
-    DANBO_CHECK_ARG(ldy >= N && (act == 0 || act == 1));
+    DANBO_CHECK_ARG((act == 0 || act == 1) && frag >= 0 && frag <= 7);
+    DANBO_CHECK_ARG(!(frag & 1) || K1 % 32 == 0);
+    DANBO_CHECK_ARG(!(frag & 2) || (K2 > 0 && K2 % 32 == 0));
+    DANBO_CHECK_ARG(!(frag & 4) || N % 32 == 0);
     // 16-byte accesses: row strides multiples of 4 floats, rows readable up to a multiple of 4 columns, aligned bases
-    DANBO_CHECK_ARG(ld1 % 4 == 0 && ld1 >= ((K1 + 3) & ~3) && (K2 == 0 || (ld2 % 4 == 0 && ld2 >= ((K2 + 3) & ~3))) && ldy % 4 == 0);
+    DANBO_CHECK_ARG((frag & 1) || (ld1 % 4 == 0 && ld1 >= ((K1 + 3) & ~3)));
+    DANBO_CHECK_ARG((frag & 2) || K2 == 0 || (ld2 % 4 == 0 && ld2 >= ((K2 + 3) & ~3)));
+    DANBO_CHECK_ARG((frag & 4) || (ldy >= N && ldy % 4 == 0));
     DANBO_CHECK_ARG((uintptr_t)x1 % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
     if (M == 0) return 0;
-    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, g_lin16_trace,
+    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, g_lin16_trace,
                 nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     const int tiles = (M + L16_BM - 1) / L16_BM;
     const dim3 grid(tiles < NUM_CU ? tiles : NUM_CU), block(L16_THREADS);
     const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;   // tile pairs in the last chunk of a k-step
-#define DANBO_L16_GO(NH_, NP_, TR_)                                                                                        \
+#define DANBO_L16_GO(NH_, NP_, TR_, FR_)                                                                                   \
     {                                                                                                                      \
-        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, TR_, false>), L16_LDS_BYTES);                                               \
-        hipLaunchKernelGGL((k_linear16<NH_, NP_, TR_, false>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);        \
+        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, TR_, false, FR_>), L16_LDS_BYTES);                                          \
+        hipLaunchKernelGGL((k_linear16<NH_, NP_, TR_, false, FR_>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);   \
     }
-    if (a.trace && nh == 2) DANBO_L16_GO(2, 0, true)
-    else if (nh == 2 && np == 8) DANBO_L16_GO(2, 8, false)
-    else if (nh == 2 && np == 6) DANBO_L16_GO(2, 6, false)   // N = 448: the A-NeRF trunk
-    else if (nh == 2) DANBO_L16_GO(2, 0, false)
-    else if (np == 8) DANBO_L16_GO(1, 8, false)              // N in 225 .. 256
-    else DANBO_L16_GO(1, 0, false)
+#define DANBO_L16_SHAPES(FR_)                                                                                              \
+    {                                                                                                                      \
+        if (nh == 2 && np == 8) DANBO_L16_GO(2, 8, false, FR_)                                                             \
+        else if (nh == 2 && np == 6) DANBO_L16_GO(2, 6, false, FR_) /* N = 448: the A-NeRF trunk */                        \
+        else if (nh == 2) DANBO_L16_GO(2, 0, false, FR_)                                                                   \
+        else if (np == 8) DANBO_L16_GO(1, 8, false, FR_)            /* N in 225 .. 256 */                                  \
+        else DANBO_L16_GO(1, 0, false, FR_)                                                                                \
+    }
+    if (a.trace && nh == 2 && frag == 0) DANBO_L16_GO(2, 0, true, 0)
+    else if (frag == 0) DANBO_L16_SHAPES(0)
+    else if (frag == 1 && nh == 1) {             // last layer of a fragment-order trunk: rows out (N <= 256: the wider
+        if (np == 8) DANBO_L16_GO(1, 8, false, 1)  // instantiations do not fit the register file, tests/test_host_logic.py)
+        else DANBO_L16_GO(1, 0, false, 1)
+    }
+    else if (frag == 4) DANBO_L16_SHAPES(4)      // first layer: rows in
+    else if (frag == 5) DANBO_L16_SHAPES(5)
+    else if (frag == 6) DANBO_L16_SHAPES(6)      // skip layer: [rows | fragments] in
+    else return DANBO_EINVAL;
+#undef DANBO_L16_SHAPES
 #undef DANBO_L16_GO
     DANBO_LAUNCH_RET();
 }
@@ -542,7 +612,7 @@ extern "C" int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* 
     DANBO_CHECK_ARG(ex->relu_in == nullptr || (ex->mask_cols >= 0 && ex->mask_cols <= 256 && ex->mask_cols % 4 == 0));
     DANBO_CHECK_ARG(ex->relu_out == nullptr || N <= 256);
     if (M == 0) return 0;
-    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, nullptr,
+    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, 0, nullptr,
                 ex->first, (const uint2*)ex->relu_in, (uint2*)ex->relu_out, ex->mask_cols, ex->in_maxabs, ex->out_maxabs,
                 ex->wscale_inv};
     const int tiles = (M + L16_BM - 1) / L16_BM;

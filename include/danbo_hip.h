@@ -308,6 +308,16 @@ int danbo_linear16_pack(const float* w, long stride_n, long stride_k, int N, int
  * 1 = ReLU; rows = min(*count, M) if count != NULL (device-side row count of a compacted list) */
 int danbo_linear16_fwd(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
                        const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, void* stream);
+/* The same layer with activations in FRAGMENT ORDER between the layers of a trunk (csrc/k_linear16.hip, Lin16Args::frag): a
+ * [rows, C] activation, C % 32 == 0, lives in a buffer of round_up(rows, 128) * C floats laid out
+ * [rows / 16][C / 32][2][4 (q)][16 (n)][4 (i)] <-> element (16 g + n, 32 s + 16 h + 4 q + i), so that every load / store
+ * instruction of a wavefront moves one contiguous KB.  frag bits: 1 = x1, 2 = x2, 4 = y are fragment-order buffers (their ld is
+ * ignored); a layer whose input part is in fragment order is packed with the matching bit of frag_in (bit 0: K1 part, bit 1: K2). */
+int danbo_linear16_pack_frag(const float* w, long stride_n, long stride_k, int N, int K1, int K2, int frag_in, void* packed,
+                             void* stream);
+int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
+                            const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, int frag,
+                            void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -116,3 +116,51 @@ def test_linear16_random_layer_shapes():
         y = ops.linear16(x, packed, shape, b, relu=bool(trial & 1))
         # 2^-22 per product plus the fp16-subnormal floor of the lo parts (k_linear16.hip): visible only for K of a few columns
         _check(y, x, w, b, bool(trial & 1), tol=3e-6 if K >= 32 else 2e-5)
+
+
+def test_fragment_order_buffer_round_trip():
+    """FragBuffer: element (16 g + n, 32 s + 16 h + 4 q + i) at [g][s][h][q][n][i] (include/danbo_hip.h)"""
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(300, 96, generator=g).to(DEV)
+    fb = ops.FragBuffer.from_rows(x)
+    assert fb.data.numel() == 384 * 96 and torch.equal(fb.rows(), x)
+    d = fb.data.view(-1, 3, 2, 4, 16, 4)
+    assert float(d[2, 1, 1, 3, 5, 2]) == float(x[16 * 2 + 5, 32 * 1 + 16 * 1 + 4 * 3 + 2])
+
+
+@pytest.mark.parametrize("W,M", [(448, 40000), (256, 1000), (64, 129)])
+def test_linear16_trunk_in_fragment_order_matches_the_row_major_chain(W, M):
+    """rows -> fragments, fragments -> fragments, [rows | fragments] -> fragments (skip layer), fragments -> rows: the chain of
+    layers the A-NeRF engine runs, against the same chain on row-major buffers (each layer sums the same products; only the
+    position of an input inside its 32-wide k-step differs) and against float64"""
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(W + M)
+    K0, Nh = 432, 225 if W >= 225 else 64
+    x0 = torch.randn(M, K0, generator=g).to(DEV)
+    ws = [(torch.randn(W, K0, generator=g) / K0 ** 0.5).to(DEV), (torch.randn(W, W, generator=g) / W ** 0.5).to(DEV),
+          (torch.randn(W, K0 + W, generator=g) / (K0 + W) ** 0.5).to(DEV), (torch.randn(Nh, W, generator=g) / W ** 0.5).to(DEV)]
+    bs = [torch.randn(w.shape[0], generator=g).to(DEV) * 0.1 for w in ws]
+    # row-major chain
+    pk = [ops.linear16_pack(ws[0]), ops.linear16_pack(ws[1]), ops.linear16_pack(ws[2], K1=K0), ops.linear16_pack(ws[3])]
+    h1 = ops.linear16(x0, *pk[0], bs[0], relu=True)
+    h2 = ops.linear16(h1, *pk[1], bs[1], relu=True)
+    h3 = ops.linear16(x0, *pk[2], bs[2], relu=True, x2=h2)
+    yr = ops.linear16(h3, *pk[3], bs[3])
+    # fragment-order chain
+    pf = [ops.linear16_pack(ws[0]), ops.linear16_pack(ws[1], frag_in=(True, False)),
+          ops.linear16_pack(ws[2], K1=K0, frag_in=(False, True)), ops.linear16_pack(ws[3], frag_in=(True, False))]
+    f1, f2, f3 = (ops.FragBuffer(M, W, DEV) for _ in range(3))
+    ops.linear16(x0, *pf[0], bs[0], relu=True, out=f1)
+    assert torch.equal(f1.rows(), h1)                              # same kernel arithmetic, only the store differs
+    ops.linear16(f1, *pf[1], bs[1], relu=True, out=f2)
+    ops.linear16(x0, *pf[2], bs[2], relu=True, x2=f2, out=f3)
+    yf = ops.linear16(f3, *pf[3], bs[3])
+    _check(f2.rows(), h1, ws[1], bs[1], True)
+    _check(f3.rows(), torch.cat([x0, f2.rows()], 1), ws[2], bs[2], True)
+    _check(yf, f3.rows(), ws[3], bs[3], False)
+    assert (yf - yr).abs().max().item() <= 2e-5 * yr.abs().max().item()
+    with pytest.raises(ValueError):
+        ops.linear16(f1, *pk[1], bs[1], relu=True, out=ops.FragBuffer(M, W + 32, DEV))
+    with pytest.raises(ValueError):
+        ops.FragBuffer(M, 100, DEV)

@@ -291,24 +291,40 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
                    check=True, capture_output=True)
     text = open(out).read()
     high = re.compile(r"\bv(24\d|25[0-5])\b|v\[(24\d|25[0-5]):")
-    # (NH, NP, EXT): EXT = the training step's variant (danbo_linear16_ex), whose recorded-ReLU load is one more asm load
-    # waited for together with everything else at the end of a row tile (one in each of the two unrolled k-steps)
-    for nh, np_, ext, handovers in ((1, 0, 0, 2), (2, 0, 0, 4), (1, 8, 0, 2), (2, 6, 0, 4), (2, 8, 0, 4),
-                                    (1, 0, 1, 2), (1, 8, 1, 2), (2, 0, 1, 4)):
-        name = f"_ZN5danbo10k_linear16ILi{nh}ELi{np_}ELb0ELb{ext}EEEvNS_9Lin16ArgsE"
+    # every instantiation <NH, NP, TRACE, EXT, FRAG>.  EXT = the training step's variant (danbo_linear16_ex), whose recorded-ReLU
+    # load is one more asm load waited for together with everything else at the end of a row tile (one in each of the two
+    # unrolled k-steps); FRAG = activations in fragment order (danbo_linear16_fwd_frag)
+    names = re.findall(r"^(_ZN5danbo10k_linear16ILi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)EEEvNS_9Lin16ArgsE):", text, re.M)
+    seen = set()
+    for name, nh, np_, trace, ext, frag in names:
+        nh, np_, trace, ext, frag = int(nh), int(np_), int(trace), int(ext), int(frag)
+        seen.add((nh, np_, trace, ext, frag))
         body = text[text.index(name + ":"):]
         body = body[:body.index(".Lfunc_end")].split("\n")
-        assert not any("scratch_" in l for l in body), "register spills"
+        assert not any("scratch_" in l for l in body), ("register spills", name)
+        # outside the inline asm nothing names v240 .. v255
+        in_asm, foreign = False, []
+        for l in body:
+            in_asm = True if "ASMSTART" in l else (False if "ASMEND" in l else in_asm)
+            if not in_asm and high.search(l):
+                foreign.append(l.strip())
+        assert not foreign, (name, foreign[:4])
         touching = [l.strip() for l in body if high.search(l)]
         loads = [l for l in touching if l.startswith("global_load_dwordx4 v[2")]
         takes = [l for l in touching if re.match(r"v_mov_b32 v\d+, v2[45]\d$", l)]
-        # requests: three in the prologue + one per unrolled k-step, 2 loads each; takes: 8 registers in the prologue and in
-        # each of the two k-steps
-        assert len(loads) == 10 and len(takes) == 24 and len(touching) == 34, touching
+        # requests: three in the prologue + one per unrolled k-step, 2 loads each (a kernel with one part in rows and one in
+        # fragment order carries both address forms); takes: 8 registers in the prologue and in each of the two k-steps
+        mixed = frag in (1, 5, 6)
+        assert len(loads) == (20 if mixed else 10) and len(takes) == 24 and len(touching) == len(loads) + len(takes), (name, touching)
         waits = sorted(re.search(r"vmcnt\(\d+\)", l).group(0) for l in body if "s_waitcnt" in l and "vmcnt" in l)
         # bias table, prologue, one per row-tile end in each of the two unrolled k-steps, final drain; one per hand-over
         # (EXT: + the two recorded-ReLU loads, + one behind the k-step loop in front of the workgroup's running-max atomic)
-        assert waits == sorted(["vmcnt(0)"] * (8 if ext else 5) + ["vmcnt(6)"] * handovers), waits
+        assert waits == sorted(["vmcnt(0)"] * (8 if ext else 5) + ["vmcnt(6)"] * (2 * nh)), (name, waits)
+    # what the launchers dispatch to
+    shapes = {(1, 0), (1, 8), (2, 0), (2, 6), (2, 8)}
+    want = {(nh, np_, 0, 0, fr) for nh, np_ in shapes for fr in (0, 4, 5, 6)} | {(1, 0, 0, 0, 1), (1, 8, 0, 0, 1), (2, 0, 1, 0, 0)}
+    want |= {(1, 0, 0, 1, 0), (1, 8, 0, 1, 0), (2, 0, 0, 1, 0)}
+    assert seen == want, (seen ^ want)
 
 
 def test_ring_kernels_do_not_spill(tmp_path):
