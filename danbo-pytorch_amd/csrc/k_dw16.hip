@@ -4,16 +4,25 @@
 // with fp32-accurate products on the fp16 matrix cores (hi/lo split as in k_linear16.hip, fp32 accumulate).  gfx950 only.
 //
 // The reduction index of this GEMM is the ROW of both operands, i.e. the slow index of both row-major buffers, while an MFMA
-// fragment wants 8 consecutive reduction indices per lane.  So a workgroup stages 32 rows of its 256 gradient columns and
-// 256 input columns through LDS *transposed* (a whole 256 x 256 layer per workgroup: every operand row is read from HBM ONCE
-// per layer -- with 128-column tiles the kernel re-read the inputs per tile and sat on the HBM roof at 3.4 TB/s): every thread loads the same 4 columns of two consecutive rows (2 x 16 B),
-// splits them into fp16 hi / lo and writes row PAIRS as 32-bit words at [column][row] (column stride 80 B: 2-way bank
-// conflicts at most for the writes and for the 16-byte fragment reads).  Eight wavefronts then own 64 x 128 of the
-// 256 x 256 output tile each (32 accumulator tiles = 128 VGPRs): per 32-row step 24 fragment reads feed 96 MFMAs.
+// fragment wants 8 consecutive reduction indices per lane.  So 32 rows of a tile's 128 gradient columns and 256 input columns
+// go through LDS *transposed*: a thread loads the same 4 columns of two consecutive rows (2 x 16 B), splits them into fp16
+// hi / lo and writes row PAIRS as 32-bit words at [column][row] (column stride 72 B, see DW_CSTRIDE).
+// The workgroup is SPECIALISED: wavefronts 4-7 are producers (global loads into two register sets, i.e. two 32-row steps
+// ahead -- one load instruction = 128 contiguous bytes of 8 rows --, hi/lo split in three instructions per value pair,
+// transposed LDS stores, bias-gradient column sums), wavefronts 0-3 -- one per SIMD -- are consumers
+// (each owns 64 x 128 of the 128 x 256 output tile = 32 accumulator tiles; 24 fragment reads feed 96 MFMAs per step).  The
+// converted tile is double-buffered in LDS, one barrier per step: the producers fill buffer (s + 1) & 1 while the consumers
+// multiply out of buffer s & 1, so HBM latency, the VALU conversion and the MFMAs overlap inside ONE workgroup per CU.  (The
+// unspecialised forms -- every wavefront loads, converts, then multiplies: 256 x 256 tiles at one workgroup per CU, 128 x 256
+// at two, 128 x 128 at three -- all measured 0.49-0.52 ms: their loads were only in flight during the MFMA phase.  This form:
+// 0.39 ms, with the MFMAs compiled out the same -- the producers set the pace, at 3.4 TB/s of HBM reads, 1.33 GB per launch by
+// the FETCH_SIZE counter against 1.0 GB if every operand row were read once.)
+// The two 128-column halves of a layer's gradient read the same input rows: they are neighbours in the work-item order and
+// blockIdx is permuted so that both run on the same XCD at the same time -- the second read of the inputs is an L2 hit.
 // Rows are split over `slices` workgroups per tile; partial tiles go to a scratch buffer and a second kernel sums the
 // slices in a fixed order (deterministic, no float atomics), undoes the power-of-two pre-scale of the gradient operand
 // (in_maxabs of danbo_linear16_ex) and writes the gradients in nn.Linear layout.
-// Algorithmic traffic per row and layer: 4 (N + K) bytes read once per 128 x 256 tile of the layer; flops 2 N K (x 3 MFMA products).
+// Algorithmic traffic per row and layer: 4 (N + K) bytes; flops 2 N K (x 3 MFMA products).
 #include "common.hpp"
 
 namespace danbo {
@@ -21,12 +30,22 @@ namespace danbo {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int DW_TN = 256, DW_TK = 256, DW_ROWS = 32, DW_THREADS = 512;
-constexpr int DW_CSTRIDE = 80;                           // bytes per column in LDS: 32 rows x 2 B + 16 B padding
+__device__ __forceinline__ half8 dw_frag(const char* p) {   // 16 bytes at an 8-byte aligned LDS address
+    const half4 a = *reinterpret_cast<const half4*>(p), b = *reinterpret_cast<const half4*>(p + 8);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+constexpr int DW_TN = 128, DW_TK = 256, DW_ROWS = 32, DW_THREADS = 512, DW_PRODUCERS = 256;
+// bytes per column in LDS: 32 rows x 2 B + 8 B padding.  18 words: the 32-bit transposed stores of a producer wavefront (8 row pairs
+// x 8 groups of 4 columns) fall into 32 different banks per half-wave, and the 16 columns a fragment read touches start in 16
+// different even banks; the price is 8-byte alignment, i.e. fragments are read as two 8-byte halves
+constexpr int DW_CSTRIDE = 72;
 constexpr int DW_A_BYTES = DW_TN * DW_CSTRIDE;           // one of hi / lo
 constexpr int DW_B_BYTES = DW_TK * DW_CSTRIDE;
-constexpr int DW_LDS_BYTES = 2 * DW_A_BYTES + 2 * DW_B_BYTES + DW_TN * 4;   // + column sums
+constexpr int DW_BUF_BYTES = 2 * DW_A_BYTES + 2 * DW_B_BYTES;               // one converted 32-row step
+constexpr int DW_LDS_BYTES = 2 * DW_BUF_BYTES + DW_TN * 4;                  // double-buffered + column sums
 constexpr int DW_MAX_LAYERS = 12;
 
 struct DwLayer {
@@ -64,144 +83,232 @@ __device__ __forceinline__ void dw_pow2_scale(float maxabs, float& s, float& inv
     inv = __builtin_bit_cast(float, (254u - se) << 23);
 }
 
+// (a, b) -> hi = {fp16(a), fp16(b)}, lo = {fp16(a - hi.x), fp16(b - hi.y)} in three instructions: one packed convert and two
+// mixed-precision fmas that subtract the fp16 half from the fp32 value and round once (a - fp16(a) is exact in fp32, so this is
+// bit for bit the four-instruction form (_Float16)(a - (float)(_Float16)a))
+__device__ __forceinline__ void dw_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(a), "v"(b));
+}
+
 // two rows x 4 columns -> hi / lo halves, stored as row pairs
+template <bool SCALE>
 __device__ __forceinline__ void dw_store4(char* hi_base, char* lo_base, int col, int rp, const f32x4& r0, const f32x4& r1, float sc) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float a = r0[j] * sc, b = r1[j] * sc;
-        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-        const half2v h = {ah, bh};
-        const half2v l = {(_Float16)(a - (float)ah), (_Float16)(b - (float)bh)};
-        *reinterpret_cast<half2v*>(hi_base + (col + j) * DW_CSTRIDE + rp * 4) = h;
-        *reinterpret_cast<half2v*>(lo_base + (col + j) * DW_CSTRIDE + rp * 4) = l;
+        unsigned h, l;
+        dw_split2(SCALE ? r0[j] * sc : r0[j], SCALE ? r1[j] * sc : r1[j], h, l);
+        *reinterpret_cast<unsigned*>(hi_base + (col + j) * DW_CSTRIDE + rp * 4) = h;
+        *reinterpret_cast<unsigned*>(lo_base + (col + j) * DW_CSTRIDE + rp * 4) = l;
     }
 }
 
 __global__ __launch_bounds__(DW_THREADS, 1) void k_dw16(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_ah = smem;
-    char* s_al = smem + DW_A_BYTES;
-    char* s_bh = smem + 2 * DW_A_BYTES;
-    char* s_bl = smem + 2 * DW_A_BYTES + DW_B_BYTES;
-    float* s_db = reinterpret_cast<float*>(smem + 2 * DW_A_BYTES + 2 * DW_B_BYTES);
+    float* s_db = reinterpret_cast<float*>(smem + 2 * DW_BUF_BYTES);
+
+    // work item: blockIdx permuted so that items 2j and 2j + 1 (the two gradient-column halves of a layer's tile) get
+    // workgroup ids 8 apart, i.e. the same XCD back to back
+    const int id = (int)blockIdx.x, xcd = id & 7, kk = id >> 3;
+    const int item = ((((kk >> 1) << 3) + xcd) << 1) + (kk & 1);
+    if (item >= a.n_tiles * a.slices) return;
+    const int sl = item / a.n_tiles, tile = item % a.n_tiles;
 
     const int M = resolve_count(a.count, a.M);
-    const int sl = blockIdx.y;
     const int rps = dw_rows_per_slice(M, a.slices);
     const int row0 = sl * rps;
     if (row0 >= M) return;                       // empty slice: the reduction only reads slices that exist
     const int row_end = min(row0 + rps, M);
 
-    // which layer / tile
+    // which layer / tile (gradient-column tile fastest)
     int li = 0;
-    while (li + 1 < a.n_layers && (int)blockIdx.x >= a.l[li + 1].tile0) ++li;
+    while (li + 1 < a.n_layers && tile >= a.l[li + 1].tile0) ++li;
     const DwLayer& L = a.l[li];
-    const int t = (int)blockIdx.x - L.tile0;
-    const int tn = t / L.nt_k, tk = t % L.nt_k;
+    const int t = tile - L.tile0;
+    const int nt_n = (L.N + DW_TN - 1) / DW_TN;
+    const int tn = t % nt_n, tk = t / nt_n;
     const int n0 = tn * DW_TN, v0 = tk * DW_TK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = tid >= DW_THREADS - DW_PRODUCERS;
     float sc = 1.f, inv = 1.f;
     if (L.dy_maxabs != nullptr) dw_pow2_scale(*L.dy_maxabs, sc, inv);
 
-    // loader mapping: lanes run over row pairs first (16 pairs = 32 rows), then over groups of 4 columns
-    const int rp = tid & 15;
-    const int ga = tid >> 4;                     // columns 4 ga .. + 3 and 4 (ga + 32) .. + 3 of both operands
-    f32x4 ra[2][2], rb[2][2];                    // [group][row of the pair]
-    // 32-bit byte offsets from the (uniform) buffer bases: 12 loads in flight would otherwise pin 24 address registers
-    const char* const dy_b = reinterpret_cast<const char*>(L.dy);
-    const char* const x1_b = reinterpret_cast<const char*>(L.x1);
-    const char* const x2_b = reinterpret_cast<const char*>(L.x2);
-
-    auto load_step = [&](int r) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int col = n0 + 4 * (ga + 32 * u);
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const int row = r + 2 * rp + w;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row < row_end && col < L.N) {
-                    const unsigned off = ((unsigned)row * (unsigned)L.ldy + (unsigned)col) * 4u;
-                    const float* p = reinterpret_cast<const float*>(dy_b + off);
-                    if (col + 4 <= L.N) v = *reinterpret_cast<const f32x4*>(p);
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (col + j < L.N) v[j] = p[j];
-                    }
-                }
-                ra[u][w] = v;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int vc = v0 + 4 * (ga + 32 * u);       // virtual column: [x1 padded to K1p | x2]
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const int row = r + 2 * rp + w;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row < row_end && vc < L.Kv) {
-                    if (vc < L.K1p) v = *reinterpret_cast<const f32x4*>(x1_b + ((unsigned)row * (unsigned)L.ld1 + (unsigned)vc) * 4u);
-                    else {
-                        const int c2 = vc - L.K1p;
-                        const float* p = reinterpret_cast<const float*>(x2_b + ((unsigned)row * (unsigned)L.ld2 + (unsigned)c2) * 4u);
-                        if (c2 + 4 <= L.K2) v = *reinterpret_cast<const f32x4*>(p);
-                        else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (c2 + j < L.K2) v[j] = p[j];
-                        }
-                    }
-                }
-                rb[u][w] = v;
-            }
-        }
+    const int nsteps = (row_end - row0 + DW_ROWS - 1) / DW_ROWS;
+    for (int i = tid; i < DW_TN; i += DW_THREADS) s_db[i] = 0.f;
+    __syncthreads();
+    float* part = a.part + L.part_off + (long)sl * ((long)L.N * L.Kv + L.N);
+    // Both roles execute the same sequence of barriers (1 + nsteps).  They are separate regions of the kernel so that neither
+    // carries the other's registers: 96 staging registers here, 128 accumulators + 40 fragment registers there.
+    auto wg_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
 
-    // wave tile: 64 gradient columns x 128 input columns (8 wavefronts: 4 x 2)
-    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
-    const int m = lane & 15, q = lane >> 4;
-    const bool wave_live = (n0 + wn < L.N) && (v0 + wk < L.Kv);
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int i = tid; i < DW_TN; i += DW_THREADS) s_db[i] = 0.f;
-    load_step(row0);
-    __syncthreads();
-    for (int r = row0; r < row_end; r += DW_ROWS) {
-        // registers -> LDS (transposed, split)
+    if (producer) {
+        // ---- producers: lanes run over row pairs first (16 pairs = 32 rows), then over groups of 4 columns
+        const int ptid = tid & (DW_PRODUCERS - 1);
+        // a wavefront covers 8 row pairs x 8 column groups: one load instruction fetches 128 contiguous bytes of 8 rows
+        // (with 16 row pairs x 4 groups it was sixteen 64-byte pieces)
+        const int pw = ptid >> 6;
+        const int rp = (lane & 7) + 8 * (pw & 1);
+        const int ga = (lane >> 3) + 8 * (pw >> 1);  // column groups ga + 16 u: u < 2 of the gradient, u < 4 of the inputs
+        struct Stage { f32x4 a[2][2], b[4][2]; };    // [group][row of the pair]
+        // Every load is issued for every thread in every step (past the last column: the group at column 0 -- no branch, no
+        // zero-initialised alternative, so two steps of loads stay in flight); what must not count is zeroed when the values
+        // are converted, and only in tiles / steps that have such columns / rows (uniform branches).  The 12 addresses are
+        // 64-bit pointers advanced by 32 rows per step: steps are requested in order.
+        unsigned a_live = 0, b_live = 0;                 // 4 bits per group, one per column
+        float db_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const char* pa[2][2];
+        const char* pb[4][2];
+        unsigned a_stride, b_stride[4];
+        a_stride = (unsigned)L.ldy * 4u * DW_ROWS;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            dw_store4(s_ah, s_al, 4 * (ga + 32 * u), rp, ra[u][0], ra[u][1], sc);
-            if (tk == 0) {   // bias gradient: the 16 lanes of a DPP row hold the 32 rows of the same 4 columns
+            const int col = n0 + 4 * (ga + 16 * u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x = ra[u][0][j] + ra[u][1][j];
-                    DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
-                    DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x118, 0xf)
-                    if (rp == 15) s_db[4 * (ga + 32 * u) + j] += x;      // this lane is the only writer of the entry
-                }
-            }
+            for (int j = 0; j < 4; ++j) a_live |= (col + j < L.N ? 1u : 0u) << (4 * u + j);
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+                pa[u][w] = reinterpret_cast<const char*>(L.dy + (long)(row0 + 2 * rp + w) * L.ldy + (col < L.N ? col : 0));
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dw_store4(s_bh, s_bl, 4 * (ga + 32 * u), rp, rb[u][0], rb[u][1], 1.f);
-        __syncthreads();
-        if (r + DW_ROWS < row_end) load_step(r + DW_ROWS);     // next step's rows fly under this step's MFMAs
-        if (wave_live) {
+        for (int u = 0; u < 4; ++u) {
+            const int vc = v0 + 4 * (ga + 16 * u);       // virtual column: [x1 padded to K1p | x2]
+            const bool first = vc < L.K1p || L.x2 == nullptr;
+            const int c = first ? (vc < L.K1p ? vc : 0) : (vc < L.Kv ? vc - L.K1p : 0);
+            const int ld = first ? L.ld1 : L.ld2;
+            b_stride[u] = (unsigned)ld * 4u * DW_ROWS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool live = first ? (vc + j < L.K1) : (vc + j < L.Kv);
+                b_live |= (live ? 1u : 0u) << (4 * u + j);
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+                pb[u][w] = reinterpret_cast<const char*>((first ? L.x1 : L.x2) + (long)(row0 + 2 * rp + w) * ld + c);
+        }
+        const bool cols_full = __all((a_live == 0xffu) && (b_live == 0xffffu));   // per wavefront
+        int next_row = row0;                            // first row of the step the next load_step requests
+        auto load_step = [&](Stage& st) {
+            if (next_row + DW_ROWS <= row_end) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w]);
+                }
+            } else {
+                // the slice's last, partial step: rows past the end read the last row again (zeroed in convert)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const long back = (long)max(next_row + 2 * rp + w - (row_end - 1), 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w] - back * (L.ldy * 4));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w] - back * (long)(b_stride[u] / DW_ROWS));
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pa[u][w] += a_stride;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pb[u][w] += b_stride[u];
+            }
+            next_row += DW_ROWS;
+        };
+        // registers -> LDS buffer `buf` (transposed, split); the bias gradient on the way
+        auto convert = [&](Stage& st, int buf, int r) {
+            char* const base = smem + buf * DW_BUF_BYTES;
+            if (!cols_full || r + DW_ROWS > row_end) {      // edge tile / last step of the slice: zero what does not exist
+                const bool ok[2] = {r + 2 * rp < row_end, r + 2 * rp + 1 < row_end};
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st.a[u][w][j] = ok[w] && ((a_live >> (4 * u + j)) & 1u) ? st.a[u][w][j] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st.b[u][w][j] = ok[w] && ((b_live >> (4 * u + j)) & 1u) ? st.b[u][w][j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dw_store4<true>(base, base + DW_A_BYTES, 4 * (ga + 16 * u), rp, st.a[u][0], st.a[u][1], sc);
+                if (tk == 0) {   // the 16 lanes of a DPP row hold the 32 rows of the same 4 columns
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = st.a[u][0][j] + st.a[u][1][j];
+                        // 8 consecutive lanes hold 16 rows of the same 4 columns: after shifts by 1, 2, 4 lane 7 of the eight has
+                        // their sum (a window of 8: lanes 8-15 of a DPP row do not see lanes 0-7)
+                        DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
+                        DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf)
+                        if ((lane & 7) == 7) db_acc[4 * u + j] += x;     // column sums stay in registers until the end
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dw_store4<false>(base + 2 * DW_A_BYTES, base + 2 * DW_A_BYTES + DW_B_BYTES, 4 * (ga + 16 * u), rp, st.b[u][0], st.b[u][1], 1.f);
+        };
+        Stage sa, sb;                                 // steps 0, 2, 4, ... / 1, 3, 5, ...
+        load_step(sa);
+        if (nsteps > 1) load_step(sb);
+        convert(sa, 0, row0);
+        if (nsteps > 2) load_step(sa);
+        wg_sync();
+        for (int s = 0; s < nsteps; s += 2) {
+            // consumers: step s out of buffer 0.  Step s + 1 into buffer 1, step s + 3 requested
+            if (s + 1 < nsteps) convert(sb, 1, row0 + (s + 1) * DW_ROWS);
+            if (s + 3 < nsteps) load_step(sb);
+            wg_sync();
+            if (s + 1 >= nsteps) break;
+            // consumers: step s + 1 out of buffer 1.  Step s + 2 into buffer 0, step s + 4 requested
+            if (s + 2 < nsteps) convert(sa, 0, row0 + (s + 2) * DW_ROWS);
+            if (s + 4 < nsteps) load_step(sa);
+            wg_sync();
+        }
+        if (tk == 0 && (lane & 7) == 7) {            // two wavefronts (row pairs 0-7 / 8-15) per column: LDS float atomics
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(s_db + 4 * (ga + 16 * u) + j, db_acc[4 * u + j]);
+        }
+    } else {
+        // ---- consumers: wave tile 64 gradient columns x 128 input columns (4 wavefronts: 2 x 2)
+        const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+        const int m = lane & 15, q = lane >> 4;
+        const bool wave_live = (n0 + wn < L.N) && (v0 + wk < L.Kv);
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto multiply = [&](int buf) {
+            const char* const s_ah = smem + buf * DW_BUF_BYTES;
+            const char* const s_al = s_ah + DW_A_BYTES;
+            const char* const s_bh = s_ah + 2 * DW_A_BYTES;
+            const char* const s_bl = s_bh + DW_B_BYTES;
             half8 ah[4], al[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(s_ah + (wn + 16 * i + m) * DW_CSTRIDE + q * 16);
-                al[i] = *reinterpret_cast<const half8*>(s_al + (wn + 16 * i + m) * DW_CSTRIDE + q * 16);
+                ah[i] = dw_frag(s_ah + (wn + 16 * i + m) * DW_CSTRIDE + q * 16);
+                al[i] = dw_frag(s_al + (wn + 16 * i + m) * DW_CSTRIDE + q * 16);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const half8 bh = *reinterpret_cast<const half8*>(s_bh + (wk + 16 * j + m) * DW_CSTRIDE + q * 16);
-                const half8 bl = *reinterpret_cast<const half8*>(s_bl + (wk + 16 * j + m) * DW_CSTRIDE + q * 16);
+                const half8 bh = dw_frag(s_bh + (wk + 16 * j + m) * DW_CSTRIDE + q * 16);
+                const half8 bl = dw_frag(s_bl + (wk + 16 * j + m) * DW_CSTRIDE + q * 16);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
@@ -209,24 +316,29 @@ __global__ __launch_bounds__(DW_THREADS, 1) void k_dw16(DwArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
                 }
             }
+        };
+        wg_sync();
+        for (int s = 0; s < nsteps; s += 2) {
+            if (wave_live) multiply(0);
+            wg_sync();
+            if (s + 1 >= nsteps) break;
+            if (wave_live) multiply(1);
+            wg_sync();
         }
-        __syncthreads();
-    }
-
-    // partial tile: lane (m, q) of accumulator tile (i, j) holds dW[n0 + wn + 16 i + 4 q + e][v0 + wk + 16 j + m]
-    float* part = a.part + L.part_off + (long)sl * ((long)L.N * L.Kv + L.N);
-    if (wave_live) {
+        // partial tile: lane (m, q) of accumulator tile (i, j) holds dW[n0 + wn + 16 i + 4 q + e][v0 + wk + 16 j + m]
+        if (wave_live) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int vc = v0 + wk + 16 * j + m;
+                for (int j = 0; j < 8; ++j) {
+                    const int vc = v0 + wk + 16 * j + m;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + wn + 16 * i + 4 * q + e;
-                    if (n < L.N && vc < L.Kv) part[(long)n * L.Kv + vc] = acc[i][j][e];
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + wn + 16 * i + 4 * q + e;
+                        if (n < L.N && vc < L.Kv) part[(long)n * L.Kv + vc] = acc[i][j][e];
+                    }
                 }
-            }
+        }
     }
     // column sums of the gradient (bias gradient), once per gradient-column tile
     if (tk == 0) {
@@ -324,7 +436,8 @@ extern "C" int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const
     }
     a.n_tiles = tile;
     DANBO_ENSURE_LDS(k_dw16, DW_LDS_BYTES);
-    hipLaunchKernelGGL(k_dw16, dim3(tile, slices), dim3(DW_THREADS), DW_LDS_BYTES, (hipStream_t)stream, a);
+    const int items = tile * slices;
+    hipLaunchKernelGGL(k_dw16, dim3((items + 15) / 16 * 16), dim3(DW_THREADS), DW_LDS_BYTES, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_dw16_reduce, dim3(128, n_layers), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

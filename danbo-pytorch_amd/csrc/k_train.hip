@@ -170,7 +170,7 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long pa
     return b;
 }
 
-constexpr int DW_SLICES = 18;      // 14 tiles of 256 x 256 x 18 row slices = 252 workgroups: one per CU
+constexpr int DW_SLICES = 10;      // 24 tiles of 128 x 256 x 10 row slices = 240 workgroups: one per CU
 
 void describe_dw(const DanboTrainModel* m, const TrainBuffers& b, DanboDwLayer* L) {
     const int mx_of_dz[8] = {MX_Z0, MX_Z1, MX_Z2, MX_Z3, MX_Z4, MX_Z5, MX_Z6, MX_Z7};
