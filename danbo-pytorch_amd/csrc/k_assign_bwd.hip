@@ -28,7 +28,10 @@ constexpr int AB_W = 32;             // hidden width of the assignment net
 constexpr int AB_STRIDE = AB_W + 1;  // padded rows: row-wise and column-wise reads are both conflict-free
 constexpr int AB_THREADS = 256;
 constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefronts x 2 halves)
-constexpr int AB_PPW = 128;          // pairs per workgroup (16 iterations of 8): amortises the weight staging and the flush
+// pairs per workgroup: amortises the weight staging and the flush.  Chosen on the device between AB_PPW_MIN and AB_PPW so that the
+// workgroups that find pairs fit the 2 x 256 resident slots in ONE round (80 k pairs at 128 each were 640 workgroups: a full
+// round and a 25 % one)
+constexpr int AB_PPW_MIN = 128, AB_PPW = 256, AB_TARGET_WGS = 2 * NUM_CU - J;
 
 struct ABArgs {
     // geometry
@@ -47,7 +50,6 @@ struct ABArgs {
     float *g_w0, *g_adj_w, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2, *g_vol /*[G,24,240]*/, *g_scale /*[24,3]*/;
     float c_ss;          // 2 coef / (R (S + Sf))
     float* loss;         // loss[2] += (label - q)^2 of in-volume rows
-    int pairs_per_wg;    // pairs one workgroup serves (workgroups are dealt to the bones in proportion to their pair counts)
 };
 
 __device__ __forceinline__ float half_sum32(float v) {
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
     __shared__ __attribute__((aligned(16))) float s_df[AB_PAIRS][AB_MAXNB][16];
     __shared__ __attribute__((aligned(16))) float s_a0[AB_PAIRS][AB_W], s_dz1[AB_PAIRS][AB_W], s_dz0[AB_PAIRS][AB_W], s_dh[AB_PAIRS][16];
 
-    // workgroup -> (bone j, chunk of its pair list): bones get ceil(pairs / pairs_per_wg) workgroups each, in bone order
+    // workgroup -> (bone j, chunk of its pair list): bones get ceil(pairs / ppw) workgroups each, in bone order
     // (the 24 counters and the bone's adjacency row are fetched by 24 lanes at once: a serial loop of dependent global loads
     //  cost ~50 us per workgroup)
     __shared__ int s_cnt[J];
@@ -77,15 +79,18 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, slot = tid >> 5;   // slot: which pair of the 8 in flight
     if (tid < J) s_cnt[tid] = min(a.cntb[tid], a.cap);
     __syncthreads();
+    int total_pairs = 0;
+    for (int k = 0; k < J; ++k) total_pairs += s_cnt[k];
+    const int ppw = min(max(((total_pairs + AB_TARGET_WGS - 1) / AB_TARGET_WGS + 7) & ~7, AB_PPW_MIN), AB_PPW);
     int j = 0, wg = blockIdx.x, npairs = 0;
     for (; j < J; ++j) {
         npairs = s_cnt[j];
-        const int need = (npairs + a.pairs_per_wg - 1) / a.pairs_per_wg;
+        const int need = (npairs + ppw - 1) / ppw;
         if (wg < need) break;
         wg -= need;
     }
     if (j == J) return;
-    const int p_begin = wg * a.pairs_per_wg, p_end = min(p_begin + a.pairs_per_wg, npairs);
+    const int p_begin = wg * ppw, p_end = min(p_begin + ppw, npairs);
 
     // ---- neighbourhood of bone j from the adjacency buffer (self first) and its weights
     if (tid < J) s_adjrow[tid] = a.adj[j * J + tid];
@@ -369,8 +374,7 @@ extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
     a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
     // 256 pairs (32 iterations of 8) per workgroup amortise its weight staging and its flush; a sample lies in at most a few
     // volumes, so 4 pairs per row of capacity is far above what geometry allows -- and workgroups without pairs exit at once
-    a.pairs_per_wg = AB_PPW;
-    const long wgs = ((long)p->rows_cap * 4 + a.pairs_per_wg - 1) / a.pairs_per_wg + J;
+    const long wgs = ((long)p->rows_cap * 4 + AB_PPW_MIN - 1) / AB_PPW_MIN + J;
     hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < 65535 ? wgs : 65535)), dim3(AB_THREADS), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
