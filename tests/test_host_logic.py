@@ -347,3 +347,28 @@ def test_ring_kernels_do_not_spill(tmp_path):
             body = text[text.index(re.search(r"^(_ZN5danbo\S*" + k + r"\S*):", text, re.M).group(1) + ":"):]
             body = body[:body.index(".Lfunc_end")]
             assert "scratch_" not in body and "buffer_store" not in body, k
+
+
+def test_fragment_order_buffer_layout_on_cpu():
+    """hip_ops.FragBuffer (the activation layout between the layers of a k_linear16 trunk, include/danbo_hip.h
+    danbo_linear16_fwd_frag): element (16 g + n, 32 s + 16 h + 4 q + i) lives at [g][s][h][q][n][i], rows padded to the 128-row
+    tile -- pure index arithmetic, checked without a GPU; and the packing permutation a consumer layer uses for such an input:
+    k-slot 8 q + e of k-step s carries column 32 s + 16 (e / 4) + 4 q + e % 4, i.e. lane (n, q) finds its 8 k-slots of k-step s
+    in the two 16-byte pieces [g][s][0][q][n][:] and [g][s][1][q][n][:]"""
+    from core import hip_ops as ops
+    rng = np.random.default_rng(5)
+    M, C = 300, 96
+    x = torch.from_numpy(rng.normal(size=(M, C)).astype(np.float32))
+    fb = ops.FragBuffer.from_rows(x)
+    assert fb.data.numel() == 384 * C and torch.equal(fb.rows(), x)
+    d = fb.data.view(-1, C // 32, 2, 4, 16, 4)
+    for g, s, h, q, n, i in ((0, 0, 0, 0, 0, 0), (2, 1, 1, 3, 5, 2), (18, 2, 0, 1, 11, 3)):
+        assert float(d[g, s, h, q, n, i]) == float(x[16 * g + n, 32 * s + 16 * h + 4 * q + i])
+    assert float(d[18, 0, 0, 0, 12, 0]) == 0.0                         # row 300: padding
+    # the consumer's view: lane (n, q), k-slot 8 q + e  <->  column 32 s + 16 (e // 4) + 4 q + e % 4
+    g, s, n, q = 3, 2, 7, 2
+    lane_vals = torch.cat([d[g, s, 0, q, n], d[g, s, 1, q, n]])
+    want = torch.stack([x[16 * g + n, 32 * s + 16 * (e // 4) + 4 * q + e % 4] for e in range(8)])
+    assert torch.equal(lane_vals, want)
+    with pytest.raises(ValueError):
+        ops.FragBuffer(10, 100, "cpu")
