@@ -128,13 +128,15 @@ def test_dense_layer_forward_backward_and_weight_gradients_match_torch():
         assert float((gb - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()) + 1e-12
 
 
-def fused_step(fixture, graph=False):
+def fused_step(fixture, graph=False, edit=None):
     g = golden(fixture)
     args, caster, trainer, opt = build_trainer(g)
     eng = trainer.fused_engine()
     assert eng is not None, trainer.fused_reason
     eng.use_graph = graph
     b = batch_of(g)
+    if edit is not None:
+        edit(b)
     G = b["N_uniques"]
     pp = caster._per_pose
     out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G), b["cam_idxs"],
@@ -276,3 +278,56 @@ def test_graph_replays_are_repeatable():
         assert torch.equal(out["counts"], ref_counts)
         assert torch.isfinite(eng.flat_g).all()
         assert float((eng.flat_g - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
+
+
+def _autograd_grads(fixture, edit):
+    g = golden(fixture)
+    args, caster, trainer, opt = build_trainer(g)
+    caster.train()
+    b = batch_of(g)
+    edit(b)
+    kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs")}
+    preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                   N_uniques=b["N_uniques"], **kw)
+    loss = trainer.compute_loss(b, preds)
+    caster.zero_grad()
+    loss["total_loss"].backward()
+    return ({n: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for n, p in caster.network.named_parameters()},
+            preds, {k: float(v.detach()) for k, v in loss.items()})
+
+
+@pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count"])
+def test_fused_step_on_degenerate_batches(case):
+    """Batches the device-side row bookkeeping has to survive: no sample inside any bone volume (zero in-volume rows: only the
+    per-ray empty-space rows carry a gradient), one pose whose rays all miss while the others hit, and a ray count that is no
+    multiple of any tile size -- against the autograd path on the same batch."""
+    def edit(b):
+        if case == "no_sample_in_any_volume":
+            b["rays_o"] = b["rays_o"] + torch.tensor([40.0, 0.0, 0.0], device=DEV)
+        elif case == "one_pose_misses":
+            per = b["rays_o"].shape[0] // b["N_uniques"]
+            b["rays_o"] = b["rays_o"].clone()
+            b["rays_o"][:per] += torch.tensor([40.0, 0.0, 0.0], device=DEV)
+        else:
+            G = b["N_uniques"]
+            per = b["rays_o"].shape[0] // G
+            keep = torch.cat([torch.arange(g0 * per, g0 * per + per - 3, device=DEV) for g0 in range(G)])   # 3 rays fewer per pose
+            for k in ("rays_o", "rays_d", "target_s", "bgs", "kp3d", "skts", "bones", "cyls", "cam_idxs"):
+                b[k] = b[k][keep].contiguous()
+    ref, preds, ref_loss = _autograd_grads("danbo_perfcap_train", edit)
+    g, args, caster, trainer, eng, out = fused_step("danbo_perfcap_train", edit=edit)
+    counts = out["counts"].cpu().numpy()
+    R = out["rgb_map"].shape[0]
+    assert torch.isfinite(out["loss"]).all() and torch.isfinite(eng.flat_g).all()
+    if case == "no_sample_in_any_volume":
+        assert counts[2] == R and counts[3] == 0, counts          # rows of the coarse pass = the R empty-space rows, fine pass: none
+    assert float((out["rgb_map"] - preds["rgb_map"].detach()).abs().max()) < 1e-4
+    assert abs(float(out["loss"][0]) - ref_loss["rgb_loss"]) <= 2e-4 * max(abs(ref_loss["rgb_loss"]), 1e-3)
+    worst = 0.0
+    for n, p in caster.network.named_parameters():
+        a, r = p.grad, ref[n]
+        scale = float(r.abs().max())
+        d = float((a - r).abs().max())
+        assert d <= 2e-3 * scale + 1e-9, (n, d, scale)
+        worst = max(worst, d / (scale + 1e-30))
+    print(case, "rows", counts[:6], "worst relative gradient deviation", worst)
