@@ -26,6 +26,7 @@ class DanboEngine:
         self.mean_code = None
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
+        self._side = None            # side stream of render()
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
@@ -160,22 +161,27 @@ class DanboEngine:
                                self.code_table)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None, fill=True):
+                        want_confd=False, volumes=None, view=None, fill=True, ready=None):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
                      the per-ray empty-space raw (identical values).
-        dense=True : every sample goes through every kernel (the reference's executed work)."""
+        dense=True : every sample goes through every kernel (the reference's executed work).
+        ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used."""
         self.refresh()
         geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts)
         vols = self.volumes(bones) if volumes is None else volumes
         cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
         S = geo.S
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready[0])
         if self.mlp_mode == "f16split":
             h, confd = ops.gather_assign_blend16(geo, vols, bits, self.aw, self.assign16, lst, cnt, geo.M, want_confd)
         else:
             h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready[1])
         # fill=False: rows outside every volume stay unwritten; the consumer reads raw_empty for them (valid_bits == 0)
         raw = ops.fill_raw(raw_empty, S) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
         if self.profile is not None:
@@ -269,14 +275,35 @@ class DanboEngine:
         Sf = N_importance or cfg["N_importance"]
         B = cfg["density_scale"]
         self.refresh()
+        # The per-pose volumes (4 small launches, ~70 us) and the per-ray view constants (~140 us at 512 x 512) depend on
+        # nothing the bounds / depths / cull chain computes: they run on a side stream under it; the main stream waits for the
+        # volumes in front of K2 and for the view constants in front of K3.  (Inside a HIP-graph capture the chain stays linear.)
+        ready = None
+        if rays_o.is_cuda and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream()
+            if self._side is None or self._side.device != rays_o.device:
+                self._side = torch.cuda.Stream(device=rays_o.device)
+            side = self._side
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                vols = self.volumes(bones)
+                ev_vols = torch.cuda.Event()
+                ev_vols.record(side)
+                view = self.view_constants(rays_d, skts, cam_idx)
+                ev_view = torch.cuda.Event()
+                ev_view.record(side)
+            for t in (vols, view[0], view[1]):
+                t.record_stream(cur)
+            ready = (ev_vols, ev_view)
         near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
         z = ops.coarse_samples(near, far, S)
-        vols = self.volumes(bones)
-        view = self.view_constants(rays_d, skts, cam_idx)
+        if ready is None:
+            vols = self.volumes(bones)
+            view = self.view_constants(rays_d, skts, cam_idx)
         fused = S <= 64 and Sf <= 64
         lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy)
+                                       fill=not lazy, ready=ready)
         if fused:
             out0, z_all, z_fine, order = ops.composite_importance(
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,

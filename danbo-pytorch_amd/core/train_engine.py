@@ -197,7 +197,7 @@ class DanboTrainEngine:
         return out
 
     def _step_phase(self, out, phase):
-        """phase 0: the whole step; 1: up to the K2 / K1b adjoint (every gradient but graph_net.layers.* final); 2: the rest"""
+        """phase 0: the whole step; 1: up to the pose-GNN adjoint (every gradient but the dense layers' final); 2: the rest"""
         _, bt, o = out['_keep']
         _hip.check(_hip.lib().danbo_train_step_phase(ctypes.byref(self._model()), ctypes.byref(bt), ctypes.byref(o), _P(self._ws),
                                                      self._ws.numel(), int(phase),
@@ -248,7 +248,7 @@ class DanboTrainEngine:
             with torch.cuda.graph(g):
                 outs = self._launch(static, S, Sf, perturb, raw_noise_std, split)
             g2 = None
-            if split:                             # the pose-GNN adjoint as its own graph: the all-reduce of the finished
+            if split:                             # the weight-gradient GEMMs as their own graph: the all-reduce of the finished
                 g2 = torch.cuda.CUDAGraph()       # gradients is launched between the two replays
                 with torch.cuda.graph(g2):
                     self._step_phase(outs, 2)
@@ -273,7 +273,7 @@ class DanboTrainEngine:
         torch.cat(parts, out=flat)
 
     def finish_backward(self):
-        """second half of a split step (forward_backward(..., split=True)): the pose-GNN adjoint"""
+        """second half of a split step (forward_backward(..., split=True)): the dense layers' weight gradients"""
         outs, g2 = self._pending
         if g2 is not None:
             g2.replay()
@@ -282,11 +282,11 @@ class DanboTrainEngine:
         self._pending = None
 
     def grad_buckets(self):
-        """(finished after phase 1, finished after phase 2): the flat gradient of everything but the pose GNN, and the pose GNN's
-        (graph_net.layers.* are the first tensors of the flat layout)"""
-        cut = self.offsets['graph_net.axis_scale'] if 'graph_net.axis_scale' in self.trainable else \
-            self.offsets['prob_linears.layers.0.lin.weight']
-        return self.flat_g[cut:self.n_train], self.flat_g[:cut]
+        """(finished after phase 1, finished after phase 2): the flat gradient of the pose GNN, the assignment net and the axis
+        scales -- the first tensors of the flat layout, 7 of its 10 MB -- and the dense layers' (+ the frame codes, which sit
+        behind them)"""
+        cut = self.offsets['pts_linears.0.weight']
+        return self.flat_g[:cut], self.flat_g[cut:self.n_train]
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, lr, grad_scale=1.0):

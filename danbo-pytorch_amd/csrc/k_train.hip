@@ -280,9 +280,10 @@ extern "C" size_t danbo_train_workspace(const DanboTrainModel* m, int R, int G, 
     return c2.used + 512;
 }
 
-// phase 0: the whole step; 1: everything up to and including the K2 / K1b adjoint -- from then on every gradient except the
-// pose GNN's (graph_net.layers.*, the first tensors of the flat buffer) is final; 2: the pose GNN adjoint and the loss copy.
-// Data-parallel training launches the all-reduce of the finished part on a side stream between phases 1 and 2.
+// phase 0: the whole step; 1: everything up to and including the pose-GNN adjoint -- from then on every gradient except the
+// dense layers' (pts_linears.*, alpha / feature / views / rgb_linear) is final; 2: the dense layers' weight gradients and the
+// loss copy.  Data-parallel training launches the all-reduce of the finished part (pose GNN, assignment net, axis scales: the
+// first tensors of the flat buffer, 7 of its 10 MB) on a side stream between phases 1 and 2.
 static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, const DanboTrainOut* o, void* workspace,
                            size_t workspace_bytes, void* stream, int phase) {
     DANBO_CHECK_ARG(model_ok(m) && bt && o && workspace && phase >= 0 && phase <= 2);
@@ -446,10 +447,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         ex.relu_in = nullptr; ex.mask_cols = 0;
         DANBO_TRY(danbo_linear16_ex(b.dz[0], 256, 256, nullptr, 0, 0, b.packed + off[19], nullptr, 195, 0, b.d_x0, LD_PE, ncap, all_rows, &ex, stream));
     }
-    DANBO_STAGE(8);
-    // ---- weight / bias gradients of all 12 layers, frame codes
-    DANBO_TRY(danbo_dw16(dwl, 12, ncap, all_rows, DW_SLICES, b.dw_scratch, stream));
     DANBO_STAGE(9);
+    // ---- frame codes
     if (m->n_codes > 0)
         DANBO_TRY(danbo_train_code_grad(b.d_vfeat, LD_VF, 256 + 3 * (1 + 2 * m->L_view), m->code_size, b.row_ray, bt->cam_idx, b.cnt, ncap,
                                         m->n_codes, m->g[DANBO_T_CODES], stream));
@@ -471,13 +470,18 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     ab.loss = b.loss;
     DANBO_TRY(danbo_assign_blend_bwd(&ab, stream));
     DANBO_STAGE(11);
-    }   // phase != 2
-    if (phase == 1) { DANBO_LAUNCH_RET(); }
     DANBO_TRY(danbo_pose_volumes_bwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], m->p[DANBO_T_G_ADJW0], m->g_adj0,
                                      m->p[DANBO_T_G_B0], m->p[DANBO_T_G_W1], m->p[DANBO_T_G_ADJW1], m->g_adj1, m->p[DANBO_T_G_B1],
                                      m->p[DANBO_T_G_W2], m->p[DANBO_T_G_W3], b.vol_scratch, b.g_vol, m->g[DANBO_T_G_W0], m->g[DANBO_T_G_ADJW0],
                                      m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
                                      m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, stream));
+    DANBO_STAGE(12);
+    }   // phase != 2
+    if (phase == 1) { DANBO_LAUNCH_RET(); }
+    // ---- weight / bias gradients of all 12 dense layers (last: it needs nothing but the activations and their gradients, and
+    //      data-parallel training hides the all-reduce of everything computed so far -- 7 of the 10 MB -- under it)
+    const int32_t* all_rows2 = b.cnt + 4;
+    DANBO_TRY(danbo_dw16(dwl, 12, ncap, all_rows2, DW_SLICES, b.dw_scratch, stream));
     // ---- loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
     hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),
                        reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),

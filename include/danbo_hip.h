@@ -497,9 +497,10 @@ size_t danbo_train_workspace(const DanboTrainModel* model, int R, int G, int S, 
 /* S >= 3, S + Sf <= 256.  Enqueues ~75 kernels on `stream`; nothing synchronises, every data-dependent size stays on the device. */
 int danbo_train_step(const DanboTrainModel* model, const DanboTrainBatch* batch, const DanboTrainOut* out, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* the same step in two pieces for data-parallel training: phase 1 = everything up to the K2 / K1b adjoint (after it every
- * gradient except graph_net.layers.* is final and can go into the all-reduce), phase 2 = the pose GNN adjoint + the loss copy;
- * phase 0 = both.  Same arguments for both calls. */
+/* the same step in two pieces for data-parallel training: phase 1 = everything up to and including the pose-GNN adjoint (after
+ * it every gradient except the dense layers' -- pts_linears.*, alpha / feature / views / rgb_linear -- is final and can go into
+ * the all-reduce), phase 2 = the dense layers' weight gradients (danbo_dw16) + the loss copy; phase 0 = both.  Same arguments
+ * for both calls. */
 int danbo_train_step_phase(const DanboTrainModel* model, const DanboTrainBatch* batch, const DanboTrainOut* out, void* workspace,
                            size_t workspace_bytes, int phase, void* stream);
 
