@@ -118,17 +118,18 @@ N_TRAIN_TENSORS = len(TRAIN_TENSORS)   # DANBO_T_COUNT
 
 
 class DanboLinearEx(ctypes.Structure):
-    _fields_ = [("first", P), ("relu_in", P), ("relu_out", P), ("mask_cols", I), ("in_maxabs", P), ("out_maxabs", P), ("wscale_inv", P)]
+    _fields_ = [("first", P), ("relu_in", P), ("relu_out", P), ("mask_cols", I), ("in_maxabs", P), ("out_maxabs", P), ("wscale_inv", P),
+                ("frag", I)]
 
 
 class DanboPackDesc(ctypes.Structure):
     _fields_ = ([("w", P), ("w2", P)] + [(n, c_long) for n in ("sn", "sk", "sn2", "sk2")]
-                + [(n, I) for n in ("N", "K1", "K2", "n_shift", "split_n", "split_k")])
+                + [(n, I) for n in ("N", "K1", "K2", "n_shift", "split_n", "split_k", "frag_in")])
 
 
 class DanboDwLayer(ctypes.Structure):
     _fields_ = ([(n, P) for n in ("dy", "x1", "x2", "dy_maxabs", "gw", "gw2", "gb", "gb2")]
-                + [(n, I) for n in ("ldy", "ld1", "ld2", "N", "K1", "K2", "split_n")])
+                + [(n, I) for n in ("ldy", "ld1", "ld2", "N", "K1", "K2", "split_n", "frag", "gw_ld", "gw_col0")])
 
 
 class DanboAssignBwd(ctypes.Structure):

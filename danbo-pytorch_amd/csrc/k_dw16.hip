@@ -46,7 +46,7 @@ constexpr int DW_A_BYTES = DW_TN * DW_CSTRIDE;           // one of hi / lo
 constexpr int DW_B_BYTES = DW_TK * DW_CSTRIDE;
 constexpr int DW_BUF_BYTES = 2 * DW_A_BYTES + 2 * DW_B_BYTES;               // one converted 32-row step
 constexpr int DW_LDS_BYTES = 2 * DW_BUF_BYTES + DW_TN * 4;                  // double-buffered + column sums
-constexpr int DW_MAX_LAYERS = 12;
+constexpr int DW_MAX_LAYERS = 13;
 
 struct DwLayer {
     const float* dy;       // [rows, ldy] gradient with respect to the layer's pre-activation
@@ -58,6 +58,8 @@ struct DwLayer {
     float* gb;
     float* gb2;
     int ldy, ld1, ld2, N, K1, K2, split_n;
+    int frag;              // bit 0: dy, 1: x1 (then K2 == 0) in the fragment order of k_linear16 ([rows/16][C/32][2][4 q][16 n][4])
+    int gw_ld, gw_col0;    // the gradient goes to gw[n * gw_ld + gw_col0 + k] (a layer whose inputs are handled as two layers)
     int K1p, Kv;           // K1 rounded up to 4; virtual width K1p + K2
     int tile0, nt_k;       // first tile of this layer, tiles along K
     long part_off;         // floats: this layer's [slices][N * Kv + N] partial block
@@ -106,6 +108,190 @@ __device__ __forceinline__ void dw_store4(char* hi_base, char* lo_base, int col,
     }
 }
 
+// The producer half of k_dw16 for one combination of operand layouts (compile-time: with run-time layout tests in the load /
+// convert loops the compiler serialises the loads of a step behind vmcnt(0) / vmcnt(1) waits).
+struct DwCtx {
+    char* smem; float* s_db;
+    int tid, lane, row0, row_end, nsteps, n0, v0, tk;
+    float sc;
+};
+__device__ __forceinline__ void dw_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <bool FA, bool FB>
+__device__ __forceinline__ void dw_producer(const DwLayer& L, const DwCtx& c) {
+    char* const smem = c.smem;
+    float* const s_db = c.s_db;
+    const int tid = c.tid, lane = c.lane, row0 = c.row0, row_end = c.row_end, nsteps = c.nsteps, n0 = c.n0, v0 = c.v0, tk = c.tk;
+    const float sc = c.sc;
+    auto wg_sync = []() { dw_sync(); };
+    {
+        // ---- producers.  A thread owns row PAIR p of the 32-row step -- rows p and p + 16, one 32-bit word of hi halves and
+        // one of lo halves per column -- and a few groups of 4 columns.  Which (p, columns) a lane gets depends on the
+        // operand's layout, so that one load instruction of a wavefront is as contiguous as the layout allows:
+        //   row-major      : 8 row pairs x 8 column groups  -> 128 contiguous bytes of 8 consecutive rows
+        //                    (with 16 pairs x 4 groups it was sixteen 64-byte pieces: 0.43 -> 0.39 ms)
+        //   fragment order : 16 row pairs x 4 column groups -> ONE contiguous KB, the [4 q][16 n][4] block of a k-step half
+        // Any pairing works as long as both operands use the same one: the sum over rows does not care.
+        const int ptid = tid & (DW_PRODUCERS - 1);
+        const int pw = ptid >> 6;
+        constexpr bool fragA = FA, fragB = FB;
+        const int pA = fragA ? (lane & 15) : (lane & 7) + 8 * (pw & 1);
+        const int pB = fragB ? (lane & 15) : (lane & 7) + 8 * (pw & 1);
+        int colA[2], colB[4];                         // first of the thread's 4 columns, relative to the tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u) colA[u] = fragA ? 16 * (pw + 4 * u) + 4 * (lane >> 4) : 4 * ((lane >> 3) + 8 * (pw >> 1) + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) colB[u] = fragB ? 16 * (pw + 4 * u) + 4 * (lane >> 4) : 4 * ((lane >> 3) + 8 * (pw >> 1) + 16 * u);
+        struct Stage { f32x4 a[2][2], b[4][2]; };    // [group][row of the pair]
+        // Every load is issued for every thread in every step (past the last column: the group at column 0 -- no branch, no
+        // zero-initialised alternative, so two steps of loads stay in flight); what must not count is zeroed when the values
+        // are converted, and only in tiles / steps that have such columns / rows (uniform branches).  The 12 addresses are
+        // 64-bit pointers advanced by 32 rows per step: steps are requested in order.
+        unsigned a_live = 0, b_live = 0;                 // 4 bits per group, one per column
+        float db_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const char* pa[2][2];
+        const char* pb[4][2];
+        unsigned a_stride, b_stride[4];
+        // address of (row, 4 columns from `col`) of a fragment-order buffer of width C
+        auto frag_ptr = [&](const float* base, int C, int row, int col) {
+            const long g = row >> 4;
+            const int nn = row & 15, cg = col >> 2;
+            return reinterpret_cast<const char*>(base + ((g * (C >> 5) + (cg >> 3)) * 2 + ((cg >> 2) & 1)) * 256 + (nn + 16 * (cg & 3)) * 4);
+        };
+        a_stride = fragA ? (unsigned)(L.N >> 5) * 4096u : (unsigned)L.ldy * 4u * DW_ROWS;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = n0 + colA[u];
+            const int cc = col < L.N ? col : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_live |= (col + j < L.N ? 1u : 0u) << (4 * u + j);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int row = row0 + pA + 16 * w;
+                pa[u][w] = fragA ? frag_ptr(L.dy, L.N, row, cc) : reinterpret_cast<const char*>(L.dy + (long)row * L.ldy + cc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int vc = v0 + colB[u];                 // virtual column: [x1 padded to K1p | x2]
+            const bool first = vc < L.K1p || L.x2 == nullptr;
+            const int c = first ? (vc < L.K1p ? vc : 0) : (vc < L.Kv ? vc - L.K1p : 0);
+            const int ld = first ? L.ld1 : L.ld2;
+            b_stride[u] = fragB ? (unsigned)(L.K1 >> 5) * 4096u : (unsigned)ld * 4u * DW_ROWS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool live = first ? (vc + j < L.K1) : (vc + j < L.Kv);
+                b_live |= (live ? 1u : 0u) << (4 * u + j);
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int row = row0 + pB + 16 * w;
+                pb[u][w] = fragB ? frag_ptr(L.x1, L.K1, row, c)
+                                 : reinterpret_cast<const char*>((first ? L.x1 : L.x2) + (long)row * ld + c);
+            }
+        }
+        const bool cols_full = __all((a_live == 0xffu) && (b_live == 0xffffu));   // per wavefront
+        int next_row = row0;                            // first row of the step the next load_step requests
+        auto load_step = [&](Stage& st) {
+            if (next_row + DW_ROWS <= row_end) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w]);
+                }
+            } else {
+                // the slice's last, partial step: rows past the end read the last row again (row-major; a fragment-order buffer is
+                // padded to whole 128-row tiles and read in place); zeroed in convert
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const long backA = (long)max(next_row + pA + 16 * w - (row_end - 1), 0);
+                    const long backB = (long)max(next_row + pB + 16 * w - (row_end - 1), 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w] - (fragA ? 0 : backA * (L.ldy * 4)));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w] - (fragB ? 0 : backB * (long)(b_stride[u] / DW_ROWS)));
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pa[u][w] += a_stride;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pb[u][w] += b_stride[u];
+            }
+            next_row += DW_ROWS;
+        };
+        // registers -> LDS buffer `buf` (transposed, split); the bias gradient on the way
+        auto convert = [&](Stage& st, int buf, int r) {
+            char* const base = smem + buf * DW_BUF_BYTES;
+            if (!cols_full || r + DW_ROWS > row_end) {      // edge tile / last step of the slice: zero what does not exist
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const bool okA = r + pA + 16 * w < row_end, okB = r + pB + 16 * w < row_end;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st.a[u][w][j] = okA && ((a_live >> (4 * u + j)) & 1u) ? st.a[u][w][j] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st.b[u][w][j] = okB && ((b_live >> (4 * u + j)) & 1u) ? st.b[u][w][j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dw_store4<true>(base, base + DW_A_BYTES, colA[u], pA, st.a[u][0], st.a[u][1], sc);
+                if (tk == 0) {   // the 16 lanes of a DPP row hold the 32 rows of the same 4 columns
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = st.a[u][0][j] + st.a[u][1][j];
+                        // row-major: 8 consecutive lanes hold 16 rows of the same 4 columns: after shifts by 1, 2, 4 lane 7 of the
+                        // eight has their sum (a window of 8: lanes 8-15 of a DPP row do not see lanes 0-7); fragment order: the
+                        // 16 lanes of a DPP row hold all 32 rows, one more shift and lane 15 has the sum
+                        DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
+                        DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf)
+                        if (fragA) DANBO_DPP_STEP(dpp_add_, 0.f, 0x118, 0xf)
+                        if (fragA ? (lane & 15) == 15 : (lane & 7) == 7) db_acc[4 * u + j] += x;   // column sums stay in registers
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dw_store4<false>(base + 2 * DW_A_BYTES, base + 2 * DW_A_BYTES + DW_B_BYTES, colB[u], pB, st.b[u][0], st.b[u][1], 1.f);
+        };
+        Stage sa, sb;                                 // steps 0, 2, 4, ... / 1, 3, 5, ...
+        load_step(sa);
+        if (nsteps > 1) load_step(sb);
+        convert(sa, 0, row0);
+        if (nsteps > 2) load_step(sa);
+        wg_sync();
+        for (int s = 0; s < nsteps; s += 2) {
+            // consumers: step s out of buffer 0.  Step s + 1 into buffer 1, step s + 3 requested
+            if (s + 1 < nsteps) convert(sb, 1, row0 + (s + 1) * DW_ROWS);
+            if (s + 3 < nsteps) load_step(sb);
+            wg_sync();
+            if (s + 1 >= nsteps) break;
+            // consumers: step s + 1 out of buffer 1.  Step s + 2 into buffer 0, step s + 4 requested
+            if (s + 2 < nsteps) convert(sa, 0, row0 + (s + 2) * DW_ROWS);
+            if (s + 4 < nsteps) load_step(sa);
+            wg_sync();
+        }
+        if (tk == 0 && (fragA ? (lane & 15) == 15 : (lane & 7) == 7)) {   // row-major: two wavefronts (row pairs 0-7 / 8-15) per column
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(s_db + colA[u] + j, db_acc[4 * u + j]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(DW_THREADS, 1) void k_dw16(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_db = reinterpret_cast<float*>(smem + 2 * DW_BUF_BYTES);
@@ -143,146 +329,15 @@ __global__ __launch_bounds__(DW_THREADS, 1) void k_dw16(DwArgs a) {
     float* part = a.part + L.part_off + (long)sl * ((long)L.N * L.Kv + L.N);
     // Both roles execute the same sequence of barriers (1 + nsteps).  They are separate regions of the kernel so that neither
     // carries the other's registers: 96 staging registers here, 128 accumulators + 40 fragment registers there.
-    auto wg_sync = []() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
+    auto wg_sync = []() { dw_sync(); };
 
     if (producer) {
-        // ---- producers: lanes run over row pairs first (16 pairs = 32 rows), then over groups of 4 columns
-        const int ptid = tid & (DW_PRODUCERS - 1);
-        // a wavefront covers 8 row pairs x 8 column groups: one load instruction fetches 128 contiguous bytes of 8 rows
-        // (with 16 row pairs x 4 groups it was sixteen 64-byte pieces)
-        const int pw = ptid >> 6;
-        const int rp = (lane & 7) + 8 * (pw & 1);
-        const int ga = (lane >> 3) + 8 * (pw >> 1);  // column groups ga + 16 u: u < 2 of the gradient, u < 4 of the inputs
-        struct Stage { f32x4 a[2][2], b[4][2]; };    // [group][row of the pair]
-        // Every load is issued for every thread in every step (past the last column: the group at column 0 -- no branch, no
-        // zero-initialised alternative, so two steps of loads stay in flight); what must not count is zeroed when the values
-        // are converted, and only in tiles / steps that have such columns / rows (uniform branches).  The 12 addresses are
-        // 64-bit pointers advanced by 32 rows per step: steps are requested in order.
-        unsigned a_live = 0, b_live = 0;                 // 4 bits per group, one per column
-        float db_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const char* pa[2][2];
-        const char* pb[4][2];
-        unsigned a_stride, b_stride[4];
-        a_stride = (unsigned)L.ldy * 4u * DW_ROWS;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int col = n0 + 4 * (ga + 16 * u);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a_live |= (col + j < L.N ? 1u : 0u) << (4 * u + j);
-#pragma unroll
-            for (int w = 0; w < 2; ++w)
-                pa[u][w] = reinterpret_cast<const char*>(L.dy + (long)(row0 + 2 * rp + w) * L.ldy + (col < L.N ? col : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int vc = v0 + 4 * (ga + 16 * u);       // virtual column: [x1 padded to K1p | x2]
-            const bool first = vc < L.K1p || L.x2 == nullptr;
-            const int c = first ? (vc < L.K1p ? vc : 0) : (vc < L.Kv ? vc - L.K1p : 0);
-            const int ld = first ? L.ld1 : L.ld2;
-            b_stride[u] = (unsigned)ld * 4u * DW_ROWS;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool live = first ? (vc + j < L.K1) : (vc + j < L.Kv);
-                b_live |= (live ? 1u : 0u) << (4 * u + j);
-            }
-#pragma unroll
-            for (int w = 0; w < 2; ++w)
-                pb[u][w] = reinterpret_cast<const char*>((first ? L.x1 : L.x2) + (long)(row0 + 2 * rp + w) * ld + c);
-        }
-        const bool cols_full = __all((a_live == 0xffu) && (b_live == 0xffffu));   // per wavefront
-        int next_row = row0;                            // first row of the step the next load_step requests
-        auto load_step = [&](Stage& st) {
-            if (next_row + DW_ROWS <= row_end) {
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w]);
-                }
-            } else {
-                // the slice's last, partial step: rows past the end read the last row again (zeroed in convert)
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const long back = (long)max(next_row + 2 * rp + w - (row_end - 1), 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w] - back * (L.ldy * 4));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w] - back * (long)(b_stride[u] / DW_ROWS));
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) pa[u][w] += a_stride;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pb[u][w] += b_stride[u];
-            }
-            next_row += DW_ROWS;
-        };
-        // registers -> LDS buffer `buf` (transposed, split); the bias gradient on the way
-        auto convert = [&](Stage& st, int buf, int r) {
-            char* const base = smem + buf * DW_BUF_BYTES;
-            if (!cols_full || r + DW_ROWS > row_end) {      // edge tile / last step of the slice: zero what does not exist
-                const bool ok[2] = {r + 2 * rp < row_end, r + 2 * rp + 1 < row_end};
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) st.a[u][w][j] = ok[w] && ((a_live >> (4 * u + j)) & 1u) ? st.a[u][w][j] : 0.f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) st.b[u][w][j] = ok[w] && ((b_live >> (4 * u + j)) & 1u) ? st.b[u][w][j] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                dw_store4<true>(base, base + DW_A_BYTES, 4 * (ga + 16 * u), rp, st.a[u][0], st.a[u][1], sc);
-                if (tk == 0) {   // the 16 lanes of a DPP row hold the 32 rows of the same 4 columns
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x = st.a[u][0][j] + st.a[u][1][j];
-                        // 8 consecutive lanes hold 16 rows of the same 4 columns: after shifts by 1, 2, 4 lane 7 of the eight has
-                        // their sum (a window of 8: lanes 8-15 of a DPP row do not see lanes 0-7)
-                        DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
-                        DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf)
-                        if ((lane & 7) == 7) db_acc[4 * u + j] += x;     // column sums stay in registers until the end
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                dw_store4<false>(base + 2 * DW_A_BYTES, base + 2 * DW_A_BYTES + DW_B_BYTES, 4 * (ga + 16 * u), rp, st.b[u][0], st.b[u][1], 1.f);
-        };
-        Stage sa, sb;                                 // steps 0, 2, 4, ... / 1, 3, 5, ...
-        load_step(sa);
-        if (nsteps > 1) load_step(sb);
-        convert(sa, 0, row0);
-        if (nsteps > 2) load_step(sa);
-        wg_sync();
-        for (int s = 0; s < nsteps; s += 2) {
-            // consumers: step s out of buffer 0.  Step s + 1 into buffer 1, step s + 3 requested
-            if (s + 1 < nsteps) convert(sb, 1, row0 + (s + 1) * DW_ROWS);
-            if (s + 3 < nsteps) load_step(sb);
-            wg_sync();
-            if (s + 1 >= nsteps) break;
-            // consumers: step s + 1 out of buffer 1.  Step s + 2 into buffer 0, step s + 4 requested
-            if (s + 2 < nsteps) convert(sa, 0, row0 + (s + 2) * DW_ROWS);
-            if (s + 4 < nsteps) load_step(sa);
-            wg_sync();
-        }
-        if (tk == 0 && (lane & 7) == 7) {            // two wavefronts (row pairs 0-7 / 8-15) per column: LDS float atomics
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(s_db + 4 * (ga + 16 * u) + j, db_acc[4 * u + j]);
+        const DwCtx ctx{smem, s_db, tid, lane, row0, row_end, nsteps, n0, v0, tk, sc};
+        switch (L.frag & 3) {
+            case 0: dw_producer<false, false>(L, ctx); break;
+            case 1: dw_producer<true, false>(L, ctx); break;
+            case 2: dw_producer<false, true>(L, ctx); break;
+            default: dw_producer<true, true>(L, ctx); break;
         }
     } else {
         // ---- consumers: wave tile 64 gradient columns x 128 input columns (4 wavefronts: 2 x 2)
@@ -384,7 +439,7 @@ __global__ __launch_bounds__(256) void k_dw16_reduce(DwArgs a) {
             if (g != nullptr) g[n < L.split_n ? n : n - L.split_n] = s;   // the bias sums use the unscaled gradient
         } else {
             float* g = n < L.split_n ? L.gw : L.gw2;
-            if (g != nullptr) g[(long)(n < L.split_n ? n : n - L.split_n) * K + k] = s * inv;
+            if (g != nullptr) g[(long)(n < L.split_n ? n : n - L.split_n) * L.gw_ld + L.gw_col0 + k] = s * inv;
         }
     }
 }
@@ -418,13 +473,17 @@ extern "C" int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const
     for (int i = 0; i < n_layers; ++i) {
         const DanboDwLayer& s = layers[i];
         DANBO_CHECK_ARG(s.dy && s.x1 && s.N >= 1 && s.K1 >= 1 && s.K2 >= 0 && (s.K2 == 0 || s.x2));
-        DANBO_CHECK_ARG(s.ld1 % 4 == 0 && s.ld1 >= ((s.K1 + 3) & ~3) && (uintptr_t)s.x1 % 16 == 0);
-        DANBO_CHECK_ARG(s.K2 == 0 || (s.ld2 % 4 == 0 && s.ld2 >= s.K2 && (uintptr_t)s.x2 % 16 == 0));
-        DANBO_CHECK_ARG(s.ldy % 4 == 0 && s.ldy >= s.N && (uintptr_t)s.dy % 16 == 0);
+        DANBO_CHECK_ARG(s.frag >= 0 && s.frag <= 3 && (uintptr_t)s.x1 % 16 == 0 && (uintptr_t)s.x2 % 16 == 0 && (uintptr_t)s.dy % 16 == 0);
+        DANBO_CHECK_ARG((s.frag & 2) ? (s.K1 % 32 == 0 && s.K2 == 0) : (s.ld1 % 4 == 0 && s.ld1 >= ((s.K1 + 3) & ~3)));
+        DANBO_CHECK_ARG(s.K2 == 0 || (s.ld2 % 4 == 0 && s.ld2 >= s.K2));
+        DANBO_CHECK_ARG(s.gw_ld == 0 || (s.gw_ld >= s.gw_col0 + s.K1 + s.K2 && s.gw_col0 >= 0 && !s.gw2));
+        DANBO_CHECK_ARG((s.frag & 1) ? s.N % 32 == 0 : (s.ldy % 4 == 0 && s.ldy >= s.N));
         DwLayer& L = a.l[i];
         L.dy = s.dy; L.x1 = s.x1; L.x2 = s.x2; L.dy_maxabs = s.dy_maxabs;
         L.gw = s.gw; L.gw2 = s.gw2; L.gb = s.gb; L.gb2 = s.gb2;
-        L.ldy = s.ldy; L.ld1 = s.ld1; L.ld2 = s.ld2; L.N = s.N; L.K1 = s.K1; L.K2 = s.K2;
+        L.ldy = s.ldy; L.ld1 = s.ld1; L.ld2 = s.ld2; L.N = s.N; L.K1 = s.K1; L.K2 = s.K2; L.frag = s.frag;
+        L.gw_ld = s.gw_ld > 0 ? s.gw_ld : s.K1 + s.K2;
+        L.gw_col0 = s.gw_ld > 0 ? s.gw_col0 : 0;
         L.split_n = s.gw2 || s.gb2 ? s.split_n : 0x7fffffff;
         L.K1p = (s.K1 + 3) & ~3;
         L.Kv = L.K1p + s.K2;

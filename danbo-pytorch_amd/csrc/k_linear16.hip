@@ -123,10 +123,15 @@ __global__ __launch_bounds__(256) void k_linear16_group_pack(PackGroupArgs a) {
         const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
         const int s = chunk / NH, hf = chunk % NH;
         const int n = 16 * (16 * hf + (piece >> 1)) + (lane & 15);
-        const int kk = 8 * (lane >> 4) + e;
+        const int kk_rows = 8 * (lane >> 4) + e, kk_frag = 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);   // see k_linear16_pack
         int col = -1;
-        if (s < KS1) { if (32 * s + kk < d.K1) col = 32 * s + kk; }
-        else if (32 * (s - KS1) + kk < d.K2) col = d.K1 + 32 * (s - KS1) + kk;
+        if (s < KS1) {
+            const int kk = (d.frag_in & 1) ? kk_frag : kk_rows;
+            if (32 * s + kk < d.K1) col = 32 * s + kk;
+        } else {
+            const int kk = (d.frag_in & 2) ? kk_frag : kk_rows;
+            if (32 * (s - KS1) + kk < d.K2) col = d.K1 + 32 * (s - KS1) + kk;
+        }
         const float v = (n < d.N && col >= 0) ? pack_fetch(d, n, col) * sc : 0.f;
         const _Float16 hi = (_Float16)v;
         out[idx] = (piece & 1) ? (_Float16)(v - (float)hi) : hi;
@@ -263,10 +268,10 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     float in_scale = 1.f, out_scale = 1.f, seen_max = 0.f;
     if (EXT) {
         if (a.first != nullptr) {
-            const long r0 = *a.first;
-            a.x1 += r0 * a.ld1;
-            if (a.x2 != nullptr) a.x2 += r0 * a.ld2;
-            a.y += r0 * a.ldy;
+            const long r0 = *a.first;      // a multiple of 128 when any operand is in fragment order (the caller's contract)
+            a.x1 += (FRAG & 1) ? (r0 >> 4) * (a.K1 >> 5) * 512 : r0 * a.ld1;
+            if (a.x2 != nullptr) a.x2 += (FRAG & 2) ? (r0 >> 4) * (a.K2 >> 5) * 512 : r0 * a.ld2;
+            a.y += (FRAG & 4) ? (r0 >> 4) * (a.N >> 5) * 512 : r0 * a.ldy;
             if (a.relu_in != nullptr) a.relu_in += r0 * 4;
             if (a.relu_out != nullptr) a.relu_out += r0 * 4;
         }
@@ -430,13 +435,36 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
 #pragma unroll
             for (int T = 0; T < 16 * NH; ++T) {
                 if (16 * T < a.N) {
-                    f32x4 v = acc[T] + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q);
+                    f32x4 v = EXT ? acc[T] * out_scale + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q)
+                                  : acc[T] + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q);
                     if (a.act == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                     }
+                    if (EXT && T < 16) {   // N <= 256 in the training instantiations: the recorded / recording ReLU bits as below
+                        const unsigned nib = (T < 8 ? relu_lo >> (4 * T) : relu_hi >> (4 * (T - 8))) & 15u;
+                        if (a.relu_in != nullptr && 16 * T + 4 * q < a.mask_cols) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = ((nib >> i) & 1u) ? v[i] : 0.f;
+                        }
+                        if (NH == 1 && a.relu_out != nullptr) {
+                            unsigned nb = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) nb |= (v[i] > 0.f ? 1u : 0u) << i;
+                            if (T < 8) new_lo |= nb << (4 * T);
+                            else new_hi |= nb << (4 * (T - 8));
+                        }
+                    }
+                    if (EXT && a.out_maxabs != nullptr && row < M) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) seen_max = fmaxf(seen_max, fabsf(v[i]));
+                    }
                     asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yf + 256 * T), "v"(v) : "memory");
                 }
+            }
+            if (EXT && NH == 1 && a.relu_out != nullptr && row < M) {
+                const unsigned long long nw = (unsigned long long)new_lo | ((unsigned long long)new_hi << 32);
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(a.relu_out + row * 4 + q), "v"(nw) : "memory");
             }
         } else
         if (row < M) {
@@ -606,26 +634,43 @@ extern "C" int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* 
                                  const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count,
                                  const DanboLinearEx* ex, void* stream) {
     DANBO_CHECK_ARG(ex && x1 && packed && y && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0 && (K2 == 0 || x2) && M >= 0);
-    DANBO_CHECK_ARG(ldy >= N && (act == 0 || act == 1));
-    DANBO_CHECK_ARG(ld1 % 4 == 0 && ld1 >= ((K1 + 3) & ~3) && (K2 == 0 || (ld2 % 4 == 0 && ld2 >= ((K2 + 3) & ~3))) && ldy % 4 == 0);
+    DANBO_CHECK_ARG(act == 0 || act == 1);
+    DANBO_CHECK_ARG((ex->frag & 4) || (ldy >= N && ldy % 4 == 0));
+    DANBO_CHECK_ARG((ex->frag & 1) || (ld1 % 4 == 0 && ld1 >= ((K1 + 3) & ~3)));
+    DANBO_CHECK_ARG((ex->frag & 2) || K2 == 0 || (ld2 % 4 == 0 && ld2 >= ((K2 + 3) & ~3)));
     DANBO_CHECK_ARG((uintptr_t)x1 % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
     DANBO_CHECK_ARG(ex->relu_in == nullptr || (ex->mask_cols >= 0 && ex->mask_cols <= 256 && ex->mask_cols % 4 == 0));
     DANBO_CHECK_ARG(ex->relu_out == nullptr || N <= 256);
     if (M == 0) return 0;
-    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, 0, nullptr,
+    const int frag = ex->frag;
+    DANBO_CHECK_ARG(frag == 0 || frag == 1 || frag == 4 || frag == 5 || frag == 6);
+    DANBO_CHECK_ARG(!(frag & 1) || K1 % 32 == 0);
+    DANBO_CHECK_ARG(!(frag & 2) || (K2 > 0 && K2 % 32 == 0));
+    DANBO_CHECK_ARG(!(frag & 4) || N % 32 == 0);
+    DANBO_CHECK_ARG(frag == 0 || N <= 256);    // the 257 .. 512-wide training instantiation has no registers for it
+    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, nullptr,
                 ex->first, (const uint2*)ex->relu_in, (uint2*)ex->relu_out, ex->mask_cols, ex->in_maxabs, ex->out_maxabs,
                 ex->wscale_inv};
     const int tiles = (M + L16_BM - 1) / L16_BM;
     const dim3 grid(tiles < NUM_CU ? tiles : NUM_CU), block(L16_THREADS);
     const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;
-#define DANBO_L16_GO(NH_, NP_)                                                                                             \
+#define DANBO_L16_GO(NH_, NP_, FR_)                                                                                        \
     {                                                                                                                      \
-        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, false, true>), L16_LDS_BYTES);                                              \
-        hipLaunchKernelGGL((k_linear16<NH_, NP_, false, true>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);       \
+        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, false, true, FR_>), L16_LDS_BYTES);                                         \
+        hipLaunchKernelGGL((k_linear16<NH_, NP_, false, true, FR_>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);  \
     }
-    if (nh == 2) DANBO_L16_GO(2, 0)
-    else if (np == 8) DANBO_L16_GO(1, 8)
-    else DANBO_L16_GO(1, 0)
+#define DANBO_L16_NH1(FR_)                                                                                                 \
+    {                                                                                                                      \
+        if (np == 8) DANBO_L16_GO(1, 8, FR_)                                                                               \
+        else DANBO_L16_GO(1, 0, FR_)                                                                                       \
+    }
+    if (nh == 2) DANBO_L16_GO(2, 0, 0)
+    else if (frag == 0) DANBO_L16_NH1(0)
+    else if (frag == 1) DANBO_L16_NH1(1)
+    else if (frag == 4) DANBO_L16_NH1(4)
+    else if (frag == 5) DANBO_L16_NH1(5)
+    else DANBO_L16_NH1(6)
+#undef DANBO_L16_NH1
 #undef DANBO_L16_GO
     DANBO_LAUNCH_RET();
 }

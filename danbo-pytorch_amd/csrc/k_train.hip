@@ -96,7 +96,17 @@ void describe_mats(const DanboTrainModel* m, DanboPackDesc* d) {
         else t = DanboPackDesc{pw[l], nullptr, 1, 256, 0, 0, 256, 256, 0, 0, NONE, NONE};
     }
     d[19] = DanboPackDesc{pw[0], nullptr, 1, 195, 0, 0, 195, 256, 0, 0, NONE, NONE};
+    // which inputs arrive in fragment order (see carve): forward y_{l-1} (the skip layer: its second input y4); backward dz_l
+    // for l = 7, 6, 3, 2, 1 and dz_0
+    for (int l = 1; l < 8; ++l) d[l].frag_in = l == 5 ? 2 : 1;
+    for (int l = 7; l >= 1; --l) d[12 + (7 - l)].frag_in = (l == 5 || l == 4) ? 0 : 1;
+    d[19].frag_in = 1;
 }
+
+// DanboLinearEx.frag of the forward layer l and of the adjoint step that consumes dz_l (l = 8: the feature/alpha adjoint -> dz7)
+inline int fwd_frag(int l) { return l == 0 ? 4 : l == 5 ? 6 : l == 7 ? 1 : 5; }
+inline int bwd_frag(int l) { return l == 8 ? 4 : l == 7 ? 5 : l == 6 ? 1 : l == 5 ? 0 : l == 4 ? 4 : l >= 1 ? 5 : 1; }
+inline bool dz_is_frag(int l) { return l != 5 && l != 4; }
 
 TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long packed_bytes, long dw_floats) {
     TrainBuffers b;
@@ -131,7 +141,11 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long pa
     b.h_rows = c.take<float>(n * 16);
     b.pe = c.take<float>(n * LD_PE);
     b.vinr = c.take<float>(n * LD_VIN);
-    for (int l = 0; l < 8; ++l) { b.y[l] = c.take<float>(n * 256); b.relu[l] = c.take<uint2>(n * 4); }
+    // trunk activations y0 .. y6 and their gradients dz7, dz6, dz3 .. dz0 live in k_linear16's fragment order between the
+    // layers (rows padded to whole 128-row tiles, + one tile of slack for the weight-gradient kernel's last step); y7, dz5 and
+    // dz4 = [d y4 | d pe] stay row-major for their other consumers (the 257- and 451-wide layers, the PE adjoint)
+    const size_t nf = (n + 127) / 128 * 128 + 128;
+    for (int l = 0; l < 8; ++l) { b.y[l] = c.take<float>((l < 7 ? nf : n) * 256); b.relu[l] = c.take<uint2>(n * 4); }
     b.fa = c.take<float>(n * LD_FA);
     b.hv = c.take<float>(n * 128);
     b.raw_rows = c.take<float>(n * 4);
@@ -152,7 +166,7 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long pa
     b.dpre_v = c.take<float>(n * 128);
     b.d_alpha4 = c.take<float>(n * 4);
     b.d_vfeat = c.take<float>(n * LD_VF);
-    for (int l = 0; l < 8; ++l) b.dz[l] = l == 4 ? nullptr : c.take<float>(n * 256);
+    for (int l = 0; l < 8; ++l) b.dz[l] = l == 4 ? nullptr : c.take<float>((l == 5 ? n : nf) * 256);
     b.d_x5 = c.take<float>(n * LD_X5);
     b.dz[4] = b.d_x5;                                   // [d y4 (masked: dz4) | d pe]
     b.d_x0 = c.take<float>(n * LD_PE);
@@ -170,6 +184,7 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long pa
     return b;
 }
 
+constexpr int N_DW = 13;           // 12 parameter matrices, the skip layer's as two (see describe_dw)
 constexpr int DW_SLICES = 10;      // 24 tiles of 128 x 256 x 10 row slices = 240 workgroups: one per CU
 
 void describe_dw(const DanboTrainModel* m, const TrainBuffers& b, DanboDwLayer* L) {
@@ -183,9 +198,15 @@ void describe_dw(const DanboTrainModel* m, const TrainBuffers& b, DanboDwLayer* 
         d.dy_maxabs = b.maxabs + mx_of_dz[l];
         d.gw = m->g[DANBO_T_PTS_W0 + l];
         d.gb = m->g[DANBO_T_PTS_B0 + l];
+        d.frag = dz_is_frag(l) ? 1 : 0;
         if (l == 0) { d.x1 = b.pe; d.ld1 = LD_PE; d.K1 = 195; }
-        else if (l == 5) { d.x1 = b.pe; d.ld1 = LD_PE; d.K1 = 195; d.x2 = b.y[4]; d.ld2 = 256; d.K2 = 256; }
-        else { d.x1 = b.y[l - 1]; d.ld1 = 256; d.K1 = 256; }
+        else if (l == 5) { d.x1 = b.pe; d.ld1 = LD_PE; d.K1 = 195; d.gw_ld = 451; d.gw_col0 = 0; }   // [pe | y4]: the pe columns ...
+        else { d.x1 = b.y[l - 1]; d.ld1 = 256; d.K1 = 256; d.frag |= 2; }
+    }
+    {   // ... and the y4 columns of pts_linears.5.weight as a layer of their own: one input layout per layer
+        DanboDwLayer& d = L[12];
+        d = L[5];
+        d.x1 = b.y[4]; d.ld1 = 256; d.K1 = 256; d.frag |= 2; d.gw_col0 = 195; d.gb = nullptr;
     }
     DanboDwLayer& f = L[8];      // feature_linear
     f = DanboDwLayer{};
@@ -272,9 +293,9 @@ extern "C" size_t danbo_train_workspace(const DanboTrainModel* m, int R, int G, 
     Shapes s{R, G, S, Sf, chunk, m->graph_width, m->n_codes, (long)R * (S + Sf + 1)};
     Carver c{nullptr, 0};
     TrainBuffers b0 = carve(c, s, m, packed_bytes, 0);
-    DanboDwLayer L[12];
+    DanboDwLayer L[N_DW];
     describe_dw(m, b0, L);
-    const long dw = danbo_dw16_scratch_floats(L, 12, DW_SLICES);
+    const long dw = danbo_dw16_scratch_floats(L, N_DW, DW_SLICES);
     Carver c2{nullptr, 0};
     carve(c2, s, m, packed_bytes, dw);
     return c2.used + 512;
@@ -299,13 +320,13 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     describe_mats(m, desc);
     const long packed_bytes = danbo_linear16_group_bytes(desc, N_MAT);
     Shapes sh{R, G, S, Sf, bt->chunk, m->graph_width, m->n_codes, (long)R * (S + Sf + 1)};
-    DanboDwLayer dwl[12];
+    DanboDwLayer dwl[N_DW];
     {
         Carver c0{nullptr, 0};
         TrainBuffers b0 = carve(c0, sh, m, packed_bytes, 0);
         describe_dw(m, b0, dwl);
     }
-    const long dw_floats = danbo_dw16_scratch_floats(dwl, 12, DW_SLICES);
+    const long dw_floats = danbo_dw16_scratch_floats(dwl, N_DW, DW_SLICES);
     Carver c{reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255), 0};
     const TrainBuffers b = carve(c, sh, m, packed_bytes, dw_floats);
     describe_dw(m, b, dwl);
@@ -367,16 +388,22 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                        b.row_ray, stream));
         NET_STAGE(23);
         DanboLinearEx ex{};
-        ex.first = first;
+        // the trunk works on whole 128-row tiles of the fragment-order buffers: the importance pass starts at the tile boundary
+        // below its first row (cnt[6], cnt[7]) and recomputes the coarse rows in between, bit for bit
+        ex.first = pass == 0 ? nullptr : b.cnt + 6;
+        const int32_t* count_t = pass == 0 ? b.cnt + 2 : b.cnt + 7;
         for (int l = 0; l < 8; ++l) {
             ex.relu_out = b.relu[l];
             ex.wscale_inv = b.wscale_inv + l;
+            ex.frag = fwd_frag(l);
             const float* x1 = l == 0 || l == 5 ? b.pe : b.y[l - 1];
             const int ld1 = l == 0 || l == 5 ? LD_PE : 256, K1 = l == 0 || l == 5 ? 195 : 256;
             DANBO_TRY(danbo_linear16_ex(x1, ld1, K1, l == 5 ? b.y[4] : nullptr, 256, l == 5 ? 256 : 0, b.packed + off[l],
-                                        m->p[DANBO_T_PTS_B0 + l], 256, 1, b.y[l], 256, ncap, count, &ex, stream));
+                                        m->p[DANBO_T_PTS_B0 + l], 256, 1, b.y[l], 256, ncap, count_t, &ex, stream));
             NET_STAGE(24 + l);
         }
+        ex.first = first;
+        ex.frag = 0;
         ex.relu_out = nullptr;
         ex.wscale_inv = b.wscale_inv + 8;
         DANBO_TRY(danbo_linear16_ex(b.y[7], 256, 256, nullptr, 0, 0, b.packed + off[8], m->p[DANBO_T_FEAT_B], 257, 0, b.fa, LD_FA, ncap, count,
@@ -428,12 +455,14 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                     all_rows, &ex, stream));
         ex.in_maxabs = b.maxabs + MX_VF; ex.out_maxabs = b.maxabs + MX_Z7; ex.wscale_inv = b.wscale_inv + 11;
         ex.relu_in = b.relu[7]; ex.mask_cols = 256;
+        ex.frag = bwd_frag(8);
         DANBO_TRY(danbo_linear16_ex(b.d_vfeat, LD_VF, 256, b.d_alpha4, 4, 1, b.packed + off[11], nullptr, 256, 0, b.dz[7], 256, ncap, all_rows,
                                     &ex, stream));
         const int mx_of_dz[8] = {MX_Z0, MX_Z1, MX_Z2, MX_Z3, MX_Z4, MX_Z5, MX_Z6, MX_Z7};
         for (int l = 7; l >= 1; --l) {      // dz_{l-1} = (dz_l W_l) * [y_{l-1} > 0]
             ex.in_maxabs = b.maxabs + mx_of_dz[l]; ex.out_maxabs = b.maxabs + mx_of_dz[l - 1]; ex.wscale_inv = b.wscale_inv + 12 + (7 - l);
             ex.relu_in = b.relu[l - 1]; ex.mask_cols = 256;
+            ex.frag = bwd_frag(l);
             const float* x = b.dz[l];
             const int ldx = l == 4 ? LD_X5 : 256;
             if (l == 5)
@@ -445,6 +474,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         }
         ex.in_maxabs = b.maxabs + MX_Z0; ex.out_maxabs = b.maxabs + MX_X0; ex.wscale_inv = b.wscale_inv + 19;
         ex.relu_in = nullptr; ex.mask_cols = 0;
+        ex.frag = bwd_frag(0);
         DANBO_TRY(danbo_linear16_ex(b.dz[0], 256, 256, nullptr, 0, 0, b.packed + off[19], nullptr, 195, 0, b.d_x0, LD_PE, ncap, all_rows, &ex, stream));
     }
     DANBO_STAGE(9);
@@ -481,7 +511,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // ---- weight / bias gradients of all 12 dense layers (last: it needs nothing but the activations and their gradients, and
     //      data-parallel training hides the all-reduce of everything computed so far -- 7 of the 10 MB -- under it)
     const int32_t* all_rows2 = b.cnt + 4;
-    DANBO_TRY(danbo_dw16(dwl, 12, ncap, all_rows2, DW_SLICES, b.dw_scratch, stream));
+    DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, all_rows2, DW_SLICES, b.dw_scratch, stream));
     // ---- loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
     hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),
                        reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),

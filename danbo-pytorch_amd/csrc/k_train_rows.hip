@@ -10,7 +10,7 @@
 //   rows [R, R + n_c)               coarse samples inside >= 1 volume, in the order K1a compacted them
 //   rows [R + n_c, R + n_c + n_f)   importance samples inside >= 1 volume
 // cnt[] (device int32): [0] running compaction counter (n_c after the coarse cull, n_c + n_f after the second),
-//   [1] n_c, [2] R + n_c, [3] n_f, [4] R + n_c + n_f, [5] n_c + n_f
+//   [1] n_c, [2] R + n_c, [3] n_f, [4] R + n_c + n_f, [5] n_c + n_f, [6] (R + n_c) rounded down to 128, [7] n_f + (R + n_c) % 128
 #include "common.hpp"
 
 namespace danbo {
@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void k_train_rows_fwd(const float* __restrict_
     const int rows = pass == 0 ? R + n_run : n_run - cnt[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (pass == 0) { cnt[1] = n_run; cnt[2] = R + n_run; }
-        else { cnt[3] = rows; cnt[4] = first + rows; cnt[5] = n_run; }
+        else {
+            cnt[3] = rows; cnt[4] = first + rows; cnt[5] = n_run;
+            // the importance pass for kernels that work on 128-row tiles of fragment-order buffers: it starts at the tile boundary
+            // at or below its first row and recomputes the (identical) coarse rows in between
+            cnt[6] = first & ~127; cnt[7] = rows + (first & 127);
+        }
     }
     const int npe = FEAT * (1 + 2 * L);
     // one thread per (row, 4-column group) of [pe | vinr]

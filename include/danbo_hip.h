@@ -340,6 +340,8 @@ typedef struct DanboLinearEx {
     const float* in_maxabs;   /* device scalar: max |x| over the inputs (power-of-two pre-scale), or NULL */
     float* out_maxabs;        /* device scalar, atomically raised to max |y| (caller zeroes it), or NULL */
     const float* wscale_inv;  /* device scalar written by danbo_linear16_pack_group for this matrix, or NULL (unscaled packing) */
+    int frag;                 /* fragment-order operands as in danbo_linear16_fwd_frag (bit 0: x1, 1: x2, 2: y; N <= 256; the
+                                 matrix packed with the matching DanboPackDesc.frag_in); *first must then be a multiple of 128 */
 } DanboLinearEx;
 int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
                       const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count,
@@ -355,6 +357,7 @@ typedef struct DanboPackDesc {
     const float *w, *w2;
     long sn, sk, sn2, sk2;
     int N, K1, K2, n_shift, split_n, split_k;
+    int frag_in;              /* bit 0 / 1: the K1 / K2 input part arrives in fragment order (k-slot permutation of that part) */
 } DanboPackDesc;
 long danbo_linear16_group_bytes(const DanboPackDesc* descs, int n);
 /* packs n <= 28 matrices back to back into `packed` (offsets[i] = byte offset of matrix i, host array or NULL), each
@@ -363,7 +366,7 @@ long danbo_linear16_group_bytes(const DanboPackDesc* descs, int n);
 int danbo_linear16_pack_group(const DanboPackDesc* descs, int n, void* packed, long* offsets, float* wmax,
                               float* wscale_inv, void* stream);
 
-/* dW / db of up to 12 dense layers in one launch pair (csrc/k_dw16.hip).  dy [rows, ldy]: gradient with respect to the layer's
+/* dW / db of up to 13 dense layers in one launch pair (csrc/k_dw16.hip).  dy [rows, ldy]: gradient with respect to the layer's
  * pre-activation; x1 | x2: the layer's input(s); gw [N, K1 + K2] and gb [N] in nn.Linear layout are OVERWRITTEN.  A layer
  * evaluated for two parameters at once (feature_linear + alpha_linear) writes rows >= split_n to gw2 / gb2.  16-byte aligned
  * bases, row strides multiples of 4 floats, x1 readable up to a multiple of 4 columns.  rows = min(*count, M). */
@@ -371,6 +374,9 @@ typedef struct DanboDwLayer {
     const float *dy, *x1, *x2, *dy_maxabs /* device scalar max |dy| recorded by the producer, or NULL */;
     float *gw, *gw2, *gb, *gb2;
     int ldy, ld1, ld2, N, K1, K2, split_n;
+    int frag;                 /* bit 0: dy, bit 1: x1 (then K2 = 0) are fragment-order buffers (widths multiples of 32, ld ignored) */
+    int gw_ld, gw_col0;       /* 0, 0: gw is [N, K1 + K2]; else the gradient goes to gw[n * gw_ld + gw_col0 + k] -- a layer with two
+                                 inputs in different layouts is passed as two layers (gb = NULL in one of them) */
 } DanboDwLayer;
 long danbo_dw16_scratch_floats(const DanboDwLayer* layers, int n_layers, int slices);
 int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const int32_t* count, int slices, float* scratch, void* stream);

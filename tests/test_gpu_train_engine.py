@@ -331,3 +331,35 @@ def test_fused_step_on_degenerate_batches(case):
         assert d <= 2e-3 * scale + 1e-9, (n, d, scale)
         worst = max(worst, d / (scale + 1e-30))
     print(case, "rows", counts[:6], "worst relative gradient deviation", worst)
+
+
+def test_weight_gradients_from_fragment_order_operands_and_split_layers():
+    """danbo_dw16 with dy / x in k_linear16's fragment order (what the trunk of the training step hands it), a layer whose two
+    inputs are passed as two layers writing column ranges of the same weight gradient, ragged row count and device-side count"""
+    from core import _hip, hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M = 5000 - 37
+    dy = (torch.randn(M, 256, generator=g) * 3e-6).to(DEV)
+    xa = torch.randn(M, 196, generator=g).to(DEV)          # 195 used columns, row-major
+    xb = torch.randn(M, 256, generator=g).to(DEV)
+    mx = dy.abs().max().reshape(1)
+    slack = lambda f: torch.cat([f.data, torch.zeros(128 * f.C, device=DEV)])
+    fdy, fxb = slack(ops.FragBuffer.from_rows(dy)), slack(ops.FragBuffer.from_rows(xb))
+    gw = torch.zeros(256, 451, device=DEV)
+    gb = torch.zeros(256, device=DEV)
+    gw2 = torch.zeros(256, 256, device=DEV)
+    gb2 = torch.zeros(256, device=DEV)
+    D = _hip.DanboDwLayer
+    common = dict(dy_maxabs=P(mx), gw2=None, gb2=None, ldy=256, ld2=0, N=256, K2=0, split_n=0, x2=None)
+    L = (D * 3)(D(dy=P(fdy), x1=P(xa), gw=P(gw), gb=P(gb), ld1=196, K1=195, frag=1, gw_ld=451, gw_col0=0, **common),
+                D(dy=P(fdy), x1=P(fxb), gw=P(gw), gb=None, ld1=256, K1=256, frag=3, gw_ld=451, gw_col0=195, **common),
+                D(dy=P(dy), x1=P(fxb), gw=P(gw2), gb=P(gb2), ld1=256, K1=256, frag=2, gw_ld=0, gw_col0=0, **common))
+    slices = 7
+    scratch = torch.empty(_hip.lib().danbo_dw16_scratch_floats(L, 3, slices), device=DEV)
+    n_live = torch.tensor([M], dtype=torch.int32, device=DEV)
+    _hip.check(_hip.lib().danbo_dw16(L, 3, M + 50, P(n_live), slices, P(scratch), stream()), "dw16")
+    ref = (dy.double().t() @ torch.cat([xa[:, :195], xb], 1).double()).float()
+    ref_b = dy.double().sum(0).float()
+    assert float((gw - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((gw2 - ref[:, 195:]).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((gb - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()) and float((gb2 - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max())

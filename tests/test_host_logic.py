@@ -323,7 +323,7 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
     # what the launchers dispatch to
     shapes = {(1, 0), (1, 8), (2, 0), (2, 6), (2, 8)}
     want = {(nh, np_, 0, 0, fr) for nh, np_ in shapes for fr in (0, 4, 5, 6)} | {(1, 0, 0, 0, 1), (1, 8, 0, 0, 1), (2, 0, 1, 0, 0)}
-    want |= {(1, 0, 0, 1, 0), (1, 8, 0, 1, 0), (2, 0, 0, 1, 0)}
+    want |= {(1, 0, 0, 1, fr) for fr in (0, 1, 4, 5, 6)} | {(1, 8, 0, 1, fr) for fr in (0, 1, 4, 5, 6)} | {(2, 0, 0, 1, 0)}
     assert seen == want, (seen ^ want)
 
 
