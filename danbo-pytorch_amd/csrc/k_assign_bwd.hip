@@ -121,7 +121,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
     // pose whose volume gradient is gathered in LDS: the pose of this chunk's first pair (rows are ray-ordered, so most pairs
     // of a chunk share it); pairs of other poses go to global memory directly
     // Everything a pair needs from the row tables is fetched ONCE per workgroup, one pair per thread, into LDS: as a chain of
-    // three dependent global loads at the top of every iteration it cost ~5 us x 32 iterations with nothing to hide it behind.
+    // three dependent global loads at the top of every iteration it cost ~5 us per iteration with nothing to hide it behind.
     __shared__ int s_pi[AB_PPW], s_pm[AB_PPW], s_pray[AB_PPW];
     __shared__ float s_pz[AB_PPW], s_plab[AB_PPW], s_pq[AB_PPW];
     __shared__ uint32_t s_pbits[AB_PPW];
@@ -372,7 +372,7 @@ extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
     a.w0 = p->w0; a.adj_w = p->adj_w; a.adj = p->adj; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
     a.g_w0 = p->g_w0; a.g_adj_w = p->g_adj_w; a.g_b0 = p->g_b0; a.g_w1 = p->g_w1; a.g_b1 = p->g_b1; a.g_w2 = p->g_w2; a.g_b2 = p->g_b2;
     a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
-    // 256 pairs (32 iterations of 8) per workgroup amortise its weight staging and its flush; a sample lies in at most a few
+    // 128 .. 256 pairs per workgroup (chosen on the device, AB_PPW_MIN) amortise its weight staging and its flush; a sample lies in at most a few
     // volumes, so 4 pairs per row of capacity is far above what geometry allows -- and workgroups without pairs exit at once
     const long wgs = ((long)p->rows_cap * 4 + AB_PPW_MIN - 1) / AB_PPW_MIN + J;
     hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < 65535 ? wgs : 65535)), dim3(AB_THREADS), 0, (hipStream_t)stream, a);

@@ -13,8 +13,10 @@
 //   pass 1       the same network on the in-volume importance samples -> composite of the merged samples
 //   loss         L1 / MSE gradients of both passes -> composite adjoints -> un-merge -> rows
 //   backward     ONE sweep over the rows of both passes: 10 input-gradient GEMMs (transposed packings, ReLU bits recorded by
-//                the forward), all weight gradients in one grouped launch, frame-code gradients, PE adjoint,
-//                K2/K1b adjoint by (row, valid bone) pairs with the forward recomputed, pose GNN adjoint, volume-scale term
+//                the forward), frame-code gradients, PE adjoint, K2/K1b adjoint by (row, valid bone) pairs with the forward
+//                recomputed, pose GNN adjoint, volume-scale term -- and LAST all weight gradients in one grouped launch
+//                (data-parallel training reduces everything else under it, danbo_train_step_phase)
+// The trunk's activations and their gradients live in k_linear16's fragment order between the layers (carve, fwd_frag / bwd_frag).
 #include <limits.h>
 #include <stdlib.h>
 #include "common.hpp"
@@ -508,7 +510,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_STAGE(12);
     }   // phase != 2
     if (phase == 1) { DANBO_LAUNCH_RET(); }
-    // ---- weight / bias gradients of all 12 dense layers (last: it needs nothing but the activations and their gradients, and
+    // ---- weight / bias gradients of all dense layers (last: it needs nothing but the activations and their gradients, and
     //      data-parallel training hides the all-reduce of everything computed so far -- 7 of the 10 MB -- under it)
     const int32_t* all_rows2 = b.cnt + 4;
     DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, all_rows2, DW_SLICES, b.dw_scratch, stream));
