@@ -363,3 +363,36 @@ def test_weight_gradients_from_fragment_order_operands_and_split_layers():
     assert float((gw - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     assert float((gw2 - ref[:, 195:]).abs().max()) <= 2e-5 * float(ref.abs().max())
     assert float((gb - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()) and float((gb2 - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max())
+
+
+def test_fused_step_with_more_than_64_samples_per_ray():
+    """S > 64 leaves the fused composite + resampling kernel (one wavefront per ray) for the general kernels: dense raw fill, plain
+    composite, importance sampling by ranks.  72 + 24 samples against the autograd path."""
+    g = golden("danbo_perfcap_train")
+    S, Sf = 72, 24
+
+    def run_autograd():
+        args, caster, trainer, opt = build_trainer(g)
+        caster.train()
+        b = batch_of(g)
+        kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
+        preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                       N_uniques=b["N_uniques"], N_samples=S, N_importance=Sf, **kw)
+        loss = trainer.compute_loss(b, preds)
+        caster.zero_grad()
+        loss["total_loss"].backward()
+        return {n: p.grad.detach().clone() for n, p in caster.network.named_parameters()}, preds
+    ref, preds = run_autograd()
+    args, caster, trainer, opt = build_trainer(g)
+    eng = trainer.fused_engine()
+    eng.use_graph = False
+    b = batch_of(g)
+    G = b["N_uniques"]
+    pp = caster._per_pose
+    out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G), b["cam_idxs"],
+                               b["target_s"], b["bgs"], S, Sf)
+    assert float((out["rgb_map"] - preds["rgb_map"].detach()).abs().max()) < 1e-4
+    assert float((out["rgb0"] - preds["rgb0"].detach()).abs().max()) < 1e-4
+    for n, p in caster.network.named_parameters():
+        a, r = p.grad, ref[n]
+        assert float((a - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-10, (n, float((a - r).abs().max()), float(r.abs().max()))
