@@ -396,3 +396,39 @@ def test_fused_step_with_more_than_64_samples_per_ray():
     for n, p in caster.network.named_parameters():
         a, r = p.grad, ref[n]
         assert float((a - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-10, (n, float((a - r).abs().max()), float(r.abs().max()))
+
+
+@pytest.mark.parametrize("fixture,extra", [("danbo_train", ["--loss_fn", "MSE"]), ("danbo_perfcap_train", ["--loss_fn", "MSE", "--coarse_weight", "0.3"]),
+                                           ("danbo_train", ["--rgb_loss_coef", "2.5", "--soft_softmax_loss_coef", "0.0"])])
+def test_fused_step_flag_variants_equal_the_autograd_path(fixture, extra):
+    """the loss options the fused step covers (train_engine.supported): MSE instead of L1, coarse / rgb weights, no soft-softmax term"""
+    g = golden(fixture)
+    grads = {}
+    outs = {}
+    for path in ("autograd", "fused"):
+        args, caster, trainer, opt = build_trainer(g, extra=extra)
+        b = batch_of(g)
+        if path == "autograd":
+            caster.train()
+            kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs")}
+            preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                           N_uniques=b["N_uniques"], **kw)
+            loss = trainer.compute_loss(b, preds)
+            caster.zero_grad()
+            loss["total_loss"].backward()
+            outs[path] = {k: float(v.detach()) for k, v in loss.items()}
+        else:
+            eng = trainer.fused_engine()
+            assert eng is not None, trainer.fused_reason
+            eng.use_graph = False
+            G = b["N_uniques"]
+            pp = caster._per_pose
+            out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G), b["cam_idxs"],
+                                       b["target_s"], b["bgs"], int(g["N_samples"]), int(g["N_importance"]))
+            outs[path] = out["loss"].cpu().numpy()
+        grads[path] = {n: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for n, p in caster.network.named_parameters()}
+    assert abs(float(outs["fused"][0]) - outs["autograd"]["rgb_loss"]) <= 2e-4 * max(abs(outs["autograd"]["rgb_loss"]), 1e-3)
+    assert abs(float(outs["fused"][1]) - outs["autograd"]["rgb_loss0"]) <= 2e-4 * max(abs(outs["autograd"]["rgb_loss0"]), 1e-3)
+    for n, r in grads["autograd"].items():      # 5e-3 of the tensor's max, as against the reference's autograd (axis_scale: 2e-3)
+        a = grads["fused"][n]
+        assert float((a - r).abs().max()) <= 5e-3 * float(r.abs().max()) + 1e-10, (n, float((a - r).abs().max()), float(r.abs().max()))
