@@ -372,6 +372,21 @@ def bench_anerf(args, rank, world, device, dist):
     ms = 1e3 * elapsed / args.steps
     achieved = 2.0 * n * mac / (ms * 1e-3)
     peak = PEAK_FP16_MFMA / 3.0
+    # HBM bytes of a frame from the PMC passes of tools/pmc_anerf.sh, quoted only for the kernel sources they were measured on
+    traffic, hbm = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_anerf.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("kernel_src_sha16") == sha16("k_linear16.hip", "k_anerf.hip", "common.hpp"):
+            traffic = rec["frame_hbm_bytes"]
+            # algorithmic: every dense layer reads its input row(s) and writes its output row once (4 (K + N) bytes per row), the
+            # encoder writes the 432 inputs + 24 cutoff weights, the colour kernel reads the 225-wide head rows + weights
+            per_row = 4 * ((inc + Wd) + 4 * 2 * Wd + (inc + 2 * Wd) + 2 * 2 * Wd + (Wd + VW + 1)) + 4 * (inc + 24) + 4 * (VW + 1 + 24) + 16
+            hbm = dict(bytes_per_frame=traffic, algorithmic_bytes_per_frame=per_row * n, achieved=traffic / (ms * 1e-3) / 1e12, peak=8.0,
+                       unit="TB/s", frac=traffic / (ms * 1e-3) / 8e12,
+                       note="the frame moves its activations through HBM once per layer (fragment order, no re-reads): it runs at the "
+                            "HBM rate this GPU sustains for mixed read/write streams (3.4 TB/s, the same as the training step's "
+                            "weight-gradient kernel) AND at the MFMA fraction of the register-resident DANBO kernel")
     result = {
         "metric": "ray-samples/sec at 512x512x64 samples (A-NeRF)", "value": world * n / (ms * 1e-3), "unit": "ray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
@@ -380,9 +395,12 @@ def bench_anerf(args, rank, world, device, dist):
                                "every sample evaluated (A-NeRF has no in-volume mask)",
                    "rays": len(ro), "samples_per_ray": S + Sf, "parallelism": f"rays-dp{world}"},
         "roofline": dict(bound="mfma", kernel="A-NeRF trunk (whole frame)", achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s",
-                         frac=achieved / peak, traffic=None, flop_per_row=2 * mac, flop_per_row_reference=2 * 2268000, peak_note=SPLIT_NOTE,
-                         note="FRAME-level lower bound: executed flops per sample x samples / whole frame time"),
+                         frac=achieved / peak, traffic=traffic, flop_per_row=2 * mac, flop_per_row_reference=2 * 2268000, peak_note=SPLIT_NOTE,
+                         note="FRAME-level lower bound: executed flops per sample x samples / whole frame time; traffic = HBM bytes of "
+                              "the whole frame (tools/pmc_anerf.sh), see `hbm`"),
     }
+    if hbm is not None:
+        result["hbm"] = hbm
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import danbo_oracle as o
