@@ -310,6 +310,16 @@ def bench_train(args, rank, world, device, dist):
     ms = 1e3 * elapsed / args.steps
     achieved = flops / (ms * 1e-3)
     peak = PEAK_FP16_MFMA / 3.0
+    # HBM bytes of a step from the PMC passes of tools/pmc_train.sh, quoted only for the kernel sources they were measured on
+    traffic, hbm = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_train.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("kernel_src_sha16") == sha16("k_train.hip", "k_linear16.hip", "k_dw16.hip", "k_assign_bwd.hip", "k_train_rows.hip", "common.hpp"):
+            traffic = rec["step_hbm_bytes"]
+            hbm = dict(bytes_per_step=traffic, achieved=traffic / (ms * 1e-3) / 1e12, peak=8.0, unit="TB/s", frac=traffic / (ms * 1e-3) / 8e12,
+                       note="every activation and gradient of the trunk crosses HBM once per use (the backward needs them all); the "
+                            "weight-gradient kernel alone reads 1.3 GB at 3.4 TB/s")
     result = {
         "metric": "training ray-samples/sec (PerfCap danbo_fast step: forward + losses + backward + Adam)", "value": world * R * S / (ms * 1e-3),
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -320,12 +330,14 @@ def bench_train(args, rank, world, device, dist):
                    "rays": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
         "rows_per_step": rows, "in_volume_fraction": in_vol / (R * S), "loss": float(loss["total_loss"]),
         "roofline": dict(bound="mfma", kernel="k_linear16<EXT> x 30 + k_dw16 (whole step)", achieved=achieved / 1e12, peak=peak / 1e12,
-                         unit="TFLOP/s", frac=achieved / peak, traffic=None, flop_per_row=2 * (2 * mac_fwd + mac_dx),
+                         unit="TFLOP/s", frac=achieved / peak, traffic=traffic, flop_per_row=2 * (2 * mac_fwd + mac_dx),
                          peak_note=SPLIT_NOTE,
                          note="STEP-level lower bound: executed dense-layer flops of the step (forward + input gradients + weight "
                               "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
                               "per-kernel durations: profiles/r02*_train_kernel_stats.csv"),
     }
+    if hbm is not None:
+        result["hbm"] = hbm
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_train(targs, caster, batch, poses)
     return result
