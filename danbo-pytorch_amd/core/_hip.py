@@ -73,7 +73,7 @@ SIGNATURES = {
     "danbo_train_bone_lists": [P, P, P, P, I, I, P, P, P],
     "danbo_assign_blend_bwd": [P, P],
     "danbo_pose_volumes_bwd": [P, I, I, I] + [P] * 24,
-    "danbo_adam_step": [P, P, P, P, c_long, P, F, F, F, P],
+    "danbo_adam_step": [P, P, P, P, c_long, F, F, F, F, F, F, F, P],
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],

@@ -31,6 +31,16 @@ def supported(args, caster):
         return 'regulariser / weight decay'
     if getattr(args, 'finetune_light', False) or getattr(args, 'opt_pose', False):
         return 'finetune_light / opt_pose'
+    # options the C step has no field for: the autograd path refuses them loudly (raycasters.RayCaster.render_rays_train),
+    # so report them here instead of training with silently different semantics
+    if getattr(args, 'lindisp', False):
+        return 'lindisp'
+    if float(getattr(args, 'ray_noise_std', 0.) or 0.) != 0.:
+        return 'ray_noise_std'
+    if getattr(args, 'density_type', 'relu') != 'relu':
+        return f'density_type {args.density_type}'
+    if not getattr(args, 'single_net', True):
+        return 'single_net=False'
     if args.agg_type != 'sigmoid' or args.N_importance <= 0 or args.N_samples + args.N_importance > 256 or args.N_samples < 3:
         return 'sampling / aggregation settings'
     if net.voxel_pe_fn.num_freqs != 6 or net.W != 256 or net.D != 8 or list(net.skips) != [4]:
@@ -86,8 +96,6 @@ class DanboTrainEngine:
         self.trainable = trainable
         self._adopt_optimizer_state()
         self.t = self._optimizer_step_count()
-        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
         self._buffers = {}
         self._ws = None
         self._model_struct = None
@@ -294,11 +302,11 @@ class DanboTrainEngine:
         grp = self.opt.param_groups[0]
         b1, b2 = grp['betas']
         self.t += 1
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3] = float(lr), 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t), float(grad_scale)
-        self.hyper.copy_(h, non_blocking=True)
+        # the step's scalars are kernel ARGUMENTS (danbo_adam_step, ABI 2): the host may run any number of steps ahead of the GPU
+        # (sync_stats=False) without a later step's bias corrections reaching an earlier step's launch
         _hip.check(_hip.lib().danbo_adam_step(_P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), self.n_train,
-                                              _P(self.hyper), float(b1), float(b2), float(grp['eps']),
+                                              float(lr), 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t), float(grad_scale),
+                                              float(b1), float(b2), float(grp['eps']),
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_adam_step")
         for p in self.params.values():
             st = self.opt.state.get(p)

@@ -29,14 +29,27 @@
 namespace danbo {
 
 constexpr int WAVE = 64;
-constexpr int NUM_CU = 256;  // MI355X; grids of persistent kernels are sized from this
+// Compute units of the calling thread's current device (hipDeviceAttributeMultiprocessorCount, cached per device): the
+// persistent kernels size their grids from it.  256 on a full MI355X; partitioned (CPX / DPX) or harvested parts report less.
+static inline int num_cu() {
+    static std::atomic<int> cached_[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::atomic<int>& c = cached_[dev & 63];
+    int n = c.load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        c.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // grid for a memory-bound grid-stride kernel: enough workgroups to fill 256 CUs x 8
 static inline int stream_grid(long items, int block) {
     long g = (items + block - 1) / block;
-    const long cap = (long)NUM_CU * 8;
+    const long cap = (long)num_cu() * 8;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;

@@ -211,7 +211,7 @@ extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, 
     if (nrows == 0) return 0;
     const int in_ch = (1 + 2 * L) * J + 3 * J;
     const int ntiles = ceil_div(nrows, AN_TS);
-    const int grid = ntiles < NUM_CU * 8 ? ntiles : NUM_CU * 8;
+    const int grid = ntiles < num_cu() * 8 ? ntiles : num_cu() * 8;
     hipLaunchKernelGGL(k_anerf_encode, dim3(grid), dim3(AN_BLOCK), AN_TS * in_ch * sizeof(float), (hipStream_t)stream,
                        rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, L, row0, nrows, x0, w_out);
     DANBO_LAUNCH_RET();
@@ -232,7 +232,7 @@ extern "C" int danbo_anerf_color_fwd(const float* featv, int ld_featv, const flo
     DANBO_CHECK_ARG(VW > 0 && VW <= AN_VW_MAX && S > 0 && nrays >= 0 && ray0 >= 0 && ray0 + nrays <= R_total && n_codes >= 0);
     if (nrays == 0) return 0;
     const int blocks = ceil_div(nrays, 4);
-    const int grid = blocks < NUM_CU * 8 ? blocks : NUM_CU * 8;
+    const int grid = blocks < num_cu() * 8 ? blocks : num_cu() * 8;
     hipLaunchKernelGGL(k_anerf_color, dim3(grid), dim3(256), 0, (hipStream_t)stream, featv, ld_featv, w, C, table, cam_idx,
                        n_codes, R_total, ray0, nrays, S, VW, rgb_w, rgb_b, alpha, ld_alpha, raw_out);
     DANBO_LAUNCH_RET();

@@ -260,7 +260,7 @@ static int launch_assign(const GatherArgs& ga, const float* part_feat, const uin
     const size_t lds = sizeof(float) * ASSIGN_LDS_FLOATS;
     DANBO_ENSURE_LDS(k_assign_blend<FUSED>, lds);
     const int tiles = ceil_div(n, ASSIGN_SPB);
-    const int grid = tiles < NUM_CU ? tiles : NUM_CU;
+    const int grid = tiles < num_cu() ? tiles : num_cu();
     hipLaunchKernelGGL(k_assign_blend<FUSED>, dim3(grid), dim3(ASSIGN_BLOCK), lds, (hipStream_t)stream, ga, part_feat,
                        valid_bits, list, count, n, w0, adjw, b0, w1, b1, w2, b2, h, confd);
     DANBO_LAUNCH_RET();

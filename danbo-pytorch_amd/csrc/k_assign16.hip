@@ -417,7 +417,7 @@ extern "C" int danbo_gather_assign_blend16_fwd(const float* rays_o, const float*
                  reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr};
     DANBO_ENSURE_LDS(k_assign16<false>, A16_LDS_BYTES);
     const int ntiles = ceil_div(n, A16_BM);
-    const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
+    const int grid = ntiles < num_cu() ? ntiles : num_cu();
     hipLaunchKernelGGL(k_assign16<false>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
@@ -434,7 +434,7 @@ extern "C" int danbo_gather_assign_blend16_train(const float* rays_o, const floa
                  reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first};
     DANBO_ENSURE_LDS(k_assign16<true>, A16_LDS_BYTES);
     const int ntiles = ceil_div(n, A16_BM);
-    const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
+    const int grid = ntiles < num_cu() ? ntiles : num_cu();
     hipLaunchKernelGGL(k_assign16<true>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

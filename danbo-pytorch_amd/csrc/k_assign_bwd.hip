@@ -31,7 +31,7 @@ constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefro
 // pairs per workgroup: amortises the weight staging and the flush.  Chosen on the device between AB_PPW_MIN and AB_PPW so that the
 // workgroups that find pairs fit the 2 x 256 resident slots in ONE round (80 k pairs at 128 each were 640 workgroups: a full
 // round and a 25 % one)
-constexpr int AB_PPW_MIN = 128, AB_PPW = 256, AB_TARGET_WGS = 2 * NUM_CU - J;
+constexpr int AB_PPW_MIN = 128, AB_PPW = 256;     // target number of workgroups with pairs: 2 per CU (kernel argument)
 
 struct ABArgs {
     // geometry
@@ -58,7 +58,7 @@ __device__ __forceinline__ float half_sum32(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
+__global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int target_wgs) {
     __shared__ float s_w0[AB_MAXNB][FEAT][AB_STRIDE];
     __shared__ float s_w1[AB_W][AB_STRIDE];
     __shared__ float s_b0[AB_W], s_b1[AB_W], s_w2[AB_W];
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
     __syncthreads();
     int total_pairs = 0;
     for (int k = 0; k < J; ++k) total_pairs += s_cnt[k];
-    const int ppw = min(max(((total_pairs + AB_TARGET_WGS - 1) / AB_TARGET_WGS + 7) & ~7, AB_PPW_MIN), AB_PPW);
-    int j = 0, wg = blockIdx.x, npairs = 0;
+    const int ppw = min(max(((total_pairs + target_wgs - 1) / target_wgs + 7) & ~7, AB_PPW_MIN), AB_PPW);
+    // grid-stride over the (bone, chunk) work items: a launch whose grid is smaller than the number of chunks (heavily
+    // overlapping volumes after axis_scale has grown, very large batches) loops instead of dropping pairs
+    for (int item = blockIdx.x;; item += gridDim.x) {
+    int j = 0, wg = item, npairs = 0;
     for (; j < J; ++j) {
         npairs = s_cnt[j];
         const int need = (npairs + ppw - 1) / ppw;
@@ -352,6 +355,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a) {
         const float v = s_gvol[i / VOL][i % VOL];
         if (v != 0.f) atomicAdd(a.g_vol + ((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL, v);
     }
+    __syncthreads();     // the next item re-stages every LDS table
+    }
 }
 
 }  // namespace danbo
@@ -374,7 +379,10 @@ extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
     a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
     // 128 .. 256 pairs per workgroup (chosen on the device, AB_PPW_MIN) amortise its weight staging and its flush; a sample lies in at most a few
     // volumes, so 4 pairs per row of capacity is far above what geometry allows -- and workgroups without pairs exit at once
+    // The grid is a guess, not a bound: the kernel strides over the items the grid does not cover.
     const long wgs = ((long)p->rows_cap * 4 + AB_PPW_MIN - 1) / AB_PPW_MIN + J;
-    hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < 65535 ? wgs : 65535)), dim3(AB_THREADS), 0, (hipStream_t)stream, a);
+    const long max_wgs = (long)num_cu() * 64;
+    hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < max_wgs ? wgs : max_wgs)), dim3(AB_THREADS), 0, (hipStream_t)stream, a,
+                       2 * num_cu() - J);
     DANBO_LAUNCH_RET();
 }

@@ -195,7 +195,7 @@ extern "C" int danbo_bone_gather_bwd(const float* rays_o, const float* rays_d, c
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     const int ntiles = ceil_div(n, GB_TS);
-    const int grid = ntiles < NUM_CU * 4 ? ntiles : NUM_CU * 4;
+    const int grid = ntiles < num_cu() * 4 ? ntiles : num_cu() * 4;
     hipLaunchKernelGGL(k_bone_gather_bwd, dim3(grid), dim3(GB_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
                        G, skts, align, axis_scale, volumes, list, n, d_part_feat, d_volumes, d_axis_scale);
     DANBO_LAUNCH_RET();

@@ -599,7 +599,7 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
     Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, g_lin16_trace,
                 nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     const int tiles = (M + L16_BM - 1) / L16_BM;
-    const dim3 grid(tiles < NUM_CU ? tiles : NUM_CU), block(L16_THREADS);
+    const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
     const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;   // tile pairs in the last chunk of a k-step
 #define DANBO_L16_GO(NH_, NP_, TR_, FR_)                                                                                   \
     {                                                                                                                      \
@@ -652,7 +652,7 @@ extern "C" int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* 
                 ex->first, (const uint2*)ex->relu_in, (uint2*)ex->relu_out, ex->mask_cols, ex->in_maxabs, ex->out_maxabs,
                 ex->wscale_inv};
     const int tiles = (M + L16_BM - 1) / L16_BM;
-    const dim3 grid(tiles < NUM_CU ? tiles : NUM_CU), block(L16_THREADS);
+    const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
     const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;
 #define DANBO_L16_GO(NH_, NP_, FR_)                                                                                        \
     {                                                                                                                      \

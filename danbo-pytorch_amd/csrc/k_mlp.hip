@@ -549,7 +549,7 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
     if (e != hipSuccess) return (int)e;
     const int iters = ceil_div(R, VIEW_RPB);
     const int per_cu = (int)((160 * 1024) / (lds + 1024)) < 8 ? (int)((160 * 1024) / (lds + 1024)) : 8;  // latency-bound phases: fill the CU
-    const int grid = iters < NUM_CU * per_cu ? iters : NUM_CU * (per_cu > 0 ? per_cu : 1);
+    const int grid = iters < num_cu() * per_cu ? iters : num_cu() * (per_cu > 0 ? per_cu : 1);
     hipLaunchKernelGGL(k_view_consts, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
                        normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
                        rgb_b, empty_consts, rgb_order, code_table, cview, raw_empty);
@@ -579,7 +579,7 @@ extern "C" int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32
     const size_t lds = sizeof(float) * MLP_LDS_FLOATS;
     DANBO_ENSURE_LDS(k_pe_mlp, lds);
     const int ntiles = ceil_div(n, MLP_BM);
-    const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
+    const int grid = ntiles < num_cu() ? ntiles : num_cu();
     hipLaunchKernelGGL(k_pe_mlp, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

@@ -523,7 +523,7 @@ extern "C" int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int
     a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.raw_out = raw_out; a.aux_out = aux_out;
     DANBO_ENSURE_LDS(k_pe_mlp16, M16_LDS_BYTES);
     const int ntiles = ceil_div(n, M16_BM);
-    const int grid = ntiles < NUM_CU ? ntiles : NUM_CU;
+    const int grid = ntiles < num_cu() ? ntiles : num_cu();
     hipLaunchKernelGGL(k_pe_mlp16, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

@@ -821,7 +821,7 @@ extern "C" int danbo_bone_gather_fwd(const float* rays_o, const float* rays_d, c
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     const int ntiles = ceil_div(n, GATHER_TS);
-    const int grid = ntiles < NUM_CU * 3 ? ntiles : NUM_CU * 3;
+    const int grid = ntiles < num_cu() * 3 ? ntiles : num_cu() * 3;
     hipLaunchKernelGGL(k_bone_gather, dim3(grid), dim3(GATHER_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
                        G, skts, align, axis_scale, volumes, list, count, n, part_feat);
     DANBO_LAUNCH_RET();

@@ -336,8 +336,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     const float B = m->density_scale;
 
     // dev aid: DANBO_TRAIN_STOP_AFTER=<stage> makes the call return after that stage (bisecting a fault inside a captured graph)
-    const char* stop_env = getenv("DANBO_TRAIN_STOP_AFTER");
-    const int stop_after = stop_env ? atoi(stop_env) : 1000;
+    // (the environment is read ONCE per process, not per step)
+    static const int stop_after = [] { const char* e = getenv("DANBO_TRAIN_STOP_AFTER"); return e ? atoi(e) : 1000; }();
 #define DANBO_STAGE(n) do { if (stop_after <= (n)) { DANBO_LAUNCH_RET(); } } while (0)
     if (phase != 2) {
     // ---- zero: counters, running maxima, loss terms, volume gradients; the flat parameter gradient

@@ -404,12 +404,12 @@ __global__ __launch_bounds__(256) void k_train_bone_lists(const uint32_t* __rest
 // ------------------------------------------------------------------------------------------------------------------
 // Adam on the flat parameter buffer, exactly the update torch.optim.Adam (amsgrad = False, weight_decay = 0) performs:
 //   m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-// hyper (device): [lr, bc1 = 1 - b1^t, sqrt(bc2) = sqrt(1 - b2^t), grad_scale]
+// lr, bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t), gs = gradient scale: kernel arguments (by value -- nothing the host can overwrite
+// between the enqueue and the execution of the launch)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, long n, const float* __restrict__ hyper, float b1, float b2,
-                                              float eps) {
-    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2], gs = hyper[3];
+                                              float* __restrict__ v, long n, float lr, float bc1, float bc2s, float gs, float b1,
+                                              float b2, float eps) {
     const float step = lr / bc1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
@@ -428,7 +428,7 @@ using namespace danbo;
 // grid of a kernel whose workgroups each end in atomics on the same few words: two workgroups per CU instead of eight
 static inline int few_grid(long items, int block) {
     const int g = stream_grid(items, block);
-    return g < 2 * NUM_CU ? g : 2 * NUM_CU;
+    return g < 2 * num_cu() ? g : 2 * num_cu();
 }
 
 extern "C" int danbo_train_view_inputs(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise, int L_view,
@@ -496,7 +496,7 @@ extern "C" int danbo_train_code_grad(const float* d_vfeat, int ldvf, int col0, i
                                      const int32_t* cnt, int rows_cap, int n_codes, float* g_codes, void* stream) {
     DANBO_CHECK_ARG(d_vfeat && row_ray && cnt && g_codes && Cf >= 1 && Cf <= 128 && n_codes >= 1 && col0 >= 0 && ldvf >= col0 + Cf);
     const int chunks = (rows_cap + CODE_CHUNK - 1) / CODE_CHUNK;
-    hipLaunchKernelGGL(k_train_code_grad, dim3(chunks < NUM_CU * 8 ? chunks : NUM_CU * 8), dim3(128), 0, (hipStream_t)stream, d_vfeat, ldvf,
+    hipLaunchKernelGGL(k_train_code_grad, dim3(chunks < num_cu() * 8 ? chunks : num_cu() * 8), dim3(128), 0, (hipStream_t)stream, d_vfeat, ldvf,
                        col0, Cf, row_ray, cam_idx, cnt, n_codes, g_codes);
     DANBO_LAUNCH_RET();
 }
@@ -517,10 +517,10 @@ extern "C" int danbo_train_bone_lists(const uint32_t* bits_c, const uint32_t* bi
     DANBO_LAUNCH_RET();
 }
 
-extern "C" int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const float* hyper,
-                               float beta1, float beta2, float eps, void* stream) {
-    DANBO_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && hyper && n > 0);
-    hipLaunchKernelGGL(k_adam, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, hyper,
-                       beta1, beta2, eps);
+extern "C" int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float bias_corr1,
+                               float sqrt_bias_corr2, float grad_scale, float beta1, float beta2, float eps, void* stream) {
+    DANBO_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && bias_corr1 > 0.f && sqrt_bias_corr2 > 0.f);
+    hipLaunchKernelGGL(k_adam, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
+                       bias_corr1, sqrt_bias_corr2, grad_scale, beta1, beta2, eps);
     DANBO_LAUNCH_RET();
 }

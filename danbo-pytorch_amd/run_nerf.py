@@ -157,14 +157,16 @@ def train(argv=None):
     log = open(os.path.join(logdir, 'scalars.jsonl'), 'a') if rank == 0 else None
     t0 = time.time()
     for i in range(start + 1, args.n_iters + 1):
-        loss, stats = trainer.train_batch(next(train_iter), i, global_step)
+        # statistics cost a device-to-host copy and a stream synchronisation: only the iterations that print ask for them
+        want_stats = rank == 0 and i % args.i_print == 0
+        loss, stats = trainer.train_batch(next(train_iter), i, global_step, sync_stats=want_stats)
         if rank == 0 and i % args.i_weights == 0:
             trainer.save_nerf(os.path.join(logdir, f'{i:06d}.tar'), global_step)
         if rank == 0 and i % args.i_testset == 0:
             metrics, _, _ = validate(args, render_data, kw_test, device, os.path.join(logdir, f'{args.expname}_val_{i:06d}_'))
             print(f"[VAL] Iter: {i} PSNR: {metrics['psnr']} SSIM: {metrics['ssim']} PSNR_FG: {metrics['psnr_fg']}")
             log.write(json.dumps(dict(iter=i, **{f'Val/{k}': v for k, v in metrics.items()})) + "\n")
-        if rank == 0 and i % args.i_print == 0:
+        if want_stats:
             print(f"[TRAIN] Iter: {i} Loss: {stats['total_loss']}  PSNR: {stats['psnr']}, Alpha: {stats['alpha']}, "
                   f"{(time.time() - t0) / (i - start):.3f} s/iter")
             log.write(json.dumps(dict(iter=i, **{f'Stats/{k}': v for k, v in stats.items()})) + "\n")

@@ -448,9 +448,11 @@ int danbo_pose_volumes_bwd(const float* bones, int G, int L_graph, int W, const 
                            float* g_w3, float* g_b3, float* bwd_scratch /*>= 2 G 24 W floats*/, void* stream);
 
 /* torch.optim.Adam's update (amsgrad = False, weight_decay = 0; core/raycasters.py:75) on a flat parameter buffer.
- * hyper (device, 4 floats): lr, 1 - beta1^t, sqrt(1 - beta2^t), gradient scale (1 / world size) */
-int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const float* hyper,
-                    float beta1, float beta2, float eps, void* stream);
+ * The step's scalars travel BY VALUE as kernel arguments (ABI 2; ABI 1 read them from a device buffer the host had to keep
+ * alive and unchanged until the kernel ran): lr, bias_corr1 = 1 - beta1^t, sqrt_bias_corr2 = sqrt(1 - beta2^t),
+ * grad_scale = 1 / world size. */
+int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float bias_corr1,
+                    float sqrt_bias_corr2, float grad_scale, float beta1, float beta2, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One training batch behind one call: forward, losses, backward (csrc/k_train.hip) -- what Trainer.train_batch

@@ -128,9 +128,11 @@ def test_dense_layer_forward_backward_and_weight_gradients_match_torch():
         assert float((gb - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()) + 1e-12
 
 
-def fused_step(fixture, graph=False, edit=None):
+def fused_step(fixture, graph=False, edit=None, model_edit=None):
     g = golden(fixture)
     args, caster, trainer, opt = build_trainer(g)
+    if model_edit is not None:
+        model_edit(caster)
     eng = trainer.fused_engine()
     assert eng is not None, trainer.fused_reason
     eng.use_graph = graph
@@ -237,6 +239,45 @@ def test_adam_kernel_matches_torch_adam_and_graph_replay_matches_eager():
     assert d <= 1e-5 * float(eager.abs().max()), d      # atomics: summation order differs between runs
 
 
+def test_adam_scalars_survive_a_host_that_runs_ahead_of_the_gpu():
+    """danbo_adam_step takes lr and the bias corrections BY VALUE.  (ABI 1 read them from one device buffer refreshed by a
+    non-blocking copy from one pinned host buffer: with the host several steps ahead -- Trainer.train_batch(sync_stats=False) -- step
+    t could be applied with step t+k's corrections.)  200 unsynchronised updates behind a long-running kernel == 200 updates
+    with a synchronisation after each, bit for bit, and both == torch.optim.Adam to round-off."""
+    g = golden("danbo_train")
+    args, caster, trainer, opt = build_trainer(g)
+    eng = trainer.fused_engine()
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    p0 = eng.flat_p.clone()
+    grads = [(torch.randn(eng.flat_g.numel(), generator=gen) * 1e-3).to(DEV) for _ in range(4)]
+    big = torch.randn(8192, 8192, device=DEV)
+
+    def run(sync):
+        eng.flat_p.copy_(p0)
+        eng.flat_m.zero_()
+        eng.flat_v.zero_()
+        eng.t = 0
+        for _ in range(3):
+            big @ big                                   # ~1.3 TFLOP each: the GPU is busy while the host enqueues all 200 updates
+        for t in range(200):
+            eng.flat_g.copy_(grads[t % 4])
+            eng.adam_step(args.lrate * (0.999 ** t), 0.5)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return eng.flat_p.clone()
+    ahead, stepwise = run(False), run(True)
+    assert torch.equal(ahead, stepwise)
+    shadow = torch.nn.Parameter(p0[:eng.n_train].clone())
+    ref_opt = torch.optim.Adam([shadow], lr=args.lrate, betas=(0.9, 0.999))
+    for t in range(200):
+        shadow.grad = grads[t % 4][:eng.n_train] * 0.5
+        ref_opt.param_groups[0]["lr"] = args.lrate * (0.999 ** t)
+        ref_opt.step()
+    d = float((shadow.detach() - ahead[:eng.n_train]).abs().max())
+    assert d <= 5e-6, d
+
+
 def test_train_batch_runs_fused_with_noise_and_updates_eval_weights():
     g = golden("danbo_perfcap_train")
     args, caster, trainer, opt = build_trainer(g, extra=["--raw_noise_std", "1.0", "--perturb", "1.0"])
@@ -280,9 +321,11 @@ def test_graph_replays_are_repeatable():
         assert float((eng.flat_g - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
 
 
-def _autograd_grads(fixture, edit):
+def _autograd_grads(fixture, edit, model_edit=None):
     g = golden(fixture)
     args, caster, trainer, opt = build_trainer(g)
+    if model_edit is not None:
+        model_edit(caster)
     caster.train()
     b = batch_of(g)
     edit(b)
@@ -296,11 +339,18 @@ def _autograd_grads(fixture, edit):
             preds, {k: float(v.detach()) for k, v in loss.items()})
 
 
-@pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count"])
+@pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count", "overlapping_volumes"])
 def test_fused_step_on_degenerate_batches(case):
     """Batches the device-side row bookkeeping has to survive: no sample inside any bone volume (zero in-volume rows: only the
-    per-ray empty-space rows carry a gradient), one pose whose rays all miss while the others hit, and a ray count that is no
-    multiple of any tile size -- against the autograd path on the same batch."""
+    per-ray empty-space rows carry a gradient), one pose whose rays all miss while the others hit, a ray count that is no
+    multiple of any tile size, and bone volumes grown 4x (axis_scale is trainable) so that a sample lies in many volumes at
+    once: more (row, bone) pairs than the K2 adjoint's launch grid has workgroups for, it has to stride -- against the autograd
+    path on the same batch."""
+    def model_edit(caster):
+        if case == "overlapping_volumes":
+            with torch.no_grad():
+                caster.network.graph_net.axis_scale.mul_(4.0)
+
     def edit(b):
         if case == "no_sample_in_any_volume":
             b["rays_o"] = b["rays_o"] + torch.tensor([40.0, 0.0, 0.0], device=DEV)
@@ -308,15 +358,19 @@ def test_fused_step_on_degenerate_batches(case):
             per = b["rays_o"].shape[0] // b["N_uniques"]
             b["rays_o"] = b["rays_o"].clone()
             b["rays_o"][:per] += torch.tensor([40.0, 0.0, 0.0], device=DEV)
-        else:
+        elif case == "odd_ray_count":
             G = b["N_uniques"]
             per = b["rays_o"].shape[0] // G
             keep = torch.cat([torch.arange(g0 * per, g0 * per + per - 3, device=DEV) for g0 in range(G)])   # 3 rays fewer per pose
             for k in ("rays_o", "rays_d", "target_s", "bgs", "kp3d", "skts", "bones", "cyls", "cam_idxs"):
                 b[k] = b[k][keep].contiguous()
-    ref, preds, ref_loss = _autograd_grads("danbo_perfcap_train", edit)
-    g, args, caster, trainer, eng, out = fused_step("danbo_perfcap_train", edit=edit)
+    ref, preds, ref_loss = _autograd_grads("danbo_perfcap_train", edit, model_edit)
+    g, args, caster, trainer, eng, out = fused_step("danbo_perfcap_train", edit=edit, model_edit=model_edit)
     counts = out["counts"].cpu().numpy()
+    if case == "overlapping_volumes":
+        pairs = int((preds["part_invalid"] == 0).sum())
+        print("(row, bone) pairs per in-volume row:", pairs / max(int(counts[5]), 1))
+        assert pairs > 4 * int(counts[5])         # more pairs than danbo_assign_blend_bwd sizes its grid for
     R = out["rgb_map"].shape[0]
     assert torch.isfinite(out["loss"]).all() and torch.isfinite(eng.flat_g).all()
     if case == "no_sample_in_any_volume":

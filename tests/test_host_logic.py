@@ -5,6 +5,7 @@
   * the core.networks / core.raycasters module surface: names, state_dict keys and shapes,
     checkpoint round trip, config parsing, and the hard failure without a GPU.
 """
+import copy
 import ctypes
 import os
 import re
@@ -34,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/danbo_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
-    assert lib.danbo_abi_version() == 1
+    assert lib.danbo_abi_version() == 2
     # argument counts of the ctypes table match the header
     for name in declared:
         m = re.search(r"(?:int|size_t|long)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
@@ -222,6 +223,23 @@ def test_unsupported_variants_raise_instead_of_falling_back():
         _build("h36m_zju/danbo_base.txt", extra=["--agg_type", "softmax"])
     with pytest.raises(NotImplementedError):
         _build("h36m_zju/danbo_base.txt", extra=["--gnn_backbone", "PNBGNN"])
+
+
+def test_fused_training_step_reports_the_options_it_does_not_cover():
+    """train_engine.supported -> None for the shipped DANBO configurations, and a reason (=> the trainer takes the autograd path,
+    whose caster raises NotImplementedError) for every option the C step has no field for"""
+    from core import train_engine
+    args, (tr, *_r) = _build("perfcap/danbo_fast.txt")
+    assert train_engine.supported(args, tr["ray_caster"]) is None
+    for flag, value, reason in [("lindisp", True, "lindisp"), ("ray_noise_std", 0.5, "ray_noise_std"), ("loss_fn", "Huber", "loss_fn"),
+                                ("weight_decay", 1e-4, "weight decay"), ("opt_pose", True, "opt_pose"), ("N_importance", 0, "sampling"),
+                                ("density_type", "softplus", "density_type")]:
+        a = copy.copy(args)
+        setattr(a, flag, value)
+        got = train_engine.supported(a, tr["ray_caster"])
+        assert got is not None and reason in got, (flag, got)
+    a_args, (a_tr, *_r) = _build("h36m_zju/anerf_base.txt")
+    assert "network" in train_engine.supported(a_args, a_tr["ray_caster"])
 
 
 @pytest.mark.parametrize("cfg_file,name", [("h36m_zju/danbo_base.txt", "danbo_base"), ("h36m_zju/anerf_base.txt", "anerf_base")])
