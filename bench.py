@@ -4,15 +4,20 @@
 Default workload = BASELINE.json's metric: ray-samples/s of the render path at 512 x 512 rays x 64 samples (48 coarse + 16
 importance: the reference cannot run N_importance = 0), H36M `danbo_base` network, seeded synthetic weights / pose /
 camera, everything resident in HBM.  A *step* is one full frame: bounds -> depths -> cull -> gather / assignment / blend ->
-PE + MLP -> composite -> importance resampling -> second network pass -> composite.  For N > 1 the driver launches one rank per
-GPU; ranks render different camera views (rays shard data-parallel, no collective on the data path) => weak scaling;
-value = N * K * units / max-over-ranks time.
+PE + MLP -> composite -> importance resampling -> second network pass -> composite.  For N > 1 there is one rank (process) per
+GPU: either the caller started them (RANK / WORLD_SIZE / LOCAL_RANK in the environment, e.g. the driver's
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`), or -- `python bench.py --gpus N` from a plain shell --
+bench.py starts them itself (launch_ranks: a `torch.distributed.run` child, BEFORE this process touches the GPU) and relays rank
+0's JSON line.  Ranks render different camera views (rays shard data-parallel, no collective on the data path) => weak scaling;
+value = N * K * units / max-over-ranks time.  `ranks_seen` = dist.get_world_size() as the ranks saw it.
 
 --config selects the other BASELINE configurations, each with its own `roofline` and `cpu_baseline`:
   2  H36M danbo_fast: 512^2 x (32 + 16), per-bone box near/far           (render)
   3  H36M danbo_base: 512^2 x (96 + 32) = 128 samples per ray              (render)
   4  PerfCap danbo_fast TRAINING step: 3072 rays = 16 poses x 192, 32 + 16, perturb, noise, L1, Adam; danbo_train_step +
-     danbo_adam_step (one C call each), RCCL all-reduce of the flat gradient for N > 1 (every rank its own 3072 rays: weak)
+     danbo_adam_step (one C call each), RCCL all-reduce of the flat gradient for N > 1.  --scaling weak (default): every rank
+     its own 3072 rays; --scaling strong: the reference's ONE 16-pose / 3072-ray batch split by whole poses over the ranks
+     (8 ranks x 2 poses x 192 rays), value = 3072 x 48 / step time
   5  A-NeRF anerf_base: 512^2 x (48 + 16), cutoff PE, W = 448             (render)
 
 `value` of the render configs is measured with exact in-volume culling (bit-identical raw to evaluating every sample:
@@ -275,9 +280,13 @@ def bench_train(args, rank, world, device, dist):
     sd = syn.make_state_dict(syn.model_config("danbo_perfcap"), 3, 20, rest)
     caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
     trainer = Trainer(targs, da, opt, None, tr_kw, te_kw, device=device)
+    strong = args.scaling == "strong"
     poses, rpp = 16, 192
-    scene = syn.make_scene(n_poses=poses, H=128, W=128, n_views=poses, pose_seed=5 + rank)
-    rng = np.random.default_rng(rank)
+    if strong and (poses % world != 0):
+        raise SystemExit(f"--scaling strong splits the 16-pose batch by whole poses: {world} ranks do not divide 16")
+    # weak: every rank draws its own 16-pose batch; strong: every rank builds the SAME batch and keeps its 16 / world poses
+    scene = syn.make_scene(n_poses=poses, H=128, W=128, n_views=poses, pose_seed=5 + (0 if strong else rank))
+    rng = np.random.default_rng(0 if strong else rank)
     js, is_ = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
     sel = np.nonzero(((np.abs(is_ - 64) < 128 * 0.22) & (np.abs(js - 64) < 128 * 0.40)).reshape(-1))[0]
     ro, rd, pose = [], [], []
@@ -285,9 +294,16 @@ def bench_train(args, rank, world, device, dist):
         idx = np.sort(rng.choice(sel, size=rpp, replace=False))
         ro.append(scene["rays"][p][0][idx]); rd.append(scene["rays"][p][1][idx]); pose += [p] * rpp
     pose = np.array(pose)
+    R_global = len(pose) * (1 if strong else world)
+    ro, rd = np.concatenate(ro), np.concatenate(rd)
+    target, bgs = rng.uniform(size=(len(pose), 3)), rng.uniform(size=(len(pose), 3))
+    if strong:          # rank r keeps poses [r * 16 / world, (r + 1) * 16 / world): whole poses, so N_uniques stays an integer
+        mine = slice(rank * (poses // world) * rpp, (rank + 1) * (poses // world) * rpp)
+        ro, rd, target, bgs, pose = ro[mine], rd[mine], target[mine], bgs[mine], pose[mine]
+        poses = poses // world
     R = len(pose)
-    batch = dict(rays_o=T(np.concatenate(ro), device), rays_d=T(np.concatenate(rd), device), target_s=T(rng.uniform(size=(R, 3)), device),
-                 bgs=T(rng.uniform(size=(R, 3)), device), kp3d=T(scene["kps"][pose], device), skts=T(scene["skts"][pose], device),
+    batch = dict(rays_o=T(ro, device), rays_d=T(rd, device), target_s=T(target, device),
+                 bgs=T(bgs, device), kp3d=T(scene["kps"][pose], device), skts=T(scene["skts"][pose], device),
                  bones=T(scene["bones"][pose], device), cyls=T(scene["cyls"][pose], device), cam_idxs=T(pose % 20, device, torch.int64),
                  N_uniques=poses)
     if trainer.fused_engine() is None:
@@ -306,9 +322,13 @@ def bench_train(args, rank, world, device, dist):
     # dense-layer work of a step: forward (pts 0..7, feature+alpha, view[411 in], rgb) + input gradients + weight gradients
     mac_fwd = 195 * 256 + 4 * 256 * 256 + 451 * 256 + 2 * 256 * 256 + 257 * 256 + 411 * 128 + 128 * 3
     mac_dx = 256 * 411 + 257 * 256 + 6 * 256 * 256 + 256 * 451 + 256 * 195          # view^T, fa^T, trunk 7..1 (5: 451 out), layer 0
-    flops = 2.0 * rows * (2 * mac_fwd + mac_dx)
     ms = 1e3 * elapsed / args.steps
-    achieved = flops / (ms * 1e-3)
+    if dist is not None:                 # whole-job executed rows: sum over the ranks
+        rt = torch.tensor([float(rows), float(in_vol)], dtype=torch.float64, device="cpu" if args.debug_single_device else device)
+        dist.all_reduce(rt)
+        rows, in_vol = int(rt[0].item()), int(rt[1].item())
+    flops = 2.0 * rows * (2 * mac_fwd + mac_dx)
+    achieved = flops / (ms * 1e-3) / world           # per GPU: the roofline is one GPU's
     peak = PEAK_FP16_MFMA / 3.0
     # HBM bytes of a step from the PMC passes of tools/pmc_train.sh, quoted only for the kernel sources they were measured on
     traffic, hbm = None, None
@@ -321,18 +341,20 @@ def bench_train(args, rank, world, device, dist):
                        note="every activation and gradient of the trunk crosses HBM once per use (the backward needs them all); the "
                             "weight-gradient kernel alone reads 1.3 GB at 3.4 TB/s")
     result = {
-        "metric": "training ray-samples/sec (PerfCap danbo_fast step: forward + losses + backward + Adam)", "value": world * R * S / (ms * 1e-3),
+        "metric": "training ray-samples/sec (PerfCap danbo_fast step: forward + losses + backward + Adam)", "value": R_global * S / (ms * 1e-3),
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16x2-split MFMA products, fp32 accumulate)", "data": "synthetic",
-        "config": {"workload": "BASELINE config 4: PerfCap danbo_fast training step, 3072 rays = 16 poses x 192 per rank, 32 + 16 samples, "
-                               "perturb = 1, raw_noise_std = 1, L1 + soft-softmax + volume-scale losses, Adam; danbo_train_step + "
-                               "danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
-                   "rays": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
-        "rows_per_step": rows, "in_volume_fraction": in_vol / (R * S), "loss": float(loss["total_loss"]),
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 (fp16x2-split MFMA products, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: PerfCap danbo_fast training step, " +
+                               (f"ONE batch of 3072 rays = 16 poses x 192 split by whole poses: {poses} poses = {R} rays per rank, " if strong
+                                else "3072 rays = 16 poses x 192 per rank, ") +
+                               "32 + 16 samples, perturb = 1, raw_noise_std = 1, L1 + soft-softmax + volume-scale losses, Adam; "
+                               "danbo_train_step + danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
+                   "rays": R_global, "rays_per_rank": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
+        "rows_per_step": rows, "in_volume_fraction": in_vol / (R_global * S), "loss": float(loss["total_loss"]),
         "roofline": dict(bound="mfma", kernel="k_linear16<EXT> x 30 + k_dw16 (whole step)", achieved=achieved / 1e12, peak=peak / 1e12,
                          unit="TFLOP/s", frac=achieved / peak, traffic=traffic, flop_per_row=2 * (2 * mac_fwd + mac_dx),
                          peak_note=SPLIT_NOTE,
-                         note="STEP-level lower bound: executed dense-layer flops of the step (forward + input gradients + weight "
+                         note="STEP-level lower bound, per GPU: executed dense-layer flops of the step (forward + input gradients + weight "
                               "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
                               "per-kernel durations: profiles/r02*_train_kernel_stats.csv"),
     }
@@ -432,6 +454,55 @@ def bench_anerf(args, rank, world, device, dist):
     return result
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` from a shell that is not already a rank: start N ranks of this script, one per GPU, as a child
+    `python -m torch.distributed.run` -- from a process that has not touched the GPU (never re-exec one that has) -- and relay
+    rank 0's JSON line.  Exit code = the child's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        raise SystemExit(proc.returncode or 1)
+    print(lines[-1])
+
+
+def bench_dry_run(args, rank, world, device, dist):
+    """--dry-run: the launch / rendezvous / timing harness with a host no-op in place of the step (no HIP call at all).  Exists so
+    that the N-rank command path can be exercised where there is no GPU; its line says so and is not a measurement."""
+    def one():
+        time.sleep(0.001)
+    for _ in range(args.warmup):
+        one()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"metric": "DRY RUN of the launch path (no GPU work, not a measurement)", "value": 0.0, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": args.scaling or "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+            "config": {"workload": f"dry run of --config {args.config}", "parallelism": f"rays-dp{world}"}}
+
+
 def main():
     global N_SAMPLES, N_IMPORTANCE
     ap = argparse.ArgumentParser()
@@ -440,6 +511,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4, 5],
                     help="1: BASELINE metric (default); 2: danbo_fast 32+16 box bounds; 3: danbo_base 96+32; 4: training step; 5: A-NeRF")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="config 4 only: weak = 3072 rays per rank (default); strong = the reference's one 16-pose / 3072-ray batch "
+                         "split by whole poses over the ranks (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the occupancy sweep (camera distance) of the render configs")
@@ -448,9 +522,20 @@ def main():
     ap.add_argument("--box-near-far", action="store_true", help="dev: per-bone box near/far (config 2 sets it)")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="dev: every rank uses cuda:0 and the gloo backend (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="dev: launch / rendezvous / timing harness only, a host no-op as the step (gloo, no GPU needed); not a measurement")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
                     help="f16split: fp32-accurate products as 3 fp16 MFMAs (default); fp32: exact fp32 MFMA kernels")
     args = ap.parse_args()
+    if args.scaling == "strong" and args.config != 4:
+        raise SystemExit("--scaling strong is defined for --config 4 (the training batch); the render configs shard views: weak")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # ---- not a rank yet?  Then become the launcher: nothing above or in this branch touches the GPU.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
+
     if args.config in CONFIGS:
         N_SAMPLES, N_IMPORTANCE, box = CONFIGS[args.config]
         args.box_near_far = args.box_near_far or box
@@ -460,24 +545,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libdanbo_hip has no CPU path")
-    if args.debug_single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    device = None
+    if not args.dry_run:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: libdanbo_hip has no CPU path")
+        if args.debug_single_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if args.debug_single_device:
+        if args.debug_single_device or args.dry_run:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+    ranks_seen = dist.get_world_size() if dist is not None else 1
 
-    fn = {4: bench_train, 5: bench_anerf}.get(args.config, bench_render)
+    fn = bench_dry_run if args.dry_run else {4: bench_train, 5: bench_anerf}.get(args.config, bench_render)
     result = fn(args, rank, world, device, dist)
+    result["ranks_seen"] = ranks_seen
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -179,3 +179,37 @@ def test_fused_training_world2_on_one_gpu_keeps_replicas_bit_identical():
     import numpy as np
     assert np.array_equal(res[0][1], res[1][1])              # every parameter, bit for bit, after 3 steps
     assert all(np.isfinite(l) for r in res for l in r[2]) and res[0][2] != res[1][2]    # the shards (and their losses) differ
+
+
+def _run_bench(*flags, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2 ...` from a shell with no RANK / WORLD_SIZE exported starts two ranks (launch_ranks) and prints ONE
+    line with n_gpus = ranks_seen = 2.  --dry-run: a host no-op as the step, so the command path runs without a GPU."""
+    r = _run_bench("--gpus", "2", "--dry-run", "--config", "4", "--scaling", "strong", "--steps", "4", "--warmup", "1")
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["scaling"] == "strong" and r["steps"] == 4
+    r1 = _run_bench("--dry-run", "--steps", "2", "--warmup", "0")
+    assert r1["n_gpus"] == 1 and r1["ranks_seen"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_config4_strong_scaling_on_two_ranks_of_one_gpu():
+    """the real thing on the GPU box: two ranks (both on cuda:0, gloo collectives) split the reference's 16-pose / 3072-ray batch by
+    whole poses; one JSON line, n_gpus = 2, 1536 rays per rank"""
+    r = _run_bench("--gpus", "2", "--debug-single-device", "--config", "4", "--scaling", "strong", "--steps", "3", "--warmup", "2",
+                   "--no-cpu-baseline")
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["scaling"] == "strong"
+    assert r["config"]["rays"] == 3072 and r["config"]["rays_per_rank"] == 1536
+    assert r["value"] > 0 and r["loss"] == r["loss"]
