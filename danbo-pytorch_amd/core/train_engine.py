@@ -101,6 +101,7 @@ class DanboTrainEngine:
         self._model_struct = None
         self.graph = None           # (key, CUDAGraph, static inputs, outputs)
         self.use_graph = True
+        self.fixed_draws = None     # dict(t_rand, u_rand, noise_c, noise_f) replaces the step's random draws (parity tests)
 
     # ------------------------------------------------------------------ optimizer state as views of the flat moments
     def _optimizer_step_count(self):
@@ -176,11 +177,22 @@ class DanboTrainEngine:
         # the step's random draws: ONE uniform and ONE normal generator launch (+ one scaling), carved into the four tensors the
         # C side wants contiguous: stratified offsets [R,S], inverse-CDF uniforms [R,Sf], density noise [R,S] and [R,S+Sf]
         rnd = {}
-        if perturb > 0.:
+        if self.fixed_draws is not None:
+            # parity hook: the caller supplies the step's random numbers (the reference's own draws, tests/golden/
+            # danbo_perfcap_train_noise.npz): t_rand [R,S], u_rand [R,Sf] uniforms; noise_c [R,S], noise_f [R,S+Sf] ALREADY
+            # multiplied by raw_noise_std * B as core/networks/nerf.py:316 forms them
+            want = dict(t_rand=(R, S), u_rand=(R, Sf), noise_c=(R, S), noise_f=(R, S + Sf))
+            for k, shp in want.items():
+                v = self.fixed_draws.get(k)
+                if v is not None:
+                    if tuple(v.shape) != shp:
+                        raise ValueError(f"fixed_draws[{k!r}]: shape {tuple(v.shape)}, expected {shp}")
+                    rnd[k] = v.to(dev).float().contiguous()
+        elif perturb > 0.:
             u = torch.rand(R * (S + Sf), device=dev)
             rnd['_u'] = u
             rnd['t_rand'], rnd['u_rand'] = u[:R * S].view(R, S), u[R * S:].view(R, Sf)
-        if raw_noise_std > 0.:
+        if self.fixed_draws is None and raw_noise_std > 0.:
             nz = torch.randn(R * (2 * S + Sf), device=dev).mul_(raw_noise_std * B)
             rnd['_n'] = nz
             rnd['noise_c'], rnd['noise_f'] = nz[:R * S].view(R, S), nz[R * S:].view(R, S + Sf)

@@ -184,11 +184,17 @@ def near_far_boxes(rays_o, rays_d, skts, align, axis_scale, near, far, bound=1.3
 # =============================================================================
 # a5  sampling along the ray
 # =============================================================================
-def coarse_z(near, far, S):
-    """sample_from_lineseg (perturb=0, lindisp=False), core/utils/ray_utils.py:206-253."""
-    t = np.linspace(0., 1., S, dtype=np.float64).astype(F32)  # torch.linspace fp32
+def coarse_z(near, far, S, t_rand=None):
+    """sample_from_lineseg (lindisp=False), core/utils/ray_utils.py:206-253.  t_rand [R,S]: the uniforms of the stratified
+    branch (perturb > 0, :233-248: one sample per interval between the mid-points of the even depths); None: perturb = 0."""
     t = torch_linspace01(S)
-    return (near * (F32(1.) - t) + far * t).astype(F32)
+    z = (near * (F32(1.) - t) + far * t).astype(F32)
+    if t_rand is None:
+        return z
+    mids = (F32(.5) * (z[:, 1:] + z[:, :-1])).astype(F32)
+    upper = np.concatenate([mids, z[:, -1:]], -1)
+    lower = np.concatenate([z[:, :1], mids], -1)
+    return (lower + ((upper - lower).astype(F32) * np.asarray(t_rand, dtype=F32)).astype(F32)).astype(F32)
 
 
 def torch_linspace01(n):
@@ -634,8 +640,11 @@ class DanboOracle:
         return n, f
 
     def render(self, ray_batch, skts, bones, cyls, cam_idxs=None, n_uniques=1,
-               N_samples=None, N_importance=None, chunk=None, stages=False, near_far=None):
+               N_samples=None, N_importance=None, chunk=None, stages=False, near_far=None, draws=None):
+        """draws: dict(t_rand [R,S], u_rand [R,Sf], noise_c [R,S], noise_f [R,S+Sf]) -- the random numbers of the training-mode
+        branches (perturb > 0: ray_utils.py:240 and :171; raw_noise_std > 0: nerf.py:316, noise already x std x B); None: eval"""
         cfg = self.cfg
+        draws = draws or {}
         S = N_samples or cfg['N_samples']
         Sf = N_importance or cfg['N_importance']
         rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
@@ -644,16 +653,16 @@ class DanboOracle:
             near, far = self.near_far(rays_o, rays_d, cyls, skts, near, far, chunk)
         else:  # decoupled parity tests feed the reference's own bounds
             near, far = near_far
-        z = coarse_z(near, far, S)
+        z = coarse_z(near, far, S, draws.get('t_rand'))
         pts = sample_points(rays_o, rays_d, z)
         raw, enc = self.forward(pts, rays_d, skts, bones, cam_idxs, n_uniques, stages)
         B = cfg['density_scale']
-        out0 = composite(raw, z, rays_d, B)
-        z_all, z_fine, order = importance_z(z, out0['weights'], Sf)
+        out0 = composite(raw, z, rays_d, B, draws.get('noise_c'))
+        z_all, z_fine, order = importance_z(z, out0['weights'], Sf, u=draws.get('u_rand'))
         pts_f = sample_points(rays_o, rays_d, z_fine)
         raw_f, enc_f = self.forward(pts_f, rays_d, skts, bones, cam_idxs, n_uniques, False)
         raw_all = np.take_along_axis(np.concatenate([raw, raw_f], 1), order[..., None], 1)
-        out = composite(raw_all, z_all, rays_d, B)
+        out = composite(raw_all, z_all, rays_d, B, draws.get('noise_f'))
         ret = dict(rgb_map=out['rgb_map'], disp_map=out['disp_map'], acc_map=out['acc_map'],
                    alpha=out['alpha'], T_i=out['weights'], rgb0=out0['rgb_map'],
                    disp0=out0['disp_map'], acc0=out0['acc_map'], alpha0=out0['alpha'])

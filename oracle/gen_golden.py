@@ -227,8 +227,23 @@ def gen_danbo_train():
     S, Sf = 16, 8
     caster.train()
     kw = {k: v for k, v in kw_test.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
-    preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
-                   cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+    draws = {}
+    if stochastic:
+        kw.update(perturb=1.0, raw_noise_std=1.0)
+        torch.manual_seed(4242)
+        with RecordedDraws() as rec:
+            preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                           cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+        R = len(pose)
+        kinds = [(k, tuple(t.shape)) for k, t in rec.calls]
+        # the reference draws, in this order: stratified offsets, coarse density noise, inverse-CDF uniforms, fine density noise
+        assert kinds == [("rand", (R, S)), ("randn", (R, S)), ("rand", (R, Sf)), ("randn", (R, S + Sf))], kinds
+        B = float(kw["preproc_kwargs"]["density_scale"]) if "preproc_kwargs" in kw else 1.0
+        draws = dict(t_rand=rec.calls[0][1].numpy(), noise_c=(rec.calls[1][1] * 1.0 * B).numpy(), u_rand=rec.calls[2][1].numpy(),
+                     noise_f=(rec.calls[3][1] * 1.0 * B).numpy(), density_scale=np.float32(B))
+    else:
+        preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                       cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
     wrap = types.SimpleNamespace(module=caster)
     tr = rtr.Trainer(args, dict(hwf=(64, 64, 80.0)), None, None, dict(ray_caster=wrap), dict(ray_caster=caster))
     loss_dict, stats = tr.compute_loss(dict(target_s=T(target), bgs=T(bgs)), preds, kp_opts=None, popt_detach=True)
@@ -236,7 +251,10 @@ def gen_danbo_train():
     loss_dict["total_loss"].backward()
     net = caster.network
     grads = {n: p.grad.numpy() for n, p in net.named_parameters() if p.grad is not None}
-    keep = {}
+    keep = {"draw/" + k: v for k, v in draws.items()}
+    if stochastic:
+        keep["alpha"] = preds["alpha"].detach().numpy()
+        keep["alpha0"] = preds["alpha0"].detach().numpy()
     for n in ("graph_net.axis_scale", "pts_linears.0.weight", "pts_linears.5.bias", "alpha_linear.weight",
               "rgb_linear.weight", "views_linears.0.bias", "framecodes.codes.weight", "prob_linears.layers.1.weight",
               "prob_linears.layers.0.adj_w", "prob_linears.layers.2.bias", "graph_net.layers.0.adj_w",
@@ -256,10 +274,38 @@ def gen_danbo_train():
     print("danbo_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()})
 
 
-def gen_danbo_perfcap_train():
+class RecordedDraws:
+    """While active, torch.rand / torch.randn hand out what they always do AND keep every draw, in call order -- so the
+    reference's stochastic branches (stratified offsets ray_utils.py:240, density noise nerf.py:316, inverse-CDF uniforms
+    ray_utils.py:171) can be replayed by feeding the same numbers to the HIP path."""
+    def __enter__(self):
+        self.calls = []
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k)
+            self.calls.append(("rand", t.clone()))
+            return t
+
+        def randn(*a, **k):
+            t = self._randn(*a, **k)
+            self.calls.append(("randn", t.clone()))
+            return t
+        torch.rand, torch.randn = rand, randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn = self._rand, self._randn
+
+
+def gen_danbo_perfcap_train(stochastic=False):
     """BASELINE config 4 in miniature: PerfCap danbo_fast (view_type relray + ray_tr_type root_local, per-bone box near/far,
-    vol_scale_penalty as configured), one deterministic training forward/backward (perturb = 0, raw_noise_std = 0) of the
-    reference: loss terms of Trainer.compute_loss, gradient norms of every parameter and a representative set of gradients"""
+    vol_scale_penalty as configured), one training forward/backward of the reference: loss terms of Trainer.compute_loss,
+    gradient norms of every parameter and a representative set of gradients.
+    stochastic=False -> danbo_perfcap_train.npz: perturb = 0, raw_noise_std = 0 (deterministic).
+    stochastic=True  -> danbo_perfcap_train_noise.npz: config 4's ACTUAL settings perturb = 1, raw_noise_std = 1, with the
+    reference's own random draws recorded (t_rand [R,S], noise_c [R,S] = randn * std * B as nerf.py:316 forms it, u [R,Sf],
+    noise_f [R,S+Sf]) so the HIP step can be run on the same numbers."""
     seed = 17
     cfg, args, caster, kw_test, rest = build("danbo_perfcap", seed)
     import types
@@ -280,8 +326,23 @@ def gen_danbo_perfcap_train():
     S, Sf = 16, 8
     caster.train()
     kw = {k: v for k, v in kw_test.items() if k not in ("ray_caster", "use_viewdirs", "N_samples", "N_importance")}
-    preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
-                   cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+    draws = {}
+    if stochastic:
+        kw.update(perturb=1.0, raw_noise_std=1.0)
+        torch.manual_seed(4242)
+        with RecordedDraws() as rec:
+            preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                           cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
+        R = len(pose)
+        kinds = [(k, tuple(t.shape)) for k, t in rec.calls]
+        # the reference draws, in this order: stratified offsets, coarse density noise, inverse-CDF uniforms, fine density noise
+        assert kinds == [("rand", (R, S)), ("randn", (R, S)), ("rand", (R, Sf)), ("randn", (R, S + Sf))], kinds
+        B = float(kw["preproc_kwargs"]["density_scale"]) if "preproc_kwargs" in kw else 1.0
+        draws = dict(t_rand=rec.calls[0][1].numpy(), noise_c=(rec.calls[1][1] * 1.0 * B).numpy(), u_rand=rec.calls[2][1].numpy(),
+                     noise_f=(rec.calls[3][1] * 1.0 * B).numpy(), density_scale=np.float32(B))
+    else:
+        preds = caster(T(rb), N_samples=S, kp_batch=T(kps), skts=T(skts), cyls=T(cyls), bones=T(bones),
+                       cams=T(cam_idx, torch.long), N_importance=Sf, N_uniques=4, **kw)
     wrap = types.SimpleNamespace(module=caster)
     tr = rtr.Trainer(args, dict(hwf=(64, 64, 80.0)), None, None, dict(ray_caster=wrap), dict(ray_caster=caster))
     loss_dict, stats = tr.compute_loss(dict(target_s=T(target), bgs=T(bgs)), preds, kp_opts=None, popt_detach=True)
@@ -289,7 +350,10 @@ def gen_danbo_perfcap_train():
     loss_dict["total_loss"].backward()
     net = caster.network
     grads = {n: p.grad.numpy() for n, p in net.named_parameters() if p.grad is not None}
-    keep = {}
+    keep = {"draw/" + k: v for k, v in draws.items()}
+    if stochastic:
+        keep["alpha"] = preds["alpha"].detach().numpy()
+        keep["alpha0"] = preds["alpha0"].detach().numpy()
     for n in ("graph_net.axis_scale", "pts_linears.0.weight", "pts_linears.5.bias", "pts_linears.7.bias", "alpha_linear.weight",
               "alpha_linear.bias", "feature_linear.bias", "rgb_linear.weight", "rgb_linear.bias", "views_linears.0.bias",
               "framecodes.codes.weight", "prob_linears.layers.0.bias", "prob_linears.layers.1.weight",
@@ -307,7 +371,7 @@ def gen_danbo_perfcap_train():
     keep["grad/feature_linear.weight[::8, ::8]"] = grads["feature_linear.weight"][::8, ::8].copy()
     norms = {"gnorm/" + n: np.float64(np.sqrt((g.astype(np.float64) ** 2).sum())) for n, g in grads.items()}
     np.savez_compressed(
-        os.path.join(OUT, "danbo_perfcap_train.npz"),
+        os.path.join(OUT, "danbo_perfcap_train_noise.npz" if stochastic else "danbo_perfcap_train.npz"),
         cfg_name="danbo_perfcap", weight_seed=seed, n_framecodes=20, N_samples=S, N_importance=Sf, n_uniques=4,
         ray_batch=rb, kps=scene["kps"], skts=scene["skts"], bones=scene["bones"], cyls=scene["cyls"],
         pose_of_ray=pose, cam_idx=cam_idx, target=target, bgs=bgs,
@@ -315,7 +379,7 @@ def gen_danbo_perfcap_train():
         rgb0=preds["rgb0"].detach().numpy(), acc0=preds["acc0"].detach().numpy(),
         part_invalid=preds["part_invalid"].detach().numpy(),
         **{"loss/" + k: np.float64(v.item()) for k, v in loss_dict.items()}, **keep, **norms)
-    print("danbo_perfcap_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()},
+    print("danbo_perfcap_train_noise:" if stochastic else "danbo_perfcap_train:", {k: round(v.item(), 6) for k, v in loss_dict.items()},
           "in-volume fraction", 1.0 - float(preds["part_invalid"].detach().numpy().all(-1).mean()))
 
 
@@ -611,7 +675,7 @@ if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "mesh", "h36m_fast", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "perfcap_train_noise", "mesh", "h36m_fast", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -628,6 +692,8 @@ if __name__ == "__main__":
         gen_anerf_train()
     if "perfcap_train" in which:
         gen_danbo_perfcap_train()
+    if "perfcap_train_noise" in which:
+        gen_danbo_perfcap_train(stochastic=True)
     if "mesh" in which:
         gen_danbo_mesh()
     if "h36m_fast" in which:

@@ -89,7 +89,7 @@ def test_model_forward_matches_reference_raw(env):
                   N_uniques=2, rays_o=T(rb[:, None, 0:3]), rays_d=T(rb[:, None, 3:6]), cam_idxs=T(g["cam_idx"], torch.int64))
     raw, enc = caster.network(inputs)
     assert raw.shape == (48, 12, 4)
-    assert raw_err(N(raw), g["raw_coarse"]) < 2e-4
+    assert raw_err(N(raw), g["raw_coarse"]) < 1e-4          # north_star bound; measured 1.4e-5 (profiles/r03_parity_measured.txt)
     # small row chunks (whole rays per chunk) give the same result
     caster._engine().rows_per_chunk = 5 * 12
     raw2, _ = caster.network(inputs)
@@ -140,4 +140,4 @@ def test_full_render_against_oracle_and_density_query(env):
     dens = caster(T(pts).reshape(-1, 1, 3), T(scene["kps"]), T(scene["skts"]), T(scene["bones"]), fwd_type="density")
     raw, _ = orc.forward(pts.reshape(-1, 1, 3), np.zeros((500, 3), np.float32) + [0, 0, 1],
                          np.repeat(scene["skts"], 500, 0), cam_idxs=None)
-    assert raw_err(N(dens).reshape(-1), raw[:, 0, 3]) < 2e-4
+    assert raw_err(N(dens).reshape(-1), raw[:, 0, 3]) < 1e-4      # measured 1.1e-5

@@ -44,6 +44,11 @@ def test_config2_h36m_danbo_fast_caster_matches_reference():
     ref = orc.render(rb, g["skts"][pose], g["bones"][pose], g["cyls"][pose], g["cam_idx"], 2, S, Sf, stages=True,
                      near_far=(g["near"], g["far"]))
     assert raw_err(N(ret["raw_coarse"]), ref["raw_coarse"]) < 1e-4
+    # the maps against the on-box oracle (same bounds, same arithmetic order up to the fp16-split products): 1e-5
+    for k in ("rgb0", "acc0", "rgb_map", "acc_map"):
+        e = max_err(N(ret[k]), ref[k])
+        print(f"config 2 {k} vs oracle: {e:.2e}")
+        assert e < 1e-5, (k, e)
 
 
 @pytest.mark.parametrize("case", ["weights_x1e-3", "weights_x1e3", "alternating", "activations_1e5"])

@@ -128,6 +128,12 @@ def test_dense_layer_forward_backward_and_weight_gradients_match_torch():
         assert float((gb - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()) + 1e-12
 
 
+# Gradient bounds against the reference's own autograd = 2x the worst deviation measured on the three training fixtures (MI355X,
+# round 3; profiles/r03_parity_measured.txt): norms 5.6e-5 -> 2e-4; stored tensors (entry-wise, relative to the tensor's max) see below
+NORM_TOL = 2e-4
+TENSOR_TOL = 2e-3        # measured 9.7e-4 (danbo_train), 2.1e-4, 5.3e-4
+
+
 def fused_step(fixture, graph=False, edit=None, model_edit=None):
     g = golden(fixture)
     args, caster, trainer, opt = build_trainer(g)
@@ -141,15 +147,23 @@ def fused_step(fixture, graph=False, edit=None, model_edit=None):
         edit(b)
     G = b["N_uniques"]
     pp = caster._per_pose
+    noise = {}
+    if "draw/t_rand" in g.files:       # the reference's own random draws (perturb = 1, raw_noise_std = 1): replay them
+        eng.fixed_draws = {k: T(g["draw/" + k]) for k in ("t_rand", "u_rand", "noise_c", "noise_f")}
+        noise = dict(perturb=1.0, raw_noise_std=1.0)
     out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G), b["cam_idxs"],
-                               b["target_s"], b["bgs"], int(g["N_samples"]), int(g["N_importance"]))
+                               b["target_s"], b["bgs"], int(g["N_samples"]), int(g["N_importance"]), **noise)
     torch.cuda.synchronize()
     return g, args, caster, trainer, eng, out
 
 
-@pytest.mark.parametrize("fixture", ["danbo_train", "danbo_perfcap_train"])
+@pytest.mark.parametrize("fixture", ["danbo_train", "danbo_perfcap_train", "danbo_perfcap_train_noise"])
 def test_fused_step_matches_reference_autograd(fixture):
+    """danbo_perfcap_train_noise: config 4's actual settings (perturb = 1, raw_noise_std = 1) on the reference's recorded draws --
+    stratified depths, both density-noise tensors and the random inverse-CDF uniforms take part in the losses and gradients"""
     g, args, caster, trainer, eng, out = fused_step(fixture)
+    if "alpha0" in g.files:
+        assert np.abs(out["alpha0"].cpu().numpy() - g["alpha0"]).max() < 1e-4
     R, St = out["rgb_map"].shape[0], out["alpha"].shape[1]
     assert np.abs(out["rgb_map"].cpu().numpy() - g["rgb_map"]).max() < 5e-4
     assert np.abs(out["rgb0"].cpu().numpy() - g["rgb0"]).max() < 5e-5
@@ -167,7 +181,8 @@ def test_fused_step_matches_reference_autograd(fixture):
             n = key[len("gnorm/"):]
             o, ref = float(np.sqrt((grads[n].astype(np.float64) ** 2).sum())), float(g[key])
             worst = max(worst, abs(o - ref) / (ref + 1e-12))
-            assert abs(o - ref) <= 5e-3 * ref + 1e-9, (n, o, ref)
+            assert abs(o - ref) <= NORM_TOL * ref + 1e-9, (n, o, ref)
+    worst_t = 0.0
     for key in g.files:
         if not key.startswith("grad/"):
             continue
@@ -179,8 +194,10 @@ def test_fused_step_matches_reference_autograd(fixture):
             o = grads[n]
         ref = g[key]
         scale = np.abs(ref).max() + 1e-12
-        assert np.abs(o - ref).max() <= 5e-3 * scale, (n, np.abs(o - ref).max(), scale)
-    print(f"{fixture}: worst gradient-norm deviation {worst:.2e}")
+        worst_t = max(worst_t, float(np.abs(o - ref).max() / scale))
+        assert np.abs(o - ref).max() <= TENSOR_TOL * scale, (n, np.abs(o - ref).max(), scale)
+    print(f"{fixture}: worst gradient-norm deviation {worst:.2e} (bound {NORM_TOL:g}), worst stored-gradient deviation {worst_t:.2e} of "
+          f"the tensor's max (bound {TENSOR_TOL:g})")
 
 
 def test_fused_step_equals_autograd_path_on_every_parameter():
@@ -378,11 +395,14 @@ def test_fused_step_on_degenerate_batches(case):
     assert float((out["rgb_map"] - preds["rgb_map"].detach()).abs().max()) < 1e-4
     assert abs(float(out["loss"][0]) - ref_loss["rgb_loss"]) <= 2e-4 * max(abs(ref_loss["rgb_loss"]), 1e-3)
     worst = 0.0
+    # overlapping volumes: h = sum of MANY p_j * feature_j reaches |h| ~ 10, and the positional encoding's sin(32 h) turns one
+    # ulp of h into 4e-5 -- the two paths' round-off differs by 3e-3 there; dropped pairs would show as tens of percent
+    bound = 1e-2 if case == "overlapping_volumes" else 2e-3
     for n, p in caster.network.named_parameters():
         a, r = p.grad, ref[n]
         scale = float(r.abs().max())
         d = float((a - r).abs().max())
-        assert d <= 2e-3 * scale + 1e-9, (n, d, scale)
+        assert d <= bound * scale + 1e-9, (n, d, scale)
         worst = max(worst, d / (scale + 1e-30))
     print(case, "rows", counts[:6], "worst relative gradient deviation", worst)
 

@@ -50,3 +50,28 @@ def test_oracle_on_mesh_density_grid():
     raw = raw[0] if isinstance(raw, tuple) else raw
     dens = raw[..., 3].reshape(res + 1, res + 1, res + 1).transpose(1, 0, 2)
     assert raw_err(dens, g["density"]) < 1e-4
+
+
+def test_oracle_stochastic_training_branches_on_the_reference_draws():
+    """BASELINE config 4's actual sampling settings (perturb = 1, raw_noise_std = 1): the reference's training-mode render with
+    its own random draws recorded (oracle/gen_golden.py RecordedDraws -> danbo_perfcap_train_noise.npz).  The oracle on the same
+    numbers: stratified depths (ray_utils.py:233-248), density noise (nerf.py:316), random inverse-CDF uniforms (ray_utils.py:171)."""
+    g = golden("danbo_perfcap_train_noise")
+    orc, cfg, sd, rest = oracle_for(g)
+    pose, rb = g["pose_of_ray"], g["ray_batch"]
+    S, Sf = int(g["N_samples"]), int(g["N_importance"])
+    draws = {k: g["draw/" + k] for k in ("t_rand", "u_rand", "noise_c", "noise_f")}
+    assert draws["t_rand"].shape == (len(rb), S) and draws["noise_f"].shape == (len(rb), S + Sf)
+    ret = orc.render(rb, g["skts"][pose], g["bones"][pose], g["cyls"][pose], g["cam_idx"], int(g["n_uniques"]), S, Sf, stages=True,
+                     draws=draws)
+    # stratified depths stay inside their strata and differ from the even ones
+    even = o.coarse_z(ret["near"], ret["far"], S)
+    assert np.all(np.diff(ret["z_coarse"], axis=1) >= 0) and max_err(ret["z_coarse"], even) > 1e-3
+    for k, tol in (("rgb0", 2e-5), ("acc0", 2e-5), ("alpha0", 5e-5), ("rgb_map", 1e-4), ("acc_map", 1e-4)):
+        e = max_err(ret[k], g[k])
+        print(k, e)
+        assert e < tol, (k, e)
+    assert o.psnr(ret["rgb_map"], g["rgb_map"]) > 65.0
+    # without the draws the same call gives visibly different maps: the fixture does exercise the stochastic branches
+    det = orc.render(rb, g["skts"][pose], g["bones"][pose], g["cyls"][pose], g["cam_idx"], int(g["n_uniques"]), S, Sf)
+    assert max_err(det["rgb0"], g["rgb0"]) > 1e-3
