@@ -74,6 +74,10 @@ SIGNATURES = {
     "danbo_assign_blend_bwd": [P, P],
     "danbo_pose_volumes_bwd": [P, I, I, I] + [P] * 24,
     "danbo_adam_step": [P, P, P, P, c_long, F, F, F, F, F, F, F, P],
+    "danbo_trunk_pack": [P, P],
+    "danbo_trunk_fwd": [P, P, I, P],
+    # "danbo_trunk_bwd": [P, P, P],
+    "danbo_trunk_pe_column": [I],
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
@@ -139,6 +143,19 @@ class DanboAssignBwd(ctypes.Structure):
                                     "bits_f", "w0", "adj_w", "adj", "b0", "w1", "b1", "w2", "b2", "g_w0", "g_adj_w", "g_b0", "g_w1",
                                     "g_b1", "g_w2", "g_b2", "g_vol", "g_scale")]
                 + [("c_ss", F), ("loss", P)])
+
+
+class DanboTrunkWeights(ctypes.Structure):
+    _fields_ = ([("pts_w", P * 8), ("pts_b", P * 8)]
+                + [(n, P) for n in ("alpha_w", "alpha_b", "feature_w", "feature_b", "views_w", "views_b", "rgb_w", "rgb_b")]
+                + [("view_ch", I)] + [(n, P) for n in ("packed", "wfv", "b_eff", "wmax", "winv")])
+
+
+class DanboTrunkRows(ctypes.Structure):
+    _fields_ = ([(n, P) for n in ("cnt", "row_sample", "h_rows", "cview")] + [(n, I) for n in ("R", "S", "Sf", "rows_cap")]
+                + [("rows_pad", c_long)]
+                + [(n, P) for n in ("y", "pe", "relu", "hv", "hv_bits", "raw_rows", "raw_c", "raw_f", "raw_empty", "row_ray",
+                                    "d_raw_c", "d_raw_f", "d_raw_rows", "dz", "dpre_v", "d_alpha4", "d_h", "maxabs")])
 
 
 class DanboTrainModel(ctypes.Structure):

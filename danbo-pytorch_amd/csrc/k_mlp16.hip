@@ -20,20 +20,10 @@
 // One workgroup = 8 wavefronts x 16 samples = 128 rows, TWO wavefronts per SIMD (<= 256 VGPRs
 // each): while one wavefront waits on the weight ring, LDS or its epilogue VALU work, the other
 // keeps the matrix pipe busy (a one-wavefront-per-SIMD version spent half its time stalled).
-#include "common.hpp"
+#include "mlp16_core.hpp"
 
 namespace danbo {
 
-#ifndef DANBO_M16_BT
-#define DANBO_M16_BT 2   // output tiles per batch of A-fragment reads (2 / 4 / 8 measured within 2 %)
-#endif
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int M16_BM = 128;            // rows per workgroup iteration
-constexpr int CHUNK_BYTES = 32768;     // 32 fragment pieces of 1 KB
-constexpr int RING_SLOTS = 4;
 constexpr int NCH_X0 = 7;              // 7 k-steps of 32 PE features (208 >= 195)
 constexpr int NCH_ACT = 8;             // 8 k-steps of 32 features
 constexpr int NCH_VIEW = 4;            // 8 k-steps, 8 output tiles -> 2 k-steps per chunk
@@ -108,6 +98,129 @@ __global__ __launch_bounds__(256) void k_mlp16_pack(Pack16Args a, _Float16* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight packing for the fused trunk of the TRAINING step (danbo_trunk_pack), once per optimizer step, two launches:
+//   k_trunk_prep  W_fv = W_v[:, :256] W_f (fp64 dot products), b_eff = b_v + W_v[:, :256] b_f, max |w| of the nine matrices
+//   k_trunk_pack  74 forward chunks in K3's order + 76 chunks of the input-gradient chain (k_mlp16_bwd.hip: the same matrices
+//                 transposed), every matrix times the power of two that puts its largest entry into [2^13, 2^14)
+// Backward chunk order: W_fv^T (4) | W_7^T (8) | W_6^T (8) | W_5[:, :195]^T (8, PE-ordered output rows, 13 tiles) |
+// W_5[:, 195:]^T (8) | W_4^T .. W_1^T (8 each) | W_0^T (8, PE-ordered output rows).
+// PE-ordered rows: output tile T, row 4 q + i of the tile = d pe_j of lane group q's channel kk = q + 4 c, j = 4 T + i = 13 c + t
+// -- the slot order in which the forward's lanes hold the encoding (pe_kstep), so the adjoint of the encoding is lane-local.
+// ---------------------------------------------------------------------------------------------
+constexpr int NCH_BWD = 4 + 2 * NCH_ACT + 2 * NCH_ACT + 4 * NCH_ACT + NCH_ACT;   // 76
+static_assert(NCH_TOTAL == DANBO_TRUNK_FWD_CHUNKS && NCH_BWD == DANBO_TRUNK_BWD_CHUNKS, "header constants out of date");
+
+struct TrunkPackArgs {
+    const float* pts_w[8];
+    const float *feature_w, *feature_b, *views_w, *views_b;
+    int Cv;
+    float *wfv, *b_eff, *wmax, *winv;
+    _Float16* packed;
+};
+
+__global__ __launch_bounds__(256) void k_trunk_prep(TrunkPackArgs a) {
+    __shared__ float s_m[4];
+    const int m = blockIdx.y;           // matrix: 0..7 pts_linears, 8: W_fv
+    float mx = 0.f;
+    if (m < 8) {
+        const long n = (long)W_ * (m == 0 ? IN_CH : (m == 5 ? IN_CH + W_ : W_));
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) mx = fmaxf(mx, fabsf(a.pts_w[m][i]));
+    } else {
+        const int ld = W_ + a.Cv;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < VW_ * W_ + VW_; i += gridDim.x * blockDim.x) {
+            if (i < VW_ * W_) {
+                const int n = i / W_, f = i % W_;
+                double acc = 0.0;
+                for (int c = 0; c < W_; ++c) acc += (double)a.views_w[(size_t)n * ld + c] * (double)a.feature_w[(size_t)c * W_ + f];
+                a.wfv[i] = (float)acc;
+                mx = fmaxf(mx, fabsf((float)acc));
+            } else {
+                const int n = i - VW_ * W_;
+                double acc = 0.0;
+                for (int c = 0; c < W_; ++c) acc += (double)a.views_w[(size_t)n * ld + c] * (double)a.feature_b[c];
+                a.b_eff[n] = (float)((double)a.views_b[n] + acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.wmax + m), __builtin_bit_cast(unsigned, mx));
+    }
+}
+
+// element [n][k] of matrix m (0..7: pts_linears.m.weight [256, K_m]; 8: W_fv [128, 256])
+__device__ __forceinline__ float trunk_w(const TrunkPackArgs& a, int m, int n, int k) {
+    if (m == 8) return a.wfv[n * W_ + k];
+    const int K = m == 0 ? IN_CH : (m == 5 ? IN_CH + W_ : W_);
+    return a.pts_w[m][(size_t)n * K + k];
+}
+
+__global__ __launch_bounds__(256) void k_trunk_pack(TrunkPackArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x < 9) {
+        float s, inv;
+        weight_pow2_scale(a.wmax[threadIdx.x], s, inv);
+        a.winv[threadIdx.x] = inv;
+    }
+    const long total = (long)(NCH_TOTAL + NCH_BWD) * (CHUNK_BYTES / 2);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int chunk = (int)(idx / (CHUNK_BYTES / 2));
+        const int within = (int)(idx % (CHUNK_BYTES / 2));
+        const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
+        const int q = lane >> 4, ma = lane & 15;
+        int mat;
+        float w = 0.f;
+        if (chunk < NCH_TOTAL) {            // ---------------- forward: k_mlp16_pack's order
+            int layer, cl, kind;            // kind 0: x0 part, 1: act part, 2: view layer
+            if (chunk < 7) { layer = 0; cl = chunk; kind = 0; }
+            else if (chunk < 39) { layer = 1 + (chunk - 7) / 8; cl = (chunk - 7) % 8; kind = 1; }
+            else if (chunk < 46) { layer = 5; cl = chunk - 39; kind = 0; }
+            else if (chunk < 54) { layer = 5; cl = chunk - 46; kind = 1; }
+            else if (chunk < 70) { layer = 6 + (chunk - 54) / 8; cl = (chunk - 54) % 8; kind = 1; }
+            else { layer = 8; cl = chunk - 70; kind = 2; }
+            int s, T;
+            if (kind == 2) { s = 2 * cl + (piece >> 4); T = (piece >> 1) & 7; }
+            else { s = cl; T = piece >> 1; }
+            const int n = 16 * T + ma;
+            mat = layer;
+            if (kind == 0) {
+                const int j = 8 * s + e;
+                const int c = j / 13, t = j % 13, kk = q + 4 * c;
+                if (j < 52 && kk < FEAT) w = trunk_w(a, layer, n, FEAT * t + kk);
+            } else {
+                const int f = 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3);
+                w = trunk_w(a, layer, n, layer == 5 ? IN_CH + f : f);
+            }
+        } else {                            // ---------------- backward: transposed
+            chunk -= NCH_TOTAL;
+            int s, kind;                    // kind 0: plain output rows, 1: PE-ordered output rows
+            int koff = 0;                   // first input column of the forward matrix this GEMM's output rows index
+            if (chunk < 4) { mat = 8; s = chunk; kind = 0; }
+            else if (chunk < 20) { mat = 7 - (chunk - 4) / 8; s = (chunk - 4) % 8; kind = 0; }
+            else if (chunk < 28) { mat = 5; s = chunk - 20; kind = 1; }
+            else if (chunk < 36) { mat = 5; s = chunk - 28; kind = 0; koff = IN_CH; }
+            else if (chunk < 68) { mat = 4 - (chunk - 36) / 8; s = (chunk - 36) % 8; kind = 0; }
+            else { mat = 0; s = chunk - 68; kind = 1; }
+            const int T = piece >> 1;
+            const int f = 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3);      // the GEMM's input feature = the forward layer's output
+            if (kind == 0) w = trunk_w(a, mat, f, koff + 16 * T + ma);
+            else if (T < 13) {
+                const int j = 4 * T + (ma & 3), c = j / 13, t = j % 13, kk = (ma >> 2) + 4 * c;
+                if (kk < FEAT) w = trunk_w(a, mat, f, FEAT * t + kk);
+            }
+        }
+        float sc, inv;
+        weight_pow2_scale(a.wmax[mat], sc, inv);
+        w *= sc;
+        const _Float16 hi = (_Float16)w;
+        a.packed[idx] = (piece & 1) ? (_Float16)(w - (float)hi) : hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // the fused MLP
 // ---------------------------------------------------------------------------------------------
 struct Mlp16Args {
@@ -127,16 +240,8 @@ struct Mlp16Args {
     float* aux_out;
 };
 
-constexpr int M16_THREADS = 512;
 constexpr int M16_TABLE_FLOATS = 8 * W_ + W_ + 3 * VW_ + 4;
 constexpr int M16_LDS_BYTES = RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4 + 8 * (1024 + 256);  // + staging, see TileSrc
-
-struct Pipe {
-    const char* packed;
-    char* ring;
-    int issue_chunk, issue_slot, cons_slot, wave, lane;
-    bool early;
-};
 
 // Tile-boundary prefetch, so that no wavefront waits on HBM between two row tiles:
 //   * the NEXT tile's rows (blended features h and list entries) are fetched by two LDS-DMA loads per wavefront
@@ -167,6 +272,11 @@ __device__ __forceinline__ void prefetch_rows(const TileSrc& t, int lane) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_l,
                                      (__attribute__((address_space(3))) void*)(t.stage + STAGE_H_BYTES), 4, 0, 0);
 }
+struct StageRows {      // pipe_handover's `extra`: the two staging loads of the next tile
+    const TileSrc& t;
+    int lane;
+    __device__ __forceinline__ void operator()() const { prefetch_rows(t, lane); }
+};
 // one base address + instruction offsets: no per-load address registers.  Four column tiles per call.
 template <int HALF>
 __device__ __forceinline__ void prefetch_cv(const float* base, f32x4 (&cv)[8]) {
@@ -175,114 +285,63 @@ __device__ __forceinline__ void prefetch_cv(const float* base, f32x4 (&cv)[8]) {
 #undef DANBO_CV_LOAD
 }
 
-// every wavefront loads 4 of the 32 pieces of a chunk
-__device__ __forceinline__ void pipe_issue(Pipe& p) {
-    const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 4096 + p.lane * 16;
-    char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 4096;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-    p.issue_chunk = p.issue_chunk + 1 == NCH_TOTAL ? 0 : p.issue_chunk + 1;
-    p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
-}
-
-// Ring hand-over #c, executed once per chunk c by every wavefront -- by the "early" wavefronts (0-3) in the
-// middle of chunk c, by the "late" ones (4-7, their SIMD partners) before they start it, so the two
-// wavefronts of a SIMD run half a chunk apart and one's VALU epilogue work and LDS latencies fall under
-// the other's MFMAs instead of both stalling at the same program point:
-//   wait: my share of chunk c+1 has landed (<= 4 younger loads = chunk c+2 outstanding);
-//   barrier: everybody's has, and everybody is past chunk c-1;  then refill that slot with chunk c+3.
-// WAIT / extra (view layer only): `extra()` issues additional loads between the barrier and the ring refill, so
-// they are OLDER than that refill and YOUNGER than the chunk the next hand-over waits for; that next hand-over
-// therefore allows WAIT = 4 + (number of extra loads) operations to stay in flight.
-struct NoExtra {
-    __device__ __forceinline__ void operator()() const {}
+// ---------------------------------------------------------------------------------------------
+// TRAIN instantiation (k_train_mlp_fwd): the same chain over the rows of one pass of a training step, with
+//   * every matrix packed times a power of two (danbo_trunk_pack; the epilogue multiplies by the exact inverse `winv`),
+//   * everything the backward pass and the weight-gradient kernel need written on the way, each value ONCE and in the order
+//     the lanes hold it (fragment order: one contiguous KB per store instruction of a wavefront):
+//       y_l   [rows, 256] l = 0..7  post-ReLU activations          (x operand of dW_{l+1}, of dW_fv / d alpha_w)
+//       relu_l 64 bits per (row, lane group): [y_l > 0]            (mask of the input-gradient chain)
+//       pe    [rows, 224] the 7 x 32 positional-encoding k-slots    (x operand of dW_0 and of the skip layer's dW)
+//       hv    [rows, 128] post-ReLU view layer + its 32 sign bits   (x operand of d rgb_w; mask of d pre_v)
+//       raw_rows [rows, 4] and the scatter into the dense raw of the pass / the ray's empty-space raw; row_ray [rows]
+//   * rows = [0, R + n_c) in pass 0 and [tile boundary at or below R + n_c, R + n_c + n_f) in pass 1 (the rows of the first
+//     tile that belong to pass 0 are recomputed, bit for bit: the fragment-order buffers are written in whole row groups).
+// ---------------------------------------------------------------------------------------------
+struct TrainFwd {
+    int32_t* cnt;               // device counters of the step (k_train_rows.hip): read [0], [1]; block 0 derives the others
+    const int32_t* row_sample;  // [rows]: sample index of row i >= R inside its pass
+    int pass, R, S_c, S_f;
+    const float* winv;          // [9]: exact inverses of the pack scales of pts_linears.0..7 and W_fv
+    float* y; long y_stride;    // y_l = y + l * y_stride (floats)
+    float* pe;
+    unsigned long long* relu; long relu_stride;
+    float* hv;
+    unsigned* hv_bits;
+    float *raw_rows, *raw_c, *raw_f, *raw_empty;
+    int32_t* row_ray;
 };
-template <int WAIT, class Extra>
-__device__ __forceinline__ void pipe_handover(Pipe& p, const Extra& extra) {
-    static_assert(WAIT == 4 || WAIT == 6 || WAIT == 8, "add the s_waitcnt immediate");
-    if (WAIT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    extra();
-    pipe_issue(p);
-}
 
-__device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
-    return *reinterpret_cast<const half8*>(base + piece * 1024);
-}
-
-// hi*hi + hi*lo + lo*hi into acc; FIRST: the accumulator starts from zero (no separate clear)
-template <bool FIRST>
-__device__ __forceinline__ void mfma3(f32x4& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-}
-
-// One 32 KB chunk = 16 (tile, hi/lo) fragment pairs.  DENSE layers: one k-step, output tiles 0..15, B = (b0h, b0l).
-// VIEW layer: two k-steps of 8 output tiles, B = b0 for pairs 0..7 and b1 for pairs 8..15.
-template <int NACC, bool VIEW, bool FIRST, int WAIT = 4, class Extra = NoExtra>
-__device__ __forceinline__ void chunk_mfma(f32x4 (&acc)[NACC], Pipe& p, const half8& b0h, const half8& b0l,
-                                           const half8& b1h, const half8& b1l, const Extra& extra = Extra()) {
-    if (!p.early) pipe_handover<WAIT>(p, extra);
-    const char* base = p.ring + p.cons_slot * CHUNK_BYTES + p.lane * 16;
-    p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
-    // batches of BT tiles: 2 BT ds_read_b128, then their 3 BT MFMAs.  (Reading a batch ahead buys nothing with
-    // compiler-tracked LDS loads -- the compiler waits with lgkmcnt(0), i.e. for the look-ahead batch too; the other
-    // wavefront of the SIMD covers the read latency.)
-    constexpr int BT = DANBO_M16_BT;
-#pragma unroll
-    for (int b = 0; b < 16 / BT; ++b) {
-        half8 ah[BT], al[BT];
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            ah[t] = lds_frag(base, 2 * (BT * b + t));
-            al[t] = lds_frag(base, 2 * (BT * b + t) + 1);
-        }
-        if (BT * b == 8 && p.early) pipe_handover<WAIT>(p, extra);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            const int T = BT * b + t;
-            if (VIEW && T >= 8) mfma3<false>(acc[T - 8], ah[t], al[t], b1h, b1l);
-            else mfma3<FIRST>(acc[T], ah[t], al[t], b0h, b0l);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)v[e];
-        hi[e] = hh;
-        lo[e] = (_Float16)(v[e] - (float)hh);
-    }
-}
-
-// sum of the four lane-group partials of a sample; identical in all four groups
-__device__ __forceinline__ float quad_sum(float p) {
-    p += lane_xor16(p);
-    p += lane_xor32(p);
-    return p;
+// lane * 16, re-derived where it is used (two VALU operations) instead of living in a register across the layer loop
+__device__ __forceinline__ unsigned lane_off16() {
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) << 4;
 }
 
 // B fragments of k-step s of the next GEMM from the previous layer's accumulators: tiles 2s and 2s+1,
 // bias + ReLU, hi/lo split.  ALPHA: also accumulate this lane's part of the density logit.
-template <bool ALPHA>
+// TRAIN: acc * winv first; the eight activations are stored (ybase: wave-uniform address of this k-step's 2 KB)
+// and their signs as byte S of the lane's 8 bytes at rbase (bit e of byte S <-> bit 8 S + e of the 64-bit word the
+// input-gradient chain loads: column 16 (2 S + e / 4) + 4 q + e % 4).
+template <bool ALPHA, bool TRAIN = false, int S = 0>
 __device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, const float* bias /* + 4qq + 32s */,
-                                             const float* aw, float& alpha_part, half8& bh, half8& bl) {
+                                             const float* aw, float& alpha_part, half8& bh, half8& bl, float winv = 1.f,
+                                             const float* ybase = nullptr, const void* rbase = nullptr) {
     float v[8];
     const float4 b0 = *reinterpret_cast<const float4*>(bias);
     const float4 b1 = *reinterpret_cast<const float4*>(bias + 16);
-    v[0] = fmaxf(a0[0] + b0.x, 0.f); v[1] = fmaxf(a0[1] + b0.y, 0.f);
-    v[2] = fmaxf(a0[2] + b0.z, 0.f); v[3] = fmaxf(a0[3] + b0.w, 0.f);
-    v[4] = fmaxf(a1[0] + b1.x, 0.f); v[5] = fmaxf(a1[1] + b1.y, 0.f);
-    v[6] = fmaxf(a1[2] + b1.z, 0.f); v[7] = fmaxf(a1[3] + b1.w, 0.f);
+    if (TRAIN) {
+        v[0] = fmaxf(fmaf(a0[0], winv, b0.x), 0.f); v[1] = fmaxf(fmaf(a0[1], winv, b0.y), 0.f);
+        v[2] = fmaxf(fmaf(a0[2], winv, b0.z), 0.f); v[3] = fmaxf(fmaf(a0[3], winv, b0.w), 0.f);
+        v[4] = fmaxf(fmaf(a1[0], winv, b1.x), 0.f); v[5] = fmaxf(fmaf(a1[1], winv, b1.y), 0.f);
+        v[6] = fmaxf(fmaf(a1[2], winv, b1.z), 0.f); v[7] = fmaxf(fmaf(a1[3], winv, b1.w), 0.f);
+    } else {
+        v[0] = fmaxf(a0[0] + b0.x, 0.f); v[1] = fmaxf(a0[1] + b0.y, 0.f);
+        v[2] = fmaxf(a0[2] + b0.z, 0.f); v[3] = fmaxf(a0[3] + b0.w, 0.f);
+        v[4] = fmaxf(a1[0] + b1.x, 0.f); v[5] = fmaxf(a1[1] + b1.y, 0.f);
+        v[6] = fmaxf(a1[2] + b1.z, 0.f); v[7] = fmaxf(a1[3] + b1.w, 0.f);
+    }
     if (ALPHA) {
         const float4 w0 = *reinterpret_cast<const float4*>(aw);
         const float4 w1 = *reinterpret_cast<const float4*>(aw + 16);
@@ -290,6 +349,16 @@ __device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, c
         alpha_part = fmaf(v[2], w0.z, alpha_part); alpha_part = fmaf(v[3], w0.w, alpha_part);
         alpha_part = fmaf(v[4], w1.x, alpha_part); alpha_part = fmaf(v[5], w1.y, alpha_part);
         alpha_part = fmaf(v[6], w1.z, alpha_part); alpha_part = fmaf(v[7], w1.w, alpha_part);
+    }
+    if (TRAIN) {
+        const unsigned l16 = lane_off16();
+        store16_s<0>(ybase, l16, f32x4{v[0], v[1], v[2], v[3]});
+        store16_s<1024>(ybase, l16, f32x4{v[4], v[5], v[6], v[7]});
+        // v >= 0: its bit pattern is non-zero exactly where the activation is positive
+        unsigned w = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w |= min(__builtin_bit_cast(unsigned, v[e]), 1u) << e;
+        asm volatile("global_store_byte %0, %1, %2 offset:%3" ::"v"(l16 >> 1), "v"(w), "s"(rbase), "i"(S) : "memory");
     }
     split8(v, bh, bl);
 }
@@ -316,7 +385,8 @@ __device__ __forceinline__ void pe_kstep(const float (&hv)[4], float& cs_keep, f
     }
 }
 
-__global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
+template <bool TRAIN>
+__device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& tr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);  // [8][256]
     float* s_aw = s_bias + 8 * W_;                                              // [256]
@@ -330,44 +400,73 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     for (int i = tid; i < 3 * VW_; i += M16_THREADS) s_rgbw[i] = a.rgb_w[i];
     if (tid < 4) s_misc[tid] = tid == 0 ? a.alpha_b[0] : a.rgb_b[tid - 1];
 
-    const int n = resolve_count(a.count, a.n_cap);
+    int n, tile0 = 0, first_f = 0;
+    if (TRAIN) {
+        // rows of this pass from the step's counters: cnt[0] = running number of in-volume samples (n_c after the coarse cull,
+        // n_c + n_f after the second), cnt[1] = n_c (written by pass 0's block 0 below: pass 0 itself takes it from cnt[0])
+        const int n_run = tr.cnt[0];
+        const int n_c = tr.pass == 0 ? n_run : tr.cnt[1];
+        first_f = tr.R + n_c;
+        n = min(tr.R + n_run, a.n_cap);
+        if (tr.pass != 0) tile0 = first_f / M16_BM;
+        if (blockIdx.x == 0 && tid == 0) {
+            if (tr.pass == 0) { tr.cnt[1] = n_run; tr.cnt[2] = tr.R + n_run; }
+            else {
+                tr.cnt[3] = n_run - n_c; tr.cnt[4] = tr.R + n_run; tr.cnt[5] = n_run;
+                tr.cnt[6] = first_f & ~127; tr.cnt[7] = n_run - n_c + (first_f & 127);
+            }
+        }
+    } else n = resolve_count(a.count, a.n_cap);
     const int ntiles = (n + M16_BM - 1) / M16_BM;
-    if ((int)blockIdx.x >= ntiles) return;
+    if (tile0 + (int)blockIdx.x >= ntiles) return;
 
     Pipe p;
     p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave; p.lane = lane;
     p.early = wave < 4;  // wavefronts w and w+4 of a workgroup share a SIMD
-    pipe_issue(p);
-    pipe_issue(p);
-    pipe_issue(p);
+    pipe_issue<NCH_TOTAL>(p);
+    pipe_issue<NCH_TOTAL>(p);
+    pipe_issue<NCH_TOTAL>(p);
     // first tile of this workgroup: the same two staging loads (later tiles: issued during the previous view layer)
     TileSrc src;
-    src.h = a.h; src.list = a.list; src.dummy = a.packed; src.n = n;
+    src.h = a.h; src.list = TRAIN ? tr.row_sample : a.list; src.dummy = a.packed; src.n = n;
     src.stage = smem + RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4 + wave * STAGE_BYTES;
-    src.next_row0 = blockIdx.x * M16_BM + wave * 16;
+    src.next_row0 = (tile0 + blockIdx.x) * M16_BM + wave * 16;
     prefetch_rows(src, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ring chunks 0-2 and the first rows (tables: the same barrier)
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = tile0 + blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ------------------------------------------------------------------ inputs (staged during the previous tile)
         const int row = tile * M16_BM + wave * 16 + m;
         const bool row_ok = row < n;
         const float* sh = reinterpret_cast<const float*>(src.stage) + m * DANBO_H_STRIDE + qq;
         const int staged_dst = reinterpret_cast<const int*>(src.stage + STAGE_H_BYTES)[m];
-        int dst = row_ok ? (a.list ? staged_dst : row) : -1;
-        asm volatile("" : "+v"(dst));  // materialised now: the staging area is overwritten during this tile's view layer
-        const int ray = dst >= 0 ? dst / a.S : 0;
+        int dst, ray;
+        bool has_h = row_ok;
+        if (TRAIN) {
+            // rows [0, R): the ray's empty-space row (h = 0); [R, first_f): coarse samples; [first_f, n): importance samples
+            const bool empty = row < tr.R;
+            dst = row_ok ? (empty ? row : staged_dst) : -1;
+            ray = 0;           // derived from dst behind the layer loop
+            has_h = row_ok && !empty;
+            asm volatile("" : "+v"(dst));
+        } else {
+            dst = row_ok ? (a.list ? staged_dst : row) : -1;
+            asm volatile("" : "+v"(dst));  // materialised now: the staging area is overwritten during this tile's view layer
+            ray = dst >= 0 ? dst / a.S : 0;
+        }
         // this lane's 4 channels: kk = qq + 4c  (kk = 15 is padding)
         float hv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) hv[c] = row_ok ? sh[4 * c] : 0.f;
+        for (int c = 0; c < 4; ++c) hv[c] = has_h ? sh[4 * c] : 0.f;
         if (qq == 3) hv[3] = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(hv[c]));
         float alpha_part = 0.f;
         f32x4 prev[16];  // pre-bias outputs of the previous layer
         src.next_row0 = (tile + (int)gridDim.x) * M16_BM + wave * 16;
+        // TRAIN: wave-uniform base addresses of this wavefront's row group (16 rows) in the fragment-order buffers
+        const long grp = (long)tile * 8 + wave;
         // steps 0..7: the density trunk; step 8: the merged feature + view layer (128 outputs, tiles 0..7 of acc)
 #pragma unroll 1
         for (int step = 0; step < 9; ++step) {
@@ -378,15 +477,24 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
                 // `#pragma unroll` loop over the 56 values exceeds the unroll budget and turns into a runtime loop
                 // with dynamically indexed registers.
                 float cs_keep = 0.f;
+                const float* peg = TRAIN ? tr.pe + grp * (16 * 224) : nullptr;
 #define DANBO_X0_STEP(KS, FIRST_)                                                  \
                 {                                                                  \
                     float v8[8], hk[4] = {hv[0], hv[1], hv[2], hv[3]};             \
                     /* re-defined after the previous chunk: the sincos of later k-steps must not be hoisted (and spilled) */ \
                     asm volatile("" : "+v"(hk[0]), "+v"(hk[1]), "+v"(hk[2]), "+v"(hk[3]));                            \
                     pe_kstep<KS>(hk, cs_keep, v8);                                 \
+                    if (TRAIN && step == 0) {                                      \
+                        const unsigned l16 = lane_off16();                         \
+                        store16_s<0>(peg + (KS) * 512, l16, f32x4{v8[0], v8[1], v8[2], v8[3]});      \
+                        store16_s<1024>(peg + (KS) * 512, l16, f32x4{v8[4], v8[5], v8[6], v8[7]});   \
+                    }                                                              \
                     half8 xh, xl;                                                  \
                     split8(v8, xh, xl);                                            \
-                    chunk_mfma<16, false, FIRST_>(acc, p, xh, xl, xh, xl);         \
+                    /* TRAIN: layer 0 stores 2 per chunk (the wait may leave this chunk's and the previous one's in flight); the \
+                       skip layer's pass over the same code stores nothing */     \
+                    chunk_mfma<NCH_TOTAL, 16, false, FIRST_, TRAIN ? ((KS) == 0 ? 6 : 8) : 4, NoExtra, 4>(acc, p, xh, xl, xh, xl, NoExtra(), \
+                                                                                                         step != 0);     \
                 }
                 DANBO_X0_STEP(0, true)
                 DANBO_X0_STEP(1, false)
@@ -402,42 +510,61 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
             int zero = 0;
             asm volatile("" : "+s"(zero));  // keeps the two mbcnt ops inside the loop (no hoist + spill)
             const int q4 = (int)((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) >> 4) & 3) * 4;
+            // TRAIN: prev holds layer step-1's accumulators: its pack scale, its activation buffer
+            float winv = 1.f;
+            const float* yg = nullptr;
+            const unsigned long long* rg = nullptr;
+            if (TRAIN && step != 0) {
+                winv = tr.winv[step - 1];
+                yg = tr.y + (long)(step - 1) * tr.y_stride + grp * 4096;
+                rg = tr.relu + (long)(step - 1) * tr.relu_stride + grp * 64;
+            }
             if (step != 0 && step != 8) {
                 const float* bias = s_bias + (step - 1) * W_ + q4;
                 {
                     half8 bh, bl;
-                    act_fragment<false>(prev[0], prev[1], bias, nullptr, alpha_part, bh, bl);
-                    if (step == 5) chunk_mfma<16, false, false>(acc, p, bh, bl, bh, bl);
-                    else chunk_mfma<16, false, true>(acc, p, bh, bl, bh, bl);
+                    act_fragment<false, TRAIN, 0>(prev[0], prev[1], bias, nullptr, alpha_part, bh, bl, winv, yg, rg);
+                    // TRAIN: 3 stores here (two halves of a k-step + its sign byte) and >= 2 in the previous chunk -- except behind the
+                    // skip layer's PE chunks, which store nothing
+                    if (step == 5) chunk_mfma<NCH_TOTAL, 16, false, false, TRAIN ? 7 : 4>(acc, p, bh, bl, bh, bl);
+                    else chunk_mfma<NCH_TOTAL, 16, false, true, TRAIN ? 9 : 4>(acc, p, bh, bl, bh, bl);
                 }
-#pragma unroll
-                for (int s = 1; s < NCH_ACT; ++s) {
-                    half8 bh, bl;
-                    int off_s = 32 * s;
-                    asm volatile("" : "+v"(off_s));   // no hoisting of all eight bias loads (the offset, not the pointer:
-                    const float* bias_s = bias + off_s;  // the pointer must stay an LDS pointer)
-                    act_fragment<false>(prev[2 * s], prev[2 * s + 1], bias_s, nullptr, alpha_part, bh, bl);
-                    chunk_mfma<16, false, false>(acc, p, bh, bl, bh, bl);
+#define DANBO_ACT_STEP(s)                                                                                               \
+                {                                                                                                       \
+                    half8 bh, bl;                                                                                       \
+                    int off_s = 32 * (s);                                                                               \
+                    asm volatile("" : "+v"(off_s));   /* no hoisting of all eight bias loads (the offset, not the pointer: */ \
+                    const float* bias_s = bias + off_s;  /* the pointer must stay an LDS pointer) */                     \
+                    act_fragment<false, TRAIN, (s)>(prev[2 * (s)], prev[2 * (s) + 1], bias_s, nullptr, alpha_part, bh, bl, winv,       \
+                                                        yg + (s) * 512, rg);                                            \
+                    chunk_mfma<NCH_TOTAL, 16, false, false, TRAIN ? 10 : 4>(acc, p, bh, bl, bh, bl);                    \
                 }
+                DANBO_ACT_STEP(1) DANBO_ACT_STEP(2) DANBO_ACT_STEP(3) DANBO_ACT_STEP(4) DANBO_ACT_STEP(5) DANBO_ACT_STEP(6) DANBO_ACT_STEP(7)
+#undef DANBO_ACT_STEP
             }
             if (step == 8) {
                 // view layer; while it runs: stage the next tile's rows (chunk 0)
                 const float* bias = s_bias + 7 * W_ + q4;
                 const float* aw = s_aw + q4;
                 f32x4 (&accv)[8] = *reinterpret_cast<f32x4 (*)[8]>(&acc[0]);
-#pragma unroll
-                for (int c = 0; c < NCH_VIEW; ++c) {
-                    half8 b0h, b0l, b1h, b1l;
-                    int off_c = 64 * c;
-                    asm volatile("" : "+v"(off_c));
-                    const float* bias_c = bias + off_c;
-                    const float* aw_c = aw + off_c;
-                    act_fragment<true>(prev[4 * c], prev[4 * c + 1], bias_c, aw_c, alpha_part, b0h, b0l);
-                    act_fragment<true>(prev[4 * c + 2], prev[4 * c + 3], bias_c + 32, aw_c + 32, alpha_part, b1h, b1l);
-                    if (c == 0) chunk_mfma<8, true, true, 4>(accv, p, b0h, b0l, b1h, b1l, [&]() { prefetch_rows(src, lane); });
-                    else if (c == 1) chunk_mfma<8, true, false, 6>(accv, p, b0h, b0l, b1h, b1l);
-                    else chunk_mfma<8, true, false, 4>(accv, p, b0h, b0l, b1h, b1l);
+#define DANBO_VIEW_STEP(c)                                                                                              \
+                {                                                                                                       \
+                    half8 b0h, b0l, b1h, b1l;                                                                           \
+                    int off_c = 64 * (c);                                                                               \
+                    asm volatile("" : "+v"(off_c));                                                                     \
+                    const float* bias_c = bias + off_c;                                                                 \
+                    const float* aw_c = aw + off_c;                                                                     \
+                    act_fragment<true, TRAIN, 2 * (c)>(prev[4 * (c)], prev[4 * (c) + 1], bias_c, aw_c, alpha_part, b0h, b0l, winv,     \
+                                                        yg + (2 * (c)) * 512, rg);                                      \
+                    act_fragment<true, TRAIN, 2 * (c) + 1>(prev[4 * (c) + 2], prev[4 * (c) + 3], bias_c + 32, aw_c + 32, alpha_part,   \
+                                                            b1h, b1l, winv, yg + (2 * (c) + 1) * 512, rg);              \
+                    /* TRAIN: 6 stores per chunk here; chunk 0 follows layer 7's last chunk (3 stores) */               \
+                    if ((c) == 0) chunk_mfma<NCH_TOTAL, 8, true, true, TRAIN ? 13 : 4, StageRows>(accv, p, b0h, b0l, b1h, b1l, StageRows{src, lane});  \
+                    else if ((c) == 1) chunk_mfma<NCH_TOTAL, 8, true, false, TRAIN ? 18 : 6>(accv, p, b0h, b0l, b1h, b1l);   \
+                    else chunk_mfma<NCH_TOTAL, 8, true, false, TRAIN ? 16 : 4>(accv, p, b0h, b0l, b1h, b1l);            \
                 }
+                DANBO_VIEW_STEP(0) DANBO_VIEW_STEP(1) DANBO_VIEW_STEP(2) DANBO_VIEW_STEP(3)
+#undef DANBO_VIEW_STEP
 #pragma unroll
                 for (int T = 8; T < 16; ++T) acc[T] = acc[T - 8];  // defined values for the copy below (never read)
             }
@@ -445,6 +572,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
             for (int T = 0; T < 16; ++T) prev[T] = acc[T];
         }
         f32x4 (&accv)[8] = *reinterpret_cast<f32x4 (*)[8]>(&prev[0]);
+        if (TRAIN) ray = dst < 0 ? 0 : (row < tr.R ? dst : dst / (row < first_f ? tr.S_c : tr.S_f));
         // this tile's per-ray view constants: eight untracked loads and ONE wait (a compiler-tracked load per column tile
         // would each wait with vmcnt(0)); the trunk's registers are free here
         f32x4 cvq[8];
@@ -459,15 +587,25 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
         // ------------------------------------------------------------------ colour head + output
         float pr = 0.f, pg = 0.f, pb = 0.f;
         float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (VW_ + 1) + 4 * qq : nullptr;
+        const float winv_v = TRAIN ? tr.winv[8] : 1.f;
+        const float* hvg = TRAIN ? tr.hv + grp * 2048 : nullptr;
+        unsigned hvb = 0u;
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             const int nn = 16 * T;  // + 4*qq + i
             f32x4 c4 = cvq[T];
             if (!a.cview) c4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float pre[4] = {accv[T][0], accv[T][1], accv[T][2], accv[T][3]};
+            const float pre[4] = {TRAIN ? accv[T][0] * winv_v : accv[T][0], TRAIN ? accv[T][1] * winv_v : accv[T][1],
+                                  TRAIN ? accv[T][2] * winv_v : accv[T][2], TRAIN ? accv[T][3] * winv_v : accv[T][3]};
             if (aux) *reinterpret_cast<float4*>(aux + nn) = make_float4(pre[0], pre[1], pre[2], pre[3]);
             const float x[4] = {fmaxf(pre[0] + c4[0], 0.f), fmaxf(pre[1] + c4[1], 0.f), fmaxf(pre[2] + c4[2], 0.f),
                                 fmaxf(pre[3] + c4[3], 0.f)};
+            if (TRAIN) {
+                if (T < 4) store16_s<0>(hvg + T * 256, (unsigned)lane * 16u, f32x4{x[0], x[1], x[2], x[3]});
+                else store16_s<0>(hvg + 1024 + (T - 4) * 256, (unsigned)lane * 16u, f32x4{x[0], x[1], x[2], x[3]});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hvb |= min(__builtin_bit_cast(unsigned, x[i]), 1u) << (4 * T + i);
+            }
             const float4 wr = *reinterpret_cast<const float4*>(s_rgbw + 0 * VW_ + nn + 4 * qq);
             const float4 wg = *reinterpret_cast<const float4*>(s_rgbw + 1 * VW_ + nn + 4 * qq);
             const float4 wb = *reinterpret_cast<const float4*>(s_rgbw + 2 * VW_ + nn + 4 * qq);
@@ -480,7 +618,17 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
         const float g_ = quad_sum(pg) + s_misc[2];
         const float b_ = quad_sum(pb) + s_misc[3];
         const float al = quad_sum(alpha_part) + s_misc[0];
-        if (qq == 0 && dst >= 0) {
+        if (TRAIN) {
+            tr.hv_bits[grp * 64 + lane] = hvb;
+            if (qq == 0 && dst >= 0) {
+                const float4 r4 = make_float4(r_, g_, b_, al);
+                reinterpret_cast<float4*>(tr.raw_rows)[row] = r4;
+                float4* dense = row < tr.R ? reinterpret_cast<float4*>(tr.raw_empty) : (row < first_f ? reinterpret_cast<float4*>(tr.raw_c)
+                                                                                                       : reinterpret_cast<float4*>(tr.raw_f));
+                dense[dst] = r4;
+                tr.row_ray[row] = ray;
+            }
+        } else if (qq == 0 && dst >= 0) {
             reinterpret_cast<float4*>(a.raw_out)[dst] = make_float4(r_, g_, b_, al);
             if (a.aux_out) a.aux_out[(size_t)row * (VW_ + 1) + VW_] = al;
         }
@@ -489,6 +637,9 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
+
+__global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) { mlp16_body<false>(a, TrainFwd{}); }
+__global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_fwd(Mlp16Args a, TrainFwd t) { mlp16_body<true>(a, t); }
 
 }  // namespace danbo
 
@@ -526,4 +677,50 @@ extern "C" int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int
     const int grid = ntiles < num_cu() ? ntiles : num_cu();
     hipLaunchKernelGGL(k_pe_mlp16, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused trunk of the training step: C ABI (include/danbo_hip.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int danbo_trunk_pack(const DanboTrunkWeights* w, void* stream) {
+    DANBO_CHECK_ARG(w && w->feature_w && w->feature_b && w->views_w && w->views_b && w->packed && w->wfv && w->b_eff && w->wmax && w->winv);
+    DANBO_CHECK_ARG(w->view_ch >= 0);
+    TrunkPackArgs a;
+    for (int i = 0; i < 8; ++i) { DANBO_CHECK_ARG(w->pts_w[i]); a.pts_w[i] = w->pts_w[i]; }
+    a.feature_w = w->feature_w; a.feature_b = w->feature_b; a.views_w = w->views_w; a.views_b = w->views_b; a.Cv = w->view_ch;
+    a.wfv = w->wfv; a.b_eff = w->b_eff; a.wmax = w->wmax; a.winv = w->winv; a.packed = reinterpret_cast<_Float16*>(w->packed);
+    hipLaunchKernelGGL(k_trunk_prep, dim3(32, 9), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_trunk_fwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, int pass, void* stream) {
+    DANBO_CHECK_ARG(w && r && (pass == 0 || pass == 1) && w->packed && w->winv && w->alpha_w && w->alpha_b && w->rgb_w && w->rgb_b);
+    DANBO_CHECK_ARG(r->cnt && r->row_sample && r->h_rows && r->cview && r->R > 0 && r->S > 0 && r->Sf > 0 && r->rows_cap >= r->R);
+    DANBO_CHECK_ARG(r->rows_pad >= (r->rows_cap + 127) / 128 * 128 && r->y && r->pe && r->relu && r->hv && r->hv_bits);
+    DANBO_CHECK_ARG(r->raw_rows && r->raw_c && r->raw_f && r->raw_empty && r->row_ray);
+    Mlp16Args a;
+    a.h = r->h_rows; a.list = nullptr; a.count = nullptr; a.n_cap = r->rows_cap; a.S = r->S;
+    a.packed = reinterpret_cast<const char*>(w->packed);
+    for (int i = 0; i < 8; ++i) { DANBO_CHECK_ARG(w->pts_b[i]); a.pts_b[i] = w->pts_b[i]; }
+    a.alpha_w = w->alpha_w; a.alpha_b = w->alpha_b; a.cview = r->cview; a.rgb_w = w->rgb_w; a.rgb_b = w->rgb_b;
+    a.raw_out = nullptr; a.aux_out = nullptr;
+    TrainFwd t;
+    t.cnt = r->cnt; t.row_sample = r->row_sample; t.pass = pass; t.R = r->R; t.S_c = r->S; t.S_f = r->Sf; t.winv = w->winv;
+    t.y = r->y; t.y_stride = r->rows_pad * 256; t.pe = r->pe;
+    t.relu = reinterpret_cast<unsigned long long*>(r->relu); t.relu_stride = r->rows_pad * 4;
+    t.hv = r->hv; t.hv_bits = r->hv_bits; t.raw_rows = r->raw_rows; t.raw_c = r->raw_c; t.raw_f = r->raw_f; t.raw_empty = r->raw_empty;
+    t.row_ray = r->row_ray;
+    DANBO_ENSURE_LDS(k_train_mlp_fwd, M16_LDS_BYTES);
+    const int ntiles = ceil_div(r->rows_cap, M16_BM);
+    const int grid = ntiles < num_cu() ? ntiles : num_cu();
+    hipLaunchKernelGGL(k_train_mlp_fwd, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a, t);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_trunk_pe_column(int k) {
+    if (k < 0 || k >= DANBO_TRUNK_PE_WIDTH) return -1;
+    const int ks = k >> 5, e = 4 * ((k >> 4) & 1) + (k & 3), q = (k >> 2) & 3;
+    const int j = 8 * ks + e, c = j / 13, t = j % 13, kk = q + 4 * c;
+    return (j < 52 && kk < FEAT) ? FEAT * t + kk : -1;
 }

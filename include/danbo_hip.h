@@ -455,6 +455,64 @@ int danbo_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     float sqrt_bias_corr2, float grad_scale, float beta1, float beta2, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused trunk of the training step: the density / colour MLP of core/networks/nerf.py:176-209 over the compacted rows of a
+ * step as ONE forward kernel per pass (csrc/k_mlp16.hip: K3's register-resident chain, which also writes every activation the
+ * backward needs, once, in the lanes' own order) and ONE input-gradient kernel (csrc/k_mlp16_bwd.hip: the mirrored chain
+ * dz_7 .. dz_0 with the adjoint of the positional encoding at its end).  feature_linear and the per-sample part of
+ * views_linears.0 are evaluated merged (W_fv = W_v[:, :256] W_f, as in danbo_mlp16_pack); the weight-gradient kernel
+ * produces dW_fv, from which danbo_train_head_chain derives the gradients of both layers (parameter-sized GEMMs).
+ * Row layout and counters: csrc/k_train_rows.hip.  Fragment order of a [rows, C] buffer: [rows/16][C/32][2][64 lanes][4 floats].
+ * ------------------------------------------------------------------------------------------- */
+#define DANBO_TRUNK_FWD_CHUNKS 74
+#define DANBO_TRUNK_BWD_CHUNKS 76
+#define DANBO_TRUNK_PACKED_BYTES ((DANBO_TRUNK_FWD_CHUNKS + DANBO_TRUNK_BWD_CHUNKS) * 32768)
+#define DANBO_TRUNK_PE_WIDTH 224    /* 7 k-steps x 32 slots; slot -> pts_linears column: danbo_trunk_pe_column */
+
+typedef struct DanboTrunkWeights {
+    const float* pts_w[8];             /* pts_linears.{0..7}.weight [256,195 | 256 | 451] */
+    const float* pts_b[8];
+    const float *alpha_w, *alpha_b, *feature_w, *feature_b, *views_w /*[128,256+view_ch]*/, *views_b, *rgb_w, *rgb_b;
+    int view_ch;
+    /* written by danbo_trunk_pack */
+    void* packed;                      /* DANBO_TRUNK_PACKED_BYTES */
+    float* wfv;                        /* [128,256] W_fv */
+    float* b_eff;                      /* [128] views_b + W_v[:, :256] feature_b */
+    float* wmax;                       /* [16]: max |w| of pts_linears.0..7, W_fv -- ZEROED by the caller before the call */
+    float* winv;                       /* [16]: exact inverses of the power-of-two pack scales, same order */
+} DanboTrunkWeights;
+int danbo_trunk_pack(const DanboTrunkWeights* w, void* stream);
+
+typedef struct DanboTrunkRows {
+    int32_t* cnt;                      /* the step's device counters (danbo_trunk_fwd derives [1]..[7] from [0]) */
+    const int32_t* row_sample;         /* [rows_cap] sample index of row i >= R inside its pass */
+    const float* h_rows;               /* [rows_cap,16] blended features (rows < R are not read: empty-space rows have h = 0) */
+    const float* cview;                /* [R,128] per-ray part of the view layer incl. b_eff (danbo_train_cview) */
+    int R, S, Sf, rows_cap;
+    long rows_pad;                     /* rows of every fragment-order buffer: rows_cap rounded up to 128, + 128 */
+    /* forward -> backward, weight gradients */
+    float* y;                          /* [8][rows_pad*256] post-ReLU activations of pts_linears.0..7 */
+    float* pe;                         /* [rows_pad*224] positional encoding in the lanes' slot order */
+    uint64_t* relu;                    /* [8][rows_pad*4] sign bits: bit 4 T + i of (row, q) <-> column 16 T + 4 q + i */
+    float* hv;                         /* [rows_pad*128] post-ReLU view layer */
+    uint32_t* hv_bits;                 /* [rows_pad*4] */
+    float* raw_rows;                   /* [rows_cap,4] */
+    float *raw_c /*[R*S,4]*/, *raw_f /*[R*Sf,4]*/, *raw_empty /*[R,4]*/;
+    int32_t* row_ray;                  /* [rows_cap] */
+    /* backward */
+    const float *d_raw_c, *d_raw_f;    /* dense gradients of the two passes' raw */
+    float* d_raw_rows;                 /* [rows_cap,4]: rows < R hold the rays' empty-space sums on entry; rows >= R are written */
+    float* dz;                         /* [8][rows_pad*256] gradients with respect to the pre-activations */
+    float* dpre_v;                     /* [rows_pad*128] */
+    float* d_alpha4;                   /* [rows_cap,4]: (d alpha, 0, 0, 0) */
+    float* d_h;                        /* [rows_cap,16] */
+    float* maxabs;                     /* [16]: running max |dz_0..7|, |dpre_v|, |d alpha| -- ZEROED by the caller */
+} DanboTrunkRows;
+int danbo_trunk_fwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, int pass, void* stream);
+int danbo_trunk_bwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, void* stream);
+/* pts_linears.0 column (0..194) of slot k (0..223) of the `pe` buffer, or -1 for the padding slots (host helper) */
+int danbo_trunk_pe_column(int k);
+
+/* ---------------------------------------------------------------------------------------------
  * One training batch behind one call: forward, losses, backward (csrc/k_train.hip) -- what Trainer.train_batch
  * (core/trainer.py:257-302) does between dict_to_device and optimizer.step(), for the shipped DANBO structure
  * (FGNNcat + vox_MIXGNN + sigmoid, D = 8, W = 256, skip after layer 4, view_W = 128, single_net).
