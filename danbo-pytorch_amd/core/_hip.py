@@ -76,7 +76,7 @@ SIGNATURES = {
     "danbo_adam_step": [P, P, P, P, c_long, F, F, F, F, F, F, F, P],
     "danbo_trunk_pack": [P, P],
     "danbo_trunk_fwd": [P, P, I, P],
-    # "danbo_trunk_bwd": [P, P, P],
+    "danbo_trunk_bwd": [P, P, P],
     "danbo_trunk_pe_column": [I],
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],

@@ -243,40 +243,6 @@ struct Mlp16Args {
 constexpr int M16_TABLE_FLOATS = 8 * W_ + W_ + 3 * VW_ + 4;
 constexpr int M16_LDS_BYTES = RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4 + 8 * (1024 + 256);  // + staging, see TileSrc
 
-// Tile-boundary prefetch, so that no wavefront waits on HBM between two row tiles:
-//   * the NEXT tile's rows (blended features h and list entries) are fetched by two LDS-DMA loads per wavefront
-//     into a 1.25 KB staging area while the view layer of the current tile runs;
-//   * the CURRENT tile's per-ray view constants are fetched by eight inline-asm loads one chunk before the
-//     colour head needs them (inline asm: a compiler-tracked load would make the compiler wait with
-//     s_waitcnt vmcnt(0), which also drains the weight ring).
-// Both ride on the ring's in-order vmcnt accounting: see pipe_handover.
-constexpr int STAGE_H_BYTES = 1024, STAGE_BYTES = 1024 + 256;  // per wavefront: h [16][16] floats, list [64] ints
-struct TileSrc {
-    const float* h;        // a.h
-    const int32_t* list;   // a.list or nullptr
-    const char* dummy;     // any readable 256 bytes (the packed weights)
-    int next_row0;         // first row of this wavefront in the next tile
-    int n;
-    char* stage;           // this wavefront's staging area (wave-uniform)
-};
-
-__device__ __forceinline__ void prefetch_rows(const TileSrc& t, int lane) {
-    int row0 = t.next_row0;
-    asm volatile("" : "+s"(row0));  // addresses are formed here, not hoisted out of the layer loop and spilled
-    const int rh = min(row0 + (lane >> 2), t.n - 1);
-    const float* src_h = t.h + (size_t)rh * DANBO_H_STRIDE + 4 * (lane & 3);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_h,
-                                     (__attribute__((address_space(3))) void*)t.stage, 16, 0, 0);
-    const int rl = min(row0 + (lane & 15), t.n - 1);
-    const void* src_l = t.list ? (const void*)(t.list + rl) : (const void*)(t.dummy + 4 * lane);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_l,
-                                     (__attribute__((address_space(3))) void*)(t.stage + STAGE_H_BYTES), 4, 0, 0);
-}
-struct StageRows {      // pipe_handover's `extra`: the two staging loads of the next tile
-    const TileSrc& t;
-    int lane;
-    __device__ __forceinline__ void operator()() const { prefetch_rows(t, lane); }
-};
 // one base address + instruction offsets: no per-load address registers.  Four column tiles per call.
 template <int HALF>
 __device__ __forceinline__ void prefetch_cv(const float* base, f32x4 (&cv)[8]) {
@@ -311,13 +277,6 @@ struct TrainFwd {
     float *raw_rows, *raw_c, *raw_f, *raw_empty;
     int32_t* row_ray;
 };
-
-// lane * 16, re-derived where it is used (two VALU operations) instead of living in a register across the layer loop
-__device__ __forceinline__ unsigned lane_off16() {
-    int zero = 0;
-    asm volatile("" : "+s"(zero));
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) << 4;
-}
 
 // B fragments of k-step s of the next GEMM from the previous layer's accumulators: tiles 2s and 2s+1,
 // bias + ReLU, hi/lo split.  ALPHA: also accumulate this lane's part of the density logit.

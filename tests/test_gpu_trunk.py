@@ -67,21 +67,31 @@ class Net:
         w.view_ch = self.view_ch
         return w
 
-    def forward64(self, h, vin):
-        """fp64 reference of the network on rows h [n,15] with per-row view inputs vin [n, view_ch]; keeps every activation"""
+    def forward64(self, h, vin, keep_graph=False):
+        """fp64 reference of the network on rows h [n,15] with per-row view inputs vin [n, view_ch]; keeps every activation
+        (keep_graph: h is a leaf and every pre-activation retains its gradient)"""
         d = lambda t: t.double()   # noqa: E731
         L = 6
-        pe = torch.cat([d(h)] + [f(d(h) * 2.0 ** l) for l in range(L) for f in (torch.sin, torch.cos)], 1)   # [n,195]
-        ys, x = [], pe
+        h = d(h)
+        if keep_graph:
+            h.requires_grad_(True)
+        pe = torch.cat([h] + [f(h * 2.0 ** l) for l in range(L) for f in (torch.sin, torch.cos)], 1)   # [n,195]
+        ys, zs, x = [], [], pe
         for l in range(8):
-            x = torch.relu(torch.cat([pe, x], 1) @ d(self.pts_w[l]).t() + d(self.pts_b[l])) if l == 5 else \
-                torch.relu(x @ d(self.pts_w[l]).t() + d(self.pts_b[l]))
+            z = (torch.cat([pe, x], 1) if l == 5 else x) @ d(self.pts_w[l]).t() + d(self.pts_b[l])
+            if keep_graph:
+                z.retain_grad()
+            x = torch.relu(z)
             ys.append(x)
+            zs.append(z)
         alpha = x @ d(self.alpha_w).t() + d(self.alpha_b)
         feat = x @ d(self.feature_w).t() + d(self.feature_b)
-        hv = torch.relu(torch.cat([feat, d(vin)], 1) @ d(self.views_w).t() + d(self.views_b))
+        pre_v = torch.cat([feat, d(vin)], 1) @ d(self.views_w).t() + d(self.views_b)
+        if keep_graph:
+            pre_v.retain_grad()
+        hv = torch.relu(pre_v)
         rgb = hv @ d(self.rgb_w).t() + d(self.rgb_b)
-        return dict(pe=pe, ys=ys, hv=hv, raw=torch.cat([rgb, alpha], 1))
+        return dict(pe=pe, ys=ys, zs=zs, hv=hv, pre_v=pre_v, h=h, raw=torch.cat([rgb, alpha], 1))
 
 
 def make_rows(net, R, S, Sf, n_c, n_f, seed):
@@ -144,7 +154,7 @@ def run_forward(net, t):
     return w, r, cview
 
 
-def reference_rows(net, t):
+def reference_rows(net, t, keep_graph=False):
     R, S, Sf, n, n_c = t["R"], t["S"], t["Sf"], t["n"], t["n_c"]
     rs = t["row_sample"][:n].long()
     ray = torch.arange(n, device=DEV)
@@ -152,7 +162,7 @@ def reference_rows(net, t):
     ray[R + n_c:] = rs[R + n_c:] // Sf
     h = t["h_rows"][:n, :15].clone()
     h[:R] = 0.0
-    return ray, net.forward64(h, t["vin"][ray])
+    return ray, net.forward64(h, t["vin"][ray], keep_graph)
 
 
 @pytest.mark.parametrize("R,S,Sf,n_c,n_f", [(96, 16, 8, 700, 333), (40, 32, 16, 0, 0), (130, 8, 4, 5, 250)])
@@ -199,3 +209,63 @@ def test_trunk_forward_matches_fp64_and_keeps_every_activation(R, S, Sf, n_c, n_
     assert (pe[:, live] - ref["pe"][:, colmap[live]]).abs().max().item() < 1e-6
     # (the padding slots hold the encoding of a zero channel -- cos 0 = 1 --: the packed weights are zero there and the
     #  weight-gradient kernel drops those columns)
+
+
+@pytest.mark.parametrize("R,S,Sf,n_c,n_f,gscale", [(96, 16, 8, 700, 333, 1e-6), (130, 8, 4, 5, 250, 3e-9), (64, 8, 4, 0, 0, 1e-4)])
+def test_trunk_backward_matches_fp64_autograd(R, S, Sf, n_c, n_f, gscale):
+    """d raw (dense gradients of the two passes + the rays' empty-space sums) -> dz_0 .. dz_7, d pre_v, d alpha, d h against
+    torch.autograd in fp64 through the same network, at gradient magnitudes far below fp16's range"""
+    from core import _hip
+    net = Net(seed=R + 1)
+    t = make_rows(net, R, S, Sf, n_c, n_f, seed=n_c + 3)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, first_f = t["n"], R + n_c
+    # per-row weights differ by orders of magnitude (an empty-space row sums a whole ray): the per-wavefront pre-scale has to cope
+    row_gain = torch.exp(torch.randn(t["cap"], 1, generator=g) * 2.0)
+    t["d_raw_c"] = (torch.randn(R * S, 4, generator=g) * gscale).to(DEV)
+    t["d_raw_f"] = (torch.randn(R * Sf, 4, generator=g) * gscale).to(DEV)
+    t["d_raw_rows"] = (torch.randn(t["cap"], 4, generator=g) * gscale * row_gain).to(DEV)
+    w, r, cview = run_forward(net, t)
+    r = rows_struct(t, cview)
+    rs = t["row_sample"][:n].long()
+    G = t["d_raw_rows"][:n].clone()
+    G[R:first_f] = t["d_raw_c"][rs[R:first_f]]
+    G[first_f:] = t["d_raw_f"][rs[first_f:]]
+    _hip.check(_hip.lib().danbo_trunk_bwd(ctypes.byref(w), ctypes.byref(r), stream()), "trunk_bwd")
+    torch.cuda.synchronize()
+    ray, ref = reference_rows(net, t, keep_graph=True)
+    (ref["raw"] * G.double()).sum().backward()
+    rows_p = (n + 15) // 16 * 16
+    assert torch.equal(t["d_raw_rows"][:n], G) and torch.equal(t["d_alpha4"][:n, 0], G[:, 3]) and float(t["d_alpha4"][:n, 1:].abs().max()) == 0.0
+    worst = 0.0
+
+    def group_err(a, b):
+        """largest error relative to the largest reference entry of the same 16-row group (the unit that shares a pre-scale; the
+        groups themselves differ by orders of magnitude)"""
+        k = a.shape[0]
+        pad = (-k) % 16
+        ea = torch.nn.functional.pad((a - b).abs().amax(1), (0, pad)).view(-1, 16).amax(1)
+        eb = torch.nn.functional.pad(b.abs().amax(1), (0, pad)).view(-1, 16).amax(1)
+        return (ea / (eb + 1e-300)).max().item()
+    for l in range(8):
+        dz = frag_to_rows(t["dz"][l], rows_p, 256)[:n].double()
+        refz = ref["zs"][l].grad
+        e = group_err(dz, refz)
+        print("layer", l, "group-relative", e, "tensor-relative", ((dz - refz).abs().max() / refz.abs().max()).item())
+        worst = max(worst, e)
+        assert e < 5e-5, (l, e)
+        mx = float(t["maxabs"][l])
+        assert mx >= float(dz.abs().max()) * (1 - 1e-6) and mx <= 64 * float(dz.abs().max()) + 1e-30, (l, mx, float(dz.abs().max()))
+    dv = frag_to_rows(t["dpre_v"], rows_p, 128)[:n].double()
+    e = group_err(dv, ref["pre_v"].grad)
+    assert e < 1e-5, e
+    dh = t["d_h"][R:n, :15].double()
+    refh = ref["h"].grad[R:]
+    if n > R:
+        k0 = (-R) % 16          # align the groups with the kernel's (rows R .. n start inside a group)
+        e = max(group_err(dh[:k0], refh[:k0]) if k0 else 0.0, group_err(dh[k0:], refh[k0:]) if n - R > k0 else 0.0)
+        print("d h group-relative", e)
+        worst = max(worst, e)
+        assert e < 5e-5, e
+        assert float(t["d_h"][R:n, 15].abs().max()) == 0.0
+    print("worst per-row relative deviation", worst)
