@@ -78,6 +78,9 @@ SIGNATURES = {
     "danbo_trunk_fwd": [P, P, I, P],
     "danbo_trunk_bwd": [P, P, P],
     "danbo_trunk_pe_column": [I],
+    "danbo_train_cview": [P, I, I, P, P, I, P, P],
+    "danbo_train_view_grads": [P, P, P, I, I, P, I, I, P, I, P, P, P, P],
+    "danbo_train_head_chain": [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
@@ -133,7 +136,7 @@ class DanboPackDesc(ctypes.Structure):
 
 class DanboDwLayer(ctypes.Structure):
     _fields_ = ([(n, P) for n in ("dy", "x1", "x2", "dy_maxabs", "gw", "gw2", "gb", "gb2")]
-                + [(n, I) for n in ("ldy", "ld1", "ld2", "N", "K1", "K2", "split_n", "frag", "gw_ld", "gw_col0")])
+                + [(n, I) for n in ("ldy", "ld1", "ld2", "N", "K1", "K2", "split_n", "frag", "gw_ld", "gw_col0", "x1_pe")])
 
 
 class DanboAssignBwd(ctypes.Structure):

@@ -60,6 +60,7 @@ struct DwLayer {
     int ldy, ld1, ld2, N, K1, K2, split_n;
     int frag;              // bit 0: dy, 1: x1 (then K2 == 0) in the fragment order of k_linear16 ([rows/16][C/32][2][4 q][16 n][4])
     int gw_ld, gw_col0;    // the gradient goes to gw[n * gw_ld + gw_col0 + k] (a layer whose inputs are handled as two layers)
+    int x1_pe;             // x1 = the fused trunk's encoding buffer: slot k -> column pe_slot_column(k), padding slots dropped
     int K1p, Kv;           // K1 rounded up to 4; virtual width K1p + K2
     int tile0, nt_k;       // first tile of this layer, tiles along K
     long part_off;         // floats: this layer's [slices][N * Kv + N] partial block
@@ -403,6 +404,13 @@ __global__ __launch_bounds__(DW_THREADS, 1) void k_dw16(DwArgs a) {
     }
 }
 
+// pts_linears column of slot k of the fused trunk's `pe` buffer (= danbo_trunk_pe_column, k_mlp16.hip), -1: padding
+__device__ __forceinline__ int pe_slot_column(int k) {
+    const int ks = k >> 5, e = 4 * ((k >> 4) & 1) + (k & 3), q = (k >> 2) & 3;
+    const int j = 8 * ks + e, c = j / 13, t = j % 13, kk = q + 4 * c;
+    return (j < 52 && kk < FEAT) ? FEAT * t + kk : -1;
+}
+
 // sums the slices in order, scales back, writes nn.Linear layout
 __global__ __launch_bounds__(256) void k_dw16_reduce(DwArgs a) {
     const int M = resolve_count(a.count, a.M);
@@ -439,7 +447,8 @@ __global__ __launch_bounds__(256) void k_dw16_reduce(DwArgs a) {
             if (g != nullptr) g[n < L.split_n ? n : n - L.split_n] = s;   // the bias sums use the unscaled gradient
         } else {
             float* g = n < L.split_n ? L.gw : L.gw2;
-            if (g != nullptr) g[(long)(n < L.split_n ? n : n - L.split_n) * L.gw_ld + L.gw_col0 + k] = s * inv;
+            const int col = L.x1_pe ? pe_slot_column(k) : k;
+            if (g != nullptr && col >= 0) g[(long)(n < L.split_n ? n : n - L.split_n) * L.gw_ld + L.gw_col0 + col] = s * inv;
         }
     }
 }
@@ -476,7 +485,8 @@ extern "C" int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const
         DANBO_CHECK_ARG(s.frag >= 0 && s.frag <= 3 && (uintptr_t)s.x1 % 16 == 0 && (uintptr_t)s.x2 % 16 == 0 && (uintptr_t)s.dy % 16 == 0);
         DANBO_CHECK_ARG((s.frag & 2) ? (s.K1 % 32 == 0 && s.K2 == 0) : (s.ld1 % 4 == 0 && s.ld1 >= ((s.K1 + 3) & ~3)));
         DANBO_CHECK_ARG(s.K2 == 0 || (s.ld2 % 4 == 0 && s.ld2 >= s.K2));
-        DANBO_CHECK_ARG(s.gw_ld == 0 || (s.gw_ld >= s.gw_col0 + s.K1 + s.K2 && s.gw_col0 >= 0 && !s.gw2));
+        DANBO_CHECK_ARG(!s.x1_pe || ((s.frag & 2) && s.K1 == DANBO_TRUNK_PE_WIDTH && s.K2 == 0 && s.gw_ld >= s.gw_col0 + 195));
+        DANBO_CHECK_ARG(s.gw_ld == 0 || s.x1_pe || (s.gw_ld >= s.gw_col0 + s.K1 + s.K2 && s.gw_col0 >= 0 && !s.gw2));
         DANBO_CHECK_ARG((s.frag & 1) ? s.N % 32 == 0 : (s.ldy % 4 == 0 && s.ldy >= s.N));
         DwLayer& L = a.l[i];
         L.dy = s.dy; L.x1 = s.x1; L.x2 = s.x2; L.dy_maxabs = s.dy_maxabs;
@@ -484,6 +494,7 @@ extern "C" int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const
         L.ldy = s.ldy; L.ld1 = s.ld1; L.ld2 = s.ld2; L.N = s.N; L.K1 = s.K1; L.K2 = s.K2; L.frag = s.frag;
         L.gw_ld = s.gw_ld > 0 ? s.gw_ld : s.K1 + s.K2;
         L.gw_col0 = s.gw_ld > 0 ? s.gw_col0 : 0;
+        L.x1_pe = s.x1_pe;
         L.split_n = s.gw2 || s.gb2 ? s.split_n : 0x7fffffff;
         L.K1p = (s.K1 + 3) & ~3;
         L.Kv = L.K1p + s.K2;

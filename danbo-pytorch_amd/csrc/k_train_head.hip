@@ -1,0 +1,209 @@
+// The view branch of the training step outside the fused trunk (k_mlp16.hip / k_mlp16_bwd.hip).
+// Reference: NeRF.forward_view (core/networks/nerf.py:196-209): views_linears.0 on cat[feature_linear(y7), PE(dir), frame code].
+// The trunk evaluates feature_linear and the per-sample columns of views_linears.0 merged (W_fv = W_v[:, :256] W_f) and takes
+// the per-RAY columns as a constant of the ray:
+//     cview[r]  = W_v[:, 256:] vin[r] + (b_v + W_v[:, :256] b_f)                         k_train_cview        (forward)
+// Its adjoint is therefore per ray, and the merged matrix' gradient is pulled back to the two layers by parameter-sized GEMMs:
+//     d cview[r] = sum over the rows of ray r of d pre_v[row]                            k_train_ray_grad
+//     d W_v[:, 256:] = d cview^T vin ;  csum[cam] = sum over the rays of camera cam      k_train_view_grad
+//     d W_v[:, :256] = d W_fv W_f^T + d b_eff b_f^T ;  d W_f = W_v[:, :256]^T d W_fv ;  d b_f = W_v[:, :256]^T d b_eff ;
+//     d b_v = d b_eff ;  d codes[cam] = W_v[:, code columns]^T csum[cam]                 k_train_head_chain
+// (d W_fv [128,256] and d b_eff [128] = sum over rows of d pre_v come from the weight-gradient kernel k_dw16.)
+#include "common.hpp"
+
+namespace danbo {
+
+constexpr int HW = 256, HVW = 128;
+
+// ------------------------------------------------------------------------------------------------------------------
+// cview[r, f] = b_eff[f] + sum_k vin[r, k] W_v[f, 256 + k]:  128 threads = features, 8 rays per workgroup
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CV_RAYS = 8;
+__global__ __launch_bounds__(128) void k_train_cview(const float* __restrict__ vin, int ldv, int Cv, const float* __restrict__ views_w,
+                                                     const float* __restrict__ b_eff, int R, float* __restrict__ cview) {
+    __shared__ float s_v[CV_RAYS][160];
+    const int f = threadIdx.x;
+    const float* wrow = views_w + (size_t)f * (HW + Cv) + HW;
+    for (int r0 = blockIdx.x * CV_RAYS; r0 < R; r0 += gridDim.x * CV_RAYS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CV_RAYS * Cv; i += 128) {
+            const int rr = i / Cv, k = i % Cv;
+            s_v[rr][k] = r0 + rr < R ? vin[(size_t)(r0 + rr) * ldv + k] : 0.f;
+        }
+        __syncthreads();
+        float acc[CV_RAYS];
+#pragma unroll
+        for (int rr = 0; rr < CV_RAYS; ++rr) acc[rr] = b_eff[f];
+        for (int k = 0; k < Cv; ++k) {
+            const float w = wrow[k];
+#pragma unroll
+            for (int rr = 0; rr < CV_RAYS; ++rr) acc[rr] = fmaf(s_v[rr][k], w, acc[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < CV_RAYS; ++rr)
+            if (r0 + rr < R) cview[(size_t)(r0 + rr) * HVW + f] = acc[rr];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// d cview[ray(row), f] += d pre_v[row, f] over all rows; d pre_v in fragment order.  128 threads = features; a workgroup owns
+// a chunk of consecutive rows (rows of a ray are mostly consecutive: running sum, one atomic per feature when the ray changes)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RG_CHUNK = 64;
+__global__ __launch_bounds__(128) void k_train_ray_grad(const float* __restrict__ dpre_v, const int32_t* __restrict__ row_ray,
+                                                        const int32_t* __restrict__ cnt, int R, float* __restrict__ d_cview) {
+    const int rows = cnt[4];
+    const int f = threadIdx.x;
+    // element (row i, feature f) of a [rows, 128] fragment-order buffer
+    const int foff = ((f >> 5) * 2 + ((f >> 4) & 1)) * 256 + 16 * ((f >> 2) & 3) * 4 + (f & 3);
+    for (int base = blockIdx.x * RG_CHUNK; base < rows; base += gridDim.x * RG_CHUNK) {
+        float acc = 0.f;
+        int cur = -1;
+        const int end = min(base + RG_CHUNK, rows);
+        for (int i = base; i < end; ++i) {
+            int ray = row_ray[i];
+            ray = ray < 0 ? 0 : (ray >= R ? R - 1 : ray);
+            if (ray != cur) {
+                if (cur >= 0 && acc != 0.f) atomicAdd(d_cview + (size_t)cur * HVW + f, acc);
+                cur = ray;
+                acc = 0.f;
+            }
+            acc += dpre_v[(size_t)(i >> 4) * 2048 + foff + (i & 15) * 4];
+        }
+        if (cur >= 0 && acc != 0.f) atomicAdd(d_cview + (size_t)cur * HVW + f, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// g_views_w[f, 256 + k] += sum_r d cview[r, f] vin[r, k]   (blockIdx.x < k-groups of 8 columns, blockIdx.y = ray slice)
+// csum[cam(r), f]      += d cview[r, f]                      (the last blockIdx.x; running sum per camera)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int VG_K = 8;
+__global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict__ d_cview, const float* __restrict__ vin, int ldv, int Cv,
+                                                         int R, const int64_t* __restrict__ cam_idx, int n_codes, float* __restrict__ g_views_w,
+                                                         float* __restrict__ csum) {
+    const int f = threadIdx.x;
+    const int kgroups = (Cv + VG_K - 1) / VG_K;
+    const int per = (R + gridDim.y - 1) / gridDim.y;
+    const int r_begin = blockIdx.y * per, r_end = min(r_begin + per, R);
+    if ((int)blockIdx.x < kgroups) {
+        const int k0 = blockIdx.x * VG_K;
+        float acc[VG_K];
+#pragma unroll
+        for (int j = 0; j < VG_K; ++j) acc[j] = 0.f;
+        for (int r = r_begin; r < r_end; ++r) {
+            const float dc = d_cview[(size_t)r * HVW + f];
+            const float* v = vin + (size_t)r * ldv + k0;      // ldv is a multiple of 4 and >= Cv rounded up: in bounds
+#pragma unroll
+            for (int j = 0; j < VG_K; ++j) acc[j] = fmaf(dc, k0 + j < Cv ? v[j] : 0.f, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < VG_K; ++j)
+            if (k0 + j < Cv && acc[j] != 0.f) atomicAdd(g_views_w + (size_t)f * (HW + Cv) + HW + k0 + j, acc[j]);
+    } else if (n_codes > 0) {
+        float acc = 0.f;
+        long cur = -1;
+        for (int r = r_begin; r < r_end; ++r) {
+            long ci = cam_idx ? cam_idx[r] : 0;
+            ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
+            if (ci != cur) {
+                if (cur >= 0 && acc != 0.f) atomicAdd(csum + cur * HVW + f, acc);
+                cur = ci;
+                acc = 0.f;
+            }
+            acc += d_cview[(size_t)r * HVW + f];
+        }
+        if (cur >= 0 && acc != 0.f) atomicAdd(csum + cur * HVW + f, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// parameter-sized chain rule of the merged feature / view layer and the frame codes; one thread per output element
+// ------------------------------------------------------------------------------------------------------------------
+struct HeadChainArgs {
+    const float *g_wfv /*[128,256]*/, *g_beff /*[128]*/, *csum /*[n_codes,128]*/;
+    const float *feature_w /*[256,256]*/, *feature_b /*[256]*/, *views_w /*[128,256+Cv]*/;
+    int Cv, n_codes, code_size, code_col0;       // code_col0: first frame-code column of vin (3 (1 + 2 L_view))
+    float *g_feature_w, *g_feature_b, *g_views_w, *g_views_b, *g_codes;
+};
+
+__global__ __launch_bounds__(256) void k_train_head_chain(HeadChainArgs a) {
+    const int ld = HW + a.Cv;
+    const long n_va = (long)HVW * HW, n_f = (long)HW * HW, n_fb = HW, n_vb = HVW, n_c = (long)a.n_codes * a.code_size;
+    const long total = n_va + n_f + n_fb + n_vb + n_c;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long i = idx;
+        if (i < n_va) {               // d W_v[f, c] = sum_j d W_fv[f, j] W_f[c, j] + d b_eff[f] b_f[c]
+            const int f = (int)(i / HW), c = (int)(i % HW);
+            float acc = a.g_beff[f] * a.feature_b[c];
+            const float* gw = a.g_wfv + (size_t)f * HW;
+            const float* wf = a.feature_w + (size_t)c * HW;
+            for (int j = 0; j < HW; ++j) acc = fmaf(gw[j], wf[j], acc);
+            a.g_views_w[(size_t)f * ld + c] = acc;
+            continue;
+        }
+        i -= n_va;
+        if (i < n_f) {                // d W_f[c, j] = sum_f W_v[f, c] d W_fv[f, j]
+            const int c = (int)(i / HW), j = (int)(i % HW);
+            float acc = 0.f;
+            for (int f = 0; f < HVW; ++f) acc = fmaf(a.views_w[(size_t)f * ld + c], a.g_wfv[(size_t)f * HW + j], acc);
+            a.g_feature_w[i] = acc;
+            continue;
+        }
+        i -= n_f;
+        if (i < n_fb) {               // d b_f[c] = sum_f W_v[f, c] d b_eff[f]
+            float acc = 0.f;
+            for (int f = 0; f < HVW; ++f) acc = fmaf(a.views_w[(size_t)f * ld + i], a.g_beff[f], acc);
+            a.g_feature_b[i] = acc;
+            continue;
+        }
+        i -= n_fb;
+        if (i < n_vb) { a.g_views_b[i] = a.g_beff[i]; continue; }
+        i -= n_vb;
+        {                             // d codes[cam, k] = sum_f csum[cam, f] W_v[f, 256 + code_col0 + k]
+            const int cam = (int)(i / a.code_size), k = (int)(i % a.code_size);
+            float acc = 0.f;
+            for (int f = 0; f < HVW; ++f) acc = fmaf(a.csum[(size_t)cam * HVW + f], a.views_w[(size_t)f * ld + HW + a.code_col0 + k], acc);
+            a.g_codes[i] = acc;
+        }
+    }
+}
+
+}  // namespace danbo
+
+using namespace danbo;
+
+extern "C" int danbo_train_cview(const float* vin, int ldv, int view_ch, const float* views_w, const float* b_eff, int R, float* cview,
+                                 void* stream) {
+    DANBO_CHECK_ARG(vin && views_w && b_eff && cview && R > 0 && view_ch >= 0 && view_ch <= 160 && ldv >= view_ch);
+    const int blocks = (R + CV_RAYS - 1) / CV_RAYS;
+    hipLaunchKernelGGL(k_train_cview, dim3(blocks < num_cu() * 8 ? blocks : num_cu() * 8), dim3(128), 0, (hipStream_t)stream, vin, ldv, view_ch,
+                       views_w, b_eff, R, cview);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_view_grads(const float* dpre_v, const int32_t* row_ray, const int32_t* cnt, int rows_cap, int R, const float* vin,
+                                      int ldv, int view_ch, const int64_t* cam_idx, int n_codes, float* d_cview /*[R,128] zeroed*/,
+                                      float* csum /*[n_codes,128] zeroed*/, float* g_views_w /*accumulated*/, void* stream) {
+    DANBO_CHECK_ARG(dpre_v && row_ray && cnt && vin && d_cview && g_views_w && rows_cap > 0 && R > 0 && view_ch >= 0 && ldv % 4 == 0);
+    DANBO_CHECK_ARG(ldv >= view_ch);
+    DANBO_CHECK_ARG(n_codes == 0 || csum);
+    const int chunks = (rows_cap + RG_CHUNK - 1) / RG_CHUNK;
+    hipLaunchKernelGGL(k_train_ray_grad, dim3(chunks < num_cu() * 8 ? chunks : num_cu() * 8), dim3(128), 0, (hipStream_t)stream, dpre_v, row_ray,
+                       cnt, R, d_cview);
+    const int kgroups = (view_ch + VG_K - 1) / VG_K;
+    hipLaunchKernelGGL(k_train_view_grad, dim3(kgroups + 1, 8), dim3(128), 0, (hipStream_t)stream, d_cview, vin, ldv, view_ch, R, cam_idx,
+                       n_codes, g_views_w, csum);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_head_chain(const float* g_wfv, const float* g_beff, const float* csum, const float* feature_w,
+                                      const float* feature_b, const float* views_w, int view_ch, int n_codes, int code_size, int code_col0,
+                                      float* g_feature_w, float* g_feature_b, float* g_views_w, float* g_views_b, float* g_codes, void* stream) {
+    DANBO_CHECK_ARG(g_wfv && g_beff && feature_w && feature_b && views_w && g_feature_w && g_feature_b && g_views_w && g_views_b);
+    DANBO_CHECK_ARG(view_ch >= 0 && (n_codes == 0 || (csum && g_codes && code_size > 0 && code_col0 >= 0 && code_col0 + code_size <= view_ch)));
+    HeadChainArgs a{g_wfv, g_beff, csum, feature_w, feature_b, views_w, view_ch, n_codes, code_size, code_col0,
+                    g_feature_w, g_feature_b, g_views_w, g_views_b, g_codes};
+    hipLaunchKernelGGL(k_train_head_chain, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}

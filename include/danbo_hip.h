@@ -377,6 +377,8 @@ typedef struct DanboDwLayer {
     int frag;                 /* bit 0: dy, bit 1: x1 (then K2 = 0) are fragment-order buffers (widths multiples of 32, ld ignored) */
     int gw_ld, gw_col0;       /* 0, 0: gw is [N, K1 + K2]; else the gradient goes to gw[n * gw_ld + gw_col0 + k] -- a layer with two
                                  inputs in different layouts is passed as two layers (gb = NULL in one of them) */
+    int x1_pe;                /* 1: x1 is the fused trunk's `pe` buffer (fragment order, K1 = 224 slots): slot k is column
+                                 danbo_trunk_pe_column(k) of the gradient, padding slots are dropped */
 } DanboDwLayer;
 long danbo_dw16_scratch_floats(const DanboDwLayer* layers, int n_layers, int slices);
 int danbo_dw16(const DanboDwLayer* layers, int n_layers, int M, const int32_t* count, int slices, float* scratch, void* stream);
@@ -511,6 +513,18 @@ int danbo_trunk_fwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, int pas
 int danbo_trunk_bwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, void* stream);
 /* pts_linears.0 column (0..194) of slot k (0..223) of the `pe` buffer, or -1 for the padding slots (host helper) */
 int danbo_trunk_pe_column(int k);
+
+/* the view branch around the fused trunk (csrc/k_train_head.hip): cview [R,128] = W_v[:, 256:] vin + b_eff */
+int danbo_train_cview(const float* vin /*[R,ldv]*/, int ldv, int view_ch, const float* views_w, const float* b_eff, int R, float* cview,
+                      void* stream);
+/* d cview[ray] = sum over the ray's rows of d pre_v (fragment order); g_views_w[:, 256:] += d cview^T vin; csum[cam] = sum over
+ * the camera's rays of d cview.  d_cview and csum must be zero on entry. */
+int danbo_train_view_grads(const float* dpre_v, const int32_t* row_ray, const int32_t* cnt, int rows_cap, int R, const float* vin, int ldv,
+                           int view_ch, const int64_t* cam_idx, int n_codes, float* d_cview, float* csum, float* g_views_w, void* stream);
+/* gradients of feature_linear, views_linears.0[:, :256] / bias and the frame codes from d W_fv, d b_eff (k_dw16) and csum */
+int danbo_train_head_chain(const float* g_wfv, const float* g_beff, const float* csum, const float* feature_w, const float* feature_b,
+                           const float* views_w, int view_ch, int n_codes, int code_size, int code_col0, float* g_feature_w,
+                           float* g_feature_b, float* g_views_w, float* g_views_b, float* g_codes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One training batch behind one call: forward, losses, backward (csrc/k_train.hip) -- what Trainer.train_batch
