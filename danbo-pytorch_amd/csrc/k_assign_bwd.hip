@@ -81,11 +81,13 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     __syncthreads();
     int total_pairs = 0;
     for (int k = 0; k < J; ++k) total_pairs += s_cnt[k];
-    const int ppw = min(max(((total_pairs + target_wgs - 1) / target_wgs + 7) & ~7, AB_PPW_MIN), AB_PPW);
-    // grid-stride over the (bone, chunk) work items: a launch whose grid is smaller than the number of chunks (heavily
-    // overlapping volumes after axis_scale has grown, very large batches) loops instead of dropping pairs
-    for (int item = blockIdx.x;; item += gridDim.x) {
-    int j = 0, wg = item, npairs = 0;
+    // pairs per workgroup: 128 .. 256 so that the workgroups with pairs fill the resident slots in one round -- and MORE than
+    // 256 (processed in sub-batches of 256 below) when the launch grid could not cover the chunks otherwise (heavily overlapping
+    // volumes after axis_scale has grown, very large batches): sum_j ceil(cnt_j / ppw) <= total / ppw + J <= gridDim.x, no pair
+    // is ever dropped
+    const int wgs_avail = max(min(target_wgs, (int)gridDim.x - J), 1);
+    const int ppw = max(((total_pairs + wgs_avail - 1) / wgs_avail + 7) & ~7, AB_PPW_MIN);
+    int j = 0, wg = blockIdx.x, npairs = 0;
     for (; j < J; ++j) {
         npairs = s_cnt[j];
         const int need = (npairs + ppw - 1) / ppw;
@@ -131,26 +133,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     __shared__ __attribute__((aligned(16))) float s_pdh[AB_PPW][16];
     __shared__ float s_skt0[AB_MAXNB][12];
     __shared__ float s_vol0[AB_MAXNB][VOL];
-    if (tid < p_end - p_begin) {
-        const int i = a.lists[(size_t)j * a.cap + p_begin + tid];
-        const bool coarse = i < first_f;
-        const int m = a.row_sample[i];
-        s_pi[tid] = i; s_pm[tid] = m; s_pray[tid] = a.row_ray[i];
-        s_pz[tid] = coarse ? a.z_c[m] : a.z_f[m];
-        s_plab[tid] = (float)(coarse ? a.label_c[m] : a.label_f[m]);
-        s_pbits[tid] = coarse ? a.bits_c[m] : a.bits_f[m];
-        s_pq[tid] = a.h_rows[(size_t)i * 16 + 15];
-        const float4* dh = reinterpret_cast<const float4*>(a.d_h + (size_t)i * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(s_pdh[tid])[e] = dh[e];
-    }
-    __syncthreads();
-    const int g0 = min(s_pray[0] / rays_per_pose, a.G - 1);
-    // pose g0's bone transforms and volumes of the neighbourhood: LDS instead of two more dependent global round trips per pair
-    for (int i = tid; i < nq * 12; i += AB_THREADS) s_skt0[i / 12][i % 12] = a.skts[((size_t)g0 * J + s_nb[i / 12]) * 16 + i % 12];
-    for (int i = tid; i < nq * VOL; i += AB_THREADS) s_vol0[i / VOL][i % VOL] = a.volumes[((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL];
-    __syncthreads();
-
+    int g0 = 0;
     // ---- gradient accumulators of this lane (hidden unit c of half `slot & 1`)
     float gw1[AB_W];                 // d W1[j][cc][c], cc = 0..31
     float gw0[AB_MAXNB][FEAT];       // d W0[nb q][t][c]
@@ -166,11 +149,36 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     // lanes 0 .. 3 nq - 1 of a half: (neighbour gq, axis gk) of the gather and of its adjoint
     const int gq = c / 3, gk = c % 3;
     const bool glane = c < 3 * nq;
+#pragma unroll 1
+    for (int sb_begin = p_begin; sb_begin < p_end; sb_begin += AB_PPW) {      // one pass unless ppw > 256
+    const int sb_end = min(sb_begin + AB_PPW, p_end);
+    if (sb_begin != p_begin) __syncthreads();                                 // the previous sub-batch's tables are still being read
+    if (tid < sb_end - sb_begin) {
+        const int i = a.lists[(size_t)j * a.cap + sb_begin + tid];
+        const bool coarse = i < first_f;
+        const int m = a.row_sample[i];
+        s_pi[tid] = i; s_pm[tid] = m; s_pray[tid] = a.row_ray[i];
+        s_pz[tid] = coarse ? a.z_c[m] : a.z_f[m];
+        s_plab[tid] = (float)(coarse ? a.label_c[m] : a.label_f[m]);
+        s_pbits[tid] = coarse ? a.bits_c[m] : a.bits_f[m];
+        s_pq[tid] = a.h_rows[(size_t)i * 16 + 15];
+        const float4* dh = reinterpret_cast<const float4*>(a.d_h + (size_t)i * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(s_pdh[tid])[e] = dh[e];
+    }
+    __syncthreads();
+    if (sb_begin == p_begin) {
+        g0 = min(s_pray[0] / rays_per_pose, a.G - 1);
+        // pose g0's bone transforms and volumes of the neighbourhood: LDS instead of two more dependent global round trips per pair
+        for (int i = tid; i < nq * 12; i += AB_THREADS) s_skt0[i / 12][i % 12] = a.skts[((size_t)g0 * J + s_nb[i / 12]) * 16 + i % 12];
+        for (int i = tid; i < nq * VOL; i += AB_THREADS) s_vol0[i / VOL][i % VOL] = a.volumes[((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL];
+        __syncthreads();
+    }
 
-    const int iters = (p_end - p_begin + AB_PAIRS - 1) / AB_PAIRS;
+    const int iters = (sb_end - sb_begin + AB_PAIRS - 1) / AB_PAIRS;
     for (int it = 0; it < iters; ++it) {
         const int pl_ = it * AB_PAIRS + slot;
-        const bool live = p_begin + pl_ < p_end;            // uniform per half
+        const bool live = sb_begin + pl_ < sb_end;          // uniform per half
         const int pl = live ? pl_ : 0;
         const int ray = s_pray[pl];
         const int g = min(ray / rays_per_pose, a.G - 1);
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         }
         // (the next iteration's first barrier orders its scratch writes after these reads)
     }
+    }   // sub-batches
 
     // ---- flush: the 8 pair slots of the workgroup first add up in LDS (the weight tables are dead by now and become the
     // accumulators), then every entry goes to global memory with one atomic
@@ -354,8 +363,6 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     for (int i = tid; i < nq * VOL; i += AB_THREADS) {
         const float v = s_gvol[i / VOL][i % VOL];
         if (v != 0.f) atomicAdd(a.g_vol + ((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL, v);
-    }
-    __syncthreads();     // the next item re-stages every LDS table
     }
 }
 
