@@ -118,29 +118,38 @@ struct TrunkPackArgs {
     _Float16* packed;
 };
 
+// grid: 8 x 32 workgroups for the max |w| of pts_linears.0..7, then 128 workgroups -- one per row n of W_fv, thread = column f
+constexpr int PREP_MAX_WGS = 32;
 __global__ __launch_bounds__(256) void k_trunk_prep(TrunkPackArgs a) {
     __shared__ float s_m[4];
-    const int m = blockIdx.y;           // matrix: 0..7 pts_linears, 8: W_fv
+    __shared__ float s_row[W_];
     float mx = 0.f;
-    if (m < 8) {
+    int m;
+    if ((int)blockIdx.x < 8 * PREP_MAX_WGS) {
+        m = blockIdx.x / PREP_MAX_WGS;
+        const int part = blockIdx.x % PREP_MAX_WGS;
         const long n = (long)W_ * (m == 0 ? IN_CH : (m == 5 ? IN_CH + W_ : W_));
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) mx = fmaxf(mx, fabsf(a.pts_w[m][i]));
+        for (long i = (long)part * blockDim.x + threadIdx.x; i < n; i += (long)PREP_MAX_WGS * blockDim.x) mx = fmaxf(mx, fabsf(a.pts_w[m][i]));
     } else {
+        m = 8;
+        const int n = blockIdx.x - 8 * PREP_MAX_WGS, f = threadIdx.x;
         const int ld = W_ + a.Cv;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < VW_ * W_ + VW_; i += gridDim.x * blockDim.x) {
-            if (i < VW_ * W_) {
-                const int n = i / W_, f = i % W_;
-                double acc = 0.0;
-                for (int c = 0; c < W_; ++c) acc += (double)a.views_w[(size_t)n * ld + c] * (double)a.feature_w[(size_t)c * W_ + f];
-                a.wfv[i] = (float)acc;
-                mx = fmaxf(mx, fabsf((float)acc));
-            } else {
-                const int n = i - VW_ * W_;
-                double acc = 0.0;
-                for (int c = 0; c < W_; ++c) acc += (double)a.views_w[(size_t)n * ld + c] * (double)a.feature_b[c];
-                a.b_eff[n] = (float)((double)a.views_b[n] + acc);
-            }
-        }
+        s_row[f] = a.views_w[(size_t)n * ld + f];
+        __syncthreads();
+        // W_fv[n, f] = sum_c W_v[n, c] W_f[c, f] in fp64: the merged matrix is as exact as its factors
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < W_; ++c) acc = fma((double)s_row[c], (double)a.feature_w[(size_t)c * W_ + f], acc);
+        a.wfv[n * W_ + f] = (float)acc;
+        mx = fabsf((float)acc);
+        // b_eff[n] = b_v[n] + sum_c W_v[n, c] b_f[c]
+        double pb = (double)s_row[f] * (double)a.feature_b[f];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pb += __shfl_xor(pb, off, 64);
+        __shared__ double s_pb[4];
+        if ((threadIdx.x & 63) == 0) s_pb[threadIdx.x >> 6] = pb;
+        __syncthreads();
+        if (threadIdx.x == 0) a.b_eff[n] = (float)((double)a.views_b[n] + ((s_pb[0] + s_pb[1]) + (s_pb[2] + s_pb[3])));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -648,7 +657,7 @@ extern "C" int danbo_trunk_pack(const DanboTrunkWeights* w, void* stream) {
     for (int i = 0; i < 8; ++i) { DANBO_CHECK_ARG(w->pts_w[i]); a.pts_w[i] = w->pts_w[i]; }
     a.feature_w = w->feature_w; a.feature_b = w->feature_b; a.views_w = w->views_w; a.views_b = w->views_b; a.Cv = w->view_ch;
     a.wfv = w->wfv; a.b_eff = w->b_eff; a.wmax = w->wmax; a.winv = w->winv; a.packed = reinterpret_cast<_Float16*>(w->packed);
-    hipLaunchKernelGGL(k_trunk_prep, dim3(32, 9), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

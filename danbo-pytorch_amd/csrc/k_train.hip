@@ -269,6 +269,34 @@ __global__ __launch_bounds__(256) void k_fill_raw_lazy(const float4* __restrict_
 
 #define DANBO_TRY(call) do { const int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
 
+// Independent branches of the step run on side streams (fork: the side stream waits for an event recorded on the caller's
+// stream; join: the caller's stream waits for the side stream's event).  Inside a stream capture these cross-stream waits become
+// the edges of the HIP graph, so a replay runs the branches concurrently.  One set per device, created on first use -- which
+// has to be an eager call (the trainer warms the step up before it captures it): streams cannot be created during a capture.
+struct SideStreams {
+    hipStream_t s[2];
+    hipEvent_t fork, join[2];
+    bool ok;
+};
+static SideStreams* side_streams() {
+    static SideStreams per_dev[64];
+    static std::atomic<unsigned long long> made{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideStreams& ss = per_dev[dev & 63];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(made.load(std::memory_order_acquire) & bit)) {
+        ss.ok = hipStreamCreateWithFlags(&ss.s[0], hipStreamNonBlocking) == hipSuccess &&
+                hipStreamCreateWithFlags(&ss.s[1], hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.join[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.join[1], hipEventDisableTiming) == hipSuccess;
+        if (!ss.ok) (void)hipGetLastError();
+        made.fetch_or(bit, std::memory_order_release);
+    }
+    return ss.ok ? &ss : nullptr;
+}
+
 }  // namespace
 
 extern "C" size_t danbo_train_workspace(const DanboTrainModel* m, int R, int G, int S, int Sf, int chunk) {
@@ -321,34 +349,51 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // (the environment is read ONCE per process, not per step)
     static const int stop_after = [] { const char* e = getenv("DANBO_TRAIN_STOP_AFTER"); return e ? atoi(e) : 1000; }();
 #define DANBO_STAGE(n) do { if (stop_after <= (n)) { DANBO_LAUNCH_RET(); } } while (0)
+    bool fused_tail = false;
     if (phase != 2) {
     // ---- zero: counters, running maxima, loss terms, volume / per-ray gradients; the flat parameter gradient
     zero_words(b.zero_begin, (long)((b.zero_end - b.zero_begin) / 4), m->g_flat, (long)m->n_flat, st);
 
-    // ---- packings of the current weights; adjacency products; volume-scale loss
-    DANBO_TRY(danbo_trunk_pack(&tw, stream));
-    hipLaunchKernelGGL(k_train_small, dim3(1), dim3(256), 0, st, m->p[DANBO_T_G_ADJW0], m->g_adj0, m->p[DANBO_T_G_ADJW1], m->g_adj1,
+    // ---- three independent prologues, concurrently:
+    //   side 0: trunk weight packing -> per-ray view inputs -> view constants (needs b_eff)
+    //   side 1: adjacency products + volume-scale loss -> assignment-net packing -> pose GNN (volumes)
+    //   main  : ray bounds -> stratified depths -> coarse cull
+    SideStreams* ss = side_streams();
+    void* s0 = stream;
+    void* s1 = stream;
+    if (ss) {
+        if (hipEventRecord(ss->fork, st) != hipSuccess) return (int)hipGetLastError();
+        if (hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess)
+            return (int)hipGetLastError();
+        s0 = ss->s[0];
+        s1 = ss->s[1];
+    }
+    auto join = [&](int i) -> int {
+        if (!ss) return 0;
+        if (hipEventRecord(ss->join[i], ss->s[i]) != hipSuccess || hipStreamWaitEvent(st, ss->join[i], 0) != hipSuccess) return (int)hipGetLastError();
+        return 0;
+    };
+    const float* axis_scale = m->p[DANBO_T_AXIS_SCALE];
+    DANBO_TRY(danbo_trunk_pack(&tw, s0));
+    DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
+                                      m->code_size, bt->cam_idx, b.vin, LD_VIN, s0));
+    DANBO_TRY(danbo_train_cview(b.vin, LD_VIN, m->view_ch, m->p[DANBO_T_VIEWS_W], b.b_eff, R, b.cview, s0));
+    hipLaunchKernelGGL(k_train_small, dim3(1), dim3(256), 0, (hipStream_t)s1, m->p[DANBO_T_G_ADJW0], m->g_adj0, m->p[DANBO_T_G_ADJW1], m->g_adj1,
                        m->p[DANBO_T_A_ADJW], m->a_adj, b.adj_prod, m->p[DANBO_T_AXIS_SCALE], m->init_scale, m->vol_scale_penalty,
                        m->g[DANBO_T_AXIS_SCALE], b.loss);
     const float* adjw0 = b.adj_prod;
     const float* adjw1 = b.adj_prod + J * J;
     const float* adjw_a = b.adj_prod + 2 * J * J;
-    DANBO_TRY(danbo_assign16_pack(m->p[DANBO_T_A_W0], adjw_a, m->p[DANBO_T_A_W1], b.assign16, stream));
-    DANBO_STAGE(1);
-
-    // ---- bounds, depths (reference raycasters.py:310-311), pose volumes, per-ray view inputs and view constants
-    const float* axis_scale = m->p[DANBO_T_AXIS_SCALE];
+    DANBO_TRY(danbo_assign16_pack(m->p[DANBO_T_A_W0], adjw_a, m->p[DANBO_T_A_W1], b.assign16, s1));
+    DANBO_TRY(danbo_pose_volumes_fwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], adjw0, m->p[DANBO_T_G_B0],
+                                     m->p[DANBO_T_G_W1], adjw1, m->p[DANBO_T_G_B1], m->p[DANBO_T_G_W2], m->p[DANBO_T_G_B2],
+                                     m->p[DANBO_T_G_W3], m->p[DANBO_T_G_B3], b.vol_scratch, b.volumes, s1));
+    // ---- bounds, depths (reference raycasters.py:310-311)
     DANBO_TRY(danbo_near_far_cylinder(bt->rays_o, bt->rays_d, bt->cyls, R, G, 0.f, 1.f, bt->near_in, bt->far_in, bt->chunk, b.cyl_scratch,
                                       b.near, b.far, stream));
     if (m->use_volume_near_far)
         DANBO_TRY(danbo_near_far_boxes(bt->rays_o, bt->rays_d, bt->skts, m->align, axis_scale, R, G, b.near, b.far, stream));
     DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, bt->t_rand, b.z_c, stream));
-    DANBO_TRY(danbo_pose_volumes_fwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], adjw0, m->p[DANBO_T_G_B0],
-                                     m->p[DANBO_T_G_W1], adjw1, m->p[DANBO_T_G_B1], m->p[DANBO_T_G_W2], m->p[DANBO_T_G_B2],
-                                     m->p[DANBO_T_G_W3], m->p[DANBO_T_G_B3], b.vol_scratch, b.volumes, stream));
-    DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
-                                      m->code_size, bt->cam_idx, b.vin, LD_VIN, stream));
-    DANBO_TRY(danbo_train_cview(b.vin, LD_VIN, m->view_ch, m->p[DANBO_T_VIEWS_W], b.b_eff, R, b.cview, stream));
     DANBO_STAGE(2);
 
     // ---- one network pass over the compacted rows
@@ -361,11 +406,13 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, bits, b.row_sample + R, b.cnt,
                                   stream));
         NET_STAGE(21);
+        if (pass == 0) DANBO_TRY(join(1));       // the pose volumes and the assignment net's packing
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,
                                                     b.row_sample + R, b.cnt, pass == 0 ? nullptr : b.cnt + 1, ncap - R, b.assign16,
                                                     m->p[DANBO_T_A_B0], m->p[DANBO_T_A_B1], m->p[DANBO_T_A_W2], m->p[DANBO_T_A_B2],
                                                     b.h_rows + (size_t)R * 16, stream));
         NET_STAGE(22);
+        if (pass == 0) DANBO_TRY(join(0));       // the trunk's packing and the view constants
         // encoding, trunk, heads, raw of the pass (and the row bookkeeping: cnt[1..7], row_ray) in ONE kernel
         return danbo_trunk_fwd(&tw, &trw, pass, stream);
     };
@@ -402,10 +449,25 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // ---- the input-gradient chain over the rows of both passes: d raw -> d pre_v -> dz_7 .. dz_0 -> d h
     DANBO_TRY(danbo_trunk_bwd(&tw, &trw, stream));
     DANBO_STAGE(9);
-    // ---- per-ray view gradients: d cview, views_linears.0's per-ray columns, per-camera sums for the frame codes
+    // ---- three independent branches behind the chain:
+    //   side 0: per-ray view gradients (d cview, views_linears.0's per-ray columns, per-camera sums for the frame codes)
+    //   side 1: (whole step only) weight / bias gradients of all dense layers, then -- with side 0's camera sums -- the chain rule of
+    //           the merged feature / view layer and the frame codes
+    //   main  : K2 / K1b adjoint -> pose GNN adjoint
+    if (ss) {
+        if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+        if (phase == 0 && hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+    }
     DANBO_TRY(danbo_train_view_grads(b.dpre_v, b.row_ray, b.cnt, ncap, R, b.vin, LD_VIN, m->view_ch, bt->cam_idx, m->n_codes, b.d_cview, b.csum,
-                                     m->g[DANBO_T_VIEWS_W], stream));
-    // ---- K2 / K1b adjoint, pose GNN adjoint
+                                     m->g[DANBO_T_VIEWS_W], s0));
+    if (phase == 0 && ss) {
+        DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, s1));
+        if (hipEventRecord(ss->join[0], ss->s[0]) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->join[0], 0) != hipSuccess)
+            return (int)hipGetLastError();
+        DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W],
+                                         m->view_ch, m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B],
+                                         m->g[DANBO_T_VIEWS_W], m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, s1));
+    }
     DANBO_TRY(danbo_train_bone_lists(b.bits_c, b.bits_f, b.row_sample, b.cnt, R, ncap, b.lists, b.cntb, stream));
     DANBO_STAGE(10);
     DanboAssignBwd ab{};
@@ -428,16 +490,20 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                      m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
                                      m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, stream));
     DANBO_STAGE(12);
+    if (phase == 0 && ss) DANBO_TRY(join(1));      // (side 1 has waited for side 0)
+    else DANBO_TRY(join(0));
+    fused_tail = phase == 0 && ss != nullptr;
     }   // phase != 2
     if (phase == 1) { DANBO_LAUNCH_RET(); }
     // ---- weight / bias gradients of all dense layers (last: it needs nothing but the activations and their gradients, and
     //      data-parallel training hides the all-reduce of everything computed so far -- 7 of the 10 MB -- under it), then the
-    //      chain rule of the merged feature / view layer and the frame codes
-    const int32_t* all_rows2 = b.cnt + 4;
-    DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, all_rows2, DW_SLICES, b.dw_scratch, stream));
-    DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W], m->view_ch,
-                                     m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B], m->g[DANBO_T_VIEWS_W],
-                                     m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, stream));
+    //      chain rule of the merged feature / view layer and the frame codes.  (The whole-step call has run both on side 1.)
+    if (!fused_tail) {
+        DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, stream));
+        DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W], m->view_ch,
+                                         m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B], m->g[DANBO_T_VIEWS_W],
+                                         m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, stream));
+    }
     // ---- loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
     hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),
                        reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),

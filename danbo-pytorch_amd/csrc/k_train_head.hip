@@ -14,6 +14,7 @@
 namespace danbo {
 
 constexpr int HW = 256, HVW = 128;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------------------------
 // cview[r, f] = b_eff[f] + sum_k vin[r, k] W_v[f, 256 + k]:  128 threads = features, 8 rays per workgroup
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(128) void k_train_ray_grad(const float* __restrict_
 // g_views_w[f, 256 + k] += sum_r d cview[r, f] vin[r, k]   (blockIdx.x < k-groups of 8 columns, blockIdx.y = ray slice)
 // csum[cam(r), f]      += d cview[r, f]                      (the last blockIdx.x; running sum per camera)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int VG_K = 8;
+constexpr int VG_K = 8, VG_SLICES = 32;
 __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict__ d_cview, const float* __restrict__ vin, int ldv, int Cv,
                                                          int R, const int64_t* __restrict__ cam_idx, int n_codes, float* __restrict__ g_views_w,
                                                          float* __restrict__ csum) {
@@ -88,12 +89,30 @@ __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict
     const int r_begin = blockIdx.y * per, r_end = min(r_begin + per, R);
     if ((int)blockIdx.x < kgroups) {
         const int k0 = blockIdx.x * VG_K;
+        // the 8 view inputs of a ray are wave-uniform (scalar loads); four rays in flight per iteration
         float acc[VG_K];
 #pragma unroll
         for (int j = 0; j < VG_K; ++j) acc[j] = 0.f;
-        for (int r = r_begin; r < r_end; ++r) {
+        const bool full = k0 + VG_K <= Cv;
+        int r = r_begin;
+        for (; r + 4 <= r_end && full; r += 4) {
+            float dc[4];
+            f32x4v v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dc[u] = d_cview[(size_t)(r + u) * HVW + f];
+                const f32x4v* vp = reinterpret_cast<const f32x4v*>(vin + (size_t)(r + u) * ldv + k0);
+                v[u][0] = vp[0];
+                v[u][1] = vp[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VG_K; ++j) acc[j] = fmaf(dc[u], v[u][j >> 2][j & 3], acc[j]);
+        }
+        for (; r < r_end; ++r) {
             const float dc = d_cview[(size_t)r * HVW + f];
-            const float* v = vin + (size_t)r * ldv + k0;      // ldv is a multiple of 4 and >= Cv rounded up: in bounds
+            const float* v = vin + (size_t)r * ldv + k0;
 #pragma unroll
             for (int j = 0; j < VG_K; ++j) acc[j] = fmaf(dc, k0 + j < Cv ? v[j] : 0.f, acc[j]);
         }
@@ -186,13 +205,13 @@ extern "C" int danbo_train_view_grads(const float* dpre_v, const int32_t* row_ra
                                       int ldv, int view_ch, const int64_t* cam_idx, int n_codes, float* d_cview /*[R,128] zeroed*/,
                                       float* csum /*[n_codes,128] zeroed*/, float* g_views_w /*accumulated*/, void* stream) {
     DANBO_CHECK_ARG(dpre_v && row_ray && cnt && vin && d_cview && g_views_w && rows_cap > 0 && R > 0 && view_ch >= 0 && ldv % 4 == 0);
-    DANBO_CHECK_ARG(ldv >= view_ch);
+    DANBO_CHECK_ARG(ldv >= view_ch && (uintptr_t)vin % 16 == 0);
     DANBO_CHECK_ARG(n_codes == 0 || csum);
     const int chunks = (rows_cap + RG_CHUNK - 1) / RG_CHUNK;
     hipLaunchKernelGGL(k_train_ray_grad, dim3(chunks < num_cu() * 8 ? chunks : num_cu() * 8), dim3(128), 0, (hipStream_t)stream, dpre_v, row_ray,
                        cnt, R, d_cview);
     const int kgroups = (view_ch + VG_K - 1) / VG_K;
-    hipLaunchKernelGGL(k_train_view_grad, dim3(kgroups + 1, 8), dim3(128), 0, (hipStream_t)stream, d_cview, vin, ldv, view_ch, R, cam_idx,
+    hipLaunchKernelGGL(k_train_view_grad, dim3(kgroups + 1, VG_SLICES), dim3(128), 0, (hipStream_t)stream, d_cview, vin, ldv, view_ch, R, cam_idx,
                        n_codes, g_views_w, csum);
     DANBO_LAUNCH_RET();
 }
