@@ -56,20 +56,12 @@ SIGNATURES = {
     "danbo_render_frame": [P, P, I, I, P, P, c_size_t, P],
     # ---- training step
     "danbo_composite_bwd_lazy": [P, P, P, P, P, I, I, F, P, P, P, P, P],
-    "danbo_linear16_ex": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P, P],
-    "danbo_linear16_group_bytes": [P, I],
-    "danbo_linear16_pack_group": [P, I, P, P, P, P, P],
     "danbo_dw16_scratch_floats": [P, I, I],
     "danbo_dw16": [P, I, I, P, I, P, P],
     "danbo_gather_assign_blend16_train": [P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P],
     "danbo_train_view_inputs": [P, P, I, I, I, I, I, P, I, I, P, P, I, P],
-    "danbo_train_rows_fwd": [P, P, P, I, I, I, I, I, P, I, P, I, P, P, P],
-    "danbo_train_rgb_head_fwd": [P, P, I, P, P, P, P, I, I, I, P, P, P, P],
     "danbo_train_loss_grad": [P, P, P, P, P, P, I, I, I, F, F, P, P, P, P, P, P],
     "danbo_train_draw_unmerge": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P],
-    "danbo_train_rgb_head_bwd": [P, P, P, P, P, P, I, I, P, P, P, P, P, P],
-    "danbo_train_code_grad": [P, I, I, I, P, P, P, I, I, P, P],
-    "danbo_train_pe_bwd": [P, I, P, I, I, P, P, I, I, I, P, P],
     "danbo_train_bone_lists": [P, P, P, P, I, I, P, P, P],
     "danbo_assign_blend_bwd": [P, P],
     "danbo_pose_volumes_bwd": [P, I, I, I] + [P] * 24,
@@ -86,7 +78,7 @@ SIGNATURES = {
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
 }
 # everything else returns int (0 = ok)
-RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t, "danbo_linear16_group_bytes": c_long,
+RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t,
             "danbo_dw16_scratch_floats": c_long}
 
 
@@ -122,16 +114,6 @@ TRAIN_TENSORS = (
     + ["alpha_linear.weight", "alpha_linear.bias", "feature_linear.weight", "feature_linear.bias", "views_linears.0.weight",
        "views_linears.0.bias", "rgb_linear.weight", "rgb_linear.bias", "framecodes.codes.weight"])
 N_TRAIN_TENSORS = len(TRAIN_TENSORS)   # DANBO_T_COUNT
-
-
-class DanboLinearEx(ctypes.Structure):
-    _fields_ = [("first", P), ("relu_in", P), ("relu_out", P), ("mask_cols", I), ("in_maxabs", P), ("out_maxabs", P), ("wscale_inv", P),
-                ("frag", I)]
-
-
-class DanboPackDesc(ctypes.Structure):
-    _fields_ = ([("w", P), ("w2", P)] + [(n, c_long) for n in ("sn", "sk", "sn2", "sk2")]
-                + [(n, I) for n in ("N", "K1", "K2", "n_shift", "split_n", "split_k", "frag_in")])
 
 
 class DanboDwLayer(ctypes.Structure):

@@ -198,7 +198,7 @@ class DanboTrainEngine:
             rnd['_u'] = u
             rnd['t_rand'], rnd['u_rand'] = u[:R * S].view(R, S), u[R * S:].view(R, Sf)
         if self.fixed_draws is None and raw_noise_std > 0.:
-            nz = torch.randn(R * (2 * S + Sf), device=dev).mul_(raw_noise_std * B)
+            nz = torch.empty(R * (2 * S + Sf), device=dev).normal_(0.0, raw_noise_std * B)      # randn * std * B in one launch
             rnd['_n'] = nz
             rnd['noise_c'], rnd['noise_f'] = nz[:R * S].view(R, S), nz[R * S:].view(R, S + Sf)
         out = dict(rgb_map=(R, 3), disp_map=(R,), acc_map=(R,), alpha=(R, S + Sf), weights=(R, S + Sf), rgb0=(R, 3), disp0=(R,),

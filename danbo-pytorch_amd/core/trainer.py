@@ -80,6 +80,60 @@ def allreduce_gradients(params, world=None):
     return flat.numel()
 
 
+class LazyLossDict(dict):
+    """The loss terms of a fused step as device tensors, formed on first access: the step leaves them in one [4] tensor (rgb,
+    coarse rgb, sum (label - q)^2, volume scale); a loop that does not look at them (every iteration that does not print)
+    launches nothing for them."""
+
+    def __init__(self, ls, ss_coef, with_ss, with_vol):
+        super().__init__()
+        self._src = (ls, ss_coef, with_ss, with_vol)
+
+    def _fill(self):
+        if self._src is not None:
+            ls, ss_coef, with_ss, with_vol = self._src
+            self._src = None
+            terms = {'rgb_loss': ls[0], 'rgb_loss0': ls[1]}
+            if with_ss:
+                terms['soft_softmax_loss'] = ls[2] * ss_coef
+            if with_vol:
+                terms['vol_scale_loss'] = ls[3]
+            terms['total_loss'] = sum(terms.values())
+            dict.update(self, terms)
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
+
 class Trainer:
     def __init__(self, args, data_attrs, optimizer, pose_optimizer=None, render_kwargs_train=None,
                  render_kwargs_test=None, popt_kwargs=None, device=None):
@@ -132,13 +186,7 @@ class Trainer:
         lr, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, self.optimizer, global_step, args.decay_unit)
         caster.update_embed_fns(global_step, args)
         R = out['rgb_map'].shape[0]
-        ls = out['loss']
-        loss = {'rgb_loss': ls[0], 'rgb_loss0': ls[1]}
-        if args.agg_type == 'sigmoid':
-            loss['soft_softmax_loss'] = ls[2] * (args.soft_softmax_loss_coef / (R * (S + Sf)))
-        if args.opt_vol_scale:
-            loss['vol_scale_loss'] = ls[3]
-        loss['total_loss'] = sum(loss.values())
+        loss = LazyLossDict(out['loss'], args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale))
         stats = dict(lrate=lr)
         if sync_stats:      # one device-to-host copy; the loop asks for it only when it prints
             bgs = batch.get('bgs', 1.0)

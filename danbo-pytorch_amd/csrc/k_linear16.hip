@@ -63,81 +63,6 @@ __global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Grouped packing for the training step: every layer of the MLP in both orientations (forward W, backward W^T) is
-// re-packed after each optimizer step by TWO launches -- per-matrix max |w|, then the fragments with every matrix
-// multiplied by the power of two that puts its largest entry into [2^13, 2^14): the lo halves of small weights
-// would otherwise be fp16 subnormals (absolute floor 2^-25), and the kernel's epilogue multiplies by the exact inverse.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int L16_MAX_GROUP = 28;
-struct PackGroupArgs {
-    DanboPackDesc d[L16_MAX_GROUP];
-    long chunk0[L16_MAX_GROUP + 1];   // first 32 KB chunk of each matrix in the grouped buffer (prefix sums)
-    int n;
-    _Float16* packed;
-    float* wmax;        // [n]
-    float* wscale_inv;  // [n]
-};
-
-__device__ __forceinline__ float pack_fetch(const DanboPackDesc& d, int n, int col) {
-    int nn = n + d.n_shift;
-    if (nn >= d.N) nn -= d.N;
-    if (nn >= d.split_n) return d.w2[(long)(nn - d.split_n) * d.sn2 + (long)col * d.sk2];
-    if (col >= d.split_k) return d.w2[(long)nn * d.sn2 + (long)(col - d.split_k) * d.sk2];
-    return d.w[(long)nn * d.sn + (long)col * d.sk];
-}
-
-__global__ __launch_bounds__(256) void k_linear16_group_max(PackGroupArgs a) {
-    __shared__ float s_m[4];
-    const int m = blockIdx.y;
-    const DanboPackDesc& d = a.d[m];
-    const int K = d.K1 + d.K2;
-    float mx = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)d.N * K; i += (long)gridDim.x * blockDim.x)
-        mx = fmaxf(mx, fabsf(pack_fetch(d, (int)(i / K), (int)(i % K))));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        if (mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.wmax + m), __builtin_bit_cast(unsigned, mx));
-    }
-}
-
-__global__ __launch_bounds__(256) void k_linear16_group_pack(PackGroupArgs a) {
-    const int m = blockIdx.y;
-    const DanboPackDesc& d = a.d[m];
-    const int NH = d.N <= 256 ? 1 : 2;
-    const int KS1 = (d.K1 + 31) / 32, KS = KS1 + (d.K2 + 31) / 32;
-    // power of two that puts the largest |w| into [2^13, 2^14)
-    const unsigned E = (__builtin_bit_cast(unsigned, a.wmax[m]) >> 23) & 255u;
-    unsigned se = (E == 0u || E == 255u) ? 127u : 267u - E;
-    se = se < 1u ? 1u : (se > 253u ? 253u : se);
-    const float sc = __builtin_bit_cast(float, se << 23);
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.wscale_inv[m] = __builtin_bit_cast(float, (254u - se) << 23);
-    const long total = (long)KS * NH * (L16_CHUNK / 2);
-    _Float16* out = a.packed + a.chunk0[m] * (L16_CHUNK / 2);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int chunk = (int)(idx / (L16_CHUNK / 2)), within = (int)(idx % (L16_CHUNK / 2));
-        const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
-        const int s = chunk / NH, hf = chunk % NH;
-        const int n = 16 * (16 * hf + (piece >> 1)) + (lane & 15);
-        const int kk_rows = 8 * (lane >> 4) + e, kk_frag = 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);   // see k_linear16_pack
-        int col = -1;
-        if (s < KS1) {
-            const int kk = (d.frag_in & 1) ? kk_frag : kk_rows;
-            if (32 * s + kk < d.K1) col = 32 * s + kk;
-        } else {
-            const int kk = (d.frag_in & 2) ? kk_frag : kk_rows;
-            if (32 * (s - KS1) + kk < d.K2) col = d.K1 + 32 * (s - KS1) + kk;
-        }
-        const float v = (n < d.N && col >= 0) ? pack_fetch(d, n, col) * sc : 0.f;
-        const _Float16 hi = (_Float16)v;
-        out[idx] = (piece & 1) ? (_Float16)(v - (float)hi) : hi;
-    }
-}
-
 struct Lin16Args {
     const float* x1;
     const float* x2;
@@ -155,27 +80,7 @@ struct Lin16Args {
     // 64-byte pieces of sixteen rows -- the row-major epilogue drains at 16 B/clk per CU (s_memtime: 14 000 cycles per tile).
     int frag;
     long long* trace;  // dev tool (tools/micro_linear16.py --trace): s_memtime stamps of one wavefront, or nullptr
-    // ---- EXT instantiations only (training step, danbo_linear16_ex) ----
-    const int32_t* first;      // device scalar: first row of x1 / x2 / y / mask this call works on, or nullptr (0)
-    // ReLU sign bits, 64 per (row, q = lane / 16): bit 4 T + i <-> column 16 T + 4 q + i (T < 16), i.e. exactly the columns
-    // lane (row, q) holds in its accumulators -- the forward layer writes the word pair it will need in the adjoint
-    const uint2* relu_in;      // [M, 4]: y[row, c] is zeroed where the recorded activation was <= 0, for c < mask_cols; or nullptr
-    uint2* relu_out;           // [M, 4]: receives [y > 0] of the first 256 columns; or nullptr
-    int mask_cols;
-    const float* in_maxabs;    // device scalar max |x| of the inputs: they are pre-scaled by a power of two into fp16's
-                               // comfortable range (gradients are ~1e-6), the result is scaled back; or nullptr
-    float* out_maxabs;         // device scalar, atomic max |y| over everything stored (the next layer's in_maxabs), or nullptr
-    const float* wscale_inv;   // device scalar: 1 / (power of two the packed weights were multiplied by), or nullptr
 };
-
-// power of two s with max * s in [8, 16) (1 for max == 0 / non-finite), and its exact reciprocal
-__device__ __forceinline__ void lin_pow2_scale(float maxabs, float& s, float& inv) {
-    const unsigned E = (__builtin_bit_cast(unsigned, maxabs) >> 23) & 255u;
-    unsigned se = (E == 0u || E == 255u) ? 127u : 257u - E;
-    se = se < 1u ? 1u : (se > 253u ? 253u : se);
-    s = __builtin_bit_cast(float, se << 23);
-    inv = __builtin_bit_cast(float, (254u - se) << 23);
-}
 
 struct LinPipe {
     const char* src_lane;   // packed + wave * 4096 + lane * 16: this lane's 16 bytes of piece 4 * wave of chunk 0
@@ -256,7 +161,7 @@ __device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
 
 // NP: tile pairs in the last chunk of a k-step known at compile time (no branches in the batch loop), 0 = taken from N
 // FRAG: Lin16Args::frag as a compile-time constant (a run-time choice costs the registers this kernel does not have)
-template <int NH, int NP, bool TRACE, bool EXT, int FRAG = 0>
+template <int NH, int NP, bool TRACE, int FRAG = 0>
 __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + L16_SLOTS * L16_CHUNK);
@@ -265,19 +170,6 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     const int M = resolve_count(a.count, a.M);
     const int n_tiles = (M + L16_BM - 1) / L16_BM;
     if ((int)blockIdx.x >= n_tiles) return;
-    float in_scale = 1.f, out_scale = 1.f, seen_max = 0.f;
-    if (EXT) {
-        if (a.first != nullptr) {
-            const long r0 = *a.first;      // a multiple of 128 when any operand is in fragment order (the caller's contract)
-            a.x1 += (FRAG & 1) ? (r0 >> 4) * (a.K1 >> 5) * 512 : r0 * a.ld1;
-            if (a.x2 != nullptr) a.x2 += (FRAG & 2) ? (r0 >> 4) * (a.K2 >> 5) * 512 : r0 * a.ld2;
-            a.y += (FRAG & 4) ? (r0 >> 4) * (a.N >> 5) * 512 : r0 * a.ldy;
-            if (a.relu_in != nullptr) a.relu_in += r0 * 4;
-            if (a.relu_out != nullptr) a.relu_out += r0 * 4;
-        }
-        if (a.in_maxabs != nullptr) lin_pow2_scale(*a.in_maxabs, in_scale, out_scale);
-        if (a.wscale_inv != nullptr) out_scale *= *a.wscale_inv;
-    }
     const int KS1 = (a.K1 + 31) / 32, KS = KS1 + (a.K2 + 31) / 32, nt = (a.N + 15) / 16;
     const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int G = my_tiles * KS;  // k-steps this workgroup runs
@@ -319,10 +211,6 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     {
         float x[8];
         lin_take_rows<0>(x);
-        if (EXT) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] *= in_scale;
-        }
         lin_split8(x, bh, bl);
         request(std::integral_constant<int, 0>{});
     }
@@ -384,7 +272,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                 if (hf == 0 && b >= 3 && b <= 6) {
 #pragma unroll
                     for (int e = 2 * (b - 3); e < 2 * (b - 3) + 2; ++e) {
-                        const float xe = EXT ? nx[e] * in_scale : nx[e];
+                        const float xe = nx[e];
                         const _Float16 hh = (_Float16)xe;
                         nbh[e] = hh;
                         nbl[e] = (_Float16)(xe - (float)hh);
@@ -415,18 +303,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         // skip their wait: a vmcnt wait right behind 28 stores per lane would stall every wavefront until the stores have
         // reached memory; this way they have two chunks of MFMA work to drain under.
         const long row = (long)(blockIdx.x + it * gridDim.x) * L16_BM + wave * 16 + n;
-        unsigned long long relu_w = 0;
-        unsigned new_lo = 0, new_hi = 0;
-        if (EXT && a.relu_in != nullptr) {
-            // the recorded ReLU bits of this lane's columns: requested and waited for in ONE asm statement, together with
-            // everything else in flight -- a load the compiler tracks would make it put s_waitcnt vmcnt(0) in front of every
-            // use, i.e. between the stores below, and each store would wait for the previous one to reach memory
-            const uint2* rp = a.relu_in + (row < M ? row : M - 1) * 4 + q;
-            asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(relu_w) : "v"(rp) : "memory");
-        } else {
-            __builtin_amdgcn_s_waitcnt(0xF70);
-        }
-        const unsigned relu_lo = (unsigned)relu_w, relu_hi = (unsigned)(relu_w >> 32);
+        __builtin_amdgcn_s_waitcnt(0xF70);
         p.skip = 2;
         if (FRAG & 4) {
             // fragment-order output: tile T of this wavefront's 16 rows is one contiguous KB (rows past M: padding of the buffer)
@@ -435,36 +312,13 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
 #pragma unroll
             for (int T = 0; T < 16 * NH; ++T) {
                 if (16 * T < a.N) {
-                    f32x4 v = EXT ? acc[T] * out_scale + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q)
-                                  : acc[T] + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q);
+                    f32x4 v = acc[T] + *reinterpret_cast<const f32x4*>(s_bias + 16 * T + 4 * q);
                     if (a.act == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                     }
-                    if (EXT && T < 16) {   // N <= 256 in the training instantiations: the recorded / recording ReLU bits as below
-                        const unsigned nib = (T < 8 ? relu_lo >> (4 * T) : relu_hi >> (4 * (T - 8))) & 15u;
-                        if (a.relu_in != nullptr && 16 * T + 4 * q < a.mask_cols) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = ((nib >> i) & 1u) ? v[i] : 0.f;
-                        }
-                        if (NH == 1 && a.relu_out != nullptr) {
-                            unsigned nb = 0;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) nb |= (v[i] > 0.f ? 1u : 0u) << i;
-                            if (T < 8) new_lo |= nb << (4 * T);
-                            else new_hi |= nb << (4 * (T - 8));
-                        }
-                    }
-                    if (EXT && a.out_maxabs != nullptr && row < M) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) seen_max = fmaxf(seen_max, fabsf(v[i]));
-                    }
                     asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yf + 256 * T), "v"(v) : "memory");
                 }
-            }
-            if (EXT && NH == 1 && a.relu_out != nullptr && row < M) {
-                const unsigned long long nw = (unsigned long long)new_lo | ((unsigned long long)new_hi << 32);
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(a.relu_out + row * 4 + q), "v"(nw) : "memory");
             }
         } else
         if (row < M) {
@@ -473,32 +327,10 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
             for (int T = 0; T < 16 * NH; ++T) {
                 const int col = 16 * T + 4 * q;
                 if (col < a.N) {
-                    f32x4 v = EXT ? acc[T] * out_scale + *reinterpret_cast<const f32x4*>(s_bias + col)
-                                  : acc[T] + *reinterpret_cast<const f32x4*>(s_bias + col);
+                    f32x4 v = acc[T] + *reinterpret_cast<const f32x4*>(s_bias + col);
                     if (a.act == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                    }
-                    if (EXT) {
-                        if (T < 16) {   // ReLU bits of columns 16 T + 4 q .. + 3 (T < 16: at most 256 masked / recorded columns)
-                            const unsigned nib = (T < 8 ? relu_lo >> (4 * T) : relu_hi >> (4 * (T - 8))) & 15u;
-                            if (a.relu_in != nullptr && col < a.mask_cols) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] = ((nib >> i) & 1u) ? v[i] : 0.f;
-                            }
-                            if (NH == 1 && a.relu_out != nullptr) {   // recording layers are 256 / 128 wide
-                                unsigned nb = 0;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) nb |= (v[i] > 0.f ? 1u : 0u) << i;
-                                if (T < 8) new_lo |= nb << (4 * T);
-                                else new_hi |= nb << (4 * (T - 8));
-                            }
-                        }
-                        if (a.out_maxabs != nullptr) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (col + i < a.N) seen_max = fmaxf(seen_max, fabsf(v[i]));
-                        }
                     }
                     // inline asm like the loads: no compiler-inserted waits.  The hand-over waits stay valid with stores in
                     // flight even if stores and loads complete out of order with respect to each other: they allow no more
@@ -511,10 +343,6 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                     }
                 }
             }
-            if (EXT && NH == 1 && a.relu_out != nullptr) {
-                const unsigned long long nw = (unsigned long long)new_lo | ((unsigned long long)new_hi << 32);
-                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(a.relu_out + row * 4 + q), "v"(nw) : "memory");
-            }
         }
         stamp();
         s = 0;
@@ -526,22 +354,6 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         if (g + 1 < G) kstep(std::integral_constant<int, 0>{}, g + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA still in flight must not outlive the workgroup's LDS
-    if (EXT && a.out_maxabs != nullptr) {
-        // one atomic per WORKGROUP: 2 048 wavefronts raising the same word serialise in the L2 (measured: ~20 us per launch)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) seen_max = fmaxf(seen_max, __shfl_xor(seen_max, off, 64));
-        __syncthreads();                       // the ring is dead: its first bytes carry the per-wave maxima
-        float* s_mx = reinterpret_cast<float*>(smem);
-        if (lane == 0) s_mx[wave] = seen_max;
-        __syncthreads();
-        if (tid == 0) {
-            float mx = 0.f;
-#pragma unroll
-            for (int w = 0; w < L16_THREADS / 64; ++w) mx = fmaxf(mx, s_mx[w]);
-            // non-negative floats order like their bit patterns; NaN / inf propagate as "huge" and poison the next scale on purpose
-            if (mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.out_maxabs), __builtin_bit_cast(unsigned, mx));
-        }
-    }
 }
 
 static inline int lin16_nh(int N) { return N <= 256 ? 1 : 2; }
@@ -596,15 +408,14 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
     DANBO_CHECK_ARG((frag & 4) || (ldy >= N && ldy % 4 == 0));
     DANBO_CHECK_ARG((uintptr_t)x1 % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
     if (M == 0) return 0;
-    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, g_lin16_trace,
-                nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, g_lin16_trace};
     const int tiles = (M + L16_BM - 1) / L16_BM;
     const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
     const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;   // tile pairs in the last chunk of a k-step
 #define DANBO_L16_GO(NH_, NP_, TR_, FR_)                                                                                   \
     {                                                                                                                      \
-        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, TR_, false, FR_>), L16_LDS_BYTES);                                          \
-        hipLaunchKernelGGL((k_linear16<NH_, NP_, TR_, false, FR_>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);   \
+        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, TR_, FR_>), L16_LDS_BYTES);                                          \
+        hipLaunchKernelGGL((k_linear16<NH_, NP_, TR_, FR_>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);   \
     }
 #define DANBO_L16_SHAPES(FR_)                                                                                              \
     {                                                                                                                      \
@@ -626,87 +437,5 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
     else return DANBO_EINVAL;
 #undef DANBO_L16_SHAPES
 #undef DANBO_L16_GO
-    DANBO_LAUNCH_RET();
-}
-
-// the training step's variant: device-side first row, ReLU-adjoint mask, power-of-two pre-scales, running max |y|
-extern "C" int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
-                                 const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count,
-                                 const DanboLinearEx* ex, void* stream) {
-    DANBO_CHECK_ARG(ex && x1 && packed && y && N >= 1 && N <= L16_MAX_N && K1 >= 1 && K2 >= 0 && (K2 == 0 || x2) && M >= 0);
-    DANBO_CHECK_ARG(act == 0 || act == 1);
-    DANBO_CHECK_ARG((ex->frag & 4) || (ldy >= N && ldy % 4 == 0));
-    DANBO_CHECK_ARG((ex->frag & 1) || (ld1 % 4 == 0 && ld1 >= ((K1 + 3) & ~3)));
-    DANBO_CHECK_ARG((ex->frag & 2) || K2 == 0 || (ld2 % 4 == 0 && ld2 >= ((K2 + 3) & ~3)));
-    DANBO_CHECK_ARG((uintptr_t)x1 % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
-    DANBO_CHECK_ARG(ex->relu_in == nullptr || (ex->mask_cols >= 0 && ex->mask_cols <= 256 && ex->mask_cols % 4 == 0));
-    DANBO_CHECK_ARG(ex->relu_out == nullptr || N <= 256);
-    if (M == 0) return 0;
-    const int frag = ex->frag;
-    DANBO_CHECK_ARG(frag == 0 || frag == 1 || frag == 4 || frag == 5 || frag == 6);
-    DANBO_CHECK_ARG(!(frag & 1) || K1 % 32 == 0);
-    DANBO_CHECK_ARG(!(frag & 2) || (K2 > 0 && K2 % 32 == 0));
-    DANBO_CHECK_ARG(!(frag & 4) || N % 32 == 0);
-    DANBO_CHECK_ARG(frag == 0 || N <= 256);    // the 257 .. 512-wide training instantiation has no registers for it
-    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, nullptr,
-                ex->first, (const uint2*)ex->relu_in, (uint2*)ex->relu_out, ex->mask_cols, ex->in_maxabs, ex->out_maxabs,
-                ex->wscale_inv};
-    const int tiles = (M + L16_BM - 1) / L16_BM;
-    const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
-    const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;
-#define DANBO_L16_GO(NH_, NP_, FR_)                                                                                        \
-    {                                                                                                                      \
-        DANBO_ENSURE_LDS((k_linear16<NH_, NP_, false, true, FR_>), L16_LDS_BYTES);                                         \
-        hipLaunchKernelGGL((k_linear16<NH_, NP_, false, true, FR_>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);  \
-    }
-#define DANBO_L16_NH1(FR_)                                                                                                 \
-    {                                                                                                                      \
-        if (np == 8) DANBO_L16_GO(1, 8, FR_)                                                                               \
-        else DANBO_L16_GO(1, 0, FR_)                                                                                       \
-    }
-    if (nh == 2) DANBO_L16_GO(2, 0, 0)
-    else if (frag == 0) DANBO_L16_NH1(0)
-    else if (frag == 1) DANBO_L16_NH1(1)
-    else if (frag == 4) DANBO_L16_NH1(4)
-    else if (frag == 5) DANBO_L16_NH1(5)
-    else DANBO_L16_NH1(6)
-#undef DANBO_L16_NH1
-#undef DANBO_L16_GO
-    DANBO_LAUNCH_RET();
-}
-
-extern "C" long danbo_linear16_group_bytes(const DanboPackDesc* descs, int n) {
-    if (!descs || n < 1 || n > L16_MAX_GROUP) return -1;
-    long total = 0;
-    for (int i = 0; i < n; ++i) {
-        const int b = danbo_linear16_packed_bytes(descs[i].N, descs[i].K1, descs[i].K2);
-        if (b < 0) return -1;
-        total += b;
-    }
-    return total;
-}
-
-extern "C" int danbo_linear16_pack_group(const DanboPackDesc* descs, int n, void* packed, long* offsets, float* wmax,
-                                         float* wscale_inv, void* stream) {
-    DANBO_CHECK_ARG(descs && n >= 1 && n <= L16_MAX_GROUP && packed && wmax && wscale_inv);
-    PackGroupArgs a;
-    a.n = n;
-    a.packed = (_Float16*)packed;
-    a.wmax = wmax;
-    a.wscale_inv = wscale_inv;
-    long chunk = 0;
-    for (int i = 0; i < n; ++i) {
-        const int b = danbo_linear16_packed_bytes(descs[i].N, descs[i].K1, descs[i].K2);
-        DANBO_CHECK_ARG(b > 0 && descs[i].w != nullptr);
-        a.d[i] = descs[i];
-        a.chunk0[i] = chunk;
-        if (offsets) offsets[i] = chunk * L16_CHUNK;
-        chunk += b / L16_CHUNK;
-    }
-    a.chunk0[n] = chunk;
-    hipStream_t st = (hipStream_t)stream;
-    zero_words(wmax, n, nullptr, 0, st);
-    hipLaunchKernelGGL(k_linear16_group_max, dim3(16, n), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_linear16_group_pack, dim3(32, n), dim3(256), 0, st, a);
     DANBO_LAUNCH_RET();
 }

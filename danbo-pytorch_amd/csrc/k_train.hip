@@ -358,9 +358,12 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     //   side 0: trunk weight packing -> per-ray view inputs -> view constants (needs b_eff)
     //   side 1: adjacency products + volume-scale loss -> assignment-net packing -> pose GNN (volumes)
     //   main  : ray bounds -> stratified depths -> coarse cull
+    static const int fork_mask = [] { const char* e = getenv("DANBO_TRAIN_FORK"); return e ? atoi(e) : 3; }();   // dev: 1 prologue, 2 backward
     SideStreams* ss = side_streams();
     void* s0 = stream;
     void* s1 = stream;
+    SideStreams* const ss_all = ss;
+    if (!(fork_mask & 1)) ss = nullptr;
     if (ss) {
         if (hipEventRecord(ss->fork, st) != hipSuccess) return (int)hipGetLastError();
         if (hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess)
@@ -454,6 +457,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     //   side 1: (whole step only) weight / bias gradients of all dense layers, then -- with side 0's camera sums -- the chain rule of
     //           the merged feature / view layer and the frame codes
     //   main  : K2 / K1b adjoint -> pose GNN adjoint
+    ss = (fork_mask & 2) ? ss_all : nullptr;
+    if (ss) { s0 = ss->s[0]; s1 = ss->s[1]; } else { s0 = stream; s1 = stream; }
     if (ss) {
         if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
         if (phase == 0 && hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();

@@ -1,6 +1,7 @@
 // Row-wise glue kernels of the training step (everything between the hand-written stages that is not a GEMM):
-// per-ray view inputs, positional encoding of the blended features and its adjoint, the colour head and its adjoint,
-// the loss gradients, un-merging of the composite gradients, frame-code gradients, per-bone pair lists, Adam.
+// per-ray view inputs, the loss gradients, un-merging of the composite gradients, per-bone pair lists, Adam.
+// (The positional encoding, the colour head and their adjoints live in the fused trunk kernels, k_mlp16.hip / k_mlp16_bwd.hip;
+// the frame-code gradients in k_train_head.hip.)
 // Reference: core/networks/nerf.py:176-209,252-279 (inference / encode_views), core/cutoff_embedder.py:62-73 (Embedder),
 // core/trainer.py:396-422,507-536 (losses), torch.optim.Adam as configured by core/raycasters.py:75.  gfx950 only.
 //
@@ -11,6 +12,7 @@
 //   rows [R + n_c, R + n_c + n_f)   importance samples inside >= 1 volume
 // cnt[] (device int32): [0] running compaction counter (n_c after the coarse cull, n_c + n_f after the second),
 //   [1] n_c, [2] R + n_c, [3] n_f, [4] R + n_c + n_f, [5] n_c + n_f, [6] (R + n_c) rounded down to 128, [7] n_f + (R + n_c) % 128
+//   ([1] .. [7] are derived by block 0 of the trunk's forward kernel of each pass, k_mlp16.hip)
 #include "common.hpp"
 
 namespace danbo {
@@ -82,96 +84,6 @@ __global__ __launch_bounds__(256) void k_train_view_inputs(const float* __restri
             out = codes[ci * Cf + (c - nd)];
         }
         vin[idx] = out;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// rows of one pass: positional encoding of h, the ray's view inputs, ray of the row, derived counters
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_train_rows_fwd(const float* __restrict__ h_rows, const int32_t* __restrict__ row_sample,
-                                                        int32_t* __restrict__ cnt, int pass, int R, int S_pass, int L,
-                                                        const float* __restrict__ vin, int ldv, float* __restrict__ pe, int ldp,
-                                                        float* __restrict__ vinr, int32_t* __restrict__ row_ray) {
-    const int n_run = cnt[0];
-    const int first = pass == 0 ? 0 : R + cnt[1];
-    const int rows = pass == 0 ? R + n_run : n_run - cnt[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (pass == 0) { cnt[1] = n_run; cnt[2] = R + n_run; }
-        else {
-            cnt[3] = rows; cnt[4] = first + rows; cnt[5] = n_run;
-            // the importance pass for kernels that work on 128-row tiles of fragment-order buffers: it starts at the tile boundary
-            // at or below its first row and recomputes the (identical) coarse rows in between
-            cnt[6] = first & ~127; cnt[7] = rows + (first & 127);
-        }
-    }
-    const int npe = FEAT * (1 + 2 * L);
-    // one thread per (row, 4-column group) of [pe | vinr]
-    const int gp = ldp / 4, gv = ldv / 4, gpr = gp + gv;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)rows * gpr; idx += (long)gridDim.x * blockDim.x) {
-        const int i = first + (int)(idx / gpr), gq = (int)(idx % gpr);
-        const bool empty = i < R;
-        const int ray = empty ? i : row_sample[i] / S_pass;
-        if (gq == 0) row_ray[i] = ray;
-        if (gq < gp) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 4 * gq + e;
-                float v = 0.f;
-                if (c < npe) {
-                    if (c < FEAT) v = empty ? 0.f : h_rows[(size_t)i * 16 + c];
-                    else {
-                        const int b = (c - FEAT) / FEAT, k = (c - FEAT) % FEAT, l = b >> 1;
-                        const float x = empty ? 0.f : h_rows[(size_t)i * 16 + k];
-                        float sn, cs;
-                        pe_sincos(mul_rn(x, (float)(1 << l)), &sn, &cs);
-                        v = (b & 1) ? cs : sn;
-                    }
-                }
-                o[e] = v;
-            }
-            *reinterpret_cast<f32x4*>(pe + (size_t)i * ldp + 4 * gq) = o;
-        } else {
-            const int c = 4 * (gq - gp);
-            *reinterpret_cast<f32x4*>(vinr + (size_t)i * ldv + c) = *reinterpret_cast<const f32x4*>(vin + (size_t)ray * ldv + c);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// colour head: raw = (rgb_linear(hv), alpha) per row, scattered to the dense raw tensor of the pass / the ray's empty raw
-// 32 lanes per row (4 columns of hv each)
-// ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a wave half
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__global__ __launch_bounds__(256) void k_train_rgb_head_fwd(const float* __restrict__ hv, const float* __restrict__ fa, int ldfa,
-                                                            const float* __restrict__ rgb_w, const float* __restrict__ rgb_b,
-                                                            const int32_t* __restrict__ row_sample, const int32_t* __restrict__ cnt,
-                                                            int pass, int R, float* __restrict__ raw_rows,
-                                                            float* __restrict__ raw_dense, float* __restrict__ raw_empty) {
-    const int first = pass == 0 ? 0 : cnt[2];
-    const int rows = pass == 0 ? cnt[2] : cnt[3];
-    const int sub = threadIdx.x & 31;
-    const long slot = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5, nslots = ((long)gridDim.x * blockDim.x) >> 5;
-    f32x4 w[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) w[c] = *reinterpret_cast<const f32x4*>(rgb_w + c * 128 + 4 * sub);
-    for (long k = slot; k < rows; k += nslots) {
-        const int i = first + (int)k;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(hv + (size_t)i * 128 + 4 * sub);
-        float o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = half_wave_sum(x[0] * w[c][0] + x[1] * w[c][1] + x[2] * w[c][2] + x[3] * w[c][3]) + rgb_b[c];
-        if (sub == 0) {
-            const f32x4 r4 = {o[0], o[1], o[2], fa[(size_t)i * ldfa + 256]};
-            *reinterpret_cast<f32x4*>(raw_rows + (size_t)i * 4) = r4;
-            float* dst = i < R ? raw_empty + (size_t)i * 4 : raw_dense + (size_t)row_sample[i] * 4;
-            *reinterpret_cast<f32x4*>(dst) = r4;
-        }
     }
 }
 
@@ -263,104 +175,6 @@ __global__ __launch_bounds__(256) void k_train_draw_unmerge(float4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// adjoint of the colour head, per row (32 lanes per row):  d raw (gathered from the dense gradients; rows < R already
-// hold the ray sums) -> d_raw_rows (kept: dy of rgb_linear), dpre_v = (d_rgb rgb_w) * [hv > 0], d_alpha4[row] = (d alpha, 0, 0, 0)
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_train_rgb_head_bwd(const float* __restrict__ hv, const float* __restrict__ rgb_w,
-                                                            const float4* __restrict__ d_raw_c, const float4* __restrict__ d_raw_f,
-                                                            const int32_t* __restrict__ row_sample, const int32_t* __restrict__ cnt, int R,
-                                                            float4* __restrict__ d_raw_rows, float* __restrict__ dpre_v,
-                                                            float4* __restrict__ d_alpha4, float* __restrict__ max_v,
-                                                            float* __restrict__ max_a) {
-    const int rows = cnt[4], first_f = cnt[2];
-    const int sub = threadIdx.x & 31;
-    const long slot = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5, nslots = ((long)gridDim.x * blockDim.x) >> 5;
-    f32x4 w[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) w[c] = *reinterpret_cast<const f32x4*>(rgb_w + c * 128 + 4 * sub);
-    float mv = 0.f, ma = 0.f;
-    for (long k = slot; k < rows; k += nslots) {
-        const int i = (int)k;
-        float4 d;
-        if (i < R) d = d_raw_rows[i];
-        else d = i < first_f ? d_raw_c[row_sample[i]] : d_raw_f[row_sample[i]];
-        const f32x4 x = *reinterpret_cast<const f32x4*>(hv + (size_t)i * 128 + 4 * sub);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float g = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e];
-            o[e] = x[e] > 0.f ? g : 0.f;
-            mv = fmaxf(mv, fabsf(o[e]));
-        }
-        *reinterpret_cast<f32x4*>(dpre_v + (size_t)i * 128 + 4 * sub) = o;
-        if (sub == 0) {
-            if (i >= R) d_raw_rows[i] = d;
-            d_alpha4[i] = make_float4(d.w, 0.f, 0.f, 0.f);
-            ma = fmaxf(ma, fabsf(d.w));
-        }
-    }
-    __shared__ float s_red[4];
-    block_atomic_max(max_v, mv, s_red);
-    block_atomic_max(max_a, ma, s_red);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// frame-code gradient: g_codes[cam(ray(row)), :] += d_vin[row, code columns]   (embedding backward).  128-thread workgroups
-// own a chunk of consecutive rows (rows of one image are consecutive: the running sum is flushed when the camera changes)
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int CODE_CHUNK = 64;
-__global__ __launch_bounds__(128) void k_train_code_grad(const float* __restrict__ d_vfeat, int ldvf, int col0, int Cf,
-                                                         const int32_t* __restrict__ row_ray, const int64_t* __restrict__ cam_idx,
-                                                         const int32_t* __restrict__ cnt, int n_codes, float* __restrict__ g_codes) {
-    const int rows = cnt[4];
-    const int c = threadIdx.x;
-    for (int base = blockIdx.x * CODE_CHUNK; base < rows; base += gridDim.x * CODE_CHUNK) {
-        float acc = 0.f;
-        long cur = -1;
-        const int end = min(base + CODE_CHUNK, rows);
-        for (int i = base; i < end; ++i) {
-            long ci = cam_idx ? cam_idx[row_ray[i]] : 0;
-            ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
-            if (ci != cur) {
-                if (cur >= 0 && c < Cf && acc != 0.f) atomicAdd(g_codes + cur * Cf + c, acc);
-                cur = ci;
-                acc = 0.f;
-            }
-            if (c < Cf) acc += d_vfeat[(size_t)i * ldvf + col0 + c];
-        }
-        if (cur >= 0 && c < Cf && acc != 0.f) atomicAdd(g_codes + cur * Cf + c, acc);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// adjoint of the positional encoding: d h[c] = d pe[c] + sum_l 2^l (cos(2^l h_c) d pe[sin_l c] - sin(2^l h_c) d pe[cos_l c]),
-// d pe = (layer-0 input gradient) + (skip layer's input gradient); in-volume rows only
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_train_pe_bwd(const float* __restrict__ d_x0, int ld0, const float* __restrict__ d_x5, int ld5,
-                                                      int col5, const float* __restrict__ h_rows, const int32_t* __restrict__ cnt, int R,
-                                                      int L, float* __restrict__ d_h) {
-    const int rows = cnt[5];
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)rows * 16; idx += (long)gridDim.x * blockDim.x) {
-        const int i = R + (int)(idx >> 4), c = (int)(idx & 15);
-        float g = 0.f;
-        if (c < FEAT) {
-            const float* a = d_x0 + (size_t)i * ld0;
-            const float* b = d_x5 + (size_t)i * ld5 + col5;
-            const float x = h_rows[(size_t)i * 16 + c];
-            g = a[c] + b[c];
-            for (int l = 0; l < L; ++l) {
-                const float f = (float)(1 << l);
-                float sn, cs;
-                pe_sincos(mul_rn(x, f), &sn, &cs);
-                const int is = FEAT + 2 * FEAT * l + c, ic = is + FEAT;
-                g += f * (cs * (a[is] + b[is]) - sn * (a[ic] + b[ic]));
-            }
-        }
-        d_h[(size_t)i * 16 + c] = g;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // per-bone lists of (row) pairs: bone j's list holds every in-volume row whose sample lies inside bone j's volume
 // (wave-aggregated appends: one atomic per wavefront and bone)
 // ------------------------------------------------------------------------------------------------------------------
@@ -441,25 +255,6 @@ extern "C" int danbo_train_view_inputs(const float* rays_d, const float* skts, i
     DANBO_LAUNCH_RET();
 }
 
-extern "C" int danbo_train_rows_fwd(const float* h_rows, const int32_t* row_sample, int32_t* cnt, int pass, int R, int S_pass,
-                                    int rows_cap, int L_voxel, const float* vin, int ldv, float* pe, int ldp, float* vinr,
-                                    int32_t* row_ray, void* stream) {
-    DANBO_CHECK_ARG(h_rows && row_sample && cnt && vin && pe && vinr && row_ray && (pass == 0 || pass == 1) && R > 0 && S_pass > 0);
-    DANBO_CHECK_ARG(ldv % 4 == 0 && ldp % 4 == 0 && ldp >= FEAT * (1 + 2 * L_voxel) && rows_cap > 0);
-    hipLaunchKernelGGL(k_train_rows_fwd, dim3(stream_grid((long)rows_cap * ((ldp + ldv) / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       h_rows, row_sample, cnt, pass, R, S_pass, L_voxel, vin, ldv, pe, ldp, vinr, row_ray);
-    DANBO_LAUNCH_RET();
-}
-
-extern "C" int danbo_train_rgb_head_fwd(const float* hv, const float* fa, int ldfa, const float* rgb_w, const float* rgb_b,
-                                        const int32_t* row_sample, const int32_t* cnt, int pass, int R, int rows_cap, float* raw_rows,
-                                        float* raw_dense, float* raw_empty, void* stream) {
-    DANBO_CHECK_ARG(hv && fa && rgb_w && rgb_b && row_sample && cnt && raw_rows && raw_dense && raw_empty && ldfa > 256);
-    hipLaunchKernelGGL(k_train_rgb_head_fwd, dim3(stream_grid((long)rows_cap * 32, 256)), dim3(256), 0, (hipStream_t)stream, hv, fa, ldfa,
-                       rgb_w, rgb_b, row_sample, cnt, pass, R, raw_rows, raw_dense, raw_empty);
-    DANBO_LAUNCH_RET();
-}
-
 extern "C" int danbo_train_loss_grad(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
                                      const float* bgs, int use_bg, int R, int mse, float w_fine, float w_coarse, float* g_rgb,
                                      float* g_acc, float* g_rgb0, float* g_acc0, float* loss, void* stream) {
@@ -479,33 +274,6 @@ extern "C" int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorte
                        reinterpret_cast<float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_sorted), order, bits_c, bits_f, weights,
                        alpha, R, S, Sf, reinterpret_cast<float4*>(d_raw_f), reinterpret_cast<float4*>(d_raw_rows), label_c, label_f, loss,
                        maxabs);
-    DANBO_LAUNCH_RET();
-}
-
-extern "C" int danbo_train_rgb_head_bwd(const float* hv, const float* rgb_w, const float* d_raw_c, const float* d_raw_f,
-                                        const int32_t* row_sample, const int32_t* cnt, int R, int rows_cap, float* d_raw_rows,
-                                        float* dpre_v, float* d_alpha4, float* max_v, float* max_a, void* stream) {
-    DANBO_CHECK_ARG(hv && rgb_w && d_raw_c && d_raw_f && row_sample && cnt && d_raw_rows && dpre_v && d_alpha4 && max_v && max_a);
-    hipLaunchKernelGGL(k_train_rgb_head_bwd, dim3(few_grid((long)rows_cap * 32, 256)), dim3(256), 0, (hipStream_t)stream, hv, rgb_w,
-                       reinterpret_cast<const float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_f), row_sample, cnt, R,
-                       reinterpret_cast<float4*>(d_raw_rows), dpre_v, reinterpret_cast<float4*>(d_alpha4), max_v, max_a);
-    DANBO_LAUNCH_RET();
-}
-
-extern "C" int danbo_train_code_grad(const float* d_vfeat, int ldvf, int col0, int Cf, const int32_t* row_ray, const int64_t* cam_idx,
-                                     const int32_t* cnt, int rows_cap, int n_codes, float* g_codes, void* stream) {
-    DANBO_CHECK_ARG(d_vfeat && row_ray && cnt && g_codes && Cf >= 1 && Cf <= 128 && n_codes >= 1 && col0 >= 0 && ldvf >= col0 + Cf);
-    const int chunks = (rows_cap + CODE_CHUNK - 1) / CODE_CHUNK;
-    hipLaunchKernelGGL(k_train_code_grad, dim3(chunks < num_cu() * 8 ? chunks : num_cu() * 8), dim3(128), 0, (hipStream_t)stream, d_vfeat, ldvf,
-                       col0, Cf, row_ray, cam_idx, cnt, n_codes, g_codes);
-    DANBO_LAUNCH_RET();
-}
-
-extern "C" int danbo_train_pe_bwd(const float* d_x0, int ld0, const float* d_x5, int ld5, int col5, const float* h_rows,
-                                  const int32_t* cnt, int R, int rows_cap, int L_voxel, float* d_h, void* stream) {
-    DANBO_CHECK_ARG(d_x0 && d_x5 && h_rows && cnt && d_h && R > 0 && L_voxel >= 0);
-    hipLaunchKernelGGL(k_train_pe_bwd, dim3(stream_grid((long)rows_cap * 16, 256)), dim3(256), 0, (hipStream_t)stream, d_x0, ld0, d_x5, ld5,
-                       col5, h_rows, cnt, R, L_voxel, d_h);
     DANBO_LAUNCH_RET();
 }
 

@@ -322,50 +322,15 @@ int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const float* x2, i
 
 /* ---------------------------------------------------------------------------------------------
  * Training step (SURVEY 8b "+ _bwd"; reference core/trainer.py:257-302,563-576 = forward, loss, loss.backward(), Adam).
- * The dense layers of the density / colour MLP run layer by layer on the compacted in-volume rows:
- *   forward   y_l   = relu(x_l W_l^T + b_l)                       danbo_linear16_ex (activations kept for the backward)
- *   backward  dz_l-1 = (dz_l W_l) * [y_l-1 > 0]                    danbo_linear16_ex on the transposed packing, mask epilogue
- *             dW_l  = dz_l^T x_l,  db_l = sum_rows dz_l            danbo_dw16 (all layers in one launch, split over row slices)
- * all with fp32-accurate products on the fp16 matrix cores (hi/lo split).  Gradients are ~1e-6: every backward
- * GEMM pre-scales its gradient operand by a power of two taken from the running max |.| the producing kernel recorded
- * (in_maxabs / out_maxabs) and scales the result back -- exact, and it keeps the lo halves out of fp16's subnormals.
+ * The density / colour MLP runs on the compacted in-volume rows as
+ *   forward   danbo_trunk_fwd   one register-resident chain per pass (activations written once, in fragment order)
+ *   backward  danbo_trunk_bwd   the mirrored input-gradient chain dz_7 .. dz_0 -> d h
+ *             danbo_dw16        dW_l = dz_l^T x_l, db_l = sum_rows dz_l: all layers in one launch, split over row slices
+ * (declared further down), all with fp32-accurate products on the fp16 matrix cores (hi/lo split).  Gradients are ~1e-6:
+ * every backward GEMM pre-scales its gradient operand by a power of two (per 16-row group in the chain; from the running
+ * max |.| the chain recorded in the weight-gradient kernel) and scales the result back -- exact, and it keeps the lo halves
+ * out of fp16's subnormals.
  * ------------------------------------------------------------------------------------------- */
-typedef struct DanboLinearEx {
-    const int32_t* first;     /* device scalar: first row (x1, x2, y, mask are shifted by it), or NULL = 0 */
-    const void* relu_in;      /* [M, 4] x 64 bits recorded by the forward layer (relu_out): y[row, c] = 0 where the recorded
-                                 activation was <= 0, for c < mask_cols (<= 256, multiple of 4); or NULL */
-    void* relu_out;           /* [M, 4] x 64 bits: receives [y > 0] of columns < 256 (bit 4 T + i of word pair q <-> column
-                                 16 T + 4 q + i); or NULL */
-    int mask_cols;
-    const float* in_maxabs;   /* device scalar: max |x| over the inputs (power-of-two pre-scale), or NULL */
-    float* out_maxabs;        /* device scalar, atomically raised to max |y| (caller zeroes it), or NULL */
-    const float* wscale_inv;  /* device scalar written by danbo_linear16_pack_group for this matrix, or NULL (unscaled packing) */
-    int frag;                 /* fragment-order operands as in danbo_linear16_fwd_frag (bit 0: x1, 1: x2, 2: y; N <= 256; the
-                                 matrix packed with the matching DanboPackDesc.frag_in); *first must then be a multiple of 128 */
-} DanboLinearEx;
-int danbo_linear16_ex(const float* x1, int ld1, int K1, const float* x2, int ld2, int K2, const void* packed,
-                      const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count,
-                      const DanboLinearEx* ex, void* stream);
-
-/* One matrix of a grouped packing: W[n, k] (n < N output features, k < K1 + K2 inputs) is read as
- *   nn = (n + n_shift) mod N;  nn >= split_n ? w2[(nn - split_n) sn2 + k sk2] : k >= split_k ? w2[nn sn2 + (k - split_k) sk2]
- *                                                                             : w[nn sn + k sk]
- * (two source tensors: feature_linear + alpha_linear evaluated as one 257-wide layer, and its transpose; n_shift: the
- * adjoint of the skip layer writes [d h | d input] instead of [d input | d h] so that both halves start 16-byte aligned).
- * Unused splits: INT32_MAX. */
-typedef struct DanboPackDesc {
-    const float *w, *w2;
-    long sn, sk, sn2, sk2;
-    int N, K1, K2, n_shift, split_n, split_k;
-    int frag_in;              /* bit 0 / 1: the K1 / K2 input part arrives in fragment order (k-slot permutation of that part) */
-} DanboPackDesc;
-long danbo_linear16_group_bytes(const DanboPackDesc* descs, int n);
-/* packs n <= 28 matrices back to back into `packed` (offsets[i] = byte offset of matrix i, host array or NULL), each
- * multiplied by the power of two that puts its largest |w| into [2^13, 2^14); wscale_inv[i] (device) receives the inverse;
- * wmax [n] is device scratch.  Two launches. */
-int danbo_linear16_pack_group(const DanboPackDesc* descs, int n, void* packed, long* offsets, float* wmax,
-                              float* wscale_inv, void* stream);
-
 /* dW / db of up to 13 dense layers in one launch pair (csrc/k_dw16.hip).  dy [rows, ldy]: gradient with respect to the layer's
  * pre-activation; x1 | x2: the layer's input(s); gw [N, K1 + K2] and gb [N] in nn.Linear layout are OVERWRITTEN.  A layer
  * evaluated for two parameters at once (feature_linear + alpha_linear) writes rows >= split_n to gw2 / gb2.  16-byte aligned
@@ -396,13 +361,6 @@ int danbo_gather_assign_blend16_train(const float* rays_o, const float* rays_d, 
 /* per-ray view inputs [PE(dir) | frame code | 0] (nerf.py:252-279); ray_mode / normalise as danbo_view_consts */
 int danbo_train_view_inputs(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise, int L_view,
                             const float* codes, int n_codes, int Cf, const int64_t* cam_idx, float* vin, int ldv, void* stream);
-/* rows of one pass (0 coarse incl. the R empty rows, 1 importance): pe = PE_L(h) (cutoff_embedder.py:62-73), vinr = the ray's view inputs */
-int danbo_train_rows_fwd(const float* h_rows, const int32_t* row_sample, int32_t* cnt, int pass, int R, int S_pass, int rows_cap,
-                         int L_voxel, const float* vin, int ldv, float* pe, int ldp, float* vinr, int32_t* row_ray, void* stream);
-/* rgb_linear + assembly of raw = (rgb, alpha), scattered to the pass' dense raw / the rays' empty-space raw (nerf.py:200-209) */
-int danbo_train_rgb_head_fwd(const float* hv, const float* fa, int ldfa, const float* rgb_w, const float* rgb_b,
-                             const int32_t* row_sample, const int32_t* cnt, int pass, int R, int rows_cap, float* raw_rows,
-                             float* raw_dense, float* raw_empty, void* stream);
 /* d loss / d (rgb_map, acc_map) of both passes for L1 (mse = 0) or MSE on rgb + (1 - acc) bg (trainer.py:396-422);
  * loss[0] += fine term, loss[1] += coarse term */
 int danbo_train_loss_grad(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
@@ -414,14 +372,6 @@ int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorted, const in
                              const uint32_t* bits_f, const float* weights, const float* alpha, int R, int S, int Sf,
                              float* d_raw_f, float* d_raw_rows, uint8_t* label_c, uint8_t* label_f, float* loss, float* maxabs,
                              void* stream);
-int danbo_train_rgb_head_bwd(const float* hv, const float* rgb_w, const float* d_raw_c, const float* d_raw_f,
-                             const int32_t* row_sample, const int32_t* cnt, int R, int rows_cap, float* d_raw_rows, float* dpre_v,
-                             float* d_alpha4, float* max_v, float* max_a, void* stream);
-/* framecodes.codes.weight.grad[cam] += d vin[row, code columns] (embedding backward, core/networks/embedding.py:17-39) */
-int danbo_train_code_grad(const float* d_vfeat, int ldvf, int col0, int Cf, const int32_t* row_ray, const int64_t* cam_idx,
-                          const int32_t* cnt, int rows_cap, int n_codes, float* g_codes, void* stream);
-int danbo_train_pe_bwd(const float* d_x0, int ld0, const float* d_x5, int ld5, int col5, const float* h_rows, const int32_t* cnt,
-                       int R, int rows_cap, int L_voxel, float* d_h, void* stream);
 int danbo_train_bone_lists(const uint32_t* bits_c, const uint32_t* bits_f, const int32_t* row_sample, const int32_t* cnt, int R,
                            int rows_cap, int32_t* lists /*[24, rows_cap]*/, int32_t* cntb /*[24], zeroed by the caller*/, void* stream);
 

@@ -1,6 +1,5 @@
 """GPU tests of the hand-written training step (csrc/k_train.hip and its building blocks):
-  * the dense-layer kernels of the step against torch (forward with recorded ReLU bits, input gradients through the transposed
-    packing with the ReLU adjoint and power-of-two pre-scales at gradient magnitudes ~1e-7, grouped weight / bias gradients),
+  * the grouped weight / bias gradient kernel against torch (the fused trunk's forward and input-gradient chain: test_gpu_trunk.py),
   * the whole step -- losses and the gradient of EVERY parameter -- against the reference's own autograd on both training
     fixtures (danbo_train: D-H36M; danbo_perfcap_train: BASELINE config 4's network),
   * the fused step against this package's autograd path on the same batch, Adam against torch.optim.Adam, HIP-graph replay.
@@ -26,80 +25,17 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def pack_group(descs):
-    from core import _hip
-    arr = (_hip.DanboPackDesc * len(descs))(*descs)
-    nbytes = _hip.lib().danbo_linear16_group_bytes(arr, len(descs))
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    offs = (ctypes.c_long * len(descs))()
-    wmax = torch.empty(len(descs), device=DEV)
-    winv = torch.empty(len(descs), device=DEV)
-    _hip.check(_hip.lib().danbo_linear16_pack_group(arr, len(descs), P(packed), offs, P(wmax), P(winv), stream()), "pack_group")
-    return packed, list(offs), winv
-
-
-def desc(w, N, K1, K2=0, transposed=False, n_shift=0):
-    from core import _hip
-    NONE = 2 ** 31 - 1
-    ldw = w.shape[1]
-    sn, sk = (1, ldw) if transposed else (ldw, 1)
-    return _hip.DanboPackDesc(w=P(w), w2=None, sn=sn, sk=sk, sn2=0, sk2=0, N=N, K1=K1, K2=K2, n_shift=n_shift, split_n=NONE, split_k=NONE)
-
-
-def linear_ex(x1, K1, packed, off, N, bias=None, act=0, x2=None, K2=0, count=None, **ex):
-    from core import _hip
-    M = x1.shape[0]
-    ldy = (N + 3) // 4 * 4
-    y = torch.zeros(M, ldy, device=DEV)
-    e = _hip.DanboLinearEx(**{k: P(v) if torch.is_tensor(v) else v for k, v in ex.items()})
-    _hip.check(_hip.lib().danbo_linear16_ex(P(x1), x1.stride(0), K1, P(x2), 0 if x2 is None else x2.stride(0), K2,
-                                            ctypes.c_void_p(packed.data_ptr() + off), P(bias), N, act, P(y), ldy, M, P(count),
-                                            ctypes.byref(e), stream()), "linear16_ex")
-    return y[:, :N]
-
-
-def test_dense_layer_forward_backward_and_weight_gradients_match_torch():
+def test_grouped_weight_gradients_match_torch():
+    """danbo_dw16 on row-major operands: a two-input layer (the skip layer's shape), a 3-wide and a 1-wide layer in ONE launch,
+    gradient magnitudes ~1e-7 (power-of-two pre-scale from the recorded max), device-side row count below the capacity"""
     from core import _hip
     g = torch.Generator(device="cpu").manual_seed(0)
-    M, first, live = 1000, 37, 700
-    W5 = (torch.randn(256, 451, generator=g) * 0.05).to(DEV)       # the skip layer: inputs [pe 195 | y 256]
-    b5 = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    M, live = 1000, 700
     pe = torch.zeros(M, 196, device=DEV)
     pe[:, :195] = torch.randn(M, 195, generator=g).to(DEV)
     y4 = torch.relu(torch.randn(M, 256, generator=g)).to(DEV)
-    packed, offs, winv = pack_group([desc(W5, 256, 195, 256), desc(W5, 451, 256, transposed=True, n_shift=195)])
-    cnt = torch.tensor([first, live], dtype=torch.int32, device=DEV)
-    bits = torch.zeros(M, 4, 2, dtype=torch.int32, device=DEV)
-    y = linear_ex(pe, 195, packed, offs[0], 256, bias=b5, act=1, x2=y4, K2=256, count=cnt[1:], first=cnt[:1], relu_out=bits,
-                  wscale_inv=winv[:1])
-    ref = torch.relu(torch.cat([pe[:, :195], y4], 1).double() @ W5.double().t() + b5.double()).float()
-    sl = slice(first, first + live)
-    assert float((y[sl] - ref[sl]).abs().max()) <= 2e-5 * float(ref.abs().max())
-    assert float(y[:first].abs().max()) == 0.0 and float(y[first + live:].abs().max()) == 0.0     # rows outside [first, first + count)
-    # recorded ReLU bits: bit 4 T + i of word pair q <-> column 16 T + 4 q + i
-    words = bits.cpu().numpy().astype(np.uint32)
-    cols = np.arange(256)
-    Tt, qq, ii = cols // 16, (cols % 16) // 4, cols % 4
-    rec = (words[:, qq, Tt // 8] >> (4 * (Tt % 8) + ii)) & 1
-    assert np.array_equal(rec[sl].astype(bool), (y[sl] > 0).cpu().numpy())
-    # ---- input gradient at gradient magnitudes (~1e-7): dX = (dz W5) reordered [d y4 | d pe], ReLU adjoint on the first 256 columns
     dz = (torch.randn(M, 256, generator=g) * 1e-7).to(DEV)
-    mx_in = dz[sl].abs().max().reshape(1).clone()
-    mx_out = torch.zeros(1, device=DEV)
-    y4_bits = torch.zeros(M, 4, 2, dtype=torch.int32, device=DEV)      # bits of y4 itself (as layer 4's forward would record them)
-    y4w = (y4 > 0).cpu().numpy()
-    w = np.zeros((M, 4, 2), np.uint32)
-    for c in range(256):
-        w[:, (c % 16) // 4, (c // 16) // 8] |= (y4w[:, c].astype(np.uint32) << np.uint32(4 * ((c // 16) % 8) + c % 4))
-    y4_bits.copy_(torch.from_numpy(w.view(np.int32)))
-    dx = linear_ex(dz, 256, packed, offs[1], 451, count=cnt[1:], first=cnt[:1], relu_in=y4_bits, mask_cols=256, in_maxabs=mx_in,
-                   out_maxabs=mx_out, wscale_inv=winv[1:])
-    full = dz.double() @ W5.double()
-    ref_dx = torch.cat([full[:, 195:] * (y4 > 0), full[:, :195]], 1).float()
-    scale = float(ref_dx[sl].abs().max())
-    assert float((dx[sl] - ref_dx[sl]).abs().max()) <= 2e-5 * scale, (float((dx[sl] - ref_dx[sl]).abs().max()), scale)
-    assert abs(float(mx_out) - float(dx[sl].abs().max())) <= 1e-12
-    # ---- weight / bias gradients: dW [256, 451] = dz^T [pe | y4], plus a 3-wide and a 1-wide layer in the same launch
+    mx_in = dz[:live].abs().max().reshape(1).clone()
     d3 = torch.zeros(M, 4, device=DEV)
     d3[:, :3] = (torch.randn(M, 3, generator=g) * 1e-6).to(DEV)
     hv = torch.relu(torch.randn(M, 128, generator=g)).to(DEV)
@@ -109,17 +45,16 @@ def test_dense_layer_forward_backward_and_weight_gradients_match_torch():
     gw3, gb3 = torch.full((3, 128), 7., device=DEV), torch.full((3,), 7., device=DEV)
     gw1, gb1 = torch.full((1, 256), 7., device=DEV), torch.full((1,), 7., device=DEV)
     mx3 = d3.abs().max().reshape(1).clone()
-    # the grouped kernel has no first-row argument: hand it the live rows directly
     L = (_hip.DanboDwLayer * 3)(
-        _hip.DanboDwLayer(dy=P(dz[sl]), x1=P(pe[sl]), x2=P(y4[sl]), dy_maxabs=P(mx_in), gw=P(gw5), gb=P(gb5), ldy=256, ld1=196, ld2=256,
+        _hip.DanboDwLayer(dy=P(dz), x1=P(pe), x2=P(y4), dy_maxabs=P(mx_in), gw=P(gw5), gb=P(gb5), ldy=256, ld1=196, ld2=256,
                           N=256, K1=195, K2=256),
-        _hip.DanboDwLayer(dy=P(d3[sl]), x1=P(hv[sl]), dy_maxabs=P(mx3), gw=P(gw3), gb=P(gb3), ldy=4, ld1=128, N=3, K1=128),
-        _hip.DanboDwLayer(dy=P(d1[sl]), x1=P(y4[sl]), dy_maxabs=P(mx3), gw=P(gw1), gb=P(gb1), ldy=4, ld1=256, N=1, K1=256))
+        _hip.DanboDwLayer(dy=P(d3), x1=P(hv), dy_maxabs=P(mx3), gw=P(gw3), gb=P(gb3), ldy=4, ld1=128, N=3, K1=128),
+        _hip.DanboDwLayer(dy=P(d1), x1=P(y4), dy_maxabs=P(mx3), gw=P(gw1), gb=P(gb1), ldy=4, ld1=256, N=1, K1=256))
     slices = 5
     scratch = torch.empty(_hip.lib().danbo_dw16_scratch_floats(L, 3, slices), device=DEV)
     n_live = torch.tensor([live - 13], dtype=torch.int32, device=DEV)       # device-side row count below the capacity
     _hip.check(_hip.lib().danbo_dw16(L, 3, live, P(n_live), slices, P(scratch), stream()), "dw16")
-    rows = slice(first, first + live - 13)
+    rows = slice(0, live - 13)
     for gw, gb, dy, x in ((gw5, gb5, dz[rows], torch.cat([pe[rows, :195], y4[rows]], 1)), (gw3, gb3, d3[rows, :3], hv[rows]),
                           (gw1, gb1, d1[rows, :1], y4[rows])):
         ref_w = (dy.double().t() @ x.double()).float()
