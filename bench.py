@@ -319,9 +319,11 @@ def bench_train(args, rank, world, device, dist):
     S = targs.N_samples + targs.N_importance
     counts = trainer.last_preds["counts"].cpu().tolist()
     rows, in_vol = counts[4], counts[5]
-    # dense-layer work of a step: forward (pts 0..7, feature+alpha, view[411 in], rgb) + input gradients + weight gradients
-    mac_fwd = 195 * 256 + 4 * 256 * 256 + 451 * 256 + 2 * 256 * 256 + 257 * 256 + 411 * 128 + 128 * 3
-    mac_dx = 256 * 411 + 257 * 256 + 6 * 256 * 256 + 256 * 451 + 256 * 195          # view^T, fa^T, trunk 7..1 (5: 451 out), layer 0
+    # dense-layer work of a step as EXECUTED per row: forward (pts 0..7, alpha, the merged feature / view matrix W_fv 256 -> 128, rgb),
+    # input gradients (the transposed matrices), weight gradients (one N x K product per matrix and row)
+    mac_fwd = 195 * 256 + 4 * 256 * 256 + 451 * 256 + 2 * 256 * 256 + 256 + 256 * 128 + 128 * 3
+    mac_dx = 3 * 128 + 128 * 256 + 256 + 6 * 256 * 256 + 256 * 451 + 256 * 195    # rgb^T, W_fv^T, alpha, trunk 7..1 (5: 451 out), layer 0
+    mac_ref = 195 * 256 + 4 * 256 * 256 + 451 * 256 + 2 * 256 * 256 + 257 * 256 + 411 * 128 + 128 * 3   # the reference's forward per row
     ms = 1e3 * elapsed / args.steps
     if dist is not None:                 # whole-job executed rows: sum over the ranks
         rt = torch.tensor([float(rows), float(in_vol)], dtype=torch.float64, device="cpu" if args.debug_single_device else device)
@@ -332,14 +334,16 @@ def bench_train(args, rank, world, device, dist):
     peak = PEAK_FP16_MFMA / 3.0
     # HBM bytes of a step from the PMC passes of tools/pmc_train.sh, quoted only for the kernel sources they were measured on
     traffic, hbm = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_train.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_train.json")
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
-        if rec.get("kernel_src_sha16") == sha16("k_train.hip", "k_linear16.hip", "k_dw16.hip", "k_assign_bwd.hip", "k_train_rows.hip", "common.hpp"):
+        if rec.get("kernel_src_sha16") == sha16("k_train.hip", "k_mlp16.hip", "k_mlp16_bwd.hip", "mlp16_core.hpp", "k_dw16.hip", "k_assign_bwd.hip",
+                                                "k_train_rows.hip", "k_train_head.hip", "common.hpp"):
             traffic = rec["step_hbm_bytes"]
             hbm = dict(bytes_per_step=traffic, achieved=traffic / (ms * 1e-3) / 1e12, peak=8.0, unit="TB/s", frac=traffic / (ms * 1e-3) / 8e12,
-                       note="every activation and gradient of the trunk crosses HBM once per use (the backward needs them all); the "
-                            "weight-gradient kernel alone reads 1.3 GB at 3.4 TB/s")
+                       note="steady-state steps only (tools/pmc_train.sh); every activation and gradient of the trunk is written once "
+                            "(forward / input-gradient chain, fragment order) and read by the weight-gradient kernel, whose two "
+                            "128-column halves re-read part of the inputs: 1.3 GB of the step's bytes")
     result = {
         "metric": "training ray-samples/sec (PerfCap danbo_fast step: forward + losses + backward + Adam)", "value": R_global * S / (ms * 1e-3),
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -348,15 +352,17 @@ def bench_train(args, rank, world, device, dist):
                                (f"ONE batch of 3072 rays = 16 poses x 192 split by whole poses: {poses} poses = {R} rays per rank, " if strong
                                 else "3072 rays = 16 poses x 192 per rank, ") +
                                "32 + 16 samples, perturb = 1, raw_noise_std = 1, L1 + soft-softmax + volume-scale losses, Adam; "
-                               "danbo_train_step + danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
+                               "danbo_train_step (fused trunk: one forward kernel per pass, one input-gradient chain) + "
+                               "danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
                    "rays": R_global, "rays_per_rank": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
         "rows_per_step": rows, "in_volume_fraction": in_vol / (R_global * S), "loss": float(loss["total_loss"]),
-        "roofline": dict(bound="mfma", kernel="k_linear16<EXT> x 30 + k_dw16 (whole step)", achieved=achieved / 1e12, peak=peak / 1e12,
-                         unit="TFLOP/s", frac=achieved / peak, traffic=traffic, flop_per_row=2 * (2 * mac_fwd + mac_dx),
+        "roofline": dict(bound="mfma", kernel="k_train_mlp_fwd x 2 + k_train_mlp_bwd + k_dw16 (whole step)", achieved=achieved / 1e12,
+                         peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak, traffic=traffic, flop_per_row=2 * (2 * mac_fwd + mac_dx),
+                         flop_per_row_reference=2 * (3 * mac_ref),
                          peak_note=SPLIT_NOTE,
                          note="STEP-level lower bound, per GPU: executed dense-layer flops of the step (forward + input gradients + weight "
                               "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
-                              "per-kernel durations: profiles/r02*_train_kernel_stats.csv"),
+                              "per-kernel durations: profiles/r03_train_kernel_stats.csv"),
     }
     if hbm is not None:
         result["hbm"] = hbm
