@@ -23,7 +23,7 @@ value = N * K * units / max-over-ranks time.  `ranks_seen` = dist.get_world_size
 `value` of the render configs is measured with exact in-volume culling (bit-identical raw to evaluating every sample:
 `dense_equals_culled`); `dense_value` pushes every sample through every kernel (the reference's executed work).
 `roofline` is for the dominant kernel, EXECUTED flops only, its launch durations taken from HIP events inside the timed region.
-`roofline.traffic` is filled from profiles/r02_pmc_hbm.json only if that file was measured on the kernel sources being timed
+`roofline.traffic` is filled from profiles/r03_pmc_hbm.json only if that file was measured on the kernel sources being timed
 (sha recorded by tools/pmc_hbm.sh), else null.  `cpu_baseline`: oracle/torch_cpu.py (a multi-threaded torch-CPU restatement
 doing the reference's executed work) on a bounded sample of the same workload, best of 3.
 """
@@ -191,12 +191,12 @@ def bench_render(args, rank, world, device, dist):
     else:
         kernel, peak, peak_note = "k_pe_mlp", PEAK_FP32_MFMA, "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
     traffic, traffic_note = None, "no PMC profile of this build of the kernel under profiles/ (tools/pmc_hbm.sh)"
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")
     if os.path.exists(pmc) and args.mlp == "f16split" and args.config == 1:
         rec = json.load(open(pmc))
-        if rec.get("kernel_src_sha16") == sha16("k_mlp16.hip", "common.hpp"):
+        if rec.get("kernel_src_sha16") == sha16("k_mlp16.hip", "mlp16_core.hpp", "common.hpp"):
             traffic = rec["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
-            traffic_note = "HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source (profiles/r02_pmc_hbm.json)"
+            traffic_note = "HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source (profiles/r03_pmc_hbm.json)"
     # algorithmic HBM bytes of a launch: 84 B per row (64 B h + 4 B list entry + 16 B raw) + the 512-byte per-ray view constants of
     # every ray that owns >= 1 row (counted on the coarse pass of one extra, untimed frame)
     keep = eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"], N_SAMPLES, N_IMPORTANCE,

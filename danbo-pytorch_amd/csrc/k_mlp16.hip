@@ -297,8 +297,10 @@ __device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, c
                                              const float* aw, float& alpha_part, half8& bh, half8& bl, float winv = 1.f,
                                              const float* ybase = nullptr, const void* rbase = nullptr) {
     float v[8];
-    const float4 b0 = *reinterpret_cast<const float4*>(bias);
-    const float4 b1 = *reinterpret_cast<const float4*>(bias + 16);
+    // the tables are read with untracked ds_read (lds_table_read2): a read the compiler tracks makes it wait for every LDS-DMA
+    // load of the weight ring in flight first (it cannot tell the tables from the ring), i.e. drain the ring once per k-step
+    float4 b0, b1;
+    lds_table_read2(bias, b0, b1);
     if (TRAIN) {
         v[0] = fmaxf(fmaf(a0[0], winv, b0.x), 0.f); v[1] = fmaxf(fmaf(a0[1], winv, b0.y), 0.f);
         v[2] = fmaxf(fmaf(a0[2], winv, b0.z), 0.f); v[3] = fmaxf(fmaf(a0[3], winv, b0.w), 0.f);
@@ -311,8 +313,8 @@ __device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, c
         v[6] = fmaxf(a1[2] + b1.z, 0.f); v[7] = fmaxf(a1[3] + b1.w, 0.f);
     }
     if (ALPHA) {
-        const float4 w0 = *reinterpret_cast<const float4*>(aw);
-        const float4 w1 = *reinterpret_cast<const float4*>(aw + 16);
+        float4 w0, w1;
+        lds_table_read2(aw, w0, w1);
         alpha_part = fmaf(v[0], w0.x, alpha_part); alpha_part = fmaf(v[1], w0.y, alpha_part);
         alpha_part = fmaf(v[2], w0.z, alpha_part); alpha_part = fmaf(v[3], w0.w, alpha_part);
         alpha_part = fmaf(v[4], w1.x, alpha_part); alpha_part = fmaf(v[5], w1.y, alpha_part);

@@ -141,6 +141,13 @@ __device__ __forceinline__ float quad_sum(float p) {
     return p;
 }
 
+// p[0..3] and p[16..19] of an LDS table that is written once before the first barrier and never again, as two ds_read_b128 the
+// compiler does not track, waited for here
+__device__ __forceinline__ void lds_table_read2(const float* p, float4& a, float4& b) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+}
+
 // power of two that puts max |w| of a matrix into [2^13, 2^14) (1 for max == 0 / non-finite) and its exact reciprocal:
 // the lo halves of small weights would otherwise be fp16 subnormals; the consumer's epilogue multiplies by the inverse
 __device__ __forceinline__ void weight_pow2_scale(float maxabs, float& s, float& inv) {

@@ -1,5 +1,5 @@
 """Shader clock and socket power (hwmon of the visible GPU) while one kernel runs back to back (dev tool):
-    python tools/clock_trace.py [mlp16|linear16|idle] [seconds]
+    python tools/clock_trace.py [mlp16|mlp16z|linear16|copy|idle] [seconds]
 Samples freq1_input (sclk) and power1_input every ~2 ms from a thread while the main thread keeps the queue full."""
 import glob, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +26,9 @@ def main():
     d = hwmon()
     print("hwmon", d, "cap W", rd(d + "/power1_cap") / 1e6 if d else None)
     dev = torch.device("cuda:0")
+    zeros = what == "mlp16z"           # same launch, all-zero weights and inputs: identical instruction stream, no operand toggling
+    if zeros:
+        what = "mlp16"
     if what == "mlp16":
         import bench
         from core import hip_ops as ops
@@ -40,6 +43,12 @@ def main():
         h = ops.gather_assign_blend16(geo, vols, bits, eng.aw, eng.assign16, lst, cnt, geo.M)[0]
         raw = torch.zeros(geo.M, 4, device=dev)
         cview, _ = eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"])
+        if zeros:
+            with torch.no_grad():
+                for prm in eng.p.values():
+                    prm.zero_()
+            eng.refresh()
+            h.zero_(), cview.zero_()
         fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n)
         flops = n * 611840 * 2 * 3
     elif what == "linear16":
