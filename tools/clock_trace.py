@@ -45,8 +45,9 @@ def main():
         cview, _ = eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"])
         if zeros:
             with torch.no_grad():
-                for prm in eng.p.values():
-                    prm.zero_()
+                for name, prm in eng.p.items():
+                    if 'adj' not in name.split('.')[-1] or 'adj_w' in name:
+                        prm.zero_()
             eng.refresh()
             h.zero_(), cview.zero_()
         fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n)
