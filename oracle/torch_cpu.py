@@ -150,3 +150,88 @@ class DanboTorchCPU:
             outs.append((out['rgb_map'].numpy(), out['acc_map'].numpy(), out0['rgb_map'].numpy()))
         return dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
                     rgb0=np.concatenate([x[2] for x in outs]))
+
+
+class AnerfTorchCPU:
+    """A-NeRF (nerf_type = nerf: joint-distance cutoff PE + unit bone-local directions -> W = 448 trunk; cutoff-weighted PE of the
+    bone-local ray directions + frame code -> colour head; reference core/networks/nerf.py:107-122,222-279,
+    core/cutoff_embedder.py:151-214) on torch's CPU kernels -- bench.py's timed cpu_baseline of config 5.  Every sample is
+    evaluated (A-NeRF has no in-volume mask).  Checked against the numpy AnerfOracle in tests/test_oracle_anerf.py."""
+
+    def __init__(self, cfg, sd, rest_pose, netchunk=65536):
+        self.cfg, self.netchunk = cfg, netchunk
+        self.np_oracle = o.AnerfOracle(cfg, sd, rest_pose)
+        self.sd = {k: torch.tensor(np.asarray(v, dtype=np.float32)) for k, v in sd.items() if np.asarray(v).dtype != np.int64}
+        self.align = torch.tensor(self.np_oracle.align.astype(np.float32))
+
+    def _cutoff_pe(self, x, v, cutoff, tau, L, dist):
+        """dist: x = v -> [cutoff - v, sin / cos of 2^l (shifted)] * w;  else x = directions [M,72], w from v repeated x 3"""
+        if dist:
+            inp = cutoff - v
+            base = inp * (2.0 / cutoff) - 1.0
+            w = 1.0 - torch.sigmoid(tau * (v - cutoff))
+        else:
+            inp = base = x
+            w = 1.0 - torch.sigmoid(tau * (v.repeat_interleave(3, -1) - cutoff.repeat_interleave(3, -1)))
+        blocks = [inp]
+        for l in range(L):
+            f = base * float(2 ** l)
+            blocks += [torch.sin(f), torch.cos(f)]
+        return (torch.stack(blocks, -2) * w[..., None, :]).reshape(x.shape[0], -1)
+
+    def _mlp(self, dens_in, vin):
+        sd, cfg = self.sd, self.cfg
+        lin = lambda n, x: F.linear(x, sd[n + '.weight'], sd[n + '.bias'])  # noqa: E731
+        out = []
+        for a in range(0, dens_in.shape[0], self.netchunk):
+            x0, v = dens_in[a:a + self.netchunk], vin[a:a + self.netchunk]
+            h = x0
+            for i in range(cfg['D']):
+                h = F.relu(lin(f'pts_linears.{i}', h))
+                if i in cfg['skips']:
+                    h = torch.cat([x0, h], -1)
+            alpha = lin('alpha_linear', h)
+            hv = F.relu(lin('views_linears.0', torch.cat([lin('feature_linear', h), v], -1)))
+            out.append(torch.cat([lin('rgb_linear', hv), alpha], -1))
+        return torch.cat(out, 0)
+
+    def forward(self, pts, rays_d, skts, cam_idxs):
+        cfg, sd = self.cfg, self.sd
+        R, S = pts.shape[:2]
+        M = R * S
+        pl = torch.einsum('rjab,rsb->rsja', skts[:, :, :3, :3], pts) + skts[:, None, :, :3, 3]
+        pt = torch.einsum('jab,rsjb->rsja', self.align[:, :3, :3], pl) + self.align[None, None, :, :3, 3]
+        v = pt.norm(dim=-1).reshape(M, J)
+        r = F.normalize(pt, dim=-1).reshape(M, 3 * J)
+        dens_in = torch.cat([self._cutoff_pe(v, v, sd['pe_fn.cutoff_dist'], float(sd['pe_fn.tau']), cfg['multires'], True), r], -1)
+        d = F.normalize(torch.einsum('rjab,rb->rja', skts[:, :, :3, :3], rays_d), dim=-1).reshape(R, 3 * J)
+        vin = self._cutoff_pe(d.repeat_interleave(S, 0), v, sd['dirs_pe_fn.cutoff_dist'], float(sd['dirs_pe_fn.tau']),
+                              cfg['multires_views'], False)
+        if cfg['use_framecode']:
+            codes = sd['framecodes.codes.weight']
+            idx = torch.as_tensor(np.asarray(cam_idxs).reshape(-1))
+            code = codes.mean(0, keepdim=True).expand(R, -1) if int(idx.max()) < 0 else codes[idx.long()]
+            vin = torch.cat([vin, code.repeat_interleave(S, 0)], -1)
+        return self._mlp(dens_in, vin).reshape(R, S, 4)
+
+    @torch.no_grad()
+    def render(self, ray_batch, skts, bones, cyls, cam_idxs, n_uniques, S, Sf, chunk=4096):
+        outs = []
+        t = lambda v: torch.tensor(np.ascontiguousarray(v, dtype=np.float32))  # noqa: E731
+        for a in range(0, ray_batch.shape[0], chunk):
+            sl = slice(a, min(a + chunk, ray_batch.shape[0]))
+            rb = ray_batch[sl]
+            near, far = o.near_far_cylinder(rb[:, 0:3], rb[:, 3:6], cyls[sl], rb[:, 6:7], rb[:, 7:8], None)
+            z = o.coarse_z(near, far, S)
+            ro, rd, sk, zt = t(rb[:, 0:3]), t(rb[:, 3:6]), t(skts[sl]), t(z)
+            cam = None if cam_idxs is None else cam_idxs[sl]
+            raw = self.forward(ro[:, None] + rd[:, None] * zt[..., None], rd, sk, cam)
+            out0 = DanboTorchCPU._composite(raw, zt, rd, self.cfg['density_scale'])
+            z_all, z_fine, order = o.importance_z(z, out0['weights'].numpy(), Sf)
+            zf = t(z_fine)
+            raw_f = self.forward(ro[:, None] + rd[:, None] * zf[..., None], rd, sk, cam)
+            raw_all = torch.gather(torch.cat([raw, raw_f], 1), 1, torch.as_tensor(order)[..., None].expand(-1, -1, 4).long())
+            out = DanboTorchCPU._composite(raw_all, t(z_all), rd, self.cfg['density_scale'])
+            outs.append((out['rgb_map'].numpy(), out['acc_map'].numpy(), out0['rgb_map'].numpy()))
+        return dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
+                    rgb0=np.concatenate([x[2] for x in outs]))
