@@ -8,12 +8,16 @@ torch.library.custom_op with register_autograd"), so that a caller -- the refere
         -> part_feat [n,24,15]                                            FactorizeGNN.sample_from_volume (gnn_backbone.py:787-828)
                                                                           backward: danbo_bone_gather_bwd (d volumes, d axis_scale)
 
-Both enqueue on the current HIP stream through the C ABI (include/danbo_hip.h); there is no CPU implementation (calling them
+    torch.ops.danbo.pe_mlp(h, row_ray, vin, [20 parameter tensors])       Embedder + NeRF.inference (cutoff_embedder.py:62-73,
+        -> raw [n,4]                                                      nerf.py:176-209) on the fused trunk kernels; backward:
+                                                                          danbo_trunk_bwd + danbo_dw16 + the view / head chain
+
+All enqueue on the current HIP stream through the C ABI (include/danbo_hip.h); there is no CPU implementation (calling them
 with CPU tensors raises), only shape-propagating fake kernels for tracing.  core/train_path.py (the autograd training path)
-is built on these two operators; the fused training step (core/train_engine.py) does not need autograd at all.
+is built on composite / bone_gather; the fused training step (core/train_engine.py) does not need autograd at all.
 """
 import ctypes
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -123,3 +127,165 @@ def _gather_backward(ctx, g):
 
 
 bone_gather.register_autograd(_gather_backward, setup_context=_gather_setup)
+
+
+# ------------------------------------------------------------------------------------------------------------------- pe + MLP
+# torch.ops.danbo.pe_mlp(h, row_ray, vin, <20 parameter tensors>) -> raw [n, 4]
+#   h [n, 15] blended voxel features of n rows, row_ray [n] int32 ray of each row, vin [R, view_ch] per-ray view inputs
+#   (PE(dir) | frame code); parameters in the reference's layouts: pts_linears.{0..7}.{weight, bias}, alpha_linear, feature_linear,
+#   views_linears.0, rgb_linear.  = Embedder (cutoff_embedder.py:62-73) + NeRF.inference (core/networks/nerf.py:176-209).
+#   forward: danbo_trunk_pack + danbo_train_cview + danbo_trunk_fwd;  backward: danbo_trunk_bwd + danbo_dw16 +
+#   danbo_train_view_grads + danbo_train_head_chain -> d h, d vin, the gradient of every parameter.
+_PE_MLP_PARAMS = ([f"pts_w{i}" for i in range(8)] + [f"pts_b{i}" for i in range(8)]
+                  + ["alpha_w", "alpha_b", "feature_w", "feature_b", "views_w", "views_b", "rgb_w", "rgb_b"])
+
+
+def _trunk_structs(h, row_ray, vin, params, need_bwd):
+    """device buffers + the two C structs for n rows handed over one by one (R = 0 empty-space rows, S = 1: row_sample = ray)"""
+    dev = h.device
+    n, R = h.shape[0], vin.shape[0]
+    pad = (n + 127) // 128 * 128 + 128
+    f32 = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
+    buf = dict(packed=torch.empty(_hip_trunk_bytes(), device=dev, dtype=torch.uint8), wfv=f32(128 * 256), b_eff=f32(128),
+               wmax=torch.zeros(16, device=dev), winv=f32(16), cnt=torch.zeros(8, device=dev, dtype=torch.int32),
+               h16=torch.zeros(n, 16, device=dev), cview=f32(R, 128), y=f32(8, pad * 256), pe=f32(pad * 224),
+               relu=torch.empty(8, pad * 4, device=dev, dtype=torch.int64), hv=f32(pad * 128),
+               hv_bits=torch.empty(pad * 4, device=dev, dtype=torch.int32), raw_rows=f32(n, 4), raw_dense=f32(max(R, 1), 4),
+               row_ray_out=torch.empty(n, device=dev, dtype=torch.int32))
+    buf["h16"][:, :15] = h
+    buf["cnt"][0] = n
+    buf["row_sample"] = row_ray.to(torch.int32).contiguous()
+    w = _hip.DanboTrunkWeights()
+    for i in range(8):
+        w.pts_w[i], w.pts_b[i] = params[i].data_ptr(), params[8 + i].data_ptr()
+    for k, t in zip(("alpha_w", "alpha_b", "feature_w", "feature_b", "views_w", "views_b", "rgb_w", "rgb_b"), params[16:]):
+        setattr(w, k, t.data_ptr())
+    for k in ("packed", "wfv", "b_eff", "wmax", "winv"):
+        setattr(w, k, buf[k].data_ptr())
+    w.view_ch = vin.shape[1]
+    r = _hip.DanboTrunkRows()
+    r.cnt, r.row_sample, r.h_rows, r.cview = (buf[k].data_ptr() for k in ("cnt", "row_sample", "h16", "cview"))
+    r.R, r.S, r.Sf, r.rows_cap, r.rows_pad = 0, 1, 1, n, pad
+    for k in ("y", "pe", "relu", "hv", "hv_bits", "raw_rows"):
+        setattr(r, k, buf[k].data_ptr())
+    r.raw_c = r.raw_f = r.raw_empty = buf["raw_dense"].data_ptr()
+    r.row_ray = buf["row_ray_out"].data_ptr()
+    if need_bwd:
+        buf.update(dz=f32(8, pad * 256), dpre_v=f32(pad * 128), d_alpha4=f32(n, 4), d_h=f32(n, 16), maxabs=torch.zeros(16, device=dev))
+        for k in ("dz", "dpre_v", "d_alpha4", "d_h", "maxabs"):
+            setattr(r, k, buf[k].data_ptr())
+    return buf, w, r
+
+
+def _hip_trunk_bytes():
+    return (74 + 76) * 32768       # DANBO_TRUNK_PACKED_BYTES
+
+
+def _vin_padded(vin):
+    """[R, view_ch] -> row stride a multiple of 4 floats with 8 floats of slack (the view-gradient kernel reads 8 columns at a time)"""
+    R, C = vin.shape
+    ld = (C + 3) // 4 * 4 + 4
+    out = torch.zeros(R * ld + 8, device=vin.device, dtype=torch.float32)
+    out[:R * ld].view(R, ld)[:, :C] = vin
+    return out, ld
+
+
+@torch.library.custom_op("danbo::pe_mlp", mutates_args=())
+def pe_mlp(h: torch.Tensor, row_ray: torch.Tensor, vin: torch.Tensor, params: List[torch.Tensor]) -> torch.Tensor:
+    if not h.is_cuda:
+        raise RuntimeError("danbo::pe_mlp runs on the HIP path only (no CPU fallback)")
+    params = [p.detach().float().contiguous() for p in params]
+    h, vin = h.detach().float().contiguous(), vin.detach().float().contiguous()
+    buf, w, r = _trunk_structs(h, row_ray, vin, params, need_bwd=False)
+    lib, st = _hip.lib(), ops._stream()
+    _hip.check(lib.danbo_trunk_pack(ctypes.byref(w), st), "danbo_trunk_pack")
+    vp, ld = _vin_padded(vin)
+    _hip.check(lib.danbo_train_cview(_p(vp), ld, vin.shape[1], _p(params[20]), _p(buf["b_eff"]), vin.shape[0], _p(buf["cview"]), st),
+               "danbo_train_cview")
+    _hip.check(lib.danbo_trunk_fwd(ctypes.byref(w), ctypes.byref(r), 0, st), "danbo_trunk_fwd")
+    return buf["raw_rows"]
+
+
+@pe_mlp.register_fake
+def _(h, row_ray, vin, params):
+    return h.new_empty(h.shape[0], 4, dtype=torch.float32)
+
+
+@torch.library.custom_op("danbo::pe_mlp_bwd", mutates_args=())
+def pe_mlp_bwd(h: torch.Tensor, row_ray: torch.Tensor, vin: torch.Tensor, params: List[torch.Tensor],
+               g_raw: torch.Tensor) -> List[torch.Tensor]:
+    """-> [d h [n,15], d vin [R, view_ch], d param_0 .. d param_19]  (the forward is re-run: a custom op's saved state are tensors,
+    and the activations are cheaper to recompute than to keep alive across the autograd graph)"""
+    params = [p.detach().float().contiguous() for p in params]
+    h, vin = h.detach().float().contiguous(), vin.detach().float().contiguous()
+    n, R, C = h.shape[0], vin.shape[0], vin.shape[1]
+    dev = h.device
+    buf, w, r = _trunk_structs(h, row_ray, vin, params, need_bwd=True)
+    lib, st = _hip.lib(), ops._stream()
+    _hip.check(lib.danbo_trunk_pack(ctypes.byref(w), st), "danbo_trunk_pack")
+    vp, ld = _vin_padded(vin)
+    _hip.check(lib.danbo_train_cview(_p(vp), ld, C, _p(params[20]), _p(buf["b_eff"]), R, _p(buf["cview"]), st), "danbo_train_cview")
+    _hip.check(lib.danbo_trunk_fwd(ctypes.byref(w), ctypes.byref(r), 0, st), "danbo_trunk_fwd")
+    buf["cnt"][4] = n                                  # total rows (the step's second pass would have set it)
+    # ---- input-gradient chain on d raw per row
+    d_raw_rows = torch.zeros(n, 4, device=dev)
+    d_raw_rows.copy_(g_raw.float())
+    r.d_raw_rows = d_raw_rows.data_ptr()
+    r.d_raw_c = r.d_raw_f = None
+    _hip.check(lib.danbo_trunk_bwd(ctypes.byref(w), ctypes.byref(r), st), "danbo_trunk_bwd")
+    # ---- weight gradients (k_dw16): the layer list of the training step (csrc/k_train.hip describe_dw)
+    g = [torch.zeros_like(p) for p in params]
+    g_wfv, g_beff = torch.zeros(128, 256, device=dev), torch.zeros(128, device=dev)
+    pad = buf["y"].shape[1] // 256
+    D = _hip.DanboDwLayer
+    y_of = lambda l: buf["y"][l].data_ptr()       # noqa: E731
+    dz_of = lambda l: buf["dz"][l].data_ptr()     # noqa: E731
+    mx = buf["maxabs"]
+    layers = []
+    for l in range(8):
+        common = dict(dy=dz_of(l), ldy=256, N=256, dy_maxabs=mx[l:].data_ptr(), gw=g[l].data_ptr(), frag=3)
+        if l in (0, 5):
+            layers.append(D(x1=buf["pe"].data_ptr(), ld1=224, K1=224, x1_pe=1, gw_ld=195 if l == 0 else 451, gw_col0=0, gb=g[8 + l].data_ptr(),
+                            **common))
+            if l == 5:
+                layers.append(D(x1=y_of(4), ld1=256, K1=256, gw_ld=451, gw_col0=195, gb=None, **common))
+        else:
+            layers.append(D(x1=y_of(l - 1), ld1=256, K1=256, gb=g[8 + l].data_ptr(), **common))
+    layers.append(D(dy=buf["dpre_v"].data_ptr(), ldy=128, N=128, dy_maxabs=mx[8:].data_ptr(), frag=3, x1=y_of(7), ld1=256, K1=256,
+                    gw=g_wfv.data_ptr(), gb=g_beff.data_ptr()))
+    layers.append(D(dy=buf["d_alpha4"].data_ptr(), ldy=4, N=1, dy_maxabs=mx[9:].data_ptr(), frag=2, x1=y_of(7), ld1=256, K1=256,
+                    gw=g[16].data_ptr(), gb=g[17].data_ptr()))
+    mraw = g_raw.detach().abs().max().reshape(1).float().contiguous()
+    layers.append(D(dy=d_raw_rows.data_ptr(), ldy=4, N=3, dy_maxabs=mraw.data_ptr(), frag=2, x1=buf["hv"].data_ptr(), ld1=128, K1=128,
+                    gw=g[22].data_ptr(), gb=g[23].data_ptr()))
+    L = (D * len(layers))(*layers)
+    slices = 8
+    scratch = torch.empty(lib.danbo_dw16_scratch_floats(L, len(layers), slices), device=dev)
+    _hip.check(lib.danbo_dw16(L, len(layers), n, _p(buf["cnt"][4:]), slices, _p(scratch), st), "danbo_dw16")
+    # ---- per-ray view gradients, then the chain rule of the merged feature / view layer
+    d_cview = torch.zeros(R, 128, device=dev)
+    _hip.check(lib.danbo_train_view_grads(_p(buf["dpre_v"]), _p(buf["row_ray_out"]), _p(buf["cnt"]), n, R, _p(vp), ld, C, None, 0, _p(d_cview),
+                                          None, _p(g[20]), st), "danbo_train_view_grads")
+    _hip.check(lib.danbo_train_head_chain(_p(g_wfv), _p(g_beff), None, _p(params[18]), _p(params[19]), _p(params[20]), C, 0, 0, 0,
+                                          _p(g[18]), _p(g[19]), _p(g[20]), _p(g[21]), None, st), "danbo_train_head_chain")
+    d_vin = d_cview @ params[20][:, 256:]              # [R,128] x [128, view_ch]: per RAY, tiny
+    return [buf["d_h"][:, :15].contiguous(), d_vin] + g
+
+
+@pe_mlp_bwd.register_fake
+def _(h, row_ray, vin, params, g_raw):
+    return [h.new_empty(h.shape[0], 15), vin.new_empty(vin.shape)] + [p.new_empty(p.shape) for p in params]
+
+
+def _pe_mlp_setup(ctx, inputs, output):
+    h, row_ray, vin, params = inputs
+    ctx.save_for_backward(h, row_ray, vin, *params)
+
+
+def _pe_mlp_backward(ctx, g_raw):
+    h, row_ray, vin, *params = ctx.saved_tensors
+    out = torch.ops.danbo.pe_mlp_bwd(h, row_ray, vin, list(params), g_raw.contiguous())
+    return out[0], None, out[1], out[2:]
+
+
+pe_mlp.register_autograd(_pe_mlp_backward, setup_context=_pe_mlp_setup)

@@ -666,7 +666,7 @@ extern "C" int danbo_trunk_pack(const DanboTrunkWeights* w, void* stream) {
 
 extern "C" int danbo_trunk_fwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, int pass, void* stream) {
     DANBO_CHECK_ARG(w && r && (pass == 0 || pass == 1) && w->packed && w->winv && w->alpha_w && w->alpha_b && w->rgb_w && w->rgb_b);
-    DANBO_CHECK_ARG(r->cnt && r->row_sample && r->h_rows && r->cview && r->R > 0 && r->S > 0 && r->Sf > 0 && r->rows_cap >= r->R);
+    DANBO_CHECK_ARG(r->cnt && r->row_sample && r->h_rows && r->cview && r->R >= 0 && r->S > 0 && r->Sf > 0 && r->rows_cap >= r->R && r->rows_cap > 0);
     DANBO_CHECK_ARG(r->rows_pad >= (r->rows_cap + 127) / 128 * 128 && r->y && r->pe && r->relu && r->hv && r->hv_bits);
     DANBO_CHECK_ARG(r->raw_rows && r->raw_c && r->raw_f && r->raw_empty && r->row_ray);
     Mlp16Args a;

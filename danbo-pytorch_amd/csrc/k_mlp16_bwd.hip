@@ -175,7 +175,8 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
         unsigned hvb;
         uint2 bits;
         {
-            const f32x4* src_d = !row_ok ? a.d_raw_rows : (row < a.R ? a.d_raw_rows + row : (row < first_f ? a.d_raw_c + staged : a.d_raw_f + staged));
+            // (d_raw_c == nullptr: the caller hands d raw per ROW -- torch.ops.danbo.pe_mlp)
+            const f32x4* src_d = !row_ok ? a.d_raw_rows : ((row < a.R || a.d_raw_c == nullptr) ? a.d_raw_rows + row : (row < first_f ? a.d_raw_c + staged : a.d_raw_f + staged));
             const unsigned* src_hb = a.hv_bits + grp * 64;                               // wave-uniform bases + lane offsets
             const unsigned long long* src_b = a.relu + 7 * a.relu_stride + grp * 64;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(draw) : "v"(src_d) : "memory");
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
         }
         if (!row_ok) draw = f32x4{0.f, 0.f, 0.f, 0.f};
         if (qq == 0 && row_ok) {
-            if (row >= a.R) a.d_raw_rows[row] = draw;
+            if (row >= a.R && a.d_raw_c != nullptr) a.d_raw_rows[row] = draw;
             a.d_alpha4[row] = f32x4{draw[3], 0.f, 0.f, 0.f};
         }
         src.next_row0 = (tile + (int)gridDim.x) * M16_BM + wave * 16;
@@ -368,8 +369,9 @@ using namespace danbo;
 
 extern "C" int danbo_trunk_bwd(const DanboTrunkWeights* w, const DanboTrunkRows* r, void* stream) {
     DANBO_CHECK_ARG(w && r && w->packed && w->winv && w->alpha_w && w->rgb_w);
-    DANBO_CHECK_ARG(r->cnt && r->row_sample && r->h_rows && r->R > 0 && r->rows_cap >= r->R && r->rows_pad >= (r->rows_cap + 127) / 128 * 128);
-    DANBO_CHECK_ARG(r->relu && r->hv_bits && r->d_raw_c && r->d_raw_f && r->d_raw_rows && r->dz && r->dpre_v && r->d_alpha4 && r->d_h && r->maxabs);
+    DANBO_CHECK_ARG(r->cnt && r->row_sample && r->h_rows && r->R >= 0 && r->rows_cap >= r->R && r->rows_pad >= (r->rows_cap + 127) / 128 * 128);
+    DANBO_CHECK_ARG(r->relu && r->hv_bits && ((r->d_raw_c && r->d_raw_f) || (!r->d_raw_c && !r->d_raw_f)) && r->d_raw_rows && r->dz && r->dpre_v);
+    DANBO_CHECK_ARG(r->d_alpha4 && r->d_h && r->maxabs);
     TrainBwd a;
     a.cnt = r->cnt; a.row_sample = r->row_sample; a.h_rows = r->h_rows; a.R = r->R; a.n_cap = r->rows_cap;
     a.packed = reinterpret_cast<const char*>(w->packed) + (size_t)DANBO_TRUNK_FWD_CHUNKS * CHUNK_BYTES;

@@ -451,7 +451,7 @@ typedef struct DanboTrunkRows {
     float *raw_c /*[R*S,4]*/, *raw_f /*[R*Sf,4]*/, *raw_empty /*[R,4]*/;
     int32_t* row_ray;                  /* [rows_cap] */
     /* backward */
-    const float *d_raw_c, *d_raw_f;    /* dense gradients of the two passes' raw */
+    const float *d_raw_c, *d_raw_f;    /* dense gradients of the two passes' raw; both NULL: d_raw_rows holds d raw of EVERY row */
     float* d_raw_rows;                 /* [rows_cap,4]: rows < R hold the rays' empty-space sums on entry; rows >= R are written */
     float* dz;                         /* [8][rows_pad*256] gradients with respect to the pre-activations */
     float* dpre_v;                     /* [rows_pad*128] */

@@ -269,3 +269,45 @@ def test_trunk_backward_matches_fp64_autograd(R, S, Sf, n_c, n_f, gscale):
         assert e < 5e-5, e
         assert float(t["d_h"][R:n, 15].abs().max()) == 0.0
     print("worst per-row relative deviation", worst)
+
+
+def test_pe_mlp_custom_op_forward_backward_and_opcheck():
+    """torch.ops.danbo.pe_mlp (core/custom_ops.py): raw and the gradient of EVERY input that carries one -- h, the per-ray view
+    inputs, the 24 parameter tensors -- against fp64 autograd through the reference's network; schema / fake-tensor opcheck"""
+    from core import custom_ops  # noqa: F401
+    net = Net(seed=7, view_ch=155)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n, R = 777, 50
+    h = (torch.randn(n, 15, generator=g) * 0.7).to(DEV).requires_grad_(True)
+    row_ray = torch.sort(torch.randint(0, R, (n,), generator=g)).values.int().to(DEV)
+    vin = torch.randn(R, 155, generator=g).to(DEV).requires_grad_(True)
+    params = [p.clone().requires_grad_(True) for p in net.pts_w + net.pts_b + [net.alpha_w, net.alpha_b, net.feature_w, net.feature_b,
+                                                                                net.views_w, net.views_b, net.rgb_w, net.rgb_b]]
+    raw = torch.ops.danbo.pe_mlp(h, row_ray, vin, params)
+    G = (torch.randn(n, 4, generator=g) * 1e-5).to(DEV)
+    (raw * G).sum().backward()
+    # fp64 reference with the same leaves
+    h64, vin64 = h.detach().double().requires_grad_(True), vin.detach().double().requires_grad_(True)
+    net64 = Net(seed=7, view_ch=155)
+    names = ["pts_w", "pts_b"]
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    net64.pts_w, net64.pts_b = p64[:8], p64[8:16]
+    net64.alpha_w, net64.alpha_b, net64.feature_w, net64.feature_b, net64.views_w, net64.views_b, net64.rgb_w, net64.rgb_b = p64[16:]
+    pe = torch.cat([h64] + [f(h64 * 2.0 ** l) for l in range(6) for f in (torch.sin, torch.cos)], 1)
+    x = pe
+    for l in range(8):
+        x = torch.relu((torch.cat([pe, x], 1) if l == 5 else x) @ p64[l].t() + p64[8 + l])
+    alpha = x @ p64[16].t() + p64[17]
+    feat = x @ p64[18].t() + p64[19]
+    hv = torch.relu(torch.cat([feat, vin64[row_ray.long()]], 1) @ p64[20].t() + p64[21])
+    ref = torch.cat([hv @ p64[22].t() + p64[23], alpha], 1)
+    (ref * G.double()).sum().backward()
+    assert ((raw.detach().double() - ref.detach()).abs() / ref.detach().abs().amax(0)).max().item() < 2e-5
+    worst = 0.0
+    for name, a, b in [("h", h.grad, h64.grad), ("vin", vin.grad, vin64.grad)] + [(f"param{i}", p.grad, q.grad) for i, (p, q) in enumerate(zip(params, p64))]:
+        e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-300)).item()
+        worst = max(worst, e)
+        assert e < 1e-4, (name, e)
+    print("pe_mlp op: worst gradient deviation relative to the tensor's max", worst)
+    torch.library.opcheck(torch.ops.danbo.pe_mlp, (h.detach(), row_ray, vin.detach(), [p.detach() for p in params]),
+                          test_utils=("test_schema", "test_faketensor"))
