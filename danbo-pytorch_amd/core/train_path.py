@@ -18,6 +18,8 @@ differentiable (core/networks/gnn_backbone.py:802-808); sample depths are detach
 """
 import ctypes
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -198,6 +200,25 @@ def assignment_logits(model, part_feat):
     return (torch.einsum("bkl,klj->bkj", y, l2.weight) + l2.bias)[..., 0]
 
 
+def _fused_mlp_params(model):
+    """the 24 parameter tensors of torch.ops.danbo.pe_mlp if the network has the shape the fused trunk kernels are built for
+    (D = 8, W = 256, skip after layer 4, 6 voxel octaves, view_W = 128), else None (-> the library-GEMM path below)"""
+    if os.environ.get("DANBO_AUTOGRAD_MLP") == "library":
+        return None
+    try:
+        ok = (len(model.pts_linears) == 8 and list(model.skips) == [4] and model.voxel_pe_fn.num_freqs == 6
+              and model.pts_linears[0].weight.shape == (256, 195) and model.views_linears[0].weight.shape[0] == 128
+              and model.feature_linear.weight.shape == (256, 256) and model.views_linears[0].weight.shape[1] <= 256 + 160)
+    except AttributeError:
+        return None
+    if not ok:
+        return None
+    from . import custom_ops  # noqa: F401  (registers the operator)
+    return ([l.weight for l in model.pts_linears] + [l.bias for l in model.pts_linears]
+            + [model.alpha_linear.weight, model.alpha_linear.bias, model.feature_linear.weight, model.feature_linear.bias,
+               model.views_linears[0].weight, model.views_linears[0].bias, model.rgb_linear.weight, model.rgb_linear.bias])
+
+
 def mlp(model, dens_in, view_in):
     h = dens_in
     for i, l in enumerate(model.pts_linears):
@@ -268,11 +289,20 @@ def forward_train(model, inputs):
     # in-volume rows and the one empty-space row per ray through the MLP in ONE batch: half the GEMM launches and half the
     # gradient accumulations of two separate calls
     # (a caller that runs several passes over the same rays -- coarse and importance samples -- shares the empty-space rows)
+    fused = _fused_mlp_params(model)
     if "raw_empty" in shared:
-        raw_rows, raw_empty = mlp(model, positional_encoding(h, L), vin[ray_of_row]), shared["raw_empty"]
+        raw_empty = shared["raw_empty"]
+        if fused is not None:   # torch.ops.danbo.pe_mlp: encoding + trunk + heads on the fused HIP kernels (core/custom_ops.py)
+            raw_rows = torch.ops.danbo.pe_mlp(h, ray_of_row.int(), vin, fused) if n > 0 else h.new_zeros(0, 4)
+        else:
+            raw_rows = mlp(model, positional_encoding(h, L), vin[ray_of_row])
     else:
-        pe_empty = positional_encoding(torch.zeros(1, h.shape[1], device=pts.device), L).expand(R, -1)
-        raw_both = mlp(model, torch.cat([positional_encoding(h, L), pe_empty], 0), torch.cat([vin[ray_of_row], vin], 0))
+        if fused is not None:
+            raw_both = torch.ops.danbo.pe_mlp(torch.cat([h, h.new_zeros(R, h.shape[1])], 0),
+                                              torch.cat([ray_of_row.int(), torch.arange(R, device=pts.device, dtype=torch.int32)]), vin, fused)
+        else:
+            pe_empty = positional_encoding(torch.zeros(1, h.shape[1], device=pts.device), L).expand(R, -1)
+            raw_both = mlp(model, torch.cat([positional_encoding(h, L), pe_empty], 0), torch.cat([vin[ray_of_row], vin], 0))
         raw_rows, raw_empty = raw_both[:n], raw_both[n:]
         shared["raw_empty"] = raw_empty
     raw = raw_empty[:, None, :].expand(R, S, 4).reshape(R * S, 4).index_copy(0, rows.long(), raw_rows)
