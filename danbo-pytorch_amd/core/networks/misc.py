@@ -56,3 +56,31 @@ def init_volume_scale(base_scale, skel_profile, skel_type):
     z[z < 0] = z.max()                      # end effectors grow freely
     z[torch.as_tensor(skel_profile['head_idxs'])] = z.max() * 1.1
     return torch.stack([x, x.clone(), z], dim=-1)
+
+
+# ---- visualisations of the bone assignment (reference core/networks/misc.py:620-673), used by NeRF.raw2outputs(render_confd /
+# render_entropy): plain element-wise torch on whatever device the logits live on -- not part of the hot path.
+# One colour per SMPL joint: the CSS colours red, blue, yellow, magenta, green, indigo, darkorange, cyan, pink, yellowgreen,
+# rosybrown, coral, chocolate, bisque, gold, yellowgreen, aquamarine, deepskyblue, navy, orchid, maroon, sienna, olive, lightgreen.
+_JOINT_COLOURS_HEX = ("ff0000 0000ff ffff00 ff00ff 008000 4b0082 ff8c00 00ffff ffc0cb 9acd32 bc8f8f ff7f50 d2691e ffe4c4 ffd700 9acd32 "
+                      "7fffd4 00bfff 000080 da70d6 800000 a0522d 808000 90ee90").split()
+
+
+def joint_colours(device=None):
+    rgb = [[int(h[i:i + 2], 16) / 255.0 for i in (0, 2, 4)] for h in _JOINT_COLOURS_HEX]
+    return torch.tensor(rgb, dtype=torch.float32, device=device)
+
+
+def get_confidence_rgb(confd, encoded=None):
+    """colour of the bone with the largest assignment logit: confd [..., 24] -> [..., 3]"""
+    return joint_colours(confd.device)[confd.argmax(dim=-1)]
+
+
+def get_entropy_rgb(confd, encoded=None, eps=1e-7):
+    """blue (one bone owns the sample) -> red (uniform over the bones) by the entropy of softmax(confd) relative to log(24)"""
+    prob = torch.softmax(confd, dim=-1)
+    ent = -(prob * (prob + eps).log()).sum(-1)
+    ratio = (ent / math.log(confd.shape[-1]))[..., None]
+    start = torch.tensor([0., 0., 1.], device=confd.device)
+    end = torch.tensor([1., 0., 0.], device=confd.device)
+    return torch.lerp(start.expand_as(ratio.expand(*ratio.shape[:-1], 3)), end.expand_as(ratio.expand(*ratio.shape[:-1], 3)), ratio)

@@ -63,11 +63,23 @@ class NeRF(nn.Module):
                     act_fn=F.relu, rgb_eps=0.001, alpha_w=None, render_confd=False, render_entropy=False, **kwargs):
         if act_fn is not F.relu and getattr(act_fn, "__name__", "") != "relu":
             raise NotImplementedError("only density_type=relu is implemented in danbo_composite_fwd")
-        if render_confd or render_entropy or alpha_w is not None or rgb_act is not torch.sigmoid:
-            raise NotImplementedError("render_confd / render_entropy / alpha_w are out of scope")
+        if alpha_w is not None or rgb_act is not torch.sigmoid:
+            raise NotImplementedError("alpha_w / a colour activation other than sigmoid are out of scope")
         noise = None
         if raw_noise_std > 0.:
             noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std * B
+        if render_confd or render_entropy:
+            # the reference's visualisations (nerf.py:306-311): the per-sample colour is replaced by the colour of the most
+            # confident bone / by a blue -> red ramp of the assignment entropy, read from raw[..., 4:]; everything else of
+            # raw2outputs is unchanged.  The composite kernel applies sigmoid(.) * (1 + 2 eps) - eps to its colour channels, so
+            # it is handed the logit of that map's inverse (a visualisation: not on the hot path, plain torch element-wise ops).
+            assert raw.shape[-1] > 4, 'Needs to have confidence/prob logit when render_confd=True'
+            from .misc import get_confidence_rgb, get_entropy_rgb
+            rgb = (get_confidence_rgb if render_confd else get_entropy_rgb)(raw[..., 4:], kwargs.get('encoded'))
+            y = ((rgb + rgb_eps) / (1. + 2. * rgb_eps)).clamp(1e-6, 1. - 1e-6)
+            raw = torch.cat([torch.log(y) - torch.log1p(-y), raw[..., 3:4]], -1).contiguous()
+        else:
+            raw = raw[..., :4]
         if raw.requires_grad:
             from .. import train_path
             return train_path.composite(raw, z_vals, rays_d, B, noise)

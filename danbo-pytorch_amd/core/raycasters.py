@@ -221,10 +221,10 @@ class RayCaster(nn.Module):
             raise NotImplementedError("N_importance=0 raises in the reference too (raycasters.py:377)")
         if perturb or raw_noise_std or ray_noise_std or lindisp:
             raise NotImplementedError("stochastic sampling belongs to the training path")
-        if render_confd or render_entropy:
-            # the reference swaps the colours for get_confidence_rgb / get_entropy_rgb (nerf.py:306-311, misc.py:620-673): a
-            # visualisation outside the hot path -- refuse instead of handing back ordinary RGB under that name
-            raise NotImplementedError("render_confd / render_entropy colourings are not implemented")
+        # render_confd / render_entropy: accepted and -- exactly as in the reference -- without effect here: its render_rays takes
+        # the two flags (raycasters.py:265-266) but never hands them to raw2outputs (:334-337, :373-375), whose colourings
+        # (nerf.py:306-311) would moreover need raw[..., 4:], which no shipped network produces.  The colourings themselves are
+        # available on NeRF.raw2outputs (core/networks/nerf.py) for a caller that passes the assignment logits in raw[..., 4:].
         eng = self._engine()
         G = int(N_uniques)
         skts_g, bones_g, cyls_g = self._per_pose(skts, G), self._per_pose(bones, G), self._per_pose(cyls, G)

@@ -671,11 +671,24 @@ def gen_pose_rot6d():
     np.savez_compressed(os.path.join(OUT, "pose_rot6d.npz"), axis_angle=aa, rot6d=out)
 
 
+def gen_confd_colours():
+    """the two assignment visualisations of NeRF.raw2outputs (reference core/networks/misc.py:620-673) on random logits"""
+    rh.install_stubs()
+    from core.networks.misc import get_confidence_rgb, get_entropy_rgb
+    rng = np.random.default_rng(12)
+    confd = (rng.normal(size=(6, 5, 24)) * 3.0).astype(np.float32)
+    confd[0, 0] = 0.0                         # uniform: maximal entropy
+    confd[0, 1] = -50.0
+    confd[0, 1, 7] = 50.0                     # one bone: zero entropy
+    np.savez_compressed(os.path.join(OUT, "confd_colours.npz"), confd=confd,
+                        confidence_rgb=get_confidence_rgb(T(confd), None).numpy(), entropy_rgb=get_entropy_rgb(T(confd), None).numpy())
+
+
 if __name__ == "__main__":
     assert rh.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "perfcap_train_noise", "mesh", "h36m_fast", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
+    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "perfcap_train_noise", "confd_colours", "mesh", "h36m_fast", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
     if "stages" in which:
         gen_danbo_stages()
     if "surreal" in which:
@@ -692,6 +705,8 @@ if __name__ == "__main__":
         gen_anerf_train()
     if "perfcap_train" in which:
         gen_danbo_perfcap_train()
+    if "confd_colours" in which:
+        gen_confd_colours()
     if "perfcap_train_noise" in which:
         gen_danbo_perfcap_train(stochastic=True)
     if "mesh" in which:

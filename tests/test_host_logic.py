@@ -399,3 +399,13 @@ def test_fragment_order_buffer_layout_on_cpu():
     assert torch.equal(lane_vals, want)
     with pytest.raises(ValueError):
         ops.FragBuffer(10, 100, "cpu")
+
+
+def test_assignment_visualisations_match_the_reference():
+    """get_confidence_rgb / get_entropy_rgb (NeRF.raw2outputs(render_confd / render_entropy), reference misc.py:620-673) against the
+    reference's outputs on random logits (tests/golden/confd_colours.npz)"""
+    from core.networks.misc import get_confidence_rgb, get_entropy_rgb
+    g = golden("confd_colours")
+    c = torch.tensor(g["confd"])
+    assert np.array_equal(get_confidence_rgb(c).numpy(), g["confidence_rgb"])
+    assert max_err(get_entropy_rgb(c).numpy(), g["entropy_rgb"]) < 1e-6
