@@ -286,6 +286,8 @@ static SideStreams* side_streams() {
     SideStreams& ss = per_dev[dev & 63];
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(made.load(std::memory_order_acquire) & bit)) {
+        // (a low-priority stream for the weight-gradient kernel, so that the K2 adjoint gets the compute units first, was measured:
+        //  2.5 instead of 1.85 ms per step -- plain streams)
         ss.ok = hipStreamCreateWithFlags(&ss.s[0], hipStreamNonBlocking) == hipSuccess &&
                 hipStreamCreateWithFlags(&ss.s[1], hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
@@ -377,10 +379,16 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         return 0;
     };
     const float* axis_scale = m->p[DANBO_T_AXIS_SCALE];
-    DANBO_TRY(danbo_trunk_pack(&tw, s0));
-    DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
-                                      m->code_size, bt->cam_idx, b.vin, LD_VIN, s0));
-    DANBO_TRY(danbo_train_cview(b.vin, LD_VIN, m->view_ch, m->p[DANBO_T_VIEWS_W], b.b_eff, R, b.cview, s0));
+    // Enqueue order = the order the captured graph submits its nodes in: the caller's stream first (it carries the critical
+    // path: bounds -> depths -> cull -> assignment net), then side 1 (needed by the assignment net), then side 0 (needed by the trunk).
+    // ---- bounds, depths (reference raycasters.py:310-311), coarse cull
+    DANBO_TRY(danbo_near_far_cylinder(bt->rays_o, bt->rays_d, bt->cyls, R, G, 0.f, 1.f, bt->near_in, bt->far_in, bt->chunk, b.cyl_scratch,
+                                      b.near, b.far, stream));
+    if (m->use_volume_near_far)
+        DANBO_TRY(danbo_near_far_boxes(bt->rays_o, bt->rays_d, bt->skts, m->align, axis_scale, R, G, b.near, b.far, stream));
+    DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, bt->t_rand, b.z_c, stream));
+    DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, b.z_c, nullptr, R, S, G, bt->skts, m->align, axis_scale, b.bits_c, b.row_sample + R, b.cnt,
+                              stream));
     hipLaunchKernelGGL(k_train_small, dim3(1), dim3(256), 0, (hipStream_t)s1, m->p[DANBO_T_G_ADJW0], m->g_adj0, m->p[DANBO_T_G_ADJW1], m->g_adj1,
                        m->p[DANBO_T_A_ADJW], m->a_adj, b.adj_prod, m->p[DANBO_T_AXIS_SCALE], m->init_scale, m->vol_scale_penalty,
                        m->g[DANBO_T_AXIS_SCALE], b.loss);
@@ -391,12 +399,10 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_TRY(danbo_pose_volumes_fwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], adjw0, m->p[DANBO_T_G_B0],
                                      m->p[DANBO_T_G_W1], adjw1, m->p[DANBO_T_G_B1], m->p[DANBO_T_G_W2], m->p[DANBO_T_G_B2],
                                      m->p[DANBO_T_G_W3], m->p[DANBO_T_G_B3], b.vol_scratch, b.volumes, s1));
-    // ---- bounds, depths (reference raycasters.py:310-311)
-    DANBO_TRY(danbo_near_far_cylinder(bt->rays_o, bt->rays_d, bt->cyls, R, G, 0.f, 1.f, bt->near_in, bt->far_in, bt->chunk, b.cyl_scratch,
-                                      b.near, b.far, stream));
-    if (m->use_volume_near_far)
-        DANBO_TRY(danbo_near_far_boxes(bt->rays_o, bt->rays_d, bt->skts, m->align, axis_scale, R, G, b.near, b.far, stream));
-    DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, bt->t_rand, b.z_c, stream));
+    DANBO_TRY(danbo_trunk_pack(&tw, s0));
+    DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
+                                      m->code_size, bt->cam_idx, b.vin, LD_VIN, s0));
+    DANBO_TRY(danbo_train_cview(b.vin, LD_VIN, m->view_ch, m->p[DANBO_T_VIEWS_W], b.b_eff, R, b.cview, s0));
     DANBO_STAGE(2);
 
     // ---- one network pass over the compacted rows
@@ -406,8 +412,9 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         const float* zz = pass == 0 ? b.z_c : b.z_f;
         const int s = pass == 0 ? S : Sf;
         uint32_t* bits = pass == 0 ? b.bits_c : b.bits_f;
-        DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, bits, b.row_sample + R, b.cnt,
-                                  stream));
+        if (pass != 0)       // (pass 0's cull ran in the prologue)
+            DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, bits, b.row_sample + R, b.cnt,
+                                      stream));
         NET_STAGE(21);
         if (pass == 0) DANBO_TRY(join(1));       // the pose volumes and the assignment net's packing
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,
