@@ -31,7 +31,7 @@ constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefro
 // pairs per workgroup: amortises the weight staging and the flush.  Chosen on the device between AB_PPW_MIN and AB_PPW so that the
 // workgroups that find pairs fit the 2 x 256 resident slots in ONE round (80 k pairs at 128 each were 640 workgroups: a full
 // round and a 25 % one)
-constexpr int AB_PPW_MIN = 128, AB_PPW = 128;     // AB_PPW: pairs per sub-batch (the LDS row tables); larger chunks take several.  48 KB of LDS: a workgroup fits beside one of k_dw16 (108 KB), which runs concurrently
+constexpr int AB_PPW_MIN = 32, AB_PPW = 128;      // AB_PPW: pairs per sub-batch (the LDS row tables); larger chunks take several.  48 KB of LDS: a workgroup fits beside one of k_dw16 (108 KB), which runs concurrently
 
 struct ABArgs {
     // geometry
