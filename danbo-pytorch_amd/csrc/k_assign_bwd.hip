@@ -31,7 +31,7 @@ constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefro
 // pairs per workgroup: amortises the weight staging and the flush.  Chosen on the device between AB_PPW_MIN and AB_PPW so that the
 // workgroups that find pairs fit the 2 x 256 resident slots in ONE round (80 k pairs at 128 each were 640 workgroups: a full
 // round and a 25 % one)
-constexpr int AB_PPW_MIN = 32, AB_PPW = 128;      // AB_PPW: pairs per sub-batch (the LDS row tables); larger chunks take several.  48 KB of LDS: a workgroup fits beside one of k_dw16 (108 KB), which runs concurrently
+constexpr int AB_PPW_MIN = 32, AB_PPW = 128;      // AB_PPW: pairs per sub-batch (the LDS row tables); larger chunks take several.  66 KB of LDS, two workgroups per CU
 
 struct ABArgs {
     // geometry
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     __shared__ float s_adj[AB_MAXNB], s_align[AB_MAXNB][12], s_scale[AB_MAXNB][4];
     __shared__ int s_nb[AB_MAXNB];
     __shared__ int s_nq;
-    __shared__ float s_gvol[AB_MAXNB][VOL];
+    __shared__ float s_gvol[2][AB_MAXNB][VOL];
     // per-pair scratch (one per wave half)
     __shared__ __attribute__((aligned(16))) float s_f[AB_PAIRS][AB_MAXNB][16];
     __shared__ __attribute__((aligned(16))) float s_df[AB_PAIRS][AB_MAXNB][16];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     if (tid < nq) s_adj[tid] = a.adj_w[j * J + s_nb[tid]] * a.adj[j * J + s_nb[tid]];
     for (int i = tid; i < nq * 12; i += AB_THREADS) s_align[i / 12][i % 12] = a.align[s_nb[i / 12] * 16 + i % 12];
     for (int i = tid; i < nq * 4; i += AB_THREADS) s_scale[i / 4][i % 4] = (i % 4) < 3 ? a.axis_scale[s_nb[i / 4] * 3 + i % 4] : 1.f;
-    for (int i = tid; i < AB_MAXNB * VOL; i += AB_THREADS) (&s_gvol[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * AB_MAXNB * VOL; i += AB_THREADS) (&s_gvol[0][0][0])[i] = 0.f;
     __syncthreads();
     const float b2 = a.b2[j];
     const int first_f = a.cnt[2];
@@ -128,11 +128,14 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     // Everything a pair needs from the row tables is fetched ONCE per workgroup, one pair per thread, into LDS: as a chain of
     // three dependent global loads at the top of every iteration it cost ~5 us per iteration with nothing to hide it behind.
     __shared__ int s_pi[AB_PPW], s_pm[AB_PPW], s_pray[AB_PPW];
-    __shared__ float s_pz[AB_PPW], s_plab[AB_PPW], s_pq[AB_PPW];
+    __shared__ float s_plab[AB_PPW], s_pq[AB_PPW];
     __shared__ uint32_t s_pbits[AB_PPW];
     __shared__ __attribute__((aligned(16))) float s_pdh[AB_PPW][16];
-    __shared__ float s_skt0[AB_MAXNB][12];
-    __shared__ float s_vol0[AB_MAXNB][VOL];
+    __shared__ float s_pp[AB_PPW][3];             // the pair's sample point o + d z
+    // two poses' transforms, volumes and volume-gradient accumulators in LDS: g0 (the pose of the chunk's first pair) and g0 + 1 --
+    // rows are ray-ordered, a chunk of ~170 pairs of one bone straddles a pose boundary about every other time
+    __shared__ float s_skt0[2][AB_MAXNB][12];
+    __shared__ float s_vol0[2][AB_MAXNB][VOL];
     int g0 = 0;
     // ---- gradient accumulators of this lane (hidden unit c of half `slot & 1`)
     float gw1[AB_W];                 // d W1[j][cc][c], cc = 0..31
@@ -157,8 +160,16 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         const int i = a.lists[(size_t)j * a.cap + sb_begin + tid];
         const bool coarse = i < first_f;
         const int m = a.row_sample[i];
-        s_pi[tid] = i; s_pm[tid] = m; s_pray[tid] = a.row_ray[i];
-        s_pz[tid] = coarse ? a.z_c[m] : a.z_f[m];
+        const int ray_ = a.row_ray[i];
+        s_pi[tid] = i; s_pm[tid] = m; s_pray[tid] = ray_;
+        const float z_ = coarse ? a.z_c[m] : a.z_f[m];
+        {
+            const float o[3] = {a.rays_o[3 * ray_], a.rays_o[3 * ray_ + 1], a.rays_o[3 * ray_ + 2]};
+            const float d[3] = {a.rays_d[3 * ray_], a.rays_d[3 * ray_ + 1], a.rays_d[3 * ray_ + 2]};
+            float p[3];
+            sample_point(o, d, z_, p);
+            s_pp[tid][0] = p[0]; s_pp[tid][1] = p[1]; s_pp[tid][2] = p[2];
+        }
         s_plab[tid] = (float)(coarse ? a.label_c[m] : a.label_f[m]);
         s_pbits[tid] = coarse ? a.bits_c[m] : a.bits_f[m];
         s_pq[tid] = a.h_rows[(size_t)i * 16 + 15];
@@ -169,9 +180,16 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     __syncthreads();
     if (sb_begin == p_begin) {
         g0 = min(s_pray[0] / rays_per_pose, a.G - 1);
-        // pose g0's bone transforms and volumes of the neighbourhood: LDS instead of two more dependent global round trips per pair
-        for (int i = tid; i < nq * 12; i += AB_THREADS) s_skt0[i / 12][i % 12] = a.skts[((size_t)g0 * J + s_nb[i / 12]) * 16 + i % 12];
-        for (int i = tid; i < nq * VOL; i += AB_THREADS) s_vol0[i / VOL][i % VOL] = a.volumes[((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL];
+        // the bone transforms and volumes of the neighbourhood for poses g0 and g0 + 1: LDS instead of two more dependent global
+        // round trips per pair
+        for (int i = tid; i < 2 * nq * 12; i += AB_THREADS) {
+            const int u = i / (nq * 12), r = i % (nq * 12), gg = min(g0 + u, a.G - 1);
+            s_skt0[u][r / 12][r % 12] = a.skts[((size_t)gg * J + s_nb[r / 12]) * 16 + r % 12];
+        }
+        for (int i = tid; i < 2 * nq * VOL; i += AB_THREADS) {
+            const int u = i / (nq * VOL), r = i % (nq * VOL), gg = min(g0 + u, a.G - 1);
+            s_vol0[u][r / VOL][r % VOL] = a.volumes[((size_t)gg * J + s_nb[r / VOL]) * VOL + r % VOL];
+        }
         __syncthreads();
     }
 
@@ -182,7 +200,9 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         const int pl = live ? pl_ : 0;
         const int ray = s_pray[pl];
         const int g = min(ray / rays_per_pose, a.G - 1);
-        const float zv = s_pz[pl], lab = s_plab[pl], qrow = s_pq[pl];
+        const int gl = g - g0;                              // 0 / 1: this pair's pose is one of the two held in LDS
+        const bool in_lds = gl == 0 || (gl == 1 && g0 + 1 < a.G);
+        const float lab = s_plab[pl], qrow = s_pq[pl];
         const uint32_t bits = s_pbits[pl];
         if (c < 16) s_dh[slot][c] = c < FEAT ? s_pdh[pl][c] : 0.f;
 
@@ -193,15 +213,13 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         const float* vol = nullptr;
         if (glane) {
             const int k = s_nb[gq];
-            const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
-            const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
-            float p[3], pl[3], pt[3], x[3], skt[12];
-            sample_point(o, d, zv, p);
-            const float* src = g == g0 ? s_skt0[gq] : a.skts + ((size_t)g * J + k) * 16;
+            const float p[3] = {s_pp[pl][0], s_pp[pl][1], s_pp[pl][2]};
+            float pl_[3], pt[3], x[3], skt[12];
+            const float* src = in_lds ? s_skt0[gl][gq] : a.skts + ((size_t)g * J + k) * 16;
 #pragma unroll
             for (int e = 0; e < 12; ++e) skt[e] = src[e];
-            affine_unfused(skt, p, pl);
-            affine_unfused(s_align[gq], pl, pt);
+            affine_unfused(skt, p, pl_);
+            affine_unfused(s_align[gq], pl_, pt);
 #pragma unroll
             for (int e = 0; e < 3; ++e) x[e] = div_rn(pt[e], fabsf(s_scale[gq][e]));
             win = coord_window(x);
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
             y1 = y0 + 1;
             ok0 = y0 >= 0 && y0 < VRES;
             ok1 = y1 >= 0 && y1 < VRES;
-            vol = g == g0 ? s_vol0[gq] : a.volumes + ((size_t)g * J + k) * VOL;
+            vol = in_lds ? s_vol0[gl][gq] : a.volumes + ((size_t)g * J + k) * VOL;
 #pragma unroll
             for (int f = 0; f < VOXF; ++f) {
                 const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         // ---- adjoint of the gather (k_backward.hip's arithmetic): lane (gq, gk)
         if (glane && live && win != 0.f) {
             const int k = s_nb[gq];
-            float* gv = g == g0 ? &s_gvol[gq][0] : a.g_vol + ((size_t)g * J + k) * VOL;
+            float* gv = in_lds ? &s_gvol[gl][gq][0] : a.g_vol + ((size_t)g * J + k) * VOL;
             float dx = 0.f;
 #pragma unroll
             for (int f = 0; f < VOXF; ++f) {
@@ -360,9 +378,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         if (s_dh[0][0] != 0.f) atomicAdd(a.g_b2 + j, s_dh[0][0]);
         if (s_dh[0][1] != 0.f) atomicAdd(a.loss + 2, s_dh[0][1]);
     }
-    for (int i = tid; i < nq * VOL; i += AB_THREADS) {
-        const float v = s_gvol[i / VOL][i % VOL];
-        if (v != 0.f) atomicAdd(a.g_vol + ((size_t)g0 * J + s_nb[i / VOL]) * VOL + i % VOL, v);
+    for (int i = tid; i < 2 * nq * VOL; i += AB_THREADS) {
+        const int u = i / (nq * VOL), r = i % (nq * VOL);
+        const float v = s_gvol[u][r / VOL][r % VOL];
+        if (v != 0.f && g0 + u < a.G) atomicAdd(a.g_vol + ((size_t)(g0 + u) * J + s_nb[r / VOL]) * VOL + r % VOL, v);
     }
 }
 
