@@ -52,10 +52,17 @@ struct ABArgs {
     float* loss;         // loss[2] += (label - q)^2 of in-volume rows
 };
 
+// sum over the 32 lanes of a wave half, in every lane of the half: DPP partial sums inside the 16-lane rows, row 0 / 2's total
+// carried into row 1 / 3 (row_bcast15), then lanes 31 and 63 read out -- about ten VALU instructions instead of five dependent
+// LDS-crossbar shuffles (the kernel takes ~7 such sums per iteration, each a chain of ~5 x 100 cycles before)
 __device__ __forceinline__ float half_sum32(float v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    float x = v;
+    DANBO_DPP_STEP(dpp_add_, 0.f, 0x111, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x112, 0xf)
+    DANBO_DPP_STEP(dpp_add_, 0.f, 0x114, 0xf) DANBO_DPP_STEP(dpp_add_, 0.f, 0x118, 0xf)
+    DANBO_DPP_STEP(dpp_add_, 0.f, 0x142, 0xa)
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+    return (threadIdx.x & 32) ? hi : lo;
 }
 
 __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int target_wgs) {
@@ -403,12 +410,12 @@ extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
     a.w0 = p->w0; a.adj_w = p->adj_w; a.adj = p->adj; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
     a.g_w0 = p->g_w0; a.g_adj_w = p->g_adj_w; a.g_b0 = p->g_b0; a.g_w1 = p->g_w1; a.g_b1 = p->g_b1; a.g_w2 = p->g_w2; a.g_b2 = p->g_b2;
     a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
-    // 128 .. 256 pairs per workgroup (chosen on the device, AB_PPW_MIN) amortise its weight staging and its flush; a sample lies in at most a few
-    // volumes, so 4 pairs per row of capacity is far above what geometry allows -- and workgroups without pairs exit at once
-    // The grid is a guess, not a bound: the kernel strides over the items the grid does not cover.
-    const long wgs = ((long)p->rows_cap * 4 + AB_PPW_MIN - 1) / AB_PPW_MIN + J;
-    const long max_wgs = (long)num_cu() * 64;
-    hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)(wgs < max_wgs ? wgs : max_wgs)), dim3(AB_THREADS), 0, (hipStream_t)stream, a,
-                       2 * num_cu() - J);
+    // The kernel chooses the pairs per workgroup on the device so that the chunks of all bones fit 2 workgroups per CU (its
+    // resident slots) -- sum_j ceil(cnt_j / ppw) <= target + J whatever the data -- so that is all the grid ever needs: a grid
+    // sized from the row CAPACITY launched thousands of workgroups that found no work (~90 us of empty launches per step).
+    const int target = 2 * num_cu() - J;
+    const long by_cap = ((long)p->rows_cap * J + AB_PPW_MIN - 1) / AB_PPW_MIN + J;      // no more chunks than that can exist
+    const long grid = by_cap < target + J ? by_cap : target + J;
+    hipLaunchKernelGGL(k_assign_bwd, dim3((unsigned)grid), dim3(AB_THREADS), 0, (hipStream_t)stream, a, target);
     DANBO_LAUNCH_RET();
 }
