@@ -65,6 +65,15 @@ __device__ __forceinline__ float half_sum32(float v) {
     return (threadIdx.x & 32) ? hi : lo;
 }
 
+// The per-pair scratch (s_f, s_a0, s_dz1, s_dz0, s_df, s_dh) is private to a 32-lane half, so the layers of one pair only have
+// to be ordered inside the wavefront: LDS executes a wavefront's operations in issue order, which leaves a compiler fence --
+// no s_barrier (with workgroup barriers the four wavefronts ran in lock step through five latency chains per iteration).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int target_wgs) {
     __shared__ float s_w0[AB_MAXNB][FEAT][AB_STRIDE];
     __shared__ float s_w1[AB_W][AB_STRIDE];
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
             }
             if (gk == 0) s_f[slot][gq][15] = 0.f;
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- layer 0: y_q[c], z0[c]
         float y[AB_MAXNB];
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         }
         const float a0 = fmaxf(z0, 0.f);
         s_a0[slot][c] = a0;
-        __syncthreads();
+        wave_sync();
         // ---- layer 1, 2
         float z1 = s_b1[c];
 #pragma unroll
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         s_dz1[slot][c] = dz1;
 #pragma unroll
         for (int cc = 0; cc < AB_W; ++cc) gw1[cc] = fmaf(s_a0[slot][cc], dz1, gw1[cc]);
-        __syncthreads();
+        wave_sync();
         float da0 = 0.f;
 #pragma unroll
         for (int cc = 0; cc < AB_W; ++cc) da0 = fmaf(s_w1[c][cc], s_dz1[slot][cc], da0);
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
                 for (int t = 0; t < FEAT; ++t) gw0[q][t] = fmaf(s_f[slot][q][t], dy, gw0[q][t]);
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- d f_q[t] = A_jq sum_cc dz0[cc] W0_q[t][cc]  (+ p d h[t] for the bone itself): (q, t) pairs spread over the half
         for (int e = c; e < nq * FEAT; e += 32) {
             const int q = e / FEAT, t = e % FEAT;
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
             if (q == 0) acc = fmaf(pj, s_dh[slot][t], acc);
             s_df[slot][q][t] = live ? acc : 0.f;
         }
-        __syncthreads();
+        wave_sync();
         // ---- adjoint of the gather (k_backward.hip's arithmetic): lane (gq, gk)
         if (glane && live && win != 0.f) {
             const int k = s_nb[gq];
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
             dx *= 0.5f * (float)VRES;
             gsc += dx * (-x_k / fabsf(sck)) * (sck < 0.f ? -1.f : 1.f);
         }
-        // (the next iteration's first barrier orders its scratch writes after these reads)
+        wave_sync();                    // the next iteration's scratch writes come after these reads
     }
     }   // sub-batches
 
