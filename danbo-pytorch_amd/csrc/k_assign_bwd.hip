@@ -33,6 +33,29 @@ constexpr int AB_PAIRS = 8;          // pairs in flight per workgroup (4 wavefro
 // round and a 25 % one)
 constexpr int AB_PPW_MIN = 32, AB_PPW = 128;      // AB_PPW: pairs per sub-batch (the LDS row tables); larger chunks take several.  66 KB of LDS, two workgroups per CU
 
+// the overlaid LDS region (bytes) and the flush's accumulator rows (fp64 words) that take it over
+constexpr int AB_OFF_W0 = 0;
+constexpr int AB_OFF_W1 = AB_OFF_W0 + AB_MAXNB * FEAT * AB_STRIDE * 4;
+constexpr int AB_OFF_PDH = (AB_OFF_W1 + AB_W * AB_STRIDE * 4 + 15) & ~15;
+constexpr int AB_OFF_VOL0 = AB_OFF_PDH + AB_PPW * 16 * 4;
+constexpr int AB_OVER_BYTES = AB_OFF_VOL0 + 2 * AB_MAXNB * VOL * 4;
+constexpr int ACC_W1 = 0;                                   // [cc][c]
+constexpr int ACC_W0 = ACC_W1 + AB_W * AB_W;                // [q][t][c]
+constexpr int ACC_B1 = ACC_W0 + AB_MAXNB * FEAT * AB_W;     // [c]
+constexpr int ACC_W2 = ACC_B1 + AB_W;
+constexpr int ACC_B0 = ACC_W2 + AB_W;
+constexpr int ACC_ADJ = ACC_B0 + AB_W;                      // [q]
+constexpr int ACC_SC = ACC_ADJ + 8;                         // [q][3]
+constexpr int ACC_B2 = ACC_SC + 3 * AB_MAXNB + 2;
+constexpr int ACC_LSS = ACC_B2 + 1;
+constexpr int ACC_N = ACC_LSS + 1;
+static_assert(ACC_N * 8 <= AB_OVER_BYTES, "the fp64 accumulators must fit the dead tables");
+
+// LDS accumulation goes through fp64: on gfx950 ds_add_f32 takes ~80 ns per wavefront instruction per CU (measured,
+// tools/probe/lds_atomic.hip: 40x a ds_add_u32, 22x a ds_add_f64 -- at every contention level), which made the 8 adds per pair of the
+// gather adjoint 49 us and the end-of-workgroup reduction 60 us of this kernel's 274
+__device__ __forceinline__ void ab_lds_add(double* p, float v) { atomicAdd(p, (double)v); }
+
 struct ABArgs {
     // geometry
     const float *rays_o, *rays_d, *z_c, *z_f, *skts, *align, *axis_scale, *volumes;
@@ -75,13 +98,18 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int target_wgs) {
-    __shared__ float s_w0[AB_MAXNB][FEAT][AB_STRIDE];
-    __shared__ float s_w1[AB_W][AB_STRIDE];
+    // s_w0, s_w1, s_pdh and s_vol0 are carved from one region: they are dead once the pair loop is over, and the flush re-uses the
+    // region as its fp64 accumulators (AbAcc)
+    __shared__ __attribute__((aligned(16))) char s_over[AB_OVER_BYTES];
+    auto& s_w0 = *reinterpret_cast<float(*)[AB_MAXNB][FEAT][AB_STRIDE]>(s_over + AB_OFF_W0);
+    auto& s_w1 = *reinterpret_cast<float(*)[AB_W][AB_STRIDE]>(s_over + AB_OFF_W1);
+    auto& s_pdh = *reinterpret_cast<float(*)[AB_PPW][16]>(s_over + AB_OFF_PDH);
+    auto& s_vol0 = *reinterpret_cast<float(*)[2][AB_MAXNB][VOL]>(s_over + AB_OFF_VOL0);
     __shared__ float s_b0[AB_W], s_b1[AB_W], s_w2[AB_W];
     __shared__ float s_adj[AB_MAXNB], s_align[AB_MAXNB][12], s_scale[AB_MAXNB][4];
     __shared__ int s_nb[AB_MAXNB];
     __shared__ int s_nq;
-    __shared__ float s_gvol[2][AB_MAXNB][VOL];
+    __shared__ double s_gvol[2][AB_MAXNB][VOL];        // fp64: see ab_lds_add
     // per-pair scratch (one per wave half)
     __shared__ __attribute__((aligned(16))) float s_f[AB_PAIRS][AB_MAXNB][16];
     __shared__ __attribute__((aligned(16))) float s_df[AB_PAIRS][AB_MAXNB][16];
@@ -134,7 +162,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     if (tid < nq) s_adj[tid] = a.adj_w[j * J + s_nb[tid]] * a.adj[j * J + s_nb[tid]];
     for (int i = tid; i < nq * 12; i += AB_THREADS) s_align[i / 12][i % 12] = a.align[s_nb[i / 12] * 16 + i % 12];
     for (int i = tid; i < nq * 4; i += AB_THREADS) s_scale[i / 4][i % 4] = (i % 4) < 3 ? a.axis_scale[s_nb[i / 4] * 3 + i % 4] : 1.f;
-    for (int i = tid; i < 2 * AB_MAXNB * VOL; i += AB_THREADS) (&s_gvol[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * AB_MAXNB * VOL; i += AB_THREADS) (&s_gvol[0][0][0])[i] = 0.0;
     __syncthreads();
     const float b2 = a.b2[j];
     const int first_f = a.cnt[2];
@@ -146,12 +174,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     __shared__ int s_pi[AB_PPW], s_pm[AB_PPW], s_pray[AB_PPW];
     __shared__ float s_plab[AB_PPW], s_pq[AB_PPW];
     __shared__ uint32_t s_pbits[AB_PPW];
-    __shared__ __attribute__((aligned(16))) float s_pdh[AB_PPW][16];
     __shared__ float s_pp[AB_PPW][3];             // the pair's sample point o + d z
     // two poses' transforms, volumes and volume-gradient accumulators in LDS: g0 (the pose of the chunk's first pair) and g0 + 1 --
     // rows are ray-ordered, a chunk of ~170 pairs of one bone straddles a pose boundary about every other time
     __shared__ float s_skt0[2][AB_MAXNB][12];
-    __shared__ float s_vol0[2][AB_MAXNB][VOL];
     int g0 = 0;
     // ---- gradient accumulators of this lane (hidden unit c of half `slot & 1`)
     float gw1[AB_W];                 // d W1[j][cc][c], cc = 0..31
@@ -329,15 +355,21 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         // ---- adjoint of the gather (k_backward.hip's arithmetic): lane (gq, gk)
         if (glane && live && win != 0.f) {
             const int k = s_nb[gq];
-            float* gv = in_lds ? &s_gvol[gl][gq][0] : a.g_vol + ((size_t)g * J + k) * VOL;
+            float* gv = a.g_vol + ((size_t)g * J + k) * VOL;
+            double* gl_v = &s_gvol[in_lds ? gl : 0][gq][0];
             float dx = 0.f;
 #pragma unroll
             for (int f = 0; f < VOXF; ++f) {
                 const float gqv = s_df[slot][gq][f * 3 + gk] * win;
                 const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
                 const float v1 = ok1 ? vol[f * (VRES * 3) + y1 * 3 + gk] : 0.f;
-                if (ok0) atomicAdd(gv + f * (VRES * 3) + y0 * 3 + gk, gqv * w0t);
-                if (ok1) atomicAdd(gv + f * (VRES * 3) + y1 * 3 + gk, gqv * w1t);
+                if (in_lds) {
+                    if (ok0) ab_lds_add(gl_v + f * (VRES * 3) + y0 * 3 + gk, gqv * w0t);
+                    if (ok1) ab_lds_add(gl_v + f * (VRES * 3) + y1 * 3 + gk, gqv * w1t);
+                } else {
+                    if (ok0) atomicAdd(gv + f * (VRES * 3) + y0 * 3 + gk, gqv * w0t);
+                    if (ok1) atomicAdd(gv + f * (VRES * 3) + y1 * 3 + gk, gqv * w1t);
+                }
                 dx += gqv * (v1 - v0);
             }
             dx *= 0.5f * (float)VRES;
@@ -347,56 +379,60 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     }
     }   // sub-batches
 
-    // ---- flush: the 8 pair slots of the workgroup first add up in LDS (the weight tables are dead by now and become the
-    // accumulators), then every entry goes to global memory with one atomic
+    // ---- flush: the 8 pair slots of the workgroup first add up in LDS (the tables of the overlaid region are dead by now and
+    // become fp64 accumulators), then every entry goes to global memory with one atomic
     __syncthreads();
-    for (int i = tid; i < AB_MAXNB * FEAT * AB_STRIDE; i += AB_THREADS) (&s_w0[0][0][0])[i] = 0.f;
-    for (int i = tid; i < AB_W * AB_STRIDE; i += AB_THREADS) (&s_w1[0][0])[i] = 0.f;
-    if (tid < AB_W) { s_b0[tid] = 0.f; s_b1[tid] = 0.f; s_w2[tid] = 0.f; }
-    if (tid < AB_MAXNB) { s_adj[tid] = 0.f; }
-    if (tid < AB_MAXNB * 4) (&s_scale[0][0])[tid] = 0.f;
-    if (tid < 16) s_dh[0][tid] = 0.f;
+    double* acc = reinterpret_cast<double*>(s_over);
+    for (int i = tid; i < ACC_N; i += AB_THREADS) acc[i] = 0.0;
     __syncthreads();
 #pragma unroll
-    for (int cc = 0; cc < AB_W; ++cc) atomicAdd(&s_w1[cc][c], gw1[cc]);
+    for (int cc = 0; cc < AB_W; ++cc) ab_lds_add(acc + ACC_W1 + cc * AB_W + c, gw1[cc]);
 #pragma unroll
     for (int q = 0; q < AB_MAXNB; ++q) {
         if (q < nq) {
 #pragma unroll
-            for (int t = 0; t < FEAT; ++t) atomicAdd(&s_w0[q][t][c], gw0[q][t]);
-            if (c == 0) atomicAdd(&s_adj[q], gadj[q]);
+            for (int t = 0; t < FEAT; ++t) ab_lds_add(acc + ACC_W0 + (q * FEAT + t) * AB_W + c, gw0[q][t]);
+            if (c == 0) ab_lds_add(acc + ACC_ADJ + q, gadj[q]);
         }
     }
-    atomicAdd(&s_b1[c], gb1);
-    atomicAdd(&s_w2[c], gw2);
-    atomicAdd(&s_b0[c], gb0);
-    if (c == 0) { atomicAdd(&s_dh[0][0], gb2); atomicAdd(&s_dh[0][1], lss); }
-    if (glane) atomicAdd(&s_scale[gq][gk], gsc);
+    ab_lds_add(acc + ACC_B1 + c, gb1);
+    ab_lds_add(acc + ACC_W2 + c, gw2);
+    ab_lds_add(acc + ACC_B0 + c, gb0);
+    if (c == 0) { ab_lds_add(acc + ACC_B2, gb2); ab_lds_add(acc + ACC_LSS, lss); }
+    if (glane) ab_lds_add(acc + ACC_SC + gq * 3 + gk, gsc);
     __syncthreads();
     float* gw1p = a.g_w1 + (size_t)j * AB_W * AB_W;
     for (int i = tid; i < AB_W * AB_W; i += AB_THREADS) {
-        const float v = s_w1[i / AB_W][i % AB_W];
+        const float v = (float)acc[ACC_W1 + i];
         if (v != 0.f) atomicAdd(gw1p + i, v);
     }
     for (int i = tid; i < nq * FEAT * AB_W; i += AB_THREADS) {
-        const int q = i / (FEAT * AB_W), t = (i / AB_W) % FEAT, cc = i % AB_W;
-        const float v = s_w0[q][t][cc];
-        if (v != 0.f) atomicAdd(a.g_w0 + ((size_t)s_nb[q] * FEAT + t) * AB_W + cc, v);
+        const int q = i / (FEAT * AB_W), r = i % (FEAT * AB_W);
+        const float v = (float)acc[ACC_W0 + i];
+        if (v != 0.f) atomicAdd(a.g_w0 + (size_t)s_nb[q] * FEAT * AB_W + r, v);
     }
     if (tid < AB_W) {
-        if (s_b1[tid] != 0.f) atomicAdd(a.g_b1 + j * AB_W + tid, s_b1[tid]);
-        if (s_w2[tid] != 0.f) atomicAdd(a.g_w2 + j * AB_W + tid, s_w2[tid]);
-        if (s_b0[tid] != 0.f) atomicAdd(a.g_b0 + tid, s_b0[tid]);
+        const float vb1 = (float)acc[ACC_B1 + tid], vw2 = (float)acc[ACC_W2 + tid], vb0 = (float)acc[ACC_B0 + tid];
+        if (vb1 != 0.f) atomicAdd(a.g_b1 + j * AB_W + tid, vb1);
+        if (vw2 != 0.f) atomicAdd(a.g_w2 + j * AB_W + tid, vw2);
+        if (vb0 != 0.f) atomicAdd(a.g_b0 + tid, vb0);
     }
-    if (tid < nq && s_adj[tid] != 0.f) atomicAdd(a.g_adj_w + j * J + s_nb[tid], s_adj[tid] * a.adj[j * J + s_nb[tid]]);
-    if (tid < nq * 3 && s_scale[tid / 3][tid % 3] != 0.f) atomicAdd(a.g_scale + s_nb[tid / 3] * 3 + tid % 3, s_scale[tid / 3][tid % 3]);
+    if (tid < nq) {
+        const float v = (float)acc[ACC_ADJ + tid];
+        if (v != 0.f) atomicAdd(a.g_adj_w + j * J + s_nb[tid], v * a.adj[j * J + s_nb[tid]]);
+    }
+    if (tid < nq * 3) {
+        const float v = (float)acc[ACC_SC + tid];
+        if (v != 0.f) atomicAdd(a.g_scale + s_nb[tid / 3] * 3 + tid % 3, v);
+    }
     if (tid == 0) {
-        if (s_dh[0][0] != 0.f) atomicAdd(a.g_b2 + j, s_dh[0][0]);
-        if (s_dh[0][1] != 0.f) atomicAdd(a.loss + 2, s_dh[0][1]);
+        const float vb2 = (float)acc[ACC_B2], vl = (float)acc[ACC_LSS];
+        if (vb2 != 0.f) atomicAdd(a.g_b2 + j, vb2);
+        if (vl != 0.f) atomicAdd(a.loss + 2, vl);
     }
     for (int i = tid; i < 2 * nq * VOL; i += AB_THREADS) {
         const int u = i / (nq * VOL), r = i % (nq * VOL);
-        const float v = s_gvol[u][r / VOL][r % VOL];
+        const float v = (float)s_gvol[u][r / VOL][r % VOL];
         if (v != 0.f && g0 + u < a.G) atomicAdd(a.g_vol + ((size_t)(g0 + u) * J + s_nb[r / VOL]) * VOL + r % VOL, v);
     }
 }
