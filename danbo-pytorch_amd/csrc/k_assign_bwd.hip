@@ -252,14 +252,21 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         float x_k = 0.f, win = 0.f, w0t = 0.f, w1t = 0.f, sck = 1.f;
         int y0 = 0, y1 = 0;
         bool ok0 = false, ok1 = false;
-        const float* vol = nullptr;
+        int o0 = 0, o1 = 0;
         if (glane) {
             const int k = s_nb[gq];
             const float p[3] = {s_pp[pl][0], s_pp[pl][1], s_pp[pl][2]};
             float pl_[3], pt[3], x[3], skt[12];
-            const float* src = in_lds ? s_skt0[gl][gq] : a.skts + ((size_t)g * J + k) * 16;
+            // (LDS and global memory take separate branches: a pointer that may be either compiles to FLAT loads, and the
+            //  conditional voxel reads to one waited round trip each -- ~17 serial vector-memory round trips per iteration)
+            if (in_lds) {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) skt[e] = src[e];
+                for (int e = 0; e < 12; ++e) skt[e] = s_skt0[gl][gq][e];
+            } else {
+                const float* src = a.skts + ((size_t)g * J + k) * 16;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) skt[e] = src[e];
+            }
             affine_unfused(skt, p, pl_);
             affine_unfused(s_align[gq], pl_, pt);
 #pragma unroll
@@ -275,13 +282,20 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
             y1 = y0 + 1;
             ok0 = y0 >= 0 && y0 < VRES;
             ok1 = y1 >= 0 && y1 < VRES;
-            vol = in_lds ? s_vol0[gl][gq] : a.volumes + ((size_t)g * J + k) * VOL;
+            o0 = min(max(y0, 0), VRES - 1) * 3 + gk;       // clamped: every voxel read is unconditional, one batch
+            o1 = min(max(y1, 0), VRES - 1) * 3 + gk;
+            float v0[VOXF], v1[VOXF];
+            if (in_lds) {
 #pragma unroll
-            for (int f = 0; f < VOXF; ++f) {
-                const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
-                const float v1 = ok1 ? vol[f * (VRES * 3) + y1 * 3 + gk] : 0.f;
-                s_f[slot][gq][f * 3 + gk] = mul_rn(add_rn(mul_rn(v0, w0t), mul_rn(v1, w1t)), win);
+                for (int f = 0; f < VOXF; ++f) { v0[f] = s_vol0[gl][gq][f * (VRES * 3) + o0]; v1[f] = s_vol0[gl][gq][f * (VRES * 3) + o1]; }
+            } else {
+                const float* vol = a.volumes + ((size_t)g * J + k) * VOL;
+#pragma unroll
+                for (int f = 0; f < VOXF; ++f) { v0[f] = vol[f * (VRES * 3) + o0]; v1[f] = vol[f * (VRES * 3) + o1]; }
             }
+#pragma unroll
+            for (int f = 0; f < VOXF; ++f)
+                s_f[slot][gq][f * 3 + gk] = mul_rn(add_rn(mul_rn(ok0 ? v0[f] : 0.f, w0t), mul_rn(ok1 ? v1[f] : 0.f, w1t)), win);
             if (gk == 0) s_f[slot][gq][15] = 0.f;
         }
         wave_sync();
@@ -355,22 +369,28 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         // ---- adjoint of the gather (k_backward.hip's arithmetic): lane (gq, gk)
         if (glane && live && win != 0.f) {
             const int k = s_nb[gq];
-            float* gv = a.g_vol + ((size_t)g * J + k) * VOL;
-            double* gl_v = &s_gvol[in_lds ? gl : 0][gq][0];
-            float dx = 0.f;
+            float dx = 0.f, gqv[VOXF];
 #pragma unroll
-            for (int f = 0; f < VOXF; ++f) {
-                const float gqv = s_df[slot][gq][f * 3 + gk] * win;
-                const float v0 = ok0 ? vol[f * (VRES * 3) + y0 * 3 + gk] : 0.f;
-                const float v1 = ok1 ? vol[f * (VRES * 3) + y1 * 3 + gk] : 0.f;
-                if (in_lds) {
-                    if (ok0) ab_lds_add(gl_v + f * (VRES * 3) + y0 * 3 + gk, gqv * w0t);
-                    if (ok1) ab_lds_add(gl_v + f * (VRES * 3) + y1 * 3 + gk, gqv * w1t);
-                } else {
-                    if (ok0) atomicAdd(gv + f * (VRES * 3) + y0 * 3 + gk, gqv * w0t);
-                    if (ok1) atomicAdd(gv + f * (VRES * 3) + y1 * 3 + gk, gqv * w1t);
+            for (int f = 0; f < VOXF; ++f) gqv[f] = s_df[slot][gq][f * 3 + gk] * win;
+            if (in_lds) {
+                double* gv = &s_gvol[gl][gq][0];
+#pragma unroll
+                for (int f = 0; f < VOXF; ++f) {
+                    const float v0 = ok0 ? s_vol0[gl][gq][f * (VRES * 3) + o0] : 0.f, v1 = ok1 ? s_vol0[gl][gq][f * (VRES * 3) + o1] : 0.f;
+                    if (ok0) ab_lds_add(gv + f * (VRES * 3) + o0, gqv[f] * w0t);
+                    if (ok1) ab_lds_add(gv + f * (VRES * 3) + o1, gqv[f] * w1t);
+                    dx += gqv[f] * (v1 - v0);
                 }
-                dx += gqv * (v1 - v0);
+            } else {
+                const float* vol = a.volumes + ((size_t)g * J + k) * VOL;
+                float* gv = a.g_vol + ((size_t)g * J + k) * VOL;
+#pragma unroll
+                for (int f = 0; f < VOXF; ++f) {
+                    const float v0 = ok0 ? vol[f * (VRES * 3) + o0] : 0.f, v1 = ok1 ? vol[f * (VRES * 3) + o1] : 0.f;
+                    if (ok0) atomicAdd(gv + f * (VRES * 3) + o0, gqv[f] * w0t);
+                    if (ok1) atomicAdd(gv + f * (VRES * 3) + o1, gqv[f] * w1t);
+                    dx += gqv[f] * (v1 - v0);
+                }
             }
             dx *= 0.5f * (float)VRES;
             gsc += dx * (-x_k / fabsf(sck)) * (sck < 0.f ? -1.f : 1.f);
