@@ -180,16 +180,21 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     __shared__ float s_skt0[2][AB_MAXNB][12];
     int g0 = 0;
     // ---- gradient accumulators of this lane (hidden unit c of half `slot & 1`)
-    float gw1[AB_W];                 // d W1[j][cc][c], cc = 0..31
-    float gw0[AB_MAXNB][FEAT];       // d W0[nb q][t][c]
+    // The two halves of a wavefront SHARE one set of weight-gradient accumulators: half h keeps rows cc = 16 h .. 16 h + 15 of
+    // d W1 and features t = 8 h .. 8 h + 7 of d W0 -- for BOTH pairs of the wavefront (the other pair's dz1 / dz0 come from its
+    // scratch).  Same FMA count as one full set per half, 70 accumulators instead of 134: nothing spills inside the pair loop
+    // (a spilled value costs a waited scratch round trip, ~0.5 us, and there were nine per iteration).
+    const int h = (lane >> 5) & 1;
+    float gw1[AB_W / 2];             // d W1[j][16 h + i][c]
+    float gw0[AB_MAXNB][8];          // d W0[nb q][8 h + i][c]   (t = 15: the zero pad of s_f, never flushed)
     float gb1 = 0.f, gw2 = 0.f, gb0 = 0.f, gb2 = 0.f, gadj[AB_MAXNB], gsc = 0.f, lss = 0.f;
 #pragma unroll
-    for (int i = 0; i < AB_W; ++i) gw1[i] = 0.f;
+    for (int i = 0; i < AB_W / 2; ++i) gw1[i] = 0.f;
 #pragma unroll
     for (int q = 0; q < AB_MAXNB; ++q) {
         gadj[q] = 0.f;
 #pragma unroll
-        for (int t = 0; t < FEAT; ++t) gw0[q][t] = 0.f;
+        for (int t = 0; t < 8; ++t) gw0[q][t] = 0.f;
     }
     // lanes 0 .. 3 nq - 1 of a half: (neighbour gq, axis gk) of the gather and of its adjoint
     const int gq = c / 3, gk = c % 3;
@@ -335,26 +340,32 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         const float dz1 = z1 > 0.f ? dlogit * s_w2[c] : 0.f;
         gb1 += dz1;
         s_dz1[slot][c] = dz1;
-#pragma unroll
-        for (int cc = 0; cc < AB_W; ++cc) gw1[cc] = fmaf(s_a0[slot][cc], dz1, gw1[cc]);
         wave_sync();
+        {
+            const float dz1_o = s_dz1[slot ^ 1][c];            // the wavefront's other pair
+#pragma unroll
+            for (int i = 0; i < AB_W / 2; ++i)
+                gw1[i] = fmaf(s_a0[slot ^ 1][16 * h + i], dz1_o, fmaf(s_a0[slot][16 * h + i], dz1, gw1[i]));
+        }
         float da0 = 0.f;
 #pragma unroll
         for (int cc = 0; cc < AB_W; ++cc) da0 = fmaf(s_w1[c][cc], s_dz1[slot][cc], da0);
         const float dz0 = z0 > 0.f ? da0 : 0.f;
         gb0 += dz0;
         s_dz0[slot][c] = dz0;
+        wave_sync();
         // ---- layer 0 adjoints: adjacency, W0
+        const float dz0_o = s_dz0[slot ^ 1][c];
 #pragma unroll
         for (int q = 0; q < AB_MAXNB; ++q) {
             if (q < nq) {
                 gadj[q] += half_sum32(dz0 * y[q]);
-                const float dy = s_adj[q] * dz0;
+                const float dy = s_adj[q] * dz0, dy_o = s_adj[q] * dz0_o;
 #pragma unroll
-                for (int t = 0; t < FEAT; ++t) gw0[q][t] = fmaf(s_f[slot][q][t], dy, gw0[q][t]);
+                for (int i = 0; i < 8; ++i)
+                    gw0[q][i] = fmaf(s_f[slot ^ 1][q][8 * h + i], dy_o, fmaf(s_f[slot][q][8 * h + i], dy, gw0[q][i]));
             }
         }
-        wave_sync();
         // ---- d f_q[t] = A_jq sum_cc dz0[cc] W0_q[t][cc]  (+ p d h[t] for the bone itself): (q, t) pairs spread over the half
         for (int e = c; e < nq * FEAT; e += 32) {
             const int q = e / FEAT, t = e % FEAT;
@@ -406,12 +417,13 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
     for (int i = tid; i < ACC_N; i += AB_THREADS) acc[i] = 0.0;
     __syncthreads();
 #pragma unroll
-    for (int cc = 0; cc < AB_W; ++cc) ab_lds_add(acc + ACC_W1 + cc * AB_W + c, gw1[cc]);
+    for (int i = 0; i < AB_W / 2; ++i) ab_lds_add(acc + ACC_W1 + (16 * h + i) * AB_W + c, gw1[i]);
 #pragma unroll
     for (int q = 0; q < AB_MAXNB; ++q) {
         if (q < nq) {
 #pragma unroll
-            for (int t = 0; t < FEAT; ++t) ab_lds_add(acc + ACC_W0 + (q * FEAT + t) * AB_W + c, gw0[q][t]);
+            for (int i = 0; i < 8; ++i)
+                if (8 * h + i < FEAT) ab_lds_add(acc + ACC_W0 + (q * FEAT + 8 * h + i) * AB_W + c, gw0[q][i]);
             if (c == 0) ab_lds_add(acc + ACC_ADJ + q, gadj[q]);
         }
     }
