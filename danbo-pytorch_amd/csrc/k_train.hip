@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_fill_raw_lazy(const float4* __restrict_
 // has to be an eager call (the trainer warms the step up before it captures it): streams cannot be created during a capture.
 struct SideStreams {
     hipStream_t s[2];
-    hipEvent_t fork, join[2];
+    hipEvent_t fork, join[2], mid;
     bool ok;
 };
 static SideStreams* side_streams() {
@@ -292,7 +292,8 @@ static SideStreams* side_streams() {
                 hipStreamCreateWithFlags(&ss.s[1], hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.join[0], hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&ss.join[1], hipEventDisableTiming) == hipSuccess;
+                hipEventCreateWithFlags(&ss.join[1], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.mid, hipEventDisableTiming) == hipSuccess;
         if (!ss.ok) (void)hipGetLastError();
         made.fetch_or(bit, std::memory_order_release);
     }
@@ -461,7 +462,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_STAGE(9);
     // ---- three independent branches behind the chain:
     //   side 0: per-ray view gradients (d cview, views_linears.0's per-ray columns, per-camera sums for the frame codes)
-    //   side 1: (whole step only) weight / bias gradients of all dense layers, then -- with side 0's camera sums -- the chain rule of
+    //   side 1: (whole step only; starts behind the K2 adjoint) weight / bias gradients of all dense layers, then -- with side 0's camera sums -- the chain rule of
     //           the merged feature / view layer and the frame codes
     //   main  : K2 / K1b adjoint -> pose GNN adjoint
     ss = (fork_mask & 2) ? ss_all : nullptr;
@@ -472,14 +473,15 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     }
     DANBO_TRY(danbo_train_view_grads(b.dpre_v, b.row_ray, b.cnt, ncap, R, b.vin, LD_VIN, m->view_ch, bt->cam_idx, m->n_codes, b.d_cview, b.csum,
                                      m->g[DANBO_T_VIEWS_W], s0));
-    if (phase == 0 && ss) {
+    auto side1_tail = [&]() -> int {
         DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, s1));
         if (hipEventRecord(ss->join[0], ss->s[0]) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->join[0], 0) != hipSuccess)
             return (int)hipGetLastError();
         DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W],
                                          m->view_ch, m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B],
                                          m->g[DANBO_T_VIEWS_W], m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, s1));
-    }
+        return 0;
+    };
     DANBO_TRY(danbo_train_bone_lists(b.bits_c, b.bits_f, b.row_sample, b.cnt, R, ncap, b.lists, b.cntb, stream));
     DANBO_STAGE(10);
     DanboAssignBwd ab{};
@@ -495,6 +497,13 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     ab.c_ss = 2.0f * m->soft_softmax_coef / ((float)R * (float)(S + Sf));
     ab.loss = b.loss;
     DANBO_TRY(danbo_assign_blend_bwd(&ab, stream));
+    // The weight-gradient kernel waits for the K2 adjoint: side by side the two just share the compute units (their LDS footprints
+    // exclude each other per CU) and the pose-GNN adjoint -- six small launches -- then ran on an otherwise idle device; behind it,
+    // those launches hide under the weight gradients (1.71 -> 1.68 ms per step, 0.98 -> 0.94 at 384 rays)
+    if (phase == 0 && ss) {
+        if (hipEventRecord(ss->mid, st) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->mid, 0) != hipSuccess) return (int)hipGetLastError();
+        DANBO_TRY(side1_tail());
+    }
     DANBO_STAGE(11);
     DANBO_TRY(danbo_pose_volumes_bwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], m->p[DANBO_T_G_ADJW0], m->g_adj0,
                                      m->p[DANBO_T_G_B0], m->p[DANBO_T_G_W1], m->p[DANBO_T_G_ADJW1], m->g_adj1, m->p[DANBO_T_G_B1],
