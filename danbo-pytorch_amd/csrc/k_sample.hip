@@ -555,6 +555,48 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int St = S + Sf;
+    if (St <= 64) {
+        // one chunk per ray, software-pipelined over the wavefront's rays: a ray is the chain sorted_idx -> in-volume word -> raw;
+        // the index of ray r + 2 and the word of ray r + 1 are in flight while ray r is composited
+        const bool act = lane < St;
+        struct Idx { int src; float zs, z1, dn; float4 re; };
+        auto fetch_idx = [&](int r) {
+            Idx in;
+            const size_t m = (size_t)r * St + (act ? lane : St - 1);
+            in.src = min(max(sorted_idx[m], 0), St - 1);     // NaN depths must not become an out-of-bounds read
+            in.zs = z[m];
+            in.z1 = (lane + 1 < St) ? z[m + 1] : 0.f;
+            in.dn = ray_norm(rays_d, r);
+            in.re = raw_empty ? raw_empty[r] : float4{0.f, 0.f, 0.f, 0.f};
+            return in;
+        };
+        auto fetch_word = [&](int r, int src) -> uint32_t {
+            if (src < S) return bits_a ? bits_a[(size_t)r * S + src] : 1u;
+            return bits_b ? bits_b[(size_t)r * Sf + (src - S)] : 1u;
+        };
+        auto clampr = [&](int r) { return r < R ? r : (wave < R ? wave : 0); };
+        Idx cur = fetch_idx(clampr(wave)), nxt = fetch_idx(clampr(wave + nwaves));
+        uint32_t cur_word = fetch_word(clampr(wave), cur.src);
+        for (int r = wave; r < R; r += nwaves) {
+            CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const size_t m = (size_t)r * St + (act ? lane : St - 1);
+            float4 rw = cur.re;
+            if (cur_word != 0u) rw = cur.src < S ? raw_a[(size_t)r * S + cur.src] : raw_b[(size_t)r * Sf + (cur.src - S)];
+            const uint32_t nxt_word = fetch_word(clampr(r + nwaves), nxt.src);
+            const Idx nn = fetch_idx(clampr(r + 2 * nwaves));
+            const float gap = (lane + 1 < St) ? sub_rn(cur.z1, cur.zs) : 1e10f;
+            float al;
+            const float w = composite_chunk(st, rw, cur.zs, gap, cur.dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+            if (act) {
+                if (weights) weights[m] = w;
+                if (alpha_out) alpha_out[m] = al;
+                if (raw_sorted) raw_sorted[m] = rw;
+            }
+            if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
+            cur = nxt; cur_word = nxt_word; nxt = nn;
+        }
+        return;
+    }
     for (int r = wave; r < R; r += nwaves) {
         const float dn = ray_norm(rays_d, r);
         CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -736,22 +778,39 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int r = wave; r < R; r += nwaves) {
-        const float dn = ray_norm(rays_d, r);
-        CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const bool act = lane < S;
+    const bool act = lane < S;
+    // A wavefront walks ~32 rays one after the other and a ray is a chain of dependent loads (in-volume word -> raw) before any
+    // arithmetic: software-pipelined by one ray -- the next ray's word, depths, direction and empty-space raw are requested before
+    // this ray's arithmetic, so only the (masked) raw load is waited for at full latency
+    struct RayIn { uint32_t word; float zs, z1, dn; float4 re; };
+    auto fetch = [&](int r) {
+        RayIn in;
         const size_t m = (size_t)r * S + (act ? lane : S - 1);
-        const float4 rw = (bits && bits[m] == 0u) ? raw_empty[r] : raw[m];
-        const float zs = z[m];
-        const float gap = (lane + 1 < S) ? sub_rn(z[m + 1], zs) : 1e10f;
+        in.word = bits ? bits[m] : 1u;
+        in.zs = z[m];
+        in.z1 = (lane + 1 < S) ? z[m + 1] : 0.f;
+        in.dn = ray_norm(rays_d, r);
+        in.re = bits ? raw_empty[r] : float4{0.f, 0.f, 0.f, 0.f};
+        return in;
+    };
+    RayIn cur = fetch(wave < R ? wave : 0);
+    for (int r = wave; r < R; r += nwaves) {
+        CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const size_t m = (size_t)r * S + (act ? lane : S - 1);
+        float4 rw = cur.re;
+        if (cur.word != 0u) rw = raw[m];
+        const RayIn nxt = fetch(r + nwaves < R ? r + nwaves : r);
+        const float zs = cur.zs;
+        const float gap = (lane + 1 < S) ? sub_rn(cur.z1, zs) : 1e10f;
         float al;
-        const float w = composite_chunk(st, rw, zs, gap, dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+        const float w = composite_chunk(st, rw, zs, gap, cur.dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
         if (act) {
             if (weights) weights[m] = w;
             if (alpha_out) alpha_out[m] = al;
         }
         if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
         importance_wave<DET>(act ? zs : INFINITY, act ? w : 0.f, r, S, Sf, u, lane, z_fine, z_sorted, sorted_idx);
+        cur = nxt;
     }
 }
 
