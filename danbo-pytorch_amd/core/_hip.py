@@ -127,7 +127,7 @@ class DanboAssignBwd(ctypes.Structure):
                 + [(n, P) for n in ("row_sample", "row_ray", "cnt", "lists", "cntb", "h_rows", "d_h", "label_c", "label_f", "bits_c",
                                     "bits_f", "w0", "adj_w", "adj", "b0", "w1", "b1", "w2", "b2", "g_w0", "g_adj_w", "g_b0", "g_w1",
                                     "g_b1", "g_w2", "g_b2", "g_vol", "g_scale")]
-                + [("c_ss", F), ("loss", P)])
+                + [("c_ss", F), ("loss", P), ("d_p", P)])
 
 
 class DanboTrunkWeights(ctypes.Structure):

@@ -8,6 +8,10 @@ torch.library.custom_op with register_autograd"), so that a caller -- the refere
         -> part_feat [n,24,15]                                            FactorizeGNN.sample_from_volume (gnn_backbone.py:787-828)
                                                                           backward: danbo_bone_gather_bwd (d volumes, d axis_scale)
 
+    torch.ops.danbo.assign_blend(volumes, axis_scale, pts, skts, align, rows, bits, [8 parameter tensors])
+        -> h [n,16], p [n,24], confd [n,24]                               sample_from_volume + MixGNN + DANBO.sigmoid / blend fused
+                                                                          (gnn_backbone.py:567-629,787-828, danbo.py:299-300,406-415);
+                                                                          backward: danbo_assign_blend_bwd (forward recomputed)
     torch.ops.danbo.pe_mlp(h, row_ray, vin, [20 parameter tensors])       Embedder + NeRF.inference (cutoff_embedder.py:62-73,
         -> raw [n,4]                                                      nerf.py:176-209) on the fused trunk kernels; backward:
                                                                           danbo_trunk_bwd + danbo_dw16 + the view / head chain
@@ -127,6 +131,130 @@ def _gather_backward(ctx, g):
 
 
 bone_gather.register_autograd(_gather_backward, setup_context=_gather_setup)
+
+
+# ------------------------------------------------------------------------------------------------------- gather + assign + blend
+# torch.ops.danbo.assign_blend(volumes [G,24,240], axis_scale [24,3], pts [R,S,3], skts [G,24,4,4], align [24,4,4],
+#                              rows [n] int32 (ascending sample ids inside >= 1 volume), bits [R*S] int32 (bone j valid: bit j),
+#                              params = prob_linears.layers.{0.lin.weight [24,15,32], 0.adj_w [1,24,24], 0.adj [1,24,24], 0.bias [32],
+#                                                            1.weight [24,32,32], 1.bias [24,1,32], 2.weight [24,32,1], 2.bias [24,1,1]})
+#   -> h [n,16]     blended voxel feature sum_j p_j f_j (15 channels + zero pad)                     differentiable
+#      p [n,24]     p_j = (1.002 sigmoid(logit_j) - 0.001) valid_j: DANBO.sigmoid(mask_invalid=False) x part_valid, what the
+#                   soft-softmax loss sums (core/trainer.py:507-536)                                   differentiable
+#      confd [n,24] the raw logits the reference returns in `encoded` (all bones, valid or not): a monitoring output, NOT
+#                   differentiable -- take gradients through p
+# The 1 440 B / row part_feat tensor of the unfused forward is never written; the backward recomputes the gather and the GNN from
+# the 23 KB pose volumes (csrc/k_assign_bwd.hip) and returns d volumes, d axis_scale and the parameter gradients (d adj is None: a
+# buffer).  No gradient to pts / skts / align (window detached, mask not differentiable, opt_pose off: gnn_backbone.py:804,808).
+def _assign_params(params):
+    w0, adj_w, adj, b0, w1, b1, w2, b2 = params
+    f = lambda t, *shape: ops._f32(t.detach().reshape(*shape), "prob_linears")  # noqa: E731
+    return dict(w0=f(w0, 24, ops.FEAT, 32), adj_w=f(adj_w, 24, 24), adj=f(adj, 24, 24), b0=f(b0, 32), w1=f(w1, 24, 32, 32),
+                b1=f(b1, 24, 32), w2=f(w2, 24, 32), b2=f(b2, 24))
+
+
+def _valid_mask(bits, rows):
+    shifts = torch.arange(ops.J, device=bits.device, dtype=torch.int32)
+    return ((bits.reshape(-1)[rows.long()].to(torch.int32).unsqueeze(-1) >> shifts) & 1).float()
+
+
+@torch.library.custom_op("danbo::assign_blend", mutates_args=())
+def assign_blend(volumes: torch.Tensor, axis_scale: torch.Tensor, pts: torch.Tensor, skts: torch.Tensor, align: torch.Tensor,
+                 rows: torch.Tensor, bits: torch.Tensor, params: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    if not pts.is_cuda:
+        raise RuntimeError("danbo::assign_blend runs on the HIP path only (no CPU fallback)")
+    a = _assign_params(params)
+    R = pts.shape[0]
+    n = rows.shape[0]
+    dev = pts.device
+    if n == 0:
+        return pts.new_zeros(0, ops.H_STRIDE), pts.new_zeros(0, ops.J), pts.new_zeros(0, ops.J)
+    dummy = pts.new_zeros(R, 3)
+    geo = ops.Geometry(dummy, dummy, ops._f32(skts, "skts"), ops._f32(align, "align"), ops._f32(axis_scale.detach(), "axis_scale"),
+                       pts=ops._f32(pts, "pts"))
+    aw = dict(w0=a["w0"], adjw=(a["adj_w"] * a["adj"]).contiguous(), b0=a["b0"], w1=a["w1"], b1=a["b1"], w2=a["w2"], b2=a["b2"])
+    cnt = torch.tensor([n], device=dev, dtype=torch.int32)
+    # exact-fp32 K1b + K2 (csrc/k_assign.hip): reads the adjacency it is given, any tree
+    h, confd = ops.gather_assign_blend(geo, ops._f32(volumes.detach(), "volumes"), bits.reshape(-1).contiguous(), aw,
+                                       rows.to(torch.int32).contiguous(), cnt, n, want_confd=True)
+    p = (torch.sigmoid(confd) * 1.002 - 0.001) * _valid_mask(bits, rows)
+    return h, p, confd
+
+
+@assign_blend.register_fake
+def _(volumes, axis_scale, pts, skts, align, rows, bits, params):
+    n = rows.shape[0]
+    f = lambda *s: pts.new_empty(s, dtype=torch.float32)  # noqa: E731
+    return f(n, ops.H_STRIDE), f(n, ops.J), f(n, ops.J)
+
+
+@torch.library.custom_op("danbo::assign_blend_bwd", mutates_args=())
+def assign_blend_bwd(volumes: torch.Tensor, axis_scale: torch.Tensor, pts: torch.Tensor, skts: torch.Tensor, align: torch.Tensor,
+                     rows: torch.Tensor, bits: torch.Tensor, params: List[torch.Tensor], g_h: torch.Tensor,
+                     g_p: torch.Tensor) -> List[torch.Tensor]:
+    """-> [d volumes, d axis_scale, d w0, d adj_w, d b0, d w1, d b1, d w2, d b2] (the parameters' own shapes)"""
+    a = _assign_params(params)
+    dev = pts.device
+    R, S = pts.shape[0], pts.shape[1]
+    G, n, M = skts.shape[0], rows.shape[0], pts.shape[0] * pts.shape[1]
+    z32 = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)  # noqa: E731
+    vol = ops._f32(volumes.detach(), "volumes")
+    g = dict(vol=z32(G, ops.J, vol.shape[-1] if vol.dim() == 3 else vol.numel() // (G * ops.J)), scale=z32(ops.J, 3),
+             w0=z32(24, ops.FEAT, 32), adj_w=z32(24, 24), b0=z32(32), w1=z32(24, 32, 32), b1=z32(24, 32), w2=z32(24, 32), b2=z32(24))
+    if n > 0:
+        # the kernel's row tables, with every sample its own "ray" (origin = the sample point, direction 0, depth 0): row i is
+        # list entry i, all rows belong to the first ("coarse") pass
+        rows32 = rows.to(torch.int32).contiguous()
+        cnt = torch.zeros(8, device=dev, dtype=torch.int32)
+        cnt[2] = n
+        cnt[5] = n
+        bits32 = bits.reshape(-1).contiguous()
+        lists = torch.empty(ops.J, n, device=dev, dtype=torch.int32)
+        cntb = torch.zeros(ops.J, device=dev, dtype=torch.int32)
+        _hip.check(_hip.lib().danbo_train_bone_lists(_p(bits32), _p(bits32), _p(rows32), _p(cnt), 0, n, _p(lists), _p(cntb), ops._stream()),
+                   "danbo_train_bone_lists")
+        zeros_m = z32(M)
+        ab = _hip.DanboAssignBwd()
+        keep = dict(o=ops._f32(pts, "pts").reshape(M, 3), d=z32(M, 3), z=zeros_m, lab=torch.zeros(M, device=dev, dtype=torch.uint8),
+                    skts=ops._f32(skts, "skts"), align=ops._f32(align, "align"), sc=ops._f32(axis_scale.detach(), "axis_scale"),
+                    h=z32(n, ops.H_STRIDE), dh=ops._f32(g_h, "g_h"), dp=ops._f32(g_p, "g_p"), loss=z32(4))
+        for k, v in dict(rays_o=keep["o"], rays_d=keep["d"], z_c=keep["z"], z_f=keep["z"], skts=keep["skts"], align=keep["align"],
+                         axis_scale=keep["sc"], volumes=vol, row_sample=rows32, row_ray=rows32, cnt=cnt, lists=lists, cntb=cntb,
+                         h_rows=keep["h"], d_h=keep["dh"], label_c=keep["lab"], label_f=keep["lab"], bits_c=bits32, bits_f=bits32,
+                         w0=a["w0"], adj_w=a["adj_w"], adj=a["adj"], b0=a["b0"], w1=a["w1"], b1=a["b1"], w2=a["w2"], b2=a["b2"],
+                         g_w0=g["w0"], g_adj_w=g["adj_w"], g_b0=g["b0"], g_w1=g["w1"], g_b1=g["b1"], g_w2=g["w2"], g_b2=g["b2"],
+                         g_vol=g["vol"], g_scale=g["scale"], loss=keep["loss"], d_p=keep["dp"]).items():
+            setattr(ab, k, v.data_ptr())
+        ab.R, ab.S, ab.Sf, ab.G, ab.rows_cap, ab.c_ss = M, 1, 1, G, n, 0.0
+        _hip.check(_hip.lib().danbo_assign_blend_bwd(ctypes.byref(ab), ops._stream()), "danbo_assign_blend_bwd")
+    w0, adj_w, adj, b0, w1, b1, w2, b2 = params
+    return [g["vol"].reshape(volumes.shape), g["scale"].reshape(axis_scale.shape), g["w0"].reshape(w0.shape), g["adj_w"].reshape(adj_w.shape),
+            g["b0"].reshape(b0.shape), g["w1"].reshape(w1.shape), g["b1"].reshape(b1.shape), g["w2"].reshape(w2.shape),
+            g["b2"].reshape(b2.shape)]
+
+
+@assign_blend_bwd.register_fake
+def _(volumes, axis_scale, pts, skts, align, rows, bits, params, g_h, g_p):
+    w0, adj_w, adj, b0, w1, b1, w2, b2 = params
+    return [torch.empty_like(t, dtype=torch.float32) for t in (volumes, axis_scale, w0, adj_w, b0, w1, b1, w2, b2)]
+
+
+def _assign_setup(ctx, inputs, output):
+    volumes, axis_scale, pts, skts, align, rows, bits, params = inputs
+    ctx.save_for_backward(volumes, axis_scale, pts, skts, align, rows, bits, *params)
+
+
+def _assign_backward(ctx, g_h, g_p, g_confd):
+    volumes, axis_scale, pts, skts, align, rows, bits, *params = ctx.saved_tensors
+    n = rows.shape[0]
+    g_h = g_h if g_h is not None else pts.new_zeros(n, ops.H_STRIDE)
+    g_p = g_p if g_p is not None else pts.new_zeros(n, ops.J)
+    d = torch.ops.danbo.assign_blend_bwd(volumes, axis_scale, pts, skts, align, rows, bits, list(params), g_h.contiguous(), g_p.contiguous())
+    d_vol, d_sc, d_w0, d_adjw, d_b0, d_w1, d_b1, d_w2, d_b2 = d
+    return d_vol, d_sc, None, None, None, None, None, [d_w0, d_adjw, None, d_b0, d_w1, d_b1, d_w2, d_b2]
+
+
+assign_blend.register_autograd(_assign_backward, setup_context=_assign_setup)
 
 
 # ------------------------------------------------------------------------------------------------------------------- pe + MLP

@@ -292,6 +292,8 @@ class RayCaster(nn.Module):
                    alpha0=out0['alpha'])
         if 'confd' in enc:   # DANBO: the assignment logits feed the soft-softmax loss (reference :710-716)
             ret.update(confd=take(enc['confd'], enc_f['confd']), part_invalid=take(enc['part_invalid'], enc_f['part_invalid']))
+            if 'p_valid' in enc and 'p_valid' in enc_f:      # torch.ops.danbo.assign_blend: the differentiable masked probabilities
+                ret['p_valid'] = take(enc['p_valid'], enc_f['p_valid'])
         return ret
 
     def render_pts_density(self, pts, kps, skts, bones, netchunk=1024 * 64, network=None):

@@ -275,12 +275,22 @@ def forward_train(model, inputs):
     if "vols" not in shared:
         shared["vols"] = pose_volumes(model, bones_g)
     vols = shared["vols"]
-    part_feat = torch.ops.danbo.bone_gather(vols, axis_scale, pts, skts_g, align, rows)
-    logits = assignment_logits(model, part_feat)
     shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
-    valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
-    p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid_rows
-    h = (part_feat * p[..., None]).sum(-2)
+    p_rows = None
+    if os.environ.get("DANBO_AUTOGRAD_ASSIGN") != "library" and n > 0:
+        # torch.ops.danbo.assign_blend: gather + assignment GNN + masked sigmoid + blend in one HIP kernel each way (core/custom_ops.py);
+        # part_feat [n,24,15] is never materialised
+        from . import custom_ops  # noqa: F401  (registers the operator)
+        l0, l1, l2 = model.prob_linears.layers
+        h16, p_rows, logits = torch.ops.danbo.assign_blend(vols, axis_scale, pts, skts_g, align, rows, bits,
+                                                           [l0.lin.weight, l0.adj_w, l0.adj, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias])
+        h = h16[:, :15]
+    else:
+        part_feat = torch.ops.danbo.bone_gather(vols, axis_scale, pts, skts_g, align, rows)
+        logits = assignment_logits(model, part_feat)
+        valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
+        p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid_rows
+        h = (part_feat * p[..., None]).sum(-2)
     if "vin" not in shared:
         shared["vin"] = view_inputs(model, rays_d, skts_g, inputs.get("cam_idxs"), R // G)
     vin = shared["vin"]
@@ -307,10 +317,15 @@ def forward_train(model, inputs):
         shared["raw_empty"] = raw_empty
     raw = raw_empty[:, None, :].expand(R, S, 4).reshape(R * S, 4).index_copy(0, rows.long(), raw_rows)
     confd = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), logits)
+    p_valid = None
+    if p_rows is not None:      # the differentiable route to the assignment net for the soft-softmax loss (confd is detached there)
+        p_valid = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), p_rows).reshape(R, S, 24)
     # confd of samples outside every volume: the reference evaluates the assignment net there too; those
     # logits never reach a loss (they are multiplied by part_valid = 0), so they are left at zero
     all_valid = ((bits.unsqueeze(-1) >> shifts) & 1).float()
     encoded = dict(confd=confd.reshape(R, S, 24), part_invalid=(1.0 - all_valid).reshape(R, S, 24))
+    if p_valid is not None:
+        encoded["p_valid"] = p_valid
     return raw.reshape(R, S, 4), encoded
 
 
@@ -369,6 +384,8 @@ def nerf_loss(args, rgb_pred, acc_pred, target, bgs=1.0, loss_weight=1.0):
 def soft_softmax_loss(args, model, preds):
     labels = ((preds["T_i"] * preds["alpha"]) > 0).float()
     part_valid = 1 - preds["part_invalid"]
+    if preds.get("p_valid") is not None:       # torch.ops.danbo.assign_blend's masked probabilities: the same p x part_valid
+        return args.soft_softmax_loss_coef * (labels - preds["p_valid"].sum(-1)).pow(2.).mean()
     p = model.sigmoid(preds["confd"], preds["part_invalid"], mask_invalid=False, clamp=False)
     return args.soft_softmax_loss_coef * (labels - (p * part_valid).sum(-1)).pow(2.).mean()
 

@@ -73,6 +73,7 @@ struct ABArgs {
     float *g_w0, *g_adj_w, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2, *g_vol /*[G,24,240]*/, *g_scale /*[24,3]*/;
     float c_ss;          // 2 coef / (R (S + Sf))
     float* loss;         // loss[2] += (label - q)^2 of in-volume rows
+    const float* d_p;    // [rows, 24] upstream gradient of the masked probabilities p_j valid_j, or nullptr (torch.ops.danbo.assign_blend)
 };
 
 // sum over the 32 lanes of a wave half, in every lane of the half: DPP partial sums inside the 16-lane rows, row 0 / 2's total
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int targ
         // ---- upstream
         float dp = c < FEAT ? s_dh[slot][c] * s_f[slot][0][c] : 0.f;   // neighbour 0 is the bone itself
         dp = half_sum32(dp);
+        if (a.d_p != nullptr) dp += a.d_p[(size_t)s_pi[pl] * J + j];
         float dlogit = (dp + a.c_ss * (qrow - lab)) * 1.002f * sg * (1.0f - sg);
         if (!live) dlogit = 0.f;
         if (live && c == 0 && j == __builtin_ctz(bits)) lss += (lab - qrow) * (lab - qrow);   // once per row
@@ -486,7 +488,7 @@ extern "C" int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream) {
     a.h_rows = p->h_rows; a.d_h = p->d_h; a.label_c = p->label_c; a.label_f = p->label_f; a.bits_c = p->bits_c; a.bits_f = p->bits_f;
     a.w0 = p->w0; a.adj_w = p->adj_w; a.adj = p->adj; a.b0 = p->b0; a.w1 = p->w1; a.b1 = p->b1; a.w2 = p->w2; a.b2 = p->b2;
     a.g_w0 = p->g_w0; a.g_adj_w = p->g_adj_w; a.g_b0 = p->g_b0; a.g_w1 = p->g_w1; a.g_b1 = p->g_b1; a.g_w2 = p->g_w2; a.g_b2 = p->g_b2;
-    a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss;
+    a.g_vol = p->g_vol; a.g_scale = p->g_scale; a.c_ss = p->c_ss; a.loss = p->loss; a.d_p = p->d_p;
     // The kernel chooses the pairs per workgroup on the device so that the chunks of all bones fit 2 workgroups per CU (its
     // resident slots) -- sum_j ceil(cnt_j / ppw) <= target + J whatever the data -- so that is all the grid ever needs: a grid
     // sized from the row CAPACITY launched thousands of workgroups that found no work (~90 us of empty launches per step).

@@ -279,7 +279,7 @@ extern "C" int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorte
 
 extern "C" int danbo_train_bone_lists(const uint32_t* bits_c, const uint32_t* bits_f, const int32_t* row_sample, const int32_t* cnt,
                                       int R, int rows_cap, int32_t* lists, int32_t* cntb, void* stream) {
-    DANBO_CHECK_ARG(bits_c && bits_f && row_sample && cnt && lists && cntb && R > 0 && rows_cap > 0);
+    DANBO_CHECK_ARG(bits_c && bits_f && row_sample && cnt && lists && cntb && R >= 0 && rows_cap > 0);
     hipLaunchKernelGGL(k_train_bone_lists, dim3(stream_grid(rows_cap, 256)), dim3(256), 0, (hipStream_t)stream, bits_c, bits_f, row_sample,
                        cnt, R, rows_cap, lists, cntb);
     DANBO_LAUNCH_RET();

