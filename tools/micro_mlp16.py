@@ -1,5 +1,6 @@
 """micro-benchmark of the f16-split MLP kernel on the bench workload's coarse pass (dev tool)
-    python tools/micro_mlp16.py [reps] [--zeros]     --zeros: same rows, all-zero weights and inputs (no operand toggling: power probe)"""
+    python tools/micro_mlp16.py [reps] [--zeros]     --zeros: same rows, all-zero weights and inputs (no operand toggling: power probe)
+    --rows=K: only the first K rows"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "danbo-pytorch_amd"))
@@ -28,6 +29,9 @@ if zeros:
                 prm.zero_()
     eng.refresh()
     h.zero_(), cview.zero_()
+for a_ in sys.argv[1:]:
+    if a_.startswith("--rows="):        # the same kernel on the first k in-volume rows only (the training step's sizes: 41 000 / 18 000)
+        n = min(n, int(a_.split("=")[1]))
 fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n)
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
