@@ -12,6 +12,10 @@ torch.library.custom_op with register_autograd"), so that a caller -- the refere
         -> h [n,16], p [n,24], confd [n,24]                               sample_from_volume + MixGNN + DANBO.sigmoid / blend fused
                                                                           (gnn_backbone.py:567-629,787-828, danbo.py:299-300,406-415);
                                                                           backward: danbo_assign_blend_bwd (forward recomputed)
+    torch.ops.danbo.anerf_cutoff_pe_mlp(pts, rays_d, skts, align, cam_idx, params, tau, multires, multires_views)
+        -> raw [R,S,4]                                                    A-NeRF's NeRF.forward (nerf.py:107-122,176-209: joint-distance
+                                                                          cutoff PE -> W-wide trunk -> view layer -> colour); forward
+                                                                          only, as SURVEY 8(b) lists it
     torch.ops.danbo.pe_mlp(h, row_ray, vin, [20 parameter tensors])       Embedder + NeRF.inference (cutoff_embedder.py:62-73,
         -> raw [n,4]                                                      nerf.py:176-209) on the fused trunk kernels; backward:
                                                                           danbo_trunk_bwd + danbo_dw16 + the view / head chain
@@ -417,3 +421,58 @@ def _pe_mlp_backward(ctx, g_raw):
 
 
 pe_mlp.register_autograd(_pe_mlp_backward, setup_context=_pe_mlp_setup)
+
+
+# ------------------------------------------------------------------------------------------------- A-NeRF cutoff PE + MLP (fwd)
+# torch.ops.danbo.anerf_cutoff_pe_mlp(pts [R,S,3], rays_d [R,3], skts [G,24,4,4], align [24,4,4], cam_idx [R] int64 or None,
+#                                     params, tau, multires, multires_views) -> raw [R,S,4]
+# params: pts_linears.{0..D-1}.weight, pts_linears.{0..D-1}.bias, alpha_linear.{weight,bias}, feature_linear.{weight,bias},
+#         views_linears.0.{weight,bias}, rgb_linear.{weight,bias}, pe_fn.cutoff_dist [24], dirs_pe_fn.cutoff_dist [24]
+#         (+ framecodes.codes.weight when the model has frame codes) -- the reference's state_dict tensors, skip after layer 4.
+# The pair SURVEY 8(b) lists without a backward (`anerf_cutoff_pe_mlp_fwd`): k_anerf_encode -> k_linear16 x (D + 1) ->
+# k_anerf_color through core/anerf_engine.AnerfEngine, whose packed weights are cached per parameter storage / version.
+# A-NeRF TRAINING differentiates core/train_path.forward_train_anerf instead (HIP encoders, dense layers recorded by autograd).
+_ANERF_ENGINES = {}
+
+
+def _anerf_engine(params, align, tau, multires, multires_views):
+    from .anerf_engine import AnerfEngine
+    n = len(params)
+    coded = n % 2 == 1                                  # 2 D + 10 tensors, + 1 with frame codes
+    D = (n - 10 - (1 if coded else 0)) // 2
+    if D < 5 or 2 * D + 10 + (1 if coded else 0) != n:
+        raise ValueError(f"danbo::anerf_cutoff_pe_mlp: {n} parameter tensors do not form D weights + D biases + 10 (+ codes)")
+    names = ([f"pts_linears.{i}.weight" for i in range(D)] + [f"pts_linears.{i}.bias" for i in range(D)]
+             + ["alpha_linear.weight", "alpha_linear.bias", "feature_linear.weight", "feature_linear.bias", "views_linears.0.weight",
+                "views_linears.0.bias", "rgb_linear.weight", "rgb_linear.bias", "pe_fn.cutoff_dist", "dirs_pe_fn.cutoff_dist"]
+             + (["framecodes.codes.weight"] if coded else []))
+    p = {k: ops._f32(v.detach(), k) for k, v in zip(names, params)}
+    p["pe_fn.tau"] = p["dirs_pe_fn.tau"] = torch.tensor(float(tau))
+    key = (align.data_ptr(), float(tau), int(multires), int(multires_views)) + tuple(v.data_ptr() for v in params)
+    eng = _ANERF_ENGINES.get(key)
+    if eng is None:
+        if len(_ANERF_ENGINES) >= 4:
+            _ANERF_ENGINES.pop(next(iter(_ANERF_ENGINES)))
+        W = p["pts_linears.1.weight"].shape[0]
+        cfg = dict(nerf_type="nerf", W=W, D=D, skips=(4,), view_W=p["views_linears.0.weight"].shape[0], multires=int(multires),
+                   multires_views=int(multires_views), use_framecode=coded)
+        eng = _ANERF_ENGINES[key] = AnerfEngine(cfg, p, ops._f32(align, "align"))
+    else:
+        eng.p = p                                       # same storages: refresh() re-packs only when a version counter moved
+    return eng
+
+
+@torch.library.custom_op("danbo::anerf_cutoff_pe_mlp", mutates_args=())
+def anerf_cutoff_pe_mlp(pts: torch.Tensor, rays_d: torch.Tensor, skts: torch.Tensor, align: torch.Tensor,
+                        cam_idx: Optional[torch.Tensor], params: List[torch.Tensor], tau: float, multires: int,
+                        multires_views: int) -> torch.Tensor:
+    if not pts.is_cuda:
+        raise RuntimeError("danbo::anerf_cutoff_pe_mlp runs on the HIP path only (no CPU fallback)")
+    eng = _anerf_engine(params, align, tau, multires, multires_views)
+    R = pts.shape[0]
+    return eng.forward_samples(None, ops._f32(rays_d.reshape(R, 3), "rays_d"), ops._f32(skts, "skts"), cam_idx, pts=ops._f32(pts, "pts")).clone()
+
+
+@anerf_cutoff_pe_mlp.register_fake
+def _(pts, rays_d, skts, align, cam_idx, params, tau, multires, multires_views):
+    return pts.new_empty(pts.shape[0], pts.shape[1], 4, dtype=torch.float32)

@@ -97,6 +97,35 @@ def test_model_forward_matches_reference_raw(env):
     assert raw_err(N(raw2), N(raw)) < 1e-5
 
 
+def test_anerf_cutoff_pe_mlp_custom_op(env):
+    """torch.ops.danbo.anerf_cutoff_pe_mlp (the forward-only pair of SURVEY 8b) on state_dict tensors: the module's raw bit for bit,
+    the reference's raw within the north_star bound; schema / fake-tensor opcheck"""
+    from core import custom_ops  # noqa: F401
+    g, caster, kw, orc = env
+    net = caster.network
+    pose = g["pose_of_ray"]
+    rb = g["ray_batch"]
+    sd = dict(net.state_dict())
+    D = len(net.pts_linears)
+    names = ([f"pts_linears.{i}.weight" for i in range(D)] + [f"pts_linears.{i}.bias" for i in range(D)]
+             + ["alpha_linear.weight", "alpha_linear.bias", "feature_linear.weight", "feature_linear.bias", "views_linears.0.weight",
+                "views_linears.0.bias", "rgb_linear.weight", "rgb_linear.bias", "pe_fn.cutoff_dist", "dirs_pe_fn.cutoff_dist",
+                "framecodes.codes.weight"])
+    params = [sd[k].detach() for k in names]
+    skts_g = T(g["skts"])
+    align = caster.transforms[0].to(DEV)
+    args = (T(g["pts"]), T(rb[:, 3:6]), skts_g, align, T(g["cam_idx"], torch.int64), params, float(net.pe_fn.tau),
+            int(net.pe_fn.num_freqs), int(net.dirs_pe_fn.num_freqs))
+    raw = torch.ops.danbo.anerf_cutoff_pe_mlp(*args)
+    inputs = dict(pts=T(g["pts"]), kps=T(g["kps"][pose]), skts=T(g["skts"][pose]), bones=T(g["bones"][pose]),
+                  rest_pose=T(g["rest_pose"]).reshape(1, 1, 24, 3), align_transforms=caster.transforms[:1, None].to(DEV),
+                  N_uniques=2, rays_o=T(rb[:, None, 0:3]), rays_d=T(rb[:, None, 3:6]), cam_idxs=T(g["cam_idx"], torch.int64))
+    ref, _ = net(inputs)
+    assert torch.equal(raw, ref)
+    assert raw_err(N(raw), g["raw_coarse"]) < 1e-4
+    torch.library.opcheck(torch.ops.danbo.anerf_cutoff_pe_mlp, args, test_utils=("test_schema", "test_faketensor"))
+
+
 def test_caster_call_matches_reference_maps_tau20_and_tau2000(env):
     g, caster, kw, orc = env
     out = call(caster, kw, g)
