@@ -291,11 +291,14 @@ def _autograd_grads(fixture, edit, model_edit=None):
             preds, {k: float(v.detach()) for k, v in loss.items()})
 
 
-@pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count", "overlapping_volumes", "every_volume"])
+@pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count", "many_small_poses", "overlapping_volumes",
+                                  "every_volume"])
 def test_fused_step_on_degenerate_batches(case):
     """Batches the device-side row bookkeeping has to survive: no sample inside any bone volume (zero in-volume rows: only the
     per-ray empty-space rows carry a gradient), one pose whose rays all miss while the others hit, a ray count that is no
-    multiple of any tile size, and bone volumes grown 4x (axis_scale is trainable) so that a sample lies in many volumes at
+    multiple of any tile size, 48 poses of 4 rays each (a workgroup of the K2 adjoint keeps two poses' tables in LDS: its chunks
+    then span many more and take the global-memory branch for the pose transforms, volumes and volume gradients), and bone volumes
+    grown 4x (axis_scale is trainable) so that a sample lies in many volumes at
     once: more (row, bone) pairs than the K2 adjoint's launch grid has workgroups for, it has to stride -- against the autograd
     path on the same batch."""
     def model_edit(caster):
@@ -312,6 +315,8 @@ def test_fused_step_on_degenerate_batches(case):
             per = b["rays_o"].shape[0] // b["N_uniques"]
             b["rays_o"] = b["rays_o"].clone()
             b["rays_o"][:per] += torch.tensor([40.0, 0.0, 0.0], device=DEV)
+        elif case == "many_small_poses":
+            b["N_uniques"] = b["rays_o"].shape[0] // 4            # every 4 consecutive rays (of the same pose) become a "pose" of their own
         elif case == "odd_ray_count":
             G = b["N_uniques"]
             per = b["rays_o"].shape[0] // G

@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage: refresh_evidence.sh TAG : everything profiles/ holds for a round, measured from the current tree in one go --
+# PMC HBM traffic (training step, K3), the GPU test-suite's measured parity values, the bench line of every config,
+# rocprofv3 kernel stats of the render frame and of the training step.  Outputs under gpurun_out/evidence_TAG/.
+TAG=$1
+R=$GRAFT_REPO_ROOT
+E=$R/gpurun_out/evidence_$TAG
+mkdir -p $E
+cd $R
+bash tools/pmc_train.sh $TAG > $E/pmc_train.log 2>&1 && cp gpurun_out/pmc_train_$TAG.json profiles/${TAG}_pmc_train.json && cp gpurun_out/pmc_train_$TAG.json $E/${TAG}_pmc_train.json
+bash tools/pmc_hbm.sh $TAG > $E/pmc_hbm.log 2>&1 && cp gpurun_out/pmc_hbm_$TAG.json profiles/${TAG}_pmc_hbm.json && cp gpurun_out/pmc_hbm_$TAG.json $E/${TAG}_pmc_hbm.json
+python -m pytest tests -m gpu -q -s 2>&1 | grep -E "raw_err|vs oracle|deviation|worst|passed|failed" > $E/${TAG}_parity_measured.txt
+for c in 1 2 3 4 5; do
+  python bench.py --config $c > $E/bench$c.log 2>&1
+  tail -1 $E/bench$c.log | python -c "import sys, json; print(json.dumps(json.loads(sys.stdin.read()), indent=1))" > $E/${TAG}_bench_config$c.json
+done
+python bench.py --config 4 --gpus 2 --scaling strong --debug-single-device > $E/bench4s.log 2>&1
+tail -1 $E/bench4s.log | python -c "import sys, json; print(json.dumps(json.loads(sys.stdin.read()), indent=1))" > $E/${TAG}_bench_config4_strong_2ranks_1gpu_debug.json
+bash tools/prof.sh ev_$TAG > $E/prof_frame.log 2>&1; cp gpurun_out/prof_ev_$TAG/ev_${TAG}_kernel_stats.csv $E/${TAG}_kernel_stats.csv
+bash tools/prof_train.sh ev_$TAG > $E/prof_train.log 2>&1; cp gpurun_out/prof_ev_$TAG/ev_${TAG}_kernel_stats.csv $E/${TAG}_train_kernel_stats.csv
+grep -h '"ms_per_step"' $E/*_bench_config*.json
+tail -3 $E/${TAG}_parity_measured.txt
