@@ -30,10 +30,10 @@ __global__ __launch_bounds__(GB_BLOCK) void k_bone_gather_bwd(const float* __res
                                                               float* __restrict__ d_volumes,
                                                               float* __restrict__ d_axis_scale) {
     __shared__ float s_align[J * 16];
-    __shared__ float s_dscale[J * 3];
+    __shared__ double s_dscale[J * 3];     // fp64: ds_add_f32 is ~20x slower than ds_add_f64 on gfx950 (tools/probe/lds_atomic.hip)
     const int tid = threadIdx.x;
     for (int i = tid; i < J * 16; i += GB_BLOCK) s_align[i] = align[i];
-    for (int i = tid; i < J * 3; i += GB_BLOCK) s_dscale[i] = 0.f;
+    for (int i = tid; i < J * 3; i += GB_BLOCK) s_dscale[i] = 0.0;
     __syncthreads();
     const long spp = (long)(R / G) * S;
     const int sl = tid / J, j = tid % J;
@@ -88,10 +88,10 @@ __global__ __launch_bounds__(GB_BLOCK) void k_bone_gather_bwd(const float* __res
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-        if (dsc[k] != 0.f) atomicAdd(&s_dscale[3 * j + k], dsc[k]);
+        if (dsc[k] != 0.f) atomicAdd(&s_dscale[3 * j + k], (double)dsc[k]);
     __syncthreads();
     for (int i = tid; i < J * 3; i += GB_BLOCK)
-        if (s_dscale[i] != 0.f) atomicAdd(d_axis_scale + i, s_dscale[i]);
+        if (s_dscale[i] != 0.0) atomicAdd(d_axis_scale + i, (float)s_dscale[i]);
 }
 
 // ======================================================================================
