@@ -44,6 +44,7 @@ SIGNATURES = {
     "danbo_composite_importance_fwd": [P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P],
     "danbo_composite_merged_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P],
     "danbo_anerf_encode_fwd": [P, P, P, P, I, I, I, P, P, P, F, I, c_long, I, P, P, P],
+    "danbo_anerf_encode_compact": [P, P, P, P, I, I, I, P, P, P, F, c_long, I, P, P, P],
     "danbo_anerf_view_pe_fwd": [P, P, I, I, I, P, P],
     "danbo_anerf_color_fwd": [P, I, P, P, P, P, I, I, I, I, I, I, P, P, P, I, P, P],
     "danbo_linear16_set_trace": [P],
@@ -52,6 +53,8 @@ SIGNATURES = {
     "danbo_linear16_fwd": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, P],
     "danbo_linear16_pack_frag": [P, c_long, c_long, I, I, I, I, P, P],
     "danbo_linear16_fwd_frag": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, I, P],
+    "danbo_linear16_pack_enc": [P, c_long, c_long, I, I, I, I, P, P],
+    "danbo_linear16_fwd_enc": [P, I, P, I, P, P, I, I, P, I, P, P],
     "danbo_render_frame_workspace": [I, I, I, I, I, I],
     "danbo_render_frame": [P, P, I, I, P, P, c_size_t, P],
     # ---- training step

@@ -6,6 +6,8 @@ layer fed from two buffers without a concatenated copy) -> k_anerf_color (HIP). 
 compositing and importance resampling are the kernels the DANBO path uses.  A-NeRF has no in-volume mask:
 every sample is evaluated, exactly as in the reference (core/networks/nerf.py:107-122).
 """
+import os
+
 import torch
 
 from . import hip_ops as ops
@@ -35,8 +37,12 @@ class AnerfEngine:
         # activations between the layers in k_linear16's fragment order (every load / store instruction one contiguous KB) when
         # the widths allow it; the first layer reads the encoder's rows, the head writes rows for k_anerf_color
         self.frag = W % 32 == 0 and VW + 1 <= 256
-        self.layers = [ops.linear16_pack(p[f"pts_linears.{i}.weight"], K1=self.in_ch if i in self.skip_into else None,
-                                         frag_in=(self.frag and i > 0 and i not in self.skip_into, self.frag and i in self.skip_into))
+        # the density inputs recomputed inside the first and the skip layer from the encoder's compact table (768 instead of
+        # 1 728 B per sample, written once and read twice): the kernel instantiation exists for the shipped width
+        self.fused_enc = os.environ.get("DANBO_ANERF_FUSED_ENC", "1") != "0" and self.frag and W == 448 and 1 <= self.L <= 7 and tuple(cfg["skips"]) == (4,) and self.in_ch == 24 * (1 + 2 * self.L) + 72
+        self.layers = [ops.linear16_pack_enc(p[f"pts_linears.{i}.weight"], self.L) if self.fused_enc and (i == 0 or i in self.skip_into)
+                       else ops.linear16_pack(p[f"pts_linears.{i}.weight"], K1=self.in_ch if i in self.skip_into else None,
+                                              frag_in=(self.frag and i > 0 and i not in self.skip_into, self.frag and i in self.skip_into))
                        for i in range(cfg["D"])]
         self._frag_store = None
         wv = p["views_linears.0.weight"].double()                       # [VW, W + view_ch + code]
@@ -103,7 +109,9 @@ class AnerfEngine:
         h = None
         for i, (packed, shape) in enumerate(self.layers):
             out = ops.FragBuffer(n, W, x0.device, storage=self._frag_store[i & 1])
-            if i == 0:
+            if self.fused_enc and (i == 0 or i in self.skip_into):      # x0: the encoder's compact table
+                ops.linear16_enc(x0, packed, shape, self.L, self.b[i], relu=True, x2=h if i else None, out=out)
+            elif i == 0:
                 ops.linear16(x0, packed, shape, self.b[i], relu=True, out=out)
             elif i in self.skip_into:
                 ops.linear16(x0, packed, shape, self.b[i], relu=True, x2=h, out=out)
@@ -127,13 +135,16 @@ class AnerfEngine:
         C = None if density_only else (self.view_constants(rays_d, skts) if view is None else view)
         rays_per_chunk = max(1, self.rows_per_chunk // S)
         n_max = min(R, rays_per_chunk) * S
-        buf = (torch.empty(n_max, self.in_ch, device=dev), torch.empty(n_max, 24, device=dev))
+        buf = (torch.empty(n_max, ops.ANERF_ENC_FLOATS if self.fused_enc else self.in_ch, device=dev), torch.empty(n_max, 24, device=dev))
         head_buf = torch.empty(n_max, (self.VW + 4) // 4 * 4, device=dev)     # [view features | density logit | pad to 16 B]
         for r0 in range(0, R, rays_per_chunk):
             nr = min(rays_per_chunk, R - r0)
             n = nr * S
-            x0, w = ops.anerf_encode(rays_o, rays_d, skts, self.align, self.cutoff, tau, self.L, r0 * S, n, z=z, pts=pts,
-                                     out=buf)
+            if self.fused_enc:
+                x0, w = ops.anerf_encode_compact(rays_o, rays_d, skts, self.align, self.cutoff, tau, r0 * S, n, z=z, pts=pts, out=buf)
+            else:
+                x0, w = ops.anerf_encode(rays_o, rays_d, skts, self.align, self.cutoff, tau, self.L, r0 * S, n, z=z, pts=pts,
+                                         out=buf)
             h = self._trunk(x0)
             head = ops.linear16(h, self.head[0], self.head[1], self.head_b, out=head_buf[:n, :self.VW + 1])
             if density_only:

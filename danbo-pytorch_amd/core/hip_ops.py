@@ -368,6 +368,34 @@ def anerf_encode(rays_o, rays_d, skts, align, cutoff, tau, L, row0, nrows, z=Non
     return x0, w
 
 
+ANERF_ENC_FLOATS = 192     # the encoder's compact table: [48][4] floats per sample (csrc/k_anerf.hip)
+LINEAR16_ENC_K = 480       # k-slots of the recomputed density inputs (15 k-steps)
+
+
+def anerf_encode_compact(rays_o, rays_d, skts, align, cutoff, tau, row0, nrows, z=None, pts=None, out=None):
+    """-> table [nrows, 192] (per joint (cutoff - distance, shifted distance, cutoff weight, 0), then the 24 unit directions padded
+    to 4), w [nrows, 24]: what linear16_enc recomputes the 24 (1 + 2 L) + 72 density inputs from (768 instead of 1 728 B per sample)"""
+    skts = _f32(skts, "skts")
+    G = skts.shape[0]
+    if pts is not None:
+        pts = _f32(pts, "pts")
+        R, S = pts.shape[0], pts.shape[1]
+        dev = pts.device
+        rays_o = rays_d = z = None
+    else:
+        rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
+        R, S = z.shape
+        dev = z.device
+    if out is None:
+        table = torch.empty(nrows, ANERF_ENC_FLOATS, device=dev, dtype=torch.float32)
+        w = torch.empty(nrows, J, device=dev, dtype=torch.float32)
+    else:
+        table, w = out[0][:nrows], out[1][:nrows]
+    _call("danbo_anerf_encode_compact", _p(rays_o), _p(rays_d), _p(z), _p(pts), R, S, G, _p(skts), _p(_f32(align, "align")),
+          _p(_f32(cutoff, "cutoff")), float(tau), int(row0), int(nrows), _p(table), _p(w), _stream())
+    return table, w
+
+
 def anerf_view_pe(rays_d, skts, L):
     rays_d, skts = _f32(rays_d, "rays_d"), _f32(skts, "skts")
     R, G = rays_d.shape[0], skts.shape[0]
@@ -420,6 +448,39 @@ def linear16_pack(weight, K1=None, transposed=False, frag_in=(False, False)):
     fr = (1 if frag_in[0] else 0) | (2 if frag_in[1] else 0)
     _call("danbo_linear16_pack_frag", _p(w), sn, sk, N, K1, K - K1, fr, _p(packed), _stream())
     return packed, (N, K1, K - K1)
+
+
+def linear16_pack_enc(weight, L, frag_second=True):
+    """nn.Linear weight [N, 24 (1 + 2 L) + 72 (+ K2)] of a layer whose first inputs are A-NeRF's density inputs -> packed buffer
+    for linear16_enc (those inputs are recomputed in the kernel from the encoder's compact table); K2: a second, fragment-order
+    input (the skip layer)."""
+    w = _f32(weight, "weight")
+    N, K = w.shape
+    K2 = K - (24 * (1 + 2 * L) + 72)
+    if K2 < 0 or K2 % 32:
+        raise ValueError(f"linear16_pack_enc: {K} columns do not hold the {24 * (1 + 2 * L) + 72} density inputs (+ a multiple of 32)")
+    nbytes = _hip.lib().danbo_linear16_packed_bytes(N, LINEAR16_ENC_K, K2)
+    if nbytes < 0:
+        raise ValueError(f"linear16: unsupported layer shape N={N}, K={K}")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _call("danbo_linear16_pack_enc", _p(w), w.stride(0), 1, N, int(L), K2, 2 if (K2 > 0 and frag_second) else 0, _p(packed), _stream())
+    return packed, (N, LINEAR16_ENC_K, K2)
+
+
+def linear16_enc(table, packed, shape, L, bias=None, relu=False, x2=None, out=None, count=None):
+    """out (FragBuffer) = act([enc(table) | x2] W^T + bias): the first / the skip layer of the A-NeRF trunk on the encoder's compact
+    table (anerf_encode_compact); x2: None or a FragBuffer."""
+    N, K1, K2 = shape
+    M = table.shape[0]
+    if K1 != LINEAR16_ENC_K or table.shape[1] != ANERF_ENC_FLOATS or not table.is_contiguous() or not isinstance(out, FragBuffer):
+        raise ValueError("linear16_enc: table must be [M, 192] contiguous, out a FragBuffer, the layer packed by linear16_pack_enc")
+    if (K2 > 0) != (x2 is not None) or (x2 is not None and (not isinstance(x2, FragBuffer) or x2.M != M or x2.C != K2)):
+        raise ValueError("linear16_enc: x2 must be the FragBuffer the layer was packed for")
+    if out.M != M or out.C != N:
+        raise ValueError("linear16_enc: out shape")
+    _call("danbo_linear16_fwd_enc", _p(table), int(L), _p(x2.data) if x2 is not None else None, K2, _p(packed), _p(_f32(bias, "bias")), N,
+          1 if relu else 0, _p(out.data), M, _p(count), _stream())
+    return out
 
 
 class FragBuffer:

@@ -18,6 +18,11 @@ constexpr int AN_MAXL = 8;
 // reference: SamplePointsEmbedder.encode_pts (encoders.py:424-450) -> RelDistEncoder / VecNormEncoder
 // (:630-651, :774-795) -> CutoffEmbedder._embed (cutoff_embedder.py:151-214; cut_to_dist, cutoff_shift,
 // cutoff_inputs) -> NeRF.encode_pts cat (nerf.py:222-250)
+// COMPACT: instead of the 432-wide density input the kernel writes what danbo_linear16_fwd_enc recomputes it from, 768 B per row:
+//   [48][4] floats -- entry j < 24: (inp_j, sh_j, w_j, 0) = cutoff - distance, the shifted distance the sin / cos take, the cutoff
+//   weight; entry 24 + j: the unit direction to joint j (x, y, z, 0)
+constexpr int AN_ENC_FLOATS = 192;
+template <bool COMPACT>
 __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d,
                                                            const float* __restrict__ z, const float* __restrict__ pts,
@@ -28,7 +33,7 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
                                                            float* __restrict__ wout) {
     extern __shared__ __attribute__((aligned(16))) float s_row[];  // [AN_TS][in_ch]
     __shared__ float s_align[J * 16];
-    const int in_ch = (1 + 2 * L) * J + 3 * J;
+    const int in_ch = COMPACT ? AN_ENC_FLOATS : (1 + 2 * L) * J + 3 * J;
     const int tid = threadIdx.x;
     for (int i = tid; i < J * 16; i += AN_BLOCK) s_align[i] = align[i];
     const long spp = (long)(R / G) * S;
@@ -60,6 +65,10 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
             const float w = sub_rn(1.0f, sigmoidf_(mul_rn(tau, sub_rn(v, c))));
             const float inp = sub_rn(c, v);
             const float sh = sub_rn(mul_rn(inp, two_over_c), 1.0f);
+            if (COMPACT) {
+                *reinterpret_cast<float4*>(out + 4 * j) = make_float4(inp, sh, w, 0.f);
+                *reinterpret_cast<float4*>(out + 4 * (J + j)) = make_float4(div_rn(pt[0], den), div_rn(pt[1], den), div_rn(pt[2], den), 0.f);
+            } else {
             out[j] = mul_rn(inp, w);
             for (int l = 0; l < L; ++l) {
                 float sn, cs;
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
             dir[0] = div_rn(pt[0], den);
             dir[1] = div_rn(pt[1], den);
             dir[2] = div_rn(pt[2], den);
+            }
             wout[(size_t)row * J + j] = w;
         }
         __syncthreads();
@@ -212,8 +222,23 @@ extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, 
     const int in_ch = (1 + 2 * L) * J + 3 * J;
     const int ntiles = ceil_div(nrows, AN_TS);
     const int grid = ntiles < num_cu() * 8 ? ntiles : num_cu() * 8;
-    hipLaunchKernelGGL(k_anerf_encode, dim3(grid), dim3(AN_BLOCK), AN_TS * in_ch * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(k_anerf_encode<false>, dim3(grid), dim3(AN_BLOCK), AN_TS * in_ch * sizeof(float), (hipStream_t)stream,
                        rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, L, row0, nrows, x0, w_out);
+    DANBO_LAUNCH_RET();
+}
+
+/* the encoder's inputs instead of its output: table [nrows, 48, 4] for danbo_linear16_fwd_enc (k_linear16.hip) + the cutoff weights */
+extern "C" int danbo_anerf_encode_compact(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
+                                          int S, int G, const float* skts, const float* align, const float* cutoff, float tau,
+                                          long row0, int nrows, float* table, float* w_out, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0 && nrows >= 0 && row0 >= 0);
+    DANBO_CHECK_ARG(row0 + nrows <= (long)R * S && skts && align && cutoff && table && w_out && (uintptr_t)table % 16 == 0);
+    DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr) && (pts || (rays_o && rays_d)));
+    if (nrows == 0) return 0;
+    const int ntiles = ceil_div(nrows, AN_TS);
+    const int grid = ntiles < num_cu() * 8 ? ntiles : num_cu() * 8;
+    hipLaunchKernelGGL(k_anerf_encode<true>, dim3(grid), dim3(AN_BLOCK), AN_TS * AN_ENC_FLOATS * sizeof(float), (hipStream_t)stream,
+                       rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, 0, row0, nrows, table, w_out);
     DANBO_LAUNCH_RET();
 }
 

@@ -39,8 +39,25 @@ constexpr int L16_LDS_BYTES = L16_SLOTS * L16_CHUNK + L16_MAX_N * 4;
 // ---------------------------------------------------------------------------------------------------------------
 // frag (bit 0: the K1 part, bit 1: the K2 part): that input arrives in FRAGMENT ORDER (see Lin16Args::frag) -- k-slot 8 q + e of
 // k-step s then carries input column 32 s + 16 (e / 4) + 4 q + e % 4 instead of 32 s + 8 q + e
+// enc_L > 0: the K1 part is A-NeRF's 24 (1 + 2 L) + 72 density inputs, RECOMPUTED by the kernel from the encoder's table
+// (danbo_linear16_fwd_enc): 15 k-steps whose slots carry the columns in the order lin_enc_column gives them
+__host__ __device__ inline int lin_enc_column(int s, int kk, int L) {
+    const int q = kk >> 3, e = kk & 7;
+    if (s < 12) {                       // joints 2 s, 2 s + 1; blocks [raw, pad, sin_0, cos_0, ..., sin_6, cos_6], 4 per lane quarter
+        const int j = 2 * s + (e >> 2), blk = 4 * q + (e & 3);
+        if (blk == 0) return j;
+        if (blk == 1) return -1;
+        const int l = (blk - 2) >> 1;
+        if (l >= L) return -1;
+        return ((blk & 1) ? 2 + 2 * l : 1 + 2 * l) * 24 + j;
+    }
+    const int j = 8 * (s - 12) + 2 * q + (e >> 2), k = e & 3;      // unit directions, (x, y, z, pad) per joint
+    return k < 3 ? (1 + 2 * L) * 24 + 3 * j + k : -1;
+}
+constexpr int L16_ENC_K = 480, L16_ENC_FLOATS = 192;
+
 __global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__ w, long sn, long sk, int N, int K1, int K2, int NH,
-                                                       int frag, _Float16* __restrict__ packed) {
+                                                       int frag, int enc_L, _Float16* __restrict__ packed) {
     const int KS1 = (K1 + 31) / 32, KS = KS1 + (K2 + 31) / 32;
     const long total = (long)KS * NH * (L16_CHUNK / 2);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -50,12 +67,14 @@ __global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__
         const int n = 16 * (16 * hf + (piece >> 1)) + (lane & 15);
         const int kk_rows = 8 * (lane >> 4) + e, kk_frag = 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
         int col = -1;
+        const int k1_cols = enc_L > 0 ? 24 * (1 + 2 * enc_L) + 72 : K1;     // columns of w in front of the K2 part
         if (s < KS1) {
             const int kk = (frag & 1) ? kk_frag : kk_rows;
-            if (32 * s + kk < K1) col = 32 * s + kk;
+            if (enc_L > 0) col = lin_enc_column(s, kk_rows, enc_L);
+            else if (32 * s + kk < K1) col = 32 * s + kk;
         } else {
             const int kk = (frag & 2) ? kk_frag : kk_rows;
-            if (32 * (s - KS1) + kk < K2) col = K1 + 32 * (s - KS1) + kk;
+            if (32 * (s - KS1) + kk < K2) col = k1_cols + 32 * (s - KS1) + kk;
         }
         const float v = (n < N && col >= 0) ? w[n * sn + col * sk] : 0.f;
         const _Float16 hi = (_Float16)v;
@@ -79,6 +98,7 @@ struct Lin16Args {
     // Every load and store instruction of a wavefront then moves one contiguous KB (8 full cache lines) instead of sixteen
     // 64-byte pieces of sixteen rows -- the row-major epilogue drains at 16 B/clk per CU (s_memtime: 14 000 cycles per tile).
     int frag;
+    int enc_L;         // FRAG & 8: x1 is the A-NeRF encoder's table [rows, 48, 4] (k_anerf.hip), K1 = 480 recomputed inputs, L levels
     long long* trace;  // dev tool (tools/micro_linear16.py --trace): s_memtime stamps of one wavefront, or nullptr
 };
 
@@ -159,6 +179,35 @@ __device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
                      : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FRAG & 8: the inputs of the K1 part are not read, they are recomputed from the encoder's table (the 432-wide tensor the
+// encoder would write is 1 728 B per row, written once and read by the first and the skip layer; the table is 768 B).  In a
+// k-step s < 12 a lane's two 16-byte loads are the entries (inp, sh, w, 0) of joints 2 s and 2 s + 1, and its eight inputs are
+// blocks 4 q .. 4 q + 3 of each joint: [inp w, 0, sin(sh) w, cos(sh) w] for q = 0, else the sin / cos pairs of levels 2 q - 1 and
+// 2 q times w (CutoffEmbedder._embed, cutoff_embedder.py:151-214; the arithmetic of k_anerf_encode with the sines from
+// v_sin_f32 / v_cos_f32 after a two-term Cody-Waite reduction instead of sincosf: <= 2e-7 on the values).  k-steps 12 .. 14 carry
+// the unit directions as stored.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_sincos(float a, float& sn, float& cs) {
+    const float k = __builtin_rintf(a * 0.15915494309189535f);
+    float r = __builtin_fmaf(k, -6.2831854820251465f, a);
+    r = __builtin_fmaf(k, 1.7484555e-7f, r);                      // 2 pi = 6.2831854820251465 - 1.7484555e-7
+    const float rev = r * 0.15915494309189535f;                   // |rev| <= 1/2
+    sn = __builtin_amdgcn_sinf(rev);
+    cs = __builtin_amdgcn_cosf(rev);
+}
+__device__ __forceinline__ void lin_enc_joint(float inp, float sh, float w, int q, int L, float* o) {
+    const int l1 = q == 0 ? 0 : 2 * q - 1, l2 = 2 * q;
+    float s1, c1, s2, c2;
+    lin_sincos(sh * __builtin_bit_cast(float, (unsigned)(127 + l1) << 23), s1, c1);
+    lin_sincos(sh * __builtin_bit_cast(float, (unsigned)(127 + l2) << 23), s2, c2);
+    const bool on1 = l1 < L, on2 = l2 < L;
+    o[0] = mul_rn(q == 0 ? inp : (on1 ? s1 : 0.f), w);
+    o[1] = mul_rn(q == 0 ? 0.f : (on1 ? c1 : 0.f), w);
+    o[2] = mul_rn(on2 ? s2 : 0.f, w);
+    o[3] = mul_rn(on2 ? c2 : 0.f, w);
+}
+
 // NP: tile pairs in the last chunk of a k-step known at compile time (no branches in the batch loop), 0 = taken from N
 // FRAG: Lin16Args::frag as a compile-time constant (a run-time choice costs the registers this kernel does not have)
 template <int NH, int NP, bool TRACE, int FRAG = 0>
@@ -188,6 +237,12 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         long row = (long)(blockIdx.x + rq_it * gridDim.x) * L16_BM + wave * 16 + n;
         row = row < M ? row : M - 1;
         const bool second = rq_s >= KS1;
+        if ((FRAG & 8) && !second) {
+            // the encoder's table: entries of joints 2 s, 2 s + 1 (s < 12) / of this lane quarter's two directions
+            const int entry = rq_s < 12 ? 2 * rq_s : 24 + 8 * (rq_s - 12) + 2 * q;
+            const float* tb = a.x1 + row * L16_ENC_FLOATS + entry * 4;
+            lin_request_rows<decltype(set)::value>(tb, tb + 4);
+        } else
         if (FRAG & (second ? 2 : 1)) {
             // fragment order: [row group][k-step][half][lane][4]
             const long g16 = (long)(blockIdx.x + rq_it * gridDim.x) * (L16_BM / 16) + wave;
@@ -211,6 +266,13 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     {
         float x[8];
         lin_take_rows<0>(x);
+        if (FRAG & 8) {                          // k-step 0 of the first row tile
+            float o[8];
+            lin_enc_joint(x[0], x[1], x[2], q, a.enc_L, o);
+            lin_enc_joint(x[4], x[5], x[6], q, a.enc_L, o + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = o[e];
+        }
         lin_split8(x, bh, bl);
         request(std::integral_constant<int, 0>{});
     }
@@ -269,9 +331,20 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                 // fragments and their registers are re-used for the request after next.
                 if (b == 1) lin_issue(p);
                 if (hf == 0 && b == 2) lin_take_rows<decltype(set)::value>(nx);
-                if (hf == 0 && b >= 3 && b <= 6) {
+                if ((FRAG & 8) && hf == 0 && (b == 3 || b == 4)) {
+                    // rows of k-step s + 1 (0 behind the last one): the recomputed inputs, one joint under each of two batches
+                    const int s_next = s + 1 < KS ? s + 1 : 0;
+                    if (s_next < 12) {
+                        float o[4];
+                        const int e0 = 4 * (b - 3);
+                        lin_enc_joint(nx[e0], nx[e0 + 1], nx[e0 + 2], q, a.enc_L, o);
+                        nx[e0] = o[0]; nx[e0 + 1] = o[1]; nx[e0 + 2] = o[2]; nx[e0 + 3] = o[3];
+                    }
+                }
+                if ((FRAG & 8) ? (hf == 1 && b <= 3) : (hf == 0 && b >= 3 && b <= 6)) {
+                    const int b0 = (FRAG & 8) ? b : b - 3;
 #pragma unroll
-                    for (int e = 2 * (b - 3); e < 2 * (b - 3) + 2; ++e) {
+                    for (int e = 2 * b0; e < 2 * b0 + 2; ++e) {
                         const float xe = nx[e];
                         const _Float16 hh = (_Float16)xe;
                         nbh[e] = hh;
@@ -381,7 +454,20 @@ extern "C" int danbo_linear16_pack_frag(const float* w, long stride_n, long stri
     DANBO_CHECK_ARG(!(frag_in & 2) || (K2 > 0 && K2 % 32 == 0));
     const long total = (long)danbo_linear16_packed_bytes(N, K1, K2) / 2;
     hipLaunchKernelGGL(k_linear16_pack, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, stride_n, stride_k, N, K1,
-                       K2, lin16_nh(N), frag_in, (_Float16*)packed);
+                       K2, lin16_nh(N), frag_in, 0, (_Float16*)packed);
+    DANBO_LAUNCH_RET();
+}
+
+/* w [N, 24 (1 + 2 L) + 72 + K2]: a layer whose first 24 (1 + 2 L) + 72 inputs are A-NeRF's density inputs, recomputed by
+ * danbo_linear16_fwd_enc from the encoder's table (15 k-steps = DANBO_LINEAR16_ENC_K slots), the other K2 a second input
+ * (frag_in bit 1: in fragment order).  packed: danbo_linear16_packed_bytes(N, DANBO_LINEAR16_ENC_K, K2) bytes. */
+extern "C" int danbo_linear16_pack_enc(const float* w, long stride_n, long stride_k, int N, int L, int K2, int frag_in, void* packed,
+                                       void* stream) {
+    DANBO_CHECK_ARG(w && packed && N >= 1 && N <= L16_MAX_N && L >= 1 && L <= 7 && K2 >= 0 && (frag_in == 0 || frag_in == 2));
+    DANBO_CHECK_ARG(!(frag_in & 2) || (K2 > 0 && K2 % 32 == 0));
+    const long total = (long)danbo_linear16_packed_bytes(N, L16_ENC_K, K2) / 2;
+    hipLaunchKernelGGL(k_linear16_pack, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, stride_n, stride_k, N,
+                       L16_ENC_K, K2, lin16_nh(N), frag_in, L, (_Float16*)packed);
     DANBO_LAUNCH_RET();
 }
 
@@ -408,7 +494,7 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
     DANBO_CHECK_ARG((frag & 4) || (ldy >= N && ldy % 4 == 0));
     DANBO_CHECK_ARG((uintptr_t)x1 % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
     if (M == 0) return 0;
-    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, g_lin16_trace};
+    Lin16Args a{x1, x2, ld1, ld2, K1, K2, (const char*)packed, bias, y, ldy, N, act, M, count, frag, 0, g_lin16_trace};
     const int tiles = (M + L16_BM - 1) / L16_BM;
     const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
     const int nh = lin16_nh(N), np = ((N + 15) / 16 - 16 * (nh - 1) + 1) / 2;   // tile pairs in the last chunk of a k-step
@@ -437,5 +523,28 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
     else return DANBO_EINVAL;
 #undef DANBO_L16_SHAPES
 #undef DANBO_L16_GO
+    DANBO_LAUNCH_RET();
+}
+
+/* y (fragment order) = act([enc(table) | x2] W^T + bias): the first / the skip layer of the A-NeRF trunk with the 24 (1 + 2 L) + 72
+ * density inputs recomputed from the encoder's table [M, 48, 4] (danbo_anerf_encode_compact) instead of read (W packed by
+ * danbo_linear16_pack_enc).  x2: NULL, or the second input [M, K2] in fragment order.  N = 448 (the shipped A-NeRF width). */
+extern "C" int danbo_linear16_fwd_enc(const float* table, int L, const float* x2, int K2, const void* packed, const float* bias, int N,
+                                      int act, float* y, int M, const int32_t* count, void* stream) {
+    DANBO_CHECK_ARG(table && packed && y && N == 448 && L >= 1 && L <= 7 && K2 >= 0 && (K2 == 0) == (x2 == nullptr) && M >= 0);
+    DANBO_CHECK_ARG((act == 0 || act == 1) && K2 % 32 == 0);
+    DANBO_CHECK_ARG((uintptr_t)table % 16 == 0 && (uintptr_t)x2 % 16 == 0 && (uintptr_t)y % 16 == 0);
+    if (M == 0) return 0;
+    const int frag = 8 | 4 | (x2 ? 2 : 0);
+    Lin16Args a{table, x2, L16_ENC_FLOATS, 0, L16_ENC_K, K2, (const char*)packed, bias, y, 0, N, act, M, count, frag, L, nullptr};
+    const int tiles = (M + L16_BM - 1) / L16_BM;
+    const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
+    if (x2) {
+        DANBO_ENSURE_LDS((k_linear16<2, 6, false, 14>), L16_LDS_BYTES);
+        hipLaunchKernelGGL((k_linear16<2, 6, false, 14>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);
+    } else {
+        DANBO_ENSURE_LDS((k_linear16<2, 6, false, 12>), L16_LDS_BYTES);
+        hipLaunchKernelGGL((k_linear16<2, 6, false, 12>), grid, block, L16_LDS_BYTES, (hipStream_t)stream, a);
+    }
     DANBO_LAUNCH_RET();
 }

@@ -319,6 +319,22 @@ int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const float* x2, i
                             const float* bias, int N, int act, float* y, int ldy, int M, const int32_t* count, int frag,
                             void* stream);
 
+/* The first / the skip layer of the A-NeRF trunk with the 24 (1 + 2 L) + 72 density inputs RECOMPUTED in the kernel
+ * (CutoffEmbedder._embed, core/cutoff_embedder.py:151-214) from the encoder's compact table [M, 48, 4] that
+ * danbo_anerf_encode_compact writes -- per joint (cutoff - distance, shifted distance, cutoff weight, 0), then the 24 unit
+ * directions padded to 4 -- instead of read: 768 instead of 1 728 B per sample, written once and read twice.
+ * danbo_linear16_pack_enc: w [N, 24 (1 + 2 L) + 72 + K2] (frag_in 2: the K2 part arrives in fragment order), packed:
+ * danbo_linear16_packed_bytes(N, DANBO_LINEAR16_ENC_K, K2) bytes.  danbo_linear16_fwd_enc: y in fragment order, N = 448. */
+#define DANBO_LINEAR16_ENC_K 480
+#define DANBO_ANERF_ENC_FLOATS 192
+int danbo_linear16_pack_enc(const float* w, long stride_n, long stride_k, int N, int L, int K2, int frag_in, void* packed,
+                            void* stream);
+int danbo_linear16_fwd_enc(const float* table, int L, const float* x2, int K2, const void* packed, const float* bias, int N,
+                           int act, float* y, int M, const int32_t* count, void* stream);
+int danbo_anerf_encode_compact(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                               const float* skts, const float* align, const float* cutoff, float tau, long row0, int nrows,
+                               float* table, float* w_out, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Training step (SURVEY 8b "+ _bwd"; reference core/trainer.py:257-302,563-576 = forward, loss, loss.backward(), Adam).

@@ -164,3 +164,50 @@ def test_linear16_trunk_in_fragment_order_matches_the_row_major_chain(W, M):
         ops.linear16(f1, *pk[1], bs[1], relu=True, out=ops.FragBuffer(M, W + 32, DEV))
     with pytest.raises(ValueError):
         ops.FragBuffer(M, 100, DEV)
+
+
+@pytest.mark.parametrize("L,M_rays,tau", [(7, 300, 20.0), (7, 37, 2000.0), (4, 129, 20.0)])
+def test_linear16_recomputes_the_anerf_density_inputs_from_the_encoder_table(L, M_rays, tau):
+    """danbo_linear16_fwd_enc: the first and the skip layer of the A-NeRF trunk on the encoder's compact table (the cutoff PE
+    recomputed per k-step in the kernel) against the same layers on the 24 (1 + 2 L) + 72 rows k_anerf_encode writes, and
+    against float64 on those rows; the compact table against the rows it stands for"""
+    from core import hip_ops as ops
+    from core.utils import synthetic as syn
+    g = torch.Generator(device="cpu").manual_seed(L * 1000 + M_rays)
+    S, G, W = 12, 1, 448
+    scene = syn.make_scene(n_poses=1, H=32, W=32, n_views=1, pose_seed=3)
+    ro, rd = scene["rays"][0]
+    sel = np.linspace(0, ro.shape[0] - 1, M_rays).astype(np.int64)
+    rays_o, rays_d = torch.tensor(ro[sel], device=DEV), torch.tensor(rd[sel], device=DEV)
+    skts = torch.tensor(scene["skts"][:1], device=DEV, dtype=torch.float32)
+    z = (torch.linspace(1.5, 4.5, S)[None, :] + torch.rand(M_rays, S, generator=g) * 0.1).to(DEV).contiguous()
+    align = torch.eye(4, device=DEV).repeat(24, 1, 1).contiguous()
+    cutoff = (torch.rand(24, generator=g) * 0.3 + 0.35).to(DEV)
+    n = M_rays * S
+    in_ch = 24 * (1 + 2 * L) + 72
+    x0, w_rows = ops.anerf_encode(rays_o, rays_d, skts, align, cutoff, tau, L, 0, n, z=z)
+    table, w_tab = ops.anerf_encode_compact(rays_o, rays_d, skts, align, cutoff, tau, 0, n, z=z)
+    assert torch.equal(w_rows, w_tab)
+    t = table.view(n, 48, 4)
+    assert torch.equal(t[:, :24, 0] * t[:, :24, 2], x0[:, :24])                         # (cutoff - v) w
+    assert torch.equal(t[:, 24:, :3].reshape(n, 72), x0[:, in_ch - 72:]) and (t[:, :, 3] == 0).all()
+    assert (torch.sin(t[:, :24, 1].double()) * t[:, :24, 2].double() - x0[:, 24:48].double()).abs().max().item() < 2e-7
+    w0 = (torch.randn(W, in_ch, generator=g) / in_ch ** 0.5).to(DEV)
+    w5 = (torch.randn(W, in_ch + W, generator=g) / (in_ch + W) ** 0.5).to(DEV)
+    b0, b5 = (torch.randn(W, generator=g) * 0.1).to(DEV), (torch.randn(W, generator=g) * 0.1).to(DEV)
+    h4 = torch.relu(torch.randn(n, W, generator=g)).to(DEV)
+    f4 = ops.FragBuffer.from_rows(h4)
+    # the ordinary layers on the rows
+    r1, r5 = ops.FragBuffer(n, W, DEV), ops.FragBuffer(n, W, DEV)
+    ops.linear16(x0, *ops.linear16_pack(w0), b0, relu=True, out=r1)
+    ops.linear16(x0, *ops.linear16_pack(w5, K1=in_ch, frag_in=(False, True)), b5, relu=True, x2=f4, out=r5)
+    # the fused layers on the table
+    e1, e5 = ops.FragBuffer(n, W, DEV), ops.FragBuffer(n, W, DEV)
+    ops.linear16_enc(table, *ops.linear16_pack_enc(w0, L), L, b0, relu=True, out=e1)
+    ops.linear16_enc(table, *ops.linear16_pack_enc(w5, L), L, b5, relu=True, x2=f4, out=e5)
+    _check(e1.rows(), x0, w0, b0, True, tol=4e-6)
+    _check(e5.rows(), torch.cat([x0, h4], 1), w5, b5, True, tol=4e-6)
+    d1 = (e1.rows() - r1.rows()).abs().max().item() / r1.rows().abs().max().item()
+    d5 = (e5.rows() - r5.rows()).abs().max().item() / r5.rows().abs().max().item()
+    print("fused encoder layers vs the layers on the encoder's rows: relative to the largest output", d1, d5)
+    assert d1 < 5e-6 and d5 < 5e-6
