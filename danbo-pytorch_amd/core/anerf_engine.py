@@ -37,7 +37,7 @@ class AnerfEngine:
         # activations between the layers in k_linear16's fragment order (every load / store instruction one contiguous KB) when
         # the widths allow it; the first layer reads the encoder's rows, the head writes rows for k_anerf_color
         self.frag = W % 32 == 0 and VW + 1 <= 256
-        # the density inputs recomputed inside the first and the skip layer from the encoder's compact table (768 instead of
+        # the density inputs recomputed inside the first and the skip layer from the encoder's compact table (576 instead of
         # 1 728 B per sample, written once and read twice): the kernel instantiation exists for the shipped width
         self.fused_enc = os.environ.get("DANBO_ANERF_FUSED_ENC", "1") != "0" and self.frag and W == 448 and 1 <= self.L <= 7 and tuple(cfg["skips"]) == (4,) and self.in_ch == 24 * (1 + 2 * self.L) + 72
         self.layers = [ops.linear16_pack_enc(p[f"pts_linears.{i}.weight"], self.L) if self.fused_enc and (i == 0 or i in self.skip_into)

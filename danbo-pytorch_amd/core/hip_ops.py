@@ -368,13 +368,13 @@ def anerf_encode(rays_o, rays_d, skts, align, cutoff, tau, L, row0, nrows, z=Non
     return x0, w
 
 
-ANERF_ENC_FLOATS = 192     # the encoder's compact table: [48][4] floats per sample (csrc/k_anerf.hip)
-LINEAR16_ENC_K = 480       # k-slots of the recomputed density inputs (15 k-steps)
+ANERF_ENC_FLOATS = 144     # the encoder's compact table: [24][4] + [24][2] floats per sample (csrc/k_anerf.hip)
+LINEAR16_ENC_K = 448       # k-slots of the recomputed density inputs (14 k-steps)
 
 
 def anerf_encode_compact(rays_o, rays_d, skts, align, cutoff, tau, row0, nrows, z=None, pts=None, out=None):
-    """-> table [nrows, 192] (per joint (cutoff - distance, shifted distance, cutoff weight, 0), then the 24 unit directions padded
-    to 4), w [nrows, 24]: what linear16_enc recomputes the 24 (1 + 2 L) + 72 density inputs from (768 instead of 1 728 B per sample)"""
+    """-> table [nrows, 144] (per joint (cutoff - distance, shifted distance, cutoff weight, direction x), then the 24 (direction y, z)
+    pairs), w [nrows, 24]: what linear16_enc recomputes the 24 (1 + 2 L) + 72 density inputs from (576 instead of 1 728 B per sample)"""
     skts = _f32(skts, "skts")
     G = skts.shape[0]
     if pts is not None:
@@ -473,7 +473,7 @@ def linear16_enc(table, packed, shape, L, bias=None, relu=False, x2=None, out=No
     N, K1, K2 = shape
     M = table.shape[0]
     if K1 != LINEAR16_ENC_K or table.shape[1] != ANERF_ENC_FLOATS or not table.is_contiguous() or not isinstance(out, FragBuffer):
-        raise ValueError("linear16_enc: table must be [M, 192] contiguous, out a FragBuffer, the layer packed by linear16_pack_enc")
+        raise ValueError("linear16_enc: table must be [M, 144] contiguous, out a FragBuffer, the layer packed by linear16_pack_enc")
     if (K2 > 0) != (x2 is not None) or (x2 is not None and (not isinstance(x2, FragBuffer) or x2.M != M or x2.C != K2)):
         raise ValueError("linear16_enc: x2 must be the FragBuffer the layer was packed for")
     if out.M != M or out.C != N:

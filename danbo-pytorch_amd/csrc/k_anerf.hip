@@ -18,10 +18,10 @@ constexpr int AN_MAXL = 8;
 // reference: SamplePointsEmbedder.encode_pts (encoders.py:424-450) -> RelDistEncoder / VecNormEncoder
 // (:630-651, :774-795) -> CutoffEmbedder._embed (cutoff_embedder.py:151-214; cut_to_dist, cutoff_shift,
 // cutoff_inputs) -> NeRF.encode_pts cat (nerf.py:222-250)
-// COMPACT: instead of the 432-wide density input the kernel writes what danbo_linear16_fwd_enc recomputes it from, 768 B per row:
-//   [48][4] floats -- entry j < 24: (inp_j, sh_j, w_j, 0) = cutoff - distance, the shifted distance the sin / cos take, the cutoff
-//   weight; entry 24 + j: the unit direction to joint j (x, y, z, 0)
-constexpr int AN_ENC_FLOATS = 192;
+// COMPACT: instead of the 432-wide density input the kernel writes what danbo_linear16_fwd_enc recomputes it from, 576 B per row:
+//   [24][4] floats (inp_j, sh_j, w_j, dir_j.x) = cutoff - distance, the shifted distance the sin / cos take, the cutoff weight, the
+//   x component of the unit direction to joint j; then [24][2] floats (dir_j.y, dir_j.z)
+constexpr int AN_ENC_FLOATS = 144;
 template <bool COMPACT>
 __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d,
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
             const float inp = sub_rn(c, v);
             const float sh = sub_rn(mul_rn(inp, two_over_c), 1.0f);
             if (COMPACT) {
-                *reinterpret_cast<float4*>(out + 4 * j) = make_float4(inp, sh, w, 0.f);
-                *reinterpret_cast<float4*>(out + 4 * (J + j)) = make_float4(div_rn(pt[0], den), div_rn(pt[1], den), div_rn(pt[2], den), 0.f);
+                *reinterpret_cast<float4*>(out + 4 * j) = make_float4(inp, sh, w, div_rn(pt[0], den));
+                *reinterpret_cast<float2*>(out + 4 * J + 2 * j) = make_float2(div_rn(pt[1], den), div_rn(pt[2], den));
             } else {
             out[j] = mul_rn(inp, w);
             for (int l = 0; l < L; ++l) {
@@ -227,7 +227,7 @@ extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, 
     DANBO_LAUNCH_RET();
 }
 
-/* the encoder's inputs instead of its output: table [nrows, 48, 4] for danbo_linear16_fwd_enc (k_linear16.hip) + the cutoff weights */
+/* the encoder's inputs instead of its output: table [nrows, 144] for danbo_linear16_fwd_enc (k_linear16.hip) + the cutoff weights */
 extern "C" int danbo_anerf_encode_compact(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
                                           int S, int G, const float* skts, const float* align, const float* cutoff, float tau,
                                           long row0, int nrows, float* table, float* w_out, void* stream) {

@@ -40,21 +40,22 @@ constexpr int L16_LDS_BYTES = L16_SLOTS * L16_CHUNK + L16_MAX_N * 4;
 // frag (bit 0: the K1 part, bit 1: the K2 part): that input arrives in FRAGMENT ORDER (see Lin16Args::frag) -- k-slot 8 q + e of
 // k-step s then carries input column 32 s + 16 (e / 4) + 4 q + e % 4 instead of 32 s + 8 q + e
 // enc_L > 0: the K1 part is A-NeRF's 24 (1 + 2 L) + 72 density inputs, RECOMPUTED by the kernel from the encoder's table
-// (danbo_linear16_fwd_enc): 15 k-steps whose slots carry the columns in the order lin_enc_column gives them
+// (danbo_linear16_fwd_enc): 14 k-steps -- as many as the 432 columns take when they are read -- whose slots carry the columns in
+// the order lin_enc_column gives them
 __host__ __device__ inline int lin_enc_column(int s, int kk, int L) {
-    const int q = kk >> 3, e = kk & 7;
-    if (s < 12) {                       // joints 2 s, 2 s + 1; blocks [raw, pad, sin_0, cos_0, ..., sin_6, cos_6], 4 per lane quarter
+    const int q = kk >> 3, e = kk & 7, dir0 = (1 + 2 * L) * 24;
+    if (s < 12) {      // joints 2 s, 2 s + 1; 16 slots each: [raw, direction x, sin_0, cos_0, ..., sin_6, cos_6], 4 per lane quarter
         const int j = 2 * s + (e >> 2), blk = 4 * q + (e & 3);
         if (blk == 0) return j;
-        if (blk == 1) return -1;
+        if (blk == 1) return dir0 + 3 * j;
         const int l = (blk - 2) >> 1;
         if (l >= L) return -1;
         return ((blk & 1) ? 2 + 2 * l : 1 + 2 * l) * 24 + j;
     }
-    const int j = 8 * (s - 12) + 2 * q + (e >> 2), k = e & 3;      // unit directions, (x, y, z, pad) per joint
-    return k < 3 ? (1 + 2 * L) * 24 + 3 * j + k : -1;
+    const int j = 16 * (s - 12) + 4 * q + (e >> 1);                // k-steps 12, 13: direction (y, z) of 16 + 8 joints
+    return j < 24 ? dir0 + 3 * j + 1 + (e & 1) : -1;
 }
-constexpr int L16_ENC_K = 480, L16_ENC_FLOATS = 192;
+constexpr int L16_ENC_K = 448, L16_ENC_FLOATS = 144;
 
 __global__ __launch_bounds__(256) void k_linear16_pack(const float* __restrict__ w, long sn, long sk, int N, int K1, int K2, int NH,
                                                        int frag, int enc_L, _Float16* __restrict__ packed) {
@@ -98,7 +99,7 @@ struct Lin16Args {
     // Every load and store instruction of a wavefront then moves one contiguous KB (8 full cache lines) instead of sixteen
     // 64-byte pieces of sixteen rows -- the row-major epilogue drains at 16 B/clk per CU (s_memtime: 14 000 cycles per tile).
     int frag;
-    int enc_L;         // FRAG & 8: x1 is the A-NeRF encoder's table [rows, 48, 4] (k_anerf.hip), K1 = 480 recomputed inputs, L levels
+    int enc_L;         // FRAG & 8: x1 is the A-NeRF encoder table [rows, 144] (k_anerf.hip), K1 = 448 slots of recomputed inputs, L levels
     long long* trace;  // dev tool (tools/micro_linear16.py --trace): s_memtime stamps of one wavefront, or nullptr
 };
 
@@ -181,12 +182,12 @@ __device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // FRAG & 8: the inputs of the K1 part are not read, they are recomputed from the encoder's table (the 432-wide tensor the
-// encoder would write is 1 728 B per row, written once and read by the first and the skip layer; the table is 768 B).  In a
-// k-step s < 12 a lane's two 16-byte loads are the entries (inp, sh, w, 0) of joints 2 s and 2 s + 1, and its eight inputs are
-// blocks 4 q .. 4 q + 3 of each joint: [inp w, 0, sin(sh) w, cos(sh) w] for q = 0, else the sin / cos pairs of levels 2 q - 1 and
+// encoder would write is 1 728 B per row, written once and read by the first and the skip layer; the table is 576 B).  In a
+// k-step s < 12 a lane's two 16-byte loads are the entries (inp, sh, w, dir x) of joints 2 s and 2 s + 1, and its eight inputs are
+// slots 4 q .. 4 q + 3 of each joint: [inp w, dir x, sin(sh) w, cos(sh) w] for q = 0, else the sin / cos pairs of levels 2 q - 1 and
 // 2 q times w (CutoffEmbedder._embed, cutoff_embedder.py:151-214; the arithmetic of k_anerf_encode with the sines from
-// v_sin_f32 / v_cos_f32 after a two-term Cody-Waite reduction instead of sincosf: <= 2e-7 on the values).  k-steps 12 .. 14 carry
-// the unit directions as stored.
+// v_sin_f32 / v_cos_f32 after a two-term Cody-Waite reduction instead of sincosf: <= 2e-7 on the values).  k-steps 12, 13 carry
+// the (y, z) components of the unit directions as stored.  14 k-steps: the MFMA work of the layer does not grow.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lin_sincos(float a, float& sn, float& cs) {
     const float k = __builtin_rintf(a * 0.15915494309189535f);
@@ -196,14 +197,14 @@ __device__ __forceinline__ void lin_sincos(float a, float& sn, float& cs) {
     sn = __builtin_amdgcn_sinf(rev);
     cs = __builtin_amdgcn_cosf(rev);
 }
-__device__ __forceinline__ void lin_enc_joint(float inp, float sh, float w, int q, int L, float* o) {
+__device__ __forceinline__ void lin_enc_joint(float inp, float sh, float w, float dx, int q, int L, float* o) {
     const int l1 = q == 0 ? 0 : 2 * q - 1, l2 = 2 * q;
     float s1, c1, s2, c2;
     lin_sincos(sh * __builtin_bit_cast(float, (unsigned)(127 + l1) << 23), s1, c1);
     lin_sincos(sh * __builtin_bit_cast(float, (unsigned)(127 + l2) << 23), s2, c2);
     const bool on1 = l1 < L, on2 = l2 < L;
     o[0] = mul_rn(q == 0 ? inp : (on1 ? s1 : 0.f), w);
-    o[1] = mul_rn(q == 0 ? 0.f : (on1 ? c1 : 0.f), w);
+    o[1] = q == 0 ? dx : mul_rn(on1 ? c1 : 0.f, w);
     o[2] = mul_rn(on2 ? s2 : 0.f, w);
     o[3] = mul_rn(on2 ? c2 : 0.f, w);
 }
@@ -238,9 +239,10 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         row = row < M ? row : M - 1;
         const bool second = rq_s >= KS1;
         if ((FRAG & 8) && !second) {
-            // the encoder's table: entries of joints 2 s, 2 s + 1 (s < 12) / of this lane quarter's two directions
-            const int entry = rq_s < 12 ? 2 * rq_s : 24 + 8 * (rq_s - 12) + 2 * q;
-            const float* tb = a.x1 + row * L16_ENC_FLOATS + entry * 4;
+            // the encoder's table: entries of joints 2 s, 2 s + 1 (s < 12) / this lane quarter's four (y, z) pairs
+            // (k-step 13 holds 8 joints: the upper two lane quarters re-read the lower ones' floats, their weights are zero)
+            const int off = rq_s < 12 ? 8 * rq_s : 96 + 32 * (rq_s - 12) + 8 * ((rq_s == 13 && q >= 2) ? q - 2 : q);
+            const float* tb = a.x1 + row * L16_ENC_FLOATS + off;
             lin_request_rows<decltype(set)::value>(tb, tb + 4);
         } else
         if (FRAG & (second ? 2 : 1)) {
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         lin_take_rows<0>(x);
         if (FRAG & 8) {                          // k-step 0 of the first row tile
             float o[8];
-            lin_enc_joint(x[0], x[1], x[2], q, a.enc_L, o);
-            lin_enc_joint(x[4], x[5], x[6], q, a.enc_L, o + 4);
+            lin_enc_joint(x[0], x[1], x[2], x[3], q, a.enc_L, o);
+            lin_enc_joint(x[4], x[5], x[6], x[7], q, a.enc_L, o + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = o[e];
         }
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                     if (s_next < 12) {
                         float o[4];
                         const int e0 = 4 * (b - 3);
-                        lin_enc_joint(nx[e0], nx[e0 + 1], nx[e0 + 2], q, a.enc_L, o);
+                        lin_enc_joint(nx[e0], nx[e0 + 1], nx[e0 + 2], nx[e0 + 3], q, a.enc_L, o);
                         nx[e0] = o[0]; nx[e0 + 1] = o[1]; nx[e0 + 2] = o[2]; nx[e0 + 3] = o[3];
                     }
                 }
@@ -459,7 +461,7 @@ extern "C" int danbo_linear16_pack_frag(const float* w, long stride_n, long stri
 }
 
 /* w [N, 24 (1 + 2 L) + 72 + K2]: a layer whose first 24 (1 + 2 L) + 72 inputs are A-NeRF's density inputs, recomputed by
- * danbo_linear16_fwd_enc from the encoder's table (15 k-steps = DANBO_LINEAR16_ENC_K slots), the other K2 a second input
+ * danbo_linear16_fwd_enc from the encoder's table (14 k-steps = DANBO_LINEAR16_ENC_K slots), the other K2 a second input
  * (frag_in bit 1: in fragment order).  packed: danbo_linear16_packed_bytes(N, DANBO_LINEAR16_ENC_K, K2) bytes. */
 extern "C" int danbo_linear16_pack_enc(const float* w, long stride_n, long stride_k, int N, int L, int K2, int frag_in, void* packed,
                                        void* stream) {
@@ -527,7 +529,7 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
 }
 
 /* y (fragment order) = act([enc(table) | x2] W^T + bias): the first / the skip layer of the A-NeRF trunk with the 24 (1 + 2 L) + 72
- * density inputs recomputed from the encoder's table [M, 48, 4] (danbo_anerf_encode_compact) instead of read (W packed by
+ * density inputs recomputed from the encoder's table [M, 144] (danbo_anerf_encode_compact) instead of read (W packed by
  * danbo_linear16_pack_enc).  x2: NULL, or the second input [M, K2] in fragment order.  N = 448 (the shipped A-NeRF width). */
 extern "C" int danbo_linear16_fwd_enc(const float* table, int L, const float* x2, int K2, const void* packed, const float* bias, int N,
                                       int act, float* y, int M, const int32_t* count, void* stream) {

@@ -320,13 +320,14 @@ int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const float* x2, i
                             void* stream);
 
 /* The first / the skip layer of the A-NeRF trunk with the 24 (1 + 2 L) + 72 density inputs RECOMPUTED in the kernel
- * (CutoffEmbedder._embed, core/cutoff_embedder.py:151-214) from the encoder's compact table [M, 48, 4] that
- * danbo_anerf_encode_compact writes -- per joint (cutoff - distance, shifted distance, cutoff weight, 0), then the 24 unit
- * directions padded to 4 -- instead of read: 768 instead of 1 728 B per sample, written once and read twice.
+ * (CutoffEmbedder._embed, core/cutoff_embedder.py:151-214) from the encoder's compact table [M, 144] that
+ * danbo_anerf_encode_compact writes -- per joint (cutoff - distance, shifted distance, cutoff weight, direction x), then the 24
+ * (direction y, z) pairs -- instead of read: 576 instead of 1 728 B per sample, written once and read twice; the layer keeps
+ * its 14 k-steps.
  * danbo_linear16_pack_enc: w [N, 24 (1 + 2 L) + 72 + K2] (frag_in 2: the K2 part arrives in fragment order), packed:
  * danbo_linear16_packed_bytes(N, DANBO_LINEAR16_ENC_K, K2) bytes.  danbo_linear16_fwd_enc: y in fragment order, N = 448. */
-#define DANBO_LINEAR16_ENC_K 480
-#define DANBO_ANERF_ENC_FLOATS 192
+#define DANBO_LINEAR16_ENC_K 448
+#define DANBO_ANERF_ENC_FLOATS 144
 int danbo_linear16_pack_enc(const float* w, long stride_n, long stride_k, int N, int L, int K2, int frag_in, void* packed,
                             void* stream);
 int danbo_linear16_fwd_enc(const float* table, int L, const float* x2, int K2, const void* packed, const float* bias, int N,

@@ -188,10 +188,10 @@ def test_linear16_recomputes_the_anerf_density_inputs_from_the_encoder_table(L, 
     x0, w_rows = ops.anerf_encode(rays_o, rays_d, skts, align, cutoff, tau, L, 0, n, z=z)
     table, w_tab = ops.anerf_encode_compact(rays_o, rays_d, skts, align, cutoff, tau, 0, n, z=z)
     assert torch.equal(w_rows, w_tab)
-    t = table.view(n, 48, 4)
-    assert torch.equal(t[:, :24, 0] * t[:, :24, 2], x0[:, :24])                         # (cutoff - v) w
-    assert torch.equal(t[:, 24:, :3].reshape(n, 72), x0[:, in_ch - 72:]) and (t[:, :, 3] == 0).all()
-    assert (torch.sin(t[:, :24, 1].double()) * t[:, :24, 2].double() - x0[:, 24:48].double()).abs().max().item() < 2e-7
+    t, yz = table[:, :96].view(n, 24, 4), table[:, 96:].view(n, 24, 2)
+    assert torch.equal(t[:, :, 0] * t[:, :, 2], x0[:, :24])                             # (cutoff - v) w
+    assert torch.equal(torch.cat([t[:, :, 3:4], yz], 2).reshape(n, 72), x0[:, in_ch - 72:])
+    assert (torch.sin(t[:, :, 1].double()) * t[:, :, 2].double() - x0[:, 24:48].double()).abs().max().item() < 2e-7
     w0 = (torch.randn(W, in_ch, generator=g) / in_ch ** 0.5).to(DEV)
     w5 = (torch.randn(W, in_ch + W, generator=g) / (in_ch + W) ** 0.5).to(DEV)
     b0, b5 = (torch.randn(W, generator=g) * 0.1).to(DEV), (torch.randn(W, generator=g) * 0.1).to(DEV)
