@@ -276,7 +276,6 @@ def forward_train(model, inputs):
         shared["vols"] = pose_volumes(model, bones_g)
     vols = shared["vols"]
     shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
-    p_rows = None
     if os.environ.get("DANBO_AUTOGRAD_ASSIGN") != "library" and n > 0:
         # torch.ops.danbo.assign_blend: gather + assignment GNN + masked sigmoid + blend in one HIP kernel each way (core/custom_ops.py);
         # part_feat [n,24,15] is never materialised
@@ -291,6 +290,7 @@ def forward_train(model, inputs):
         valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
         p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid_rows
         h = (part_feat * p[..., None]).sum(-2)
+        p_rows = p                            # (both routes hand the loss the same differentiable masked probabilities)
     if "vin" not in shared:
         shared["vin"] = view_inputs(model, rays_d, skts_g, inputs.get("cam_idxs"), R // G)
     vin = shared["vin"]
@@ -317,15 +317,13 @@ def forward_train(model, inputs):
         shared["raw_empty"] = raw_empty
     raw = raw_empty[:, None, :].expand(R, S, 4).reshape(R * S, 4).index_copy(0, rows.long(), raw_rows)
     confd = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), logits)
-    p_valid = None
-    if p_rows is not None:      # the differentiable route to the assignment net for the soft-softmax loss (confd is detached there)
-        p_valid = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), p_rows).reshape(R, S, 24)
+    # the differentiable route to the assignment net for the soft-softmax loss (the operator's confd carries no gradient)
+    p_valid = torch.zeros(R * S, 24, device=pts.device).index_copy(0, rows.long(), p_rows).reshape(R, S, 24)
     # confd of samples outside every volume: the reference evaluates the assignment net there too; those
     # logits never reach a loss (they are multiplied by part_valid = 0), so they are left at zero
     all_valid = ((bits.unsqueeze(-1) >> shifts) & 1).float()
     encoded = dict(confd=confd.reshape(R, S, 24), part_invalid=(1.0 - all_valid).reshape(R, S, 24))
-    if p_valid is not None:
-        encoded["p_valid"] = p_valid
+    encoded["p_valid"] = p_valid
     return raw.reshape(R, S, 4), encoded
 
 
