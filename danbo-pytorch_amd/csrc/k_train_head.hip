@@ -61,15 +61,26 @@ __global__ __launch_bounds__(128) void k_train_ray_grad(const float* __restrict_
         float acc = 0.f;
         int cur = -1;
         const int end = min(base + RG_CHUNK, rows);
-        for (int i = base; i < end; ++i) {
-            int ray = row_ray[i];
-            ray = ray < 0 ? 0 : (ray >= R ? R - 1 : ray);
-            if (ray != cur) {
-                if (cur >= 0 && acc != 0.f) atomicAdd(d_cview + (size_t)cur * HVW + f, acc);
-                cur = ray;
-                acc = 0.f;
+        for (int i0 = base; i0 < end; i0 += 8) {          // eight rows' loads in one batch (same summation order as row by row)
+            int ry[8];
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, end - 1);
+                ry[u] = row_ray[i];
+                dv[u] = dpre_v[(size_t)(i >> 4) * 2048 + foff + (i & 15) * 4];
             }
-            acc += dpre_v[(size_t)(i >> 4) * 2048 + foff + (i & 15) * 4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u >= end) break;
+                const int ray = ry[u] < 0 ? 0 : (ry[u] >= R ? R - 1 : ry[u]);
+                if (ray != cur) {
+                    if (cur >= 0 && acc != 0.f) atomicAdd(d_cview + (size_t)cur * HVW + f, acc);
+                    cur = ray;
+                    acc = 0.f;
+                }
+                acc += dv[u];
+            }
         }
         if (cur >= 0 && acc != 0.f) atomicAdd(d_cview + (size_t)cur * HVW + f, acc);
     }
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(128) void k_train_ray_grad(const float* __restrict_
 // g_views_w[f, 256 + k] += sum_r d cview[r, f] vin[r, k]   (blockIdx.x < k-groups of 8 columns, blockIdx.y = ray slice)
 // csum[cam(r), f]      += d cview[r, f]                      (the last blockIdx.x; running sum per camera)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int VG_K = 8, VG_SLICES = 32;
+constexpr int VG_K = 8, VG_SLICES = 16, VG_U = 8;      // VG_U rays in flight per iteration
 __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict__ d_cview, const float* __restrict__ vin, int ldv, int Cv,
                                                          int R, const int64_t* __restrict__ cam_idx, int n_codes, float* __restrict__ g_views_w,
                                                          float* __restrict__ csum) {
@@ -89,24 +100,25 @@ __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict
     const int r_begin = blockIdx.y * per, r_end = min(r_begin + per, R);
     if ((int)blockIdx.x < kgroups) {
         const int k0 = blockIdx.x * VG_K;
-        // the 8 view inputs of a ray are wave-uniform (scalar loads); four rays in flight per iteration
+        // the 8 view inputs of a ray are wave-uniform (scalar loads); VG_U rays in flight per iteration.  (The launch is bound by its
+        // final atomics -- 96 ray slices: 139 us, 32: 70 -- so few slices and long, well-fed loops)
         float acc[VG_K];
 #pragma unroll
         for (int j = 0; j < VG_K; ++j) acc[j] = 0.f;
         const bool full = k0 + VG_K <= Cv;
         int r = r_begin;
-        for (; r + 4 <= r_end && full; r += 4) {
-            float dc[4];
-            f32x4v v[4][2];
+        for (; r + VG_U <= r_end && full; r += VG_U) {
+            float dc[VG_U];
+            f32x4v v[VG_U][2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < VG_U; ++u) {
                 dc[u] = d_cview[(size_t)(r + u) * HVW + f];
                 const f32x4v* vp = reinterpret_cast<const f32x4v*>(vin + (size_t)(r + u) * ldv + k0);
                 v[u][0] = vp[0];
                 v[u][1] = vp[1];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < VG_U; ++u)
 #pragma unroll
                 for (int j = 0; j < VG_K; ++j) acc[j] = fmaf(dc[u], v[u][j >> 2][j & 3], acc[j]);
         }
@@ -120,17 +132,29 @@ __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict
         for (int j = 0; j < VG_K; ++j)
             if (k0 + j < Cv && acc[j] != 0.f) atomicAdd(g_views_w + (size_t)f * (HW + Cv) + HW + k0 + j, acc[j]);
     } else if (n_codes > 0) {
+        // (eight rays' loads in one batch: ray by ray this was a chain of ~100 dependent round trips, the longest block of the launch)
         float acc = 0.f;
         long cur = -1;
-        for (int r = r_begin; r < r_end; ++r) {
-            long ci = cam_idx ? cam_idx[r] : 0;
-            ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
-            if (ci != cur) {
-                if (cur >= 0 && acc != 0.f) atomicAdd(csum + cur * HVW + f, acc);
-                cur = ci;
-                acc = 0.f;
+        for (int r = r_begin; r < r_end; r += 8) {
+            long ci[8];
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = min(r + u, r_end - 1);
+                ci[u] = cam_idx ? cam_idx[rr] : 0;
+                dv[u] = d_cview[(size_t)rr * HVW + f];
             }
-            acc += d_cview[(size_t)r * HVW + f];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (r + u >= r_end) break;
+                const long c = ci[u] < 0 ? 0 : (ci[u] >= n_codes ? n_codes - 1 : ci[u]);
+                if (c != cur) {
+                    if (cur >= 0 && acc != 0.f) atomicAdd(csum + cur * HVW + f, acc);
+                    cur = c;
+                    acc = 0.f;
+                }
+                acc += dv[u];
+            }
         }
         if (cur >= 0 && acc != 0.f) atomicAdd(csum + cur * HVW + f, acc);
     }
