@@ -23,6 +23,7 @@
 // slices in a fixed order (deterministic, no float atomics), undoes the power-of-two pre-scale of the gradient operand
 // (in_maxabs of danbo_linear16_ex) and writes the gradients in nn.Linear layout.
 // Algorithmic traffic per row and layer: 4 (N + K) bytes; flops 2 N K (x 3 MFMA products).
+#include <type_traits>
 #include "common.hpp"
 
 namespace danbo {
@@ -121,6 +122,11 @@ __device__ __forceinline__ void dw_sync() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+template <int T> __device__ __forceinline__ void dw_issue(const char* const (&pa)[2][2], const char* const (&pb)[4][2]);
+template <int T> __device__ __forceinline__ void dw_take(f32x4 (&a)[2][2], f32x4 (&bb)[4][2]);
+#include "k_dw16_regs.inc"
+template <int N> __device__ __forceinline__ void dw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <bool FA, bool FB>
 __device__ __forceinline__ void dw_producer(const DwLayer& L, const DwCtx& c) {
     char* const smem = c.smem;
@@ -196,29 +202,28 @@ __device__ __forceinline__ void dw_producer(const DwLayer& L, const DwCtx& c) {
         }
         const bool cols_full = __all((a_live == 0xffu) && (b_live == 0xffffu));   // per wavefront
         int next_row = row0;                            // first row of the step the next load_step requests
-        auto load_step = [&](Stage& st) {
+        // The loads are inline asm into fixed registers (k_dw16_regs.inc) and are waited for BY COUNT: vmcnt retires in issue order,
+        // every step issues the same 12 loads per lane, so "at most 12 y outstanding" means everything but the y youngest steps has
+        // arrived.  (With compiler-tracked loads every convert ended in vmcnt(0) -- the requests of the steps ahead were drained
+        // at every step and the kernel ran at one memory latency per step, MFMAs or not.)
+        auto issue = [&](auto stage) {
             if (next_row + DW_ROWS <= row_end) {
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w]);
-                }
+                dw_issue<decltype(stage)::value>(pa, pb);
             } else {
                 // the slice's last, partial step: rows past the end read the last row again (row-major; a fragment-order buffer is
                 // padded to whole 128-row tiles and read in place); zeroed in convert
+                const char* qa[2][2];
+                const char* qb[4][2];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
                     const long backA = (long)max(next_row + pA + 16 * w - (row_end - 1), 0);
                     const long backB = (long)max(next_row + pB + 16 * w - (row_end - 1), 0);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        st.a[u][w] = *reinterpret_cast<const f32x4*>(pa[u][w] - (fragA ? 0 : backA * (L.ldy * 4)));
+                    for (int u = 0; u < 2; ++u) qa[u][w] = pa[u][w] - (fragA ? 0 : backA * (L.ldy * 4));
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        st.b[u][w] = *reinterpret_cast<const f32x4*>(pb[u][w] - (fragB ? 0 : backB * (long)(b_stride[u] / DW_ROWS)));
+                    for (int u = 0; u < 4; ++u) qb[u][w] = pb[u][w] - (fragB ? 0 : backB * (long)(b_stride[u] / DW_ROWS));
                 }
+                dw_issue<decltype(stage)::value>(qa, qb);
             }
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
@@ -267,22 +272,26 @@ __device__ __forceinline__ void dw_producer(const DwLayer& L, const DwCtx& c) {
             for (int u = 0; u < 4; ++u)
                 dw_store4<false>(base + 2 * DW_A_BYTES, base + 2 * DW_A_BYTES + DW_B_BYTES, colB[u], pB, st.b[u][0], st.b[u][1], 1.f);
         };
-        Stage sa, sb;                                 // steps 0, 2, 4, ... / 1, 3, 5, ...
-        load_step(sa);
-        if (nsteps > 1) load_step(sb);
-        convert(sa, 0, row0);
-        if (nsteps > 2) load_step(sa);
-        wg_sync();
-        for (int s = 0; s < nsteps; s += 2) {
-            // consumers: step s out of buffer 0.  Step s + 1 into buffer 1, step s + 3 requested
-            if (s + 1 < nsteps) convert(sb, 1, row0 + (s + 1) * DW_ROWS);
-            if (s + 3 < nsteps) load_step(sb);
+        // TWO steps in flight: step k lives in register set k & 1 and is converted into LDS buffer k & 1 while the consumers
+        // multiply step k - 1; its registers are re-used for step k + 2.  1 + nsteps barriers, as the consumers.
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        issue(S0{});
+        if (nsteps > 1) issue(S1{});
+        auto step = [&](auto stage, int k) {
+            if (k < nsteps) {
+                if (k + 1 < nsteps) dw_wait_vm<12>();                 // step k + 1 has been requested behind step k
+                else dw_wait_vm<0>();
+                Stage st;
+                dw_take<decltype(stage)::value>(st.a, st.b);
+                if (k + 2 < nsteps) issue(stage);
+                convert(st, k & 1, row0 + k * DW_ROWS);
+            }
             wg_sync();
-            if (s + 1 >= nsteps) break;
-            // consumers: step s + 1 out of buffer 1.  Step s + 2 into buffer 0, step s + 4 requested
-            if (s + 2 < nsteps) convert(sa, 0, row0 + (s + 2) * DW_ROWS);
-            if (s + 4 < nsteps) load_step(sa);
-            wg_sync();
+        };
+        for (int k = 0;;) {
+            step(S0{}, k); if (++k > nsteps) break;
+            step(S1{}, k); if (++k > nsteps) break;
         }
         if (tk == 0 && (fragA ? (lane & 15) == 15 : (lane & 7) == 7)) {   // row-major: two wavefronts (row pairs 0-7 / 8-15) per column
 #pragma unroll
