@@ -156,7 +156,8 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long dw
 }
 
 constexpr int N_DW = 12;           // 8 trunk matrices (the skip layer's as two), W_fv, alpha_linear, rgb_linear
-constexpr int DW_SLICES = 10;      // ~24 tiles of 128 x 256 x 10 row slices: about one workgroup per CU
+constexpr int DW_SLICES = 10;      // 21 (padded: 22) tiles of 128 x 256 x 10 row slices = 210 workgroups: a k_dw16 workgroup fills its CU (two 256-register
+                                   // wavefronts per SIMD), the CUs left over run the pose-GNN adjoint beside it (8 .. 12 slices measured: 1.71 / 1.67 / 1.65 / 1.66 ms per step)
 
 void describe_dw(const DanboTrainModel* m, const TrainBuffers& b, DanboDwLayer* L) {
     const size_t lstride = (size_t)b.rows_pad * 256;
