@@ -342,6 +342,46 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
     assert seen == want, (seen ^ want)
 
 
+def test_dw16_isa_leaves_the_producers_load_registers_alone(tmp_path):
+    """k_dw16's producer wavefronts request their operands two steps ahead with inline-asm loads into the fixed accumulation
+    registers a0 .. a95 and wait for them by count (csrc/k_dw16_regs.inc): nothing the compiler generates for the producer code may
+    name those registers (a value parked there would be overwritten by a load in flight), the kernel must not spill, must fit two
+    wavefronts per SIMD (256 registers), and its waits must be the counted ones."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "danbo-pytorch_amd", "csrc", "k_dw16.hip")
+    out = str(tmp_path / "k_dw16.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out, src],
+                   check=True, capture_output=True)
+    text = open(out).read()
+    meta = re.search(r"\.name:\s+_ZN5danbo6k_dw16ENS_6DwArgsE\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text)
+    assert meta is not None and int(meta.group(1)) <= 256, meta and meta.group(1)
+    body = text[text.index("_ZN5danbo6k_dw16ENS_6DwArgsE:"):]
+    body = body[:body.index(".Lfunc_end")].split("\n")
+    assert not any("scratch_" in l for l in body)
+    pinned = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
+    first_load = next(i for i, l in enumerate(body) if "global_load_dwordx4 a[" in l)
+    in_asm, loads, foreign = False, 0, []
+    for i, l in enumerate(body):
+        in_asm = True if "ASMSTART" in l else (False if "ASMEND" in l else in_asm)
+        code = l.split(";")[0]
+        if in_asm:
+            loads += "global_load_dwordx4 a[" in code
+            continue
+        if i < first_load:          # the consumers' code (MFMA accumulators live in a0 .. a127 there) is emitted first
+            continue
+        for m in pinned.finditer(code):
+            lo = int(m.group(1) or m.group(2))
+            if lo < 96:
+                foreign.append(code.strip())
+    assert not foreign, foreign[:4]
+    assert loads > 0 and loads % 12 == 0, loads                                     # 12 loads per lane and step, always
+    waits = {re.search(r"vmcnt\(\d+\)", l).group(0) for l in body[first_load:] if "s_waitcnt" in l and "vmcnt" in l}
+    assert "vmcnt(12)" in waits, waits
+
+
 def test_ring_kernels_do_not_spill(tmp_path):
     """The kernels that stream weights through an LDS ring with hand-counted vmcnt waits must not spill: a scratch access is a
     VMEM operation the compiler waits for with vmcnt(0), which drains the ring (k_pe_mlp16 with 196 B of spills moved 10x the HBM
