@@ -74,8 +74,8 @@ SIGNATURES = {
     "danbo_trunk_bwd": [P, P, P],
     "danbo_trunk_pe_column": [I],
     "danbo_train_cview": [P, I, I, P, P, I, P, P],
-    "danbo_train_view_grads": [P, P, P, I, I, P, I, I, P, I, P, P, P, P],
-    "danbo_train_head_chain": [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "danbo_train_view_grads": [P, P, P, I, I, P, I, I, P, I, P, P, P, P, P],
+    "danbo_train_head_chain": [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P],
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],

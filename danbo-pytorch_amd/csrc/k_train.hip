@@ -64,7 +64,7 @@ struct TrainBuffers {
     float *weights0;
     // backward
     float *g_rgb, *g_acc, *g_rgb0, *g_acc0, *d_raw_c, *d_raw_f, *d_raw_sorted, *d_raw_rows, *dz, *dpre_v, *d_alpha4, *d_h, *pose_bwd_scratch,
-        *dw_scratch, *g_wfv, *g_beff;
+        *dw_scratch, *g_wfv, *g_beff, *vg_part;
     uint8_t *label_c, *label_f;
     // packing
     char* packed;
@@ -143,6 +143,7 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long dw
     b.dw_scratch = c.take<float>(dw_floats);
     b.g_wfv = c.take<float>(128 * 256);
     b.g_beff = c.take<float>(128);
+    b.vg_part = c.take<float>(DANBO_TRAIN_VG_PART_FLOATS);
     b.label_c = c.take<uint8_t>(Mc);
     b.label_f = c.take<uint8_t>(Mf);
     // ---- packing
@@ -473,14 +474,14 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         if (phase == 0 && hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
     }
     DANBO_TRY(danbo_train_view_grads(b.dpre_v, b.row_ray, b.cnt, ncap, R, b.vin, LD_VIN, m->view_ch, bt->cam_idx, m->n_codes, b.d_cview, b.csum,
-                                     m->g[DANBO_T_VIEWS_W], s0));
+                                     m->g[DANBO_T_VIEWS_W], b.vg_part, s0));
     auto side1_tail = [&]() -> int {
         DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, s1));
         if (hipEventRecord(ss->join[0], ss->s[0]) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->join[0], 0) != hipSuccess)
             return (int)hipGetLastError();
         DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W],
                                          m->view_ch, m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B],
-                                         m->g[DANBO_T_VIEWS_W], m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, s1));
+                                         m->g[DANBO_T_VIEWS_W], m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, b.vg_part, s1));
         return 0;
     };
     DANBO_TRY(danbo_train_bone_lists(b.bits_c, b.bits_f, b.row_sample, b.cnt, R, ncap, b.lists, b.cntb, stream));
@@ -524,7 +525,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, stream));
         DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W], m->view_ch,
                                          m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B], m->g[DANBO_T_VIEWS_W],
-                                         m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, stream));
+                                         m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, b.vg_part, stream));
     }
     // ---- loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
     hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),

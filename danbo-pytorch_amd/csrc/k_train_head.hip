@@ -91,9 +91,10 @@ __global__ __launch_bounds__(128) void k_train_ray_grad(const float* __restrict_
 // csum[cam(r), f]      += d cview[r, f]                      (the last blockIdx.x; running sum per camera)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int VG_K = 8, VG_SLICES = 16, VG_U = 8;      // VG_U rays in flight per iteration
+constexpr int VG_PART_LD = 160;                         // row stride of the per-slice partial sums [VG_SLICES][128][VG_PART_LD]
 __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict__ d_cview, const float* __restrict__ vin, int ldv, int Cv,
                                                          int R, const int64_t* __restrict__ cam_idx, int n_codes, float* __restrict__ g_views_w,
-                                                         float* __restrict__ csum) {
+                                                         float* __restrict__ csum, float* __restrict__ part) {
     const int f = threadIdx.x;
     const int kgroups = (Cv + VG_K - 1) / VG_K;
     const int per = (R + gridDim.y - 1) / gridDim.y;
@@ -128,9 +129,18 @@ __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict
 #pragma unroll
             for (int j = 0; j < VG_K; ++j) acc[j] = fmaf(dc, k0 + j < Cv ? v[j] : 0.f, acc[j]);
         }
+        if (part != nullptr) {
+            // per-slice partial sums, added up by k_train_head_chain (16 atomics per gradient entry were what this launch spent its
+            // time on -- and, running beside the K2 adjoint, that kernel's)
+            float* dst = part + ((size_t)blockIdx.y * HVW + f) * VG_PART_LD + k0;
 #pragma unroll
-        for (int j = 0; j < VG_K; ++j)
-            if (k0 + j < Cv && acc[j] != 0.f) atomicAdd(g_views_w + (size_t)f * (HW + Cv) + HW + k0 + j, acc[j]);
+            for (int j = 0; j < VG_K; ++j)
+                if (k0 + j < Cv) dst[j] = acc[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < VG_K; ++j)
+                if (k0 + j < Cv && acc[j] != 0.f) atomicAdd(g_views_w + (size_t)f * (HW + Cv) + HW + k0 + j, acc[j]);
+        }
     } else if (n_codes > 0) {
         // (eight rays' loads in one batch: ray by ray this was a chain of ~100 dependent round trips, the longest block of the launch)
         float acc = 0.f;
@@ -168,14 +178,25 @@ struct HeadChainArgs {
     const float *feature_w /*[256,256]*/, *feature_b /*[256]*/, *views_w /*[128,256+Cv]*/;
     int Cv, n_codes, code_size, code_col0;       // code_col0: first frame-code column of vin (3 (1 + 2 L_view))
     float *g_feature_w, *g_feature_b, *g_views_w, *g_views_b, *g_codes;
+    const float* vg_part;                        // [VG_SLICES][128][VG_PART_LD] partial d W_v[:, 256:] of k_train_view_grad, or nullptr
 };
 
 __global__ __launch_bounds__(256) void k_train_head_chain(HeadChainArgs a) {
     const int ld = HW + a.Cv;
     const long n_va = (long)HVW * HW, n_f = (long)HW * HW, n_fb = HW, n_vb = HVW, n_c = (long)a.n_codes * a.code_size;
-    const long total = n_va + n_f + n_fb + n_vb + n_c;
+    const long n_vk = a.vg_part ? (long)HVW * a.Cv : 0;
+    const long total = n_va + n_f + n_fb + n_vb + n_c + n_vk;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long i = idx;
+        if (i >= total - n_vk) {      // d W_v[f, 256 + k] = sum over the ray slices of k_train_view_grad's partial sums (fixed order)
+            i -= total - n_vk;
+            const int f = (int)(i / a.Cv), k = (int)(i % a.Cv);
+            float acc = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < VG_SLICES; ++sl) acc += a.vg_part[((size_t)sl * HVW + f) * VG_PART_LD + k];
+            a.g_views_w[(size_t)f * ld + HW + k] += acc;
+            continue;
+        }
         if (i < n_va) {               // d W_v[f, c] = sum_j d W_fv[f, j] W_f[c, j] + d b_eff[f] b_f[c]
             const int f = (int)(i / HW), c = (int)(i % HW);
             float acc = a.g_beff[f] * a.feature_b[c];
@@ -227,26 +248,29 @@ extern "C" int danbo_train_cview(const float* vin, int ldv, int view_ch, const f
 
 extern "C" int danbo_train_view_grads(const float* dpre_v, const int32_t* row_ray, const int32_t* cnt, int rows_cap, int R, const float* vin,
                                       int ldv, int view_ch, const int64_t* cam_idx, int n_codes, float* d_cview /*[R,128] zeroed*/,
-                                      float* csum /*[n_codes,128] zeroed*/, float* g_views_w /*accumulated*/, void* stream) {
+                                      float* csum /*[n_codes,128] zeroed*/, float* g_views_w /*accumulated*/,
+                                      float* vg_part /*DANBO_TRAIN_VG_PART_FLOATS or NULL*/, void* stream) {
     DANBO_CHECK_ARG(dpre_v && row_ray && cnt && vin && d_cview && g_views_w && rows_cap > 0 && R > 0 && view_ch >= 0 && ldv % 4 == 0);
     DANBO_CHECK_ARG(ldv >= view_ch && (uintptr_t)vin % 16 == 0);
     DANBO_CHECK_ARG(n_codes == 0 || csum);
+    DANBO_CHECK_ARG(view_ch <= VG_PART_LD);
     const int chunks = (rows_cap + RG_CHUNK - 1) / RG_CHUNK;
     hipLaunchKernelGGL(k_train_ray_grad, dim3(chunks < num_cu() * 8 ? chunks : num_cu() * 8), dim3(128), 0, (hipStream_t)stream, dpre_v, row_ray,
                        cnt, R, d_cview);
     const int kgroups = (view_ch + VG_K - 1) / VG_K;
     hipLaunchKernelGGL(k_train_view_grad, dim3(kgroups + 1, VG_SLICES), dim3(128), 0, (hipStream_t)stream, d_cview, vin, ldv, view_ch, R, cam_idx,
-                       n_codes, g_views_w, csum);
+                       n_codes, g_views_w, csum, vg_part);
     DANBO_LAUNCH_RET();
 }
 
 extern "C" int danbo_train_head_chain(const float* g_wfv, const float* g_beff, const float* csum, const float* feature_w,
                                       const float* feature_b, const float* views_w, int view_ch, int n_codes, int code_size, int code_col0,
-                                      float* g_feature_w, float* g_feature_b, float* g_views_w, float* g_views_b, float* g_codes, void* stream) {
+                                      float* g_feature_w, float* g_feature_b, float* g_views_w, float* g_views_b, float* g_codes,
+                                      const float* vg_part, void* stream) {
     DANBO_CHECK_ARG(g_wfv && g_beff && feature_w && feature_b && views_w && g_feature_w && g_feature_b && g_views_w && g_views_b);
     DANBO_CHECK_ARG(view_ch >= 0 && (n_codes == 0 || (csum && g_codes && code_size > 0 && code_col0 >= 0 && code_col0 + code_size <= view_ch)));
     HeadChainArgs a{g_wfv, g_beff, csum, feature_w, feature_b, views_w, view_ch, n_codes, code_size, code_col0,
-                    g_feature_w, g_feature_b, g_views_w, g_views_b, g_codes};
+                    g_feature_w, g_feature_b, g_views_w, g_views_b, g_codes, vg_part};
     hipLaunchKernelGGL(k_train_head_chain, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

@@ -488,11 +488,15 @@ int danbo_train_cview(const float* vin /*[R,ldv]*/, int ldv, int view_ch, const 
 /* d cview[ray] = sum over the ray's rows of d pre_v (fragment order); g_views_w[:, 256:] += d cview^T vin; csum[cam] = sum over
  * the camera's rays of d cview.  d_cview and csum must be zero on entry. */
 int danbo_train_view_grads(const float* dpre_v, const int32_t* row_ray, const int32_t* cnt, int rows_cap, int R, const float* vin, int ldv,
-                           int view_ch, const int64_t* cam_idx, int n_codes, float* d_cview, float* csum, float* g_views_w, void* stream);
+                           int view_ch, const int64_t* cam_idx, int n_codes, float* d_cview, float* csum, float* g_views_w,
+                           float* vg_part, void* stream);
+/* vg_part (ABI 3): DANBO_TRAIN_VG_PART_FLOATS floats or NULL.  With it the per-ray-slice partial sums of d W_v[:, 256:] are
+ * stored there and danbo_train_head_chain adds them to g_views_w in a fixed order; without it they are accumulated with atomics. */
+#define DANBO_TRAIN_VG_PART_FLOATS (16 * 128 * 160)
 /* gradients of feature_linear, views_linears.0[:, :256] / bias and the frame codes from d W_fv, d b_eff (k_dw16) and csum */
 int danbo_train_head_chain(const float* g_wfv, const float* g_beff, const float* csum, const float* feature_w, const float* feature_b,
                            const float* views_w, int view_ch, int n_codes, int code_size, int code_col0, float* g_feature_w,
-                           float* g_feature_b, float* g_views_w, float* g_views_b, float* g_codes, void* stream);
+                           float* g_feature_b, float* g_views_w, float* g_views_b, float* g_codes, const float* vg_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One training batch behind one call: forward, losses, backward (csrc/k_train.hip) -- what Trainer.train_batch
