@@ -90,8 +90,9 @@ __global__ __launch_bounds__(128) void k_train_ray_grad(const float* __restrict_
 // g_views_w[f, 256 + k] += sum_r d cview[r, f] vin[r, k]   (blockIdx.x < k-groups of 8 columns, blockIdx.y = ray slice)
 // csum[cam(r), f]      += d cview[r, f]                      (the last blockIdx.x; running sum per camera)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int VG_K = 8, VG_SLICES = 16, VG_U = 8;      // VG_U rays in flight per iteration
+constexpr int VG_K = 8, VG_SLICES = 32, VG_U = 8;      // VG_U rays in flight per iteration
 constexpr int VG_PART_LD = 160;                         // row stride of the per-slice partial sums [VG_SLICES][128][VG_PART_LD]
+static_assert(DANBO_TRAIN_VG_PART_FLOATS == VG_SLICES * 128 * VG_PART_LD, "include/danbo_hip.h");
 __global__ __launch_bounds__(128) void k_train_view_grad(const float* __restrict__ d_cview, const float* __restrict__ vin, int ldv, int Cv,
                                                          int R, const int64_t* __restrict__ cam_idx, int n_codes, float* __restrict__ g_views_w,
                                                          float* __restrict__ csum, float* __restrict__ part) {

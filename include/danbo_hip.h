@@ -492,7 +492,7 @@ int danbo_train_view_grads(const float* dpre_v, const int32_t* row_ray, const in
                            float* vg_part, void* stream);
 /* vg_part (ABI 3): DANBO_TRAIN_VG_PART_FLOATS floats or NULL.  With it the per-ray-slice partial sums of d W_v[:, 256:] are
  * stored there and danbo_train_head_chain adds them to g_views_w in a fixed order; without it they are accumulated with atomics. */
-#define DANBO_TRAIN_VG_PART_FLOATS (16 * 128 * 160)
+#define DANBO_TRAIN_VG_PART_FLOATS (32 * 128 * 160)
 /* gradients of feature_linear, views_linears.0[:, :256] / bias and the frame codes from d W_fv, d b_eff (k_dw16) and csum */
 int danbo_train_head_chain(const float* g_wfv, const float* g_beff, const float* csum, const float* feature_w, const float* feature_b,
                            const float* views_w, int view_ch, int n_codes, int code_size, int code_col0, float* g_feature_w,
