@@ -450,3 +450,41 @@ def test_assignment_visualisations_match_the_reference():
     c = torch.tensor(g["confd"])
     assert np.array_equal(get_confidence_rgb(c).numpy(), g["confidence_rgb"])
     assert max_err(get_entropy_rgb(c).numpy(), g["entropy_rgb"]) < 1e-6
+
+
+def test_custom_operators_register_and_propagate_shapes_without_a_gpu():
+    """core/custom_ops.py: every torch.ops.danbo.* operator is registered with a schema and a fake kernel (shape propagation on the
+    meta device works without the HIP library being called), and refuses CPU tensors instead of falling back to anything."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "danbo-pytorch_amd"))
+    from core import custom_ops  # noqa: F401
+    M = lambda *s, dt=torch.float32: torch.empty(*s, device="meta", dtype=dt)  # noqa: E731
+    R, S, G, n = 6, 5, 2, 11
+    # composite
+    out = torch.ops.danbo.composite(M(R, S, 4), M(R, S), M(R, 3), 1.0, None)
+    assert [tuple(o.shape) for o in out] == [(R, 3), (R,), (R,), (R, S), (R, S)]
+    # bone gather
+    pf = torch.ops.danbo.bone_gather(M(G, 24, 240), M(24, 3), M(R, S, 3), M(G, 24, 4, 4), M(24, 4, 4), M(n, dt=torch.int32))
+    assert tuple(pf.shape) == (n, 24, 15)
+    # assign + blend
+    ap = [M(24, 15, 32), M(1, 24, 24), M(1, 24, 24), M(32), M(24, 32, 32), M(24, 1, 32), M(24, 32, 1), M(24, 1, 1)]
+    h, p, confd = torch.ops.danbo.assign_blend(M(G, 24, 240), M(24, 3), M(R, S, 3), M(G, 24, 4, 4), M(24, 4, 4), M(n, dt=torch.int32),
+                                               M(R * S, dt=torch.int32), ap)
+    assert tuple(h.shape) == (n, 16) and tuple(p.shape) == (n, 24) and tuple(confd.shape) == (n, 24)
+    # PE + MLP
+    mp = ([M(256, 195)] + [M(256, 256)] * 4 + [M(256, 451)] + [M(256, 256)] * 2 + [M(256)] * 8
+          + [M(1, 256), M(1), M(256, 256), M(256), M(128, 256 + 155), M(128), M(3, 128), M(3)])
+    raw = torch.ops.danbo.pe_mlp(M(n, 15), M(n, dt=torch.int32), M(R, 155), mp)
+    assert tuple(raw.shape) == (n, 4)
+    # A-NeRF chain (forward only)
+    anp = ([M(448, 432)] + [M(448, 448)] * 4 + [M(448, 880)] + [M(448, 448)] * 2 + [M(448)] * 8
+           + [M(1, 448), M(1), M(448, 448), M(448), M(224, 448 + 648 + 128), M(224), M(3, 224), M(3), M(24), M(24), M(20, 128)])
+    raw = torch.ops.danbo.anerf_cutoff_pe_mlp(M(R, S, 3), M(R, 3), M(G, 24, 4, 4), M(24, 4, 4), M(R, dt=torch.int64), anp, 20.0, 7, 4)
+    assert tuple(raw.shape) == (R, S, 4)
+    # no CPU fallback
+    with pytest.raises(RuntimeError):
+        torch.ops.danbo.pe_mlp(torch.zeros(n, 15), torch.zeros(n, dtype=torch.int32), torch.zeros(R, 155), [torch.zeros(1)] * 24)
+    with pytest.raises(RuntimeError):
+        torch.ops.danbo.assign_blend(torch.zeros(G, 24, 240), torch.zeros(24, 3), torch.zeros(R, S, 3), torch.zeros(G, 24, 4, 4), torch.zeros(24, 4, 4),
+                                     torch.zeros(n, dtype=torch.int32), torch.zeros(R * S, dtype=torch.int32), [torch.zeros(1)] * 8)
