@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
             }
             a16_split8(even, fh[2 * i], fl[2 * i]);
             a16_split8(odd, fh[2 * i + 1], fl[2 * i + 1]);
-            // one bone pair at a time: without this fence hipcc hoists every bone's loads and spills
-            __builtin_amdgcn_sched_barrier(0);
+            // two bone pairs at a time: without a fence hipcc hoists every bone's loads and spills
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // ---------------------------------------------------------------- assignment GNN + blend
         float hacc[8];
