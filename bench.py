@@ -96,7 +96,7 @@ def best_of(fn, reps=3):
     return best, out
 
 
-def cpu_baseline_render(extra, box_bounds, frame=None, budget_s=6.0):
+def cpu_baseline_render(extra, box_bounds, frame=None, stages=None, budget_s=6.0):
     """oracle/torch_cpu.py on centre rays of the same frame; the sample is grown until one repetition takes ~budget_s"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import danbo_oracle as o
@@ -112,7 +112,7 @@ def cpu_baseline_render(extra, box_bounds, frame=None, budget_s=6.0):
         z = np.zeros(n_rays, dtype=np.int64)
         rb = syn.ray_batch(ro[sl], rd[sl])
         return sl, model.render(rb, scene["skts"][z], scene["bones"][z], scene["cyls"][z], np.zeros(n_rays, np.int64), 1, N_SAMPLES,
-                                N_IMPORTANCE)
+                                N_IMPORTANCE, stages=stages is not None)
     n = 4096
     run(512)                                                    # thread pools, allocator
     # torch's default of one thread per hardware thread is far from the fastest setting for 4096-ray chunks on a 128-core
@@ -139,16 +139,36 @@ def cpu_baseline_render(extra, box_bounds, frame=None, budget_s=6.0):
         rgb, acc = frame["rgb_map"][sl].cpu().numpy(), frame["acc_map"][sl].cpu().numpy()
         parity = dict(against="oracle/torch_cpu.py on the cpu_baseline sample", rays=n, psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])),
                       max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()), max_abs_acc=float(np.abs(acc - ref["acc_map"]).max()))
-    return dict(value=n * (N_SAMPLES + N_IMPORTANCE) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()), kind="port",
+        if stages is not None:
+            # in-volume mask flips and the max relative error of the RGB / sigma logits of the coarse pass
+            # (identical depths on both sides), on the same rays
+            raw = stages["raw_coarse"][sl].cpu().numpy()
+            bits = stages["valid_bits"].view(H * W, N_SAMPLES)[sl].cpu().numpy().astype(np.uint32)
+            valid = ((bits[..., None] >> np.arange(24, dtype=np.uint32)) & 1).astype(bool)
+            rr = ref["raw_coarse"]
+            cmax = np.abs(rr).reshape(-1, 4).max(0)
+            big = np.abs(rr) > 0.1 * cmax                       # un-floored relative error where the logit is not near zero ...
+            rel = np.abs(raw - rr) / np.maximum(np.abs(rr), 1e-30)
+            floored = np.abs(raw - rr) / np.maximum(np.abs(rr), 0.05 * cmax)     # ... and tests/helpers.raw_err's measure everywhere
+            parity.update(mask_mismatches=int((valid != ref["valid_coarse"]).sum()), mask_entries=int(valid.size),
+                          max_rel_raw=float(rel[big].max()), max_rel_raw_rgb=float(rel[..., :3][big[..., :3]].max()),
+                          max_rel_raw_sigma=float(rel[..., 3][big[..., 3]].max()), max_rel_raw_floored_5pct=float(floored.max()),
+                          raw_note="coarse-pass logits; max_rel_raw = max |a - b| / |b| over entries with |b| > 0.1 x the channel's "
+                                   "largest |b| (no floor)")
+    return dict(value=n * (N_SAMPLES + N_IMPORTANCE) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()),
+                host_cpu_count=os.cpu_count(), kind="port",
                 sample=f"{n} centre rays x {N_SAMPLES}+{N_IMPORTANCE} samples of the same frame, every sample through every bone and "
                        f"the full MLP (the reference's executed work), oracle/torch_cpu.py (torch CPU kernels, "
                        f"{torch.get_num_threads()} threads), 4096-ray chunks, best of 3: {dt:.2f} s"), parity
 
 
 # ---------------------------------------------------------------------------------------------- timing harness
-def timed(fn, steps, warmup, dist, device, cpu_dist):
-    for _ in range(warmup):
-        fn()
+N_BLOCKS = 5               # timed blocks of --steps steps each; ms_per_step = their MEDIAN
+SETTLE_MIN_S, SETTLE_MAX_S, SETTLE_TOL = 0.5, 8.0, 0.02
+
+
+def _block(fn, steps, dist, device, cpu_dist):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> (seconds, MAX over the ranks; last output)"""
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -168,14 +188,50 @@ def timed(fn, steps, warmup, dist, device, cpu_dist):
     return elapsed, out
 
 
+def timed(fn, steps, warmup, dist, device, cpu_dist, settle_block=10, on_timed_start=None):
+    """The number must not depend on where in the process it is taken (the first tens of milliseconds after idle
+    run ~10 % slower -- clocks, caches, the allocator's pool -- and a 0.12 s timed region sat inside them):
+      1. settle: blocks of `settle_block` steps until >= SETTLE_MIN_S of work has run AND two consecutive blocks agree within
+         SETTLE_TOL (give up after SETTLE_MAX_S and say so); block times are max-over-ranks, so every rank takes the same
+         decisions and runs the same number of steps (the training step contains collectives);
+      2. the CLI's `warmup` untimed steps;
+      3. N_BLOCKS timed blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize, each the MAX over the ranks.
+    -> (median block seconds, last output, info for the JSON line)"""
+    spent, prev, settled, n_settle = 0.0, None, False, 0
+    while spent < SETTLE_MAX_S:
+        dt, _ = _block(fn, settle_block, dist, device, cpu_dist)
+        spent += dt
+        n_settle += 1
+        if prev is not None and spent >= SETTLE_MIN_S and abs(dt - prev) <= SETTLE_TOL * max(dt, prev):
+            settled = True
+            break
+        prev = dt
+    for _ in range(warmup):
+        fn()
+    if on_timed_start is not None:
+        on_timed_start()
+    blocks, out = [], None
+    for _ in range(N_BLOCKS):
+        dt, out = _block(fn, steps, dist, device, cpu_dist)
+        blocks.append(dt)
+    med = float(np.median(blocks))
+    info = dict(block_ms=[1e3 * b / steps for b in blocks], spread=(max(blocks) - min(blocks)) / med,
+                timing=f"median of {N_BLOCKS} blocks of --steps steps (each: barrier + synchronize on both sides, max over ranks) after "
+                       f"a settle phase of {n_settle} x {settle_block} steps = {spent:.2f} s "
+                       f"({'two consecutive blocks within 2 %' if settled else 'NOT settled within %.0f s' % SETTLE_MAX_S}) and "
+                       f"--warmup untimed steps")
+    return med, out, info
+
+
 # ---------------------------------------------------------------------------------------------- render configs 1-3
 def bench_render(args, rank, world, device, dist):
     eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
     eng.cfg["use_volume_near_far"] = bool(args.box_near_far)
-    for _ in range(args.warmup):
-        render(eng, inp)
-    eng.profile = {}
-    elapsed, out = timed(lambda: render(eng, inp), args.steps, 0, dist, device, args.debug_single_device)
+
+    def start_profile():                    # HIP events around K3 from the first timed block on (settle / warm-up frames carry none)
+        eng.profile = {}
+    elapsed, out, tinfo = timed(lambda: render(eng, inp), args.steps, args.warmup, dist, device, args.debug_single_device,
+                                on_timed_start=start_profile)
     samples_per_frame = H * W * (N_SAMPLES + N_IMPORTANCE)
     value = world * args.steps * samples_per_frame / elapsed
 
@@ -203,7 +259,7 @@ def bench_render(args, rank, world, device, dist):
                       chunk=4096, keep=True)
     rays_hit = int((keep["valid_bits"].view(H * W, N_SAMPLES) != 0).any(1).sum())
     algo_bytes = 84.0 * rows / len(prof) + 512.0 * rays_hit
-    del keep
+    keep = dict(raw_coarse=keep["raw_coarse"], valid_bits=keep["valid_bits"])         # for the parity block below
     roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak,
                     traffic=traffic, algorithmic_bytes=algo_bytes, launches=len(prof), avg_launch_ms=ms / len(prof),
                     rows_per_launch=rows / len(prof), flop_per_row=2 * mac, flop_per_row_reference=2 * MAC_PER_ROW_REF,
@@ -220,8 +276,8 @@ def bench_render(args, rank, world, device, dist):
                                f"samples, 1 pose / 1 camera per rank, {'per-bone box' if args.box_near_far else 'cylinder'} near/far, "
                                "exact in-volume culling",
                    "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
-        "in_volume_fraction": rows / (args.steps * samples_per_frame),
-        "roofline": roofline,
+        "in_volume_fraction": rows / (N_BLOCKS * args.steps * samples_per_frame),
+        "roofline": roofline, **tinfo,
     }
     if rank == 0 and world == 1:
         if not args.no_dense:
@@ -243,22 +299,18 @@ def bench_render(args, rank, world, device, dist):
             for dist_ in (2.0, 3.0, 4.5):
                 e2, i2, _ = build_workload(device, view=0, mlp_mode=args.mlp, cam_dist=dist_)
                 e2.cfg["use_volume_near_far"] = bool(args.box_near_far)
-                for _ in range(3):
-                    render(e2, i2)
-                e2.profile = {}
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    render(e2, i2)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 10
-                r2 = sum(int(c.item()) for _, _, c in e2.profile["k_pe_mlp"]) / 10
+
+                def start2(e=e2):
+                    e.profile = {}
+                dt, _, ti = timed(lambda: render(e2, i2), 10, 0, None, device, False, on_timed_start=start2)
+                dt /= 10
+                r2 = sum(int(c.item()) for _, _, c in e2.profile["k_pe_mlp"]) / (10 * N_BLOCKS)
                 sweep.append(dict(camera_distance=dist_, in_volume_fraction=r2 / samples_per_frame, value=samples_per_frame / dt,
-                                  ms_per_step=1e3 * dt))
+                                  ms_per_step=1e3 * dt, spread=ti["spread"]))
                 del e2, i2
             result["occupancy_sweep"] = sweep
         if not args.no_cpu_baseline:
-            result["cpu_baseline"], parity = cpu_baseline_render(extra, bool(args.box_near_far), frame=out)
+            result["cpu_baseline"], parity = cpu_baseline_render(extra, bool(args.box_near_far), frame=out, stages=keep)
             if parity is not None:
                 result["parity"] = parity
     return result
@@ -280,6 +332,7 @@ def bench_train(args, rank, world, device, dist):
     sd = syn.make_state_dict(syn.model_config("danbo_perfcap"), 3, 20, rest)
     caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
     trainer = Trainer(targs, da, opt, None, tr_kw, te_kw, device=device)
+    trainer.collectives_at_world_1 = bool(args.nccl_world_1)
     strong = args.scaling == "strong"
     poses, rpp = 16, 192
     if strong and (poses % world != 0):
@@ -315,7 +368,7 @@ def bench_train(args, rank, world, device, dist):
         out = trainer.train_batch(batch, i=step[0], global_step=step[0], sync_stats=False)
         step[0] += 1
         return out
-    elapsed, (loss, stats) = timed(one, args.steps, args.warmup, dist, device, args.debug_single_device)
+    elapsed, (loss, stats), tinfo = timed(one, args.steps, args.warmup, dist, device, args.debug_single_device, settle_block=50)
     S = targs.N_samples + targs.N_importance
     counts = trainer.last_preds["counts"].cpu().tolist()
     rows, in_vol = counts[4], counts[5]
@@ -363,6 +416,15 @@ def bench_train(args, rank, world, device, dist):
                          note="STEP-level lower bound, per GPU: executed dense-layer flops of the step (forward + input gradients + weight "
                               "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
                               "per-kernel durations: profiles/r03_train_kernel_stats.csv"),
+        **tinfo,
+        "collectives": ("none (one rank, no process group)" if dist is None and not args.nccl_world_1 else
+                        f"two in-place all-reduces of the flat gradient per step ({'gloo' if args.debug_single_device else 'nccl = RCCL'}, "
+                        f"world {world}{', forced at world 1: --nccl-world-1' if args.nccl_world_1 else ''}), the first on a side stream "
+                        "under the weight-gradient kernels; split step = two HIP graphs"),
+        "strong_scaling_bound": "the reference's ONE 3072-ray batch is small for eight MI355X: a 384-ray shard (8 ranks x 2 poses x 192) "
+                                "still takes 0.90 ms of the 1.53 ms the whole batch takes on one GPU (tile rounds of 128 rows x 256 "
+                                "CUs are the granule), so --scaling strong is bounded at ~1.7x on 8 GPUs before the collective; "
+                                "--scaling weak (3072 rays per rank, the default) is the scaling configuration",
     }
     if hbm is not None:
         result["hbm"] = hbm
@@ -384,7 +446,7 @@ def cpu_baseline_train(targs, caster, batch, poses, n_poses=2):
     step()
     dt, _ = best_of(step)
     S = targs.N_samples + targs.N_importance
-    return dict(value=R * S / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()), kind="port",
+    return dict(value=R * S / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()), host_cpu_count=os.cpu_count(), kind="port",
                 sample=f"{R} rays = {n_poses} poses x 192 of the same batch, forward + L1 losses + backward + Adam with torch autograd on "
                        f"CPU kernels ({torch.get_num_threads()} threads), every sample through every bone and the full MLP, best of 3: "
                        f"{dt:.2f} s per step")
@@ -405,7 +467,7 @@ def bench_anerf(args, rank, world, device, dist):
                cyls=T(scene["cyls"], device), cam_idx=torch.zeros(len(ro), dtype=torch.int64, device=device))
     S, Sf = 48, 16
     run = lambda: eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"], S, Sf)  # noqa: E731
-    elapsed, out = timed(run, args.steps, args.warmup, dist, device, args.debug_single_device)
+    elapsed, out, tinfo = timed(run, args.steps, args.warmup, dist, device, args.debug_single_device, settle_block=2)
     n = len(ro) * (S + Sf)
     Wd, inc, VW = cfg["W"], 432, cfg["view_W"]
     mac = inc * Wd + 4 * Wd * Wd + (inc + Wd) * Wd + 2 * Wd * Wd + Wd + Wd * VW + 24 * VW + 3 * VW
@@ -438,6 +500,7 @@ def bench_anerf(args, rank, world, device, dist):
                          frac=achieved / peak, traffic=traffic, flop_per_row=2 * mac, flop_per_row_reference=2 * 2268000, peak_note=SPLIT_NOTE,
                          note="FRAME-level lower bound: executed flops per sample x samples / whole frame time; traffic = HBM bytes of "
                               "the whole frame (tools/pmc_anerf.sh), see `hbm`"),
+        **tinfo,
     }
     if hbm is not None:
         result["hbm"] = hbm
@@ -469,7 +532,8 @@ def bench_anerf(args, rank, world, device, dist):
         n_rays = 4096
         dt, (r0, ref) = best_of(lambda: run(n_rays))
         rgb = out["rgb_map"][r0:r0 + n_rays].cpu().numpy()
-        result["cpu_baseline"] = dict(value=n_rays * (S + Sf) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()), kind="port",
+        result["cpu_baseline"] = dict(value=n_rays * (S + Sf) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()),
+                                      host_cpu_count=os.cpu_count(), kind="port",
                                       sample=f"{n_rays} centre rays x {S}+{Sf} samples of the same frame through oracle/torch_cpu.AnerfTorchCPU "
                                              f"(torch CPU kernels, {torch.get_num_threads()} threads), 4096-ray chunks, best of 3: {dt:.2f} s")
         result["parity"] = dict(against="oracle/torch_cpu.AnerfTorchCPU on the cpu_baseline sample", rays=n_rays,
@@ -545,6 +609,9 @@ def main():
     ap.add_argument("--box-near-far", action="store_true", help="dev: per-bone box near/far (config 2 sets it)")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="dev: every rank uses cuda:0 and the gloo backend (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--nccl-world-1", action="store_true",
+                    help="config 4 with --gpus 1: create a ONE-rank nccl (= RCCL) process group and run the data-parallel form of the "
+                         "step (split phases, both in-place all-reduces, comm side stream) -- everything of the N > 1 path but the wire")
     ap.add_argument("--dry-run", action="store_true",
                     help="dev: launch / rendezvous / timing harness only, a host no-op as the step (gloo, no GPU needed); not a measurement")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",
@@ -585,6 +652,15 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+    elif args.nccl_world_1:
+        if args.config != 4:
+            raise SystemExit("--nccl-world-1 is defined for --config 4 (the only path with a collective)")
+        import socket
+        import torch.distributed as dist1
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     ranks_seen = dist.get_world_size() if dist is not None else 1
 
     fn = bench_dry_run if args.dry_run else {4: bench_train, 5: bench_anerf}.get(args.config, bench_render)
@@ -594,6 +670,8 @@ def main():
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    elif args.nccl_world_1:
+        dist1.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -79,6 +79,7 @@ SIGNATURES = {
     "danbo_train_workspace": [P, I, I, I, I, I],
     "danbo_train_step": [P, P, P, P, c_size_t, P],
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
+    "danbo_train_workspace_view": [P, I, I, I, I, I, P, P],
 }
 # everything else returns int (0 = ok)
 RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t,
@@ -163,6 +164,10 @@ class DanboTrainBatch(ctypes.Structure):
 class DanboTrainOut(ctypes.Structure):
     _fields_ = [(n, P) for n in ("rgb_map", "disp_map", "acc_map", "alpha", "weights", "rgb0", "disp0", "acc0", "alpha0", "loss",
                                  "counts")]
+
+
+class DanboTrainView(ctypes.Structure):
+    _fields_ = [(n, P) for n in ("z_coarse", "z_fine", "z_sorted", "order", "bits_coarse", "bits_fine")]
 
 
 _lib = None

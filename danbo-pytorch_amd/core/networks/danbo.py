@@ -106,10 +106,31 @@ class DANBO(NeRF):
         rays_d = inputs['rays_d'].reshape(R, 3)
         rays_o = inputs['rays_o'].reshape(R, 3) if inputs.get('rays_o') is not None else rays_d
         raw, ex = eng.forward_samples(rays_o, rays_d, skts_g, bones_g, inputs.get('cam_idxs'), pts=pts)
-        return raw, self.collect_encoded(ex, None)
+        return raw, self.collect_encoded(dict(ex, eng=eng, pts=pts, rays_d=rays_d, skts=skts_g), None)
 
     def collect_encoded(self, encoded_pts, encoded_views):
-        return {}
+        """`encoded` of the reference's DANBO.forward (core/networks/danbo.py:341-346): confd [R,S,24] = the assignment logits of
+        EVERY sample and bone, part_invalid [R,S,24] = 1 outside the bone's volume -- in eval mode too.  The reference's caster
+        reads them in training only (raycasters.py:710-716), so they are formed on first access: the render path (which culls
+        and never evaluates the assignment net outside the volumes) pays nothing for them."""
+        from .. import hip_ops as ops
+        from ..utils.lazy import LazyDict
+        ex = encoded_pts
+
+        def fill():
+            eng, pts = ex['eng'], ex['pts']
+            R, S = pts.shape[:2]
+            geo = ops.Geometry(ex['rays_d'], ex['rays_d'], ex['skts'], eng.align, eng.axis_scale, pts=pts.contiguous().float())
+            bits = ex['valid_bits']
+            # dense: all R x S rows, all 24 bones (the culled pass evaluates only bones some sample of the wavefront is inside)
+            if eng.mlp_mode == "f16split":
+                _, confd = ops.gather_assign_blend16(geo, ex['volumes'], bits, eng.aw, eng.assign16, want_confd=True)
+            else:
+                _, confd = ops.gather_assign_blend(geo, ex['volumes'], bits, eng.aw, want_confd=True)
+            shifts = torch.arange(24, device=bits.device, dtype=torch.int32)
+            valid = ((bits.reshape(R, S, 1) >> shifts) & 1).float()
+            return dict(confd=confd.reshape(R, S, 24), part_invalid=1.0 - valid)
+        return LazyDict(fill)
 
     # ---- helpers the trainer calls on the module (reference danbo.py:382-415) ----
     def get_adjw(self):

@@ -57,6 +57,34 @@ def supported(args, caster):
     return None
 
 
+def adopt_adam_state(opt, params, offsets, flat_m, flat_v):
+    """torch.optim.Adam's per-parameter state (what the checkpoint stores) becomes views of flat_m / flat_v; a state that was
+    loaded from a checkpoint is copied in first.  -> the list of `step` tensors.
+
+    `step`: ONE DISTINCT CPU tensor per parameter, as torch.optim.Adam keeps them.  (Round 3 let every entry reference one shared
+    tensor; the sharing survives state_dict() / torch.save / load_state_dict, and a plain Adam that resumes from such a checkpoint
+    -- the reference's loader, or this repo's autograd path -- then adds 1 per PARAMETER per step: bias corrections and the lr
+    decay that reads state['step'] run ~43x too fast.)  The engine advances them together with one torch._foreach_add_."""
+    count = None
+    for p in params:
+        st = opt.state.get(p)
+        if st and 'step' in st:         # every parameter of the group has made the same number of steps
+            count = float(st['step'])
+            break
+    steps = []
+    for p, o in zip(params, offsets):
+        k = p.numel()
+        m, v = flat_m[o:o + k].view(p.shape), flat_v[o:o + k].view(p.shape)
+        st = opt.state.get(p)
+        if st and st['exp_avg'].data_ptr() != m.data_ptr():
+            m.copy_(st['exp_avg'])
+            v.copy_(st['exp_avg_sq'])
+        step = torch.tensor(0. if count is None else count)
+        opt.state[p] = dict(step=step, exp_avg=m, exp_avg_sq=v)
+        steps.append(step)
+    return steps
+
+
 class DanboTrainEngine:
     def __init__(self, args, caster, optimizer):
         self.args, self.caster, self.opt = args, caster, optimizer
@@ -112,26 +140,9 @@ class DanboTrainEngine:
         return 0
 
     def _adopt_optimizer_state(self):
-        """torch.optim.Adam's per-parameter state (what the checkpoint stores) becomes views of flat_m / flat_v; a state that
-        was loaded from a checkpoint is copied in first."""
         self._param_list = list(self.params.values())
-        shared = getattr(self, '_step_tensor', None)
-        for n in self.trainable:
-            p = self.params[n]
-            o, k = self.offsets[n], p.numel()
-            m, v = self.flat_m[o:o + k].view(p.shape), self.flat_v[o:o + k].view(p.shape)
-            st = self.opt.state.get(p)
-            if st:
-                if st['exp_avg'].data_ptr() == m.data_ptr():
-                    continue
-                m.copy_(st['exp_avg'])
-                v.copy_(st['exp_avg_sq'])
-                if shared is None:      # every parameter of the group has made the same number of steps
-                    shared = st['step'].detach().clone().cpu().float() if torch.is_tensor(st['step']) else torch.tensor(float(st['step']))
-            if shared is None:
-                shared = torch.tensor(0.)
-            self.opt.state[p] = dict(step=shared, exp_avg=m, exp_avg_sq=v)
-        self._step_tensor = shared if shared is not None else torch.tensor(0.)
+        self._step_tensors = adopt_adam_state(self.opt, [self.params[n] for n in self.trainable],
+                                              [self.offsets[n] for n in self.trainable], self.flat_m, self.flat_v)
 
     # ------------------------------------------------------------------ model description for the C side
     def _model(self):
@@ -192,7 +203,14 @@ class DanboTrainEngine:
                 if v is not None:
                     if tuple(v.shape) != shp:
                         raise ValueError(f"fixed_draws[{k!r}]: shape {tuple(v.shape)}, expected {shp}")
-                    rnd[k] = v.to(dev).float().contiguous()
+                    if v.device != dev:
+                        raise ValueError(f"fixed_draws[{k!r}] lives on {v.device}: move the draws to {dev} before the step (a copy "
+                                         "inside a graph capture would be recorded into the graph)")
+                    rnd[k] = v.float().contiguous()
+            if perturb > 0. and ('t_rand' not in rnd or 'u_rand' not in rnd):
+                raise ValueError("fixed_draws without t_rand / u_rand while perturb > 0: the step would run unperturbed")
+            if raw_noise_std > 0. and ('noise_c' not in rnd or 'noise_f' not in rnd):
+                raise ValueError("fixed_draws without noise_c / noise_f while raw_noise_std > 0: the step would run without noise")
         elif perturb > 0.:
             u = torch.rand(R * (S + Sf), device=dev)
             rnd['_u'] = u
@@ -244,7 +262,7 @@ class DanboTrainEngine:
                                 near_in, far_in)
         if t.get('bgs') is not None and t['bgs'].numel() != t['target'].numel():
             t['bgs'] = t['bgs'].expand_as(t['target']).contiguous()
-        if not self.use_graph:
+        if not self.use_graph or self.fixed_draws is not None:   # supplied draws are per-step inputs: never captured into a graph
             out = self._launch(t, S, Sf, perturb, raw_noise_std, split)
             self._pending = (out, None) if split else None
             return out
@@ -325,8 +343,8 @@ class DanboTrainEngine:
                                               float(lr), 1.0 - b1 ** self.t, math.sqrt(1.0 - b2 ** self.t), float(grad_scale),
                                               float(b1), float(b2), float(grp['eps']),
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_adam_step")
-        # torch.optim.Adam's per-parameter `step` entries all reference ONE CPU tensor (_adopt_optimizer_state): one in-place add
-        self._step_tensor += 1
+        # torch.optim.Adam's per-parameter `step` entries (distinct CPU tensors, _adopt_optimizer_state): one fused in-place add
+        torch._foreach_add_(self._step_tensors, 1.0)
         # the kernel wrote the parameters behind torch's back: bump their version counters, which the eval engine's packed weight
         # buffers (and their HIP graphs) are keyed on.  ONE call with the list: handed a single tensor, this torch iterates over
         # it (Tensor.__iter__ -> unbind) -- 43 parameters x unbind was 1.8 ms of host time per step, more than the step's GPU time.

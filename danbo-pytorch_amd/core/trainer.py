@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import train_path
+from .utils.lazy import LazyDict
 
 
 def batchify_rays(rays_flat, chunk=1024 * 64, ray_caster=None, **kwargs):
@@ -80,58 +81,21 @@ def allreduce_gradients(params, world=None):
     return flat.numel()
 
 
-class LazyLossDict(dict):
+class LazyLossDict(LazyDict):
     """The loss terms of a fused step as device tensors, formed on first access: the step leaves them in one [4] tensor (rgb,
     coarse rgb, sum (label - q)^2, volume scale); a loop that does not look at them (every iteration that does not print)
     launches nothing for them."""
 
     def __init__(self, ls, ss_coef, with_ss, with_vol):
-        super().__init__()
-        self._src = (ls, ss_coef, with_ss, with_vol)
-
-    def _fill(self):
-        if self._src is not None:
-            ls, ss_coef, with_ss, with_vol = self._src
-            self._src = None
+        def fill():
             terms = {'rgb_loss': ls[0], 'rgb_loss0': ls[1]}
             if with_ss:
                 terms['soft_softmax_loss'] = ls[2] * ss_coef
             if with_vol:
                 terms['vol_scale_loss'] = ls[3]
             terms['total_loss'] = sum(terms.values())
-            dict.update(self, terms)
-
-    def __getitem__(self, k):
-        self._fill()
-        return dict.__getitem__(self, k)
-
-    def __iter__(self):
-        self._fill()
-        return dict.__iter__(self)
-
-    def __len__(self):
-        self._fill()
-        return dict.__len__(self)
-
-    def __contains__(self, k):
-        self._fill()
-        return dict.__contains__(self, k)
-
-    def keys(self):
-        self._fill()
-        return dict.keys(self)
-
-    def values(self):
-        self._fill()
-        return dict.values(self)
-
-    def items(self):
-        self._fill()
-        return dict.items(self)
-
-    def get(self, k, default=None):
-        self._fill()
-        return dict.get(self, k, default)
+            return terms
+        super().__init__(fill)
 
 
 class Trainer:
@@ -141,6 +105,9 @@ class Trainer:
         self.render_kwargs_train, self.render_kwargs_test = render_kwargs_train, render_kwargs_test
         self.hwf, self.data_attrs = data_attrs.get('hwf'), data_attrs
         self.engine, self.fused_reason, self._comm_stream = None, None, None
+        # run the data-parallel form of the step (split phases, both in-place all-reduces, the comm side stream) whenever a
+        # process group exists, also at world size 1: how the RCCL branch is exercised on a one-GPU box
+        self.collectives_at_world_1 = False
 
     def fused_engine(self):
         """the HIP training engine for this caster / optimizer, or None with `self.fused_reason` saying why not"""
@@ -162,11 +129,13 @@ class Trainer:
         G = int(batch['N_uniques'])
         pp = caster._per_pose
         S, Sf = int(kw['N_samples']), int(kw['N_importance'])
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        grouped = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if grouped else 1
+        parallel = world > 1 or (grouped and self.collectives_at_world_1)
         out = eng.forward_backward(batch['rays_o'], batch['rays_d'], pp(batch['skts'], G), pp(batch['bones'], G), pp(batch['cyls'], G),
                                    batch.get('cam_idxs'), batch['target_s'], batch.get('bgs'), S, Sf,
-                                   perturb=float(kw['perturb']), raw_noise_std=float(kw['raw_noise_std']), split=world > 1)
-        if world > 1:
+                                   perturb=float(kw['perturb']), raw_noise_std=float(kw['raw_noise_std']), split=parallel)
+        if parallel:
             # Two in-place all-reduces on the flat gradient (no packing, no copies).  The first -- pose GNN, assignment net, axis
             # scales: 7 of the 10 MB, final once the pose-GNN adjoint has run -- is launched on a side stream and overlaps the
             # weight-gradient GEMMs of the dense layers (0.4 ms), whose 2.5 MB follow as the second ("overlapped
@@ -186,7 +155,8 @@ class Trainer:
         lr, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, self.optimizer, global_step, args.decay_unit)
         caster.update_embed_fns(global_step, args)
         R = out['rgb_map'].shape[0]
-        loss = LazyLossDict(out['loss'], args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale))
+        # a snapshot (one tiny launch): out['loss'] is the HIP graph's static output, overwritten by the next replay
+        loss = LazyLossDict(out['loss'].clone(), args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale))
         stats = dict(lrate=lr)
         if sync_stats:      # one device-to-host copy; the loop asks for it only when it prints
             bgs = batch.get('bgs', 1.0)

@@ -22,6 +22,7 @@
 // order), and read once by the weight-gradient kernel; the input-gradient chain itself reads only sign bits.
 #include <limits.h>
 #include <stdlib.h>
+#include <mutex>
 #include "common.hpp"
 
 using namespace danbo;
@@ -282,12 +283,13 @@ struct SideStreams {
 };
 static SideStreams* side_streams() {
     static SideStreams per_dev[64];
-    static std::atomic<unsigned long long> made{0};
+    static bool made[64];
+    static std::mutex mu;          // two host threads stepping on the same device must not both create (or half-see) the set
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     SideStreams& ss = per_dev[dev & 63];
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(made.load(std::memory_order_acquire) & bit)) {
+    if (!made[dev & 63]) {
         // (a low-priority stream for the weight-gradient kernel, so that the K2 adjoint gets the compute units first, was measured:
         //  2.5 instead of 1.85 ms per step -- plain streams)
         ss.ok = hipStreamCreateWithFlags(&ss.s[0], hipStreamNonBlocking) == hipSuccess &&
@@ -297,10 +299,25 @@ static SideStreams* side_streams() {
                 hipEventCreateWithFlags(&ss.join[1], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&ss.mid, hipEventDisableTiming) == hipSuccess;
         if (!ss.ok) (void)hipGetLastError();
-        made.fetch_or(bit, std::memory_order_release);
+        made[dev & 63] = true;
     }
     return ss.ok ? &ss : nullptr;
 }
+
+// Every exit path of the step -- the error returns included -- leaves the side streams joined: work forked onto them and never
+// joined would race with the caller's next step on the shared workspace (eager mode) or leave a capture unjoined.
+struct ForkGuard {
+    SideStreams* ss = nullptr;
+    hipStream_t st = nullptr;
+    bool pending[2] = {false, false};
+    int join(int i) {
+        if (!ss || !pending[i]) return 0;
+        pending[i] = false;
+        if (hipEventRecord(ss->join[i], ss->s[i]) != hipSuccess || hipStreamWaitEvent(st, ss->join[i], 0) != hipSuccess) return (int)hipGetLastError();
+        return 0;
+    }
+    ~ForkGuard() { (void)join(0); (void)join(1); }
+};
 
 }  // namespace
 
@@ -315,6 +332,15 @@ extern "C" size_t danbo_train_workspace(const DanboTrainModel* m, int R, int G, 
     Carver c2{nullptr, 0};
     carve(c2, s, m, dw);
     return c2.used + 512;
+}
+
+extern "C" int danbo_train_workspace_view(const DanboTrainModel* m, int R, int G, int S, int Sf, int chunk, void* workspace, DanboTrainView* v) {
+    DANBO_CHECK_ARG(model_ok(m) && workspace && v && R >= 1 && G >= 1 && S >= 3 && Sf >= 1 && chunk >= 1);
+    Shapes sh{R, G, S, Sf, chunk, m->graph_width, m->n_codes, (long)R * (S + Sf + 1)};
+    Carver c{reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255), 0};
+    const TrainBuffers b = carve(c, sh, m, 0);      // (the weight-gradient scratch lies behind everything named here)
+    v->z_coarse = b.z_c; v->z_fine = b.z_f; v->z_sorted = b.z_sorted; v->order = b.order; v->bits_coarse = b.bits_c; v->bits_fine = b.bits_f;
+    return 0;
 }
 
 // phase 0: the whole step; 1: everything up to and including the pose-GNN adjoint -- from then on every gradient except the
@@ -369,18 +395,19 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     void* s1 = stream;
     SideStreams* const ss_all = ss;
     if (!(fork_mask & 1)) ss = nullptr;
+    ForkGuard guard;
+    guard.ss = ss_all;
+    guard.st = st;
     if (ss) {
         if (hipEventRecord(ss->fork, st) != hipSuccess) return (int)hipGetLastError();
-        if (hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess)
-            return (int)hipGetLastError();
+        if (hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+        guard.pending[0] = true;
+        if (hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+        guard.pending[1] = true;
         s0 = ss->s[0];
         s1 = ss->s[1];
     }
-    auto join = [&](int i) -> int {
-        if (!ss) return 0;
-        if (hipEventRecord(ss->join[i], ss->s[i]) != hipSuccess || hipStreamWaitEvent(st, ss->join[i], 0) != hipSuccess) return (int)hipGetLastError();
-        return 0;
-    };
+    auto join = [&](int i) -> int { return guard.join(i); };
     const float* axis_scale = m->p[DANBO_T_AXIS_SCALE];
     // Enqueue order = the order the captured graph submits its nodes in: the caller's stream first (it carries the critical
     // path: bounds -> depths -> cull -> assignment net), then side 1 (needed by the assignment net), then side 0 (needed by the trunk).
@@ -471,7 +498,11 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     if (ss) { s0 = ss->s[0]; s1 = ss->s[1]; } else { s0 = stream; s1 = stream; }
     if (ss) {
         if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
-        if (phase == 0 && hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+        guard.pending[0] = true;
+        if (phase == 0) {
+            if (hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+            guard.pending[1] = true;
+        }
     }
     DANBO_TRY(danbo_train_view_grads(b.dpre_v, b.row_ray, b.cnt, ncap, R, b.vin, LD_VIN, m->view_ch, bt->cam_idx, m->n_codes, b.d_cview, b.csum,
                                      m->g[DANBO_T_VIEWS_W], b.vg_part, s0));
@@ -513,8 +544,12 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                      m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
                                      m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, stream));
     DANBO_STAGE(12);
-    if (phase == 0 && ss) DANBO_TRY(join(1));      // (side 1 has waited for side 0)
-    else DANBO_TRY(join(0));
+    if (phase == 0 && ss) {                        // (side 1 has waited for side 0: joining it joins both)
+        DANBO_TRY(join(1));
+        guard.pending[0] = false;
+    } else {
+        DANBO_TRY(join(0));
+    }
     fused_tail = phase == 0 && ss != nullptr;
     }   // phase != 2
     if (phase == 1) { DANBO_LAUNCH_RET(); }

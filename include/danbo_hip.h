@@ -556,6 +556,17 @@ int danbo_train_step(const DanboTrainModel* model, const DanboTrainBatch* batch,
 int danbo_train_step_phase(const DanboTrainModel* model, const DanboTrainBatch* batch, const DanboTrainOut* out, void* workspace,
                            size_t workspace_bytes, int phase, void* stream);
 
+/* Where a finished step left its sampling decisions inside `workspace` (device pointers, valid until the next step on it): the
+ * depths and merge order RayCaster.render_rays forms and does not return (core/raycasters.py:310-311,346-361: z_vals,
+ * z_samples, sorted_idxs) and the in-volume words of both passes.  Host-only (no launch); for callers that want to re-evaluate
+ * the same samples elsewhere (the parity tests hand them to a float64 reference).  0 on success. */
+typedef struct DanboTrainView {
+    const float *z_coarse /*[R,S]*/, *z_fine /*[R,Sf]*/, *z_sorted /*[R,S+Sf]*/;
+    const int32_t* order /*[R,S+Sf]: index into [coarse | fine]*/;
+    const uint32_t *bits_coarse /*[R,S]*/, *bits_fine /*[R,Sf]*/;
+} DanboTrainView;
+int danbo_train_workspace_view(const DanboTrainModel* model, int R, int G, int S, int Sf, int chunk, void* workspace, DanboTrainView* view);
+
 /* ---------------------------------------------------------------------------------------------
  * The whole eval chain of one ray batch behind one call: RayCaster.render_rays (core/raycasters.py:245-377) with the DANBO
  * network (core/networks/danbo.py) -- what a C host binds instead of the reference's caster(ray_batch, ...) call.

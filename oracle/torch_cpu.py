@@ -122,9 +122,10 @@ class DanboTorchCPU:
         return dict(rgb_map=(w[..., None] * rgb).sum(-2), acc_map=torch.minimum(acc, torch.ones(())), weights=w, alpha=alpha)
 
     @torch.no_grad()
-    def render(self, ray_batch, skts, bones, cyls, cam_idxs, n_uniques, S, Sf, chunk=4096):
-        """-> dict(rgb_map, acc_map) as numpy; per-ray skts / bones / cyls like the reference's caster call"""
-        outs = []
+    def render(self, ray_batch, skts, bones, cyls, cam_idxs, n_uniques, S, Sf, chunk=4096, stages=False):
+        """-> dict(rgb_map, acc_map) as numpy; per-ray skts / bones / cyls like the reference's caster call.
+        stages: also the coarse pass' raw [R,S,4] and in-volume mask [R,S,24] (bench.py's parity block)"""
+        outs, st = [], []
         R_all = ray_batch.shape[0]
         for a in range(0, R_all, chunk):
             sl = slice(a, min(a + chunk, R_all))
@@ -140,7 +141,10 @@ class DanboTorchCPU:
             ro, rd, sk = t(rb[:, 0:3]), t(rb[:, 3:6]), t(skts[sl])
             cam = None if cam_idxs is None else cam_idxs[sl]
             zt = t(z)
-            raw = self.forward(ro[:, None] + rd[:, None] * zt[..., None], rd, sk, vols, pose_of_ray, cam)
+            raw = self.forward(ro[:, None] + rd[:, None] * zt[..., None], rd, sk, vols, pose_of_ray, cam, return_enc=stages)
+            if stages:
+                raw, _, valid = raw
+                st.append((raw.numpy(), valid.numpy()))
             out0 = self._composite(raw, zt, rd, self.cfg['density_scale'])
             z_all, z_fine, order = o.importance_z(z, out0['weights'].numpy(), Sf)
             zf = t(z_fine)
@@ -148,8 +152,11 @@ class DanboTorchCPU:
             raw_all = torch.gather(torch.cat([raw, raw_f], 1), 1, torch.as_tensor(order)[..., None].expand(-1, -1, 4).long())
             out = self._composite(raw_all, t(z_all), rd, self.cfg['density_scale'])
             outs.append((out['rgb_map'].numpy(), out['acc_map'].numpy(), out0['rgb_map'].numpy()))
-        return dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
-                    rgb0=np.concatenate([x[2] for x in outs]))
+        ret = dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
+                   rgb0=np.concatenate([x[2] for x in outs]))
+        if stages:
+            ret.update(raw_coarse=np.concatenate([x[0] for x in st]), valid_coarse=np.concatenate([x[1] for x in st]))
+        return ret
 
 
 class AnerfTorchCPU:

@@ -51,7 +51,11 @@ def raw_err(a, b):
         a, b = a.reshape(-1, 1), b.reshape(-1, 1)
     floor = RAW_FLOOR_FRACTION * np.abs(b).reshape(-1, b.shape[-1]).max(0)
     e = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), np.maximum(floor, 1e-12))))
-    print(f"raw_err = {e:.3e} over {a.size} values (channel floors {np.round(floor, 4).tolist()})")
+    # next to it, with NO floor: the plain relative error of every entry above 10 % of its channel's range (<= e by construction)
+    big = np.abs(b) > 2 * np.maximum(floor, 1e-12)
+    u = float(np.max((np.abs(a - b) / np.maximum(np.abs(b), 1e-300))[big])) if big.any() else 0.0
+    print(f"raw_err = {e:.3e} over {a.size} values (channel floors {np.round(floor, 4).tolist()}); un-floored max rel on |b| > 0.1 x "
+          f"channel max = {u:.3e} ({int(big.sum())} values)")
     return e
 
 
@@ -62,4 +66,17 @@ def rel_err(a, b, floor=1e-3):
     b = np.asarray(b, dtype=np.float64)
     e = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
     print(f"rel_err(floor={floor:g}) = {e:.3e} over {a.size} values")
+    return e
+
+
+def raw_rel_unfloored(a, b, frac=0.1):
+    """max |a - b| / |b| over the entries with |b| > frac x the largest |b| of their channel: the plain relative error where a
+    logit is not near its zero crossing, NO floor (reported next to raw_err's floored measure).  Prints it."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.ndim < 2:
+        a, b = a.reshape(-1, 1), b.reshape(-1, 1)
+    big = np.abs(b) > frac * np.abs(b).reshape(-1, b.shape[-1]).max(0)
+    e = float(np.max((np.abs(a - b) / np.maximum(np.abs(b), 1e-300))[big])) if big.any() else 0.0
+    print(f"raw_rel_unfloored(|b| > {frac:g} x channel max) = {e:.3e} over {int(big.sum())} of {a.size} values")
     return e

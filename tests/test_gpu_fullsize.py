@@ -1,5 +1,6 @@
-"""Size-independent properties at the FULL bench size (512 x 512 rays x (48 + 16) samples, BASELINE.json's
-metric configuration): the oracle cannot run there in seconds, these invariants can."""
+"""Size-independent properties at the FULL sizes of BASELINE.json's render configurations -- 512 x 512 rays x (48 + 16) samples (the
+metric's), config 3's 96 + 32 = 128 samples per ray (the general > 64-sample kernels) and config 2's 32 + 16 with per-bone box
+near/far: the oracle cannot run there in seconds, these invariants can."""
 import os
 import sys
 
@@ -13,24 +14,37 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def frame():
+class Frame(tuple):
+    """(eng, inp, args, out) + the sample counts of the configuration"""
+    S = Sf = 0
+
+
+@pytest.fixture(scope="module", params=[(48, 16, False), (96, 32, False), (32, 16, True)],
+                ids=["metric_48+16", "config3_96+32", "config2_32+16_box_bounds"])
+def frame(request):
     sys.path.insert(0, ROOT)
     import bench
+    S, Sf, box = request.param
     eng, inp, _ = bench.build_workload(torch.device(DEV), view=0)
+    eng.cfg["use_volume_near_far"] = box
     args = (inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"])
-    out = eng.render(*args, 48, 16, keep=True)
-    return eng, inp, args, out
+    out = eng.render(*args, S, Sf, keep=True)
+    f = Frame((eng, inp, args, out))
+    f.S, f.Sf = S, Sf
+    yield f
+    del f, out, eng, inp
+    torch.cuda.empty_cache()
 
 
 def test_culled_render_equals_dense_render_bitwise(frame):
     eng, inp, args, out = frame
-    fast = eng.render(*args, 48, 16)
-    dense = eng.render(*args, 48, 16, dense=True)
+    S, Sf = frame.S, frame.Sf
+    fast = eng.render(*args, S, Sf)
+    dense = eng.render(*args, S, Sf, dense=True)
     for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "acc0", "alpha0"):
         assert torch.equal(fast[k], dense[k]), k
         assert torch.equal(fast[k], out[k]), k          # and the materialising (keep=True) path
-    again = eng.render(*args, 48, 16)
+    again = eng.render(*args, S, Sf)
     assert all(torch.equal(fast[k], again[k]) for k in fast)   # run-to-run deterministic (compaction order is free)
 
 
@@ -38,9 +52,9 @@ def test_sample_order_is_a_sorted_permutation(frame):
     eng, inp, args, out = frame
     order, z_all = out["sorted_idxs"].long(), out["z_sorted"]
     R = z_all.shape[0]
-    assert R == 512 * 512 and z_all.shape[1] == 64
+    assert R == 512 * 512 and z_all.shape[1] == frame.S + frame.Sf
     assert bool((z_all[:, 1:] >= z_all[:, :-1]).all())
-    assert bool((torch.sort(order, -1).values == torch.arange(64, device=DEV)).all())
+    assert bool((torch.sort(order, -1).values == torch.arange(frame.S + frame.Sf, device=DEV)).all())
     both = torch.cat([out["z_coarse"], out["z_fine"]], 1)
     assert torch.equal(torch.gather(both, 1, order), z_all)
     assert bool((out["z_fine"] >= out["z_coarse"][:, :1]).all()) and bool((out["z_fine"] <= out["z_coarse"][:, -1:]).all())
@@ -57,7 +71,7 @@ def test_compositing_invariants(frame):
     assert bool((out["acc_map"] >= 0).all()) and bool((out["acc_map"] <= 1).all())
     assert bool(((out["rgb_map"] >= -2e-3) & (out["rgb_map"] <= 1.002)).all())
     # rays whose every sample lies outside all volumes see only the empty-space density (calibrated to -2 -> alpha 0)
-    bits = out["valid_bits"].reshape(512 * 512, 48)
+    bits = out["valid_bits"].reshape(512 * 512, frame.S)
     empty_rays = (bits == 0).all(-1)
     assert 0.3 < float(empty_rays.float().mean()) < 0.99
     assert float(out["acc0"][empty_rays].abs().max()) == 0.0
@@ -73,7 +87,7 @@ def test_ray_shards_reproduce_the_full_frame(frame):
         a, b = shard_range(512 * 512, rank, 4)
         sl = slice(a, b)
         part = eng.render(inp["rays_o"][sl], inp["rays_d"][sl], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"][sl],
-                          48, 16)
+                          frame.S, frame.Sf)
         for k in ("rgb_map", "acc_map", "disp_map"):
             assert torch.equal(part[k], out[k][sl]), (rank, k)
 

@@ -66,6 +66,12 @@ def test_model_forward_on_reference_nerf_inputs():
     raw, enc = caster.network(inputs)
     assert raw.shape == (R, int(g["N_samples"]), 4)
     assert raw_err(N(raw), g["raw_coarse"]) < 1e-4
+    # eval-mode `encoded` as the reference returns it (core/networks/danbo.py:341-346): formed on first access
+    assert set(enc.keys()) == {"confd", "part_invalid"}
+    assert enc["confd"].shape == g["confd"].shape and max_err(N(enc["confd"]), g["confd"]) < 2e-5
+    assert np.array_equal(N(enc["part_invalid"]), g["invalid"].astype(np.float32).reshape(g["confd"].shape))
+    p = caster.network.sigmoid(enc["confd"], enc["part_invalid"], mask_invalid=False)   # what trainer.py:521 does with them
+    assert p.shape == enc["confd"].shape
     out = caster.network.raw2outputs(raw, T(g["z_coarse"]), T(rb[:, 3:6]), B=1.0)
     assert max_err(N(out["weights"]), g["weights_coarse"]) < 2e-5
     assert max_err(N(out["rgb_map"]), g["rgb_coarse"]) < 2e-5

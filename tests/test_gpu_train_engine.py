@@ -65,6 +65,8 @@ def test_grouped_weight_gradients_match_torch():
 
 # Gradient bounds against the reference's own autograd = 2x the worst deviation measured on the three training fixtures (MI355X,
 # round 3; profiles/r03_parity_measured.txt): norms 5.6e-5 -> 2e-4; stored tensors (entry-wise, relative to the tensor's max) see below
+# each path against float64 autograd on its own depths (test_fused_step_on_degenerate_batches): 2x measured, see profiles/r04_parity_measured.txt
+F64_BOUND, F64_BOUND_OVERLAP, F64_BOUND_EVERY = 2e-3, 1e-2, 5e-2
 NORM_TOL = 2e-4
 TENSOR_TOL = 2e-3        # measured 9.7e-4 (danbo_train), 2.1e-4, 5.3e-4
 
@@ -273,7 +275,9 @@ def test_graph_replays_are_repeatable():
         assert float((eng.flat_g - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
 
 
-def _autograd_grads(fixture, edit, model_edit=None):
+def _autograd_grads(fixture, edit, model_edit=None, sampling=None):
+    """sampling: a dict that receives the depths / merge order the path used (z_c, z_f, order), for the float64 reference"""
+    from core import hip_ops
     g = golden(fixture)
     args, caster, trainer, opt = build_trainer(g)
     if model_edit is not None:
@@ -282,13 +286,53 @@ def _autograd_grads(fixture, edit, model_edit=None):
     b = batch_of(g)
     edit(b)
     kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs")}
-    preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
-                   N_uniques=b["N_uniques"], **kw)
+    orig = hip_ops.importance_samples
+
+    def spy(z, w, n, u=None):
+        out = orig(z, w, n, u)
+        if sampling is not None:
+            sampling.update(z_c=z.detach().clone(), z_f=out[1].detach().clone(), order=out[2].detach().clone())
+        return out
+    hip_ops.importance_samples = spy
+    try:
+        preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                       N_uniques=b["N_uniques"], **kw)
+    finally:
+        hip_ops.importance_samples = orig
     loss = trainer.compute_loss(b, preds)
     caster.zero_grad()
     loss["total_loss"].backward()
     return ({n: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for n, p in caster.network.named_parameters()},
             preds, {k: float(v.detach()) for k, v in loss.items()})
+
+
+def _fused_sampling(eng, R, G, S, Sf):
+    """depths and merge order the fused step left in its workspace (danbo_train_workspace_view)"""
+    from core import _hip
+    v = _hip.DanboTrainView()
+    _hip.check(_hip.lib().danbo_train_workspace_view(ctypes.byref(eng._model()), R, G, S, Sf, R, ctypes.c_void_p(eng._ws.data_ptr()),
+                                                     ctypes.byref(v)), "danbo_train_workspace_view")
+    base = eng._ws.data_ptr()
+
+    def at(ptr, n, dt):
+        return eng._ws[ptr - base:ptr - base + 4 * n].view(dt)
+    return dict(z_c=at(v.z_coarse, R * S, torch.float32).view(R, S).clone(), z_f=at(v.z_fine, R * Sf, torch.float32).view(R, Sf).clone(),
+                order=at(v.order, R * (S + Sf), torch.int32).view(R, S + Sf).clone())
+
+
+def _f64_reference(g, args, caster, b, sampling):
+    """oracle/torch_f64_train.py on the batch `b`, the model as `caster` holds it, and the depths of the path under test"""
+    import torch_f64_train as t64
+    from core.utils import synthetic as syn
+    cfg = syn.model_config(str(g["cfg_name"]))
+    sd = {k: v.detach().cpu().numpy() for k, v in caster.network.state_dict().items()}
+    coef = dict(loss_fn=args.loss_fn, use_background=bool(args.use_background), rgb_loss_coef=float(args.rgb_loss_coef),
+                coarse_weight=float(args.coarse_weight), soft_softmax_loss_coef=float(args.soft_softmax_loss_coef),
+                vol_scale_penalty=float(args.vol_scale_penalty) if args.opt_vol_scale else 0.0)
+    nb = {k: b[k].detach().cpu().numpy() for k in ("rays_o", "rays_d", "skts", "bones", "target_s", "bgs", "cam_idxs")}
+    return t64.step(cfg, coef, sd, caster.transforms[0].cpu().numpy(), caster.network.graph_net.init_scale.cpu().numpy(), nb,
+                    sampling["z_c"].cpu().numpy(), sampling["z_f"].cpu().numpy(), sampling["order"].cpu().numpy(), int(b["N_uniques"]),
+                    device=DEV)
 
 
 @pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count", "many_small_poses", "overlapping_volumes",
@@ -323,9 +367,29 @@ def test_fused_step_on_degenerate_batches(case):
             keep = torch.cat([torch.arange(g0 * per, g0 * per + per - 3, device=DEV) for g0 in range(G)])   # 3 rays fewer per pose
             for k in ("rays_o", "rays_d", "target_s", "bgs", "kp3d", "skts", "bones", "cyls", "cam_idxs"):
                 b[k] = b[k][keep].contiguous()
-    ref, preds, ref_loss = _autograd_grads("danbo_perfcap_train", edit, model_edit)
+    samp_a = {}
+    ref, preds, ref_loss = _autograd_grads("danbo_perfcap_train", edit, model_edit, sampling=samp_a)
     g, args, caster, trainer, eng, out = fused_step("danbo_perfcap_train", edit=edit, model_edit=model_edit)
     counts = out["counts"].cpu().numpy()
+    # ---- each path against float64 autograd of the SAME batch on the path's own depths (oracle/torch_f64_train.py, pinned to the
+    # reference's autograd in tests/test_oracle_configs.py): which of the two is how far from the truth
+    b64 = batch_of(g)
+    edit(b64)
+    R64, G64 = b64["rays_o"].shape[0], int(b64["N_uniques"])
+    samp_f = _fused_sampling(eng, R64, G64, int(g["N_samples"]), int(g["N_importance"]))
+    assert torch.equal(samp_f["z_c"], samp_a["z_c"])                # perturb = 0: the coarse depths are the same function of the rays
+    f64_bound = {"overlapping_volumes": F64_BOUND_OVERLAP, "every_volume": F64_BOUND_EVERY}.get(case, F64_BOUND)
+    for path, grads, samp in (("autograd", ref, samp_a), ("fused", {n: p.grad for n, p in caster.network.named_parameters()}, samp_f)):
+        r64 = _f64_reference(g, args, caster, b64, samp)
+        worst64, name64 = 0.0, ""
+        for n, gr in grads.items():
+            t = r64["grads"][n]
+            scale = float(np.abs(t).max())
+            d = float(np.abs(gr.detach().cpu().numpy().astype(np.float64) - t).max())
+            if d / (scale + 1e-30) > worst64:
+                worst64, name64 = d / (scale + 1e-30), n
+            assert d <= f64_bound * scale + 1e-9, (path, n, d, scale)
+        print(case, path, "vs float64: worst gradient deviation (of the tensor's max)", worst64, "in", name64)
     if case in ("overlapping_volumes", "every_volume"):
         pairs = int((preds["part_invalid"] == 0).sum())
         cap = out["rgb_map"].shape[0] * (out["alpha"].shape[1] + 1)

@@ -488,3 +488,43 @@ def test_custom_operators_register_and_propagate_shapes_without_a_gpu():
     with pytest.raises(RuntimeError):
         torch.ops.danbo.assign_blend(torch.zeros(G, 24, 240), torch.zeros(24, 3), torch.zeros(R, S, 3), torch.zeros(G, 24, 4, 4), torch.zeros(24, 4, 4),
                                      torch.zeros(n, dtype=torch.int32), torch.zeros(R * S, dtype=torch.int32), [torch.zeros(1)] * 8)
+
+
+def test_fused_engine_adam_state_resumes_under_plain_adam(tmp_path):
+    """The fused engine's Adam state (train_engine.adopt_adam_state: exp_avg / exp_avg_sq as views of flat buffers, one DISTINCT
+    `step` tensor per parameter) must survive state_dict -> torch.save -> torch.load -> load_state_dict into a plain torch.optim.Adam
+    -- the reference's loader (core/raycasters.py:63-86), and this repo's autograd path -- with `step` advancing by ONE per
+    optimizer.step().  (A shared step tensor stays shared through the round trip and advances by the parameter count: ADVICE r3.)"""
+    from core.train_engine import adopt_adam_state
+    torch.manual_seed(0)
+    shapes = [(5, 3), (7,), (2, 2), (4,), (3, 3)]
+    params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    opt = torch.optim.Adam(params, lr=1e-2)
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += p.numel()
+    flat_m, flat_v = torch.zeros(off), torch.zeros(off)
+    steps = adopt_adam_state(opt, params, offsets, flat_m, flat_v)
+    assert len({id(s) for s in steps}) == len(params) and len({s.data_ptr() for s in steps}) == len(params)
+    t = 8
+    for _ in range(t):                                   # what DanboTrainEngine.adam_step does to the counters
+        torch._foreach_add_(steps, 1.0)
+    flat_m.uniform_(-1, 1)
+    flat_v.uniform_(0.1, 1)
+    path = tmp_path / "opt.tar"
+    torch.save({"optimizer_state_dict": opt.state_dict()}, path)
+    params2 = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt2 = torch.optim.Adam(params2, lr=1e-2)
+    opt2.load_state_dict(torch.load(path, weights_only=False)["optimizer_state_dict"])
+    for p in params2:
+        p.grad = torch.ones_like(p)
+    opt2.step()
+    for p in params2:
+        assert float(opt2.state[p]["step"]) == t + 1
+    # and the engine adopts a loaded state: moments copied into the flat buffers, the count taken over
+    flat_m2, flat_v2 = torch.zeros(off), torch.zeros(off)
+    steps2 = adopt_adam_state(opt2, params2, offsets, flat_m2, flat_v2)
+    assert all(float(s) == t + 1 for s in steps2) and len({s.data_ptr() for s in steps2}) == len(params)
+    assert torch.equal(flat_m2[offsets[1]:offsets[1] + 7], opt2.state[params2[1]]["exp_avg"].reshape(-1))
+    assert flat_m2.abs().sum() > 0 and opt2.state[params2[0]]["exp_avg"].data_ptr() == flat_m2.data_ptr()

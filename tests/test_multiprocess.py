@@ -213,3 +213,76 @@ def test_bench_config4_strong_scaling_on_two_ranks_of_one_gpu():
     assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["scaling"] == "strong"
     assert r["config"]["rays"] == 3072 and r["config"]["rays_per_rank"] == 1536
     assert r["value"] > 0 and r["loss"] == r["loss"]
+
+
+def _nccl_world1_worker(port, q):
+    """ONE rank, backend "nccl" (= RCCL on ROCm), cuda:0: the data-parallel form of Trainer.train_batch -- split step as two HIP
+    graphs, the first in-place all-reduce on the comm side stream under phase 2, the second behind it, 1 / world folded into Adam --
+    against the plain one-rank step of a second, identically built trainer."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(os.path.dirname(here), "danbo-pytorch_amd"), os.path.join(os.path.dirname(here), "oracle"), here):
+        sys.path.insert(0, p)
+    from helpers import golden
+    from test_gpu_training import batch_of, build_trainer
+
+    def run(parallel):
+        g = golden("danbo_perfcap_train")
+        args, caster, trainer, opt = build_trainer(g)         # perturb = 0, no density noise: the step is a function of the batch
+        trainer.collectives_at_world_1 = parallel
+        full = batch_of(g)
+        grads, losses = [], []
+        for i in range(4):
+            loss, stats = trainer.train_batch(full, i=i, global_step=i)
+            torch.cuda.synchronize()
+            grads.append(trainer.engine.flat_g.detach().cpu().numpy().copy())
+            losses.append(stats["total_loss"])
+        eng = trainer.engine
+        graphs = (eng.graph is not None, eng.graph is not None and eng.graph[4] is not None)
+        return grads, losses, eng.flat_p.detach().cpu().numpy().copy(), graphs, trainer._comm_stream is not None, float(args.lrate)
+
+    a = run(True)
+    b = run(False)
+    c = run(False)          # the step's own run-to-run repeatability (float atomics in the adjoints), measured the same way
+    q.put((a, b, c))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fused_training_step_through_rccl_at_world_size_1():
+    """Executes the nccl branch (bench.py:init_process_group("nccl"), core/trainer.py: two in-place all-reduces, one on a side
+    stream between the two graph-replayed phases) -- communicator creation, stream ordering against the captured graphs and the
+    in-place flat-buffer collectives, everything except the wire.  Replaces the reference's nn.DataParallel
+    (core/raycasters.py:116); SURVEY 8(e).  The sum over one rank is the identity, so the gradients must equal the plain step's:
+    the first step (identical parameters on both sides) within the step's own repeatability (its adjoints use float atomics:
+    test_graph_replays_are_repeatable allows 1e-5 of the largest entry), the losses of every step to 1e-5 relative."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    p = ctx.Process(target=_nccl_world1_worker, args=(port, q))
+    p.start()
+    (ga, la, pa, graphs_a, comm_a, lr), (gb, lb, pb, graphs_b, comm_b, _), (gc, lc, pc, _, _, _) = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert graphs_a == (True, True) and comm_a            # two graphs (phase 1 | phase 2) and the comm stream were in use
+    assert graphs_b == (True, False) and not comm_b       # the plain step: one graph, no collective
+    scale = np.abs(gb[0]).max()
+    noise = np.abs(gb[0] - gc[0]).max()
+    assert noise <= 1e-5 * scale
+    assert np.abs(ga[0] - gb[0]).max() <= max(2 * noise, 1e-6 * scale), (np.abs(ga[0] - gb[0]).max(), noise, scale)
+    for x, y in zip(la, lb):
+        assert np.isfinite(x) and abs(x - y) <= 1e-5 * abs(y), (la, lb)
+    assert np.isfinite(pa).all() and np.abs(pa - pb).max() <= 4 * 2.5 * lr       # 4 Adam steps bound any entry's drift (|update| <~ lr)
+    assert not np.array_equal(pa, np.zeros_like(pa))
+
+
+@pytest.mark.gpu
+def test_bench_config4_through_the_rccl_branch_at_world_1():
+    """bench.py --config 4 --gpus 1 --nccl-world-1: the bench's own training loop through a one-rank nccl process group"""
+    r = _run_bench("--config", "4", "--nccl-world-1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline")
+    assert r["n_gpus"] == 1 and "nccl" in r["collectives"] and "forced at world 1" in r["collectives"]
+    assert r["value"] > 0 and r["loss"] == r["loss"] and len(r["block_ms"]) >= 3
