@@ -2,6 +2,8 @@
 torch.library.custom_op with register_autograd"), so that a caller -- the reference's trainer included -- can trace or
 `torch.compile` around them:
 
+    torch.ops.danbo.pose_volumes(bones, L_graph, params)                  rot6d + PE + FactorizeGNN (reference core/networks/gnn_backbone.py:683-704)
+        -> volumes [G,24,240] (+ the adjoint's scratch)                  backward: danbo_pose_volumes_bwd -> every parameter's gradient
     torch.ops.danbo.composite(raw, z, rays_d, B, noise)                  NeRF.raw2outputs (reference core/networks/nerf.py:281-347)
         -> rgb_map, disp_map, acc_map, weights, alpha                     backward: danbo_composite_bwd (d rgb_map, d acc_map -> d raw)
     torch.ops.danbo.bone_gather(volumes, axis_scale, pts, skts, align, rows)
@@ -135,6 +137,93 @@ def _gather_backward(ctx, g):
 
 
 bone_gather.register_autograd(_gather_backward, setup_context=_gather_setup)
+
+
+# ----------------------------------------------------------------------------------------------------------------- pose volumes
+# torch.ops.danbo.pose_volumes(bones [G,24,3], L_graph, params) -> volumes [G,24,240], scratch
+#   params = graph_net.layers.{0.lin.weight [24,6(1+2L),W], 0.adj_w [1,24,24], 0.adj [1,24,24], 0.bias [W],
+#                              1.lin.weight [24,W,W], 1.adj_w, 1.adj, 1.bias [W], 2.weight [24,W,W], 2.bias [1,24,W],
+#                              3.weight [24,W,240], 3.bias [1,24,240]}       (the reference's state_dict tensors)
+#   = encode_graph_inputs (core/encoders.py:460-473) + AxisAngtoRot6DEncoder (:859-877) + Embedder (cutoff_embedder.py:62-73) +
+#     FactorizeGNN / BodyGNN.forward (core/networks/gnn_backbone.py:683-704) incl. mask_root and the doubled first layer.
+#   forward: danbo_pose_volumes_fwd (csrc/k_pose.hip); backward: danbo_pose_volumes_bwd (csrc/k_pose_bwd.hip) -> the gradient of
+#   every parameter (the 0/1 adjacency buffers get None; no gradient to the pose: opt_pose is off).
+#   `scratch` [3 G 24 W]: the layer activations the forward leaves for the adjoint -- an output so that autograd keeps it alive;
+#   not differentiable, ignore it.
+def _pose_params(params):
+    w0, aw0, a0, b0, w1, aw1, a1, b1, w2, b2, w3, b3 = params
+    W = w1.shape[-1]
+    f = lambda t, *shape: ops._f32(t.detach().reshape(*shape), "graph_net")  # noqa: E731
+    return dict(w0=f(w0, 24, -1, W), aw0=f(aw0, 24, 24), a0=f(a0, 24, 24), b0=f(b0, W), w1=f(w1, 24, W, W), aw1=f(aw1, 24, 24),
+                a1=f(a1, 24, 24), b1=f(b1, W), w2=f(w2, 24, W, W), b2=f(b2, 24, W), w3=f(w3, 24, W, ops.VOL), b3=f(b3, 24, ops.VOL)), W
+
+
+@torch.library.custom_op("danbo::pose_volumes", mutates_args=())
+def pose_volumes(bones: torch.Tensor, L_graph: int, params: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    if not bones.is_cuda:
+        raise RuntimeError("danbo::pose_volumes runs on the HIP path only (no CPU fallback)")
+    a, W = _pose_params(params)
+    if a["w0"].shape[1] != 6 * (1 + 2 * int(L_graph)):
+        raise ValueError(f"danbo::pose_volumes: layer 0 takes {a['w0'].shape[1]} inputs, the rot6d encoding with L = {L_graph} has "
+                         f"{6 * (1 + 2 * int(L_graph))}")
+    bones = ops._f32(bones.detach(), "bones")
+    G = bones.shape[0]
+    scratch = torch.empty(3 * G * ops.J * W, device=bones.device, dtype=torch.float32)
+    vol = torch.empty(G, ops.J, ops.VOL, device=bones.device, dtype=torch.float32)
+    # (named: a temporary handed to _p() is freed -- and its block re-used by the next temporary -- before the launch)
+    adjw0, adjw1 = (a["aw0"] * a["a0"]).contiguous(), (a["aw1"] * a["a1"]).contiguous()
+    _hip.check(_hip.lib().danbo_pose_volumes_fwd(_p(bones), G, int(L_graph), W, _p(a["w0"]), _p(adjw0), _p(a["b0"]), _p(a["w1"]), _p(adjw1),
+                                                 _p(a["b1"]), _p(a["w2"]), _p(a["b2"]), _p(a["w3"]), _p(a["b3"]), _p(scratch), _p(vol),
+                                                 ops._stream()), "danbo_pose_volumes_fwd")
+    return vol, scratch
+
+
+@pose_volumes.register_fake
+def _(bones, L_graph, params):
+    G, W = bones.shape[0], params[4].shape[-1]
+    return bones.new_empty(G, ops.J, ops.VOL, dtype=torch.float32), bones.new_empty(3 * G * ops.J * W, dtype=torch.float32)
+
+
+@torch.library.custom_op("danbo::pose_volumes_bwd", mutates_args=())
+def pose_volumes_bwd(bones: torch.Tensor, L_graph: int, params: List[torch.Tensor], scratch: torch.Tensor,
+                     g_vol: torch.Tensor) -> List[torch.Tensor]:
+    """-> [d w0, d adj_w0, d b0, d w1, d adj_w1, d b1, d w2, d b2, d w3, d b3] in the parameters' own shapes"""
+    a, W = _pose_params(params)
+    bones = ops._f32(bones.detach(), "bones")
+    G, dev = bones.shape[0], bones.device
+    names = ("w0", "aw0", "b0", "w1", "aw1", "b1", "w2", "b2", "w3", "b3")
+    g = {k: torch.zeros(a[k].shape, device=dev, dtype=torch.float32) for k in names}     # (adj_w / b0 / b1 are accumulated into)
+    bwd_scratch = torch.empty(2 * G * ops.J * W, device=dev, dtype=torch.float32)
+    _hip.check(_hip.lib().danbo_pose_volumes_bwd(
+        _p(bones), G, int(L_graph), W, _p(a["w0"]), _p(a["aw0"]), _p(a["a0"]), _p(a["b0"]), _p(a["w1"]), _p(a["aw1"]), _p(a["a1"]), _p(a["b1"]),
+        _p(a["w2"]), _p(a["w3"]), _p(ops._f32(scratch, "scratch")), _p(ops._f32(g_vol, "g_vol")), _p(g["w0"]), _p(g["aw0"]), _p(g["b0"]),
+        _p(g["w1"]), _p(g["aw1"]), _p(g["b1"]), _p(g["w2"]), _p(g["b2"]), _p(g["w3"]), _p(g["b3"]), _p(bwd_scratch), ops._stream()),
+        "danbo_pose_volumes_bwd")
+    w0, aw0, a0, b0, w1, aw1, a1, b1, w2, b2, w3, b3 = params
+    return [g[k].reshape(t.shape) for k, t in zip(names, (w0, aw0, b0, w1, aw1, b1, w2, b2, w3, b3))]
+
+
+@pose_volumes_bwd.register_fake
+def _(bones, L_graph, params, scratch, g_vol):
+    w0, aw0, a0, b0, w1, aw1, a1, b1, w2, b2, w3, b3 = params
+    return [torch.empty_like(t, dtype=torch.float32) for t in (w0, aw0, b0, w1, aw1, b1, w2, b2, w3, b3)]
+
+
+def _pose_setup(ctx, inputs, output):
+    bones, L_graph, params = inputs
+    ctx.L_graph = L_graph
+    ctx.save_for_backward(bones, output[1], *params)
+    ctx.mark_non_differentiable(output[1])
+
+
+def _pose_backward(ctx, g_vol, g_scratch):
+    bones, scratch, *params = ctx.saved_tensors
+    d = torch.ops.danbo.pose_volumes_bwd(bones, ctx.L_graph, list(params), scratch, g_vol.contiguous())
+    d_w0, d_aw0, d_b0, d_w1, d_aw1, d_b1, d_w2, d_b2, d_w3, d_b3 = d
+    return None, None, [d_w0, d_aw0, None, d_b0, d_w1, d_aw1, None, d_b1, d_w2, d_b2, d_w3, d_b3]
+
+
+pose_volumes.register_autograd(_pose_backward, setup_context=_pose_setup)
 
 
 # ------------------------------------------------------------------------------------------------------- gather + assign + blend

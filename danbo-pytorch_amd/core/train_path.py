@@ -18,8 +18,6 @@ differentiable (core/networks/gnn_backbone.py:802-808); sample depths are detach
 """
 import ctypes
 
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -139,8 +137,33 @@ def axis_angle_to_rot6d(aa):
                         1 - two_s * (i * i + k * k), two_s * (i * k - j * r), two_s * (j * k + i * r)], -1)
 
 
+def _pose_op_params(model):
+    """the 12 tensors of torch.ops.danbo.pose_volumes if graph_net has the structure k_pose_layer is built for (two graph
+    convolutions, two per-bone linears, 240 outputs, width <= 256: every shipped DANBO config), else None"""
+    gn = model.graph_net
+    try:
+        l0, l1, l2, l3 = gn.layers
+        ok = (hasattr(l0, "adj_w") and hasattr(l1, "adj_w") and not hasattr(l2, "adj_w") and not hasattr(l3, "adj_w")
+              and l3.weight.shape[-1] == ops.VOL and l1.lin.weight.shape[-1] <= 256
+              and l0.lin.weight.shape[1] == 6 * (1 + 2 * model.graph_pe_fn.num_freqs))
+    except (ValueError, AttributeError):
+        return None
+    if not ok:
+        return None
+    return [l0.lin.weight, l0.adj_w, l0.adj, l0.bias, l1.lin.weight, l1.adj_w, l1.adj, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias]
+
+
 def pose_volumes(model, bones_g):
-    """FactorizeGNN forward (reference gnn_backbone.py:683-704) -> [G,24,240], differentiable."""
+    """FactorizeGNN forward (reference gnn_backbone.py:683-704) -> [G,24,240], differentiable: torch.ops.danbo.pose_volumes
+    (k_pose_layer both ways, core/custom_ops.py); a graph net of another structure is recorded layer by layer with torch ops."""
+    params = _pose_op_params(model)
+    if params is not None and bones_g.is_cuda:
+        return torch.ops.danbo.pose_volumes(bones_g.contiguous().float(), int(model.graph_pe_fn.num_freqs), params)[0]
+    return pose_volumes_layerwise(model, bones_g)
+
+
+def pose_volumes_layerwise(model, bones_g):
+    """the same with torch ops (any layer structure; the comparison of tests/test_gpu_training.py)"""
     gn = model.graph_net
     n = positional_encoding(axis_angle_to_rot6d(bones_g), model.graph_pe_fn.num_freqs)
     mask = torch.ones(1, 24, 1, device=n.device)
@@ -200,11 +223,20 @@ def assignment_logits(model, part_feat):
     return (torch.einsum("bkl,klj->bkj", y, l2.weight) + l2.bias)[..., 0]
 
 
+def _assign_op_applies(model):
+    """torch.ops.danbo.assign_blend covers the shipped assignment net (MixGNN: one graph convolution 15 -> 32, two per-bone
+    linears 32 -> 32 -> 1); anything else takes the layer-by-layer route on a materialised part_feat"""
+    try:
+        l0, l1, l2 = model.prob_linears.layers
+        return (tuple(l0.lin.weight.shape) == (24, ops.FEAT, 32) and tuple(l1.weight.shape) == (24, 32, 32)
+                and tuple(l2.weight.shape) == (24, 32, 1))
+    except (ValueError, AttributeError):
+        return False
+
+
 def _fused_mlp_params(model):
     """the 24 parameter tensors of torch.ops.danbo.pe_mlp if the network has the shape the fused trunk kernels are built for
     (D = 8, W = 256, skip after layer 4, 6 voxel octaves, view_W = 128), else None (-> the library-GEMM path below)"""
-    if os.environ.get("DANBO_AUTOGRAD_MLP") == "library":
-        return None
     try:
         ok = (len(model.pts_linears) == 8 and list(model.skips) == [4] and model.voxel_pe_fn.num_freqs == 6
               and model.pts_linears[0].weight.shape == (256, 195) and model.views_linears[0].weight.shape[0] == 128
@@ -276,7 +308,7 @@ def forward_train(model, inputs):
         shared["vols"] = pose_volumes(model, bones_g)
     vols = shared["vols"]
     shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
-    if os.environ.get("DANBO_AUTOGRAD_ASSIGN") != "library" and n > 0:
+    if n > 0 and _assign_op_applies(model):
         # torch.ops.danbo.assign_blend: gather + assignment GNN + masked sigmoid + blend in one HIP kernel each way (core/custom_ops.py);
         # part_feat [n,24,15] is never materialised
         from . import custom_ops  # noqa: F401  (registers the operator)

@@ -28,7 +28,9 @@ extern "C" {
 #define DANBO_FEAT 15       /* voxel_feat * 3 ('cat' construct)                     */
 #define DANBO_H_STRIDE 16   /* blended feature rows are padded 15 -> 16 floats      */
 
-/* library / device identification (host only) */
+/* library / device identification (host only).
+ * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view
+ * (additive). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 

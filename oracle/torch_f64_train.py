@@ -22,7 +22,44 @@ import torch.nn.functional as F
 import danbo_oracle as o
 
 J = 24
-F64 = torch.float64
+F64 = torch.float64        # (tools/diag sets this to torch.float32 to see what plain fp32 arithmetic gives on the same graph)
+
+
+class Kinks:
+    """ReLU units whose SIGN is not determined at fp32 precision.  A ReLU network's gradient is discontinuous where a
+    pre-activation crosses zero; when a (sample, unit) pair sits within round-off of that kink, two correct fp32 evaluations land
+    on different sides and their gradients differ by that sample's whole contribution through the unit (measured: one pair worth
+    4 % of pts_linears.6.weight on a 192-ray batch).  No float64 number is "the" reference there -- but float64 can BRACKET it:
+    record every pre-activation in float64 and in float32 (the same graph in both precisions), call a unit ambiguous when the
+    two disagree in sign or |z64| < KAPPA |z64 - z32| (KAPPA = 16: the paths under test do not round like this restatement;
+    measured on the pin fixture: the reference's own fp32 autograd sits on the other side of a unit at 4 .. 16 x), and differentiate twice more with the ambiguous units' derivative forced to
+    1 and to 0.  |g_on - g_off| is what the kink decisions can move each gradient by (step_bracketed)."""
+    KAPPA = 16.0
+
+    def __init__(self, masks=None, side=0):
+        self.z, self.masks, self.side, self.i = [], masks, side, 0
+
+
+class _ForcedRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, ambiguous, side):
+        ctx.save_for_backward((torch.where(ambiguous, torch.full_like(z, float(side)), (z > 0).to(z.dtype))))
+        return torch.relu(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.saved_tensors[0], None, None
+
+
+def _relu(z, kinks):
+    if kinks is None:
+        return F.relu(z)
+    i = kinks.i
+    kinks.i += 1
+    if kinks.masks is None:
+        kinks.z.append(z.detach())
+        return F.relu(z)
+    return _ForcedRelu.apply(z, kinks.masks[i], kinks.side)
 
 
 def _pe(x, L):
@@ -45,7 +82,7 @@ def _rot6d(aa):
                         1 - two_s * (i * i + k * k), two_s * (i * k - j * r), two_s * (j * k + i * r)], -1)
 
 
-def pose_volumes(p, bones, L):
+def pose_volumes(p, bones, L, kinks=None):
     """FactorizeGNN forward (gnn_backbone.py:683-704) incl. the skip_gcn=False doubling of layer 0"""
     n = _pe(_rot6d(bones), L)
     mask = torch.ones(1, J, 1, dtype=F64, device=bones.device)
@@ -60,11 +97,11 @@ def pose_volumes(p, bones, L):
             out = torch.einsum('bkl,klj->bkj', n, p[f'{g}{i}.weight']) + p[f'{g}{i}.bias']
         if i == 0:
             out = out + out
-        n = F.relu(out) if i < 3 else out
+        n = _relu(out, kinks) if i < 3 else out
     return n
 
 
-def network(cfg, p, pts_t, valid, vols, pose_of_ray, vin):
+def network(cfg, p, pts_t, valid, vols, pose_of_ray, vin, keep=None, kinks=None):
     """DANBO.forward on [R,S] samples given their aligned bone-local coordinates pts_t [R,S,24,3] (float64 copies of the float32
     values) and the in-volume mask valid [R,S,24] -> raw [R,S,4], logits [R,S,24]"""
     R, S = pts_t.shape[:2]
@@ -89,25 +126,27 @@ def network(cfg, p, pts_t, valid, vols, pose_of_ray, vin):
     pf = (torch.stack(feat, -1).reshape(R, S, J, Fc * 3) * win[..., None]).reshape(R * S, J, Fc * 3)
     p0 = 'prob_linears.layers.0'
     y = torch.einsum('bkl,klj->bkj', pf, p[p0 + '.lin.weight'])
-    y = F.relu(torch.matmul((p[p0 + '.adj_w'] * p[p0 + '.adj'])[0], y) + p[p0 + '.bias'])
-    y = F.relu(torch.einsum('bkl,klj->bkj', y, p['prob_linears.layers.1.weight']) + p['prob_linears.layers.1.bias'])
+    y = _relu(torch.matmul((p[p0 + '.adj_w'] * p[p0 + '.adj'])[0], y) + p[p0 + '.bias'], kinks)
+    y = _relu(torch.einsum('bkl,klj->bkj', y, p['prob_linears.layers.1.weight']) + p['prob_linears.layers.1.bias'], kinks)
     logits = (torch.einsum('bkl,klj->bkj', y, p['prob_linears.layers.2.weight']) + p['prob_linears.layers.2.bias'])[..., 0]
     pr = (torch.sigmoid(logits) * 1.002 - 0.001) * valid.reshape(R * S, J).to(F64)
     h = (pf * pr[..., None]).sum(-2)
+    if keep is not None:
+        keep.append(h)
     x0 = _pe(h, cfg['multires_voxel'])
     lin = lambda n, t: F.linear(t, p[n + '.weight'], p[n + '.bias'])  # noqa: E731
     t = x0
     for i in range(cfg['D']):
-        t = F.relu(lin(f'pts_linears.{i}', t))
+        t = _relu(lin(f'pts_linears.{i}', t), kinks)
         if i in cfg['skips']:
             t = torch.cat([x0, t], -1)
     alpha = lin('alpha_linear', t)
-    hv = F.relu(lin('views_linears.0', torch.cat([lin('feature_linear', t), vin.repeat_interleave(S, 0)], -1)))
+    hv = _relu(lin('views_linears.0', torch.cat([lin('feature_linear', t), vin.repeat_interleave(S, 0)], -1)), kinks)
     raw = torch.cat([lin('rgb_linear', hv), alpha], -1)
     return raw.reshape(R, S, 4), logits.reshape(R, S, J)
 
 
-def composite(raw, z, rays_d, B, noise=None):
+def composite(raw, z, rays_d, B, noise=None, clamped=None):
     d = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1) * torch.norm(rays_d, dim=-1, keepdim=True)
     rgb = torch.sigmoid(raw[..., :3]) * 1.002 - 0.001
     s = raw[..., 3] / B
@@ -115,17 +154,29 @@ def composite(raw, z, rays_d, B, noise=None):
         s = s + noise
     alpha = 1.0 - torch.exp(-F.relu(s) * d)
     w = alpha * torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
-    return (w[..., None] * rgb).sum(-2), torch.minimum(w.sum(-1), torch.ones((), dtype=F64, device=raw.device)), w, alpha
+    sw = w.sum(-1)
+    if clamped is None:
+        acc = torch.minimum(sw, torch.ones((), dtype=F64, device=raw.device))
+    else:       # the branch of min(sum w, 1) the path under test took, per ray (see step())
+        acc = torch.where(clamped, torch.ones_like(sw), sw)
+    return (w[..., None] * rgb).sum(-2), acc, w, alpha
 
 
 def step(cfg, coef, sd, align, init_scale, batch, z_c, z_f, order, n_uniques, noise_c=None, noise_f=None, device='cpu', Sf=None,
-         u_rand=None):
+         u_rand=None, clamped_c=None, clamped_f=None, debug=None, kinks=None):
     """One forward + backward.
     cfg: synthetic.model_config(...); coef: dict(loss_fn 'L1' | 'MSE', use_background, rgb_loss_coef, coarse_weight,
     soft_softmax_loss_coef, vol_scale_penalty (0 = term off)); sd: name -> numpy array (float32 parameters and 0/1 adjacency
     buffers); align [24,4,4] float32; init_scale [24,3]; batch: numpy rays_o, rays_d [R,3], skts [R,24,4,4], bones [R,24,3] (per
     ray), target, bgs [R,3], cam_idxs [R]; z_c [R,S], z_f [R,Sf] float32 depths and order [R,S+Sf] (argsort of [z_c | z_f]) of the
-    path under test.  -> dict(loss: name -> float, grads: name -> float64 numpy, rgb_map, rgb0, acc_map, labels)"""
+    path under test.
+    clamped_c / clamped_f [R] bool or None: which rays of the coarse / final composite the path under test saw at acc_map = 1,
+    i.e. on the constant branch of acc = min(sum w, 1) (nerf.py:344).  An opaque ray sits EXACTLY on that kink: its last sample
+    has delta = 1e10, so alpha = 1 and sum w = 1 + O(1e-10) in exact arithmetic (the +1e-10 inside the transmittance), which
+    float64 resolves (always clamped: no gradient through acc) and float32 does not (1 - a + 1e-10 == 1 - a; sum w lands on
+    either side of 1 by round-off, ray by ray).  Which side is taken is not a property of the function being differentiated;
+    like the sampling, the decision is taken from the path under test.  None: float64's own min().
+    -> dict(loss: name -> float, grads: name -> float64 numpy, rgb_map, rgb0, acc_map, labels)"""
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
     T = lambda a: torch.tensor(np.asarray(a), dtype=F64, device=device)  # noqa: E731
     ro, rd, skts, bones = f32(batch['rays_o']), f32(batch['rays_d']), f32(batch['skts']), f32(batch['bones'])
@@ -156,22 +207,26 @@ def step(cfg, coef, sd, align, init_scale, batch, z_c, z_f, order, n_uniques, no
     vin = _pe(d, cfg['multires_views'])
     if cfg['use_framecode']:
         vin = torch.cat([vin, p['framecodes.codes.weight'][torch.as_tensor(np.asarray(batch['cam_idxs']).reshape(-1), device=device).long()]], -1)
-    vols = pose_volumes(p, T(bones[::skip]), cfg['multires_graph'])
+    vols = pose_volumes(p, T(bones[::skip]), cfg['multires_graph'], kinks)
     B = float(cfg['density_scale'])
     rdt = T(rd)
     zc, zf = T(z_c), (None if z_f is None else T(z_f))
     pt_c, va_c = geometry(z_c)
-    raw_c, lg_c = network(cfg, p, pt_c, va_c, vols, pose_of_ray, vin)
-    rgb0, acc0, w0, _ = composite(raw_c, zc, rdt, B, None if noise_c is None else T(noise_c))
+    hs = [] if debug is not None else None
+    raw_c, lg_c = network(cfg, p, pt_c, va_c, vols, pose_of_ray, vin, hs, kinks)
+    as_mask = lambda m: None if m is None else torch.as_tensor(np.asarray(m), device=device).bool()  # noqa: E731
+    raw_c1 = raw_c * 1.0            # (own graph nodes for the two composites' inputs: `debug` reads the gradients arriving there)
+    rgb0, acc0, w0, _ = composite(raw_c1, zc, rdt, B, None if noise_c is None else T(noise_c), as_mask(clamped_c))
     if z_f is None:     # pin mode only (no path under test): resample from this restatement's own coarse weights, rounded to float32
         _, z_f, order = o.importance_z(f32(z_c), w0.detach().cpu().numpy().astype(np.float32), int(Sf), u=u_rand)
         zf = T(z_f)
     pt_f, va_f = geometry(z_f)
-    raw_f, lg_f = network(cfg, p, pt_f, va_f, vols, pose_of_ray, vin)
+    raw_f, lg_f = network(cfg, p, pt_f, va_f, vols, pose_of_ray, vin, hs, kinks)
     idx = torch.as_tensor(np.asarray(order), device=device).long()
     take = lambda a, b: torch.gather(torch.cat([a, b], 1), 1, idx[..., None].expand(-1, -1, a.shape[-1]))  # noqa: E731
     z_all = torch.gather(torch.cat([zc, zf], 1), 1, idx)
-    rgb, acc, w, alpha = composite(take(raw_c, raw_f), z_all, rdt, B, None if noise_f is None else T(noise_f))
+    raw_all1 = take(raw_c, raw_f) * 1.0
+    rgb, acc, w, alpha = composite(raw_all1, z_all, rdt, B, None if noise_f is None else T(noise_f), as_mask(clamped_f))
     target, bgs = T(batch['target_s']), T(batch['bgs'])
     fn = {'L1': F.l1_loss, 'MSE': F.mse_loss}[coef.get('loss_fn', 'L1')]
     bg = (lambda c, a: c + (1.0 - a)[:, None] * bgs) if coef.get('use_background', True) else (lambda c, a: c)
@@ -186,8 +241,38 @@ def step(cfg, coef, sd, align, init_scale, batch, z_c, z_f, order, n_uniques, no
         loss['vol_scale_loss'] = coef['vol_scale_penalty'] * torch.prod(sc, -1).sum()
     loss['total_loss'] = sum(loss.values())
     leaves = {k: v for k, v in p.items() if v.requires_grad}
+    if debug is not None:
+        d1, d2 = torch.autograd.grad(loss['total_loss'], [raw_c1, raw_all1], retain_graph=True)
+        debug.update(d_raw_coarse=d1.cpu().numpy(), d_raw_sorted=d2.cpu().numpy(), raw_coarse=raw_c.detach().cpu().numpy(),
+                     raw_sorted=raw_all1.detach().cpu().numpy(), acc0=acc0.detach().cpu().numpy(), acc=acc.detach().cpu().numpy())
+    if debug is not None:
+        gh = torch.autograd.grad(loss['total_loss'], hs, retain_graph=True)
+        debug.update(h_c=hs[0].detach().cpu().numpy(), h_f=hs[1].detach().cpu().numpy(), d_h_c=gh[0].cpu().numpy(), d_h_f=gh[1].cpu().numpy(),
+                     any_c=va_c.any(-1).reshape(-1).cpu().numpy(), any_f=va_f.any(-1).reshape(-1).cpu().numpy())
     grads = torch.autograd.grad(loss['total_loss'], list(leaves.values()), allow_unused=True)
     return dict(loss={k: float(v.detach()) for k, v in loss.items()},
                 grads={k: (np.zeros(tuple(v.shape)) if g is None else g.cpu().numpy()) for (k, v), g in zip(leaves.items(), grads)},
                 rgb_map=rgb.detach().cpu().numpy(), rgb0=rgb0.detach().cpu().numpy(), acc_map=acc.detach().cpu().numpy(),
-                labels=labels.cpu().numpy(), weights0=w0.detach().cpu().numpy())
+                labels=labels.cpu().numpy(), weights0=w0.detach().cpu().numpy(), z_f=np.asarray(z_f), order=np.asarray(order))
+
+
+def step_bracketed(*args, **kw):
+    """step() in float64 + the bracket of the ReLU-kink decisions (class Kinks): -> step()'s dict with two more entries,
+    `bracket`: name -> max |g_on - g_off| of the tensor, `ambiguous`: (units whose sign fp32 does not determine, units)."""
+    global F64
+    k32, k64 = Kinks(), Kinks()
+    F64 = torch.float32
+    try:
+        step(*args, kinks=k32, **kw)
+    finally:
+        F64 = torch.float64
+    ret = step(*args, kinks=k64, **kw)
+    masks = []
+    for a, b in zip(k32.z, k64.z):
+        a = a.to(torch.float64)
+        masks.append(((a > 0) != (b > 0)) | (b.abs() < Kinks.KAPPA * (b - a).abs()))
+    g_on = step(*args, kinks=Kinks(masks, 1), **kw)['grads']
+    g_off = step(*args, kinks=Kinks(masks, 0), **kw)['grads']
+    ret['bracket'] = {n: float(np.abs(g_on[n] - g_off[n]).max()) for n in g_on}
+    ret['ambiguous'] = (int(sum(int(m.sum()) for m in masks)), int(sum(m.numel() for m in masks)))
+    return ret

@@ -66,7 +66,7 @@ def test_grouped_weight_gradients_match_torch():
 # Gradient bounds against the reference's own autograd = 2x the worst deviation measured on the three training fixtures (MI355X,
 # round 3; profiles/r03_parity_measured.txt): norms 5.6e-5 -> 2e-4; stored tensors (entry-wise, relative to the tensor's max) see below
 # each path against float64 autograd on its own depths (test_fused_step_on_degenerate_batches): 2x measured, see profiles/r04_parity_measured.txt
-F64_BOUND, F64_BOUND_OVERLAP, F64_BOUND_EVERY = 2e-3, 1e-2, 5e-2
+F64_BOUND, F64_BOUND_OVERLAP, F64_BOUND_EVERY = 3e-5, 3e-5, 3e-5
 NORM_TOL = 2e-4
 TENSOR_TOL = 2e-3        # measured 9.7e-4 (danbo_train), 2.1e-4, 5.3e-4
 
@@ -320,7 +320,7 @@ def _fused_sampling(eng, R, G, S, Sf):
                 order=at(v.order, R * (S + Sf), torch.int32).view(R, S + Sf).clone())
 
 
-def _f64_reference(g, args, caster, b, sampling):
+def _f64_reference(g, args, caster, b, sampling, debug=None):
     """oracle/torch_f64_train.py on the batch `b`, the model as `caster` holds it, and the depths of the path under test"""
     import torch_f64_train as t64
     from core.utils import synthetic as syn
@@ -330,9 +330,10 @@ def _f64_reference(g, args, caster, b, sampling):
                 coarse_weight=float(args.coarse_weight), soft_softmax_loss_coef=float(args.soft_softmax_loss_coef),
                 vol_scale_penalty=float(args.vol_scale_penalty) if args.opt_vol_scale else 0.0)
     nb = {k: b[k].detach().cpu().numpy() for k in ("rays_o", "rays_d", "skts", "bones", "target_s", "bgs", "cam_idxs")}
-    return t64.step(cfg, coef, sd, caster.transforms[0].cpu().numpy(), caster.network.graph_net.init_scale.cpu().numpy(), nb,
+    return (t64.step if debug is not None else t64.step_bracketed)(cfg, coef, sd, caster.transforms[0].cpu().numpy(), caster.network.graph_net.init_scale.cpu().numpy(), nb,
                     sampling["z_c"].cpu().numpy(), sampling["z_f"].cpu().numpy(), sampling["order"].cpu().numpy(), int(b["N_uniques"]),
-                    device=DEV)
+                    device=DEV, clamped_c=sampling["acc0"].detach().cpu().numpy() >= 1.0, clamped_f=sampling["acc_map"].detach().cpu().numpy() >= 1.0,
+                    **({} if debug is None else dict(debug=debug)))
 
 
 @pytest.mark.parametrize("case", ["no_sample_in_any_volume", "one_pose_misses", "odd_ray_count", "many_small_poses", "overlapping_volumes",
@@ -342,7 +343,7 @@ def test_fused_step_on_degenerate_batches(case):
     per-ray empty-space rows carry a gradient), one pose whose rays all miss while the others hit, a ray count that is no
     multiple of any tile size, 48 poses of 4 rays each (a workgroup of the K2 adjoint keeps two poses' tables in LDS: its chunks
     then span many more and take the global-memory branch for the pose transforms, volumes and volume gradients), and bone volumes
-    grown 4x (axis_scale is trainable) so that a sample lies in many volumes at
+    grown 4x / 12x (axis_scale is trainable) so that a sample lies in many volumes at
     once: more (row, bone) pairs than the K2 adjoint's launch grid has workgroups for, it has to stride -- against the autograd
     path on the same batch."""
     def model_edit(caster):
@@ -377,10 +378,14 @@ def test_fused_step_on_degenerate_batches(case):
     edit(b64)
     R64, G64 = b64["rays_o"].shape[0], int(b64["N_uniques"])
     samp_f = _fused_sampling(eng, R64, G64, int(g["N_samples"]), int(g["N_importance"]))
+    samp_f.update(acc0=out["acc0"], acc_map=out["acc_map"])         # which rays sat on the constant branch of min(sum w, 1)
+    samp_a.update(acc0=preds["acc0"], acc_map=preds["acc_map"])
     assert torch.equal(samp_f["z_c"], samp_a["z_c"])                # perturb = 0: the coarse depths are the same function of the rays
     f64_bound = {"overlapping_volumes": F64_BOUND_OVERLAP, "every_volume": F64_BOUND_EVERY}.get(case, F64_BOUND)
+    brackets = {}
     for path, grads, samp in (("autograd", ref, samp_a), ("fused", {n: p.grad for n, p in caster.network.named_parameters()}, samp_f)):
         r64 = _f64_reference(g, args, caster, b64, samp)
+        brackets[path] = r64["bracket"]
         worst64, name64 = 0.0, ""
         for n, gr in grads.items():
             t = r64["grads"][n]
@@ -388,8 +393,11 @@ def test_fused_step_on_degenerate_batches(case):
             d = float(np.abs(gr.detach().cpu().numpy().astype(np.float64) - t).max())
             if d / (scale + 1e-30) > worst64:
                 worst64, name64 = d / (scale + 1e-30), n
-            assert d <= f64_bound * scale + 1e-9, (path, n, d, scale)
-        print(case, path, "vs float64: worst gradient deviation (of the tensor's max)", worst64, "in", name64)
+            # + what the ReLU units whose sign fp32 does not determine can move this gradient by (torch_f64_train.Kinks)
+            assert d <= f64_bound * scale + r64["bracket"][n] + 1e-9, (path, n, d, scale, r64["bracket"][n])
+        kn = max(r64["bracket"], key=lambda k: r64["bracket"][k] / (float(np.abs(r64["grads"][k]).max()) + 1e-30))
+        print(case, path, "vs float64: worst gradient deviation (of the tensor's max)", worst64, "in", name64, "| ambiguous ReLU units",
+              r64["ambiguous"], "their bracket at most", r64["bracket"][kn] / (float(np.abs(r64["grads"][kn]).max()) + 1e-30), "in", kn)
     if case in ("overlapping_volumes", "every_volume"):
         pairs = int((preds["part_invalid"] == 0).sum())
         cap = out["rgb_map"].shape[0] * (out["alpha"].shape[1] + 1)
@@ -404,14 +412,14 @@ def test_fused_step_on_degenerate_batches(case):
     assert float((out["rgb_map"] - preds["rgb_map"].detach()).abs().max()) < (1e-4 if case != "every_volume" else 1e-3)
     assert abs(float(out["loss"][0]) - ref_loss["rgb_loss"]) <= 2e-4 * max(abs(ref_loss["rgb_loss"]), 1e-3)
     worst, worst_name = 0.0, ""
-    # overlapping volumes: h = sum of MANY p_j * feature_j reaches |h| ~ 10, and the positional encoding's sin(32 h) turns one
-    # ulp of h into 4e-5 -- the two paths' round-off differs by 3e-3 there; dropped pairs would show as tens of percent
-    bound = {"overlapping_volumes": 1e-2, "every_volume": 5e-2}.get(case, 2e-3)
+    # fused step against autograd path: NOT the same function -- each resamples from its own coarse weights (importance depths are
+    # a chaotic function of fp32 round-off) and each takes its own side of every ReLU kink; the tight statement is the one above,
+    # each path against float64 on its own depths.  (Dropped (row, bone) pairs would show as tens of percent.)
     for n, p in caster.network.named_parameters():
         a, r = p.grad, ref[n]
         scale = float(r.abs().max())
         d = float((a - r).abs().max())
-        assert d <= bound * scale + 1e-9, (n, d, scale)
+        assert d <= 2e-3 * scale + brackets["autograd"][n] + brackets["fused"][n] + 1e-9, (n, d, scale)
         if d / (scale + 1e-30) > worst:
             worst, worst_name = d / (scale + 1e-30), n
     print(case, "rows", counts[:6], "worst relative gradient deviation", worst, "in", worst_name)

@@ -217,6 +217,94 @@ def test_assign_blend_custom_op_forward_backward_and_opcheck():
                           test_utils=("test_schema", "test_faketensor"))
 
 
+def test_pose_volumes_custom_op_forward_backward_and_opcheck():
+    """torch.ops.danbo.pose_volumes (rot6d + PE + FactorizeGNN on k_pose_layer, adjoint on k_pose_layer_bwd / k_pose_mix_bwd)
+    against the same network recorded layer by layer with torch ops in float64 (reference core/networks/gnn_backbone.py:683-704
+    incl. mask_root and the doubled first layer): the volumes and the gradient of all ten parameters for a random upstream
+    gradient; schema / fake-tensor opcheck"""
+    from core import custom_ops  # noqa: F401
+    from core import train_path
+    from core.utils import synthetic as syn
+    g = golden("danbo_stages")
+    cfg = syn.model_config("danbo_base")
+    sd = syn.make_state_dict(cfg, int(g["weight_seed"]), 20, syn.rest_pose(0.48))
+    p_ = "graph_net.layers."
+    names = ["0.lin.weight", "0.adj_w", "0.adj", "0.bias", "1.lin.weight", "1.adj_w", "1.adj", "1.bias", "2.weight", "2.bias", "3.weight", "3.bias"]
+    bones = T(np.concatenate([g["bones"], g["bones"][::-1] * 0.7, np.zeros_like(g["bones"][:1])]))       # 5 poses incl. the rest pose
+    L = cfg["multires_graph"]
+    params = [T(sd[p_ + k]).requires_grad_(not k.endswith(".adj")) for k in names]
+    vol, scratch = torch.ops.danbo.pose_volumes(bones, L, params)
+    assert vol.shape == (bones.shape[0], 24, 240) and not scratch.requires_grad
+    gv = T(np.random.default_rng(5).normal(size=tuple(vol.shape)) * 1e-3)
+    (vol * gv).sum().backward()
+    # float64 reference
+    q = [T(sd[p_ + k], torch.float64).requires_grad_(not k.endswith(".adj")) for k in names]
+    w0, aw0, a0, b0, w1, aw1, a1, b1, w2, b2, w3, b3 = q
+    n = train_path.positional_encoding(train_path.axis_angle_to_rot6d(bones.double()), L)
+    mask = torch.ones(1, 24, 1, device=DEV, dtype=torch.float64)
+    mask[:, 0] = 0.
+    n = n * mask
+    y = torch.matmul((aw0 * a0)[0], torch.einsum("bkl,klj->bkj", n, w0)) + b0
+    n = torch.relu(y + y)
+    n = torch.relu(torch.matmul((aw1 * a1)[0], torch.einsum("bkl,klj->bkj", n, w1)) + b1)
+    n = torch.relu(torch.einsum("bkl,klj->bkj", n, w2) + b2)
+    ref = torch.einsum("bkl,klj->bkj", n, w3) + b3
+    (ref * gv.double()).sum().backward()
+    assert (vol.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    worst = 0.0
+    for k, a, r in zip(names, params, q):
+        if k.endswith(".adj"):
+            assert a.grad is None
+            continue
+        e = ((a.grad.double() - r.grad).abs().max() / (r.grad.abs().max() + 1e-300)).item()
+        worst = max(worst, e)
+        assert a.grad.shape == a.shape and e < 5e-5, (k, e)
+    print("pose_volumes op: worst parameter-gradient deviation from float64 (of the tensor's max):", worst)
+    # the route core/train_path.py takes for a DANBO module, against its layer-by-layer fall-back
+    torch.library.opcheck(torch.ops.danbo.pose_volumes, (bones, L, [t.detach() for t in params]), test_utils=("test_schema", "test_faketensor"))
+
+
+def test_autograd_path_operators_equal_the_layerwise_torch_route():
+    """core/train_path.py's differentiable caster forward on the three HIP operators (danbo.pose_volumes, danbo.assign_blend,
+    danbo.pe_mlp) against the same forward recorded layer by layer with torch / library GEMMs (the route a network of another
+    shape takes): loss terms and the gradient of EVERY parameter on the config-4 network.  (Round 3 kept this comparison as
+    DANBO_AUTOGRAD_*=library switches inside the product.)"""
+    from core import train_path
+    g = golden("danbo_perfcap_train")
+
+    def run(layerwise):
+        saved = (train_path._pose_op_params, train_path._assign_op_applies, train_path._fused_mlp_params)
+        if layerwise:
+            train_path._pose_op_params = lambda m: None
+            train_path._assign_op_applies = lambda m: False
+            train_path._fused_mlp_params = lambda m: None
+        try:
+            args, caster, trainer, opt = build_trainer(g)
+            caster.train()
+            b = batch_of(g)
+            kw = {k: v for k, v in trainer.render_kwargs_train.items() if k not in ("ray_caster", "use_viewdirs")}
+            preds = caster(trainer._ray_batch(b), kp_batch=b["kp3d"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=b["cam_idxs"],
+                           N_uniques=b["N_uniques"], **kw)
+            loss = trainer.compute_loss(b, preds)
+            caster.zero_grad()
+            loss["total_loss"].backward()
+        finally:
+            train_path._pose_op_params, train_path._assign_op_applies, train_path._fused_mlp_params = saved
+        return ({n: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for n, p in caster.network.named_parameters()},
+                {k: float(v.detach()) for k, v in loss.items()})
+    g_op, l_op = run(False)
+    g_lw, l_lw = run(True)
+    for k in l_op:
+        assert abs(l_op[k] - l_lw[k]) <= 2e-6 * max(abs(l_lw[k]), 1e-3), (k, l_op[k], l_lw[k])
+    worst, name = 0.0, ""
+    for n, r in g_lw.items():
+        e = float((g_op[n] - r).abs().max()) / (float(r.abs().max()) + 1e-30)
+        if e > worst:
+            worst, name = e, n
+        assert e < 1e-4, (n, e)
+    print("operators vs layer-by-layer torch route: worst gradient deviation (of the tensor's max)", worst, "in", name)
+
+
 def test_one_optimiser_step_changes_parameters_and_stays_finite():
     g = golden("danbo_train")
     args, caster, trainer, opt = build_trainer(g, extra=["--raw_noise_std", "1.0", "--perturb", "1.0"])

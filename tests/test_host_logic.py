@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/danbo_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
-    assert lib.danbo_abi_version() == 3
+    assert lib.danbo_abi_version() == 4
     # argument counts of the ctypes table match the header
     for name in declared:
         m = re.search(r"(?:int|size_t|long)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
@@ -477,6 +477,13 @@ def test_custom_operators_register_and_propagate_shapes_without_a_gpu():
           + [M(1, 256), M(1), M(256, 256), M(256), M(128, 256 + 155), M(128), M(3, 128), M(3)])
     raw = torch.ops.danbo.pe_mlp(M(n, 15), M(n, dt=torch.int32), M(R, 155), mp)
     assert tuple(raw.shape) == (n, 4)
+    # pose -> volumes
+    gp = [M(24, 66, 128), M(1, 24, 24), M(1, 24, 24), M(128), M(24, 128, 128), M(1, 24, 24), M(1, 24, 24), M(128), M(24, 128, 128), M(1, 24, 128),
+          M(24, 128, 240), M(1, 24, 240)]
+    vol, scratch = torch.ops.danbo.pose_volumes(M(G, 24, 3), 5, gp)
+    assert tuple(vol.shape) == (G, 24, 240) and scratch.numel() == 3 * G * 24 * 128
+    with pytest.raises(RuntimeError):
+        torch.ops.danbo.pose_volumes(torch.zeros(G, 24, 3), 5, [torch.zeros(1)] * 12)
     # A-NeRF chain (forward only)
     anp = ([M(448, 432)] + [M(448, 448)] * 4 + [M(448, 880)] + [M(448, 448)] * 2 + [M(448)] * 8
            + [M(1, 448), M(1), M(448, 448), M(448), M(224, 448 + 648 + 128), M(224), M(3, 224), M(3), M(24), M(24), M(20, 128)])

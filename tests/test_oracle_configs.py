@@ -105,7 +105,12 @@ def test_f64_training_step_reproduces_the_reference_losses_and_gradients(fixture
     near, far = orc.near_far(rb[:, 0:3], rb[:, 3:6], cyls, skts, rb[:, 6:7], rb[:, 7:8])
     z_c = o.coarse_z(near, far, S)
     batch = dict(rays_o=rb[:, 0:3], rays_d=rb[:, 3:6], skts=skts, bones=bones, target_s=g["target"], bgs=g["bgs"], cam_idxs=g["cam_idx"])
-    ret = t64.step(cfg, coef, sd, orc.align, np.abs(sd["graph_net.axis_scale"]), batch, z_c, None, None, int(g["n_uniques"]), Sf=Sf)
+    first = t64.step(cfg, coef, sd, orc.align, np.abs(sd["graph_net.axis_scale"]), batch, z_c, None, None, int(g["n_uniques"]), Sf=Sf)
+    # ... and again on those depths with the bracket of the ReLU-kink decisions (torch_f64_train.Kinks)
+    ret = t64.step_bracketed(cfg, coef, sd, orc.align, np.abs(sd["graph_net.axis_scale"]), batch, z_c, first["z_f"], first["order"],
+                             int(g["n_uniques"]))
+    assert np.array_equal(ret["rgb_map"], first["rgb_map"])
+    print("ambiguous ReLU units:", ret["ambiguous"])
     for k in ("rgb_loss", "rgb_loss0", "soft_softmax_loss", "vol_scale_loss", "total_loss"):
         if "loss/" + k in g.files:
             ref = float(g["loss/" + k])
@@ -126,11 +131,12 @@ def test_f64_training_step_reproduces_the_reference_losses_and_gradients(fixture
             else:
                 mine = ret["grads"][n]
             ref = g[key]
-            dev = np.abs(mine - ref) / (float(np.abs(ref).max()) + 1e-30)
-            e = float(dev.max())
+            scale = float(np.abs(ref).max()) + 1e-30
+            e = float(np.abs(mine - ref).max()) / scale
             worst_t = max(worst_t, e)
-            # fp32 vs float64 may sit on different sides of a ReLU kink for ONE (sample, unit) pair: that unit's row of the weight
-            # gradient then differs by the sample's whole contribution (danbo_perfcap_train: unit 26 of pts_linears.0, 0.9 % of
-            # the tensor's max, every other row <= 6e-4).  Allowed: < 0.5 % of a tensor's entries above 1e-3, none above 2e-2.
-            assert float((dev > 1e-3).mean()) < 5e-3 and e < 2e-2, (n, e, float((dev > 1e-3).mean()))
+            # 1e-3 of the tensor's max + what the ReLU units whose sign fp32 does not determine can move it by: the reference's
+            # fp32 autograd sits on one side of each of those kinks, float64 possibly on the other (danbo_perfcap_train: one
+            # (sample, unit) pair of pts_linears.0, 0.9 % of that tensor's max)
+            base = n.split("[")[0]
+            assert e <= 1e-3 + ret["bracket"][base] / scale, (n, e, ret["bracket"][base] / scale)
     print(fixture, "worst gradient-norm deviation", worst_n, "worst tensor deviation (of its max)", worst_t)
