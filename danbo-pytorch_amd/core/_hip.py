@@ -80,6 +80,8 @@ SIGNATURES = {
     "danbo_train_step": [P, P, P, P, c_size_t, P],
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
     "danbo_train_workspace_view": [P, I, I, I, I, I, P, P],
+    "danbo_group_rows": [P, P, P, I, P],
+    "danbo_assign16_set_trace": [P],
 }
 # everything else returns int (0 = ok)
 RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t,

@@ -124,6 +124,13 @@ def bone_cull(geo, compact=True):
     return bits, lst, cnt
 
 
+def group_rows(bits, lst, cnt):
+    """in place: rows of the compacted list whose samples lie inside the same set of bone volumes become neighbours
+    (csrc/k_group.hip) -- k_assign16 then evaluates ~1.7 instead of ~2.9 bones per wavefront"""
+    _call("danbo_group_rows", _p(bits), _p(lst), _p(cnt), lst.shape[0], _stream())
+    return lst
+
+
 def bone_gather(geo, volumes, lst=None, cnt=None, n=None):
     n = geo.M if n is None else n
     out = torch.empty(n, J, FEAT, device=geo.device, dtype=torch.float32)

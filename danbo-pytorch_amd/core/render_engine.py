@@ -30,6 +30,8 @@ class DanboEngine:
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
+        # re-order the compacted rows by bone set in front of K2 (k_group.hip); False: the cull kernel's order (profiling, tests)
+        self.group_rows = True
 
     # ------------------------------------------------------------------ derived buffers
     def _key(self):
@@ -174,6 +176,8 @@ class DanboEngine:
         cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
         S = geo.S
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense)
+        if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
+            ops.group_rows(bits, lst, cnt)
         if ready is not None:
             torch.cuda.current_stream().wait_event(ready[0])
         if self.mlp_mode == "f16split":

@@ -9,8 +9,9 @@
 // i.e. the 70-nonzero skeleton adjacency is folded into the layer-0 weights at pack time, and
 // the output tile of layer 0 (lane (m,h), reg r <-> channel 8(r>>2)+4h+(r&3)) is directly the B
 // fragment of layer 1.  Each lane computes 8 of the 15 gathered features of every bone for its
-// sample (h=0: features 0..7, h=1: 8..14) and keeps them as fp16 hi/lo fragments (192 VGPRs);
-// weights (236 KB in fragment order) stream through a 3-slot LDS ring shared by the workgroup.
+// sample (h=0: features 0..7, h=1: 8..14) as fp16 hi/lo fragments.
+// Weights (236 KB in fragment order, L2-resident): the 8 .. 14 one-KB pieces of a bone are loaded into registers by the
+// wavefront that evaluates it, and kept while the bone stays the same (see k_assign16 below).
 #include "common.hpp"
 
 namespace danbo {
@@ -19,7 +20,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int A16_CHUNK = 32768;
-constexpr int A16_SLOTS = 3;
 constexpr int A16_NCHUNK = 8;  // 236 pieces of 1 KB, padded to 256
 static_assert(A16_NCHUNK * A16_CHUNK == DANBO_ASSIGN16_PACKED_BYTES, "header constant out of date");
 constexpr int A16_BM = 128;    // samples per workgroup iteration (4 wavefronts x 32)
@@ -105,36 +105,54 @@ struct A16Args {
     float* confd;     // [n][24] or NULL
     // TRAIN instantiation only (danbo_gather_assign_blend16_train):
     const int32_t* first;   // device scalar: rows [*first, count) of list / h_out / confd are processed, or nullptr (0)
+    long long* trace;       // dev tool (tools/micro_assign.py --trace): s_memtime stamps of one wavefront, or nullptr
 };
 
-constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16;  // + one pose's volumes and transforms
-constexpr int A16_LDS_BYTES = A16_SLOTS * A16_CHUNK + ((A16_TABLE_FLOATS * 4 + 15) & ~15);
+// per bone: neighbours (self first), number of layer-0 terms, first 1-KB piece of the packed stream
+constexpr int A16_NBI = 8;        // ints per bone: nb[0..4], nq = deg + 1, piece0, pad
+constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16 + J * A16_NBI + J * 4;
+constexpr int A16_LDS_BYTES = (A16_TABLE_FLOATS * 4 + 15) & ~15;
+constexpr int A16_TILE_RUN = 4;   // consecutive 128-row tiles a workgroup takes at a time (the rows are grouped by bone set,
+                                  // k_group.hip: neighbouring tiles need the same bones, whose weights stay in registers)
 
-struct APipe {
-    const char* packed;
-    char* ring;
-    int issue_chunk, issue_slot, cons_slot, wave, lane;
-};
-
-__device__ __forceinline__ void apipe_issue(APipe& p) {
-    const char* src = p.packed + (size_t)p.issue_chunk * A16_CHUNK + p.wave * 8192 + p.lane * 16;
-    char* dst = p.ring + p.issue_slot * A16_CHUNK + p.wave * 8192;
+// One bone's 15 windowed features for K2's matrix-core operands: the same quantities as sample_math.hpp's bone_local +
+// gather_bone_features (reference core/encoders.py:288-303,442-444, gnn_backbone.py:802-826, misc.py:331-351) in ~320 instead of
+// ~400 instructions -- the feature phase is VALU-issue bound (s_memtime trace, kernel comment below).
+// What may NOT change is the rounding sequence point -> x -> interpolation weight: the reference forms the cell coordinate as
+// ((x + 1) res - 1) / 2 in fp32, whose first addition quantises x to 1.2e-7 ABSOLUTE, the weight inherits 1e-6, and the blended
+// feature goes through sin(32 h) and the MLP -- a mathematically better x (fused transforms, one fma for the coordinate) moved the
+// raw logits by 1e-4 of their range, the whole north_star budget.  So: the two rigid transforms unfused in the reference's order,
+// x = p / |scale| correctly rounded (Markstein: q = p r, q + fma(-q, s, p) r with r = RN(1 / s) from the table), the coordinate in
+// the reference's order, exp by expf.  What does change, at the 1e-7 level: the window and the zero padding are folded into the two
+// interpolation weights of each axis (one multiply + one fma per feature, unconditional clamped reads).
+// The LDS (staged pose) and the global (another pose inside the tile) route run THIS code: a row's result does not depend on
+// which one it takes.  abs_scale: [4] = |scale_x|, |scale_y|, |scale_z|, -; inv_scale likewise.
+template <typename VolPtr>
+__device__ __forceinline__ void a16_bone_features(const float* __restrict__ skt, const float* __restrict__ align, VolPtr vol,
+                                                  const float* __restrict__ abs_scale, const float* __restrict__ inv_scale,
+                                                  const float* pnt, float* out) {
+    float pt[3], x[3];
+    bone_local(skt, align, pnt, pt);
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-    p.issue_chunk = p.issue_chunk + 1 == A16_NCHUNK ? 0 : p.issue_chunk + 1;
-    p.issue_slot = p.issue_slot + 1 == A16_SLOTS ? 0 : p.issue_slot + 1;
-}
-
-__device__ __forceinline__ const char* apipe_begin(APipe& p) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    apipe_issue(p);
-    const char* base = p.ring + p.cons_slot * A16_CHUNK + p.lane * 16;
-    p.cons_slot = p.cons_slot + 1 == A16_SLOTS ? 0 : p.cons_slot + 1;
-    return base;
+    for (int k = 0; k < 3; ++k) {
+        const float q = mul_rn(pt[k], inv_scale[k]);
+        x[k] = fmaf(fmaf(-q, abs_scale[k], pt[k]), inv_scale[k], q);
+    }
+    const float win = coord_window(x);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float iy = mul_rn(sub_rn(mul_rn(add_rn(x[k], 1.0f), (float)VRES), 1.0f), 0.5f);
+        const float fl = floorf(iy);
+        const float w1 = sub_rn(iy, fl);
+        // clamp before the int conversion: far-away samples have |iy| ~ 1e3..1e6
+        const int y0 = (int)fminf(fmaxf(fl, -2.0f), (float)VRES + 1.0f);
+        const int y1 = y0 + 1;
+        const bool ok0 = (unsigned)y0 < (unsigned)VRES, ok1 = (unsigned)y1 < (unsigned)VRES;
+        const float a0 = ok0 ? mul_rn(sub_rn(1.0f, w1), win) : 0.f, a1 = ok1 ? mul_rn(w1, win) : 0.f;
+        const int c0 = (ok0 ? y0 : 0) * 3 + k, c1 = (ok1 ? y1 : 0) * 3 + k;
+#pragma unroll
+        for (int f = 0; f < VOXF; ++f) out[f * 3 + k] = fmaf(vol[f * (VRES * 3) + c1], a1, mul_rn(vol[f * (VRES * 3) + c0], a0));
+    }
 }
 
 __device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo) {
@@ -146,16 +164,21 @@ __device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo)
     }
 }
 
-__device__ __forceinline__ half8 a16_frag(const char* base, int piece_in_chunk) {
-    return *reinterpret_cast<const half8*>(base + piece_in_chunk * 1024);
-}
-
+// Round 4 structure.  A wavefront = 32 rows (lane = row + 32 * half) and loops, at RUN time, over the bones valid for at least
+// one of them (grouped rows: 1.7 on the bench frame).  Per bone j: the features of j and its tree neighbours are gathered for
+// the wavefront's samples (lane half h takes neighbour 2t + h, the halves then trade 8 values: the B-fragment layout), the
+// 2 (deg + 1) + 4 weight fragments of the bone sit in registers -- loaded from L2 only when the bone differs from the one the
+// wavefront evaluated last -- and the three layers, the masked sigmoid and the blend follow as before.
+// Rounds 1-3 unrolled the bone loop 24 x at compile time (features of all 24 bones in 192 registers, 495 VGPRs = one wavefront
+// per SIMD, 27 000 instructions = three times the instruction cache) and streamed all 236 KB of weights through an LDS ring per
+// 128-row tile.  An s_memtime trace (tools/micro_assign.py --trace) put 55-70 % of a tile into the feature phase at ~13 cycles
+// per instruction: latency nothing covered.  Now: ~2 500 instructions, <= 256 VGPRs and 34 KB of LDS = two wavefronts per SIMD.
 // TRAIN: device-side first row, and the pad slot h[15] receives q = sum_j p_j valid_j (the row's assignment mass, which the
 // soft-softmax loss compares with its label -- reference core/trainer.py:507-536)
 template <bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
+__global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_b0 = reinterpret_cast<float*>(smem + A16_SLOTS * A16_CHUNK);  // [32]
+    float* s_b0 = reinterpret_cast<float*>(smem);                          // [32]
     float* s_b1 = s_b0 + 32;                                               // [24][32]
     float* s_w2 = s_b1 + J * 32;                                           // [24][32]
     float* s_b2 = s_w2 + J * 32;                                           // [24]
@@ -163,6 +186,8 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
     float* s_scale = s_align + J * 16;                                     // [24][4]
     float* s_vol = s_scale + J * 4 + 8;                                    // [24][240] volumes of the staged pose (16-B aligned)
     float* s_skt = s_vol + J * VOL;                                        // [24][16]  its bone transforms
+    int* s_nbi = reinterpret_cast<int*>(s_skt + J * 16);                   // [24][8]
+    float* s_inv = reinterpret_cast<float*>(s_nbi + J * A16_NBI);          // [24][4] RN(1 / |scale|)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hh = lane >> 5;
@@ -170,7 +195,21 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
     for (int i = tid; i < J * 32; i += 256) { s_b1[i] = a.b1[i]; s_w2[i] = a.w2[i]; }
     if (tid < J) s_b2[tid] = a.b2[tid];
     for (int i = tid; i < J * 16; i += 256) s_align[i] = a.align[i];
-    for (int i = tid; i < J * 4; i += 256) s_scale[i] = (i & 3) < 3 ? fabsf(a.axis_scale[(i >> 2) * 3 + (i & 3)]) : 1.f;
+    for (int i = tid; i < J * 4; i += 256) {
+        s_scale[i] = (i & 3) < 3 ? fabsf(a.axis_scale[(i >> 2) * 3 + (i & 3)]) : 1.f;
+        s_inv[i] = div_rn(1.0f, s_scale[i]);
+    }
+    if (tid < J) {
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj)
+            if (jj == tid) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) s_nbi[jj * A16_NBI + q] = a16_nb(jj, q) < 0 ? jj : a16_nb(jj, q);
+                s_nbi[jj * A16_NBI + 5] = a16_deg(jj) + 1;
+                s_nbi[jj * A16_NBI + 6] = a16_piece0(jj);
+                s_nbi[jj * A16_NBI + 7] = 0;
+            }
+    }
     __syncthreads();
 
     int n = resolve_count(a.count, a.n_cap);
@@ -182,55 +221,82 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
         if (a.confd != nullptr) a.confd += (size_t)f0 * J;
     }
     const int ntiles = (n + A16_BM - 1) / A16_BM;
-    if ((int)blockIdx.x >= ntiles) return;
-
-    APipe p;
-    p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave; p.lane = lane;
-    apipe_issue(p);
-    apipe_issue(p);
+    if ((int)blockIdx.x * A16_TILE_RUN >= ntiles) return;
     const long spp = (long)(a.R / a.G) * a.S;
 
-    // Per-tile inputs are fetched one tile ahead: list entry -> (valid bits, sample point) is a chain of two dependent
-    // HBM round trips (about 9 000 cycles with nothing to hide them behind at one wavefront per SIMD).
-    struct TileIn {
-        int ms;
-        uint32_t bits;
-        float pnt[3];
+    // tile sequence of this workgroup: runs of A16_TILE_RUN consecutive tiles, the runs round-robin over the workgroups
+    auto next_tile = [&](int t) {
+        const int t1 = t + 1;
+        return (t1 % A16_TILE_RUN) != 0 ? t1 : (t / A16_TILE_RUN + (int)gridDim.x) * A16_TILE_RUN;
     };
-    auto load_ms = [&](int tile_) {
-        const int row_ = tile_ * A16_BM + wave * 32 + m;
+    // Per-tile inputs are fetched one tile ahead: list entry -> (valid bits, ray, depth) is a chain of two dependent HBM round
+    // trips.  The record keeps what was LOADED (the point o + d z is formed when the tile starts): anything computed from the
+    // loads here would make the compiler wait for them here -- the round-3 kernel formed the point at once and stalled a full
+    // round trip per tile on its own "prefetch" (s_memtime trace: 2 000 of a tile's 7 500 ticks).
+    struct TileIn {
+        int ms, first_ms;
+        uint32_t bits;
+        float o[3], d[3], z;
+    };
+    const bool multi_pose = a.G > 1;      // (one pose: every row's pose index is 0, no look-up of the tile's first row)
+    const unsigned spp32 = (unsigned)spp;
+    auto load_ms = [&](int tile_, int& first_) {
+        const int t_ = tile_ < ntiles ? tile_ : ntiles - 1;
+        const int row_ = t_ * A16_BM + wave * 32 + m;
         const int rowc_ = row_ < n ? row_ : n - 1;
+        first_ = 0;
+        if (multi_pose) first_ = a.list ? a.list[t_ * A16_BM] : t_ * A16_BM;          // (tile starts are < n)
         return a.list ? a.list[rowc_] : rowc_;
     };
-    auto load_rest = [&](int ms_, TileIn& t) {
+    auto load_rest = [&](int ms_, int first_, TileIn& t) {
         t.ms = ms_;
+        t.first_ms = first_;
         t.bits = a.valid_bits[ms_];
         if (a.pts != nullptr) {
-            t.pnt[0] = a.pts[3 * (size_t)ms_]; t.pnt[1] = a.pts[3 * (size_t)ms_ + 1]; t.pnt[2] = a.pts[3 * (size_t)ms_ + 2];
+            t.o[0] = a.pts[3 * (size_t)ms_]; t.o[1] = a.pts[3 * (size_t)ms_ + 1]; t.o[2] = a.pts[3 * (size_t)ms_ + 2];
+            t.d[0] = t.d[1] = t.d[2] = 0.f;
+            t.z = 0.f;
         } else {
-            const int r = ms_ / a.S;
-            const float o[3] = {a.rays_o[3 * r], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2]};
-            const float d[3] = {a.rays_d[3 * r], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2]};
-            sample_point(o, d, a.z[ms_], t.pnt);
+            const int r = (int)((unsigned)ms_ / (unsigned)a.S);
+            t.o[0] = a.rays_o[3 * r]; t.o[1] = a.rays_o[3 * r + 1]; t.o[2] = a.rays_o[3 * r + 2];
+            t.d[0] = a.rays_d[3 * r]; t.d[1] = a.rays_d[3 * r + 1]; t.d[2] = a.rays_d[3 * r + 2];
+            t.z = a.z[ms_];
         }
     };
     int g_lds = -1;
+    const int tile0 = blockIdx.x * A16_TILE_RUN;
     TileIn cur;
-    load_rest(load_ms(blockIdx.x), cur);
-    int ms_next = load_ms(min((int)(blockIdx.x + gridDim.x), ntiles - 1));
+    int first_next = 0;
+    {
+        const int ms0 = load_ms(tile0, first_next);
+        load_rest(ms0, first_next, cur);
+    }
+    int ms_next = load_ms(next_tile(tile0), first_next);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the weight fragments of the bone this wavefront evaluated last: layer 0 (<= 5 neighbour terms x hi, lo), layer 1 (2 k-steps x hi, lo)
+    half8 w0[10], w1[4];
+    int w_bone = -1;
+
+    int tr = 0, it = 0;
+    auto stamp = [&](int tag) {    // workgroup 7, wavefront 1, its tiles 2 .. 5: (tag, s_memtime) pairs
+        if (a.trace != nullptr && blockIdx.x == 7 && wave == 1 && it >= 2 && it < 6 && lane == 0 && tr < 250) {
+            a.trace[tr++] = tag;
+            a.trace[tr++] = (long long)__builtin_amdgcn_s_memtime();
+        }
+    };
+    for (int tile = tile0; tile < ntiles; tile = next_tile(tile), ++it) {
+        stamp(0);
         const int row = tile * A16_BM + wave * 32 + m;
         const bool row_ok = row < n;
         const int ms = cur.ms;
         const uint32_t bits = cur.bits;
-        const int g = (int)min((long)ms / spp, (long)a.G - 1);
-        const float pnt[3] = {cur.pnt[0], cur.pnt[1], cur.pnt[2]};
+        const int g = multi_pose ? (int)min((unsigned)ms / spp32, (unsigned)a.G - 1u) : 0;
+        float pnt[3];
+        if (a.pts != nullptr) { pnt[0] = cur.o[0]; pnt[1] = cur.o[1]; pnt[2] = cur.o[2]; }
+        else sample_point(cur.o, cur.d, cur.z, pnt);
         // the pose of the tile's first row: its volumes (23 KB) and transforms are staged in LDS -- the 30 interpolation
-        // taps per bone then cost LDS latency instead of an L2 round trip that nothing hides at one wavefront per SIMD
-        const int first_row = tile * A16_BM;
-        const int first_ms = a.list ? a.list[first_row < n ? first_row : n - 1] : first_row;   // workgroup-uniform
-        const int g_tile = (int)min((long)first_ms / spp, (long)a.G - 1);
+        // taps per bone then cost LDS latency instead of an L2 round trip
+        const int g_tile = multi_pose ? (int)min((unsigned)__builtin_amdgcn_readfirstlane(cur.first_ms) / spp32, (unsigned)a.G - 1u) : 0;
         if (g_tile != g_lds) {
             __syncthreads();  // nobody still reads the previous pose
             const float4* srcv = reinterpret_cast<const float4*>(a.volumes + (size_t)g_tile * J * VOL);
@@ -241,85 +307,74 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
         }
         // stage 2 of the NEXT tile (its list entry was requested a tile ago) and stage 1 of the one after
         TileIn nxt;
-        load_rest(ms_next, nxt);
-        ms_next = load_ms(min(tile + 2 * (int)gridDim.x, ntiles - 1));
+        load_rest(ms_next, first_next, nxt);
+        ms_next = load_ms(next_tile(next_tile(tile)), first_next);
         // ---------------------------------------------------------------- which bones matter here
-        // A bone's logit only enters the blend where that bone is valid (p_j = s(a_j) * valid_j), so
-        // for this wavefront only bones valid for >= 1 of its 32 samples are evaluated (all 24 when
-        // the caller wants confd); their layer-0 inputs are the features of those bones and of
-        // their tree neighbours.  Everything else is skipped wave-uniformly -- exact, not approximate.
-        uint32_t need_gnn = 0;
-        {
-            const uint32_t mybits = row_ok ? bits : 0u;
-#pragma unroll
-            for (int j = 0; j < J; ++j) need_gnn |= (__ballot((mybits >> j) & 1u) != 0ull ? 1u : 0u) << j;
-            if (a.confd != nullptr) need_gnn = (1u << J) - 1u;
-        }
-        uint32_t need_feat = 0;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            uint32_t nbmask = 0;
-#pragma unroll
-            for (int q = 0; q <= a16_deg(j); ++q) nbmask |= 1u << a16_nb(j, q);
-            if ((need_gnn >> j) & 1u) need_feat |= nbmask;
-        }
-        // ---------------------------------------------------------------- per-bone features
-        // lane half h evaluates bones 2i + h completely (transform, window, 15-feature gather --
-        // the same gather_bone_features() as K1b), then the halves trade 8 values so that lane
-        // (m, h) ends up with features 8h..8h+7 of BOTH bones: the B-fragment layout.
-        half8 fh[J], fl[J];
-#pragma unroll
-        for (int i = 0; i < J / 2; ++i) {
-            if (((need_feat >> (2 * i)) & 3u) == 0u) continue;  // wave-uniform
-            const int jb = 2 * i + hh;
-            float pt[3], f[16];
-            if (g == g_lds) {
-                bone_local(s_skt + 16 * jb, s_align + 16 * jb, pnt, pt);
-                gather_bone_features(s_vol + jb * VOL, pt, s_scale + 4 * jb, f);
-            } else {  // a row of another pose inside this tile (multi-pose chunks only): through L1 / L2
-                float sk[12];
-                const float* src = a.skts + ((size_t)g * J + jb) * 16;
-#pragma unroll
-                for (int q = 0; q < 12; ++q) sk[q] = src[q];
-                bone_local(sk, s_align + 16 * jb, pnt, pt);
-                gather_bone_features(a.volumes + ((size_t)g * J + jb) * VOL, pt, s_scale + 4 * jb, f);
-            }
-            f[15] = 0.f;
-            float keep[8], recv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                keep[e] = hh ? f[8 + e] : f[e];                       // my half of my own bone
-                recv[e] = lane_xor32(hh ? f[e] : f[8 + e]);           // my half of the partner's bone
-            }
-            // bone 2i: half 0 keeps, half 1 receives; bone 2i+1: the other way round
-            float even[8], odd[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                even[e] = hh ? recv[e] : keep[e];
-                odd[e] = hh ? keep[e] : recv[e];
-            }
-            a16_split8(even, fh[2 * i], fl[2 * i]);
-            a16_split8(odd, fh[2 * i + 1], fl[2 * i + 1]);
-            // two bone pairs at a time: without a fence hipcc hoists every bone's loads and spills
-            if (i & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---------------------------------------------------------------- assignment GNN + blend
+        // A bone's logit only enters the blend where that bone is valid (p_j = s(a_j) * valid_j), so for this wavefront only
+        // bones valid for >= 1 of its 32 samples are evaluated (all 24 when the caller wants confd) -- exact, not approximate.
+        uint32_t todo = wave_or(row_ok ? (bits & ((1u << J) - 1u)) : 0u);
+        if (a.confd != nullptr) todo = (1u << J) - 1u;
+        stamp(1);
         float hacc[8];
         float qsum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) hacc[e] = 0.f;
-        const char* base = nullptr;
+        while (todo != 0u) {            // wave-uniform
+            const int j = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            const int nq = __builtin_amdgcn_readfirstlane(s_nbi[j * A16_NBI + 5]);
+            stamp(100 + j);
+            // ---- the bone's weight fragments (L2-resident stream, 1 KB per piece = 16 B per lane) ----
+            if (j != w_bone) {
+                const char* src = a.packed + (size_t)__builtin_amdgcn_readfirstlane(s_nbi[j * A16_NBI + 6]) * 1024 + lane * 16;
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int p0 = a16_piece0(j);
-            const int nq = a16_deg(j) + 1;
-            const int pend = p0 + 2 * nq + 4;
-            if (((need_gnn >> j) & 1u) == 0u) {
-                // skipped bone: still take part in the weight ring (every wavefront must hit the
-                // same barriers); at most one chunk boundary falls inside a bone's <= 14 pieces
-                if (((p0 + 31) & ~31) < pend) base = apipe_begin(p);
-                continue;
+                for (int q = 0; q < 5; ++q)
+                    if (q < nq) {
+                        w0[2 * q] = *reinterpret_cast<const half8*>(src + (2 * q) * 1024);
+                        w0[2 * q + 1] = *reinterpret_cast<const half8*>(src + (2 * q + 1) * 1024);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const half8*>(src + (2 * nq + i) * 1024);
+                w_bone = j;
             }
+            // ---- features of the bone and its tree neighbours ----
+            // lane half h evaluates neighbour 2t + h completely (transform, window, 15-feature gather -- the same
+            // gather_bone_features() as K1b), then the halves trade 8 values so that lane (m, h) ends up with features
+            // 8h .. 8h+7 of BOTH bones: the B-fragment layout.
+            half8 fh[6], fl[6];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (2 * t >= nq) break;     // wave-uniform
+                const int qm = 2 * t + hh < nq ? 2 * t + hh : nq - 1;       // (an odd count: the last half repeats a neighbour, unused)
+                const int jb = s_nbi[j * A16_NBI + qm];
+                float f[16];
+                if (g == g_lds) {
+                    a16_bone_features(s_skt + 16 * jb, s_align + 16 * jb, s_vol + jb * VOL, s_scale + 4 * jb, s_inv + 4 * jb, pnt, f);
+                } else {  // a row of another pose inside this tile (multi-pose chunks only): through L1 / L2
+                    float sk[12];
+                    const float* srcp = a.skts + ((size_t)g * J + jb) * 16;
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) sk[q] = srcp[q];
+                    a16_bone_features(sk, s_align + 16 * jb, a.volumes + ((size_t)g * J + jb) * VOL, s_scale + 4 * jb, s_inv + 4 * jb, pnt, f);
+                }
+                f[15] = 0.f;
+                float keep[8], recv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    keep[e] = hh ? f[8 + e] : f[e];                       // my half of my own bone
+                    recv[e] = lane_xor32(hh ? f[e] : f[8 + e]);           // my half of the partner's bone
+                }
+                // neighbour 2t: half 0 keeps, half 1 receives; neighbour 2t+1: the other way round
+                float even[8], odd[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    even[e] = hh ? recv[e] : keep[e];
+                    odd[e] = hh ? keep[e] : recv[e];
+                }
+                a16_split8(even, fh[2 * t], fl[2 * t]);
+                a16_split8(odd, fh[2 * t + 1], fl[2 * t + 1]);
+            }
+            stamp(200 + j);
             // ---- layer 0 with the adjacency folded in; accumulator starts at the shared bias ----
             f32x16 acc;
 #pragma unroll
@@ -328,15 +383,12 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
                 acc[4 * jj] = b.x; acc[4 * jj + 1] = b.y; acc[4 * jj + 2] = b.z; acc[4 * jj + 3] = b.w;
             }
 #pragma unroll
-            for (int q = 0; q < nq; ++q) {
-                const int piece = p0 + 2 * q;
-                if ((piece & 31) == 0) base = apipe_begin(p);
-                const half8 ah = a16_frag(base, piece & 31), al = a16_frag(base, (piece & 31) + 1);
-                const int jp = a16_nb(j, q);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[jp], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[jp], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[jp], acc, 0, 0, 0);
-            }
+            for (int q = 0; q < 5; ++q)
+                if (q < nq) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q], fh[q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q], fl[q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q + 1], fh[q], acc, 0, 0, 0);
+                }
             // ---- relu -> layer-1 B fragments ----
             float v[16];
 #pragma unroll
@@ -353,12 +405,9 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int piece = p0 + 2 * nq + 2 * ks;
-                if ((piece & 31) == 0) base = apipe_begin(p);
-                const half8 ah = a16_frag(base, piece & 31), al = a16_frag(base, (piece & 31) + 1);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, zh[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, zl[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, zh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[2 * ks], zh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[2 * ks], zl[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[2 * ks + 1], zh[ks], acc, 0, 0, 0);
             }
             // ---- layer 2 (32 -> 1): half dot per lane, halves combined by one shuffle ----
             const float* w2 = s_w2 + j * 32 + 4 * hh;
@@ -373,14 +422,16 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
             }
             const float logit = (part + lane_xor32(part)) + s_b2[j];
             if (a.confd != nullptr && row_ok && hh == 0) a.confd[(size_t)row * J + j] = logit;
-            // ---- masked sigmoid + blend of this lane's 8 features ----
+            // ---- masked sigmoid + blend of this lane's 8 features (neighbour 0 is the bone itself) ----
             const float valid = ((bits >> j) & 1u) ? 1.0f : 0.0f;
-            const float pj = (sigmoidf_(logit) * 1.002f - 0.001f) * valid;
+            // sigmoid through v_exp_f32 / v_rcp_f32 (1 ulp each; p enters h = sum p_j f_j, compared at 5e-6)
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit * -1.44269504088896340736f));
+            const float pj = (sg * 1.002f - 0.001f) * valid;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hacc[e] = fmaf(pj, (float)fh[j][e] + (float)fl[j][e], hacc[e]);
+            for (int e = 0; e < 8; ++e) hacc[e] = fmaf(pj, (float)fh[0][e] + (float)fl[0][e], hacc[e]);
             if (TRAIN) qsum += pj;
-            __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(3);
         if (row_ok) {
             float4* dst = reinterpret_cast<float4*>(a.h_out + (size_t)row * DANBO_H_STRIDE + 8 * hh);
             dst[0] = make_float4(hacc[0], hacc[1], hacc[2], hacc[3]);
@@ -388,13 +439,19 @@ __global__ __launch_bounds__(256, 1) void k_assign16(A16Args a) {
         }
         cur = nxt;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace danbo
 
 using namespace danbo;
+
+static long long* g_a16_trace = nullptr;
+/* dev tool: a buffer of 256 int64 that receives (tag, s_memtime) stamps of one wavefront of k_assign16 (tags: 0 tile start, 1 inputs
+ * and bone masks ready, 2 features done, 100 + j before / 200 + j after the wait for bone j's weights, 3 all bones done); NULL: off */
+extern "C" int danbo_assign16_set_trace(void* buf) {
+    g_a16_trace = (long long*)buf;
+    return 0;
+}
 
 extern "C" int danbo_assign16_pack(const float* w0, const float* adjw, const float* w1, void* packed16, void* stream) {
     DANBO_CHECK_ARG(w0 && adjw && w1 && packed16);
@@ -414,10 +471,10 @@ extern "C" int danbo_gather_assign_blend16_fwd(const float* rays_o, const float*
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, pts, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr};
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr, g_a16_trace};
     DANBO_ENSURE_LDS(k_assign16<false>, A16_LDS_BYTES);
-    const int ntiles = ceil_div(n, A16_BM);
-    const int grid = ntiles < num_cu() ? ntiles : num_cu();
+    const int nruns = ceil_div(ceil_div(n, A16_BM), A16_TILE_RUN);
+    const int grid = nruns < 2 * num_cu() ? nruns : 2 * num_cu();      // two workgroups per CU (launch bounds)
     hipLaunchKernelGGL(k_assign16<false>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
@@ -431,10 +488,10 @@ extern "C" int danbo_gather_assign_blend16_train(const float* rays_o, const floa
     DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && list && count && z && R > 0 && S > 0 && G > 0 && R % G == 0);
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, nullptr, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first};
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first, nullptr};
     DANBO_ENSURE_LDS(k_assign16<true>, A16_LDS_BYTES);
-    const int ntiles = ceil_div(n, A16_BM);
-    const int grid = ntiles < num_cu() ? ntiles : num_cu();
+    const int nruns = ceil_div(ceil_div(n, A16_BM), A16_TILE_RUN);
+    const int grid = nruns < 2 * num_cu() ? nruns : 2 * num_cu();
     hipLaunchKernelGGL(k_assign16<true>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

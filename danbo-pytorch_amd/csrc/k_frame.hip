@@ -89,6 +89,7 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
         zero_words(count, 1, nullptr, 0, st);
         DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, bits, b.list, count, stream));
+        DANBO_TRY(danbo_group_rows(bits, b.list, count, R * s, stream));     // rows of the same bone set next to each other (k_group.hip)
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,
                                                   bits, b.list, count, R * s, m->assign16, m->a_b0, m->a_b1, m->a_w2, m->a_b2, b.h,
                                                   nullptr, stream));

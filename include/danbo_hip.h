@@ -29,8 +29,8 @@ extern "C" {
 #define DANBO_H_STRIDE 16   /* blended feature rows are padded 15 -> 16 floats      */
 
 /* library / device identification (host only).
- * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view
- * (additive). */
+ * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
+ * danbo_group_rows (additive). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -126,6 +126,17 @@ int danbo_gather_assign_blend_fwd(const float* rays_o, const float* rays_d, cons
                                   const float* w0, const float* adjw, const float* b0,
                                   const float* w1, const float* b1, const float* w2, const float* b2,
                                   float* h, float* confd, void* stream);
+
+/* In-place re-ordering of the compacted in-volume rows (list[0 .. *count)) so that rows whose samples lie inside the SAME SET of
+ * bone volumes (equal valid_bits words) are neighbours, inside windows of 16 384 rows (csrc/k_group.hip).  No reference
+ * counterpart: the reference evaluates every sample against every bone (core/networks/gnn_backbone.py:787-828); this serves the
+ * launch that follows -- danbo_gather_assign_blend16_fwd evaluates, per wavefront of 32 consecutive rows, every bone valid for
+ * at least one of them.  The order of the list is free: every consumer (the h rows, K3's scatter) goes through it and a row's
+ * result does not depend on its neighbours.  count: device scalar or NULL (= n_cap rows). */
+int danbo_group_rows(const uint32_t* valid_bits, int32_t* list, const int32_t* count, int n_cap, void* stream);
+/* dev tool (tools/micro_assign.py --trace): int64[256] device buffer for (tag, s_memtime) stamps of one wavefront of
+ * danbo_gather_assign_blend16_fwd, NULL = off */
+int danbo_assign16_set_trace(void* buf);
 
 /* K1b + K2, fast variant (csrc/k_assign16.hip): same contract as danbo_gather_assign_blend_fwd with the
  * two per-bone GEMMs on fp16 hi/lo-split MFMAs (fp32 accumulate) and the skeleton adjacency folded

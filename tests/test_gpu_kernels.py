@@ -493,3 +493,58 @@ def test_render_frame_c_entry_point_equals_the_python_chain():
     eng.cfg["use_volume_near_far"] = False
     assert _hip.lib().danbo_render_frame_workspace(6000, 1, 48, 16, 4096, 128) > 6000 * 64 * 16
     assert _hip.lib().danbo_render_frame(None, None, 48, 16, None, None, 0, None) == -22
+
+
+def test_group_rows_is_a_permutation_that_groups_equal_bone_sets(ops):
+    """danbo_group_rows (csrc/k_group.hip): inside each window of 16 384 compacted rows the list becomes a permutation of itself in
+    which rows with the same in-volume word are contiguous and the sets are ordered by their bit-reversed value; rows beyond the
+    device-side count are untouched; a window with more distinct sets than the kernel's table keeps its order"""
+    W = 16384
+    rng = np.random.default_rng(0)
+    M = 5 * W + 777
+    n = 3 * W + 1234                         # three full windows + a partial one; the rest of the list is capacity
+    # ~40 distinct bone sets with a skewed frequency, as a frame has them
+    sets = np.unique(rng.integers(1, 1 << 24, size=60, dtype=np.int64) & rng.integers(1, 1 << 24, size=60, dtype=np.int64))
+    sets = sets[sets != 0][:40]
+    bits_np = sets[np.minimum((rng.exponential(6.0, size=M)).astype(np.int64), len(sets) - 1)].astype(np.uint32)
+    lst_np = rng.permutation(M).astype(np.int32)             # row -> sample, any order
+    bits, lst, cnt = T(bits_np.astype(np.int64), torch.int64).to(torch.int32), T(lst_np, torch.int32), T([n], torch.int32)
+    before = lst.clone()
+    ops.group_rows(bits, lst, cnt)
+    out = N(lst)
+    assert np.array_equal(out[n:], lst_np[n:])
+    for w0 in range(0, n, W):
+        a, b = out[w0:min(w0 + W, n)], lst_np[w0:min(w0 + W, n)]
+        assert np.array_equal(np.sort(a), np.sort(b))                                  # same rows
+        key = bits_np[a]
+        runs = 1 + int((key[1:] != key[:-1]).sum())
+        assert runs == len(np.unique(key)), (w0, runs, len(np.unique(key)))             # each set is ONE run
+        firsts = key[np.concatenate([[True], key[1:] != key[:-1]])].astype(np.uint32)
+        rev = np.array([int(format(int(k), "032b")[::-1], 2) for k in firsts])
+        assert np.all(np.diff(rev) > 0)                                                 # ordered by bit-reversed set
+    # more than 1024 distinct sets in a window: left alone
+    bits2 = T(rng.integers(1, 1 << 24, size=M), torch.int64).to(torch.int32)
+    lst2 = before.clone()
+    ops.group_rows(bits2, lst2, cnt)
+    assert torch.equal(lst2, before)
+
+
+def test_render_is_bitwise_independent_of_the_row_order(stage):
+    """the re-ordering in front of K2 must not change a single bit of the frame (a row's result does not depend on the rows it
+    shares a wavefront with)"""
+    from core.utils import synthetic as syn
+    eng = stage["eng"]
+    scene = syn.make_scene(n_poses=2, H=96, W=96, n_views=2, pose_seed=4)
+    ro = np.concatenate([scene["rays"][0][0], scene["rays"][1][0]])
+    rd = np.concatenate([scene["rays"][0][1], scene["rays"][1][1]])
+    args = (T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(scene["cyls"]), torch.zeros(len(ro), dtype=torch.int64, device=DEV))
+    assert eng.group_rows is True
+    a = eng.render(*args, 24, 12, keep=True)
+    eng.group_rows = False
+    try:
+        b = eng.render(*args, 24, 12, keep=True)
+    finally:
+        eng.group_rows = True
+    assert int(a["count_coarse"].item()) == int(b["count_coarse"].item()) > 20000      # more than one window of 16 384 rows
+    for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "alpha0", "raw_coarse", "raw_fine", "z_fine"):
+        assert torch.equal(a[k], b[k]), k

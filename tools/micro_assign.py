@@ -37,3 +37,28 @@ raw = torch.zeros(geo.M, 4, device="cuda")
 cview, raw_empty = eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"])
 print("mlp16           ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, ls, None, n)))
 print("mlp16 cap=M     ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, cnt, geo.M)))
+
+# grouped rows (k_group.hip) and the s_memtime trace of one wavefront
+lg = lst.clone()
+print("group_rows      ms", timeit(lambda: ops.group_rows(bits, lg, cnt)))
+print("assign16 grouped ms", timeit(lambda: ops.gather_assign_blend16(geo, vols, bits, eng.aw, eng.assign16, lg, cnt, geo.M)))
+if "--trace" in sys.argv:
+    import ctypes
+    from core import _hip
+    for name, l_ in (("cull order", lst), ("grouped", lg)):
+        buf = torch.zeros(256, dtype=torch.int64, device="cuda")
+        _hip.lib().danbo_assign16_set_trace(ctypes.c_void_p(buf.data_ptr()))
+        ops.gather_assign_blend16(geo, vols, bits, eng.aw, eng.assign16, l_, cnt, geo.M)
+        torch.cuda.synchronize()
+        _hip.lib().danbo_assign16_set_trace(None)
+        t = buf.cpu().numpy().reshape(-1, 2)
+        t = t[t[:, 1] != 0]
+        print("trace", name, "(tag, delta of s_memtime ticks [100 MHz: 10 ns each])")
+        prev = None
+        line = []
+        for tag, tm in t:
+            if tag == 0 and line:
+                print("   ", " ".join(line)); line = []
+            line.append(f"{tag}:{'' if prev is None else tm - prev}")
+            prev = tm
+        print("   ", " ".join(line))
