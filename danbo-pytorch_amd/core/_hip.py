@@ -28,7 +28,7 @@ SIGNATURES = {
     "danbo_assign_blend_fwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
     "danbo_gather_assign_blend_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
     "danbo_assign16_pack": [P, P, P, P, P],
-    "danbo_gather_assign_blend16_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P],
+    "danbo_gather_assign_blend16_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P],
     "danbo_mlp_pack": [POINTER(c_void_p), P, P, I, P, P, P],
     "danbo_view_consts": [P, P, I, I, I, I, I, P, I, I, P, P, P, P, P, P, P, I, P, P, P, P],
     "danbo_view_code_table": [P, P, I, I, I, P, P, P, P],
@@ -61,7 +61,7 @@ SIGNATURES = {
     "danbo_composite_bwd_lazy": [P, P, P, P, P, I, I, F, P, P, P, P, P],
     "danbo_dw16_scratch_floats": [P, I, I],
     "danbo_dw16": [P, I, I, P, I, P, P],
-    "danbo_gather_assign_blend16_train": [P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P],
+    "danbo_gather_assign_blend16_train": [P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P],
     "danbo_train_view_inputs": [P, P, I, I, I, I, I, P, I, I, P, P, I, P],
     "danbo_train_loss_grad": [P, P, P, P, P, P, I, I, I, F, F, P, P, P, P, P, P],
     "danbo_train_draw_unmerge": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P],

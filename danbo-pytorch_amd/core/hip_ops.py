@@ -188,12 +188,28 @@ def assign16_pack(aw):
     return packed
 
 
+_TICKETS = {}
+
+
+def _ticket(device):
+    """the tile-ticket word of danbo_gather_assign_blend16_fwd: zeroed once, it returns to 0 at the end of every launch; one per
+    (device, stream), since launches on different streams may overlap"""
+    if torch.cuda.is_current_stream_capturing():
+        # memory allocated during a capture belongs to that graph's private pool and dies with the graph: never cache it
+        return torch.zeros(1, device=device, dtype=torch.int32)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return t
+
+
 def gather_assign_blend16(geo, volumes, bits, aw, packed16, lst=None, cnt=None, n=None, want_confd=False):
     n = geo.M if n is None else n
     h = torch.empty(n, H_STRIDE, device=geo.device, dtype=torch.float32)
     confd = torch.empty(n, J, device=geo.device, dtype=torch.float32) if want_confd else None
     _call("danbo_gather_assign_blend16_fwd", *geo.head(), _p(volumes), _p(bits), _p(lst), _p(cnt), n, _p(packed16),
-          _p(aw["b0"]), _p(aw["b1"]), _p(aw["w2"]), _p(aw["b2"]), _p(h), _p(confd), _stream())
+          _p(aw["b0"]), _p(aw["b1"]), _p(aw["w2"]), _p(aw["b2"]), _p(h), _p(confd), _p(_ticket(geo.device)), _stream())
     return h, confd
 
 

@@ -106,14 +106,14 @@ struct A16Args {
     // TRAIN instantiation only (danbo_gather_assign_blend16_train):
     const int32_t* first;   // device scalar: rows [*first, count) of list / h_out / confd are processed, or nullptr (0)
     long long* trace;       // dev tool (tools/micro_assign.py --trace): s_memtime stamps of one wavefront, or nullptr
+    unsigned* ticket;       // device word, 0 at launch, 0 again when the launch has finished: the next 128-row tile to hand out
 };
 
 // per bone: neighbours (self first), number of layer-0 terms, first 1-KB piece of the packed stream
 constexpr int A16_NBI = 8;        // ints per bone: nb[0..4], nq = deg + 1, piece0, pad
 constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16 + J * A16_NBI + J * 4;
 constexpr int A16_LDS_BYTES = (A16_TABLE_FLOATS * 4 + 15) & ~15;
-constexpr int A16_TILE_RUN = 4;   // consecutive 128-row tiles a workgroup takes at a time (the rows are grouped by bone set,
-                                  // k_group.hip: neighbouring tiles need the same bones, whose weights stay in registers)
+constexpr int A16_TICKETS_AHEAD = 4;   // tile tickets a workgroup holds beyond the tile it works on (see k_assign16)
 
 // One bone's 15 windowed features for K2's matrix-core operands: the same quantities as sample_math.hpp's bone_local +
 // gather_bone_features (reference core/encoders.py:288-303,442-444, gnn_backbone.py:802-826, misc.py:331-351) in ~320 instead of
@@ -221,14 +221,33 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
         if (a.confd != nullptr) a.confd += (size_t)f0 * J;
     }
     const int ntiles = (n + A16_BM - 1) / A16_BM;
-    if ((int)blockIdx.x * A16_TILE_RUN >= ntiles) return;
     const long spp = (long)(a.R / a.G) * a.S;
 
-    // tile sequence of this workgroup: runs of A16_TILE_RUN consecutive tiles, the runs round-robin over the workgroups
-    auto next_tile = [&](int t) {
-        const int t1 = t + 1;
-        return (t1 % A16_TILE_RUN) != 0 ? t1 : (t / A16_TILE_RUN + (int)gridDim.x) * A16_TILE_RUN;
-    };
+    // Tiles are handed out by a ticket counter (one atomic per workgroup and tile, issued a tile ahead of its use): a tile costs
+    // between 1 500 and 60 000 ticks depending on how many bones its rows lie in, and with ~10 tiles per workgroup no static
+    // assignment balances that -- the slowest wavefront of a round-robin schedule took 1.5 x (cull order) to 2.5 x (grouped rows,
+    // whose windows alias with the stride) the mean (tools/micro_assign.py --model).  The counter resets itself: every
+    // workgroup draws exactly (tiles it processed) + A16_TICKETS_AHEAD tickets, atomicInc wraps to 0 on the last draw of the launch.
+    __shared__ unsigned s_ticket[2];
+    const unsigned wrap = (unsigned)ntiles + (unsigned)A16_TICKETS_AHEAD * gridDim.x - 1u;
+    unsigned pending = 0;             // thread 0: the ticket drawn one tile ahead
+    int q0, q1, q2;                   // this tile, the next (its inputs are being loaded), the one after (its list entry is)
+    {
+        if (tid == 0) {
+            s_ticket[0] = atomicInc(a.ticket, wrap);
+            s_ticket[1] = atomicInc(a.ticket, wrap);
+        }
+        __syncthreads();
+        q0 = (int)s_ticket[0];
+        q1 = (int)s_ticket[1];
+        __syncthreads();
+        if (tid == 0) {
+            s_ticket[0] = atomicInc(a.ticket, wrap);
+            pending = atomicInc(a.ticket, wrap);
+        }
+        __syncthreads();
+        q2 = (int)s_ticket[0];
+    }
     // Per-tile inputs are fetched one tile ahead: list entry -> (valid bits, ray, depth) is a chain of two dependent HBM round
     // trips.  The record keeps what was LOADED (the point o + d z is formed when the tile starts): anything computed from the
     // loads here would make the compiler wait for them here -- the round-3 kernel formed the point at once and stalled a full
@@ -264,14 +283,13 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
         }
     };
     int g_lds = -1;
-    const int tile0 = blockIdx.x * A16_TILE_RUN;
-    TileIn cur;
-    int first_next = 0;
-    {
-        const int ms0 = load_ms(tile0, first_next);
+    TileIn cur = {};
+    int first_next = 0, ms_next = 0;
+    if (q0 < ntiles) {      // (a workgroup without a tile -- n == 0 included -- touches nothing: its four draws above were its part)
+        const int ms0 = load_ms(q0, first_next);
         load_rest(ms0, first_next, cur);
+        ms_next = load_ms(q1, first_next);
     }
-    int ms_next = load_ms(next_tile(tile0), first_next);
 
     // the weight fragments of the bone this wavefront evaluated last: layer 0 (<= 5 neighbour terms x hi, lo), layer 1 (2 k-steps x hi, lo)
     half8 w0[10], w1[4];
@@ -284,7 +302,17 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             a.trace[tr++] = (long long)__builtin_amdgcn_s_memtime();
         }
     };
-    for (int tile = tile0; tile < ntiles; tile = next_tile(tile), ++it) {
+    for (; q0 < ntiles; ++it) {
+        const int tile = q0;
+        // the ticket drawn during the previous tile becomes the tile after the next two; the following draw is issued now and
+        // read a tile from now (its latency is covered by this tile's work).  One barrier per tile: the four wavefronts of a
+        // workgroup share the tile (and the pose staged in LDS).
+        if (tid == 0) {
+            s_ticket[(it + 1) & 1] = pending;
+            pending = atomicInc(a.ticket, wrap);
+        }
+        __syncthreads();
+        const int q3 = (int)s_ticket[(it + 1) & 1];
         stamp(0);
         const int row = tile * A16_BM + wave * 32 + m;
         const bool row_ok = row < n;
@@ -308,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
         // stage 2 of the NEXT tile (its list entry was requested a tile ago) and stage 1 of the one after
         TileIn nxt;
         load_rest(ms_next, first_next, nxt);
-        ms_next = load_ms(next_tile(next_tile(tile)), first_next);
+        ms_next = load_ms(q2, first_next);
         // ---------------------------------------------------------------- which bones matter here
         // A bone's logit only enters the blend where that bone is valid (p_j = s(a_j) * valid_j), so for this wavefront only
         // bones valid for >= 1 of its 32 samples are evaluated (all 24 when the caller wants confd) -- exact, not approximate.
@@ -438,6 +466,9 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             dst[1] = make_float4(hacc[4], hacc[5], hacc[6], hh ? (TRAIN ? qsum : 0.f) : hacc[7]);
         }
         cur = nxt;
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
     }
 }
 
@@ -466,15 +497,15 @@ extern "C" int danbo_gather_assign_blend16_fwd(const float* rays_o, const float*
                                                 const uint32_t* valid_bits, const int32_t* list, const int32_t* count,
                                                 int n, const void* packed16, const float* b0, const float* b1,
                                                 const float* w2, const float* b2, float* h, float* confd,
-                                                void* stream) {
-    DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && R > 0 && S > 0 && G > 0 && R % G == 0);
+                                                uint32_t* ticket, void* stream) {
+    DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && ticket && R > 0 && S > 0 && G > 0 && R % G == 0);
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, pts, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr, g_a16_trace};
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr, g_a16_trace, ticket};
     DANBO_ENSURE_LDS(k_assign16<false>, A16_LDS_BYTES);
-    const int nruns = ceil_div(ceil_div(n, A16_BM), A16_TILE_RUN);
-    const int grid = nruns < 2 * num_cu() ? nruns : 2 * num_cu();      // two workgroups per CU (launch bounds)
+    const int ntiles = ceil_div(n, A16_BM);
+    const int grid = ntiles < 2 * num_cu() ? ntiles : 2 * num_cu();      // two workgroups per CU (launch bounds)
     hipLaunchKernelGGL(k_assign16<false>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
@@ -484,14 +515,14 @@ extern "C" int danbo_gather_assign_blend16_train(const float* rays_o, const floa
                                                  const float* volumes, const uint32_t* valid_bits, const int32_t* list,
                                                  const int32_t* count, const int32_t* first, int n, const void* packed16,
                                                  const float* b0, const float* b1, const float* w2, const float* b2, float* h,
-                                                 void* stream) {
-    DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && list && count && z && R > 0 && S > 0 && G > 0 && R % G == 0);
+                                                 uint32_t* ticket, void* stream) {
+    DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && list && count && z && ticket && R > 0 && S > 0 && G > 0 && R % G == 0);
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, nullptr, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first, nullptr};
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first, nullptr, ticket};
     DANBO_ENSURE_LDS(k_assign16<true>, A16_LDS_BYTES);
-    const int nruns = ceil_div(ceil_div(n, A16_BM), A16_TILE_RUN);
-    const int grid = nruns < 2 * num_cu() ? nruns : 2 * num_cu();
+    const int ntiles = ceil_div(n, A16_BM);
+    const int grid = ntiles < 2 * num_cu() ? ntiles : 2 * num_cu();
     hipLaunchKernelGGL(k_assign16<true>, dim3(grid), dim3(256), A16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

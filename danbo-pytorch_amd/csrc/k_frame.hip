@@ -40,7 +40,7 @@ FrameBuffers carve(Carver& c, int R, int G, int S, int Sf, int chunk, int Wg) {
     b.bits_a = c.take<uint32_t>(M);
     b.bits_b = c.take<uint32_t>(Mf);
     b.list = c.take<int32_t>(M);          // re-used by the importance pass (Mf <= M is not assumed: max below)
-    b.count = c.take<int32_t>(2);
+    b.count = c.take<int32_t>(4);         // [0], [1]: rows of the two passes; [2]: K2's tile ticket
     b.h = c.take<float>((M > Mf ? M : Mf) * 16);
     b.raw_a = c.take<float>(M * 4);
     b.raw_b = c.take<float>(Mf * 4);
@@ -86,13 +86,13 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
                                 m->mean_code, r->cam_idx, m->views_w_ray_t, m->views_b_eff, m->rgb_w, m->rgb_b, m->empty_consts, 1,
                                 m->code_table, b.cview, b.raw_empty, stream));
     // one network pass over R x s samples at depths zz -> raw (rows outside every volume stay unwritten: bits == 0)
+    zero_words(b.count, 4, nullptr, 0, st);      // both row counters and the ticket (which returns to 0 after each launch)
     auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
-        zero_words(count, 1, nullptr, 0, st);
         DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, bits, b.list, count, stream));
         DANBO_TRY(danbo_group_rows(bits, b.list, count, R * s, stream));     // rows of the same bone set next to each other (k_group.hip)
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,
                                                   bits, b.list, count, R * s, m->assign16, m->a_b0, m->a_b1, m->a_w2, m->a_b2, b.h,
-                                                  nullptr, stream));
+                                                  nullptr, reinterpret_cast<uint32_t*>(b.count + 2), stream));
         return danbo_pe_mlp16_fwd(b.h, b.list, count, R * s, s, m->mlp16, m->pts_b, m->alpha_w, m->alpha_b, b.cview, m->rgb_w,
                                   m->rgb_b, raw, nullptr, stream);
     };

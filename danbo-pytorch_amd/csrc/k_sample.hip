@@ -585,8 +585,19 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
             const uint32_t nxt_word = fetch_word(clampr(r + nwaves), nxt.src);
             const Idx nn = fetch_idx(clampr(r + 2 * nwaves));
             const float gap = (lane + 1 < St) ? sub_rn(cur.z1, cur.zs) : 1e10f;
-            float al;
-            const float w = composite_chunk(st, rw, cur.zs, gap, cur.dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+            float al, w;
+            // a ray without an in-volume sample in either pass: constants, as in k_composite_importance below (bit for bit)
+            const float dist = mul_rn(gap, cur.dn);
+            const float rgb_sum = add_rn(add_rn(cur.re.x, cur.re.y), cur.re.z);
+            const bool flat = raw_empty != nullptr && bits_a != nullptr && bits_b != nullptr && noise == nullptr &&
+                              !(div_rn(cur.re.w, B) > 0.f) && sub_rn(rgb_sum, rgb_sum) == 0.f &&
+                              __all(cur_word == 0u && sub_rn(dist, dist) == 0.f);
+            if (flat) {
+                al = 0.f;
+                w = 0.f;
+            } else {
+                w = composite_chunk(st, rw, cur.zs, gap, cur.dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+            }
             if (act) {
                 if (weights) weights[m] = w;
                 if (alpha_out) alpha_out[m] = al;
@@ -802,8 +813,23 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
         const RayIn nxt = fetch(r + nwaves < R ? r + nwaves : r);
         const float zs = cur.zs;
         const float gap = (lane + 1 < S) ? sub_rn(cur.z1, zs) : 1e10f;
-        float al;
-        const float w = composite_chunk(st, rw, zs, gap, cur.dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+        float al, w;
+        // A ray with no sample inside any volume (two thirds of the bench frame) carries ONE raw for all its samples -- the ray's
+        // empty-space raw.  If its density pre-activation is <= 0 (or NaN: fmaxf drops it) and every interval length is finite,
+        // the general chain below computes sig = 0, alpha = 1 - exp(-0) = +0, T = 1, w = +0 for every sample and +0 for all five
+        // sums: the maps are constants.  Taken wave-uniformly, bit for bit the general result (the importance depths still go
+        // through importance_wave: they depend on the ray's depths only).
+        const float dist = mul_rn(gap, cur.dn);
+        const float rgb_sum = add_rn(add_rn(cur.re.x, cur.re.y), cur.re.z);     // (NaN / inf colour logits would make 0 * c a NaN)
+        const bool flat = bits != nullptr && noise == nullptr && !(div_rn(cur.re.w, B) > 0.f) && sub_rn(rgb_sum, rgb_sum) == 0.f &&
+                          __all(cur.word == 0u && sub_rn(dist, dist) == 0.f);
+        if (flat) {
+            al = 0.f;
+            w = 0.f;
+            st.sr = st.sg = st.sb = st.sd = st.sa = 0.f;
+        } else {
+            w = composite_chunk(st, rw, zs, gap, cur.dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+        }
         if (act) {
             if (weights) weights[m] = w;
             if (alpha_out) alpha_out[m] = al;

@@ -49,6 +49,7 @@ struct TrainBuffers {
     // zeroed at the start of every step (one launch)
     char* zero_begin;
     int32_t *cnt, *cntb;
+    uint32_t* ticket;      // K2's tile ticket (0 at launch, 0 after)
     float *maxabs, *loss, *g_vol, *wmax, *d_cview, *csum;
     char* zero_end;
     // geometry
@@ -89,6 +90,7 @@ TrainBuffers carve(Carver& c, const Shapes& s, const DanboTrainModel* m, long dw
     b.zero_begin = c.base ? c.base + c.used : nullptr;
     b.cnt = c.take<int32_t>(8);
     b.cntb = c.take<int32_t>(J);
+    b.ticket = c.take<uint32_t>(4);
     b.maxabs = c.take<float>(32);
     b.loss = c.take<float>(8);
     b.g_vol = c.take<float>((size_t)s.G * J * VOL);
@@ -450,7 +452,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,
                                                     b.row_sample + R, b.cnt, pass == 0 ? nullptr : b.cnt + 1, ncap - R, b.assign16,
                                                     m->p[DANBO_T_A_B0], m->p[DANBO_T_A_B1], m->p[DANBO_T_A_W2], m->p[DANBO_T_A_B2],
-                                                    b.h_rows + (size_t)R * 16, stream));
+                                                    b.h_rows + (size_t)R * 16, b.ticket, stream));
         NET_STAGE(22);
         if (pass == 0) DANBO_TRY(join(0));       // the trunk's packing and the view constants
         // encoding, trunk, heads, raw of the pass (and the row bookkeeping: cnt[1..7], row_ray) in ONE kernel

@@ -149,7 +149,10 @@ int danbo_gather_assign_blend16_fwd(const float* rays_o, const float* rays_d, co
                                     const uint32_t* valid_bits, const int32_t* list, const int32_t* count, int n,
                                     const void* packed16, const float* b0, const float* b1 /*[24,32]*/,
                                     const float* w2 /*[24,32]*/, const float* b2 /*[24]*/,
-                                    float* h, float* confd, void* stream);
+                                    float* h, float* confd, uint32_t* ticket, void* stream);
+/* ticket (ABI 4): one device word the launch hands its 128-row tiles out with -- a tile costs 1 .. 40 x the cheapest one,
+ * depending on how many bone volumes its rows lie in.  It must be 0 at launch and is 0 again when the launch has finished (the
+ * counter wraps on the last draw), so one word allocated and zeroed ONCE serves every launch enqueued on the same stream. */
 
 /* ---------------------------------------------------------------------------------------
  * K3  voxel-feature PE + density/colour MLP on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -387,7 +390,7 @@ int danbo_gather_assign_blend16_train(const float* rays_o, const float* rays_d, 
                                       const float* skts, const float* align, const float* axis_scale, const float* volumes,
                                       const uint32_t* valid_bits, const int32_t* list, const int32_t* count, const int32_t* first,
                                       int n, const void* packed16, const float* b0, const float* b1, const float* w2,
-                                      const float* b2, float* h, void* stream);
+                                      const float* b2, float* h, uint32_t* ticket, void* stream);
 /* per-ray view inputs [PE(dir) | frame code | 0] (nerf.py:252-279); ray_mode / normalise as danbo_view_consts */
 int danbo_train_view_inputs(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise, int L_view,
                             const float* codes, int n_codes, int Cf, const int64_t* cam_idx, float* vin, int ldv, void* stream);

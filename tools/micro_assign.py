@@ -42,6 +42,27 @@ print("mlp16 cap=M     ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng
 lg = lst.clone()
 print("group_rows      ms", timeit(lambda: ops.group_rows(bits, lg, cnt)))
 print("assign16 grouped ms", timeit(lambda: ops.gather_assign_blend16(geo, vols, bits, eng.aw, eng.assign16, lg, cnt, geo.M)))
+# reference orders made with torch (same box, same run): by the whole bit set / by (lowest, second lowest) inside windows of 16 384
+b = bits[lst[:n].long()].long() & 0xFFFFFF
+W = 16384
+pad = (-n) % W
+def windowed(key):
+    k = torch.cat([key, key.new_full((pad,), 1 << 40)]).view(-1, W)
+    idx = torch.sort(k, dim=1, stable=True).indices + (torch.arange(k.shape[0], device=k.device) * W)[:, None]
+    idx = idx.reshape(-1)
+    return lst[:n][idx[idx < n]].contiguous()
+low = torch.full_like(b, 24)
+for j in reversed(range(24)):
+    low = torch.where(((b >> j) & 1) == 1, torch.full_like(b, j), low)
+rest = b & ~(1 << low)
+second = torch.full_like(b, 24)
+for j in reversed(range(24)):
+    second = torch.where(((rest >> j) & 1) == 1, torch.full_like(b, j), second)
+for name, key in (("whole set", b), ("(low, second)", low * 25 + second), ("lowest", low)):
+    l_ = windowed(key)
+    print(f"assign16 torch-sorted by {name:14s} ms", timeit(lambda: ops.gather_assign_blend16(geo, vols, bits, eng.aw, eng.assign16, l_, None, n)))
+print("same rows as the kernel's order:", bool(torch.equal(torch.sort(lg[:n]).values, torch.sort(lst[:n]).values)),
+      " kernel order == torch (low, second) order:", bool(torch.equal(lg[:n], windowed(low * 25 + second))))
 if "--trace" in sys.argv:
     import ctypes
     from core import _hip
@@ -62,3 +83,74 @@ if "--trace" in sys.argv:
             line.append(f"{tag}:{'' if prev is None else tm - prev}")
             prev = tm
         print("   ", " ".join(line))
+
+# cost model of the round-4 kernel per wavefront (s_memtime trace: ~2 600 ticks per feature pair-step, ~1 800 per bone for the three
+# layers, ~1 500 per tile of fixed work) summed along each wavefront's tile sequence: average vs slowest wavefront, for each order
+if "--model" in sys.argv:
+    DEG = torch.tensor([3, 2, 2, 2, 2, 2, 2, 2, 2, 4, 1, 1, 2, 2, 2, 1, 2, 2, 2, 2, 2, 2, 1, 1], device="cuda")
+    bone_cost = ((DEG + 2) // 2) * 2600 + 1800           # ceil((deg + 1) / 2) pair-steps
+    NWG = 512
+    def model(name, l_, RUN=4, sched=None):
+        bb = bits[l_[:n].long()].long() & 0xFFFFFF
+        padr = (-n) % 128
+        bw = torch.cat([bb, bb.new_zeros(padr)]).view(-1, 4, 32)           # [tile, wave, row]
+        need = torch.zeros(bw.shape[:2], dtype=torch.int64, device="cuda")
+        for k in range(32):
+            need |= bw[:, :, k]
+        cost = torch.full(need.shape, 1500, dtype=torch.int64, device="cuda")
+        nb = torch.zeros_like(need)
+        for j in range(24):
+            on = (need >> j) & 1
+            cost += on * bone_cost[j]
+            nb += on
+        ntiles = cost.shape[0]
+        wg = (torch.arange(ntiles, device="cuda") // RUN) % NWG
+        if sched is not None:
+            wg = sched(ntiles)
+        per_wave = torch.zeros(NWG, 4, dtype=torch.int64, device="cuda").index_add_(0, wg, cost)
+        lock = cost.max(1).values.float().sum().item() / NWG
+        print(f"model RUN={RUN} {name:28s} dynamic WG tickets, waves in lockstep per tile: {lock:.0f} ticks (+ <= one tile {cost.max().item()}) |  bones/wave {nb.float().mean():.2f}  ticks: mean wavefront {per_wave.float().mean():.0f}  slowest {per_wave.max().item()}  "
+              f"(x {per_wave.max().item() / per_wave.float().mean():.2f})")
+    for RUN in (1, 2, 4):
+        model("cull order", lst, RUN)
+        model("kernel grouped (low, second)", lg, RUN)
+        model("torch whole set", windowed(b), RUN)
+    for name, key in (("whole set", b), ("(low, second)", low * 25 + second), ("lowest", low)):
+        model("torch " + name, windowed(key))
+
+    import math
+    def golden(ntiles, nwg=512):
+        P = int(ntiles * 0.6180339887) | 1
+        while math.gcd(P, ntiles) != 1:
+            P += 2
+        visit = (torch.arange(ntiles, device="cuda") * P) % ntiles          # i-th visited tile
+        wg = torch.empty(ntiles, dtype=torch.int64, device="cuda")
+        wg[visit] = torch.arange(ntiles, device="cuda") % nwg
+        return wg
+    for nm, l_ in (("cull order", lst), ("kernel grouped", lg), ("torch whole set", windowed(b))):
+        model(nm + " stride 509", l_, 1, lambda nt: torch.arange(nt, device="cuda") % 509)
+        model(nm + " golden perm", l_, 1, golden)
+    # greedy list scheduling (what the ticket counter does): 512 workgroups, tiles in list order, chunks of 1 / 2 / 4 tiles per draw
+    import heapq
+    def simulate(name, l_):
+        bb = bits[l_[:n].long()].long() & 0xFFFFFF
+        padr = (-n) % 128
+        bw = torch.cat([bb, bb.new_zeros(padr)]).view(-1, 4, 32)
+        need = torch.zeros(bw.shape[:2], dtype=torch.int64, device="cuda")
+        for k in range(32):
+            need |= bw[:, :, k]
+        cost = torch.full(need.shape, 1500, dtype=torch.int64, device="cuda")
+        for j in range(24):
+            cost += ((need >> j) & 1) * bone_cost[j]
+        tile_cost = cost.max(1).values.cpu().tolist()
+        out = []
+        for chunk in (1, 2, 4):
+            heap = [0] * NWG
+            for i in range(0, len(tile_cost), chunk):
+                t = heapq.heappop(heap)
+                heapq.heappush(heap, t + sum(tile_cost[i:i + chunk]))
+            out.append(f"chunk {chunk}: {max(heap)}")
+        print(f"greedy {name:28s} sum/512 = {sum(tile_cost) / NWG:.0f}  makespan " + "  ".join(out))
+    simulate("cull order", lst)
+    simulate("kernel grouped", lg)
+    simulate("torch whole set", windowed(b))
