@@ -93,6 +93,97 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def _packed(weight, K1=None, transposed=False, cols=None):
+    """fragment packing of a dense-layer weight for Linear16Fn; cols = (c0, c1): of the column slice weight[:, c0:c1].  Cached ON
+    the parameter object, per version counter (an optimizer step re-packs; a new tensor at a recycled address cannot hit)"""
+    cache = getattr(weight, "_danbo_packs", None)
+    if cache is None or cache[0] != weight._version:
+        cache = (weight._version, {})
+        try:
+            weight._danbo_packs = cache
+        except AttributeError:
+            pass
+    key = (K1, transposed, cols)
+    hit = cache[1].get(key)
+    if hit is None:
+        w = weight.detach()
+        if cols is not None:
+            w = w[:, cols[0]:cols[1]]
+        hit = cache[1][key] = ops.linear16_pack(w, K1=K1, transposed=transposed)
+    return hit
+
+
+class Linear16Fn(torch.autograd.Function):
+    """y = act([x1 | x2] W^T + b) on k_linear16 (fp16 hi/lo-split MFMA products, fp32 accumulate -- the kernel of A-NeRF's eval
+    trunk) with a hand-written backward on the same family: dX = dZ W through the transposed packing of the weight
+    (danbo_linear16_fwd on W^T), dW = dZ^T X and db through danbo_dw16.  Gradients are ~1e-6 .. 1e-9: dZ is multiplied by the
+    power of two that brings its largest entry to ~1 before the split (fp16's lo halves would otherwise be subnormal) and the
+    product by the exact inverse.  x1 carries no gradient when `x1_grad` is False (the network input); x2: optional second
+    input of a skip layer.  Reference: nn.Linear + F.relu of NeRF.inference (core/networks/nerf.py:176-209)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, relu, x1_grad):
+        x1 = x1.contiguous()
+        K1 = x1.shape[1]
+        K2 = 0 if x2 is None else x2.shape[1]
+        if x2 is not None:
+            x2 = x2.contiguous()
+        packed, shape = _packed(weight, K1=K1 if K2 else None)
+        y = ops.linear16(x1, packed, shape, bias.detach() if bias is not None else None, relu=relu, x2=x2)
+        ctx.relu, ctx.x1_grad, ctx.K1, ctx.K2 = relu, x1_grad, K1, K2
+        ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight, y if relu else x1.new_empty(0))
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        x1, x2, weight, y = ctx.saved_tensors
+        K1, K2 = ctx.K1, ctx.K2
+        N, M = weight.shape[0], x1.shape[0]
+        dz = (g * (y > 0)) if ctx.relu else g
+        dz = dz.contiguous().float()
+        mx = dz.abs().max().reshape(1).clamp_min(torch.finfo(torch.float32).tiny)
+        scale = torch.exp2(-torch.floor(torch.log2(mx)))                      # power of two: exact both ways
+        dzs = dz * scale
+        dx1 = dx2 = None
+        if ctx.x1_grad:
+            packed_t, shape_t = _packed(weight, transposed=True, cols=(0, K1) if K2 else None)
+            dx1 = ops.linear16(dzs, packed_t, shape_t, None) / scale
+        if K2:
+            packed_t, shape_t = _packed(weight, transposed=True, cols=(K1, K1 + K2))
+            dx2 = ops.linear16(dzs, packed_t, shape_t, None) / scale
+        gw = torch.empty(N, K1 + K2, device=dz.device, dtype=torch.float32)
+        gb = torch.empty(N, device=dz.device, dtype=torch.float32)
+        D = _hip.DanboDwLayer
+        common = dict(dy=dz.data_ptr(), x2=None, dy_maxabs=mx.data_ptr(), gw=gw.data_ptr(), gw2=None, gb2=None, ldy=N, ld2=0, N=N, K2=0,
+                      split_n=0, frag=0, gw_ld=K1 + K2, x1_pe=0)
+        layers = [D(x1=x1.data_ptr(), ld1=K1, K1=K1, gw_col0=0, gb=gb.data_ptr(), **common)]
+        if K2:      # the second input as a layer of its own writing its column range of the same weight gradient
+            layers.append(D(x1=x2.data_ptr(), ld1=K2, K1=K2, gw_col0=K1, gb=None, **common))
+        L = (D * len(layers))(*layers)
+        slices = 8
+        lib = _hip.lib()
+        scratch = torch.empty(lib.danbo_dw16_scratch_floats(L, len(layers), slices), device=dz.device)
+        _hip.check(lib.danbo_dw16(L, len(layers), M, None, slices, _p(scratch), ops._stream()), "danbo_dw16")
+        return dx1, dx2, gw, (gb if ctx.has_bias else None), None, None
+
+
+def _linear16_ok(layer, K):
+    """k_linear16 / k_dw16 take 16-byte aligned rows: input and output widths multiples of 4, N <= 512"""
+    N = layer.weight.shape[0]
+    return layer.weight.is_cuda and K % 4 == 0 and N % 4 == 0 and 4 <= N <= 512 and layer.weight.shape[1] == K
+
+
+def linear16(layer, x, relu=False, x2=None, x_grad=True):
+    """layer([x | x2]) (+ ReLU) on the HIP kernels both ways when the shape allows, else the library route"""
+    K = x.shape[1] + (0 if x2 is None else x2.shape[1])
+    if _linear16_ok(layer, K) and x.shape[1] % 4 == 0 and x.shape[0] > 0:
+        return Linear16Fn.apply(x, x2, layer.weight, layer.bias, relu, x_grad)
+    y = linear(layer, x if x2 is None else torch.cat([x, x2], -1))
+    return F.relu(y) if relu else y
+
+
 def linear(layer, x):
     return LinearFn.apply(x, layer.weight, layer.bias)
 
@@ -379,13 +470,21 @@ def forward_train_anerf(model, inputs):
     with torch.no_grad():
         x0, w = ops.anerf_encode(None, None, skts_g, align, model.pe_fn.cutoff_dist.detach(), tau, L, 0, R * S, pts=pts)
         E = ops.anerf_view_pe(rays_d, skts_g, Lv)                                  # [R, nb*72], block-major
-    h = x0
+    # the W-wide trunk and feature_linear on k_linear16 both ways (Linear16Fn); alpha_linear (N = 1) and rgb_linear (N = 3) are
+    # matrix-vector products: library route
+    h, skip_in = x0, None
     for i, l in enumerate(model.pts_linears):
-        h = F.relu(linear(l, h))
+        if skip_in is not None:       # the layer behind a skip: [input | h] as two operands, no concatenated copy
+            h = linear16(l, x0, relu=True, x2=h, x_grad=False)
+            skip_in = None
+        else:
+            h = linear16(l, h, relu=True, x_grad=i > 0)
         if i in model.skips:
-            h = torch.cat([x0, h], -1)
+            skip_in = h
+    if skip_in is not None:           # (a skip after the last layer: the heads see the concatenation)
+        h = torch.cat([x0, h], -1)
     alpha = linear(model.alpha_linear, h)
-    feat = linear(model.feature_linear, h)
+    feat = linear16(model.feature_linear, h)
     W, nb = model.W, 1 + 2 * Lv
     wv, bv = model.views_linears[0].weight, model.views_linears[0].bias           # [VW, W + nb*72 + code]
     view_ch = nb * 72

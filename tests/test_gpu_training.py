@@ -378,3 +378,40 @@ def test_anerf_losses_and_gradients_match_reference_autograd():
     # and one optimiser step runs
     l2, stats = trainer.train_batch(batch, i=0, global_step=0)
     assert np.isfinite(stats["total_loss"])
+
+
+@pytest.mark.parametrize("gscale", [1.0, 3e-7])
+def test_linear16_autograd_function_matches_float64(gscale):
+    """core/train_path.Linear16Fn (A-NeRF's training trunk: k_linear16 forward, transposed-weight k_linear16 for dX, k_dw16 for dW /
+    db) against float64 autograd of relu([x1 | x2] W^T + b): one- and two-input (skip) layers of A-NeRF's widths, upstream
+    gradients of ordinary size and at 3e-7 (what the loss hands the trunk: below fp16's normal range before the pre-scaling)"""
+    from core import train_path
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    M = 1500 - 13
+    for K1, K2, N in ((432, 0, 448), (448, 0, 448), (432, 448, 448)):
+        lin = torch.nn.Linear(K1 + K2, N).to(DEV)
+        x1 = torch.randn(M, K1, generator=gen).to(DEV).requires_grad_(True)
+        x2 = torch.randn(M, K2, generator=gen).to(DEV).requires_grad_(True) if K2 else None
+        gy = (torch.randn(M, N, generator=gen) * gscale).to(DEV)
+        y = train_path.linear16(lin, x1, relu=True, x2=x2, x_grad=True)
+        assert y.grad_fn is not None and "Linear16Fn" in type(y.grad_fn).__name__
+        (y * gy).sum().backward()
+        w64, b64 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+        a1 = x1.detach().double().requires_grad_(True)
+        a2 = x2.detach().double().requires_grad_(True) if K2 else None
+        xin = a1 if a2 is None else torch.cat([a1, a2], -1)
+        z64 = xin @ w64.t() + b64
+        # the ReLU's branch per element is taken from the kernel's output (a pre-activation within fp32 round-off of 0 may sit on
+        # either side: one such (row, unit) pair moves that unit's weight gradient by the row's whole contribution) -- after
+        # checking that the two only disagree there
+        mask = y.detach() > 0
+        assert float(z64.detach()[mask != (z64.detach() > 0)].abs().max().item() if bool((mask != (z64.detach() > 0)).any()) else 0.0) < 1e-5
+        y64 = z64 * mask
+        (y64 * gy.double()).sum().backward()
+        assert float((y.detach().double() - y64.detach()).abs().max()) <= 3e-6 * float(y64.detach().abs().max())
+        pairs = [("weight", lin.weight.grad, w64.grad), ("bias", lin.bias.grad, b64.grad), ("x1", x1.grad, a1.grad)]
+        if K2:
+            pairs.append(("x2", x2.grad, a2.grad))
+        for name, a, r in pairs:
+            e = float((a.double() - r).abs().max()) / float(r.abs().max())
+            assert e < 2e-5, (K1, K2, name, e)
