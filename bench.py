@@ -23,7 +23,7 @@ value = N * K * units / max-over-ranks time.  `ranks_seen` = dist.get_world_size
 `value` of the render configs is measured with exact in-volume culling (bit-identical raw to evaluating every sample:
 `dense_equals_culled`); `dense_value` pushes every sample through every kernel (the reference's executed work).
 `roofline` is for the dominant kernel, EXECUTED flops only, its launch durations taken from HIP events inside the timed region.
-`roofline.traffic` is filled from profiles/r03_pmc_hbm.json only if that file was measured on the kernel sources being timed
+`roofline.traffic` is filled from the newest profiles/rNN_pmc_hbm.json that was measured on the kernel sources being timed
 (sha recorded by tools/pmc_hbm.sh), else null.  `cpu_baseline`: oracle/torch_cpu.py (a multi-threaded torch-CPU restatement
 doing the reference's executed work) on a bounded sample of the same workload, best of 3.
 """
@@ -76,6 +76,22 @@ def build_workload(device, view, mlp_mode="f16split", cam_dist=3.0):
 def render(eng, inp, dense=False):
     return eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"],
                       N_SAMPLES, N_IMPORTANCE, chunk=4096, dense=dense)
+
+
+def pmc_record(kind, *files):
+    """the newest profiles/rNN_pmc_<kind>.json whose recorded hash equals the hash of the kernel sources being timed, or None: a
+    traffic figure is only quoted for the code it was measured on"""
+    import glob
+    want = sha16(*files)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except ValueError:
+            continue
+        if rec.get("kernel_src_sha16") == want:
+            rec["_file"] = os.path.relpath(path, ROOT)
+            return rec
+    return None
 
 
 def sha16(*files):
@@ -247,12 +263,10 @@ def bench_render(args, rank, world, device, dist):
     else:
         kernel, peak, peak_note = "k_pe_mlp", PEAK_FP32_MFMA, "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
     traffic, traffic_note = None, "no PMC profile of this build of the kernel under profiles/ (tools/pmc_hbm.sh)"
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")
-    if os.path.exists(pmc) and args.mlp == "f16split" and args.config == 1:
-        rec = json.load(open(pmc))
-        if rec.get("kernel_src_sha16") == sha16("k_mlp16.hip", "mlp16_core.hpp", "common.hpp"):
-            traffic = rec["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
-            traffic_note = "HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source (profiles/r03_pmc_hbm.json)"
+    rec = pmc_record("hbm", "k_mlp16.hip", "mlp16_core.hpp", "common.hpp") if (args.mlp == "f16split" and args.config == 1) else None
+    if rec is not None:
+        traffic = rec["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
+        traffic_note = f"HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source ({rec['_file']})"
     # algorithmic HBM bytes of a launch: 84 B per row (64 B h + 4 B list entry + 16 B raw) + the 512-byte per-ray view constants of
     # every ray that owns >= 1 row (counted on the coarse pass of one extra, untimed frame)
     keep = eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"], N_SAMPLES, N_IMPORTANCE,
@@ -387,11 +401,10 @@ def bench_train(args, rank, world, device, dist):
     peak = PEAK_FP16_MFMA / 3.0
     # HBM bytes of a step from the PMC passes of tools/pmc_train.sh, quoted only for the kernel sources they were measured on
     traffic, hbm = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_train.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("kernel_src_sha16") == sha16("k_train.hip", "k_mlp16.hip", "k_mlp16_bwd.hip", "mlp16_core.hpp", "k_dw16.hip", "k_assign_bwd.hip",
-                                                "k_train_rows.hip", "k_train_head.hip", "common.hpp"):
+    rec = pmc_record("train", "k_train.hip", "k_mlp16.hip", "k_mlp16_bwd.hip", "mlp16_core.hpp", "k_dw16.hip", "k_assign_bwd.hip",
+                     "k_train_rows.hip", "k_train_head.hip", "common.hpp")
+    if rec is not None:
+        if True:
             traffic = rec["step_hbm_bytes"]
             hbm = dict(bytes_per_step=traffic, achieved=traffic / (ms * 1e-3) / 1e12, peak=8.0, unit="TB/s", frac=traffic / (ms * 1e-3) / 8e12,
                        note="steady-state steps only (tools/pmc_train.sh); every activation and gradient of the trunk is written once "
@@ -415,7 +428,7 @@ def bench_train(args, rank, world, device, dist):
                          peak_note=SPLIT_NOTE,
                          note="STEP-level lower bound, per GPU: executed dense-layer flops of the step (forward + input gradients + weight "
                               "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
-                              "per-kernel durations: profiles/r03_train_kernel_stats.csv"),
+                              "per-kernel durations: profiles/r04_train_kernel_stats.csv"),
         **tinfo,
         "collectives": ("none (one rank, no process group)" if dist is None and not args.nccl_world_1 else
                         f"two in-place all-reduces of the flat gradient per step ({'gloo' if args.debug_single_device else 'nccl = RCCL'}, "
@@ -476,10 +489,9 @@ def bench_anerf(args, rank, world, device, dist):
     peak = PEAK_FP16_MFMA / 3.0
     # HBM bytes of a frame from the PMC passes of tools/pmc_anerf.sh, quoted only for the kernel sources they were measured on
     traffic, hbm = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_anerf.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("kernel_src_sha16") == sha16("k_linear16.hip", "k_anerf.hip", "common.hpp"):
+    rec = pmc_record("anerf", "k_linear16.hip", "k_anerf.hip", "common.hpp")
+    if rec is not None:
+        if True:
             traffic = rec["frame_hbm_bytes"]
             # algorithmic: every dense layer reads its input row(s) and writes its output row once (4 (K + N) bytes per row), the
             # encoder writes the 432 inputs + 24 cutoff weights, the colour kernel reads the 225-wide head rows + weights

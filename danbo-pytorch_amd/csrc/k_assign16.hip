@@ -113,7 +113,7 @@ struct A16Args {
 constexpr int A16_NBI = 8;        // ints per bone: nb[0..4], nq = deg + 1, piece0, pad
 constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16 + J * A16_NBI + J * 4;
 constexpr int A16_LDS_BYTES = (A16_TABLE_FLOATS * 4 + 15) & ~15;
-constexpr int A16_TICKETS_AHEAD = 4;   // tile tickets a workgroup holds beyond the tile it works on (see k_assign16)
+constexpr int A16_TICKETS_AHEAD = 4;   // draws of a workgroup that come back without a tile: the one that ends it + three in its pipeline
 
 // One bone's 15 windowed features for K2's matrix-core operands: the same quantities as sample_math.hpp's bone_local +
 // gather_bone_features (reference core/encoders.py:288-303,442-444, gnn_backbone.py:802-826, misc.py:331-351) in ~320 instead of
@@ -226,27 +226,28 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
     // Tiles are handed out by a ticket counter (one atomic per workgroup and tile, issued a tile ahead of its use): a tile costs
     // between 1 500 and 60 000 ticks depending on how many bones its rows lie in, and with ~10 tiles per workgroup no static
     // assignment balances that -- the slowest wavefront of a round-robin schedule took 1.5 x (cull order) to 2.5 x (grouped rows,
-    // whose windows alias with the stride) the mean (tools/micro_assign.py --model).  The counter resets itself: every
-    // workgroup draws exactly (tiles it processed) + A16_TICKETS_AHEAD tickets, atomicInc wraps to 0 on the last draw of the launch.
+    // whose windows alias with the stride) the mean (tools/micro_assign.py --model).  Every workgroup starts on tile blockIdx.x;
+    // tickets hand out the tiles from gridDim.x on.  A launch with no more tiles than workgroups (the training step's) draws
+    // nothing.  The counter resets itself: every workgroup draws exactly (tiles it took by ticket) + A16_TICKETS_AHEAD tickets, so
+    // atomicInc wraps to 0 on the last draw of the launch.  (Same-address atomics retire at ~17 ns each on this part: a draw per
+    // tile is affordable, four per IDLE workgroup -- the first version -- cost the small training launches 35 us.)
     __shared__ unsigned s_ticket[2];
-    const unsigned wrap = (unsigned)ntiles + (unsigned)A16_TICKETS_AHEAD * gridDim.x - 1u;
+    const int nwg = (int)gridDim.x;
+    if ((int)blockIdx.x >= ntiles) return;
+    const bool dynamic = ntiles > nwg;                       // (grid-uniform)
+    const unsigned wrap = (unsigned)(ntiles - nwg) + (unsigned)A16_TICKETS_AHEAD * (unsigned)nwg - 1u;
     unsigned pending = 0;             // thread 0: the ticket drawn one tile ahead
-    int q0, q1, q2;                   // this tile, the next (its inputs are being loaded), the one after (its list entry is)
-    {
+    int q0 = (int)blockIdx.x, q1 = ntiles, q2 = ntiles;      // this tile, the next (its inputs are being loaded), the one after
+    if (dynamic) {
         if (tid == 0) {
             s_ticket[0] = atomicInc(a.ticket, wrap);
             s_ticket[1] = atomicInc(a.ticket, wrap);
-        }
-        __syncthreads();
-        q0 = (int)s_ticket[0];
-        q1 = (int)s_ticket[1];
-        __syncthreads();
-        if (tid == 0) {
-            s_ticket[0] = atomicInc(a.ticket, wrap);
             pending = atomicInc(a.ticket, wrap);
         }
         __syncthreads();
-        q2 = (int)s_ticket[0];
+        q1 = nwg + (int)s_ticket[0];
+        q2 = nwg + (int)s_ticket[1];
+        __syncthreads();
     }
     // Per-tile inputs are fetched one tile ahead: list entry -> (valid bits, ray, depth) is a chain of two dependent HBM round
     // trips.  The record keeps what was LOADED (the point o + d z is formed when the tile starts): anything computed from the
@@ -307,12 +308,15 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
         // the ticket drawn during the previous tile becomes the tile after the next two; the following draw is issued now and
         // read a tile from now (its latency is covered by this tile's work).  One barrier per tile: the four wavefronts of a
         // workgroup share the tile (and the pose staged in LDS).
-        if (tid == 0) {
-            s_ticket[(it + 1) & 1] = pending;
-            pending = atomicInc(a.ticket, wrap);
+        int q3 = ntiles;
+        if (dynamic) {
+            if (tid == 0) {
+                s_ticket[it & 1] = pending;
+                pending = atomicInc(a.ticket, wrap);
+            }
+            __syncthreads();
+            q3 = nwg + (int)s_ticket[it & 1];
         }
-        __syncthreads();
-        const int q3 = (int)s_ticket[(it + 1) & 1];
         stamp(0);
         const int row = tile * A16_BM + wave * 32 + m;
         const bool row_ok = row < n;

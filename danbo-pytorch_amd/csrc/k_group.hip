@@ -13,9 +13,9 @@
 // share their lowest bone, so a wavefront that straddles two bins evaluates a small union.  No atomics: every wavefront counts
 // into its OWN row of the LDS histogram (the leader lane of each distinct key of a 64-row vector adds the ballot's population),
 // ranks inside a vector come from the ballot, and bin starts from two scans (over the 16 wavefronts of a bin, over the bins).
-// The output order is a pure function of the input.  (First version: one LDS hash table of the window's distinct sets with
-// atomicCAS / atomicAdd per wavefront and set -- 27 us alone, 86 us beside the view-constant kernel on the side stream: sixteen
-// wavefronts queueing on the same few LDS words.)
+// The output order is a pure function of the input, and stable (rows of a bin keep their input order).  (First version: one LDS
+// hash table of the window's distinct sets with atomicCAS / atomicAdd per wavefront and set -- 27 us alone, 86 us beside the
+// view-constant kernel on the side stream: sixteen wavefronts queueing on the same few LDS words.)
 #include "common.hpp"
 
 namespace danbo {
@@ -49,7 +49,10 @@ __global__ __launch_bounds__(GR_THREADS) void k_group_rows(const uint32_t* __res
     uint32_t bk[GR_PER_THREAD];            // all 16 gathers in flight at once
 #pragma unroll
     for (int k = 0; k < GR_PER_THREAD; ++k) {
-        const int row = win0 + k * GR_THREADS + tid;
+        // a wavefront owns 1 024 CONSECUTIVE rows (16 vectors of 64): position inside a bin = (wavefront, vector, lane) is then
+        // the input order -- the sort is stable, samples of a ray stay together, and with them the rarer third / fourth bones
+        // of a bin (an interleaved assignment scattered those over the whole bin: K2 157 instead of 135 us)
+        const int row = win0 + wave * (64 * GR_PER_THREAD) + k * 64 + lane;
         ms[k] = row < n ? list[row] : -1;
     }
 #pragma unroll

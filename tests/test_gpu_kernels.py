@@ -531,6 +531,7 @@ def test_group_rows_is_a_permutation_that_groups_rows_by_their_lowest_bones(ops)
         assert np.array_equal(np.sort(a), np.sort(b))                                  # same rows
         key = bins(bits_np[a])
         assert np.all(np.diff(key) >= 0), w0                                           # ordered by bin
+        assert np.array_equal(a, b[np.argsort(bins(bits_np[b]), kind="stable")]), w0   # ... and stable inside a bin
         moved += int((a != b).sum())
     assert moved > n // 2
 

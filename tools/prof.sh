@@ -7,7 +7,10 @@ grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"achieved": [0-9.]*\|"avg_lau
 python3 - <<PY
 import csv,os
 rows=list(csv.DictReader(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv")))
-for r in rows[:8]:
-    print(r["Name"][:42].ljust(42), r["Calls"].rjust(3), "avg_us", str(round(float(r["AverageNs"])/1e3,1)).rjust(8), "ms/frame", str(round(int(r["TotalDurationNs"])/7e6,3)).rjust(7), r["Percentage"])
-print("sum per frame ms (5 timed + 1 warm-up + 1 untimed reference frame)", round(sum(int(r["TotalDurationNs"]) for r in rows)/7e6,3))
+# frames of the run (settle phase + warm-up + timed blocks + the reference frame): the final composite runs once per frame
+frames = max([int(r["Calls"]) for r in rows if "k_composite_merged" in r["Name"]] + [1])
+for r in rows[:10]:
+    print(r["Name"][:42].ljust(42), r["Calls"].rjust(4), "avg_us", str(round(float(r["AverageNs"])/1e3,1)).rjust(8), "ms/frame", str(round(int(r["TotalDurationNs"])/1e6/frames,3)).rjust(7), r["Percentage"])
+print("frames", frames, " sum of all kernels per frame ms", round(sum(int(r["TotalDurationNs"]) for r in rows)/1e6/frames,3),
+      " without k_pe_mlp16:", round(sum(int(r["TotalDurationNs"]) for r in rows if "k_pe_mlp16" not in r["Name"])/1e6/frames,3))
 PY
