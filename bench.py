@@ -166,11 +166,32 @@ def cpu_baseline_render(extra, box_bounds, frame=None, stages=None, budget_s=6.0
             big = np.abs(rr) > 0.1 * cmax                       # un-floored relative error where the logit is not near zero ...
             rel = np.abs(raw - rr) / np.maximum(np.abs(rr), 1e-30)
             floored = np.abs(raw - rr) / np.maximum(np.abs(rr), 0.05 * cmax)     # ... and tests/helpers.raw_err's measure everywhere
+            # ... and against the SAME restatement evaluated in float64 on the float32 points and mask: the GPU's own distance from
+            # the exact result of the reference's graph (the float32 restatement is as far from it as the GPU is)
+            m64 = torch_cpu.DanboTorchCPU(cfg, sd, rest, dtype=torch.float64)
+            raw64, a0 = [], 0
+            t64 = lambda v: torch.tensor(np.ascontiguousarray(v)).double()  # noqa: E731
+            rb_all = syn.ray_batch(ro[sl], rd[sl])
+            for nrows, pose_of_ray, bones_g in ref["chunks"]:
+                c = slice(a0, a0 + nrows)
+                z0 = np.zeros(nrows, dtype=np.int64)
+                raw64.append(m64.forward(t64(ref["pts_coarse"][c]), t64(rb_all[c, 3:6]), t64(scene["skts"][z0]), m64._volumes(bones_g),
+                                         torch.as_tensor(pose_of_ray), np.zeros(nrows, np.int64),
+                                         valid=torch.as_tensor(ref["valid_coarse"][c])).numpy())
+                a0 += nrows
+            r64 = np.concatenate(raw64)
+            c64 = np.abs(r64).reshape(-1, 4).max(0)
+            big64 = np.abs(r64) > 0.1 * c64
+            parity.update(max_rel_raw_vs_float64=float((np.abs(raw - r64) / np.maximum(np.abs(r64), 1e-30))[big64].max()),
+                          max_rel_raw_floored_5pct_vs_float64=float((np.abs(raw - r64) / np.maximum(np.abs(r64), 0.05 * c64)).max()),
+                          restatement_fp32_vs_float64_floored_5pct=float((np.abs(rr - r64) / np.maximum(np.abs(r64), 0.05 * c64)).max()))
             parity.update(mask_mismatches=int((valid != ref["valid_coarse"]).sum()), mask_entries=int(valid.size),
                           max_rel_raw=float(rel[big].max()), max_rel_raw_rgb=float(rel[..., :3][big[..., :3]].max()),
                           max_rel_raw_sigma=float(rel[..., 3][big[..., 3]].max()), max_rel_raw_floored_5pct=float(floored.max()),
                           raw_note="coarse-pass logits; max_rel_raw = max |a - b| / |b| over entries with |b| > 0.1 x the channel's "
-                                   "largest |b| (no floor)")
+                                   "largest |b| (no floor), b = the float32 CPU restatement; *_vs_float64: b = the same restatement "
+                                   "in float64 on the float32 points and mask (the float32 restatement's own distance from it is "
+                                   "reported beside: two fp32 evaluations differ by the sum of both)")
     return dict(value=n * (N_SAMPLES + N_IMPORTANCE) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()),
                 host_cpu_count=os.cpu_count(), kind="port",
                 sample=f"{n} centre rays x {N_SAMPLES}+{N_IMPORTANCE} samples of the same frame, every sample through every bone and "

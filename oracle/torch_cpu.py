@@ -28,15 +28,17 @@ def _pe(x, L):
 
 
 class DanboTorchCPU:
-    def __init__(self, cfg, sd, rest_pose, netchunk=65536):
-        self.cfg, self.netchunk = cfg, netchunk
+    def __init__(self, cfg, sd, rest_pose, netchunk=65536, dtype=torch.float32):
+        """dtype = torch.float64: the same graph in double precision on the float32 parameters (bench.py's parity block measures
+        the GPU's logits against it: both fp32 sides -- the GPU and this restatement in float32 -- carry their own round-off)"""
+        self.cfg, self.netchunk, self.dtype = cfg, netchunk, dtype
         self.np_oracle = o.DanboOracle(cfg, sd, rest_pose)
-        self.sd = {k: torch.tensor(np.asarray(v, dtype=np.float32)) for k, v in sd.items() if np.asarray(v).dtype != np.int64}
-        self.align = torch.tensor(self.np_oracle.align.astype(np.float32))
+        self.sd = {k: torch.tensor(np.asarray(v, dtype=np.float32)).to(dtype) for k, v in sd.items() if np.asarray(v).dtype != np.int64}
+        self.align = torch.tensor(self.np_oracle.align.astype(np.float32)).to(dtype)
 
     # ---- network on R x S points
     def _volumes(self, bones):
-        return torch.tensor(o.pose_volumes(self.np_oracle.sd, bones, self.cfg['multires_graph']))      # tiny: per pose
+        return torch.tensor(o.pose_volumes(self.np_oracle.sd, bones, self.cfg['multires_graph'])).to(self.dtype)      # tiny: per pose
 
     def _assign(self, pf):
         sd = self.sd
@@ -67,14 +69,16 @@ class DanboTorchCPU:
             out.append(torch.cat([lin('rgb_linear', hv), alpha], -1))
         return torch.cat(out, 0)
 
-    def forward(self, pts, rays_d, skts, vols, pose_of_ray, cam_idxs, return_enc=False):
+    def forward(self, pts, rays_d, skts, vols, pose_of_ray, cam_idxs, return_enc=False, valid=None):
+        """valid [R,S,24] bool: take the in-volume mask from the caller (a float64 run on float32 points uses the float32 mask)"""
         cfg, sd = self.cfg, self.sd
         R, S = pts.shape[:2]
         # world -> bone -> aligned
         pl = torch.einsum('rjab,rsb->rsja', skts[:, :, :3, :3], pts) + skts[:, None, :, :3, 3]
         pt = torch.einsum('jab,rsjb->rsja', self.align[:, :3, :3], pl) + self.align[None, None, :, :3, 3]
         x = pt / sd['graph_net.axis_scale'].abs()
-        valid = ~(x.abs() > 1).any(-1)
+        if valid is None:
+            valid = ~(x.abs() > 1).any(-1)
         win = torch.exp(-2.0 * (x ** 6).sum(-1))
         # factorised 1-D interpolation (zero padding)
         Fc, res = cfg['voxel_feat'], cfg['voxel_res']
@@ -83,17 +87,17 @@ class DanboTorchCPU:
         y0 = torch.floor(iy)
         w1 = iy - y0
         y0 = y0.long()
-        feat = torch.zeros(R, S, J, Fc, 3)
+        feat = torch.zeros(R, S, J, Fc, 3, dtype=self.dtype)
         for k in range(3):
             vk = vol[..., k].permute(0, 1, 3, 2)                                 # [R,24,res,F]
             for yy, ww in ((y0[..., k], 1.0 - w1[..., k]), (y0[..., k] + 1, w1[..., k])):
                 ok = (yy >= 0) & (yy < res)
                 idx = yy.clamp(0, res - 1).permute(0, 2, 1)[..., None].expand(-1, -1, -1, Fc)        # [R,24,S,F]
                 v = torch.gather(vk, 2, idx).permute(0, 2, 1, 3)                                     # [R,S,24,F]
-                feat[..., k] += torch.where(ok[..., None], v * ww[..., None], torch.zeros(()))
+                feat[..., k] += torch.where(ok[..., None], v * ww[..., None], torch.zeros((), dtype=self.dtype))
         pf = (feat.reshape(R, S, J, Fc * 3) * win[..., None]).reshape(R * S, J, Fc * 3)
         logits = self._assign(pf)
-        p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid.reshape(R * S, J).float()
+        p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid.reshape(R * S, J).to(self.dtype)
         h = (pf * p[..., None]).sum(-2)
         dens_in = _pe(h, cfg['multires_voxel'])
         d = rays_d
@@ -144,7 +148,8 @@ class DanboTorchCPU:
             raw = self.forward(ro[:, None] + rd[:, None] * zt[..., None], rd, sk, vols, pose_of_ray, cam, return_enc=stages)
             if stages:
                 raw, _, valid = raw
-                st.append((raw.numpy(), valid.numpy()))
+                st.append((raw.numpy(), valid.numpy(), (ro[:, None] + rd[:, None] * zt[..., None]).numpy(), pose_of_ray.numpy(),
+                           bones[sl][::skip]))
             out0 = self._composite(raw, zt, rd, self.cfg['density_scale'])
             z_all, z_fine, order = o.importance_z(z, out0['weights'].numpy(), Sf)
             zf = t(z_fine)
@@ -155,7 +160,8 @@ class DanboTorchCPU:
         ret = dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
                    rgb0=np.concatenate([x[2] for x in outs]))
         if stages:
-            ret.update(raw_coarse=np.concatenate([x[0] for x in st]), valid_coarse=np.concatenate([x[1] for x in st]))
+            ret.update(raw_coarse=np.concatenate([x[0] for x in st]), valid_coarse=np.concatenate([x[1] for x in st]),
+                       pts_coarse=np.concatenate([x[2] for x in st]), chunks=[(len(x[0]), x[3], x[4]) for x in st])
         return ret
 
 
