@@ -374,6 +374,8 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             // gather_bone_features() as K1b), then the halves trade 8 values so that lane (m, h) ends up with features
             // 8h .. 8h+7 of BOTH bones: the B-fragment layout.
             half8 fh[6], fl[6];
+            float fself[8];         // this lane's 8 features of the bone ITSELF in fp32: the blend h = sum_j p_j f_j uses these, not the
+                                    // 22-bit hi + lo reconstruction (2.4e-7 of f, which sin(32 h) turns into 8e-6 of the MLP's inputs)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 if (2 * t >= nq) break;     // wave-uniform
@@ -405,6 +407,10 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
                 }
                 a16_split8(even, fh[2 * t], fl[2 * t]);
                 a16_split8(odd, fh[2 * t + 1], fl[2 * t + 1]);
+                if (t == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fself[e] = even[e];
+                }
             }
             stamp(200 + j);
             // ---- layer 0 with the adjacency folded in; accumulator starts at the shared bias ----
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit * -1.44269504088896340736f));
             const float pj = (sg * 1.002f - 0.001f) * valid;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hacc[e] = fmaf(pj, (float)fh[0][e] + (float)fl[0][e], hacc[e]);
+            for (int e = 0; e < 8; ++e) hacc[e] = fmaf(pj, fself[e], hacc[e]);
             if (TRAIN) qsum += pj;
         }
         stamp(3);
