@@ -23,7 +23,8 @@ SIGNATURES = {
     "danbo_near_far_cylinder": [P, P, P, I, I, F, F, P, P, I, P, P, P, P],
     "danbo_near_far_boxes": [P, P, P, P, P, I, I, P, P, P],
     "danbo_coarse_samples": [P, P, I, I, P, P, P],
-    "danbo_bone_cull": [P, P, P, P, I, I, I, P, P, P, P, P, P, P],
+    "danbo_bone_cull": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "danbo_ray_bone_mask": [P, P, P, P, I, I, P, P, P, P, P],
     "danbo_bone_gather_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P, P],
     "danbo_assign_blend_fwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
     "danbo_gather_assign_blend_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],

@@ -93,7 +93,7 @@ def coarse_samples(near, far, S, t_rand=None):
 class Geometry:
     """Per-call bundle of the geometric inputs shared by K1a / K1b / K2."""
 
-    def __init__(self, rays_o, rays_d, skts, align, axis_scale, z=None, pts=None):
+    def __init__(self, rays_o, rays_d, skts, align, axis_scale, z=None, pts=None, ray_mask=None):
         self.rays_o = _f32(rays_o, "rays_o")
         self.rays_d = _f32(rays_d, "rays_d")
         self.skts = _f32(skts, "skts")          # [G,24,4,4]
@@ -107,21 +107,43 @@ class Geometry:
         self.S = self.z.shape[1] if self.z is not None else self.pts.shape[1]
         self.M = self.R * self.S
         self.device = self.rays_o.device
+        # (mask [R] int32, t_lo [R], t_hi [R]) of ray_bone_mask() for these rays, or None: bone_cull's accelerator
+        self.ray_mask = ray_mask if self.z is not None else None
 
     def head(self):
         return (_p(self.rays_o), _p(self.rays_d), _p(self.z), _p(self.pts), self.R, self.S, self.G,
                 _p(self.skts), _p(self.align), _p(self.axis_scale))
 
 
-def bone_cull(geo, compact=True):
-    """-> valid_bits [M] (int32 view of uint32), list [M] int32 or None, count [1] int32 or None."""
+def bone_cull(geo, compact=True, cnt=None):
+    """-> valid_bits [M] (int32 view of uint32), list [M] int32 or None, count [1] int32 or None.
+    cnt: a ZEROED [1] int32 the caller provides (render(): one fill for both passes) instead of a fresh one."""
     bits = torch.empty(geo.M, device=geo.device, dtype=torch.int32)
-    lst = cnt = None
+    lst = None
     if compact:
         lst = torch.empty(geo.M, device=geo.device, dtype=torch.int32)
-        cnt = torch.zeros(1, device=geo.device, dtype=torch.int32)
-    _call("danbo_bone_cull", *geo.head(), _p(bits), _p(lst), _p(cnt), _stream())
+        if cnt is None:
+            cnt = torch.zeros(1, device=geo.device, dtype=torch.int32)
+        assert cnt.dtype == torch.int32 and cnt.numel() == 1 and cnt.is_contiguous()
+    else:
+        cnt = None
+    rm = geo.ray_mask if geo.ray_mask is not None else (None, None, None)
+    _call("danbo_bone_cull", *geo.head(), _p(rm[0]), _p(rm[1]), _p(rm[2]), _p(bits), _p(lst), _p(cnt), _stream())
     return bits, lst, cnt
+
+
+def ray_bone_mask(rays_o, rays_d, skts, align, axis_scale, t_lo, t_hi):
+    """-> (mask [R] int32, t_lo, t_hi): bit j of mask[r] clear = no point of ray r between t_lo[r] and t_hi[r] can lie inside
+    bone j's volume (conservative slab test, csrc/k_sample.hip:k_ray_bone_mask).  Pass it to Geometry(ray_mask=...): bone_cull
+    then skips the rays -- and whole workgroups -- that miss every volume; the in-volume mask itself does not depend on it."""
+    rays_o, rays_d, skts = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(skts, "skts")
+    t_lo, t_hi = _f32(t_lo, "t_lo").reshape(-1), _f32(t_hi, "t_hi").reshape(-1)
+    R, G = rays_o.shape[0], skts.shape[0]
+    assert t_lo.shape[0] == R and t_hi.shape[0] == R
+    mask = torch.empty(R, device=rays_o.device, dtype=torch.int32)
+    _call("danbo_ray_bone_mask", _p(rays_o), _p(rays_d), _p(t_lo), _p(t_hi), R, G, _p(skts), _p(_f32(align, "align")),
+          _p(_f32(axis_scale, "axis_scale")), _p(mask), _stream())
+    return mask, t_lo, t_hi
 
 
 def group_rows(bits, lst, cnt):

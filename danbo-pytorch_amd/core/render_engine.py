@@ -26,7 +26,7 @@ class DanboEngine:
         self.mean_code = None
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
-        self._side = None            # side stream of render()
+        self._side = None            # side streams of render()
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
@@ -163,19 +163,21 @@ class DanboEngine:
                                self.code_table)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None, fill=True, ready=None):
+                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
                      the per-ray empty-space raw (identical values).
         dense=True : every sample goes through every kernel (the reference's executed work).
-        ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used."""
+        ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used.
+        ray_mask: ops.ray_bone_mask() of these rays over an interval that holds every depth of z (render: [near, far]).
+        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once)."""
         self.refresh()
-        geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts)
+        geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts, ray_mask=ray_mask)
         vols = self.volumes(bones) if volumes is None else volumes
         cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
         S = geo.S
-        bits, lst, cnt = ops.bone_cull(geo, compact=not dense)
+        bits, lst, cnt = ops.bone_cull(geo, compact=not dense, cnt=count)
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
         if ready is not None:
@@ -279,35 +281,42 @@ class DanboEngine:
         Sf = N_importance or cfg["N_importance"]
         B = cfg["density_scale"]
         self.refresh()
-        # The per-pose volumes (4 small launches, ~70 us) and the per-ray view constants (~140 us at 512 x 512) depend on
-        # nothing the bounds / depths / cull chain computes: they run on a side stream under it; the main stream waits for the
-        # volumes in front of K2 and for the view constants in front of K3.  (Inside a HIP-graph capture the chain stays linear.)
+        # The per-pose volumes (4 small launches, ~110 us of latency) and the per-ray view constants (~190 us at 512 x 512) depend
+        # on nothing the bounds / depths / cull chain computes: each runs on its own side stream under that chain (all of it
+        # latency-bound: they share the GPU well); the main stream waits for the volumes in front of K2 and for the view constants
+        # in front of K3.  (The view constants behind the volumes on ONE side stream started 120 us late and then ran beside the
+        # row grouping and K2: 27 -> 96 us for the grouping.)  Inside a HIP-graph capture the chain stays linear.
         ready = None
         if rays_o.is_cuda and not torch.cuda.is_current_stream_capturing():
             cur = torch.cuda.current_stream()
-            if self._side is None or self._side.device != rays_o.device:
-                self._side = torch.cuda.Stream(device=rays_o.device)
-            side = self._side
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                vols = self.volumes(bones)
-                ev_vols = torch.cuda.Event()
-                ev_vols.record(side)
+            if self._side is None or self._side[0].device != rays_o.device:
+                self._side = (torch.cuda.Stream(device=rays_o.device), torch.cuda.Stream(device=rays_o.device))
+            for side in self._side:
+                side.wait_stream(cur)
+            with torch.cuda.stream(self._side[0]):
                 view = self.view_constants(rays_d, skts, cam_idx)
                 ev_view = torch.cuda.Event()
-                ev_view.record(side)
+                ev_view.record(self._side[0])
+            with torch.cuda.stream(self._side[1]):
+                vols = self.volumes(bones)
+                ev_vols = torch.cuda.Event()
+                ev_vols.record(self._side[1])
             for t in (vols, view[0], view[1]):
                 t.record_stream(cur)
             ready = (ev_vols, ev_view)
         near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
         z = ops.coarse_samples(near, far, S)
+        # candidate bones of every ray over [near, far] (coarse and importance depths both lie inside): the two culls skip the
+        # rays, and whole workgroups, that miss every volume -- most of a frame
+        ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far)
+        counts = torch.zeros(2, device=rays_o.device, dtype=torch.int32)       # rows of the two passes: one fill
         if ready is None:
             vols = self.volumes(bones)
             view = self.view_constants(rays_d, skts, cam_idx)
         fused = S <= 64 and Sf <= 64
         lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy, ready=ready)
+                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1])
         if fused:
             out0, z_all, z_fine, order = ops.composite_importance(
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
@@ -316,7 +325,7 @@ class DanboEngine:
             out0 = ops.composite(raw, z, rays_d, B)
             z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
         raw_f, ex_f = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z_fine, dense=dense,
-                                           volumes=vols, view=view, fill=not lazy)
+                                           volumes=vols, view=view, fill=not lazy, ray_mask=ray_mask, count=counts[1:2])
         out = ops.composite_merged(raw, raw_f, order, z_all, rays_d, B, bits_a=ex["valid_bits"] if lazy else None,
                                    bits_b=ex_f["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
                                    want_raw=keep)

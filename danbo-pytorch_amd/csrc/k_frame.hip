@@ -22,7 +22,7 @@ struct Carver {
 
 struct FrameBuffers {
     float *near, *far, *cyl_scratch, *z, *vol_scratch, *volumes, *cview, *raw_empty, *h, *raw_a, *raw_b, *z_fine, *z_sorted;
-    uint32_t *bits_a, *bits_b;
+    uint32_t *bits_a, *bits_b, *ray_mask;
     int32_t *list, *count, *order;
 };
 
@@ -37,6 +37,7 @@ FrameBuffers carve(Carver& c, int R, int G, int S, int Sf, int chunk, int Wg) {
     b.volumes = c.take<float>((size_t)G * 24 * 240);
     b.cview = c.take<float>((size_t)R * 128);
     b.raw_empty = c.take<float>((size_t)R * 4);
+    b.ray_mask = c.take<uint32_t>(R);
     b.bits_a = c.take<uint32_t>(M);
     b.bits_b = c.take<uint32_t>(Mf);
     b.list = c.take<int32_t>(M);          // re-used by the importance pass (Mf <= M is not assumed: max below)
@@ -79,6 +80,8 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     if (m->use_volume_near_far)
         DANBO_TRY(danbo_near_far_boxes(r->rays_o, r->rays_d, r->skts, m->align, m->axis_scale, R, G, b.near, b.far, stream));
     DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, nullptr, b.z, stream));
+    // candidate bones of every ray over [near, far]: both culls below skip the rays (and workgroups) that miss every volume
+    DANBO_TRY(danbo_ray_bone_mask(r->rays_o, r->rays_d, b.near, b.far, R, G, r->skts, m->align, m->axis_scale, b.ray_mask, stream));
     // per pose / per ray
     DANBO_TRY(danbo_pose_volumes_fwd(r->bones, G, m->L_graph, m->graph_width, m->g_w0, m->g_adjw0, m->g_b0, m->g_w1, m->g_adjw1, m->g_b1,
                                      m->g_w2, m->g_b2, m->g_w3, m->g_b3, b.vol_scratch, b.volumes, stream));
@@ -88,7 +91,8 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     // one network pass over R x s samples at depths zz -> raw (rows outside every volume stay unwritten: bits == 0)
     zero_words(b.count, 4, nullptr, 0, st);      // both row counters and the ticket (which returns to 0 after each launch)
     auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
-        DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, bits, b.list, count, stream));
+        DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.near, b.far, bits,
+                                  b.list, count, stream));
         DANBO_TRY(danbo_group_rows(bits, b.list, count, R * s, stream));     // rows of the same bone set next to each other (k_group.hip)
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,
                                                   bits, b.list, count, R * s, m->assign16, m->a_b0, m->a_b1, m->a_w2, m->a_b2, b.h,

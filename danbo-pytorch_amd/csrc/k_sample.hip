@@ -187,6 +187,81 @@ __device__ __forceinline__ void affine_pk(const float* M, v2f x, v2f y, v2f z, v
     }
 }
 
+// Conservative ray-level rejection shared by k_ray_bone_mask and the in-kernel prefilter of k_bone_cull: true when the
+// segment {o + t d : zl - pad <= t <= zh + pad} provably misses the slightly inflated box of the bone (margins far above the
+// fp32 round-off of the transform chain).  NaN anywhere -> not provably missed -> false.
+__device__ __forceinline__ bool segment_misses_bone(const float* sk, const float* al, const float* sc /*|axis scale|, 3*/,
+                                                    const float* o, const float* d, float zl, float zh) {
+    float ol[3], dl[3], t[3];
+    bone_local(sk, al, o, ol);
+    for (int k = 0; k < 3; ++k) t[k] = sk[4 * k] * d[0] + sk[4 * k + 1] * d[1] + sk[4 * k + 2] * d[2];
+    for (int k = 0; k < 3; ++k) dl[k] = al[4 * k] * t[0] + al[4 * k + 1] * t[1] + al[4 * k + 2] * t[2];
+    const float pad = 1e-4f * fmaxf(fabsf(zl), fabsf(zh)) + 1e-5f;
+    float tmin = zl - pad, tmax = zh + pad;
+    bool miss = false;
+    for (int k = 0; k < 3; ++k) {
+        const float s = sc[k] * 1.001f + 1e-4f;
+        if (fabsf(dl[k]) < 1e-12f) {
+            miss = miss || fabsf(ol[k]) > s;
+        } else {
+            const float inv = 1.0f / dl[k];
+            const float t1 = (-s - ol[k]) * inv, t2 = (s - ol[k]) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2));
+            tmax = fminf(tmax, fmaxf(t1, t2));
+        }
+    }
+    return miss || tmin > tmax;
+}
+
+// ray_mask[r] bit j = 0: no point o + t d of ray r with t_lo[r] <= t <= t_hi[r] (+ the pad above) can lie inside the volume of
+// bone j.  Once per frame -- both sampling passes of a ray stay inside its [near, far].  A thread per ray walks the 24 bones out
+// of LDS (the poses of the workgroup's 256 rays are staged: POSES_IN_LDS; otherwise the matrices come from global memory): no
+// memory round trip inside the loop.  (A lane per (ray, bone) as k_box_bounds, matrices from global: 48 us for 262 144 rays, all
+// of it load latency; this: see DESIGN.md section 3.)
+// No reference counterpart (the reference tests every sample against every bone, gnn_backbone.py:787-828): the exact per-sample
+// test of k_bone_cull is unchanged, this only tells it which bones (and which whole workgroups) cannot matter.
+template <bool POSES_IN_LDS>
+__global__ __launch_bounds__(256) void k_ray_bone_mask(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const float* __restrict__ t_lo, const float* __restrict__ t_hi,
+                                                       const float* __restrict__ skts, const float* __restrict__ align,
+                                                       const float* __restrict__ axis_scale, int R, int G,
+                                                       uint32_t* __restrict__ ray_mask) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_align = smem;                 // [24][16]
+    float* s_scale = smem + J * 16;        // [24][4]
+    float* s_skt = smem + J * 16 + J * 4;  // [poses of this workgroup][24][16]
+    const int rays_per_pose = R / G;
+    const int r_a = blockIdx.x * 256, r_b = min(r_a + 255, R - 1);
+    const int g0 = min(r_a / rays_per_pose, G - 1), g1 = min(r_b / rays_per_pose, G - 1);
+    // this thread's ray first: its loads fly while the matrices are staged
+    const int r = min(r_a + (int)threadIdx.x, R - 1);
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const float zl = t_lo[r], zh = t_hi[r];
+    for (int i = threadIdx.x; i < J * 16; i += 256) s_align[i] = align[i];
+    for (int i = threadIdx.x; i < J * 4; i += 256) s_scale[i] = (i & 3) < 3 ? fabsf(axis_scale[(i >> 2) * 3 + (i & 3)]) : 0.f;
+    if (POSES_IN_LDS)
+        for (int i = threadIdx.x; i < (g1 - g0 + 1) * J * 16; i += 256) s_skt[i] = skts[(size_t)g0 * J * 16 + i];
+    __syncthreads();
+    const int g = min(r / rays_per_pose, G - 1);
+    uint32_t bits = 0u;
+    if (POSES_IN_LDS) {
+        const float* sk = s_skt + (size_t)(g - g0) * J * 16;
+#pragma unroll 2
+        for (int j = 0; j < J; ++j)
+            bits |= segment_misses_bone(sk + 16 * j, s_align + 16 * j, s_scale + 4 * j, o, d, zl, zh) ? 0u : 1u << j;
+    } else {
+        for (int j = 0; j < J; ++j) {
+            float sk[12];
+            const float* src = skts + ((size_t)g * J + j) * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) sk[i] = src[i];
+            bits |= segment_misses_bone(sk, s_align + 16 * j, s_scale + 4 * j, o, d, zl, zh) ? 0u : 1u << j;
+        }
+    }
+    if (r_a + (int)threadIdx.x < R) ray_mask[r] = bits;
+}
+
 constexpr int CULL_BLOCK = 256;
 constexpr int CULL_SPT = 4;  // samples per thread -> 1024 consecutive samples per workgroup
 constexpr int CULL_MAX_RAYS = 130;  // rays a workgroup may span (S >= 8) for the ray-level bone rejection
@@ -198,6 +273,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
                                                           const float* __restrict__ skts,
                                                           const float* __restrict__ align,
                                                           const float* __restrict__ axis_scale, int np_lds,
+                                                          const uint32_t* __restrict__ ray_mask,
+                                                          const float* __restrict__ t_lo, const float* __restrict__ t_hi,
                                                           uint32_t* __restrict__ valid_bits,
                                                           int32_t* __restrict__ list, int32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -214,56 +291,99 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
     const int g0 = (int)min(base / spp, (long)G - 1);
     const int g1 = (int)min(last / spp, (long)G - 1);
 
+    const int lane = threadIdx.x & 63;
+    // 32-bit bookkeeping of the workgroup's 1024 samples: sample k * 256 + tid of the workgroup is ray r_first + li / S with
+    // li = off0 + k * 256 + tid < S + 1024 (one 64-bit division per workgroup instead of a dozen per thread -- the emulated 64-bit
+    // divides of m / S and m / spp were most of this kernel's instructions), pose = ray / rays_per_pose
+    const int r_first = (int)(base / S), r_last = (int)(last / S);
+    const int off0 = (int)(base - (long)r_first * S);
+    const int rays_per_pose = R / G;
+    const float inv_S = 1.0f / (float)S;
+    auto ray_of = [&](int li) {          // r_first + li / S, exact for li < 2^22
+        int q = (int)((float)li * inv_S);
+        q -= (q * S > li) ? 1 : 0;
+        q += ((q + 1) * S <= li) ? 1 : 0;
+        return q;
+    };
+    auto pose_of = [&](int r) { return G == 1 ? 0 : min(r / rays_per_pose, G - 1); };
+    // ---- ray-level rejection (z mode): a bone whose slightly inflated box the ray's sampled segment misses
+    // cannot contain any of the ray's samples, so whole wavefronts skip it.  Conservative (margins far above
+    // fp32 round-off of the transform chain); the per-sample test below is unchanged, so the mask stays exact.
+    const int nrays = r_last - r_first + 1;
+    const bool prefilter = pts == nullptr && ray_mask == nullptr && nrays <= CULL_MAX_RAYS;
+    // this thread's depths (z mode): sample k * 256 + tid of the workgroup -- read once, used by the ray extents and by the points
+    float zreg[CULL_SPT];
+    if (pts == nullptr) {
+#pragma unroll
+        for (int k = 0; k < CULL_SPT; ++k) zreg[k] = z[min(base + k * CULL_BLOCK + threadIdx.x, M - 1)];
+    }
+    // ---- with a per-ray bone mask (k_ray_bone_mask, once per frame): candidate bones of every sample without touching a
+    // matrix.  A depth outside the interval the mask was made for falls back to all bones (the mask stays exact whatever the
+    // caller passes); a workgroup none of whose samples has a candidate -- most of a frame: the body covers a tenth of the
+    // image -- stores its zeros and leaves before staging anything.
+    uint32_t pre[CULL_SPT];
+    if (ray_mask != nullptr) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < CULL_SPT; ++k) {
+            pre[k] = 0u;
+            if (base + k * CULL_BLOCK + threadIdx.x < M) {
+                const int r = r_first + ray_of(off0 + k * CULL_BLOCK + threadIdx.x);
+                const float lo = t_lo[r], hi = t_hi[r];
+                const float slack = 5e-5f * fmaxf(fabsf(lo), fabsf(hi));   // half of segment_misses_bone's pad
+                const bool inside = zreg[k] >= lo - slack && zreg[k] <= hi + slack;
+                pre[k] = inside ? ray_mask[r] : (1u << J) - 1u;
+            }
+            any = any || pre[k] != 0u;
+        }
+        if (!__syncthreads_or(any ? 1 : 0)) {
+#pragma unroll
+            for (int k = 0; k < CULL_SPT; ++k)
+                if (base + k * CULL_BLOCK + threadIdx.x < M) valid_bits[base + k * CULL_BLOCK + threadIdx.x] = 0u;
+            return;
+        }
+    }
     for (int i = threadIdx.x; i < J * 16; i += CULL_BLOCK) s_align[i] = align[i];
     for (int i = threadIdx.x; i < J * 4; i += CULL_BLOCK) s_scale[i] = (i & 3) < 3 ? fabsf(axis_scale[(i >> 2) * 3 + (i & 3)]) : 0.f;
     const int npose = g1 - g0 + 1;  // <= np_lds by construction of the launch
     for (int i = threadIdx.x; i < npose * J * 16; i += CULL_BLOCK) s_skt[i] = skts[(size_t)g0 * J * 16 + i];
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    // ---- ray-level rejection (z mode): a bone whose slightly inflated box the ray's sampled segment misses
-    // cannot contain any of the ray's samples, so whole wavefronts skip it.  Conservative (margins far above
-    // fp32 round-off of the transform chain); the per-sample test below is unchanged, so the mask stays exact.
-    const int r_first = (int)(base / S), r_last = (int)(last / S);
-    const int nrays = r_last - r_first + 1;
-    const bool prefilter = pts == nullptr && nrays <= CULL_MAX_RAYS;
     if (prefilter) {
+        // extent [min z, max z] of every ray's samples in this workgroup's window -- the samples of a ray are either sorted
+        // (coarse / deterministic importance) or not (random draws): LDS atomics on an order-preserving integer image of the
+        // floats, all 256 threads (one thread per ray walking its S depths one after the other was a chain of S loads)
+        int* s_lo = reinterpret_cast<int*>(s_zlo);
+        int* s_hi = reinterpret_cast<int*>(s_zhi);
+        for (int i = threadIdx.x; i < nrays; i += CULL_BLOCK) { s_lo[i] = INT_MAX; s_hi[i] = INT_MIN; s_mask[i] = 0u; }
+        __syncthreads();
+        auto ordered = [](float f) { const int b = __builtin_bit_cast(int, f); return b >= 0 ? b : (int)(0x80000000u - (unsigned)b); };
+        auto unordered = [](int o) { return __builtin_bit_cast(float, o >= 0 ? o : (int)(0x80000000u - (unsigned)o)); };
+#pragma unroll
+        for (int k = 0; k < CULL_SPT; ++k) {
+            if (base + k * CULL_BLOCK + threadIdx.x < M) {
+                const int i = ray_of(off0 + k * CULL_BLOCK + threadIdx.x);
+                const int oz = ordered(zreg[k]);
+                atomicMin(&s_lo[i], oz);
+                atomicMax(&s_hi[i], oz);
+            }
+        }
+        __syncthreads();
+        // A window that starts or ends inside a ray sees only part of that ray's samples: its extent here covers exactly the
+        // samples THIS workgroup tests, which is all the rejection needs.
         for (int i = threadIdx.x; i < nrays; i += CULL_BLOCK) {
-            const size_t m0 = (size_t)(r_first + i) * S;
-            // the samples of a ray are either sorted (coarse / deterministic importance) or not (random draws):
-            // take the true min / max of the row
-            float lo = z[m0], hi = lo;
-            for (int k = 1; k < S; ++k) { const float v = z[m0 + k]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
-            s_zlo[i] = lo; s_zhi[i] = hi; s_mask[i] = 0u;
+            const float lo = unordered(s_lo[i]), hi = unordered(s_hi[i]);
+            s_zlo[i] = lo; s_zhi[i] = hi;
         }
         __syncthreads();
         for (int q = threadIdx.x; q < nrays * J; q += CULL_BLOCK) {
             const int i = q / J, j = q % J, r = r_first + i;
-            const int g = (int)min((long)r * S / spp, (long)G - 1);
+            const int g = pose_of(r);
             const float* sk = s_skt + (g - g0) * J * 16 + 16 * j;
             const float* al = s_align + 16 * j;
             const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
             const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-            float ol[3], dl[3], t[3];
-            bone_local(sk, al, o, ol);
-            for (int k = 0; k < 3; ++k) t[k] = sk[4 * k] * d[0] + sk[4 * k + 1] * d[1] + sk[4 * k + 2] * d[2];
-            for (int k = 0; k < 3; ++k) dl[k] = al[4 * k] * t[0] + al[4 * k + 1] * t[1] + al[4 * k + 2] * t[2];
-            const float zl = s_zlo[i], zh = s_zhi[i];
-            const float pad = 1e-4f * fmaxf(fabsf(zl), fabsf(zh)) + 1e-5f;
-            float tmin = zl - pad, tmax = zh + pad;
-            bool miss = false;
-            for (int k = 0; k < 3; ++k) {
-                const float sc = s_scale[4 * j + k] * 1.001f + 1e-4f;
-                if (fabsf(dl[k]) < 1e-12f) {
-                    miss = miss || fabsf(ol[k]) > sc;
-                } else {
-                    const float inv = 1.0f / dl[k];
-                    const float t1 = (-sc - ol[k]) * inv, t2 = (sc - ol[k]) * inv;
-                    tmin = fmaxf(tmin, fminf(t1, t2));
-                    tmax = fminf(tmax, fmaxf(t1, t2));
-                }
-            }
-            miss = miss || tmin > tmax;   // NaN anywhere -> not provably missed -> keep the bone
+            const bool miss = segment_misses_bone(sk, al, s_scale + 4 * j, o, d, s_zlo[i], s_zhi[i]);
             if (!miss) atomicOr(&s_mask[i], 1u << j);
         }
         __syncthreads();
@@ -277,15 +397,30 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
         const long ma = base + (2 * pr) * CULL_BLOCK + threadIdx.x;
         const long mb = ma + CULL_BLOCK;
         const long mac = min(ma, M - 1), mbc = min(mb, M - 1);
+        // (clamped tail samples repeat the last sample: local index of the clamp)
+        const int lia = (int)(mac - base) + off0, lib = (int)(mbc - base) + off0;
+        const int ra = r_first + ray_of(lia), rb = r_first + ray_of(lib);
         float pa[3], pb[3];
-        load_point(rays_o, rays_d, z, pts, mac, S, pa);
-        load_point(rays_o, rays_d, z, pts, mbc, S, pb);
-        const int ga = (int)min(mac / spp, (long)G - 1), gb = (int)min(mbc / spp, (long)G - 1);
+        if (pts != nullptr) {
+            pa[0] = pts[3 * mac]; pa[1] = pts[3 * mac + 1]; pa[2] = pts[3 * mac + 2];
+            pb[0] = pts[3 * mbc]; pb[1] = pts[3 * mbc + 1]; pb[2] = pts[3 * mbc + 2];
+        } else {
+            const float oa[3] = {rays_o[3 * ra], rays_o[3 * ra + 1], rays_o[3 * ra + 2]};
+            const float da[3] = {rays_d[3 * ra], rays_d[3 * ra + 1], rays_d[3 * ra + 2]};
+            const float ob[3] = {rays_o[3 * rb], rays_o[3 * rb + 1], rays_o[3 * rb + 2]};
+            const float db[3] = {rays_d[3 * rb], rays_d[3 * rb + 1], rays_d[3 * rb + 2]};
+            // (a clamped tail sample re-reads the last depth, as z[mac] did)
+            sample_point(oa, da, ma < M ? zreg[2 * pr] : z[M - 1], pa);
+            sample_point(ob, db, mb < M ? zreg[2 * pr + 1] : z[M - 1], pb);
+        }
+        const int ga = pose_of(ra), gb = pose_of(rb);
         uint32_t ba = 0, bb = 0;
         // bones any lane of this wavefront may be inside (wave-uniform)
         uint32_t need = (1u << J) - 1u;
-        if (prefilter) {
-            uint32_t mine = s_mask[(int)(mac / S) - r_first] | s_mask[(int)(mbc / S) - r_first];
+        if (ray_mask != nullptr) {
+            need = wave_or(pre[2 * pr] | pre[2 * pr + 1]);
+        } else if (prefilter) {
+            uint32_t mine = s_mask[ra - r_first] | s_mask[rb - r_first];
             need = wave_or(mine);
         }
         if (__builtin_amdgcn_readfirstlane((int)__all(ga == gb))) {
@@ -880,11 +1015,13 @@ extern "C" int danbo_coarse_samples(const float* near, const float* far, int R, 
 }
 
 extern "C" int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
-                                const float* skts, const float* align, const float* axis_scale, uint32_t* valid_bits,
-                                int32_t* list, int32_t* count, void* stream) {
+                                const float* skts, const float* align, const float* axis_scale, const uint32_t* ray_mask,
+                                const float* t_lo, const float* t_hi, uint32_t* valid_bits, int32_t* list, int32_t* count,
+                                void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0);
     DANBO_CHECK_ARG((list == nullptr) == (count == nullptr));
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
+    DANBO_CHECK_ARG(ray_mask == nullptr || (z != nullptr && t_lo != nullptr && t_hi != nullptr));
     const long M = (long)R * S;
     const long spp = (long)(R / G) * S;
     const int per_block = CULL_BLOCK * CULL_SPT;
@@ -894,7 +1031,24 @@ extern "C" int danbo_bone_cull(const float* rays_o, const float* rays_d, const f
     DANBO_CHECK_ARG(lds <= 64 * 1024);
     const int grid = ceil_div(M, per_block);
     hipLaunchKernelGGL(k_bone_cull, dim3(grid), dim3(CULL_BLOCK), lds, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
-                       G, skts, align, axis_scale, (int)np, valid_bits, list, count);
+                       G, skts, align, axis_scale, (int)np, ray_mask, t_lo, t_hi, valid_bits, list, count);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_ray_bone_mask(const float* rays_o, const float* rays_d, const float* t_lo, const float* t_hi, int R, int G,
+                                    const float* skts, const float* align, const float* axis_scale, uint32_t* ray_mask,
+                                    void* stream) {
+    DANBO_CHECK_ARG(rays_o && rays_d && t_lo && t_hi && skts && align && axis_scale && ray_mask);
+    DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0);
+    const long np = 256 / (R / G) + 2 < G ? 256 / (R / G) + 2 : G;     // poses a workgroup's 256 rays can span
+    const bool in_lds = np <= 8;
+    const size_t lds = sizeof(float) * (J * 16 + J * 4 + (in_lds ? np * J * 16 : 0));
+    if (in_lds)
+        hipLaunchKernelGGL(k_ray_bone_mask<true>, dim3(ceil_div(R, 256)), dim3(256), lds, (hipStream_t)stream, rays_o, rays_d, t_lo, t_hi,
+                           skts, align, axis_scale, R, G, ray_mask);
+    else
+        hipLaunchKernelGGL(k_ray_bone_mask<false>, dim3(ceil_div(R, 256)), dim3(256), lds, (hipStream_t)stream, rays_o, rays_d, t_lo,
+                           t_hi, skts, align, axis_scale, R, G, ray_mask);
     DANBO_LAUNCH_RET();
 }
 

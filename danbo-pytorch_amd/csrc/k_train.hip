@@ -419,7 +419,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     if (m->use_volume_near_far)
         DANBO_TRY(danbo_near_far_boxes(bt->rays_o, bt->rays_d, bt->skts, m->align, axis_scale, R, G, b.near, b.far, stream));
     DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, bt->t_rand, b.z_c, stream));
-    DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, b.z_c, nullptr, R, S, G, bt->skts, m->align, axis_scale, b.bits_c, b.row_sample + R, b.cnt,
+    DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, b.z_c, nullptr, R, S, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, b.bits_c,
+                              b.row_sample + R, b.cnt,
                               stream));
     hipLaunchKernelGGL(k_train_small, dim3(1), dim3(256), 0, (hipStream_t)s1, m->p[DANBO_T_G_ADJW0], m->g_adj0, m->p[DANBO_T_G_ADJW1], m->g_adj1,
                        m->p[DANBO_T_A_ADJW], m->a_adj, b.adj_prod, m->p[DANBO_T_AXIS_SCALE], m->init_scale, m->vol_scale_penalty,
@@ -445,7 +446,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         const int s = pass == 0 ? S : Sf;
         uint32_t* bits = pass == 0 ? b.bits_c : b.bits_f;
         if (pass != 0)       // (pass 0's cull ran in the prologue)
-            DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, bits, b.row_sample + R, b.cnt,
+            DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, bits,
+                                      b.row_sample + R, b.cnt,
                                       stream));
         NET_STAGE(21);
         if (pass == 0) DANBO_TRY(join(1));       // the pose volumes and the assignment net's packing

@@ -30,7 +30,7 @@ extern "C" {
 
 /* library / device identification (host only).
  * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
- * danbo_group_rows (additive). */
+ * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, and danbo_bone_cull takes its result (three nullable pointers). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -88,12 +88,27 @@ int danbo_coarse_samples(const float* near, const float* far, int R, int S, cons
  *   valid_bits[m] bit j = sample m inside bone j's volume.
  *   If `list` != NULL: indices of samples with valid_bits != 0 are appended to list and
  *   *count (which the caller zeroes) is incremented -- order unspecified.
+ *   ray_mask / t_lo / t_hi (all three or none; z mode only): the result of danbo_ray_bone_mask for
+ *   these rays.  Purely an accelerator -- the per-sample test is the same and a depth outside
+ *   [t_lo, t_hi] of its ray is tested against every bone, so valid_bits never depends on it;
+ *   workgroups whose rays miss every volume write their zeros and leave (a 512 x 512 x 48 pass:
+ *   135 -> 3x us).  Without it the kernel derives the same rejection per 1024-sample window.
  * ------------------------------------------------------------------------------------- */
 int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
                     const float* skts /*[G,24,4,4]*/, const float* align /*[24,4,4]*/,
-                    const float* axis_scale /*[24,3]*/,
+                    const float* axis_scale /*[24,3]*/, const uint32_t* ray_mask /*[R] or NULL*/,
+                    const float* t_lo /*[R] or NULL*/, const float* t_hi /*[R] or NULL*/,
                     uint32_t* valid_bits /*[R*S]*/, int32_t* list /*[R*S] or NULL*/,
                     int32_t* count /*[1] or NULL*/, void* stream);
+
+/* Per-ray candidate bones: ray_mask[r] bit j = 0 when no point rays_o + t rays_d with
+ * t_lo[r] <= t <= t_hi[r] can lie inside the volume of bone j (slab test of the segment against the
+ * slightly inflated box, conservative).  Once per ray batch -- the coarse and the importance samples
+ * of a ray both lie inside its [near, far].  No reference counterpart: the reference evaluates every
+ * sample against every bone (core/networks/gnn_backbone.py:787-828); this feeds danbo_bone_cull. */
+int danbo_ray_bone_mask(const float* rays_o, const float* rays_d, const float* t_lo /*[R]*/, const float* t_hi /*[R]*/,
+                        int R, int G, const float* skts, const float* align, const float* axis_scale,
+                        uint32_t* ray_mask /*[R]*/, void* stream);
 
 /* K1b  factorised tri-axis gather (factorize_grid_sample, core/networks/misc.py:331-351;
  * windowing + 'cat' construct, gnn_backbone.py:803-826) for the n listed samples

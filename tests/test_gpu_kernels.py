@@ -50,7 +50,7 @@ def test_library_and_device(ops):
     import ctypes
     from core import _hip
     l = _hip.lib()
-    assert l.danbo_abi_version() == 4
+    assert l.danbo_abi_version() == 5
     cu, lds = ctypes.c_int(), ctypes.c_int()
     arch = ctypes.create_string_buffer(64)
     assert l.danbo_device_info(ctypes.byref(cu), ctypes.byref(lds), arch, 64) == 0
@@ -555,3 +555,54 @@ def test_render_is_bitwise_independent_of_the_row_order(stage):
     assert int(a["count_coarse"].item()) == int(b["count_coarse"].item()) > 20000      # more than one window of 16 384 rows
     for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "alpha0", "raw_coarse", "raw_fine", "z_fine"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_ray_bone_mask_is_conservative_and_never_changes_the_in_volume_mask(ops, stage):
+    """k_ray_bone_mask only tells k_bone_cull what it may skip: with it, without it (the per-window rejection inside the kernel),
+    and with an interval that does NOT hold the depths (every sample then falls back to all bones) the in-volume mask and the
+    compacted list are the same; every bone a sample of a ray is inside is a candidate of that ray."""
+    from core.utils import synthetic as syn
+    eng = stage["eng"]
+    eng.refresh()
+    scene = syn.make_scene(n_poses=2, H=96, W=96, n_views=2, pose_seed=4)
+    ro = T(np.concatenate([scene["rays"][0][0], scene["rays"][1][0]]))
+    rd = T(np.concatenate([scene["rays"][0][1], scene["rays"][1][1]]))
+    skts = T(scene["skts"])
+    near, far = eng.near_far(ro, rd, T(scene["cyls"]), skts)
+    R = ro.shape[0]
+    for S, seed in ((48, None), (16, 0), (5, 1)):              # sorted depths, unsorted draws, fewer than 8 samples per ray
+        if seed is None:
+            z = ops.coarse_samples(near, far, S)
+        else:
+            u = torch.rand(R, S, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+            z = near.reshape(R, 1) + (far - near).reshape(R, 1) * u
+        mask, lo, hi = ops.ray_bone_mask(ro, rd, skts, eng.align, eng.axis_scale, near, far)
+        plain = ops.bone_cull(ops.Geometry(ro, rd, skts, eng.align, eng.axis_scale, z=z), True)
+        pts = ops.bone_cull(ops.Geometry(ro, rd, skts, eng.align, eng.axis_scale, pts=(ro[:, None] + rd[:, None] * z[..., None])), True)
+        assert torch.equal(plain[0], pts[0])        # (the per-window rejection against no rejection at all)
+        n = int(plain[2].item())
+        assert n > 1000
+        wrong = (mask, lo + 10.0, hi + 10.0)        # no depth lies inside: the kernel must not trust the mask
+        tight = ops.ray_bone_mask(ro, rd, skts, eng.align, eng.axis_scale, z.min(1).values, z.max(1).values)
+        for rm in ((mask, lo, hi), wrong, tight, (torch.zeros_like(mask), lo + 10.0, hi + 10.0)):
+            got = ops.bone_cull(ops.Geometry(ro, rd, skts, eng.align, eng.axis_scale, z=z, ray_mask=rm), True)
+            assert torch.equal(got[0], plain[0])
+            assert int(got[2].item()) == n
+            assert torch.equal(torch.sort(got[1][:n]).values, torch.sort(plain[1][:n]).values)
+        per_ray = torch.zeros(R, dtype=torch.int32, device=DEV)
+        for s in range(S):
+            per_ray |= plain[0].view(R, S)[:, s]
+        assert int((per_ray & ~mask).count_nonzero()) == 0
+        assert int((mask == 0).sum()) > R // 2       # most rays of the frame miss every volume
+    # many poses with few rays each: the matrices no longer fit the workgroup's LDS (the kernel's second variant)
+    Rs, G = 960, 96
+    many = skts[torch.arange(G, device=DEV) % 2].contiguous()
+    sel = torch.arange(Rs, device=DEV) * (R // Rs)
+    o_s, d_s, lo_s, hi_s = ro[sel].contiguous(), rd[sel].contiguous(), near.reshape(-1)[sel].contiguous(), far.reshape(-1)[sel].contiguous()
+    got = ops.ray_bone_mask(o_s, d_s, many, eng.align, eng.axis_scale, lo_s, hi_s)[0]
+    per = Rs // G
+    want = torch.cat([ops.ray_bone_mask(o_s[g * per:(g + 1) * per].contiguous(), d_s[g * per:(g + 1) * per].contiguous(),
+                                        many[g:g + 1].contiguous(), eng.align, eng.axis_scale,
+                                        lo_s[g * per:(g + 1) * per].contiguous(), hi_s[g * per:(g + 1) * per].contiguous())[0]
+                      for g in range(G)])
+    assert torch.equal(got, want) and int((got != 0).sum()) > 0
