@@ -23,8 +23,8 @@ SIGNATURES = {
     "danbo_near_far_cylinder": [P, P, P, I, I, F, F, P, P, I, P, P, P, P],
     "danbo_near_far_boxes": [P, P, P, P, P, I, I, P, P, P],
     "danbo_coarse_samples": [P, P, I, I, P, P, P],
-    "danbo_bone_cull": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
-    "danbo_ray_bone_mask": [P, P, P, P, I, I, P, P, P, P, P],
+    "danbo_bone_cull": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P],
+    "danbo_ray_bone_mask": [P, P, P, P, I, I, P, P, P, P, P, P],
     "danbo_bone_gather_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P, P],
     "danbo_assign_blend_fwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
     "danbo_gather_assign_blend_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P],
@@ -42,8 +42,9 @@ SIGNATURES = {
     "danbo_bone_gather_bwd": [P, P, P, P, I, I, I, P, P, P, P, P, I, P, P, P, P],
     "danbo_importance_samples": [P, P, I, I, I, P, P, P, P, P],
     "danbo_merge_samples": [P, P, P, I, I, I, I, P, P],
-    "danbo_composite_importance_fwd": [P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P],
-    "danbo_composite_merged_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P],
+    "danbo_composite_importance_fwd": [P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "danbo_composite_merged_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P],
+    "danbo_flat_rays": [P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "danbo_anerf_encode_fwd": [P, P, P, P, I, I, I, P, P, P, F, I, c_long, I, P, P, P],
     "danbo_anerf_encode_compact": [P, P, P, P, I, I, I, P, P, P, F, c_long, I, P, P, P],
     "danbo_anerf_view_pe_fwd": [P, P, I, I, I, P, P],

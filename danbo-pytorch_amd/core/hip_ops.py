@@ -107,7 +107,7 @@ class Geometry:
         self.S = self.z.shape[1] if self.z is not None else self.pts.shape[1]
         self.M = self.R * self.S
         self.device = self.rays_o.device
-        # (mask [R] int32, t_lo [R], t_hi [R]) of ray_bone_mask() for these rays, or None: bone_cull's accelerator
+        # (mask [R] int32, t_lo [R], t_hi [R][, flat [R] int32]) of ray_bone_mask() for these rays, or None: bone_cull's accelerator
         self.ray_mask = ray_mask if self.z is not None else None
 
     def head(self):
@@ -127,23 +127,27 @@ def bone_cull(geo, compact=True, cnt=None):
         assert cnt.dtype == torch.int32 and cnt.numel() == 1 and cnt.is_contiguous()
     else:
         cnt = None
-    rm = geo.ray_mask if geo.ray_mask is not None else (None, None, None)
-    _call("danbo_bone_cull", *geo.head(), _p(rm[0]), _p(rm[1]), _p(rm[2]), _p(bits), _p(lst), _p(cnt), _stream())
+    rm = tuple(geo.ray_mask) if geo.ray_mask is not None else (None, None, None)
+    flat = rm[3] if len(rm) > 3 else None
+    _call("danbo_bone_cull", *geo.head(), _p(rm[0]), _p(rm[1]), _p(rm[2]), _p(flat), _p(bits), _p(lst), _p(cnt), _stream())
     return bits, lst, cnt
 
 
-def ray_bone_mask(rays_o, rays_d, skts, align, axis_scale, t_lo, t_hi):
-    """-> (mask [R] int32, t_lo, t_hi): bit j of mask[r] clear = no point of ray r between t_lo[r] and t_hi[r] can lie inside
-    bone j's volume (conservative slab test, csrc/k_sample.hip:k_ray_bone_mask).  Pass it to Geometry(ray_mask=...): bone_cull
-    then skips the rays -- and whole workgroups -- that miss every volume; the in-volume mask itself does not depend on it."""
+def ray_bone_mask(rays_o, rays_d, skts, align, axis_scale, t_lo, t_hi, want_flat=False):
+    """-> (mask [R] int32, t_lo, t_hi[, flat [R] int32]): bit j of mask[r] clear = no point of ray r between t_lo[r] and t_hi[r]
+    can lie inside bone j's volume (conservative slab test, csrc/k_sample.hip:k_ray_bone_mask).  Pass it to
+    Geometry(ray_mask=...): bone_cull then skips the rays -- and whole workgroups -- that miss every volume; the in-volume mask
+    itself does not depend on it.  want_flat: also the flags of the candidate rays of constants, which bone_cull (given the
+    4-tuple) confirms and composite_importance(ray_flat=...) / composite_merged(ray_flat=...) act on (danbo_hip.h)."""
     rays_o, rays_d, skts = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(skts, "skts")
     t_lo, t_hi = _f32(t_lo, "t_lo").reshape(-1), _f32(t_hi, "t_hi").reshape(-1)
     R, G = rays_o.shape[0], skts.shape[0]
     assert t_lo.shape[0] == R and t_hi.shape[0] == R
     mask = torch.empty(R, device=rays_o.device, dtype=torch.int32)
+    flat = torch.empty(R, device=rays_o.device, dtype=torch.int32) if want_flat else None
     _call("danbo_ray_bone_mask", _p(rays_o), _p(rays_d), _p(t_lo), _p(t_hi), R, G, _p(skts), _p(_f32(align, "align")),
-          _p(_f32(axis_scale, "axis_scale")), _p(mask), _stream())
-    return mask, t_lo, t_hi
+          _p(_f32(axis_scale, "axis_scale")), _p(mask), _p(flat), _stream())
+    return (mask, t_lo, t_hi, flat) if want_flat else (mask, t_lo, t_hi)
 
 
 def group_rows(bits, lst, cnt):
@@ -336,42 +340,77 @@ def importance_samples(z, weights, Sf, u=None):
     return zs, zf, idx
 
 
-def composite_importance(raw, z, rays_d, Sf, B=1.0, noise=None, u=None, bits=None, raw_empty=None, want_weights=True):
+def flat_rays(raw_empty, t_lo, ray_flat, S, Sf, B=1.0, want_weights=False):
+    """the rays of constants (danbo_flat_rays, include/danbo_hip.h): allocates the outputs of BOTH fused composites, writes them
+    for every flagged ray with an empty-space density <= 0, and lists the other rays ->
+    dict(out0=..., out=..., z_fine=..., ray_list=..., ray_count=...) for composite_importance(into=...) / composite_merged(into=...)"""
+    raw_empty, t_lo = _f32(raw_empty, "raw_empty"), _f32(t_lo, "t_lo").reshape(-1)
+    R, dev = raw_empty.shape[0], raw_empty.device
+    assert ray_flat.dtype == torch.int32 and ray_flat.shape[0] == R and t_lo.shape[0] == R
+    f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)  # noqa: E731
+    out0 = dict(rgb_map=f(R, 3), disp_map=f(R), acc_map=f(R), weights=f(R, S) if want_weights else None, alpha=f(R, S))
+    out = dict(rgb_map=f(R, 3), disp_map=f(R), acc_map=f(R), weights=f(R, S + Sf), alpha=f(R, S + Sf))
+    zf = f(R, Sf)
+    lst = torch.empty(R, device=dev, dtype=torch.int32)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    _call("danbo_flat_rays", _p(raw_empty), _p(t_lo), _p(ray_flat), R, int(S), int(Sf), float(B), _p(out0["rgb_map"]),
+          _p(out0["disp_map"]), _p(out0["acc_map"]), _p(out0["weights"]), _p(out0["alpha"]), _p(zf), _p(out["rgb_map"]),
+          _p(out["disp_map"]), _p(out["acc_map"]), _p(out["weights"]), _p(out["alpha"]), _p(lst), _p(cnt), _stream())
+    return dict(out0=out0, out=out, z_fine=zf, ray_list=lst, ray_count=cnt)
+
+
+def composite_importance(raw, z, rays_d, Sf, B=1.0, noise=None, u=None, bits=None, raw_empty=None, want_weights=True,
+                         flat=None):
     """coarse composite + importance resampling in one launch (S, Sf <= 64) ->
-    (out0 dict, z_sorted, z_fine, sorted_idx); bits/raw_empty: un-filled raw (see danbo_hip.h)."""
+    (out0 dict, z_sorted, z_fine, sorted_idx); bits/raw_empty: un-filled raw (see danbo_hip.h).
+    flat: flat_rays()'s result -- only its listed rays are composited, into its buffers (the rows of the other rays are already
+    there; their z_sorted / sorted_idx rows are never made)."""
     raw, z, rays_d = _f32(raw, "raw"), _f32(z, "z"), _f32(rays_d, "rays_d")
     R, S = z.shape
     dev = raw.device
-    rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
-    disp = torch.empty(R, device=dev, dtype=torch.float32)
-    acc = torch.empty(R, device=dev, dtype=torch.float32)
-    w = torch.empty(R, S, device=dev, dtype=torch.float32) if want_weights else None
-    al = torch.empty(R, S, device=dev, dtype=torch.float32)
-    zf = torch.empty(R, Sf, device=dev, dtype=torch.float32)
+    if flat is not None:
+        o0, zf = flat["out0"], flat["z_fine"]
+        rgb, disp, acc, w, al = o0["rgb_map"], o0["disp_map"], o0["acc_map"], o0["weights"], o0["alpha"]
+        assert al.shape == (R, S) and zf.shape == (R, Sf)
+    else:
+        rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+        disp = torch.empty(R, device=dev, dtype=torch.float32)
+        acc = torch.empty(R, device=dev, dtype=torch.float32)
+        w = torch.empty(R, S, device=dev, dtype=torch.float32) if want_weights else None
+        al = torch.empty(R, S, device=dev, dtype=torch.float32)
+        zf = torch.empty(R, Sf, device=dev, dtype=torch.float32)
     zs = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
     idx = torch.empty(R, S + Sf, device=dev, dtype=torch.int32)
     _call("danbo_composite_importance_fwd", _p(raw), _p(_f32(raw_empty, "raw_empty")), _p(bits), _p(z), _p(rays_d), R, S,
           int(Sf), float(B), _p(_f32(noise, "noise")), _p(_f32(u, "u")), _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _p(zf),
-          _p(zs), _p(idx), _stream())
+          _p(zs), _p(idx), _p(flat["ray_list"] if flat else None), _p(flat["ray_count"] if flat else None), _stream())
     return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al), zs, zf, idx
 
 
 def composite_merged(raw_a, raw_b, idx, z_sorted, rays_d, B=1.0, noise=None, bits_a=None, bits_b=None, raw_empty=None,
-                     want_raw=False):
-    """final composite reading the coarse / importance raw through the sorted order (no merged copy)"""
+                     want_raw=False, flat=None):
+    """final composite reading the coarse / importance raw through the sorted order (no merged copy);
+    flat: flat_rays()'s result, as composite_importance"""
     raw_a, raw_b, rays_d = _f32(raw_a, "raw_a"), _f32(raw_b, "raw_b"), _f32(rays_d, "rays_d")
     R, S = raw_a.shape[:2]
     Sf = raw_b.shape[1]
     dev = raw_a.device
-    rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
-    disp = torch.empty(R, device=dev, dtype=torch.float32)
-    acc = torch.empty(R, device=dev, dtype=torch.float32)
-    w = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
-    al = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
+    if flat is not None:
+        assert not want_raw
+        o = flat["out"]
+        rgb, disp, acc, w, al = o["rgb_map"], o["disp_map"], o["acc_map"], o["weights"], o["alpha"]
+        assert al.shape == (R, S + Sf)
+    else:
+        rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+        disp = torch.empty(R, device=dev, dtype=torch.float32)
+        acc = torch.empty(R, device=dev, dtype=torch.float32)
+        w = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
+        al = torch.empty(R, S + Sf, device=dev, dtype=torch.float32)
     rs = torch.empty(R, S + Sf, 4, device=dev, dtype=torch.float32) if want_raw else None
     _call("danbo_composite_merged_fwd", _p(raw_a), _p(raw_b), _p(_f32(raw_empty, "raw_empty")), _p(bits_a), _p(bits_b),
           _p(idx), _p(_f32(z_sorted, "z_sorted")), _p(rays_d), R, S, Sf, float(B), _p(_f32(noise, "noise")), _p(rgb),
-          _p(disp), _p(acc), _p(w), _p(al), _p(rs), _stream())
+          _p(disp), _p(acc), _p(w), _p(al), _p(rs), _p(flat["ray_list"] if flat else None),
+          _p(flat["ray_count"] if flat else None), _stream())
     out = dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
     if want_raw:
         out["raw_sorted"] = rs

@@ -27,6 +27,8 @@ class DanboEngine:
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
         self._side = None            # side streams of render()
+        self._flat = self._flat_done = None
+        self.skip_flat_rays = True   # render(): no resampling for rays that cannot meet a volume (tests switch it off to compare)
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
@@ -163,7 +165,8 @@ class DanboEngine:
                                self.code_table)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None):
+                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None,
+                        after_cull=None):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
@@ -171,13 +174,16 @@ class DanboEngine:
         dense=True : every sample goes through every kernel (the reference's executed work).
         ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used.
         ray_mask: ops.ray_bone_mask() of these rays over an interval that holds every depth of z (render: [near, far]).
-        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once)."""
+        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once).
+        after_cull: called right behind the cull's launch (render(): the rays of constants, on a side stream beside K2 / K3)."""
         self.refresh()
         geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts, ray_mask=ray_mask)
         vols = self.volumes(bones) if volumes is None else volumes
         cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
         S = geo.S
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense, cnt=count)
+        if after_cull is not None:
+            after_cull()
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
         if ready is not None:
@@ -267,6 +273,31 @@ class DanboEngine:
         return out
 
     # ------------------------------------------------------------------ RayCaster.render_rays (eval)
+    def _flat_rays_hook(self, ray_flat, t_lo, view, ready, S, Sf, B):
+        """-> callable for forward_samples(after_cull=...): ops.flat_rays() of the frame, behind the coarse cull (which confirms the
+        flags) and the view constants (whose empty-space raw decides), on a side stream beside K2 / K3 -- it depends on neither.
+        The result is left in self._flat."""
+        self._flat = None
+        if ray_flat is None:
+            return None
+
+        def run():
+            if ready is None:
+                self._flat = ops.flat_rays(view[1], t_lo, ray_flat, S, Sf, B)
+                return
+            cur, side = torch.cuda.current_stream(), self._side[0]      # (the view constants' stream: ordered behind them)
+            side.wait_stream(cur)
+            for t in (ray_flat, t_lo):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                self._flat = ops.flat_rays(view[1], t_lo, ray_flat, S, Sf, B)
+                self._flat_done = torch.cuda.Event()
+                self._flat_done.record(side)
+            for t in list(self._flat["out0"].values()) + list(self._flat["out"].values()) + [self._flat[k] for k in ("z_fine", "ray_list", "ray_count")]:
+                if t is not None:
+                    t.record_stream(cur)
+        return run
+
     def near_far(self, rays_o, rays_d, cyls, skts, near0=0.0, far0=1.0, chunk=4096):
         self.refresh()
         near, far = ops.near_far_cylinder(rays_o, rays_d, cyls, near0, far0, chunk)
@@ -308,27 +339,37 @@ class DanboEngine:
         z = ops.coarse_samples(near, far, S)
         # candidate bones of every ray over [near, far] (coarse and importance depths both lie inside): the two culls skip the
         # rays, and whole workgroups, that miss every volume -- most of a frame
-        ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far)
+        fused = S <= 64 and Sf <= 64
+        lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
+        # (lazy: nobody outside this function sees z_fine / the sorted order -- the rays that cannot meet a volume are flagged,
+        # confirmed by the coarse cull, and get their constants without resampling or a final composite: danbo_hip.h)
+        ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far,
+                                                        want_flat=lazy and self.skip_flat_rays)
+        ray_flat = ray_mask[3] if ray_mask is not None and len(ray_mask) > 3 else None
         counts = torch.zeros(2, device=rays_o.device, dtype=torch.int32)       # rows of the two passes: one fill
         if ready is None:
             vols = self.volumes(bones)
             view = self.view_constants(rays_d, skts, cam_idx)
-        fused = S <= 64 and Sf <= 64
-        lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1])
+                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1], after_cull=self._flat_rays_hook(
+                                           ray_flat, None if ray_mask is None else ray_mask[1], view, ready, S, Sf, B))
+        flat = self._flat
+        self._flat = None
+        if flat is not None and ready is not None:
+            torch.cuda.current_stream().wait_event(self._flat_done)
         if fused:
             out0, z_all, z_fine, order = ops.composite_importance(
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
-                want_weights=keep)
+                want_weights=keep, flat=flat)
         else:
             out0 = ops.composite(raw, z, rays_d, B)
             z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
         raw_f, ex_f = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z_fine, dense=dense,
-                                           volumes=vols, view=view, fill=not lazy, ray_mask=ray_mask, count=counts[1:2])
+                                           volumes=vols, view=view, fill=not lazy,
+                                           ray_mask=None if ray_mask is None else ray_mask[:3], count=counts[1:2])
         out = ops.composite_merged(raw, raw_f, order, z_all, rays_d, B, bits_a=ex["valid_bits"] if lazy else None,
                                    bits_b=ex_f["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
-                                   want_raw=keep)
+                                   want_raw=keep, flat=flat)
         raw_all = out.get("raw_sorted")
         ret = dict(rgb_map=out["rgb_map"], disp_map=out["disp_map"], acc_map=out["acc_map"], alpha=out["alpha"],
                    T_i=out["weights"], rgb0=out0["rgb_map"], disp0=out0["disp_map"], acc0=out0["acc_map"],

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <atomic>
 #include "../../include/danbo_hip.h"
 #include "sample_math.hpp"
@@ -50,6 +51,20 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int stream_grid(long items, int block) {
     long g = (items + block - 1) / block;
     const long cap = (long)num_cu() * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// grid of a kernel whose workgroups loop over their share of the items: as many workgroups as are RESIDENT at once (what the
+// kernel's registers / LDS allow per CU, asked from the runtime once per kernel), never more -- stream_grid's 8 per CU is two
+// rounds for a kernel that fits 7 (k_composite_importance, 106 SGPRs: the eighth workgroup of every CU ran alone afterwards).
+template <class K>
+static inline int resident_grid(K kernel, long items, int block, size_t lds = 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    long g = (items + block - 1) / block;
+    const long cap = (long)num_cu() * per_cu;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;

@@ -22,8 +22,8 @@ struct Carver {
 
 struct FrameBuffers {
     float *near, *far, *cyl_scratch, *z, *vol_scratch, *volumes, *cview, *raw_empty, *h, *raw_a, *raw_b, *z_fine, *z_sorted;
-    uint32_t *bits_a, *bits_b, *ray_mask;
-    int32_t *list, *count, *order;
+    uint32_t *bits_a, *bits_b, *ray_mask, *ray_flat;
+    int32_t *list, *count, *order, *ray_list;
 };
 
 FrameBuffers carve(Carver& c, int R, int G, int S, int Sf, int chunk, int Wg) {
@@ -38,10 +38,12 @@ FrameBuffers carve(Carver& c, int R, int G, int S, int Sf, int chunk, int Wg) {
     b.cview = c.take<float>((size_t)R * 128);
     b.raw_empty = c.take<float>((size_t)R * 4);
     b.ray_mask = c.take<uint32_t>(R);
+    b.ray_flat = c.take<uint32_t>(R);
+    b.ray_list = c.take<int32_t>(R);
     b.bits_a = c.take<uint32_t>(M);
     b.bits_b = c.take<uint32_t>(Mf);
     b.list = c.take<int32_t>(M);          // re-used by the importance pass (Mf <= M is not assumed: max below)
-    b.count = c.take<int32_t>(4);         // [0], [1]: rows of the two passes; [2]: K2's tile ticket
+    b.count = c.take<int32_t>(4);         // [0], [1]: rows of the two passes; [2]: K2's tile ticket; [3]: rays that are not rays of constants
     b.h = c.take<float>((M > Mf ? M : Mf) * 16);
     b.raw_a = c.take<float>(M * 4);
     b.raw_b = c.take<float>(Mf * 4);
@@ -81,7 +83,7 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
         DANBO_TRY(danbo_near_far_boxes(r->rays_o, r->rays_d, r->skts, m->align, m->axis_scale, R, G, b.near, b.far, stream));
     DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, nullptr, b.z, stream));
     // candidate bones of every ray over [near, far]: both culls below skip the rays (and workgroups) that miss every volume
-    DANBO_TRY(danbo_ray_bone_mask(r->rays_o, r->rays_d, b.near, b.far, R, G, r->skts, m->align, m->axis_scale, b.ray_mask, stream));
+    DANBO_TRY(danbo_ray_bone_mask(r->rays_o, r->rays_d, b.near, b.far, R, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.ray_flat, stream));
     // per pose / per ray
     DANBO_TRY(danbo_pose_volumes_fwd(r->bones, G, m->L_graph, m->graph_width, m->g_w0, m->g_adjw0, m->g_b0, m->g_w1, m->g_adjw1, m->g_b1,
                                      m->g_w2, m->g_b2, m->g_w3, m->g_b3, b.vol_scratch, b.volumes, stream));
@@ -91,8 +93,9 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     // one network pass over R x s samples at depths zz -> raw (rows outside every volume stay unwritten: bits == 0)
     zero_words(b.count, 4, nullptr, 0, st);      // both row counters and the ticket (which returns to 0 after each launch)
     auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
-        DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.near, b.far, bits,
-                                  b.list, count, stream));
+        // (the coarse pass's cull confirms the flags of the rays of constants; the importance pass leaves them alone)
+        DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.near, b.far,
+                                  zz == b.z ? b.ray_flat : nullptr, bits, b.list, count, stream));
         DANBO_TRY(danbo_group_rows(bits, b.list, count, R * s, stream));     // rows of the same bone set next to each other (k_group.hip)
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,
                                                   bits, b.list, count, R * s, m->assign16, m->a_b0, m->a_b1, m->a_w2, m->a_b2, b.h,
@@ -101,9 +104,14 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
                                   m->rgb_b, raw, nullptr, stream);
     };
     DANBO_TRY(network(b.z, S, b.bits_a, b.count, b.raw_a));
+    // the rays of constants get every output of both composites here; the composites take the list of the others
+    DANBO_TRY(danbo_flat_rays(b.raw_empty, b.near, b.ray_flat, R, S, Sf, m->density_scale, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0,
+                              b.z_fine, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, b.ray_list, b.count + 3, stream));
     DANBO_TRY(danbo_composite_importance_fwd(b.raw_a, b.raw_empty, b.bits_a, b.z, r->rays_d, R, S, Sf, m->density_scale, nullptr, nullptr,
-                                             o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order, stream));
+                                             o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order, b.ray_list,
+                                             b.count + 3, stream));
     DANBO_TRY(network(b.z_fine, Sf, b.bits_b, b.count + 1, b.raw_b));
     return danbo_composite_merged_fwd(b.raw_a, b.raw_b, b.raw_empty, b.bits_a, b.bits_b, b.order, b.z_sorted, r->rays_d, R, S, Sf,
-                                      m->density_scale, nullptr, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, nullptr, stream);
+                                      m->density_scale, nullptr, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, nullptr,
+                                      b.ray_list, b.count + 3, stream);
 }

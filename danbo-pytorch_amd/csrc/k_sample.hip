@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_ray_bone_mask(const float* __restrict__
                                                        const float* __restrict__ t_lo, const float* __restrict__ t_hi,
                                                        const float* __restrict__ skts, const float* __restrict__ align,
                                                        const float* __restrict__ axis_scale, int R, int G,
-                                                       uint32_t* __restrict__ ray_mask) {
+                                                       uint32_t* __restrict__ ray_mask, uint32_t* __restrict__ ray_flat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_align = smem;                 // [24][16]
     float* s_scale = smem + J * 16;        // [24][4]
@@ -259,7 +259,18 @@ __global__ __launch_bounds__(256) void k_ray_bone_mask(const float* __restrict__
             bits |= segment_misses_bone(sk, s_align + 16 * j, s_scale + 4 * j, o, d, zl, zh) ? 0u : 1u << j;
         }
     }
-    if (r_a + (int)threadIdx.x < R) ray_mask[r] = bits;
+    if (r_a + (int)threadIdx.x < R) {
+        ray_mask[r] = bits;
+        if (ray_flat != nullptr) {
+            // candidate for a ray of constants (k_composite_importance): no volume anywhere along [zl, zh], and every interval
+            // length any set of depths inside [zl, zh] can produce -- |gap| * |d|, 1e10 * |d| for the last sample -- is finite
+            const float dn = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
+            const float span = mul_rn(add_rn(sub_rn(zh, zl), mul_rn(1e-3f, fmaxf(fabsf(zl), fabsf(zh)))), dn);
+            const float tail = mul_rn(1e10f, dn);
+            const bool fin = zl <= zh && sub_rn(span, span) == 0.f && sub_rn(tail, tail) == 0.f;
+            ray_flat[r] = (bits == 0u && fin) ? 1u : 0u;
+        }
+    }
 }
 
 constexpr int CULL_BLOCK = 256;
@@ -275,6 +286,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
                                                           const float* __restrict__ axis_scale, int np_lds,
                                                           const uint32_t* __restrict__ ray_mask,
                                                           const float* __restrict__ t_lo, const float* __restrict__ t_hi,
+                                                          uint32_t* __restrict__ ray_flat,
                                                           uint32_t* __restrict__ valid_bits,
                                                           int32_t* __restrict__ list, int32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restric
                 const float slack = 5e-5f * fmaxf(fabsf(lo), fabsf(hi));   // half of segment_misses_bone's pad
                 const bool inside = zreg[k] >= lo - slack && zreg[k] <= hi + slack;
                 pre[k] = inside ? ray_mask[r] : (1u << J) - 1u;
+                if (!inside && ray_flat != nullptr) ray_flat[r] = 0u;     // not a ray of constants after all (every writer stores 0)
             }
             any = any || pre[k] != 0u;
         }
@@ -600,6 +613,15 @@ struct CompositeState {
     float carry, sr, sg, sb, sd, sa;
 };
 
+// Item g of a launch -> ray (g * scatter) mod R, scatter coprime to R (ray_scatter below): a bijection that spreads the rays of
+// an image region over all wavefronts.  Wavefront w walks items w, w + nwaves, ...; with rays in image order and nwaves a
+// multiple of the image width those are the pixels of ONE column -- the wavefronts of the columns that cross the body did all
+// the work of the frame while the others found nothing but rays of constants (k_composite_importance: 217 us for 37 % of the
+// rays, 265 us for all of them).
+__device__ __forceinline__ int scattered_ray(long g, unsigned scatter, int R) {
+    return (int)((unsigned long long)g * scatter % (unsigned)R);
+}
+
 // one 64-sample chunk of a ray: rw = raw of this lane's sample, zs its depth, gap = z[s+1] - z[s] (1e10 for the
 // last sample of the ray), nz = optional density noise.  Returns the sample's weight; al = its alpha.
 __device__ __forceinline__ float composite_chunk(CompositeState& st, const float4 rw, float zs, float gap, float dn,
@@ -685,7 +707,9 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
                                                           int R, int S, int Sf, float B, const float* __restrict__ noise,
                                                           float* __restrict__ rgb_map, float* __restrict__ disp,
                                                           float* __restrict__ acc_out, float* __restrict__ weights,
-                                                          float* __restrict__ alpha_out, float4* __restrict__ raw_sorted) {
+                                                          float* __restrict__ alpha_out, float4* __restrict__ raw_sorted,
+                                                          const int32_t* __restrict__ ray_list,
+                                                          const int32_t* __restrict__ ray_count, unsigned scatter) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -709,16 +733,23 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
             if (src < S) return bits_a ? bits_a[(size_t)r * S + src] : 1u;
             return bits_b ? bits_b[(size_t)r * Sf + (src - S)] : 1u;
         };
-        auto clampr = [&](int r) { return r < R ? r : (wave < R ? wave : 0); };
-        Idx cur = fetch_idx(clampr(wave)), nxt = fetch_idx(clampr(wave + nwaves));
-        uint32_t cur_word = fetch_word(clampr(wave), cur.src);
-        for (int r = wave; r < R; r += nwaves) {
+        // item i of the launch: the i-th listed ray, or (no list) ray scattered_ray(i); the index of item i + 2 and the word of
+        // item i + 1 are in flight while item i is composited
+        const int n = ray_list ? min(max(*ray_count, 0), R) : R;
+        auto ray_at = [&](int i) { return i < n ? (ray_list ? min(max(ray_list[i], 0), R - 1) : scattered_ray(i, scatter, R)) : -1; };
+        int r = ray_at(wave), r_nxt = ray_at(wave + nwaves);
+        if (r < 0) return;
+        Idx cur = fetch_idx(r), nxt = fetch_idx(r_nxt >= 0 ? r_nxt : r);
+        uint32_t cur_word = fetch_word(r, cur.src);
+        for (int i = wave; i < n; i += nwaves) {
             CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const size_t m = (size_t)r * St + (act ? lane : St - 1);
             float4 rw = cur.re;
             if (cur_word != 0u) rw = cur.src < S ? raw_a[(size_t)r * S + cur.src] : raw_b[(size_t)r * Sf + (cur.src - S)];
-            const uint32_t nxt_word = fetch_word(clampr(r + nwaves), nxt.src);
-            const Idx nn = fetch_idx(clampr(r + 2 * nwaves));
+            const int r_n = r_nxt >= 0 ? r_nxt : r;
+            const uint32_t nxt_word = fetch_word(r_n, nxt.src);
+            const int r_nn = ray_at(i + 2 * nwaves);
+            const Idx nn = fetch_idx(r_nn >= 0 ? r_nn : r_n);
             const float gap = (lane + 1 < St) ? sub_rn(cur.z1, cur.zs) : 1e10f;
             float al, w;
             // a ray without an in-volume sample in either pass: constants, as in k_composite_importance below (bit for bit)
@@ -739,7 +770,7 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
                 if (raw_sorted) raw_sorted[m] = rw;
             }
             if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
-            cur = nxt; cur_word = nxt_word; nxt = nn;
+            cur = nxt; cur_word = nxt_word; nxt = nn; r = r_n; r_nxt = r_nn;
         }
         return;
     }
@@ -910,6 +941,9 @@ __global__ __launch_bounds__(256) void k_importance_wave(const float* __restrict
 
 // coarse composite + importance resampling of a ray in one pass (S, Sf <= 64): the weights never leave the
 // wavefront's registers unless the caller asks for them
+// coarse composite + importance resampling of a ray in one pass (S, Sf <= 64): the weights never leave the
+// wavefront's registers unless the caller asks for them.  Item i of the launch is the i-th listed ray (ray_list / ray_count:
+// k_flat_rays' list of the rays that are NOT rays of constants) or, without a list, ray scattered_ray(i).
 template <bool DET>
 __global__ __launch_bounds__(256) void k_composite_importance(const float4* __restrict__ raw,
                                                               const float4* __restrict__ raw_empty,
@@ -920,14 +954,16 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
                                                               float* __restrict__ disp, float* __restrict__ acc_out,
                                                               float* __restrict__ weights, float* __restrict__ alpha_out,
                                                               float* __restrict__ z_fine, float* __restrict__ z_sorted,
-                                                              int32_t* __restrict__ sorted_idx) {
+                                                              int32_t* __restrict__ sorted_idx,
+                                                              const int32_t* __restrict__ ray_list,
+                                                              const int32_t* __restrict__ ray_count, unsigned scatter) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const bool act = lane < S;
-    // A wavefront walks ~32 rays one after the other and a ray is a chain of dependent loads (in-volume word -> raw) before any
-    // arithmetic: software-pipelined by one ray -- the next ray's word, depths, direction and empty-space raw are requested before
-    // this ray's arithmetic, so only the (masked) raw load is waited for at full latency
+    // A wavefront walks its rays one after the other and a ray is a chain of dependent loads (list entry -> in-volume word -> raw)
+    // before any arithmetic: software-pipelined -- the next ray's word, depths, direction and empty-space raw (and the list entry
+    // after it) are requested before this ray's arithmetic, so only the (masked) raw load is waited for at full latency
     struct RayIn { uint32_t word; float zs, z1, dn; float4 re; };
     auto fetch = [&](int r) {
         RayIn in;
@@ -939,21 +975,27 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
         in.re = bits ? raw_empty[r] : float4{0.f, 0.f, 0.f, 0.f};
         return in;
     };
-    RayIn cur = fetch(wave < R ? wave : 0);
-    for (int r = wave; r < R; r += nwaves) {
+    const int n = ray_list ? min(max(*ray_count, 0), R) : R;
+    auto ray_at = [&](int i) { return i < n ? (ray_list ? min(max(ray_list[i], 0), R - 1) : scattered_ray(i, scatter, R)) : -1; };
+    int r = ray_at(wave), r_nxt = ray_at(wave + nwaves);
+    if (r < 0) return;
+    RayIn cur = fetch(r);
+    for (int i = wave; i < n; i += nwaves) {
         CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const size_t m = (size_t)r * S + (act ? lane : S - 1);
         float4 rw = cur.re;
         if (cur.word != 0u) rw = raw[m];
-        const RayIn nxt = fetch(r + nwaves < R ? r + nwaves : r);
+        const int r_n = r_nxt >= 0 ? r_nxt : r;
+        const RayIn nxt = fetch(r_n);
+        const int r_nn = ray_at(i + 2 * nwaves);
         const float zs = cur.zs;
         const float gap = (lane + 1 < S) ? sub_rn(cur.z1, zs) : 1e10f;
         float al, w;
-        // A ray with no sample inside any volume (two thirds of the bench frame) carries ONE raw for all its samples -- the ray's
-        // empty-space raw.  If its density pre-activation is <= 0 (or NaN: fmaxf drops it) and every interval length is finite,
-        // the general chain below computes sig = 0, alpha = 1 - exp(-0) = +0, T = 1, w = +0 for every sample and +0 for all five
-        // sums: the maps are constants.  Taken wave-uniformly, bit for bit the general result (the importance depths still go
-        // through importance_wave: they depend on the ray's depths only).
+        // A ray with no sample inside any volume carries ONE raw for all its samples -- the ray's empty-space raw.  If its density
+        // pre-activation is <= 0 (or NaN: fmaxf drops it) and every interval length is finite, the general chain below computes
+        // sig = 0, alpha = 1 - exp(-0) = +0, T = 1, w = +0 for every sample and +0 for all five sums: the maps are constants.
+        // Taken wave-uniformly, bit for bit the general result (the importance depths still go through importance_wave: they
+        // depend on the ray's depths only).
         const float dist = mul_rn(gap, cur.dn);
         const float rgb_sum = add_rn(add_rn(cur.re.x, cur.re.y), cur.re.z);     // (NaN / inf colour logits would make 0 * c a NaN)
         const bool flat = bits != nullptr && noise == nullptr && !(div_rn(cur.re.w, B) > 0.f) && sub_rn(rgb_sum, rgb_sum) == 0.f &&
@@ -971,8 +1013,75 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
         }
         if (lane == 0) composite_finish(st, r, rgb_map, disp, acc_out);
         importance_wave<DET>(act ? zs : INFINITY, act ? w : 0.f, r, S, Sf, u, lane, z_fine, z_sorted, sorted_idx);
-        cur = nxt;
+        cur = nxt; r = r_n; r_nxt = r_nn;
     }
+}
+
+// Rays of constants.  A ray that cannot meet a volume anywhere between t_lo and t_hi (k_ray_bone_mask's flag), all of whose coarse
+// depths lie in that interval (k_bone_cull clears the flag otherwise), whose empty-space density is <= 0 and whose empty-space
+// colour is finite has sig = 0, alpha = +0, T = 1, w = +0 on every sample of BOTH passes -- its importance depths would lie
+// between its coarse depths.  This kernel writes every output of the two composites for those rays (the values the general chain
+// computes, bit for bit: +0 everywhere), z_fine = t_lo (inside the interval: the importance pass's cull drops the ray on its
+// mask), and lists all OTHER rays for k_composite_importance / k_composite_merged -- which then share them evenly over their
+// wavefronts (a static split of ALL rays left the wavefronts with 5 to 25 rays of work each: as slow as without the flags).
+// Nothing here depends on the network pass: it runs beside K3 on a side stream.  63 % of the rays of the bench frame.
+constexpr int FLAT_BLOCK = 1024;
+__global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float4* __restrict__ raw_empty, const float* __restrict__ t_lo,
+                                                          const uint32_t* __restrict__ ray_flat, int R, int S, int Sf, float B,
+                                                          float* __restrict__ rgb0, float* __restrict__ disp0, float* __restrict__ acc0,
+                                                          float* __restrict__ weights0, float* __restrict__ alpha0,
+                                                          float* __restrict__ z_fine, float* __restrict__ rgb_map,
+                                                          float* __restrict__ disp, float* __restrict__ acc_out,
+                                                          float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                          int32_t* __restrict__ ray_list, int32_t* __restrict__ ray_count) {
+    __shared__ int s_cnt[FLAT_BLOCK / 64];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int St = S + Sf;
+    const int r = blockIdx.x * FLAT_BLOCK + threadIdx.x;
+    bool flat = false;
+    float lo = 0.f;
+    if (r < R && ray_flat[r] != 0u) {
+        const float4 re = raw_empty[r];
+        const float rgb_sum = add_rn(add_rn(re.x, re.y), re.z);
+        flat = !(div_rn(re.w, B) > 0.f) && sub_rn(rgb_sum, rgb_sum) == 0.f;
+        lo = t_lo[r];
+    }
+    if (flat) {     // composite_finish of five +0 sums, twice
+        rgb0[3 * r] = 0.f; rgb0[3 * r + 1] = 0.f; rgb0[3 * r + 2] = 0.f;
+        disp0[r] = 0.f;
+        acc0[r] = 0.f;
+        rgb_map[3 * r] = 0.f; rgb_map[3 * r + 1] = 0.f; rgb_map[3 * r + 2] = 0.f;
+        disp[r] = 0.f;
+        acc_out[r] = 0.f;
+    }
+    // the rows of the wavefront's flat rays, a ray per turn
+    unsigned long long rows = __ballot(flat);
+    const unsigned long long listed = __ballot(r < R && !flat);
+    while (rows != 0ull) {
+        const int b = (int)__builtin_ctzll(rows);
+        rows &= rows - 1ull;
+        const size_t rr = (size_t)(blockIdx.x * FLAT_BLOCK + wave * 64 + b);
+        if (lane < S) {
+            if (weights0) weights0[rr * S + lane] = 0.f;
+            if (alpha0) alpha0[rr * S + lane] = 0.f;
+        }
+        if (lane < Sf) z_fine[rr * Sf + lane] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), b));
+        for (int c = lane; c < St; c += 64) {
+            if (weights) weights[rr * St + c] = 0.f;
+            if (alpha_out) alpha_out[rr * St + c] = 0.f;
+        }
+    }
+    // the other rays, in ray order inside the workgroup: one atomic per workgroup
+    if (lane == 0) s_cnt[wave] = (int)__popcll(listed);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < FLAT_BLOCK / 64; ++w) { const int c = s_cnt[w]; s_cnt[w] = run; run += c; }
+        s_base = run > 0 ? atomicAdd(ray_count, run) : 0;
+    }
+    __syncthreads();
+    if (r < R && !flat) ray_list[s_base + s_cnt[wave] + (int)__popcll(listed & ((1ull << lane) - 1ull))] = r;
 }
 
 }  // namespace danbo
@@ -981,6 +1090,17 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
 // C ABI
 // ======================================================================================
 using namespace danbo;
+
+// a multiplier coprime to R, far from the image widths (scattered_ray)
+static unsigned ray_scatter(int R) {
+    static const unsigned primes[] = {40507u, 40519u, 40529u, 40531u, 40543u, 40559u};
+    for (unsigned p : primes) {
+        unsigned a = p, b = (unsigned)R;
+        while (b != 0u) { const unsigned t = a % b; a = b; b = t; }
+        if (a == 1u) return p;
+    }
+    return 1u;
+}
 
 extern "C" int danbo_near_far_cylinder(const float* rays_o, const float* rays_d, const float* cyl, int R, int G,
                                         float near0, float far0, const float* near_in, const float* far_in, int chunk,
@@ -1016,12 +1136,13 @@ extern "C" int danbo_coarse_samples(const float* near, const float* far, int R, 
 
 extern "C" int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
                                 const float* skts, const float* align, const float* axis_scale, const uint32_t* ray_mask,
-                                const float* t_lo, const float* t_hi, uint32_t* valid_bits, int32_t* list, int32_t* count,
-                                void* stream) {
+                                const float* t_lo, const float* t_hi, uint32_t* ray_flat, uint32_t* valid_bits, int32_t* list,
+                                int32_t* count, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0);
     DANBO_CHECK_ARG((list == nullptr) == (count == nullptr));
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     DANBO_CHECK_ARG(ray_mask == nullptr || (z != nullptr && t_lo != nullptr && t_hi != nullptr));
+    DANBO_CHECK_ARG(ray_flat == nullptr || ray_mask != nullptr);
     const long M = (long)R * S;
     const long spp = (long)(R / G) * S;
     const int per_block = CULL_BLOCK * CULL_SPT;
@@ -1031,13 +1152,13 @@ extern "C" int danbo_bone_cull(const float* rays_o, const float* rays_d, const f
     DANBO_CHECK_ARG(lds <= 64 * 1024);
     const int grid = ceil_div(M, per_block);
     hipLaunchKernelGGL(k_bone_cull, dim3(grid), dim3(CULL_BLOCK), lds, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
-                       G, skts, align, axis_scale, (int)np, ray_mask, t_lo, t_hi, valid_bits, list, count);
+                       G, skts, align, axis_scale, (int)np, ray_mask, t_lo, t_hi, ray_flat, valid_bits, list, count);
     DANBO_LAUNCH_RET();
 }
 
 extern "C" int danbo_ray_bone_mask(const float* rays_o, const float* rays_d, const float* t_lo, const float* t_hi, int R, int G,
                                     const float* skts, const float* align, const float* axis_scale, uint32_t* ray_mask,
-                                    void* stream) {
+                                    uint32_t* ray_flat, void* stream) {
     DANBO_CHECK_ARG(rays_o && rays_d && t_lo && t_hi && skts && align && axis_scale && ray_mask);
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0);
     const long np = 256 / (R / G) + 2 < G ? 256 / (R / G) + 2 : G;     // poses a workgroup's 256 rays can span
@@ -1045,10 +1166,10 @@ extern "C" int danbo_ray_bone_mask(const float* rays_o, const float* rays_d, con
     const size_t lds = sizeof(float) * (J * 16 + J * 4 + (in_lds ? np * J * 16 : 0));
     if (in_lds)
         hipLaunchKernelGGL(k_ray_bone_mask<true>, dim3(ceil_div(R, 256)), dim3(256), lds, (hipStream_t)stream, rays_o, rays_d, t_lo, t_hi,
-                           skts, align, axis_scale, R, G, ray_mask);
+                           skts, align, axis_scale, R, G, ray_mask, ray_flat);
     else
         hipLaunchKernelGGL(k_ray_bone_mask<false>, dim3(ceil_div(R, 256)), dim3(256), lds, (hipStream_t)stream, rays_o, rays_d, t_lo,
-                           t_hi, skts, align, axis_scale, R, G, ray_mask);
+                           t_hi, skts, align, axis_scale, R, G, ray_mask, ray_flat);
     DANBO_LAUNCH_RET();
 }
 
@@ -1085,7 +1206,8 @@ extern "C" int danbo_composite_fwd(const float* raw, const float* z, const float
                                     const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
                                     float* alpha, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && B > 0.f);
-    const int grid = stream_grid((long)R * 64, 256);
+    static const int per_launch = resident_grid(k_composite, 1L << 40, 256);
+    const int grid = (int)std::min<long>(ceil_div((long)R * 64, 256), per_launch);
     hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(raw), z,
                        rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha);
     DANBO_LAUNCH_RET();
@@ -1112,19 +1234,36 @@ extern "C" int danbo_composite_importance_fwd(const float* raw, const float* raw
                                                const float* z, const float* rays_d, int R, int S, int Sf, float B,
                                                const float* noise, const float* u, float* rgb_map, float* disp,
                                                float* acc, float* weights, float* alpha, float* z_fine, float* z_sorted,
-                                               int32_t* sorted_idx, void* stream) {
+                                               int32_t* sorted_idx, const int32_t* ray_list, const int32_t* ray_count,
+                                               void* stream) {
     DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64 && B > 0.f);
     DANBO_CHECK_ARG(raw && z && rays_d && rgb_map && disp && acc && z_fine && z_sorted && sorted_idx);
     DANBO_CHECK_ARG((valid_bits == nullptr) || (raw_empty != nullptr));
-    const dim3 grid(stream_grid((long)R * 64, 256)), block(256);
+    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
+    static const int resident[2] = {resident_grid(k_composite_importance<false>, 1L << 40, 256), resident_grid(k_composite_importance<true>, 1L << 40, 256)};
+    const dim3 grid((unsigned)std::min<long>(ceil_div((long)R * 64, 256), resident[u ? 0 : 1])), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(raw);
     const float4* e4 = reinterpret_cast<const float4*>(raw_empty);
     if (u)
         hipLaunchKernelGGL(k_composite_importance<false>, grid, block, 0, (hipStream_t)stream, r4, e4, valid_bits, z, rays_d,
-                           R, S, Sf, B, noise, u, rgb_map, disp, acc, weights, alpha, z_fine, z_sorted, sorted_idx);
+                           R, S, Sf, B, noise, u, rgb_map, disp, acc, weights, alpha, z_fine, z_sorted, sorted_idx, ray_list, ray_count,
+                           ray_scatter(R));
     else
         hipLaunchKernelGGL(k_composite_importance<true>, grid, block, 0, (hipStream_t)stream, r4, e4, valid_bits, z, rays_d,
-                           R, S, Sf, B, noise, u, rgb_map, disp, acc, weights, alpha, z_fine, z_sorted, sorted_idx);
+                           R, S, Sf, B, noise, u, rgb_map, disp, acc, weights, alpha, z_fine, z_sorted, sorted_idx, ray_list, ray_count,
+                           ray_scatter(R));
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_flat_rays(const float* raw_empty, const float* t_lo, const uint32_t* ray_flat, int R, int S, int Sf, float B,
+                                float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
+                                float* rgb_map, float* disp, float* acc, float* weights, float* alpha, int32_t* ray_list,
+                                int32_t* ray_count, void* stream) {
+    DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64 && B > 0.f);
+    DANBO_CHECK_ARG(raw_empty && t_lo && ray_flat && rgb0 && disp0 && acc0 && z_fine && rgb_map && disp && acc && ray_list && ray_count);
+    hipLaunchKernelGGL(k_flat_rays, dim3(ceil_div(R, FLAT_BLOCK)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(raw_empty), t_lo, ray_flat, R, S, Sf, B, rgb0, disp0, acc0, weights0, alpha0, z_fine,
+                       rgb_map, disp, acc, weights, alpha, ray_list, ray_count);
     DANBO_LAUNCH_RET();
 }
 
@@ -1132,12 +1271,15 @@ extern "C" int danbo_composite_merged_fwd(const float* raw_a, const float* raw_b
                                            const uint32_t* bits_a, const uint32_t* bits_b, const int32_t* sorted_idx,
                                            const float* z_sorted, const float* rays_d, int R, int S, int Sf, float B,
                                            const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
-                                           float* alpha, float* raw_sorted, void* stream) {
+                                           float* alpha, float* raw_sorted, const int32_t* ray_list, const int32_t* ray_count,
+                                           void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && Sf > 0 && B > 0.f && raw_a && raw_b && sorted_idx && z_sorted && rays_d);
     DANBO_CHECK_ARG(rgb_map && disp && acc && ((bits_a == nullptr && bits_b == nullptr) || raw_empty != nullptr));
-    hipLaunchKernelGGL(k_composite_merged, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
+    static const int per_launch = resident_grid(k_composite_merged, 1L << 40, 256);
+    hipLaunchKernelGGL(k_composite_merged, dim3((unsigned)std::min<long>(ceil_div((long)R * 64, 256), per_launch)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(raw_a), reinterpret_cast<const float4*>(raw_b),
                        reinterpret_cast<const float4*>(raw_empty), bits_a, bits_b, sorted_idx, z_sorted, rays_d, R, S, Sf, B,
-                       noise, rgb_map, disp, acc, weights, alpha, reinterpret_cast<float4*>(raw_sorted));
+                       noise, rgb_map, disp, acc, weights, alpha, reinterpret_cast<float4*>(raw_sorted), ray_list, ray_count, ray_scatter(R));
     DANBO_LAUNCH_RET();
 }

@@ -419,7 +419,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     if (m->use_volume_near_far)
         DANBO_TRY(danbo_near_far_boxes(bt->rays_o, bt->rays_d, bt->skts, m->align, axis_scale, R, G, b.near, b.far, stream));
     DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, bt->t_rand, b.z_c, stream));
-    DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, b.z_c, nullptr, R, S, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, b.bits_c,
+    DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, b.z_c, nullptr, R, S, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, nullptr, b.bits_c,
                               b.row_sample + R, b.cnt,
                               stream));
     hipLaunchKernelGGL(k_train_small, dim3(1), dim3(256), 0, (hipStream_t)s1, m->p[DANBO_T_G_ADJW0], m->g_adj0, m->p[DANBO_T_G_ADJW1], m->g_adj1,
@@ -446,7 +446,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         const int s = pass == 0 ? S : Sf;
         uint32_t* bits = pass == 0 ? b.bits_c : b.bits_f;
         if (pass != 0)       // (pass 0's cull ran in the prologue)
-            DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, bits,
+            DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, zz, nullptr, R, s, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, nullptr, bits,
                                       b.row_sample + R, b.cnt,
                                       stream));
         NET_STAGE(21);
@@ -465,7 +465,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_STAGE(3);
     if (S <= 64 && Sf <= 64) {
         DANBO_TRY(danbo_composite_importance_fwd(b.raw_c, b.raw_empty, b.bits_c, b.z_c, bt->rays_d, R, S, Sf, B, bt->noise_c, bt->u_rand, o->rgb0,
-                                                 o->disp0, o->acc0, b.weights0, o->alpha0, b.z_f, b.z_sorted, b.order, stream));
+                                                 o->disp0, o->acc0, b.weights0, o->alpha0, b.z_f, b.z_sorted, b.order, nullptr, nullptr,
+                                                 stream));
     } else {
         hipLaunchKernelGGL(k_fill_raw_lazy, dim3(stream_grid((long)R * S, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(b.raw_empty),
                            b.bits_c, R, S, reinterpret_cast<float4*>(b.raw_c));
@@ -477,7 +478,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     if (stopped) { DANBO_LAUNCH_RET(); }
     DANBO_STAGE(5);
     DANBO_TRY(danbo_composite_merged_fwd(b.raw_c, b.raw_f, b.raw_empty, b.bits_c, b.bits_f, b.order, b.z_sorted, bt->rays_d, R, S, Sf, B,
-                                         bt->noise_f, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, b.raw_sorted, stream));
+                                         bt->noise_f, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, b.raw_sorted, nullptr, nullptr,
+                                         stream));
 
     DANBO_STAGE(6);
     // ---- losses and the adjoints of the two composites

@@ -30,7 +30,8 @@ extern "C" {
 
 /* library / device identification (host only).
  * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
- * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, and danbo_bone_cull takes its result (three nullable pointers). */
+ * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, danbo_flat_rays;
+ * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -92,23 +93,29 @@ int danbo_coarse_samples(const float* near, const float* far, int R, int S, cons
  *   these rays.  Purely an accelerator -- the per-sample test is the same and a depth outside
  *   [t_lo, t_hi] of its ray is tested against every bone, so valid_bits never depends on it;
  *   workgroups whose rays miss every volume write their zeros and leave (a 512 x 512 x 48 pass:
- *   135 -> 3x us).  Without it the kernel derives the same rejection per 1024-sample window.
+ *   133 -> 73 us).  Without it the kernel derives the same rejection per 1024-sample window.
+ *   ray_flat (optional, with ray_mask): danbo_ray_bone_mask's flags; cleared for every ray with a
+ *   depth outside its interval, so that a flag still set afterwards means "no sample of this pass,
+ *   nor any depth in between, is inside a volume" (see danbo_flat_rays).
  * ------------------------------------------------------------------------------------- */
 int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
                     const float* skts /*[G,24,4,4]*/, const float* align /*[24,4,4]*/,
                     const float* axis_scale /*[24,3]*/, const uint32_t* ray_mask /*[R] or NULL*/,
                     const float* t_lo /*[R] or NULL*/, const float* t_hi /*[R] or NULL*/,
+                    uint32_t* ray_flat /*[R] or NULL, in/out*/,
                     uint32_t* valid_bits /*[R*S]*/, int32_t* list /*[R*S] or NULL*/,
                     int32_t* count /*[1] or NULL*/, void* stream);
 
 /* Per-ray candidate bones: ray_mask[r] bit j = 0 when no point rays_o + t rays_d with
  * t_lo[r] <= t <= t_hi[r] can lie inside the volume of bone j (slab test of the segment against the
  * slightly inflated box, conservative).  Once per ray batch -- the coarse and the importance samples
- * of a ray both lie inside its [near, far].  No reference counterpart: the reference evaluates every
- * sample against every bone (core/networks/gnn_backbone.py:787-828); this feeds danbo_bone_cull. */
+ * of a ray both lie inside its [near, far].  ray_flat (optional) [R]: 1 when ray_mask[r] == 0 and every
+ * interval length the ray can produce inside [t_lo, t_hi] is finite -- the ray is a candidate for the
+ * constants of an empty ray (danbo_flat_rays).  No reference counterpart: the reference evaluates every sample against
+ * every bone (core/networks/gnn_backbone.py:787-828); this feeds danbo_bone_cull and the composites. */
 int danbo_ray_bone_mask(const float* rays_o, const float* rays_d, const float* t_lo /*[R]*/, const float* t_hi /*[R]*/,
                         int R, int G, const float* skts, const float* align, const float* axis_scale,
-                        uint32_t* ray_mask /*[R]*/, void* stream);
+                        uint32_t* ray_mask /*[R]*/, uint32_t* ray_flat /*[R] or NULL*/, void* stream);
 
 /* K1b  factorised tri-axis gather (factorize_grid_sample, core/networks/misc.py:331-351;
  * windowing + 'cat' construct, gnn_backbone.py:803-826) for the n listed samples
@@ -278,12 +285,31 @@ int danbo_merge_samples(const float* a /*[R,S,C]*/, const float* b /*[R,Sf,C]*/,
 /* raw2outputs of the coarse pass + isample_from_lineseg in one launch (S, Sf <= 64; same arithmetic as
  * danbo_composite_fwd followed by danbo_importance_samples).  valid_bits / raw_empty (optional, together):
  * samples whose in-volume word is 0 were not written to raw and take raw_empty[ray] instead.
- * weights / alpha may be NULL. */
+ * weights / alpha may be NULL.
+ * ray_list / ray_count (optional, together): composite only the listed rays (danbo_flat_rays' list; *ray_count is read on the
+ * device) -- every output row of an unlisted ray is left untouched. */
 int danbo_composite_importance_fwd(const float* raw /*[R,S,4]*/, const float* raw_empty /*[R,4]*/,
                                    const uint32_t* valid_bits /*[R,S]*/, const float* z, const float* rays_d, int R, int S,
                                    int Sf, float B, const float* noise, const float* u, float* rgb_map, float* disp,
                                    float* acc, float* weights, float* alpha, float* z_fine, float* z_sorted,
-                                   int32_t* sorted_idx, void* stream);
+                                   int32_t* sorted_idx, const int32_t* ray_list /*[R] or NULL*/,
+                                   const int32_t* ray_count /*[1] or NULL*/, void* stream);
+
+/* Rays of constants (no reference counterpart; the values are the reference's).  ray_flat: the flags danbo_ray_bone_mask made
+ * and danbo_bone_cull of the COARSE pass (same rays, depths, mask, interval) has passed on -- a set flag says the ray cannot
+ * meet a volume anywhere in [t_lo, t_hi], which holds all of its coarse depths.  If in addition its empty-space density
+ * raw_empty[r][3] / B is <= 0 and its empty-space colour finite, every sample of the ray in the coarse AND in the importance pass
+ * (whose depths lie between the coarse ones) has sig = 0, alpha = +0, T = 1, w = +0, and raw2outputs gives +0 maps for both.  This
+ * call writes exactly those outputs for such rays -- the coarse composite's (rgb0, disp0, acc0, weights0 / alpha0 rows, may be
+ * NULL) and the merged composite's (rgb_map, disp, acc, weights / alpha rows, may be NULL) -- sets their z_fine row to t_lo (so
+ * that the importance pass's danbo_bone_cull drops them on their mask; their z_sorted / sorted_idx rows are never made), and
+ * appends every OTHER ray to ray_list / *ray_count (zeroed by the caller), to be passed to danbo_composite_importance_fwd and
+ * danbo_composite_merged_fwd.  All maps / alphas / weights of the frame are then bit-identical to compositing every ray; only a
+ * caller that wants z_fine / z_sorted / sorted_idx of every ray must not use this (eval without noise only). */
+int danbo_flat_rays(const float* raw_empty /*[R,4]*/, const float* t_lo /*[R]*/, const uint32_t* ray_flat /*[R]*/, int R, int S,
+                    int Sf, float B, float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
+                    float* rgb_map, float* disp, float* acc, float* weights /*[R,S+Sf]*/, float* alpha,
+                    int32_t* ray_list /*[R]*/, int32_t* ray_count /*[1]*/, void* stream);
 
 /* merge_samples (core/raycasters.py:745-761) folded into raw2outputs of the merged samples: sample i of the sorted
  * order is read from raw_a (sorted_idx < S) or raw_b; raw_sorted (optional) receives the merged raw tensor. */
@@ -291,7 +317,9 @@ int danbo_composite_merged_fwd(const float* raw_a /*[R,S,4]*/, const float* raw_
                                const uint32_t* bits_a, const uint32_t* bits_b, const int32_t* sorted_idx,
                                const float* z_sorted /*[R,S+Sf]*/, const float* rays_d, int R, int S, int Sf, float B,
                                const float* noise, float* rgb_map, float* disp, float* acc, float* weights /*[R,S+Sf]*/,
-                               float* alpha, float* raw_sorted /*[R,S+Sf,4] or NULL*/, void* stream);
+                               float* alpha, float* raw_sorted /*[R,S+Sf,4] or NULL*/,
+                               const int32_t* ray_list /*[R] or NULL: as danbo_composite_importance_fwd*/,
+                               const int32_t* ray_count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A-NeRF (nerf_type = nerf): the per-sample encoders around the W = 448 trunk.

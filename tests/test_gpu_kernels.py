@@ -557,6 +557,81 @@ def test_render_is_bitwise_independent_of_the_row_order(stage):
         assert torch.equal(a[k], b[k]), k
 
 
+def test_render_without_resampling_of_rays_that_miss_every_volume_is_bitwise_the_full_render(stage):
+    """render() flags the rays that cannot meet a volume (ray mask 0, empty-space density <= 0) in the coarse composite, gives
+    them no importance resampling and writes their final maps as constants: every output equals, bit for bit, the render that
+    resamples and composites every ray -- and the keep=True render that materialises everything"""
+    from core.utils import synthetic as syn
+    eng = stage["eng"]
+    scene = syn.make_scene(n_poses=2, H=96, W=96, n_views=2, pose_seed=4)
+    ro = np.concatenate([scene["rays"][0][0], scene["rays"][1][0]])
+    rd = np.concatenate([scene["rays"][0][1], scene["rays"][1][1]])
+    args = (T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(scene["cyls"]), torch.zeros(len(ro), dtype=torch.int64, device=DEV))
+    assert eng.skip_flat_rays is True
+    a = eng.render(*args, 24, 12)
+    eng.skip_flat_rays = False
+    try:
+        b = eng.render(*args, 24, 12)
+    finally:
+        eng.skip_flat_rays = True
+    c = eng.render(*args, 24, 12, keep=True)
+    for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0"):
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
+    # the flags themselves: most rays of the frame, none of them with an in-volume sample in either pass
+    ops_ = eng_ops(eng)
+    eng.refresh()
+    near, far = eng.near_far(args[0], args[1], args[4], args[2])
+    rm = ops_.ray_bone_mask(args[0], args[1], args[2], eng.align, eng.axis_scale, near, far, want_flat=True)
+    R = rm[0].numel()
+    assert torch.equal(rm[3] != 0, rm[0] == 0)                      # finite geometry: every ray that misses all volumes
+    bits, _, _ = ops_.bone_cull(ops_.Geometry(args[0], args[1], args[2], eng.align, eng.axis_scale, z=c["z_coarse"], ray_mask=rm), True)
+    assert torch.equal(bits, c["valid_bits"]) and torch.equal(rm[3] != 0, rm[0] == 0)      # the cull confirms them all
+    view = eng.view_constants(args[1], args[2], args[5])
+    B = eng.cfg["density_scale"]
+    assert float(view[1][:, 3].max()) <= 0        # (the constants need an empty-space density <= 0: this network's is)
+    fr = ops_.flat_rays(view[1], rm[1], rm[3], 24, 12, B, want_weights=True)
+    n = int(fr["ray_count"].item())
+    listed = torch.sort(fr["ray_list"][:n].long()).values
+    flat = torch.ones(R, dtype=torch.bool, device=DEV)
+    flat[listed] = False
+    assert torch.equal(flat, rm[3] != 0) and int(flat.sum()) > R // 2 and len(torch.unique(listed)) == n
+    assert not bool((c["valid_bits"].view(R, -1)[flat] != 0).any())
+    out0, z_all, z_fine, order = ops_.composite_importance(c["raw_coarse"], c["z_coarse"], args[1], 12, B, bits=bits, raw_empty=view[1], flat=fr)
+    assert torch.equal(z_fine[~flat], c["z_fine"][~flat]) and torch.equal(z_all[~flat], c["z_sorted"][~flat]) and torch.equal(order[~flat], c["sorted_idxs"][~flat])
+    assert torch.equal(z_fine[flat], near.reshape(-1, 1)[flat].expand(-1, 12))
+    for k, k0 in (("rgb_map", "rgb0"), ("disp_map", "disp0"), ("acc_map", "acc0"), ("alpha", "alpha0"), ("weights", "weights_coarse")):
+        assert torch.equal(out0[k], c[k0]), k
+    bits_f, _, _ = ops_.bone_cull(ops_.Geometry(args[0], args[1], args[2], eng.align, eng.axis_scale, z=z_fine, ray_mask=rm[:3]), True)
+    assert not bool((bits_f.view(R, -1)[flat] != 0).any()) and torch.equal(bits_f.view(R, -1)[~flat], eng_bits(eng, args, c["z_fine"]).view(R, -1)[~flat])
+    out = ops_.composite_merged(c["raw_coarse"], c["raw_fine"], order, z_all, args[1], B, bits_a=bits, bits_b=bits_f, raw_empty=view[1], flat=fr)
+    for k, k0 in (("rgb_map", "rgb_map"), ("disp_map", "disp_map"), ("acc_map", "acc_map"), ("alpha", "alpha"), ("weights", "T_i")):
+        assert torch.equal(out[k], c[k0]), k
+    # an empty-space density > 0: no ray of constants, every ray is listed, everything takes the general path
+    pos = view[1].clone()
+    pos[:, 3] = 0.5
+    fr2 = ops_.flat_rays(pos, rm[1], rm[3], 24, 12, B, want_weights=True)
+    assert int(fr2["ray_count"].item()) == R and torch.equal(torch.sort(fr2["ray_list"].long()).values, torch.arange(R, device=DEV))
+    o2 = ops_.composite_importance(c["raw_coarse"], c["z_coarse"], args[1], 12, B, bits=bits, raw_empty=pos, flat=fr2)
+    o3 = ops_.composite_importance(c["raw_coarse"], c["z_coarse"], args[1], 12, B, bits=bits, raw_empty=pos)
+    assert all(torch.equal(o2[0][k], o3[0][k]) for k in o3[0]) and all(torch.equal(x, y) for x, y in zip(o2[1:], o3[1:]))
+    # depths outside the interval the flags were made for: the cull takes the flags back
+    rm_far = ops_.ray_bone_mask(args[0], args[1], args[2], eng.align, eng.axis_scale, near + 10.0, far + 10.0, want_flat=True)
+    assert int(rm_far[3].sum()) > 0
+    bits2, _, _ = ops_.bone_cull(ops_.Geometry(args[0], args[1], args[2], eng.align, eng.axis_scale, z=c["z_coarse"], ray_mask=rm_far), True)
+    assert torch.equal(bits2, c["valid_bits"]) and int(rm_far[3].sum()) == 0
+
+
+def eng_ops(eng):
+    from core import hip_ops
+    return hip_ops
+
+
+def eng_bits(eng, args, z):
+    from core import hip_ops
+    return hip_ops.bone_cull(hip_ops.Geometry(args[0], args[1], args[2], eng.align, eng.axis_scale, z=z), False)[0]
+
+
 def test_ray_bone_mask_is_conservative_and_never_changes_the_in_volume_mask(ops, stage):
     """k_ray_bone_mask only tells k_bone_cull what it may skip: with it, without it (the per-window rejection inside the kernel),
     and with an interval that does NOT hold the depths (every sample then falls back to all bones) the in-volume mask and the

@@ -41,3 +41,11 @@ print("composite_merged, frame's bits              us", timeit(lambda: cm(bits, 
 print("composite_merged, all empty                 us", timeit(lambda: cm(torch.zeros_like(bits), torch.zeros_like(bits_f), raw_empty)))
 print("composite_merged, none empty                us", timeit(lambda: cm(torch.ones_like(bits), torch.ones_like(bits_f), raw_empty)))
 print("composite_merged, dense                     us", timeit(lambda: cm(None, None, None)))
+# rays that cannot meet a volume (ray_bone_mask) skip the resampling
+rm = ops.ray_bone_mask(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, out["near"], out["far"], want_flat=True)
+print("empty-space density pre-activation: min", float(raw_empty[:, 3].min()), "max", float(raw_empty[:, 3].max()),
+      " rays with mask 0:", int((rm[0] == 0).sum()), " flagged:", int(rm[3].sum()))
+fr = ops.flat_rays(raw_empty, rm[1], rm[3], 48, 16, 1.0)
+print("flat_rays us", timeit(lambda: ops.flat_rays(raw_empty, rm[1], rm[3], 48, 16, 1.0)), " listed rays", int(fr["ray_count"].item()))
+print("composite_importance, listed rays only us", timeit(lambda: ops.composite_importance(raw, z, inp["rays_d"], 16, 1.0, bits=bits, raw_empty=raw_empty, want_weights=False, flat=fr)))
+print("composite_merged, listed rays only     us", timeit(lambda: ops.composite_merged(raw, out["raw_fine"], out["sorted_idxs"], out["z_sorted"], inp["rays_d"], 1.0, bits_a=bits, bits_b=bits_f, raw_empty=raw_empty, flat=fr)))
