@@ -31,7 +31,7 @@ SIGNATURES = {
     "danbo_assign16_pack": [P, P, P, P, P],
     "danbo_gather_assign_blend16_fwd": [P, P, P, P, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P],
     "danbo_mlp_pack": [POINTER(c_void_p), P, P, I, P, P, P],
-    "danbo_view_consts": [P, P, I, I, I, I, I, P, I, I, P, P, P, P, P, P, P, I, P, P, P, P],
+    "danbo_view_consts": [P, P, I, I, I, I, I, P, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P],
     "danbo_view_code_table": [P, P, I, I, I, P, P, P, P],
     "danbo_mlp16_pack": [POINTER(c_void_p), P, P, P, P, I, P, P, P],
     "danbo_pe_mlp16_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P],
@@ -44,7 +44,7 @@ SIGNATURES = {
     "danbo_merge_samples": [P, P, P, I, I, I, I, P, P],
     "danbo_composite_importance_fwd": [P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "danbo_composite_merged_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P],
-    "danbo_flat_rays": [P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "danbo_flat_rays": [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "danbo_anerf_encode_fwd": [P, P, P, P, I, I, I, P, P, P, F, I, c_long, I, P, P, P],
     "danbo_anerf_encode_compact": [P, P, P, P, I, I, I, P, P, P, F, c_long, I, P, P, P],
     "danbo_anerf_view_pe_fwd": [P, P, I, I, I, P, P],
@@ -98,7 +98,7 @@ class DanboModel(ctypes.Structure):
                 + [(n, P) for n in ("alpha_w", "alpha_b", "rgb_w", "rgb_b", "views_w_ray_t", "views_b_eff", "framecodes",
                                     "mean_code", "code_table", "empty_consts")]
                 + [(n, I) for n in ("n_codes", "code_size", "L_view", "ray_mode", "normalise")]
-                + [("density_scale", F), ("use_volume_near_far", I)])
+                + [("density_scale", F), ("use_volume_near_far", I), ("flat_rays_ok", I)])
 
 
 class DanboRays(ctypes.Structure):

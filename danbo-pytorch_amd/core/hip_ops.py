@@ -13,6 +13,7 @@ from . import _hip
 J = 24
 VOL = 240
 FEAT = 15
+RAY_FLAT_VMAX = 1e4          # DANBO_RAY_FLAT_VMAX (include/danbo_hip.h)
 H_STRIDE = 16
 MLP_PACKED_FLOATS = 659456
 VIEW_W = 128
@@ -252,7 +253,8 @@ def mlp_pack(pts_w, feature_w, views_w):
 
 
 def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code, cam_idx, wrt, views_b,
-                rgb_w, rgb_b, empty_consts=None, rgb_order=0, code_table=None):
+                rgb_w, rgb_b, empty_consts=None, rgb_order=0, code_table=None, ray_list=None, ray_count=None):
+    """-> cview [R,128], raw_empty [R,4]; ray_list / ray_count (flat_rays()): only the listed rays' rows are computed"""
     rays_d = _f32(rays_d, "rays_d")
     R, G = rays_d.shape[0], skts.shape[0]
     Cf = 0 if mean_code is None else mean_code.shape[0]
@@ -263,7 +265,7 @@ def view_consts(rays_d, skts, ray_mode, normalise, L_view, framecodes, mean_code
         cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
     _call("danbo_view_consts", _p(rays_d), _p(_f32(skts, "skts")), R, G, int(ray_mode), int(normalise), int(L_view),
           _p(framecodes), n_codes, Cf, _p(mean_code), _p(cam_idx), _p(wrt), _p(views_b), _p(rgb_w), _p(rgb_b),
-          _p(empty_consts), int(rgb_order), _p(code_table), _p(cview), _p(raw_empty), _stream())
+          _p(empty_consts), int(rgb_order), _p(code_table), _p(ray_list), _p(ray_count), _p(cview), _p(raw_empty), _stream())
     return cview, raw_empty
 
 
@@ -340,22 +342,23 @@ def importance_samples(z, weights, Sf, u=None):
     return zs, zf, idx
 
 
-def flat_rays(raw_empty, t_lo, ray_flat, S, Sf, B=1.0, want_weights=False):
-    """the rays of constants (danbo_flat_rays, include/danbo_hip.h): allocates the outputs of BOTH fused composites, writes them
-    for every flagged ray with an empty-space density <= 0, and lists the other rays ->
-    dict(out0=..., out=..., z_fine=..., ray_list=..., ray_count=...) for composite_importance(into=...) / composite_merged(into=...)"""
-    raw_empty, t_lo = _f32(raw_empty, "raw_empty"), _f32(t_lo, "t_lo").reshape(-1)
-    R, dev = raw_empty.shape[0], raw_empty.device
-    assert ray_flat.dtype == torch.int32 and ray_flat.shape[0] == R and t_lo.shape[0] == R
+def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False):
+    """the rays of constants (danbo_flat_rays, include/danbo_hip.h -- the caller vouches for the model's empty-space density and
+    colour): allocates the outputs of BOTH fused composites, writes them for every flagged ray, and lists the other rays ->
+    dict(out0=..., out=..., z_fine=..., ray_list=..., ray_count=...) for view_consts(ray_list=...),
+    composite_importance(flat=...) and composite_merged(flat=...)"""
+    t_lo = _f32(t_lo, "t_lo").reshape(-1)
+    R, dev = t_lo.shape[0], t_lo.device
+    assert ray_flat.dtype == torch.int32 and ray_flat.shape[0] == R
     f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)  # noqa: E731
     out0 = dict(rgb_map=f(R, 3), disp_map=f(R), acc_map=f(R), weights=f(R, S) if want_weights else None, alpha=f(R, S))
     out = dict(rgb_map=f(R, 3), disp_map=f(R), acc_map=f(R), weights=f(R, S + Sf), alpha=f(R, S + Sf))
     zf = f(R, Sf)
     lst = torch.empty(R, device=dev, dtype=torch.int32)
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-    _call("danbo_flat_rays", _p(raw_empty), _p(t_lo), _p(ray_flat), R, int(S), int(Sf), float(B), _p(out0["rgb_map"]),
-          _p(out0["disp_map"]), _p(out0["acc_map"]), _p(out0["weights"]), _p(out0["alpha"]), _p(zf), _p(out["rgb_map"]),
-          _p(out["disp_map"]), _p(out["acc_map"]), _p(out["weights"]), _p(out["alpha"]), _p(lst), _p(cnt), _stream())
+    _call("danbo_flat_rays", _p(t_lo), _p(ray_flat), R, int(S), int(Sf), _p(out0["rgb_map"]), _p(out0["disp_map"]),
+          _p(out0["acc_map"]), _p(out0["weights"]), _p(out0["alpha"]), _p(zf), _p(out["rgb_map"]), _p(out["disp_map"]),
+          _p(out["acc_map"]), _p(out["weights"]), _p(out["alpha"]), _p(lst), _p(cnt), _stream())
     return dict(out0=out0, out=out, z_fine=zf, ray_list=lst, ray_count=cnt)
 
 

@@ -27,7 +27,6 @@ class DanboEngine:
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
         self._side = None            # side streams of render()
-        self._flat = self._flat_done = None
         self.skip_flat_rays = True   # render(): no resampling for rays that cannot meet a volume (tests switch it off to compare)
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
@@ -90,8 +89,35 @@ class DanboEngine:
         h0 = torch.zeros(1, ops.H_STRIDE, device=dev)
         scratch_raw = torch.empty(1, 4, device=dev)
         self.empty_consts = self._mlp(h0, 1, None, scratch_raw, aux=True).reshape(-1).contiguous()
+        self.flat_rays_ok = self._flat_rays_ok()
         self._built_mode = self.mlp_mode
         self._packed_key = key
+
+    def _flat_rays_ok(self):
+        """The two statements danbo_flat_rays (include/danbo_hip.h) needs about these weights, once per weight update (one host
+        sync): (a) the empty-space density -- the MLP's density for a zero feature row -- is <= 0; (b) the empty-space colour
+        logits are finite for every flagged ray: danbo_ray_bone_mask flags no ray whose view-direction inputs can exceed
+        DANBO_RAY_FLAT_VMAX in magnitude (normalised directions, sines and cosines: 1), so |cview_c| <= vmax * sum_i |W_ci| +
+        |b_c| (or the largest entry of the per-camera table), the hidden row is at most |empty_pre_c| + that, and the logits at
+        most sum_c |rgb_w_c| * hidden_c + |rgb_b| -- finite and far from overflow means no inf - inf, no NaN.  Then a ray that
+        cannot meet a volume is a ray of constants."""
+        cfg = self.cfg
+        if self.mlp_mode != "f16split":
+            return False
+        ec = self.empty_consts
+        Cpe = 3 * (1 + 2 * cfg["multires_views"])
+        vmax = 1.0 if cfg["view_type"] == "relray" else ops.RAY_FLAT_VMAX
+        a_max = self.wrt[:Cpe].abs().sum(0) * vmax
+        if self.code_table is not None:
+            a_max = a_max + self.code_table.abs().max(0).values
+        elif self.wrt.shape[0] > Cpe:
+            return False
+        else:
+            a_max = a_max + self.views_b16.abs()
+        hidden = ec[:128].abs() + a_max
+        logit = (self.rgb_w.abs() @ hidden + self.rgb_b.abs()).max()
+        ok = (ec[128] / float(cfg["density_scale"]) <= 0) & (logit < 1e30)
+        return bool(ok.item())
 
     @staticmethod
     def _equalized(p):
@@ -153,7 +179,7 @@ class DanboEngine:
         self.refresh()
         return ops.pose_volumes(bones, self.gw, self.cfg["multires_graph"])
 
-    def view_constants(self, rays_d, skts, cam_idx):
+    def view_constants(self, rays_d, skts, cam_idx, ray_list=None, ray_count=None):
         self.refresh()
         cfg = self.cfg
         ray_mode = {"world": 0, "root_local": 1}[cfg["ray_tr_type"]]
@@ -162,7 +188,7 @@ class DanboEngine:
                                self.mean_code, cam_idx, self.wrt,
                                self.views_b16 if self.mlp_mode == "f16split" else self.views_b, self.rgb_w,
                                self.rgb_b, self.empty_consts, 1 if self.mlp_mode == "f16split" else 0,
-                               self.code_table)
+                               self.code_table, ray_list, ray_count)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
                         want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None,
@@ -175,15 +201,17 @@ class DanboEngine:
         ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used.
         ray_mask: ops.ray_bone_mask() of these rays over an interval that holds every depth of z (render: [near, far]).
         count: zeroed [1] int32 for the row count (render() fills both passes' counters at once).
-        after_cull: called right behind the cull's launch (render(): the rays of constants, on a side stream beside K2 / K3)."""
+        after_cull: called right behind the cull's launch, returns (view, event) in place of `view` / ready[1] (render(): the
+                    rays of constants and the view constants of the others, on a side stream beside the grouping and K2)."""
         self.refresh()
         geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts, ray_mask=ray_mask)
         vols = self.volumes(bones) if volumes is None else volumes
-        cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
+        cview, raw_empty = (None, None) if after_cull is not None else (self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view)
         S = geo.S
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense, cnt=count)
-        if after_cull is not None:
-            after_cull()
+        if after_cull is not None:           # render(): the view constants of the rays that are not rays of constants
+            (cview, raw_empty), ev_view = after_cull()
+            ready = None if ready is None else (ready[0], ev_view)
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
         if ready is not None:
@@ -258,6 +286,7 @@ class DanboEngine:
         m.L_view = cfg["multires_views"]
         m.ray_mode, m.normalise = {"world": 0, "root_local": 1}[cfg["ray_tr_type"]], 1 if cfg["view_type"] == "relray" else 0
         m.density_scale, m.use_volume_near_far = float(cfg["density_scale"]), int(bool(cfg["use_volume_near_far"]))
+        m.flat_rays_ok = int(self.flat_rays_ok and self.skip_flat_rays)
         r = _hip.DanboRays(rays_o=rays_o.data_ptr(), rays_d=rays_d.data_ptr(), skts=skts.data_ptr(), bones=bones.data_ptr(),
                            cyls=cyls.data_ptr(), cam_idx=None if cam is None else cam.data_ptr(), near_in=None, far_in=None,
                            R=R, G=G, chunk=int(chunk))
@@ -273,31 +302,6 @@ class DanboEngine:
         return out
 
     # ------------------------------------------------------------------ RayCaster.render_rays (eval)
-    def _flat_rays_hook(self, ray_flat, t_lo, view, ready, S, Sf, B):
-        """-> callable for forward_samples(after_cull=...): ops.flat_rays() of the frame, behind the coarse cull (which confirms the
-        flags) and the view constants (whose empty-space raw decides), on a side stream beside K2 / K3 -- it depends on neither.
-        The result is left in self._flat."""
-        self._flat = None
-        if ray_flat is None:
-            return None
-
-        def run():
-            if ready is None:
-                self._flat = ops.flat_rays(view[1], t_lo, ray_flat, S, Sf, B)
-                return
-            cur, side = torch.cuda.current_stream(), self._side[0]      # (the view constants' stream: ordered behind them)
-            side.wait_stream(cur)
-            for t in (ray_flat, t_lo):
-                t.record_stream(side)
-            with torch.cuda.stream(side):
-                self._flat = ops.flat_rays(view[1], t_lo, ray_flat, S, Sf, B)
-                self._flat_done = torch.cuda.Event()
-                self._flat_done.record(side)
-            for t in list(self._flat["out0"].values()) + list(self._flat["out"].values()) + [self._flat[k] for k in ("z_fine", "ray_list", "ray_count")]:
-                if t is not None:
-                    t.record_stream(cur)
-        return run
-
     def near_far(self, rays_o, rays_d, cyls, skts, near0=0.0, far0=1.0, chunk=4096):
         self.refresh()
         near, far = ops.near_far_cylinder(rays_o, rays_d, cyls, near0, far0, chunk)
@@ -312,51 +316,76 @@ class DanboEngine:
         Sf = N_importance or cfg["N_importance"]
         B = cfg["density_scale"]
         self.refresh()
-        # The per-pose volumes (4 small launches, ~110 us of latency) and the per-ray view constants (~190 us at 512 x 512) depend
-        # on nothing the bounds / depths / cull chain computes: each runs on its own side stream under that chain (all of it
-        # latency-bound: they share the GPU well); the main stream waits for the volumes in front of K2 and for the view constants
-        # in front of K3.  (The view constants behind the volumes on ONE side stream started 120 us late and then ran beside the
-        # row grouping and K2: 27 -> 96 us for the grouping.)  Inside a HIP-graph capture the chain stays linear.
-        ready = None
-        if rays_o.is_cuda and not torch.cuda.is_current_stream_capturing():
+        fused = S <= 64 and Sf <= 64
+        lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
+        # lazy: nobody outside this function sees z_fine, the sorted order or the per-ray view constants.  If the weights allow it
+        # (_flat_rays_ok), the rays that cannot meet a volume -- flagged with the ray mask, confirmed by the coarse cull -- get
+        # their constants from ops.flat_rays and nothing else: no view constants, no resampling, no composite (danbo_hip.h)
+        flat_mode = lazy and self.skip_flat_rays and self.flat_rays_ok
+        # The per-pose volumes (4 small launches) and the per-ray view constants depend on nothing the bounds / depths / cull chain
+        # computes: each runs on its own side stream under that chain; the main stream waits for the volumes in front of K2 and
+        # for the view constants in front of K3.  In flat mode the view constants follow the coarse cull (they need the list of the
+        # rays that are not rays of constants) and run beside the row grouping and K2.  Inside a HIP-graph capture the chain stays
+        # linear.
+        use_side = rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
+        ready = vols = view = None
+        if use_side:
             cur = torch.cuda.current_stream()
             if self._side is None or self._side[0].device != rays_o.device:
                 self._side = (torch.cuda.Stream(device=rays_o.device), torch.cuda.Stream(device=rays_o.device))
             for side in self._side:
                 side.wait_stream(cur)
-            with torch.cuda.stream(self._side[0]):
-                view = self.view_constants(rays_d, skts, cam_idx)
-                ev_view = torch.cuda.Event()
-                ev_view.record(self._side[0])
+            ev_view = None
+            if not flat_mode:
+                with torch.cuda.stream(self._side[0]):
+                    view = self.view_constants(rays_d, skts, cam_idx)
+                    ev_view = torch.cuda.Event()
+                    ev_view.record(self._side[0])
+                for t in view:
+                    t.record_stream(cur)
             with torch.cuda.stream(self._side[1]):
                 vols = self.volumes(bones)
                 ev_vols = torch.cuda.Event()
                 ev_vols.record(self._side[1])
-            for t in (vols, view[0], view[1]):
-                t.record_stream(cur)
+            vols.record_stream(cur)
             ready = (ev_vols, ev_view)
         near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
         z = ops.coarse_samples(near, far, S)
         # candidate bones of every ray over [near, far] (coarse and importance depths both lie inside): the two culls skip the
         # rays, and whole workgroups, that miss every volume -- most of a frame
-        fused = S <= 64 and Sf <= 64
-        lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
-        # (lazy: nobody outside this function sees z_fine / the sorted order -- the rays that cannot meet a volume are flagged,
-        # confirmed by the coarse cull, and get their constants without resampling or a final composite: danbo_hip.h)
         ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far,
-                                                        want_flat=lazy and self.skip_flat_rays)
-        ray_flat = ray_mask[3] if ray_mask is not None and len(ray_mask) > 3 else None
+                                                        want_flat=flat_mode)
         counts = torch.zeros(2, device=rays_o.device, dtype=torch.int32)       # rows of the two passes: one fill
-        if ready is None:
+        if not use_side:
             vols = self.volumes(bones)
-            view = self.view_constants(rays_d, skts, cam_idx)
+            if not flat_mode:
+                view = self.view_constants(rays_d, skts, cam_idx)
+        flat = None
+
+        def after_coarse_cull():
+            nonlocal flat, view
+            if not use_side:
+                flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf)
+                view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
+                return view, None
+            side = self._side[0]
+            side.wait_stream(cur)
+            for t in (ray_mask[1], ray_mask[3]):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf)
+                view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
+                ev = torch.cuda.Event()
+                ev.record(side)
+            made = list(flat["out0"].values()) + list(flat["out"].values()) + [flat[k] for k in ("z_fine", "ray_list", "ray_count")] + list(view)
+            for t in made:
+                if t is not None:
+                    t.record_stream(cur)
+            return view, ev
+
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1], after_cull=self._flat_rays_hook(
-                                           ray_flat, None if ray_mask is None else ray_mask[1], view, ready, S, Sf, B))
-        flat = self._flat
-        self._flat = None
-        if flat is not None and ready is not None:
-            torch.cuda.current_stream().wait_event(self._flat_done)
+                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1],
+                                       after_cull=after_coarse_cull if flat_mode else None)
         if fused:
             out0, z_all, z_fine, order = ops.composite_importance(
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,

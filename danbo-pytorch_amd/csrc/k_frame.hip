@@ -83,35 +83,51 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
         DANBO_TRY(danbo_near_far_boxes(r->rays_o, r->rays_d, r->skts, m->align, m->axis_scale, R, G, b.near, b.far, stream));
     DANBO_TRY(danbo_coarse_samples(b.near, b.far, R, S, nullptr, b.z, stream));
     // candidate bones of every ray over [near, far]: both culls below skip the rays (and workgroups) that miss every volume
-    DANBO_TRY(danbo_ray_bone_mask(r->rays_o, r->rays_d, b.near, b.far, R, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.ray_flat, stream));
+    DANBO_TRY(danbo_ray_bone_mask(r->rays_o, r->rays_d, b.near, b.far, R, G, r->skts, m->align, m->axis_scale, b.ray_mask,
+                                  m->flat_rays_ok ? b.ray_flat : nullptr, stream));
     // per pose / per ray
     DANBO_TRY(danbo_pose_volumes_fwd(r->bones, G, m->L_graph, m->graph_width, m->g_w0, m->g_adjw0, m->g_b0, m->g_w1, m->g_adjw1, m->g_b1,
                                      m->g_w2, m->g_b2, m->g_w3, m->g_b3, b.vol_scratch, b.volumes, stream));
-    DANBO_TRY(danbo_view_consts(r->rays_d, r->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->framecodes, m->n_codes, m->code_size,
-                                m->mean_code, r->cam_idx, m->views_w_ray_t, m->views_b_eff, m->rgb_w, m->rgb_b, m->empty_consts, 1,
-                                m->code_table, b.cview, b.raw_empty, stream));
+    zero_words(b.count, 4, nullptr, 0, st);      // both row counters, the ticket (which returns to 0 after each launch), the ray counter
+    const bool flat_rays = m->flat_rays_ok != 0;
+    auto view_consts = [&](const int32_t* ray_list, const int32_t* ray_count) -> int {
+        return danbo_view_consts(r->rays_d, r->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->framecodes, m->n_codes, m->code_size,
+                                 m->mean_code, r->cam_idx, m->views_w_ray_t, m->views_b_eff, m->rgb_w, m->rgb_b, m->empty_consts, 1,
+                                 m->code_table, ray_list, ray_count, b.cview, b.raw_empty, stream);
+    };
+    if (!flat_rays) DANBO_TRY(view_consts(nullptr, nullptr));
     // one network pass over R x s samples at depths zz -> raw (rows outside every volume stay unwritten: bits == 0)
-    zero_words(b.count, 4, nullptr, 0, st);      // both row counters and the ticket (which returns to 0 after each launch)
-    auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
+    auto cull = [&](const float* zz, int s, uint32_t* bits, int32_t* count) -> int {
         // (the coarse pass's cull confirms the flags of the rays of constants; the importance pass leaves them alone)
         DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.near, b.far,
-                                  zz == b.z ? b.ray_flat : nullptr, bits, b.list, count, stream));
-        DANBO_TRY(danbo_group_rows(bits, b.list, count, R * s, stream));     // rows of the same bone set next to each other (k_group.hip)
+                                  flat_rays && zz == b.z ? b.ray_flat : nullptr, bits, b.list, count, stream));
+        return danbo_group_rows(bits, b.list, count, R * s, stream);     // rows of the same bone set next to each other (k_group.hip)
+    };
+    auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,
                                                   bits, b.list, count, R * s, m->assign16, m->a_b0, m->a_b1, m->a_w2, m->a_b2, b.h,
                                                   nullptr, reinterpret_cast<uint32_t*>(b.count + 2), stream));
         return danbo_pe_mlp16_fwd(b.h, b.list, count, R * s, s, m->mlp16, m->pts_b, m->alpha_w, m->alpha_b, b.cview, m->rgb_w,
                                   m->rgb_b, raw, nullptr, stream);
     };
+    DANBO_TRY(cull(b.z, S, b.bits_a, b.count));
+    const int32_t *ray_list = nullptr, *ray_count = nullptr;
+    if (flat_rays) {
+        // the rays of constants get every output of both composites here; the view constants and the composites take the list of
+        // the others
+        DANBO_TRY(danbo_flat_rays(b.near, b.ray_flat, R, S, Sf, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, o->rgb_map,
+                                  o->disp_map, o->acc_map, o->weights, o->alpha, b.ray_list, b.count + 3, stream));
+        ray_list = b.ray_list;
+        ray_count = b.count + 3;
+        DANBO_TRY(view_consts(ray_list, ray_count));
+    }
     DANBO_TRY(network(b.z, S, b.bits_a, b.count, b.raw_a));
-    // the rays of constants get every output of both composites here; the composites take the list of the others
-    DANBO_TRY(danbo_flat_rays(b.raw_empty, b.near, b.ray_flat, R, S, Sf, m->density_scale, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0,
-                              b.z_fine, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, b.ray_list, b.count + 3, stream));
     DANBO_TRY(danbo_composite_importance_fwd(b.raw_a, b.raw_empty, b.bits_a, b.z, r->rays_d, R, S, Sf, m->density_scale, nullptr, nullptr,
-                                             o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order, b.ray_list,
-                                             b.count + 3, stream));
+                                             o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order, ray_list,
+                                             ray_count, stream));
+    DANBO_TRY(cull(b.z_fine, Sf, b.bits_b, b.count + 1));
     DANBO_TRY(network(b.z_fine, Sf, b.bits_b, b.count + 1, b.raw_b));
     return danbo_composite_merged_fwd(b.raw_a, b.raw_b, b.raw_empty, b.bits_a, b.bits_b, b.order, b.z_sorted, r->rays_d, R, S, Sf,
                                       m->density_scale, nullptr, o->rgb_map, o->disp_map, o->acc_map, o->weights, o->alpha, nullptr,
-                                      b.ray_list, b.count + 3, stream);
+                                      ray_list, ray_count, stream);
 }

@@ -135,8 +135,6 @@ __device__ __forceinline__ float rgb_dot_halves(const float* x, const float* __r
 // ======================================================================================
 // per-ray view constants
 // ======================================================================================
-constexpr int VIEW_RPB = 16;  // rays per workgroup iteration (8 per half-workgroup)
-
 // table[c][n] = views_b[n] + sum_k W_view[n][256 + Cpe + k] * code_c[k]   for every frame code c and,
 // in row n_codes, for the mean code (Optcodes eval with idx < 0).  One workgroup per code.
 __global__ __launch_bounds__(128) void k_view_code_table(const float* __restrict__ framecodes,
@@ -151,9 +149,13 @@ __global__ __launch_bounds__(128) void k_view_code_table(const float* __restrict
     table[(size_t)c * MLP_VW + n] = acc + views_b[n];
 }
 
-// Each thread owns one of the 128 view-layer columns for 8 rays: per input i it reads ONE weight
-// (conflict-free, lane = column) and the 8 rays' v_i as two broadcast ds_read_b128, then issues
-// 8 FMAs -- 3 LDS reads per 8 FMAs instead of 2 per FMA.
+// RPB rays per workgroup iteration, RPB / 2 per half-workgroup.  Each thread owns one of the 128 view-layer columns for RPB / 2
+// rays: per input i it reads ONE weight (conflict-free, lane = column) and the rays' v_i as broadcast ds_read_b128, then issues
+// RPB / 2 FMAs.  An iteration is a chain of five barriers with a global-memory round trip behind most of them (directions ->
+// pose matrix -> code row -> colour weights): 17.8 us per iteration whatever RPB is -- RPB = 64 (large batches) divides the number
+// of iterations by four (512 x 512 rays: 194 -> see DESIGN.md section 3); RPB = 16 keeps a training batch's 3 072 rays spread over
+// 192 workgroups.  Per-ray arithmetic (summation orders) does not depend on RPB.
+template <int RPB>
 __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ rays_d, const float* __restrict__ skts,
                                                      int R, int G, int ray_mode, int normalise, int L_view,
                                                      const float* __restrict__ framecodes, int n_codes, int Cf,
@@ -164,126 +166,146 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                                                      const float* __restrict__ rgb_b,
                                                      const float* __restrict__ empty_consts, int rgb_order,
                                                      const float* __restrict__ code_table,
+                                                     const int32_t* __restrict__ ray_list,
+                                                     const int32_t* __restrict__ ray_count,
                                                      float* __restrict__ cview, float* __restrict__ raw_empty) {
+    constexpr int NR = RPB / 2;               // rays per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Cpe = 3 * (1 + 2 * L_view);
     // with a code table the frame-code part (and the bias) is a per-camera constant: only PE(dir) is summed
     const int Cv = code_table ? Cpe : Cpe + Cf;
     if (code_table) Cf = 0;
     float* s_w = smem;                        // [Cv][128]
-    float* s_v = s_w + Cv * MLP_VW;           // [Cv][16]   (transposed: input-major, ray-minor)
-    float* s_x = s_v + Cv * VIEW_RPB;         // [16][128]
+    float* s_v = s_w + Cv * MLP_VW;           // [Cv][RPB]   (transposed: input-major, ray-minor)
+    float* s_x = s_v + Cv * RPB;              // [RPB][128]
+    float* s_rgbw = s_x + RPB * MLP_VW;       // [3][128]
+    int* s_row = reinterpret_cast<int*>(s_rgbw + 3 * MLP_VW);   // [RPB] code-table row of each ray
+    int* s_ray = s_row + RPB;                                   // [RPB] ray of each slot of the iteration (-1: none)
+    // ray_list / ray_count: only the listed rays (k_flat_rays' list: the others are rays of constants, nobody reads their rows)
+    const int n = ray_list ? min(max(*ray_count, 0), R) : R;
     const int tid = threadIdx.x;
     for (int i = tid; i < Cv * MLP_VW; i += 256) s_w[i] = wt[i];
+    for (int i = tid; i < 3 * MLP_VW; i += 256) s_rgbw[i] = rgb_w[i];
     const int rays_per_pose = R / G;
     const int c = tid & 127, half = tid >> 7;
     const float bias = views_b[c];
     const float ec = empty_consts ? empty_consts[c] : 0.f;
 
-    for (int r0 = blockIdx.x * VIEW_RPB; r0 < R; r0 += gridDim.x * VIEW_RPB) {
+    auto ray_of = [&](int i) { i = min(i, n - 1); return ray_list ? min(max(ray_list[i], 0), R - 1) : i; };
+    for (int r0 = blockIdx.x * RPB; r0 < n; r0 += gridDim.x * RPB) {
         __syncthreads();
+        for (int rl = tid; rl < RPB; rl += 256) s_ray[rl] = r0 + rl < n ? ray_of(r0 + rl) : -1;
         // ---- build the per-ray view vectors [PE(dir) | frame code], stored [i][ray] ----
-        if (tid < VIEW_RPB * 3) {
-            const int rl = tid / 3, k = tid % 3;
-            const int r = min(r0 + rl, R - 1);
+        for (int q = tid; q < RPB * 3; q += 256) {
+            const int rl = q / 3, k = q % 3;
+            const int r = ray_of(r0 + rl);
             float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
             if (ray_mode == 1) {
                 const float* M = skts + (size_t)min(r / rays_per_pose, G - 1) * J * 16;  // bone 0 = root
-                float q[3];
+                float t[3];
                 for (int a = 0; a < 3; ++a)
-                    q[a] = add_rn(add_rn(mul_rn(M[4 * a], d[0]), mul_rn(M[4 * a + 1], d[1])), mul_rn(M[4 * a + 2], d[2]));
-                d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+                    t[a] = add_rn(add_rn(mul_rn(M[4 * a], d[0]), mul_rn(M[4 * a + 1], d[1])), mul_rn(M[4 * a + 2], d[2]));
+                d[0] = t[0]; d[1] = t[1]; d[2] = t[2];
             }
             if (normalise) {
                 const float nrm = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
                 const float den = fmaxf(nrm, 1e-12f);
                 d[0] = div_rn(d[0], den); d[1] = div_rn(d[1], den); d[2] = div_rn(d[2], den);
             }
-            s_v[k * VIEW_RPB + rl] = d[k];
+            s_v[k * RPB + rl] = d[k];
+        }
+        if (code_table) {
+            for (int rl = tid; rl < RPB; rl += 256) {
+                const int r = ray_of(r0 + rl);
+                const long idx = cam_idx ? (long)cam_idx[r] : -1;
+                s_row[rl] = idx < 0 ? n_codes : (int)min(idx, (long)n_codes - 1);
+            }
+        }
+        for (int i = tid; i < RPB * Cf; i += 256) {
+            const int rl = i / Cf, k = i % Cf;
+            const int r = ray_of(r0 + rl);
+            const long idx = cam_idx ? (long)cam_idx[r] : -1;
+            const float val = idx < 0 ? mean_code[k] : framecodes[(size_t)min(idx, (long)n_codes - 1) * Cf + k];
+            s_v[(Cpe + k) * RPB + rl] = val;
         }
         __syncthreads();
         // one (ray, axis, level) per thread: sin / cos of 2^l d
-        for (int q = tid; q < VIEW_RPB * 3 * L_view; q += 256) {
-            const int rl = q % VIEW_RPB, k = (q / VIEW_RPB) % 3, l = q / (VIEW_RPB * 3);
+        for (int q = tid; q < RPB * 3 * L_view; q += 256) {
+            const int rl = q % RPB, k = (q / RPB) % 3, l = q / (RPB * 3);
             float sn, cs;
-            pe_sincos(mul_rn(s_v[k * VIEW_RPB + rl], (float)(1 << l)), &sn, &cs);
-            s_v[(3 * (1 + 2 * l) + k) * VIEW_RPB + rl] = sn;
-            s_v[(3 * (2 + 2 * l) + k) * VIEW_RPB + rl] = cs;
-        }
-        if (code_table && tid < VIEW_RPB) {
-            const int r = min(r0 + tid, R - 1);
-            const long idx = cam_idx ? (long)cam_idx[r] : -1;
-            reinterpret_cast<int*>(s_x)[tid] = idx < 0 ? n_codes : (int)min(idx, (long)n_codes - 1);
-        }
-        for (int i = tid; i < VIEW_RPB * Cf; i += 256) {
-            const int rl = i / Cf, k = i % Cf;
-            const int r = min(r0 + rl, R - 1);
-            const long idx = cam_idx ? (long)cam_idx[r] : -1;
-            const float val = idx < 0 ? mean_code[k] : framecodes[(size_t)min(idx, (long)n_codes - 1) * Cf + k];
-            s_v[(Cpe + k) * VIEW_RPB + rl] = val;
+            pe_sincos(mul_rn(s_v[k * RPB + rl], (float)(1 << l)), &sn, &cs);
+            s_v[(3 * (1 + 2 * l) + k) * RPB + rl] = sn;
+            s_v[(3 * (2 + 2 * l) + k) * RPB + rl] = cs;
         }
         __syncthreads();
         // ---- cview[r][c] = sum_i W[c][256+i] v[i] + b[c]   (sequential fmaf over i) ----
-        float acc[8];
+        float acc[NR];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-        int trow[8];
+        for (int q = 0; q < NR; ++q) acc[q] = 0.f;
+        // the code-table rows of this thread's rays: requested now, added after the sum
+        float trow[NR];
         if (code_table) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) trow[q] = reinterpret_cast<const int*>(s_x)[half * 8 + q];
-            __syncthreads();  // s_x is reused for the activations below
+            for (int q = 0; q < NR; ++q) trow[q] = code_table[(size_t)s_row[half * NR + q] * MLP_VW + c];
         }
-        const float* vp = s_v + half * 8;
-#pragma unroll 4
+        const float* vp = s_v + half * NR;
+#pragma unroll 2
         for (int i = 0; i < Cv; ++i) {
             const float w = s_w[i * MLP_VW + c];
-            const float4 v0 = *reinterpret_cast<const float4*>(vp + i * VIEW_RPB);
-            const float4 v1 = *reinterpret_cast<const float4*>(vp + i * VIEW_RPB + 4);
-            acc[0] = fmaf(v0.x, w, acc[0]); acc[1] = fmaf(v0.y, w, acc[1]);
-            acc[2] = fmaf(v0.z, w, acc[2]); acc[3] = fmaf(v0.w, w, acc[3]);
-            acc[4] = fmaf(v1.x, w, acc[4]); acc[5] = fmaf(v1.y, w, acc[5]);
-            acc[6] = fmaf(v1.z, w, acc[6]); acc[7] = fmaf(v1.w, w, acc[7]);
+#pragma unroll
+            for (int q4 = 0; q4 < NR / 4; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(vp + i * RPB + 4 * q4);
+                acc[4 * q4] = fmaf(v.x, w, acc[4 * q4]);
+                acc[4 * q4 + 1] = fmaf(v.y, w, acc[4 * q4 + 1]);
+                acc[4 * q4 + 2] = fmaf(v.z, w, acc[4 * q4 + 2]);
+                acc[4 * q4 + 3] = fmaf(v.w, w, acc[4 * q4 + 3]);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int rl = half * 8 + q, r = r0 + rl;
-            const float a = code_table ? acc[q] + code_table[(size_t)trow[q] * MLP_VW + c] : acc[q] + bias;
-            if (r < R) cview[(size_t)r * MLP_VW + c] = a;
+        for (int q = 0; q < NR; ++q) {
+            const int rl = half * NR + q, r = s_ray[rl];
+            const float a = code_table ? acc[q] + trow[q] : acc[q] + bias;
+            if (r >= 0) cview[(size_t)r * MLP_VW + c] = a;
             if (empty_consts) s_x[rl * MLP_VW + c] = fmaxf(ec + a, 0.f);
         }
         if (empty_consts) {
             __syncthreads();
             if (rgb_order) {
                 // the summation order of k_pe_mlp16: four lane-group partials per (ray, channel), then
-                // ((p0 + p1) + (p2 + p3)) + b -- one partial chain per thread (192 threads busy instead of 48)
-                float part = 0.f;
-                const int rl = tid >> 4, ch = (tid >> 2) & 3, q = tid & 3;
-                if (ch < 3) {
-                    const float* x = s_x + rl * MLP_VW;
-                    const float* wv = rgb_w + ch * MLP_VW;
+                // ((p0 + p1) + (p2 + p3)) + b -- one partial chain per thread, 16 rays per pass
+                for (int pass = 0; pass < RPB / 16; ++pass) {
+                    float part = 0.f;
+                    const int rl = pass * 16 + (tid >> 4), ch = (tid >> 2) & 3, q = tid & 3;
+                    if (ch < 3) {
+                        const float* x = s_x + rl * MLP_VW;
+                        const float* wv = s_rgbw + ch * MLP_VW;
 #pragma unroll
-                    for (int T = 0; T < 8; ++T) {
-                        const int n = 16 * T + 4 * q;
-                        const float4 xv = *reinterpret_cast<const float4*>(x + n);
-                        part = fmaf(xv.x, wv[n], part);
-                        part = fmaf(xv.y, wv[n + 1], part);
-                        part = fmaf(xv.z, wv[n + 2], part);
-                        part = fmaf(xv.w, wv[n + 3], part);
+                        for (int T = 0; T < 8; ++T) {
+                            const int n = 16 * T + 4 * q;
+                            const float4 xv = *reinterpret_cast<const float4*>(x + n);
+                            const float4 ww = *reinterpret_cast<const float4*>(wv + n);
+                            part = fmaf(xv.x, ww.x, part);
+                            part = fmaf(xv.y, ww.y, part);
+                            part = fmaf(xv.z, ww.z, part);
+                            part = fmaf(xv.w, ww.w, part);
+                        }
                     }
+                    // lanes 4k..4k+3 hold p0..p3 of one (ray, channel)
+                    const float p1 = __shfl_xor(part, 1, 64);
+                    const float pair = (q & 1) ? p1 + part : part + p1;      // p0+p1 in lanes q=0,1 ; p2+p3 in lanes q=2,3
+                    const float other = __shfl_xor(pair, 2, 64);
+                    const int r = s_ray[rl];
+                    if (q == 0 && r >= 0) raw_empty[(size_t)r * 4 + ch] = ch < 3 ? (pair + other) + rgb_b[ch] : empty_consts[MLP_VW];
                 }
-                // lanes 4k..4k+3 hold p0..p3 of one (ray, channel)
-                const float p1 = __shfl_xor(part, 1, 64);
-                const float pair = (q & 1) ? p1 + part : part + p1;      // p0+p1 in lanes q=0,1 ; p2+p3 in lanes q=2,3
-                const float other = __shfl_xor(pair, 2, 64);
-                const int r = r0 + rl;
-                if (q == 0 && r < R) raw_empty[(size_t)r * 4 + ch] = ch < 3 ? (pair + other) + rgb_b[ch] : empty_consts[MLP_VW];
-            } else if (tid < VIEW_RPB * 4) {
-                const int rl = tid >> 2, ch = tid & 3;
-                const int r = r0 + rl;
-                if (r < R) {
-                    float val = empty_consts[MLP_VW];
-                    if (ch < 3) val = rgb_dot(s_x + rl * MLP_VW, rgb_w + ch * MLP_VW, rgb_b[ch]);
-                    raw_empty[(size_t)r * 4 + ch] = val;
+            } else {
+                for (int q = tid; q < RPB * 4; q += 256) {
+                    const int rl = q >> 2, ch = q & 3;
+                    const int r = s_ray[rl];
+                    if (r >= 0) {
+                        float val = empty_consts[MLP_VW];
+                        if (ch < 3) val = rgb_dot(s_x + rl * MLP_VW, s_rgbw + ch * MLP_VW, rgb_b[ch]);
+                        raw_empty[(size_t)r * 4 + ch] = val;
+                    }
                 }
             }
         }
@@ -537,22 +559,30 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
                                   int L_view, const float* framecodes, int n_codes, int Cf, const float* mean_code,
                                   const int64_t* cam_idx, const float* views_w_ray_t, const float* views_b,
                                   const float* rgb_w, const float* rgb_b, const float* empty_consts, int rgb_order,
-                                  const float* code_table, float* cview, float* raw_empty, void* stream) {
+                                  const float* code_table, const int32_t* ray_list, const int32_t* ray_count, float* cview,
+                                  float* raw_empty, void* stream) {
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && L_view >= 0 && Cf >= 0);
+    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
     DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
     DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
     const int Cv = 3 * (1 + 2 * L_view) + (code_table ? 0 : Cf);
-    const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + VIEW_RPB * Cv + VIEW_RPB * MLP_VW);
+    const int rpb = R >= 16384 ? 64 : 16;
+    const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + (size_t)rpb * Cv + (size_t)rpb * MLP_VW + 3 * MLP_VW + 2 * rpb);
     DANBO_CHECK_ARG(lds <= 160 * 1024);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_view_consts),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fn = rpb == 64 ? reinterpret_cast<const void*>(k_view_consts<64>) : reinterpret_cast<const void*>(k_view_consts<16>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    const int iters = ceil_div(R, VIEW_RPB);
+    const int iters = ceil_div(R, rpb);
     const int per_cu = (int)((160 * 1024) / (lds + 1024)) < 8 ? (int)((160 * 1024) / (lds + 1024)) : 8;  // latency-bound phases: fill the CU
     const int grid = iters < num_cu() * per_cu ? iters : num_cu() * (per_cu > 0 ? per_cu : 1);
-    hipLaunchKernelGGL(k_view_consts, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
-                       normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
-                       rgb_b, empty_consts, rgb_order, code_table, cview, raw_empty);
+    if (rpb == 64)
+        hipLaunchKernelGGL(k_view_consts<64>, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
+                           normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
+                           rgb_b, empty_consts, rgb_order, code_table, ray_list, ray_count, cview, raw_empty);
+    else
+        hipLaunchKernelGGL(k_view_consts<16>, dim3(grid), dim3(256), lds, (hipStream_t)stream, rays_d, skts, R, G, ray_mode,
+                           normalise, L_view, framecodes, n_codes, Cf, mean_code, cam_idx, views_w_ray_t, views_b, rgb_w,
+                           rgb_b, empty_consts, rgb_order, code_table, ray_list, ray_count, cview, raw_empty);
     DANBO_LAUNCH_RET();
 }
 

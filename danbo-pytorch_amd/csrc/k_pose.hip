@@ -51,10 +51,16 @@ __global__ __launch_bounds__(256) void k_pose_layer(const float* __restrict__ bo
         }
     } else if (MODE == 1) {
         for (int k = tid; k < Cin; k += 256) {
+            // all 24 rows requested at once (a zero adjacency entry leaves acc as it is: a * y = +-0); walking the non-zero entries
+            // one dependent load after the other cost more than the layer's arithmetic
+            float y[J];
+#pragma unroll
+            for (int jp = 0; jp < J; ++jp) y[jp] = Yp[((size_t)g * J + jp) * Cin + k];
             float acc = 0.f;
+#pragma unroll
             for (int jp = 0; jp < J; ++jp) {
                 const float a = adjw_p[j * J + jp];
-                if (a != 0.f) acc = fmaf(a, Yp[((size_t)g * J + jp) * Cin + k], acc);
+                acc = a != 0.f ? fmaf(a, y[jp], acc) : acc;
             }
             acc = scale * (acc + bias_p[k]);
             s_x[k] = fmaxf(acc, 0.f);
@@ -65,9 +71,18 @@ __global__ __launch_bounds__(256) void k_pose_layer(const float* __restrict__ bo
     __syncthreads();
     for (int c = tid; c < Cout; c += 256) {
         const float* w = W + (size_t)j * Cin * Cout + c;
+        // same summation order as before (one fmaf chain over k), 32 weight loads in flight instead of 4: the layer is the
+        // latency of Cin / unroll round trips (4 launches of ~30 us each for 1.7 MMAC)
         float acc = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < Cin; ++k) acc = fmaf(s_x[k], w[(size_t)k * Cout], acc);
+        int k = 0;
+        for (; k + 32 <= Cin; k += 32) {
+            float wv[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) wv[i] = w[(size_t)(k + i) * Cout];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc = fmaf(s_x[k + i], wv[i], acc);
+        }
+        for (; k < Cin; ++k) acc = fmaf(s_x[k], w[(size_t)k * Cout], acc);
         if (bias) acc += bias[j * Cout + c];
         Y[((size_t)g * J + j) * Cout + c] = acc;
     }

@@ -220,6 +220,8 @@ __device__ __forceinline__ bool segment_misses_bone(const float* sk, const float
 // of it load latency; this: see DESIGN.md section 3.)
 // No reference counterpart (the reference tests every sample against every bone, gnn_backbone.py:787-828): the exact per-sample
 // test of k_bone_cull is unchanged, this only tells it which bones (and which whole workgroups) cannot matter.
+constexpr float RAY_FLAT_VMAX = DANBO_RAY_FLAT_VMAX;
+
 template <bool POSES_IN_LDS>
 __global__ __launch_bounds__(256) void k_ray_bone_mask(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const float* __restrict__ t_lo, const float* __restrict__ t_hi,
@@ -262,12 +264,19 @@ __global__ __launch_bounds__(256) void k_ray_bone_mask(const float* __restrict__
     if (r_a + (int)threadIdx.x < R) {
         ray_mask[r] = bits;
         if (ray_flat != nullptr) {
-            // candidate for a ray of constants (k_composite_importance): no volume anywhere along [zl, zh], and every interval
-            // length any set of depths inside [zl, zh] can produce -- |gap| * |d|, 1e10 * |d| for the last sample -- is finite
+            // candidate for a ray of constants (k_flat_rays): no volume anywhere along [zl, zh], every interval length any set of
+            // depths inside [zl, zh] can produce -- |gap| * |d|, 1e10 * |d| for the last sample -- is finite, and every input the
+            // view layer can see of this ray (its direction, raw or turned by the root bone's matrix; sines and cosines are
+            // <= 1 anyway) is at most RAY_FLAT_VMAX in magnitude: what the caller's bound on the empty-space colour assumes
             const float dn = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
             const float span = mul_rn(add_rn(sub_rn(zh, zl), mul_rn(1e-3f, fmaxf(fabsf(zl), fabsf(zh)))), dn);
             const float tail = mul_rn(1e10f, dn);
-            const bool fin = zl <= zh && sub_rn(span, span) == 0.f && sub_rn(tail, tail) == 0.f;
+            const float* m0 = POSES_IN_LDS ? s_skt + (size_t)(g - g0) * J * 16 : skts + (size_t)g * J * 16;     // the root bone
+            float msum = 0.f;
+            for (int a = 0; a < 3; ++a)
+                for (int k = 0; k < 3; ++k) msum = add_rn(msum, fabsf(m0[4 * a + k]));
+            const float vin = mul_rn(dn, fmaxf(1.0f, msum));
+            const bool fin = zl <= zh && sub_rn(span, span) == 0.f && sub_rn(tail, tail) == 0.f && vin <= RAY_FLAT_VMAX;
             ray_flat[r] = (bits == 0u && fin) ? 1u : 0u;
         }
     }
@@ -1018,16 +1027,17 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
 }
 
 // Rays of constants.  A ray that cannot meet a volume anywhere between t_lo and t_hi (k_ray_bone_mask's flag), all of whose coarse
-// depths lie in that interval (k_bone_cull clears the flag otherwise), whose empty-space density is <= 0 and whose empty-space
-// colour is finite has sig = 0, alpha = +0, T = 1, w = +0 on every sample of BOTH passes -- its importance depths would lie
-// between its coarse depths.  This kernel writes every output of the two composites for those rays (the values the general chain
-// computes, bit for bit: +0 everywhere), z_fine = t_lo (inside the interval: the importance pass's cull drops the ray on its
-// mask), and lists all OTHER rays for k_composite_importance / k_composite_merged -- which then share them evenly over their
-// wavefronts (a static split of ALL rays left the wavefronts with 5 to 25 rays of work each: as slow as without the flags).
-// Nothing here depends on the network pass: it runs beside K3 on a side stream.  63 % of the rays of the bench frame.
+// depths lie in that interval (k_bone_cull clears the flag otherwise), has ONE raw on every sample of BOTH passes -- its
+// importance depths would lie between its coarse depths -- the ray's empty-space raw.  If the model's empty-space density is <= 0
+// and its empty-space colour logits cannot be NaN (the CALLER's statement about the model, danbo_hip.h: both are properties of
+// the weights, not of the ray), that is sig = 0, alpha = +0, T = 1, w = +0 everywhere.  This kernel writes every output of the
+// two composites for those rays (the values the general chain computes, bit for bit: +0 everywhere), z_fine = t_lo (inside the
+// interval: the importance pass's cull drops the ray on its mask), and lists all OTHER rays for k_view_consts,
+// k_composite_importance and k_composite_merged -- which then share them evenly over their wavefronts (a static split of ALL
+// rays left the wavefronts with 5 to 25 rays of work each: as slow as without the flags).  63 % of the rays of the bench frame.
 constexpr int FLAT_BLOCK = 1024;
-__global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float4* __restrict__ raw_empty, const float* __restrict__ t_lo,
-                                                          const uint32_t* __restrict__ ray_flat, int R, int S, int Sf, float B,
+__global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restrict__ t_lo,
+                                                          const uint32_t* __restrict__ ray_flat, int R, int S, int Sf,
                                                           float* __restrict__ rgb0, float* __restrict__ disp0, float* __restrict__ acc0,
                                                           float* __restrict__ weights0, float* __restrict__ alpha0,
                                                           float* __restrict__ z_fine, float* __restrict__ rgb_map,
@@ -1039,14 +1049,8 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float4* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int St = S + Sf;
     const int r = blockIdx.x * FLAT_BLOCK + threadIdx.x;
-    bool flat = false;
-    float lo = 0.f;
-    if (r < R && ray_flat[r] != 0u) {
-        const float4 re = raw_empty[r];
-        const float rgb_sum = add_rn(add_rn(re.x, re.y), re.z);
-        flat = !(div_rn(re.w, B) > 0.f) && sub_rn(rgb_sum, rgb_sum) == 0.f;
-        lo = t_lo[r];
-    }
+    const bool flat = r < R && ray_flat[r] != 0u;
+    const float lo = flat ? t_lo[r] : 0.f;
     if (flat) {     // composite_finish of five +0 sums, twice
         rgb0[3 * r] = 0.f; rgb0[3 * r + 1] = 0.f; rgb0[3 * r + 2] = 0.f;
         disp0[r] = 0.f;
@@ -1255,14 +1259,13 @@ extern "C" int danbo_composite_importance_fwd(const float* raw, const float* raw
     DANBO_LAUNCH_RET();
 }
 
-extern "C" int danbo_flat_rays(const float* raw_empty, const float* t_lo, const uint32_t* ray_flat, int R, int S, int Sf, float B,
-                                float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
+extern "C" int danbo_flat_rays(const float* t_lo, const uint32_t* ray_flat, int R, int S, int Sf, float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
                                 float* rgb_map, float* disp, float* acc, float* weights, float* alpha, int32_t* ray_list,
                                 int32_t* ray_count, void* stream) {
-    DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64 && B > 0.f);
-    DANBO_CHECK_ARG(raw_empty && t_lo && ray_flat && rgb0 && disp0 && acc0 && z_fine && rgb_map && disp && acc && ray_list && ray_count);
+    DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64);
+    DANBO_CHECK_ARG(t_lo && ray_flat && rgb0 && disp0 && acc0 && z_fine && rgb_map && disp && acc && ray_list && ray_count);
     hipLaunchKernelGGL(k_flat_rays, dim3(ceil_div(R, FLAT_BLOCK)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(raw_empty), t_lo, ray_flat, R, S, Sf, B, rgb0, disp0, acc0, weights0, alpha0, z_fine,
+                       t_lo, ray_flat, R, S, Sf, rgb0, disp0, acc0, weights0, alpha0, z_fine,
                        rgb_map, disp, acc, weights, alpha, ray_list, ray_count);
     DANBO_LAUNCH_RET();
 }

@@ -27,6 +27,7 @@ extern "C" {
 #define DANBO_VOL 240       /* voxel_feat(5) * voxel_res(16) * 3 axes               */
 #define DANBO_FEAT 15       /* voxel_feat * 3 ('cat' construct)                     */
 #define DANBO_H_STRIDE 16   /* blended feature rows are padded 15 -> 16 floats      */
+#define DANBO_RAY_FLAT_VMAX 1e4f /* danbo_ray_bone_mask flags no ray whose view direction inputs may exceed this */
 
 /* library / device identification (host only).
  * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
@@ -109,9 +110,11 @@ int danbo_bone_cull(const float* rays_o, const float* rays_d, const float* z, co
 /* Per-ray candidate bones: ray_mask[r] bit j = 0 when no point rays_o + t rays_d with
  * t_lo[r] <= t <= t_hi[r] can lie inside the volume of bone j (slab test of the segment against the
  * slightly inflated box, conservative).  Once per ray batch -- the coarse and the importance samples
- * of a ray both lie inside its [near, far].  ray_flat (optional) [R]: 1 when ray_mask[r] == 0 and every
- * interval length the ray can produce inside [t_lo, t_hi] is finite -- the ray is a candidate for the
- * constants of an empty ray (danbo_flat_rays).  No reference counterpart: the reference evaluates every sample against
+ * of a ray both lie inside its [near, far].  ray_flat (optional) [R]: 1 when ray_mask[r] == 0, every
+ * interval length the ray can produce inside [t_lo, t_hi] is finite, and |rays_d| times max(1, the
+ * absolute row sums of the root bone's 3x3 matrix) -- a bound on every view-direction input of the
+ * colour branch -- is at most DANBO_RAY_FLAT_VMAX: the ray is a candidate for the constants of an empty
+ * ray (danbo_flat_rays).  No reference counterpart: the reference evaluates every sample against
  * every bone (core/networks/gnn_backbone.py:787-828); this feeds danbo_bone_cull and the composites. */
 int danbo_ray_bone_mask(const float* rays_o, const float* rays_d, const float* t_lo /*[R]*/, const float* t_hi /*[R]*/,
                         int R, int G, const float* skts, const float* align, const float* axis_scale,
@@ -194,7 +197,9 @@ int danbo_mlp_pack(const float* const* pts_w /*8 ptrs [256,195|256|451]*/, const
  * mean code), cview[r] = W_view[:,256:] . [PE(dir)|code] + b_view;  if empty_consts != NULL
  * also raw_empty[r] = (rgb_linear(relu(empty_view_pre + cview[r])), empty_alpha): the raw
  * of every sample of ray r that lies in no bone volume (blended feature h = 0).
- *   ray_mode 0: 'world' raw rays_d; 1: 'root_local' (skts[g,0,:3,:3] . d);  normalise: relray */
+ *   ray_mode 0: 'world' raw rays_d; 1: 'root_local' (skts[g,0,:3,:3] . d);  normalise: relray
+ *   ray_list / ray_count (optional, together): only the listed rays' rows are computed and written
+ *   (danbo_flat_rays' list: nobody reads the rows of a ray of constants). */
 int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise,
                       int L_view, const float* framecodes /*[n_codes,Cf] or NULL*/, int n_codes, int Cf,
                       const float* mean_code /*[Cf]: codes.mean(0), used where cam_idx < 0*/,
@@ -204,6 +209,7 @@ int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int 
                       const float* empty_consts /*[129] or NULL*/,
                       int rgb_order /*0: summation order of danbo_pe_mlp_fwd, 1: of danbo_pe_mlp16_fwd*/,
                       const float* code_table /*[n_codes+1,128] from danbo_view_code_table, or NULL*/,
+                      const int32_t* ray_list /*[R] or NULL*/, const int32_t* ray_count /*[1] or NULL*/,
                       float* cview /*[R,128]*/, float* raw_empty /*[R,4] or NULL*/, void* stream);
 
 /* Per-camera part of the view constants, once per weight update: table[c] = views_b + W_view[:, code
@@ -297,19 +303,22 @@ int danbo_composite_importance_fwd(const float* raw /*[R,S,4]*/, const float* ra
 
 /* Rays of constants (no reference counterpart; the values are the reference's).  ray_flat: the flags danbo_ray_bone_mask made
  * and danbo_bone_cull of the COARSE pass (same rays, depths, mask, interval) has passed on -- a set flag says the ray cannot
- * meet a volume anywhere in [t_lo, t_hi], which holds all of its coarse depths.  If in addition its empty-space density
- * raw_empty[r][3] / B is <= 0 and its empty-space colour finite, every sample of the ray in the coarse AND in the importance pass
- * (whose depths lie between the coarse ones) has sig = 0, alpha = +0, T = 1, w = +0, and raw2outputs gives +0 maps for both.  This
- * call writes exactly those outputs for such rays -- the coarse composite's (rgb0, disp0, acc0, weights0 / alpha0 rows, may be
- * NULL) and the merged composite's (rgb_map, disp, acc, weights / alpha rows, may be NULL) -- sets their z_fine row to t_lo (so
- * that the importance pass's danbo_bone_cull drops them on their mask; their z_sorted / sorted_idx rows are never made), and
- * appends every OTHER ray to ray_list / *ray_count (zeroed by the caller), to be passed to danbo_composite_importance_fwd and
- * danbo_composite_merged_fwd.  All maps / alphas / weights of the frame are then bit-identical to compositing every ray; only a
- * caller that wants z_fine / z_sorted / sorted_idx of every ray must not use this (eval without noise only). */
-int danbo_flat_rays(const float* raw_empty /*[R,4]*/, const float* t_lo /*[R]*/, const uint32_t* ray_flat /*[R]*/, int R, int S,
-                    int Sf, float B, float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
-                    float* rgb_map, float* disp, float* acc, float* weights /*[R,S+Sf]*/, float* alpha,
-                    int32_t* ray_list /*[R]*/, int32_t* ray_count /*[1]*/, void* stream);
+ * meet a volume anywhere in [t_lo, t_hi], which holds all of its coarse depths: every sample of the ray, in the coarse AND in the
+ * importance pass (whose depths lie between the coarse ones), carries the ray's empty-space raw.  The CALLER states that
+ *   (a) the model's empty-space density empty_consts[128] / B is <= 0, and
+ *   (b) the empty-space colour logits cannot be NaN for the flagged rays: a finite bound from the weights' magnitudes with
+ *       view-direction inputs of at most DANBO_RAY_FLAT_VMAX (core/render_engine.py:_flat_rays_ok),
+ * both properties of the weights; then sig = 0, alpha = +0, T = 1, w = +0 on every sample and raw2outputs gives +0 maps for both
+ * passes.  This call writes exactly those outputs for the flagged rays -- the coarse composite's (rgb0, disp0, acc0, weights0 /
+ * alpha0 rows, may be NULL) and the merged composite's (rgb_map, disp, acc, weights / alpha rows, may be NULL) -- sets their z_fine
+ * row to t_lo (so that the importance pass's danbo_bone_cull drops them on their mask; their z_sorted / sorted_idx rows are never
+ * made), and appends every OTHER ray to ray_list / *ray_count (zeroed by the caller), to be passed to danbo_view_consts,
+ * danbo_composite_importance_fwd and danbo_composite_merged_fwd.  All maps / alphas / weights of the frame are then bit-identical
+ * to evaluating every ray; a caller that wants z_fine / z_sorted / sorted_idx / cview / raw_empty of every ray, density noise, or
+ * cannot state (a) and (b), must not use it. */
+int danbo_flat_rays(const float* t_lo /*[R]*/, const uint32_t* ray_flat /*[R]*/, int R, int S, int Sf, float* rgb0, float* disp0,
+                    float* acc0, float* weights0, float* alpha0, float* z_fine, float* rgb_map, float* disp, float* acc,
+                    float* weights /*[R,S+Sf]*/, float* alpha, int32_t* ray_list /*[R]*/, int32_t* ray_count /*[1]*/, void* stream);
 
 /* merge_samples (core/raycasters.py:745-761) folded into raw2outputs of the merged samples: sample i of the sorted
  * order is read from raw_a (sorted_idx < S) or raw_b; raw_sorted (optional) receives the merged raw tensor. */
@@ -649,6 +658,8 @@ typedef struct DanboModel {
     int n_codes, code_size, L_view, ray_mode, normalise;
     float density_scale;
     int use_volume_near_far;
+    int flat_rays_ok;   /* the caller's statements (a) and (b) of danbo_flat_rays about these weights: 1 = rays that cannot meet a
+                           volume get their constants without view constants, resampling or composites; 0 = every ray is evaluated */
 } DanboModel;
 
 typedef struct DanboRays {

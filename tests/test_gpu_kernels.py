@@ -589,8 +589,8 @@ def test_render_without_resampling_of_rays_that_miss_every_volume_is_bitwise_the
     assert torch.equal(bits, c["valid_bits"]) and torch.equal(rm[3] != 0, rm[0] == 0)      # the cull confirms them all
     view = eng.view_constants(args[1], args[2], args[5])
     B = eng.cfg["density_scale"]
-    assert float(view[1][:, 3].max()) <= 0        # (the constants need an empty-space density <= 0: this network's is)
-    fr = ops_.flat_rays(view[1], rm[1], rm[3], 24, 12, B, want_weights=True)
+    assert eng.flat_rays_ok and float(view[1][:, 3].max()) <= 0      # (the constants need an empty-space density <= 0: this network's is)
+    fr = ops_.flat_rays(rm[1], rm[3], 24, 12, want_weights=True)
     n = int(fr["ray_count"].item())
     listed = torch.sort(fr["ray_list"][:n].long()).values
     flat = torch.ones(R, dtype=torch.bool, device=DEV)
@@ -607,14 +607,25 @@ def test_render_without_resampling_of_rays_that_miss_every_volume_is_bitwise_the
     out = ops_.composite_merged(c["raw_coarse"], c["raw_fine"], order, z_all, args[1], B, bits_a=bits, bits_b=bits_f, raw_empty=view[1], flat=fr)
     for k, k0 in (("rgb_map", "rgb_map"), ("disp_map", "disp_map"), ("acc_map", "acc_map"), ("alpha", "alpha"), ("weights", "T_i")):
         assert torch.equal(out[k], c[k0]), k
-    # an empty-space density > 0: no ray of constants, every ray is listed, everything takes the general path
-    pos = view[1].clone()
-    pos[:, 3] = 0.5
-    fr2 = ops_.flat_rays(pos, rm[1], rm[3], 24, 12, B, want_weights=True)
-    assert int(fr2["ray_count"].item()) == R and torch.equal(torch.sort(fr2["ray_list"].long()).values, torch.arange(R, device=DEV))
-    o2 = ops_.composite_importance(c["raw_coarse"], c["z_coarse"], args[1], 12, B, bits=bits, raw_empty=pos, flat=fr2)
-    o3 = ops_.composite_importance(c["raw_coarse"], c["z_coarse"], args[1], 12, B, bits=bits, raw_empty=pos)
-    assert all(torch.equal(o2[0][k], o3[0][k]) for k in o3[0]) and all(torch.equal(x, y) for x, y in zip(o2[1:], o3[1:]))
+    # the view constants of the listed rays alone: the same rows
+    cv, re_ = eng.view_constants(args[1], args[2], args[5], fr["ray_list"], fr["ray_count"])
+    assert torch.equal(cv[~flat], view[0][~flat]) and torch.equal(re_[~flat], view[1][~flat])
+    # weights that do not allow it (an empty-space density > 0): the engine says so, and render() evaluates every ray
+    sd = eng.p["alpha_linear.bias"]
+    old = sd.clone()
+    try:
+        sd += 5.0
+        eng.refresh()
+        assert not eng.flat_rays_ok
+        d1 = eng.render(*args, 24, 12)
+        d2 = eng.render(*args, 24, 12, keep=True)
+        for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0"):
+            assert torch.equal(d1[k], d2[k]), k
+        assert float(d1["acc_map"].min()) > 0          # (empty space is not empty any more)
+    finally:
+        sd.copy_(old)
+        eng.refresh()
+    assert eng.flat_rays_ok
     # depths outside the interval the flags were made for: the cull takes the flags back
     rm_far = ops_.ray_bone_mask(args[0], args[1], args[2], eng.align, eng.axis_scale, near + 10.0, far + 10.0, want_flat=True)
     assert int(rm_far[3].sum()) > 0

@@ -45,7 +45,9 @@ print("composite_merged, dense                     us", timeit(lambda: cm(None, 
 rm = ops.ray_bone_mask(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, out["near"], out["far"], want_flat=True)
 print("empty-space density pre-activation: min", float(raw_empty[:, 3].min()), "max", float(raw_empty[:, 3].max()),
       " rays with mask 0:", int((rm[0] == 0).sum()), " flagged:", int(rm[3].sum()))
-fr = ops.flat_rays(raw_empty, rm[1], rm[3], 48, 16, 1.0)
-print("flat_rays us", timeit(lambda: ops.flat_rays(raw_empty, rm[1], rm[3], 48, 16, 1.0)), " listed rays", int(fr["ray_count"].item()))
+fr = ops.flat_rays(rm[1], rm[3], 48, 16)
+print("flat_rays us", timeit(lambda: ops.flat_rays(rm[1], rm[3], 48, 16)), " listed rays", int(fr["ray_count"].item()))
 print("composite_importance, listed rays only us", timeit(lambda: ops.composite_importance(raw, z, inp["rays_d"], 16, 1.0, bits=bits, raw_empty=raw_empty, want_weights=False, flat=fr)))
 print("composite_merged, listed rays only     us", timeit(lambda: ops.composite_merged(raw, out["raw_fine"], out["sorted_idxs"], out["z_sorted"], inp["rays_d"], 1.0, bits_a=bits, bits_b=bits_f, raw_empty=raw_empty, flat=fr)))
+print("view constants, all rays    us", timeit(lambda: eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"])))
+print("view constants, listed rays us", timeit(lambda: eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"], fr["ray_list"], fr["ray_count"])))
