@@ -44,7 +44,7 @@ SIGNATURES = {
     "danbo_merge_samples": [P, P, P, I, I, I, I, P, P],
     "danbo_composite_importance_fwd": [P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "danbo_composite_merged_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P],
-    "danbo_flat_rays": [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "danbo_flat_rays": [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
     "danbo_anerf_encode_fwd": [P, P, P, P, I, I, I, P, P, P, F, I, c_long, I, P, P, P],
     "danbo_anerf_encode_compact": [P, P, P, P, I, I, I, P, P, P, F, c_long, I, P, P, P],
     "danbo_anerf_view_pe_fwd": [P, P, I, I, I, P, P],

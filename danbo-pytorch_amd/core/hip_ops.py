@@ -342,11 +342,13 @@ def importance_samples(z, weights, Sf, u=None):
     return zs, zf, idx
 
 
-def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False):
+def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False, rows_later=False):
     """the rays of constants (danbo_flat_rays, include/danbo_hip.h -- the caller vouches for the model's empty-space density and
     colour): allocates the outputs of BOTH fused composites, writes them for every flagged ray, and lists the other rays ->
     dict(out0=..., out=..., z_fine=..., ray_list=..., ray_count=...) for view_consts(ray_list=...),
-    composite_importance(flat=...) and composite_merged(flat=...)"""
+    composite_importance(flat=...) and composite_merged(flat=...).
+    rows_later: only the list and the per-ray outputs now; the caller runs result["rows"]() (same stream or a later one) before
+    anything reads the per-sample rows -- render() puts the view constants of the listed rays in between."""
     t_lo = _f32(t_lo, "t_lo").reshape(-1)
     R, dev = t_lo.shape[0], t_lo.device
     assert ray_flat.dtype == torch.int32 and ray_flat.shape[0] == R
@@ -356,10 +358,15 @@ def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False):
     zf = f(R, Sf)
     lst = torch.empty(R, device=dev, dtype=torch.int32)
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-    _call("danbo_flat_rays", _p(t_lo), _p(ray_flat), R, int(S), int(Sf), _p(out0["rgb_map"]), _p(out0["disp_map"]),
-          _p(out0["acc_map"]), _p(out0["weights"]), _p(out0["alpha"]), _p(zf), _p(out["rgb_map"]), _p(out["disp_map"]),
-          _p(out["acc_map"]), _p(out["weights"]), _p(out["alpha"]), _p(lst), _p(cnt), _stream())
-    return dict(out0=out0, out=out, z_fine=zf, ray_list=lst, ray_count=cnt)
+    def launch(parts):
+        _call("danbo_flat_rays", _p(t_lo), _p(ray_flat), R, int(S), int(Sf), _p(out0["rgb_map"]), _p(out0["disp_map"]),
+              _p(out0["acc_map"]), _p(out0["weights"]), _p(out0["alpha"]), _p(zf), _p(out["rgb_map"]), _p(out["disp_map"]),
+              _p(out["acc_map"]), _p(out["weights"]), _p(out["alpha"]), _p(lst), _p(cnt), parts, _stream())
+    launch(1 if rows_later else 3)
+    res = dict(out0=out0, out=out, z_fine=zf, ray_list=lst, ray_count=cnt)
+    if rows_later:
+        res["rows"] = lambda: launch(2)
+    return res
 
 
 def composite_importance(raw, z, rays_d, Sf, B=1.0, noise=None, u=None, bits=None, raw_empty=None, want_weights=True,

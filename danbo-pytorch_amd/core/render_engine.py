@@ -191,8 +191,7 @@ class DanboEngine:
                                self.code_table, ray_list, ray_count)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None,
-                        after_cull=None):
+                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
@@ -200,18 +199,13 @@ class DanboEngine:
         dense=True : every sample goes through every kernel (the reference's executed work).
         ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used.
         ray_mask: ops.ray_bone_mask() of these rays over an interval that holds every depth of z (render: [near, far]).
-        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once).
-        after_cull: called right behind the cull's launch, returns (view, event) in place of `view` / ready[1] (render(): the
-                    rays of constants and the view constants of the others, on a side stream beside the grouping and K2)."""
+        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once)."""
         self.refresh()
         geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts, ray_mask=ray_mask)
         vols = self.volumes(bones) if volumes is None else volumes
-        cview, raw_empty = (None, None) if after_cull is not None else (self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view)
+        cview, raw_empty = self.view_constants(geo.rays_d, geo.skts, cam_idx) if view is None else view
         S = geo.S
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense, cnt=count)
-        if after_cull is not None:           # render(): the view constants of the rays that are not rays of constants
-            (cview, raw_empty), ev_view = after_cull()
-            ready = None if ready is None else (ready[0], ev_view)
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
         if ready is not None:
@@ -319,73 +313,73 @@ class DanboEngine:
         fused = S <= 64 and Sf <= 64
         lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
         # lazy: nobody outside this function sees z_fine, the sorted order or the per-ray view constants.  If the weights allow it
-        # (_flat_rays_ok), the rays that cannot meet a volume -- flagged with the ray mask, confirmed by the coarse cull -- get
-        # their constants from ops.flat_rays and nothing else: no view constants, no resampling, no composite (danbo_hip.h)
+        # (_flat_rays_ok), the rays that cannot meet a volume anywhere in [near, far] -- flagged with the ray mask -- get their
+        # constants from ops.flat_rays and nothing else: no view constants, no resampling, no composite (danbo_hip.h).  The
+        # coarse depths are this function's own: near (1 - t) + far t lies in [near, far] up to a few ulps, far inside the slack
+        # the flags allow, so they need no confirmation by the cull.
         flat_mode = lazy and self.skip_flat_rays and self.flat_rays_ok
-        # The per-pose volumes (4 small launches) and the per-ray view constants depend on nothing the bounds / depths / cull chain
+        # The per-pose volumes (4 small launches) and the per-ray view constants depend on nothing the depths / cull chain
         # computes: each runs on its own side stream under that chain; the main stream waits for the volumes in front of K2 and
-        # for the view constants in front of K3.  In flat mode the view constants follow the coarse cull (they need the list of the
-        # rays that are not rays of constants) and run beside the row grouping and K2.  Inside a HIP-graph capture the chain stays
-        # linear.
+        # for the view constants in front of K3.  In flat mode the view constants follow the ray mask (they need the list of the
+        # rays that are not rays of constants) and run beside the cull.  Inside a HIP-graph capture the chain stays linear.
         use_side = rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
-        ready = vols = view = None
+        ready = vols = view = flat = None
         if use_side:
             cur = torch.cuda.current_stream()
             if self._side is None or self._side[0].device != rays_o.device:
                 self._side = (torch.cuda.Stream(device=rays_o.device), torch.cuda.Stream(device=rays_o.device))
             for side in self._side:
                 side.wait_stream(cur)
-            ev_view = None
             if not flat_mode:
                 with torch.cuda.stream(self._side[0]):
                     view = self.view_constants(rays_d, skts, cam_idx)
-                    ev_view = torch.cuda.Event()
-                    ev_view.record(self._side[0])
-                for t in view:
-                    t.record_stream(cur)
             with torch.cuda.stream(self._side[1]):
                 vols = self.volumes(bones)
                 ev_vols = torch.cuda.Event()
                 ev_vols.record(self._side[1])
             vols.record_stream(cur)
-            ready = (ev_vols, ev_view)
         near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
         z = ops.coarse_samples(near, far, S)
         # candidate bones of every ray over [near, far] (coarse and importance depths both lie inside): the two culls skip the
         # rays, and whole workgroups, that miss every volume -- most of a frame
         ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far,
                                                         want_flat=flat_mode)
-        counts = torch.zeros(2, device=rays_o.device, dtype=torch.int32)       # rows of the two passes: one fill
-        if not use_side:
-            vols = self.volumes(bones)
-            if not flat_mode:
-                view = self.view_constants(rays_d, skts, cam_idx)
-        flat = None
-
-        def after_coarse_cull():
-            nonlocal flat, view
-            if not use_side:
-                flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf)
-                view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
-                return view, None
+        if use_side:
             side = self._side[0]
-            side.wait_stream(cur)
-            for t in (ray_mask[1], ray_mask[3]):
-                t.record_stream(side)
-            with torch.cuda.stream(side):
+            if flat_mode:
+                side.wait_stream(cur)
+                for t in (ray_mask[1], ray_mask[3]):
+                    t.record_stream(side)
+                with torch.cuda.stream(side):
+                    flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, rows_later=True)
+                    view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
+                for t in list(flat["out0"].values()) + list(flat["out"].values()) + [flat[k] for k in ("z_fine", "ray_list", "ray_count")]:
+                    if t is not None:
+                        t.record_stream(cur)
+            ev_view = torch.cuda.Event()
+            ev_view.record(side)
+            for t in view:
+                t.record_stream(cur)
+            ready = (ev_vols, ev_view)
+            if flat_mode:          # the constant rows: nobody needs them before the coarse composite
+                with torch.cuda.stream(side):
+                    flat.pop("rows")()
+                    ev_rows = torch.cuda.Event()
+                    ev_rows.record(side)
+        else:
+            vols = self.volumes(bones)
+            if flat_mode:
                 flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf)
                 view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
-                ev = torch.cuda.Event()
-                ev.record(side)
-            made = list(flat["out0"].values()) + list(flat["out"].values()) + [flat[k] for k in ("z_fine", "ray_list", "ray_count")] + list(view)
-            for t in made:
-                if t is not None:
-                    t.record_stream(cur)
-            return view, ev
-
+            else:
+                view = self.view_constants(rays_d, skts, cam_idx)
+        if ray_mask is not None:
+            ray_mask = ray_mask[:3]
+        counts = torch.zeros(2, device=rays_o.device, dtype=torch.int32)       # rows of the two passes: one fill
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1],
-                                       after_cull=after_coarse_cull if flat_mode else None)
+                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1])
+        if flat_mode and use_side:
+            torch.cuda.current_stream().wait_event(ev_rows)
         if fused:
             out0, z_all, z_fine, order = ops.composite_importance(
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
@@ -395,7 +389,7 @@ class DanboEngine:
             z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf)
         raw_f, ex_f = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z_fine, dense=dense,
                                            volumes=vols, view=view, fill=not lazy,
-                                           ray_mask=None if ray_mask is None else ray_mask[:3], count=counts[1:2])
+                                           ray_mask=ray_mask, count=counts[1:2])
         out = ops.composite_merged(raw, raw_f, order, z_all, rays_d, B, bits_a=ex["valid_bits"] if lazy else None,
                                    bits_b=ex_f["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
                                    want_raw=keep, flat=flat)

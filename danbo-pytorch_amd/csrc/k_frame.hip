@@ -95,12 +95,21 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
                                  m->mean_code, r->cam_idx, m->views_w_ray_t, m->views_b_eff, m->rgb_w, m->rgb_b, m->empty_consts, 1,
                                  m->code_table, ray_list, ray_count, b.cview, b.raw_empty, stream);
     };
-    if (!flat_rays) DANBO_TRY(view_consts(nullptr, nullptr));
+    // the rays of constants (model->flat_rays_ok: flagged by the ray mask; the coarse depths are made here from the same near / far,
+    // so they lie inside the interval the flags hold for) get every output of both composites now; the view constants and the
+    // composites take the list of the others
+    const int32_t *ray_list = nullptr, *ray_count = nullptr;
+    if (flat_rays) {
+        DANBO_TRY(danbo_flat_rays(b.near, b.ray_flat, R, S, Sf, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, o->rgb_map,
+                                  o->disp_map, o->acc_map, o->weights, o->alpha, b.ray_list, b.count + 3, 3, stream));
+        ray_list = b.ray_list;
+        ray_count = b.count + 3;
+    }
+    DANBO_TRY(view_consts(ray_list, ray_count));
     // one network pass over R x s samples at depths zz -> raw (rows outside every volume stay unwritten: bits == 0)
     auto cull = [&](const float* zz, int s, uint32_t* bits, int32_t* count) -> int {
-        // (the coarse pass's cull confirms the flags of the rays of constants; the importance pass leaves them alone)
         DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.near, b.far,
-                                  flat_rays && zz == b.z ? b.ray_flat : nullptr, bits, b.list, count, stream));
+                                  nullptr, bits, b.list, count, stream));
         return danbo_group_rows(bits, b.list, count, R * s, stream);     // rows of the same bone set next to each other (k_group.hip)
     };
     auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
@@ -111,16 +120,6 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
                                   m->rgb_b, raw, nullptr, stream);
     };
     DANBO_TRY(cull(b.z, S, b.bits_a, b.count));
-    const int32_t *ray_list = nullptr, *ray_count = nullptr;
-    if (flat_rays) {
-        // the rays of constants get every output of both composites here; the view constants and the composites take the list of
-        // the others
-        DANBO_TRY(danbo_flat_rays(b.near, b.ray_flat, R, S, Sf, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, o->rgb_map,
-                                  o->disp_map, o->acc_map, o->weights, o->alpha, b.ray_list, b.count + 3, stream));
-        ray_list = b.ray_list;
-        ray_count = b.count + 3;
-        DANBO_TRY(view_consts(ray_list, ray_count));
-    }
     DANBO_TRY(network(b.z, S, b.bits_a, b.count, b.raw_a));
     DANBO_TRY(danbo_composite_importance_fwd(b.raw_a, b.raw_empty, b.bits_a, b.z, r->rays_d, R, S, Sf, m->density_scale, nullptr, nullptr,
                                              o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order, ray_list,

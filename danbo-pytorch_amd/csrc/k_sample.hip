@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_composite_importance(const float4* __re
 // interval: the importance pass's cull drops the ray on its mask), and lists all OTHER rays for k_view_consts,
 // k_composite_importance and k_composite_merged -- which then share them evenly over their wavefronts (a static split of ALL
 // rays left the wavefronts with 5 to 25 rays of work each: as slow as without the flags).  63 % of the rays of the bench frame.
-constexpr int FLAT_BLOCK = 1024;
+constexpr int FLAT_BLOCK = 256;   // (small workgroups: the launch runs beside the cull and has to fit into the wave slots that one leaves)
 __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restrict__ t_lo,
                                                           const uint32_t* __restrict__ ray_flat, int R, int S, int Sf,
                                                           float* __restrict__ rgb0, float* __restrict__ disp0, float* __restrict__ acc0,
@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restric
                                                           float* __restrict__ z_fine, float* __restrict__ rgb_map,
                                                           float* __restrict__ disp, float* __restrict__ acc_out,
                                                           float* __restrict__ weights, float* __restrict__ alpha_out,
-                                                          int32_t* __restrict__ ray_list, int32_t* __restrict__ ray_count) {
+                                                          int32_t* __restrict__ ray_list, int32_t* __restrict__ ray_count,
+                                                          int parts) {
     __shared__ int s_cnt[FLAT_BLOCK / 64];
     __shared__ int s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restric
     const int r = blockIdx.x * FLAT_BLOCK + threadIdx.x;
     const bool flat = r < R && ray_flat[r] != 0u;
     const float lo = flat ? t_lo[r] : 0.f;
-    if (flat) {     // composite_finish of five +0 sums, twice
+    if (flat && (parts & 1)) {     // composite_finish of five +0 sums, twice
         rgb0[3 * r] = 0.f; rgb0[3 * r + 1] = 0.f; rgb0[3 * r + 2] = 0.f;
         disp0[r] = 0.f;
         acc0[r] = 0.f;
@@ -1060,7 +1061,7 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restric
         acc_out[r] = 0.f;
     }
     // the rows of the wavefront's flat rays, a ray per turn
-    unsigned long long rows = __ballot(flat);
+    unsigned long long rows = (parts & 2) ? __ballot(flat) : 0ull;
     const unsigned long long listed = __ballot(r < R && !flat);
     while (rows != 0ull) {
         const int b = (int)__builtin_ctzll(rows);
@@ -1076,6 +1077,7 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restric
             if (alpha_out) alpha_out[rr * St + c] = 0.f;
         }
     }
+    if (!(parts & 1)) return;
     // the other rays, in ray order inside the workgroup: one atomic per workgroup
     if (lane == 0) s_cnt[wave] = (int)__popcll(listed);
     __syncthreads();
@@ -1261,12 +1263,13 @@ extern "C" int danbo_composite_importance_fwd(const float* raw, const float* raw
 
 extern "C" int danbo_flat_rays(const float* t_lo, const uint32_t* ray_flat, int R, int S, int Sf, float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
                                 float* rgb_map, float* disp, float* acc, float* weights, float* alpha, int32_t* ray_list,
-                                int32_t* ray_count, void* stream) {
+                                int32_t* ray_count, int parts, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64);
     DANBO_CHECK_ARG(t_lo && ray_flat && rgb0 && disp0 && acc0 && z_fine && rgb_map && disp && acc && ray_list && ray_count);
+    DANBO_CHECK_ARG(parts >= 1 && parts <= 3);
     hipLaunchKernelGGL(k_flat_rays, dim3(ceil_div(R, FLAT_BLOCK)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
                        t_lo, ray_flat, R, S, Sf, rgb0, disp0, acc0, weights0, alpha0, z_fine,
-                       rgb_map, disp, acc, weights, alpha, ray_list, ray_count);
+                       rgb_map, disp, acc, weights, alpha, ray_list, ray_count, parts);
     DANBO_LAUNCH_RET();
 }
 

@@ -315,10 +315,13 @@ int danbo_composite_importance_fwd(const float* raw /*[R,S,4]*/, const float* ra
  * made), and appends every OTHER ray to ray_list / *ray_count (zeroed by the caller), to be passed to danbo_view_consts,
  * danbo_composite_importance_fwd and danbo_composite_merged_fwd.  All maps / alphas / weights of the frame are then bit-identical
  * to evaluating every ray; a caller that wants z_fine / z_sorted / sorted_idx / cview / raw_empty of every ray, density noise, or
- * cannot state (a) and (b), must not use it. */
+ * cannot state (a) and (b), must not use it.
+ * parts: 1 = the list and the per-ray outputs (a few us: what danbo_view_consts waits for), 2 = the per-sample rows (weights0 /
+ * alpha0 / z_fine / weights / alpha: ~130 MB of a 512 x 512 frame, needed only by the composites' consumers), 3 = both. */
 int danbo_flat_rays(const float* t_lo /*[R]*/, const uint32_t* ray_flat /*[R]*/, int R, int S, int Sf, float* rgb0, float* disp0,
                     float* acc0, float* weights0, float* alpha0, float* z_fine, float* rgb_map, float* disp, float* acc,
-                    float* weights /*[R,S+Sf]*/, float* alpha, int32_t* ray_list /*[R]*/, int32_t* ray_count /*[1]*/, void* stream);
+                    float* weights /*[R,S+Sf]*/, float* alpha, int32_t* ray_list /*[R]*/, int32_t* ray_count /*[1]*/, int parts,
+                    void* stream);
 
 /* merge_samples (core/raycasters.py:745-761) folded into raw2outputs of the merged samples: sample i of the sorted
  * order is read from raw_a (sorted_idx < S) or raw_b; raw_sorted (optional) receives the merged raw tensor. */

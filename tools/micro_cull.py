@@ -26,6 +26,12 @@ print("rays", rm[0].numel(), "with a candidate bone", int((rm[0] != 0).sum()), "
 for name, z in (("coarse 48", out["z_coarse"]), ("fine 16", out["z_fine"])):
     geo_m = ops.Geometry(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, z=z, ray_mask=rm)
     print(name, " bone_cull + list with the ray mask us", round(timeit(lambda: ops.bone_cull(geo_m, True)), 1))
+    none = (torch.zeros_like(rm[0]), rm[1], rm[2])
+    geo_0 = ops.Geometry(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, z=z, ray_mask=none)
+    print(name, " every workgroup leaves early (mask 0 everywhere) us", round(timeit(lambda: ops.bone_cull(geo_0, True)), 1))
+    full = (torch.full_like(rm[0], (1 << 24) - 1), rm[1], rm[2])
+    geo_f = ops.Geometry(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, z=z, ray_mask=full)
+    print(name, " every bone a candidate of every ray us", round(timeit(lambda: ops.bone_cull(geo_f, True)), 1))
     geo = ops.Geometry(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, z=z)
     bits, lst, cnt = ops.bone_cull(geo, True)
     print(name, "rows", int(cnt.item()), "of", bits.numel(), " bone_cull + list us", round(timeit(lambda: ops.bone_cull(geo, True)), 1),
