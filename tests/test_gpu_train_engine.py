@@ -258,21 +258,33 @@ def test_train_batch_runs_fused_with_noise_and_updates_eval_weights():
 
 
 def test_graph_replays_are_repeatable():
-    """Ten replays of the captured step on the same deterministic batch: identical device counters and gradients every time.
-    (A hipMemsetAsync node inside the captured graph used to be replayed wrongly -- the counters stayed non-zero and the second
-    replay wrote out of bounds; the step now zeroes with kernels.)"""
+    """300 replays of the captured step on the same deterministic batch: identical device counters, forward outputs and (up to the
+    order of the atomics) gradients every time.  (A hipMemsetAsync node inside the captured graph used to be replayed wrongly --
+    the counters stayed non-zero and the second replay wrote out of bounds; the step now zeroes with kernels.  Round 4: about one
+    replay in 200 had one ray's colour off by 1e-3 while K2 ran beside the view-constant kernel of the prologue -- see the join
+    in front of K2 in csrc/k_train.hip; tools/stress_replay.py is the long form of this test.)"""
     g, args, caster, trainer, eng, out = fused_step("danbo_perfcap_train", graph=True)
     b = batch_of(g)
     G = b["N_uniques"]
     pp = caster._per_pose
     ref_counts, ref_grad = out["counts"].clone(), eng.flat_g.clone()
-    for _ in range(10):
+    ref_maps = {k: out[k].clone() for k in ("rgb_map", "rgb0", "acc_map", "alpha")}
+    for _ in range(300):
         out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"], G), pp(b["bones"], G), pp(b["cyls"], G), b["cam_idxs"],
                                    b["target_s"], b["bgs"], int(g["N_samples"]), int(g["N_importance"]))
         torch.cuda.synchronize()
         assert torch.equal(out["counts"], ref_counts)
+        for k, v in ref_maps.items():
+            assert torch.equal(out[k], v), k           # the forward pass has no atomics in its arithmetic
         assert torch.isfinite(eng.flat_g).all()
-        assert float((eng.flat_g - ref_grad).abs().max()) <= 1e-5 * float(ref_grad.abs().max())
+        diff = (eng.flat_g - ref_grad).abs()
+        if float(diff.max()) > 1e-5 * float(ref_grad.abs().max()):          # say WHERE before failing
+            offs = sorted(eng.offsets.items(), key=lambda kv: kv[1])
+            for (n, o), (_, o2) in zip(offs, offs[1:] + [("end", diff.numel())]):
+                if o2 > o and float(diff[o:o2].max()) > 0:
+                    print("replay", _, "differs in", n, "max", float(diff[o:o2].max()), "of", float(ref_grad[o:o2].abs().max()),
+                          "entries", int((diff[o:o2] > 0).sum()), "/", o2 - o)
+        assert float(diff.max()) <= 1e-5 * float(ref_grad.abs().max())
 
 
 def _autograd_grads(fixture, edit, model_edit=None, sampling=None):
