@@ -453,20 +453,22 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         if (pass == 0) DANBO_TRY(join(1));       // the pose volumes and the assignment net's packing
         // ... and side 0 (the trunk's packing, the view constants) HERE, not in front of the trunk where they are needed: round 4's
         // faster pose layers let K2 start while side 0 was still running, and about one step in 200 then had ONE ray's view
-        // constants wrong in 16 features (tools/stress_replay.py: 54 of 5 000 replays of one deterministic batch; 0 of 5 000 with
-        // this join, 0 of 4 000 with round 3's slow pose layers, which hid it).  Established: k_train_cview's two evaluations of the
-        // same sum from the same LDS rows disagreed inside the kernel in those steps (16 lanes = the last quarter of a
-        // wavefront, one of its eight rays), its LDS rows matched its inputs at the end of the kernel, K2 alone beside it is
-        // the trigger (not the cull, the pose layers or the packing kernels), padding K2's LDS allocation changes nothing, the
-        // same kernel reading its inputs from global memory instead of LDS does not show it, the render path (K2 beside
-        // k_view_consts, the same broadcast-read pattern) is bit-stable over 3 000 frames.  NOT established: the mechanism.  Until
-        // it is, K2 runs beside nothing in the training step -- which also is 0.7 % faster (1.628 vs 1.640 ms).
-        if (pass == 0) DANBO_TRY(join(0));
+        // constants wrong in 16 features (tools/stress_replay.py: 54 of 5 000 replays of one deterministic batch; 0 of 8 000 with
+        // this join, 0 of 4 000 with round 3's slow pose layers, which hid it).  Established: inside k_train_cview two evaluations
+        // of the same sum from the same LDS rows disagreed in those steps (the last quarter of a wavefront, one of its eight
+        // rays) while its LDS rows matched its inputs; K2 beside it is the trigger (not the cull, the pose layers or the packing
+        // kernels); the same kernel with its eight FMA chains kept scalar (no v_pk_fma_f32) does not show it under the old order
+        // (0 of 6 000 against 9 of 6 000) -- that version is the one compiled now.  Not established: why (other kernels use packed
+        // FMAs beside MFMA all the time, K3 itself does, and are bit-stable).  K2 runs beside nothing in the training step --
+        // which also is 0.7 % faster (1.628 vs 1.640 ms).  DANBO_TRAIN_LATE_JOIN=1 restores the old order for experiments.
+        static const int late_join = [] { const char* e = getenv("DANBO_TRAIN_LATE_JOIN"); return e ? atoi(e) : 0; }();   // dev: the round-3 order
+        if (pass == 0 && !late_join) DANBO_TRY(join(0));
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,
                                                     b.row_sample + R, b.cnt, pass == 0 ? nullptr : b.cnt + 1, ncap - R, b.assign16,
                                                     m->p[DANBO_T_A_B0], m->p[DANBO_T_A_B1], m->p[DANBO_T_A_W2], m->p[DANBO_T_A_B2],
                                                     b.h_rows + (size_t)R * 16, b.ticket, stream));
         NET_STAGE(22);
+        if (pass == 0 && late_join) DANBO_TRY(join(0));
         // encoding, trunk, heads, raw of the pass (and the row bookkeeping: cnt[1..7], row_ray) in ONE kernel
         return danbo_trunk_fwd(&tw, &trw, pass, stream);
     };
