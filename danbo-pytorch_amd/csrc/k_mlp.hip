@@ -149,12 +149,10 @@ __global__ __launch_bounds__(128) void k_view_code_table(const float* __restrict
     table[(size_t)c * MLP_VW + n] = acc + views_b[n];
 }
 
-// RPB rays per workgroup iteration, RPB / 2 per half-workgroup.  Each thread owns one of the 128 view-layer columns for RPB / 2
-// rays: per input i it reads ONE weight (conflict-free, lane = column) and the rays' v_i as broadcast ds_read_b128, then issues
-// RPB / 2 FMAs.  An iteration is a chain of five barriers with a global-memory round trip behind most of them (directions ->
-// pose matrix -> code row -> colour weights): 17.8 us per iteration whatever RPB is -- RPB = 64 (large batches) divides the number
-// of iterations by four (512 x 512 rays: 194 -> see DESIGN.md section 3); RPB = 16 keeps a training batch's 3 072 rays spread over
-// 192 workgroups.  Per-ray arithmetic (summation orders) does not depend on RPB.
+// RPB rays per workgroup iteration.  An iteration is a chain of five barriers with a global-memory round trip behind most of them
+// (directions -> pose matrix -> code row): 17.8 us per iteration whatever RPB is -- RPB = 64 (large batches) divides the number of
+// iterations by four; RPB = 16 keeps a training-sized batch spread over many workgroups.  The matrix product runs on 8 x 4
+// register tiles (see there).  Per-ray arithmetic (summation orders) depends on neither.
 template <int RPB>
 __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ rays_d, const float* __restrict__ skts,
                                                      int R, int G, int ray_mode, int normalise, int L_view,
@@ -169,7 +167,6 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                                                      const int32_t* __restrict__ ray_list,
                                                      const int32_t* __restrict__ ray_count,
                                                      float* __restrict__ cview, float* __restrict__ raw_empty) {
-    constexpr int NR = RPB / 2;               // rays per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Cpe = 3 * (1 + 2 * L_view);
     // with a code table the frame-code part (and the bias) is a per-camera constant: only PE(dir) is summed
@@ -187,9 +184,6 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
     for (int i = tid; i < Cv * MLP_VW; i += 256) s_w[i] = wt[i];
     for (int i = tid; i < 3 * MLP_VW; i += 256) s_rgbw[i] = rgb_w[i];
     const int rays_per_pose = R / G;
-    const int c = tid & 127, half = tid >> 7;
-    const float bias = views_b[c];
-    const float ec = empty_consts ? empty_consts[c] : 0.f;
 
     auto ray_of = [&](int i) { i = min(i, n - 1); return ray_list ? min(max(ray_list[i], 0), R - 1) : i; };
     for (int r0 = blockIdx.x * RPB; r0 < n; r0 += gridDim.x * RPB) {
@@ -239,34 +233,52 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
         }
         __syncthreads();
         // ---- cview[r][c] = sum_i W[c][256+i] v[i] + b[c]   (sequential fmaf over i) ----
-        float acc[NR];
+        // A thread owns a tile of 8 rays x 4 columns: per input i one b128 of weights (columns 4 cg .. 4 cg + 3, conflict-free) and
+        // two broadcast b128 of the rays' v_i feed 32 FMAs -- 3 LDS reads per 32 FMAs.  (Round 4's first version, one column and
+        // RPB / 2 rays per thread, read 8.25 b128 per 32 FMAs and was bound by exactly those broadcast reads: 97 us for 262 144
+        // rays, half of it the LDS pipe.)  Threads 32 rg + cg: column group cg, ray group rg (RPB / 8 groups; RPB = 16: 64 threads).
+        const int cg = tid & 31, rg = tid >> 5;
+        const bool tile_on = rg < RPB / 8;
+        float acc[8][4];
 #pragma unroll
-        for (int q = 0; q < NR; ++q) acc[q] = 0.f;
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
         // the code-table rows of this thread's rays: requested now, added after the sum
-        float trow[NR];
-        if (code_table) {
+        float4 trow[8];
+        if (code_table && tile_on) {
 #pragma unroll
-            for (int q = 0; q < NR; ++q) trow[q] = code_table[(size_t)s_row[half * NR + q] * MLP_VW + c];
+            for (int q = 0; q < 8; ++q) trow[q] = *reinterpret_cast<const float4*>(code_table + (size_t)s_row[rg * 8 + q] * MLP_VW + 4 * cg);
         }
-        const float* vp = s_v + half * NR;
+        if (tile_on) {
+            const float* vp = s_v + rg * 8;
+            const float* wp = s_w + 4 * cg;
 #pragma unroll 2
-        for (int i = 0; i < Cv; ++i) {
-            const float w = s_w[i * MLP_VW + c];
+            for (int i = 0; i < Cv; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(wp + i * MLP_VW);
+                const float4 va = *reinterpret_cast<const float4*>(vp + i * RPB);
+                const float4 vb = *reinterpret_cast<const float4*>(vp + i * RPB + 4);
+                const float v8[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-            for (int q4 = 0; q4 < NR / 4; ++q4) {
-                const float4 v = *reinterpret_cast<const float4*>(vp + i * RPB + 4 * q4);
-                acc[4 * q4] = fmaf(v.x, w, acc[4 * q4]);
-                acc[4 * q4 + 1] = fmaf(v.y, w, acc[4 * q4 + 1]);
-                acc[4 * q4 + 2] = fmaf(v.z, w, acc[4 * q4 + 2]);
-                acc[4 * q4 + 3] = fmaf(v.w, w, acc[4 * q4 + 3]);
+                for (int q = 0; q < 8; ++q) {
+                    acc[q][0] = fmaf(v8[q], w.x, acc[q][0]);
+                    acc[q][1] = fmaf(v8[q], w.y, acc[q][1]);
+                    acc[q][2] = fmaf(v8[q], w.z, acc[q][2]);
+                    acc[q][3] = fmaf(v8[q], w.w, acc[q][3]);
+                }
             }
-        }
+            const float4 b4 = *reinterpret_cast<const float4*>(views_b + 4 * cg);
+            const float4 e4 = empty_consts ? *reinterpret_cast<const float4*>(empty_consts + 4 * cg) : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < NR; ++q) {
-            const int rl = half * NR + q, r = s_ray[rl];
-            const float a = code_table ? acc[q] + trow[q] : acc[q] + bias;
-            if (r >= 0) cview[(size_t)r * MLP_VW + c] = a;
-            if (empty_consts) s_x[rl * MLP_VW + c] = fmaxf(ec + a, 0.f);
+            for (int q = 0; q < 8; ++q) {
+                const int rl = rg * 8 + q, r = s_ray[rl];
+                const float4 add = code_table ? trow[q] : b4;
+                const float4 a = make_float4(acc[q][0] + add.x, acc[q][1] + add.y, acc[q][2] + add.z, acc[q][3] + add.w);
+                if (r >= 0) *reinterpret_cast<float4*>(cview + (size_t)r * MLP_VW + 4 * cg) = a;
+                if (empty_consts)
+                    *reinterpret_cast<float4*>(s_x + rl * MLP_VW + 4 * cg) =
+                        make_float4(fmaxf(e4.x + a.x, 0.f), fmaxf(e4.y + a.y, 0.f), fmaxf(e4.z + a.z, 0.f), fmaxf(e4.w + a.w, 0.f));
+            }
         }
         if (empty_consts) {
             __syncthreads();
@@ -566,7 +578,7 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
     DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
     DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
     const int Cv = 3 * (1 + 2 * L_view) + (code_table ? 0 : Cf);
-    const int rpb = R >= 16384 ? 64 : 16;
+    const int rpb = R >= 16384 ? 64 : 16;      // (32 and 16 rays per iteration on the 512 x 512 frame: 95 and 117 us against 74)
     const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + (size_t)rpb * Cv + (size_t)rpb * MLP_VW + 3 * MLP_VW + 2 * rpb);
     DANBO_CHECK_ARG(lds <= 160 * 1024);
     const void* fn = rpb == 64 ? reinterpret_cast<const void*>(k_view_consts<64>) : reinterpret_cast<const void*>(k_view_consts<16>);
