@@ -458,9 +458,10 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         // of the same sum from the same LDS rows disagreed in those steps (the last quarter of a wavefront, one of its eight
         // rays) while its LDS rows matched its inputs; K2 beside it is the trigger (not the cull, the pose layers or the packing
         // kernels); the same kernel with its eight FMA chains kept scalar (no v_pk_fma_f32) does not show it under the old order
-        // (0 of 6 000 against 9 of 6 000) -- that version is the one compiled now.  Not established: why (other kernels use packed
-        // FMAs beside MFMA all the time, K3 itself does, and are bit-stable).  K2 runs beside nothing in the training step --
-        // which also is 0.7 % faster (1.628 vs 1.640 ms).  DANBO_TRAIN_LATE_JOIN=1 restores the old order for experiments.
+        // (0 of 6 000 against 9 of 6 000) but is four times slower (71 vs 18 us), so the packed code stays and this join is the
+        // fence.  Not established: why (other kernels use packed FMAs beside MFMA all the time, K3 itself does, and are
+        // bit-stable).  K2 runs beside nothing in the training step -- which also is 0.7 % faster (1.628 vs 1.640 ms).
+        // DANBO_TRAIN_LATE_JOIN=1 restores the old order for experiments.
         static const int late_join = [] { const char* e = getenv("DANBO_TRAIN_LATE_JOIN"); return e ? atoi(e) : 0; }();   // dev: the round-3 order
         if (pass == 0 && !late_join) DANBO_TRY(join(0));
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,

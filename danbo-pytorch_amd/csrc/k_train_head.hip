@@ -38,14 +38,12 @@ __global__ __launch_bounds__(128) void k_train_cview(const float* __restrict__ v
         for (int k = 0; k < Cv; ++k) {
             const float w = wrow[k];
 #pragma unroll
-            for (int rr = 0; rr < CV_RAYS; ++rr) {
-                acc[rr] = fmaf(s_v[rr][k], w, acc[rr]);
-                // keeps the eight chains scalar: the compiler's version of this loop (pairs of rays on v_pk_fma_f32, their LDS
-                // values shuffled into register pairs by v_mov) produced a wrong sum for one ray in the last 16 lanes of a
-                // wavefront about once in 200 training steps while K2 (MFMA) ran on the same CUs -- 9 of 6 000 replays against 0 of
-                // 6 000 with this line, everything else equal (tools/stress_replay.py, DANBO_TRAIN_LATE_JOIN=1)
-                asm volatile("" : "+v"(acc[rr]));
-            }
+            for (int rr = 0; rr < CV_RAYS; ++rr) acc[rr] = fmaf(s_v[rr][k], w, acc[rr]);
+            // (The compiler pairs these chains on v_pk_fma_f32, shuffling the LDS values into register pairs with v_mov.  That code
+            // produced a wrong sum for one ray in the last 16 lanes of a wavefront about once in 200 training steps WHILE K2 (MFMA)
+            // RAN ON THE SAME CUs; kept scalar with `asm volatile("" : "+v"(acc[rr]))` it did not -- 0 of 6 000 replays against 9 of
+            // 6 000, tools/stress_replay.py with DANBO_TRAIN_LATE_JOIN=1 -- but takes 71 instead of 18 us.  The training step now
+            // orders this kernel in front of K2 (csrc/k_train.hip), where the packed code is bit-stable: 0 of 8 000 replays.)
         }
 #pragma unroll
         for (int rr = 0; rr < CV_RAYS; ++rr)
