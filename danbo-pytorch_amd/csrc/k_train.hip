@@ -411,8 +411,11 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     }
     auto join = [&](int i) -> int { return guard.join(i); };
     const float* axis_scale = m->p[DANBO_T_AXIS_SCALE];
-    // Enqueue order = the order the captured graph submits its nodes in: the caller's stream first (it carries the critical
-    // path: bounds -> depths -> cull -> assignment net), then side 1 (needed by the assignment net), then side 0 (needed by the trunk).
+    // Enqueue order = the order the captured graph submits its nodes in: the caller's stream first (bounds -> depths -> cull), then
+    // side 0 (trunk packing -> view inputs -> view constants: the longest chain), then side 1 (adjacency products -> assignment
+    // packing -> pose GNN).  Round 4's timeline (tools/timeline_train.sh): with side 1 enqueued first, side 0's first kernel started
+    // only when side 1's last one had ended (129 us into the step) and K2 at 187; in this order all three run side by side and K2
+    // starts at 137.
     // ---- bounds, depths (reference raycasters.py:310-311), coarse cull
     DANBO_TRY(danbo_near_far_cylinder(bt->rays_o, bt->rays_d, bt->cyls, R, G, 0.f, 1.f, bt->near_in, bt->far_in, bt->chunk, b.cyl_scratch,
                                       b.near, b.far, stream));
@@ -422,6 +425,10 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_TRY(danbo_bone_cull(bt->rays_o, bt->rays_d, b.z_c, nullptr, R, S, G, bt->skts, m->align, axis_scale, nullptr, nullptr, nullptr, nullptr, b.bits_c,
                               b.row_sample + R, b.cnt,
                               stream));
+    DANBO_TRY(danbo_trunk_pack(&tw, s0));
+    DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
+                                      m->code_size, bt->cam_idx, b.vin, LD_VIN, s0));
+    DANBO_TRY(danbo_train_cview(b.vin, LD_VIN, m->view_ch, m->p[DANBO_T_VIEWS_W], b.b_eff, R, b.cview, s0));
     hipLaunchKernelGGL(k_train_small, dim3(1), dim3(256), 0, (hipStream_t)s1, m->p[DANBO_T_G_ADJW0], m->g_adj0, m->p[DANBO_T_G_ADJW1], m->g_adj1,
                        m->p[DANBO_T_A_ADJW], m->a_adj, b.adj_prod, m->p[DANBO_T_AXIS_SCALE], m->init_scale, m->vol_scale_penalty,
                        m->g[DANBO_T_AXIS_SCALE], b.loss);
@@ -432,10 +439,6 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_TRY(danbo_pose_volumes_fwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], adjw0, m->p[DANBO_T_G_B0],
                                      m->p[DANBO_T_G_W1], adjw1, m->p[DANBO_T_G_B1], m->p[DANBO_T_G_W2], m->p[DANBO_T_G_B2],
                                      m->p[DANBO_T_G_W3], m->p[DANBO_T_G_B3], b.vol_scratch, b.volumes, s1));
-    DANBO_TRY(danbo_trunk_pack(&tw, s0));
-    DANBO_TRY(danbo_train_view_inputs(bt->rays_d, bt->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->p[DANBO_T_CODES], m->n_codes,
-                                      m->code_size, bt->cam_idx, b.vin, LD_VIN, s0));
-    DANBO_TRY(danbo_train_cview(b.vin, LD_VIN, m->view_ch, m->p[DANBO_T_VIEWS_W], b.b_eff, R, b.cview, s0));
     DANBO_STAGE(2);
 
     // ---- one network pass over the compacted rows
