@@ -31,8 +31,9 @@ class DanboEngine:
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
-        # re-order the compacted rows by bone set in front of K2 (k_group.hip); False: the cull kernel's order (profiling, tests)
-        self.group_rows = True
+        # True: re-order the compacted rows by bone set in front of K2 (k_group.hip).  Off since the end of round 4: K2 gains 2 x 20 us
+        # from it, the grouping costs 2 x 27 us and scatters K3's rows (tools/ab_group_rows.py: 4.734 ms with, 4.712 ms without)
+        self.group_rows = False
 
     # ------------------------------------------------------------------ derived buffers
     def _key(self):

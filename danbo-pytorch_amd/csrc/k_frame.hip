@@ -110,7 +110,9 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     auto cull = [&](const float* zz, int s, uint32_t* bits, int32_t* count) -> int {
         DANBO_TRY(danbo_bone_cull(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.ray_mask, b.near, b.far,
                                   nullptr, bits, b.list, count, stream));
-        return danbo_group_rows(bits, b.list, count, R * s, stream);     // rows of the same bone set next to each other (k_group.hip)
+        // (danbo_group_rows -- rows of the same bone set next to each other -- is not part of the chain any more: it costs what it
+        // saves in K2 and scatters K3's rows; core/render_engine.py: group_rows)
+        return 0;
     };
     auto network = [&](const float* zz, int s, uint32_t* bits, int32_t* count, float* raw) -> int {
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,

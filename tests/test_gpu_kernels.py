@@ -545,13 +545,13 @@ def test_render_is_bitwise_independent_of_the_row_order(stage):
     ro = np.concatenate([scene["rays"][0][0], scene["rays"][1][0]])
     rd = np.concatenate([scene["rays"][0][1], scene["rays"][1][1]])
     args = (T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(scene["cyls"]), torch.zeros(len(ro), dtype=torch.int64, device=DEV))
-    assert eng.group_rows is True
-    a = eng.render(*args, 24, 12, keep=True)
-    eng.group_rows = False
+    assert eng.group_rows is False
+    b = eng.render(*args, 24, 12, keep=True)
+    eng.group_rows = True
     try:
-        b = eng.render(*args, 24, 12, keep=True)
+        a = eng.render(*args, 24, 12, keep=True)
     finally:
-        eng.group_rows = True
+        eng.group_rows = False
     assert int(a["count_coarse"].item()) == int(b["count_coarse"].item()) > 20000      # more than one window of 16 384 rows
     for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "alpha0", "raw_coarse", "raw_fine", "z_fine"):
         assert torch.equal(a[k], b[k]), k
