@@ -29,8 +29,17 @@ def popcount(x):
     return c
 
 
-def stats(name, bits_rows):
+def stats(name, bits_rows, group=32):
     n = bits_rows.shape[0]
+    if group != 32:        # evaluated (row, bone) slots per valid pair if a wavefront served `group` rows instead of 32
+        pad = (-n) % group
+        bg = torch.cat([bits_rows, bits_rows.new_zeros(pad)]).view(-1, group)
+        g = torch.zeros(bg.shape[0], dtype=torch.int64, device=dev)
+        for k in range(group):
+            g |= bg[:, k]
+        print(f"{name:42s} groups of {group} rows: bones per group {popcount(g).float().mean():.2f}, evaluated slots / valid pairs = "
+              f"{popcount(g).sum().item() * group / popcount(bits_rows).sum().item():.2f}")
+        return
     pad = (-n) % 32
     b = torch.cat([bits_rows, bits_rows.new_zeros(pad)]).view(-1, 32)
     gnn = torch.zeros(b.shape[0], dtype=torch.int64, device=dev)
@@ -60,6 +69,8 @@ for S, Sf, box in ((48, 16, False),):
         b = bits[rows].long() & 0xFFFFFF
         print(f"--- {S}+{Sf} box={box} {tag}")
         stats("cull order (as launched)", b)
+        for grp in (16, 8):
+            stats("cull order (as launched)", b, group=grp)
         stats("ray-major (sorted sample index)", bits[torch.sort(rows).values].long() & 0xFFFFFF)
         low = torch.full_like(b, 24)
         for j in reversed(range(24)):
