@@ -107,11 +107,12 @@ struct A16Args {
     const int32_t* first;   // device scalar: rows [*first, count) of list / h_out / confd are processed, or nullptr (0)
     long long* trace;       // dev tool (tools/micro_assign.py --trace): s_memtime stamps of one wavefront, or nullptr
     unsigned* ticket;       // device word, 0 at launch, 0 again when the launch has finished: the next 128-row tile to hand out
+    int no_skip;            // dev (DANBO_A16_NOSKIP=1): evaluate every neighbour pair
 };
 
 // per bone: neighbours (self first), number of layer-0 terms, first 1-KB piece of the packed stream
 constexpr int A16_NBI = 8;        // ints per bone: nb[0..4], nq = deg + 1, piece0, pad
-constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16 + J * A16_NBI + J * 4;
+constexpr int A16_TABLE_FLOATS = 32 + J * 32 + J * 32 + J + J * 16 + J * 4 + 8 /*pad*/ + J * VOL + J * 16 + J * A16_NBI + J * 4 + J;
 constexpr int A16_LDS_BYTES = (A16_TABLE_FLOATS * 4 + 15) & ~15;
 constexpr int A16_TICKETS_AHEAD = 4;   // draws of a workgroup that come back without a tile: the one that ends it + three in its pipeline
 
@@ -127,18 +128,23 @@ constexpr int A16_TICKETS_AHEAD = 4;   // draws of a workgroup that come back wi
 // interpolation weights of each axis (one multiply + one fma per feature, unconditional clamped reads).
 // The LDS (staged pose) and the global (another pose inside the tile) route run THIS code: a row's result does not depend on
 // which one it takes.  abs_scale: [4] = |scale_x|, |scale_y|, |scale_z|, -; inv_scale likewise.
-template <typename VolPtr>
-__device__ __forceinline__ void a16_bone_features(const float* __restrict__ skt, const float* __restrict__ align, VolPtr vol,
-                                                  const float* __restrict__ abs_scale, const float* __restrict__ inv_scale,
-                                                  const float* pnt, float* out) {
-    float pt[3], x[3];
+// (in two parts: the coordinates x and the window -- 80 of the instructions -- and the gather; K2 looks at the window of a
+// neighbour bone before it pays for that bone's gather)
+__device__ __forceinline__ float a16_bone_coords(const float* __restrict__ skt, const float* __restrict__ align,
+                                                 const float* __restrict__ abs_scale, const float* __restrict__ inv_scale,
+                                                 const float* pnt, float* x) {
+    float pt[3];
     bone_local(skt, align, pnt, pt);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float q = mul_rn(pt[k], inv_scale[k]);
         x[k] = fmaf(fmaf(-q, abs_scale[k], pt[k]), inv_scale[k], q);
     }
-    const float win = coord_window(x);
+    return coord_window(x);
+}
+
+template <typename VolPtr>
+__device__ __forceinline__ void a16_bone_gather(VolPtr vol, const float* x, float win, float* out) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float iy = mul_rn(sub_rn(mul_rn(add_rn(x[k], 1.0f), (float)VRES), 1.0f), 0.5f);
@@ -153,6 +159,15 @@ __device__ __forceinline__ void a16_bone_features(const float* __restrict__ skt,
 #pragma unroll
         for (int f = 0; f < VOXF; ++f) out[f * 3 + k] = fmaf(vol[f * (VRES * 3) + c1], a1, mul_rn(vol[f * (VRES * 3) + c0], a0));
     }
+}
+
+template <typename VolPtr>
+__device__ __forceinline__ void a16_bone_features(const float* __restrict__ skt, const float* __restrict__ align, VolPtr vol,
+                                                  const float* __restrict__ abs_scale, const float* __restrict__ inv_scale,
+                                                  const float* pnt, float* out) {
+    float x[3];
+    const float win = a16_bone_coords(skt, align, abs_scale, inv_scale, pnt, x);
+    a16_bone_gather(vol, x, win, out);
 }
 
 __device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo) {
@@ -188,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
     float* s_skt = s_vol + J * VOL;                                        // [24][16]  its bone transforms
     int* s_nbi = reinterpret_cast<int*>(s_skt + J * 16);                   // [24][8]
     float* s_inv = reinterpret_cast<float*>(s_nbi + J * A16_NBI);          // [24][4] RN(1 / |scale|)
+    float* s_vmax = s_inv + J * 4;                                         // [24] largest |entry| of the staged pose's volume of each bone
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hh = lane >> 5;
@@ -336,6 +352,19 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             for (int i = tid; i < J * 16; i += 256) s_skt[i] = a.skts[(size_t)g_tile * J * 16 + i];
             g_lds = g_tile;
             __syncthreads();
+            if (tid < J * 8) {          // eight threads per bone: max |v| over its 240 entries
+                float mx = 0.f;
+                for (int i = tid & 7; i < VOL; i += 8) mx = fmaxf(mx, fabsf(s_vol[(tid >> 3) * VOL + i]));
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+                // (a NaN entry would be dropped by fmaxf: such a bone is never skipped)
+                float bad = 0.f;
+                for (int i = tid & 7; i < VOL; i += 8) bad += s_vol[(tid >> 3) * VOL + i] != s_vol[(tid >> 3) * VOL + i] ? 1.f : 0.f;
+                bad += __shfl_xor(bad, 1, 64); bad += __shfl_xor(bad, 2, 64); bad += __shfl_xor(bad, 4, 64);
+                if ((tid & 7) == 0) s_vmax[tid >> 3] = bad > 0.f ? INFINITY : mx;
+            }
+            __syncthreads();
         }
         // stage 2 of the NEXT tile (its list entry was requested a tile ago) and stage 1 of the one after
         TileIn nxt;
@@ -374,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             // gather_bone_features() as K1b), then the halves trade 8 values so that lane (m, h) ends up with features
             // 8h .. 8h+7 of BOTH bones: the B-fragment layout.
             half8 fh[6], fl[6];
+            bool pair_off[3] = {false, false, false};
             float fself[8];         // this lane's 8 features of the bone ITSELF in fp32: the blend h = sum_j p_j f_j uses these, not the
                                     // 22-bit hi + lo reconstruction (2.4e-7 of f, which sin(32 h) turns into 8e-6 of the MLP's inputs)
 #pragma unroll
@@ -382,9 +412,27 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
                 const int qm = 2 * t + hh < nq ? 2 * t + hh : nq - 1;       // (an odd count: the last half repeats a neighbour, unused)
                 const int jb = s_nbi[j * A16_NBI + qm];
                 float f[16];
-                if (g == g_lds) {
-                    a16_bone_features(s_skt + 16 * jb, s_align + 16 * jb, s_vol + jb * VOL, s_scale + 4 * jb, s_inv + 4 * jb, pnt, f);
-                } else {  // a row of another pose inside this tile (multi-pose chunks only): through L1 / L2
+                const bool lds_route = g == g_lds;      // (else: a row of another pose inside this tile -- multi-pose chunks only)
+                float x[3] = {0.f, 0.f, 0.f}, win = 0.f;
+                bool needed = true;
+                if (lds_route) {
+                    win = a16_bone_coords(s_skt + 16 * jb, s_align + 16 * jb, s_scale + 4 * jb, s_inv + 4 * jb, pnt, x);
+                    // A neighbour's features enter layer 0 as fp16 hi + lo pairs: a feature below 2^-25 is (0, 0) there.  Every feature
+                    // of a bone is at most (largest |entry| of its volume) x window, so where that product is below 2^-26 for EVERY
+                    // row whose logit of bone j is used (rows valid in j; all rows when the caller wants confd), both neighbours of
+                    // this pair contribute exact zeros to the matrix products: no gather, no MFMAs -- the accumulators (which start at
+                    // the bias) come out bit for bit the same.  A sample inside the forearm is beyond that distance of the upper arm
+                    // unless it is near the elbow.
+                    const bool used = row_ok && (a.confd != nullptr || ((bits >> j) & 1u) != 0u);
+                    needed = used && !(mul_rn(win, s_vmax[jb]) < 0x1p-26f);
+                }
+                if (t >= 1 && !a.no_skip && !__any(needed)) {         // wave-uniform
+                    pair_off[t] = true;
+                    continue;
+                }
+                if (lds_route) {
+                    a16_bone_gather(s_vol + jb * VOL, x, win, f);
+                } else {  // through L1 / L2
                     float sk[12];
                     const float* srcp = a.skts + ((size_t)g * J + jb) * 16;
 #pragma unroll
@@ -422,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             }
 #pragma unroll
             for (int q = 0; q < 5; ++q)
-                if (q < nq) {
+                if (q < nq && !pair_off[q >> 1]) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q], fh[q], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q], fl[q], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q + 1], fh[q], acc, 0, 0, 0);
@@ -487,6 +535,10 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
 using namespace danbo;
 
 static long long* g_a16_trace = nullptr;
+static int a16_no_skip() {
+    static const int v = [] { const char* e = getenv("DANBO_A16_NOSKIP"); return e ? atoi(e) : 0; }();
+    return v;
+}
 /* dev tool: a buffer of 256 int64 that receives (tag, s_memtime) stamps of one wavefront of k_assign16 (tags: 0 tile start, 1 inputs
  * and bone masks ready, 2 features done, 100 + j before / 200 + j after the wait for bone j's weights, 3 all bones done); NULL: off */
 extern "C" int danbo_assign16_set_trace(void* buf) {
@@ -512,7 +564,7 @@ extern "C" int danbo_gather_assign_blend16_fwd(const float* rays_o, const float*
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, pts, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr, g_a16_trace, ticket};
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, confd, nullptr, g_a16_trace, ticket, a16_no_skip()};
     DANBO_ENSURE_LDS(k_assign16<false>, A16_LDS_BYTES);
     const int ntiles = ceil_div(n, A16_BM);
     const int grid = ntiles < 2 * num_cu() ? ntiles : 2 * num_cu();      // two workgroups per CU (launch bounds)
@@ -529,7 +581,7 @@ extern "C" int danbo_gather_assign_blend16_train(const float* rays_o, const floa
     DANBO_CHECK_ARG(n >= 0 && valid_bits && h && packed16 && list && count && z && ticket && R > 0 && S > 0 && G > 0 && R % G == 0);
     if (n == 0) return 0;
     A16Args a = {rays_o, rays_d, z, nullptr, R, S, G, skts, align, axis_scale, volumes, valid_bits, list, count, n,
-                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first, nullptr, ticket};
+                 reinterpret_cast<const char*>(packed16), b0, b1, w2, b2, h, nullptr, first, nullptr, ticket, a16_no_skip()};
     DANBO_ENSURE_LDS(k_assign16<true>, A16_LDS_BYTES);
     const int ntiles = ceil_div(n, A16_BM);
     const int grid = ntiles < 2 * num_cu() ? ntiles : 2 * num_cu();
