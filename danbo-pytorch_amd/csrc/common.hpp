@@ -40,6 +40,7 @@ static inline int num_cu() {
     int n = c.load(std::memory_order_relaxed);
     if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (const char* e = getenv("DANBO_NUM_CU")) { const int v = atoi(e); if (v > 0 && v <= n) n = v; }   // dev: size the grids for a CU-masked stream
         c.store(n, std::memory_order_relaxed);
     }
     return n;
