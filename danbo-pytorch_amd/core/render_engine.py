@@ -210,13 +210,16 @@ class DanboEngine:
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
         if ready is not None:
+            # the volumes (K2 reads them) AND the view constants (K3 does): K2 does not start beside the view-constant kernel.  It
+            # costs nothing -- that kernel ends before the cull does -- and in the training step K2 beside the view-constant
+            # kernel of that path was the one combination that produced a wrong sum once in 200 steps; this
+            # path never showed it (tools/stress_render.py: 3 000 bit-identical frames with the overlap allowed)
             torch.cuda.current_stream().wait_event(ready[0])
+            torch.cuda.current_stream().wait_event(ready[1])
         if self.mlp_mode == "f16split":
             h, confd = ops.gather_assign_blend16(geo, vols, bits, self.aw, self.assign16, lst, cnt, geo.M, want_confd)
         else:
             h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
-        if ready is not None:
-            torch.cuda.current_stream().wait_event(ready[1])
         # fill=False: rows outside every volume stay unwritten; the consumer reads raw_empty for them (valid_bits == 0)
         raw = ops.fill_raw(raw_empty, S) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
         if self.profile is not None:
