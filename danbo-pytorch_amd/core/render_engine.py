@@ -27,6 +27,7 @@ class DanboEngine:
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
         self._side = None            # side streams of render()
+        self.k2_waits_for_view = False   # see forward_samples
         self.skip_flat_rays = True   # render(): no resampling for rays that cannot meet a volume (tests switch it off to compare)
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
@@ -210,16 +211,19 @@ class DanboEngine:
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
         if ready is not None:
-            # the volumes (K2 reads them) AND the view constants (K3 does): K2 does not start beside the view-constant kernel.  It
-            # costs nothing -- that kernel ends before the cull does -- and in the training step K2 beside the view-constant
-            # kernel of that path was the one combination that produced a wrong sum once in 200 steps; this
-            # path never showed it (tools/stress_render.py: 3 000 bit-identical frames with the overlap allowed)
+            # the volumes (K2 reads them); the view constants (K3 reads them) are waited for behind K2.  k2_waits_for_view = True
+            # orders K2 behind the view-constant kernel as well (~30 us per frame): in the TRAINING step K2 beside that path's
+            # view-constant kernel was the one combination that produced a wrong sum once in 200 steps; here
+            # the two do overlap (flat mode, ~30 us per frame) and 6 000 frames are bit-identical (tools/stress_render.py --overlap)
             torch.cuda.current_stream().wait_event(ready[0])
-            torch.cuda.current_stream().wait_event(ready[1])
+            if self.k2_waits_for_view:
+                torch.cuda.current_stream().wait_event(ready[1])
         if self.mlp_mode == "f16split":
             h, confd = ops.gather_assign_blend16(geo, vols, bits, self.aw, self.assign16, lst, cnt, geo.M, want_confd)
         else:
             h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
+        if ready is not None and not self.k2_waits_for_view:
+            torch.cuda.current_stream().wait_event(ready[1])
         # fill=False: rows outside every volume stay unwritten; the consumer reads raw_empty for them (valid_bits == 0)
         raw = ops.fill_raw(raw_empty, S) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
         if self.profile is not None:
