@@ -948,8 +948,136 @@ __global__ __launch_bounds__(256) void k_importance_wave(const float* __restrict
     }
 }
 
-// coarse composite + importance resampling of a ray in one pass (S, Sf <= 64): the weights never leave the
-// wavefront's registers unless the caller asks for them
+// 64 < S <= 256, Sf <= 64 (config 3: 96 + 32): one wavefront per ray, the coarse samples in chunks of 64, depths / weights / cdf
+// in 3 KB of LDS per wavefront.  (These shapes used to take k_importance's thread-per-ray walk: 2.85 ms of config 3's 11.7 ms
+// frame.)  Same arithmetic as importance_wave: pdf, total and cdf by DPP scans (chunk after chunk, the carry added per chunk),
+// inverse CDF and ranks by binary searches -- in LDS instead of shuffles.
+constexpr int IMPB_MAX_S = 256;
+template <bool DET>
+__global__ __launch_bounds__(256) void k_importance_wave_long(const float* __restrict__ z, const float* __restrict__ weights,
+                                                              int R, int S, int Sf, const float* __restrict__ u,
+                                                              float* __restrict__ z_fine, float* __restrict__ z_sorted,
+                                                              int32_t* __restrict__ sorted_idx, unsigned scatter) {
+    __shared__ float s_all[4][3 * IMPB_MAX_S + 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* s_z = s_all[wv];                   // [S] coarse depths
+    float* s_w = s_z + IMPB_MAX_S;            // [S] weights, then [S - 1] the cdf
+    float* s_b = s_w + IMPB_MAX_S;            // [S - 1] mid-points
+    float* s_f = s_b + IMPB_MAX_S;            // [64] importance depths
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nb = S - 2, ncdf = S - 1;
+    const int nchunk = (S + 63) >> 6;
+    for (int i = wave; i < R; i += nwaves) {
+        const int r = scattered_ray(i, scatter, R);
+        const size_t o = (size_t)r * S;
+        for (int c = 0; c < nchunk; ++c) {
+            const int s0 = 64 * c + lane;
+            if (s0 < S) { s_z[s0] = z[o + s0]; s_w[s0] = weights[o + s0]; }
+        }
+        // (one wavefront: its LDS writes are complete before its next LDS reads -- the compiler's lgkmcnt waits)
+        float sum = 0.f;
+        float dwv[IMPB_MAX_S / 64];
+        bool asc = true;
+#pragma unroll
+        for (int c = 0; c < IMPB_MAX_S / 64; ++c) {
+            const int s0 = 64 * c + lane;
+            float dw = 0.f;
+            if (c < nchunk && s0 < nb) {
+                const float w0 = s_w[s0], w1 = s_w[s0 + 1], w2 = s_w[s0 + 2];
+                dw = add_rn(add_rn(mul_rn(0.5f, add_rn(fmaxf(w0, w1), fmaxf(w1, w2))), 0.01f), 1e-5f);
+            }
+            dwv[c] = dw;
+            if (c < nchunk) {
+                sum = add_rn(sum, wave_total(dw));
+                if (s0 + 1 < S) {
+                    const float z0 = s_z[s0], z1 = s_z[s0 + 1];
+                    s_b[s0] = mul_rn(0.5f, add_rn(z1, z0));
+                    asc = asc && z1 >= z0;
+                }
+            }
+        }
+        const bool ascending = __all(asc);
+        float carry = 0.f;
+#pragma unroll
+        for (int c = 0; c < IMPB_MAX_S / 64; ++c) {
+            if (c < nchunk) {
+                const int s0 = 64 * c + lane;
+                const float inc = add_rn(carry, wave_scan_add(div_rn(dwv[c], sum)));     // cdf[s0 + 1]
+                if (s0 < nb) s_w[s0 + 1] = inc;
+                carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 63));
+            }
+        }
+        if (lane == 0) s_w[0] = 0.f;
+        // ---- inverse CDF for fine sample `lane` ----
+        const bool fact = lane < Sf;
+        const float uk = DET ? linspace01(fact ? lane : 0, Sf) : (fact ? u[(size_t)r * Sf + lane] : 0.f);
+        int lo = 0, hi = ncdf;  // searchsorted(cdf, u, right=True)
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const float cm = s_w[mid < ncdf ? mid : ncdf - 1];
+            if (lo < hi) {
+                if (cm > uk) hi = mid; else lo = mid + 1;
+            }
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < ncdf - 1 ? lo : ncdf - 1;
+        const float c0 = s_w[below], c1 = s_w[above];
+        const float b0 = s_b[below], b1 = s_b[above];
+        float denom = sub_rn(c1, c0);
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = div_rn(sub_rn(uk, c0), denom);
+        const float zf = fact ? add_rn(b0, mul_rn(t, sub_rn(b1, b0))) : INFINITY;
+        if (fact) z_fine[(size_t)r * Sf + lane] = zf;
+        s_f[lane] = zf;
+        // ---- merged order by rank (stable: coarse first on ties, fine by index) ----
+        const size_t oo = (size_t)r * (S + Sf);
+        if (DET && ascending) {
+            // both sequences are non-decreasing: #coarse <= zf and #fine < z_i by binary search
+            int l1 = 0, h1 = S;
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                const int m1 = (l1 + h1) >> 1;
+                const float cz = s_z[m1 < S ? m1 : S - 1];
+                if (l1 < h1) { if (cz <= zf) l1 = m1 + 1; else h1 = m1; }
+            }
+            if (fact) { z_sorted[oo + lane + l1] = zf; sorted_idx[oo + lane + l1] = S + lane; }
+            for (int c = 0; c < nchunk; ++c) {
+                const int s0 = 64 * c + lane;
+                const float zi = s_z[s0 < S ? s0 : S - 1];
+                int l0 = 0, h0 = Sf;
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {
+                    const int m0 = (l0 + h0) >> 1;
+                    const float fz = s_f[m0 < 63 ? m0 : 63];
+                    if (l0 < h0) { if (fz < zi) l0 = m0 + 1; else h0 = m0; }
+                }
+                if (s0 < S) { z_sorted[oo + s0 + l0] = zi; sorted_idx[oo + s0 + l0] = s0; }
+            }
+        } else {
+            // general case: rank = number of predecessors in (value, coarse-before-fine, index) order
+            int rank_f = 0;
+            for (int k = 0; k < Sf; ++k) {
+                const float zk = s_f[k];
+                rank_f += (zk < zf) || (zk == zf && k < lane);
+            }
+            for (int q = 0; q < S; ++q) rank_f += s_z[q] <= zf;
+            if (fact) { z_sorted[oo + rank_f] = zf; sorted_idx[oo + rank_f] = S + lane; }
+            for (int c = 0; c < nchunk; ++c) {
+                const int s0 = 64 * c + lane;
+                const float zi = s_z[s0 < S ? s0 : S - 1];
+                int rank_c = 0;
+                for (int k = 0; k < Sf; ++k) rank_c += s_f[k] < zi;
+                if (ascending) rank_c += s0;
+                else
+                    for (int q = 0; q < S; ++q) { const float zq = s_z[q]; rank_c += (zq < zi) || (zq == zi && q < s0); }
+                if (s0 < S) { z_sorted[oo + rank_c] = zi; sorted_idx[oo + rank_c] = s0; }
+            }
+        }
+    }
+}
+
 // coarse composite + importance resampling of a ray in one pass (S, Sf <= 64): the weights never leave the
 // wavefront's registers unless the caller asks for them.  Item i of the launch is the i-th listed ray (ray_list / ray_count:
 // k_flat_rays' list of the rays that are NOT rays of constants) or, without a list, ray scattered_ray(i).
@@ -1229,6 +1357,14 @@ extern "C" int danbo_importance_samples(const float* z, const float* weights, in
         else
             hipLaunchKernelGGL(k_importance_wave<true>, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0,
                                (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx);
+    } else if (S <= IMPB_MAX_S && Sf <= 64) {
+        const dim3 grid(stream_grid((long)R * 64, 256));
+        if (u)
+            hipLaunchKernelGGL(k_importance_wave_long<false>, grid, dim3(256), 0, (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine,
+                               z_sorted, sorted_idx, ray_scatter(R));
+        else
+            hipLaunchKernelGGL(k_importance_wave_long<true>, grid, dim3(256), 0, (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine,
+                               z_sorted, sorted_idx, ray_scatter(R));
     } else {
         hipLaunchKernelGGL(k_importance, dim3(stream_grid(R, 64)), dim3(64), 0, (hipStream_t)stream, z, weights, R, S, Sf,
                            u, z_fine, z_sorted, sorted_idx);

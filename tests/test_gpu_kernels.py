@@ -289,9 +289,10 @@ def test_importance_samples_and_merge(ops, stage):
     assert np.array_equal(N(m), want)
 
 
-@pytest.mark.parametrize("S,Sf", [(48, 16), (32, 16), (96, 48), (7, 3)])
+@pytest.mark.parametrize("S,Sf", [(48, 16), (32, 16), (96, 48), (7, 3), (200, 64), (272, 24), (80, 72)])
 def test_importance_random_uniforms_and_long_rays(ops, S, Sf):
-    """wave-per-ray kernel (S <= 64) and the per-thread fallback, deterministic and random u"""
+    """wave-per-ray kernel (S <= 64), its long-ray form (64 < S <= 256, Sf <= 64: chunks of 64 through LDS) and the per-thread
+    fallback (S > 256 or Sf > 64), deterministic and random u"""
     rng = np.random.default_rng(S)
     R = 200
     z = np.sort(rng.uniform(2, 5, size=(R, S)).astype(np.float32), -1)
@@ -439,7 +440,7 @@ def test_render_lazy_fill_equals_filled(ops, stage):
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("S,Sf", [(16, 8), (48, 16), (96, 32)])
+@pytest.mark.parametrize("S,Sf", [(16, 8), (48, 16), (96, 32), (130, 64), (260, 16)])
 def test_importance_with_descending_and_mixed_depth_order(ops, S, Sf):
     """a ray looking away from the body has its far bound before its near bound: descending coarse depths.  The merged
     order must still be the stable sort of cat([z, z_fine]) (torch.sort in the reference), for the wavefront kernel,
