@@ -260,6 +260,11 @@ def timed(fn, steps, warmup, dist, device, cpu_dist, settle_block=10, on_timed_s
     return med, out, info
 
 
+def ops_mod():
+    from core import hip_ops
+    return hip_ops
+
+
 # ---------------------------------------------------------------------------------------------- render configs 1-3
 def bench_render(args, rank, world, device, dist):
     eng, inp, extra = build_workload(device, view=rank, mlp_mode=args.mlp)
@@ -294,6 +299,13 @@ def bench_render(args, rank, world, device, dist):
                       chunk=4096, keep=True)
     rays_hit = int((keep["valid_bits"].view(H * W, N_SAMPLES) != 0).any(1).sum())
     algo_bytes = 84.0 * rows / len(prof) + 512.0 * rays_hit
+    # what the exact sparsity of the frame amounts to (untimed): rays that cannot meet a bone volume between their bounds are rays of
+    # constants when the weights allow it (include/danbo_hip.h: danbo_flat_rays) -- no view constants, resampling or composite for them
+    rm = ops_mod().ray_bone_mask(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, keep["near"], keep["far"], want_flat=True)
+    sparsity = dict(rays=H * W, rays_with_a_candidate_bone=int((rm[0] != 0).sum()), rays_with_an_in_volume_coarse_sample=rays_hit,
+                    rays_of_constants=int(rm[3].sum()) if (eng.flat_rays_ok and eng.skip_flat_rays and N_SAMPLES <= 64 and N_IMPORTANCE <= 64) else 0,
+                    note="every output of the timed frame is compared bitwise with the render that evaluates every sample of every ray "
+                         "(dense_equals_culled)")
     keep = dict(raw_coarse=keep["raw_coarse"], valid_bits=keep["valid_bits"])         # for the parity block below
     roofline = dict(bound="mfma", kernel=kernel, achieved=achieved / 1e12, peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak,
                     traffic=traffic, algorithmic_bytes=algo_bytes, launches=len(prof), avg_launch_ms=ms / len(prof),
@@ -311,7 +323,7 @@ def bench_render(args, rank, world, device, dist):
                                f"samples, 1 pose / 1 camera per rank, {'per-bone box' if args.box_near_far else 'cylinder'} near/far, "
                                "exact in-volume culling",
                    "rays": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE, "parallelism": f"rays-dp{world}"},
-        "in_volume_fraction": rows / (N_BLOCKS * args.steps * samples_per_frame),
+        "in_volume_fraction": rows / (N_BLOCKS * args.steps * samples_per_frame), "sparsity": sparsity,
         "roofline": roofline, **tinfo,
     }
     if rank == 0 and world == 1:
@@ -327,7 +339,9 @@ def bench_render(args, rank, world, device, dist):
             result["dense_value"] = samples_per_frame / td
             result["dense_ms_per_step"] = 1e3 * td
             result["dense_mlp_tflops_lower_bound"] = 2.0 * mac * samples_per_frame / td / 1e12
-            result["dense_equals_culled"] = bool(torch.equal(out_d["rgb_map"], out["rgb_map"]))
+            # every output of the timed (culled, rays-of-constants) frame against the frame that evaluates every sample of every ray
+            result["dense_equals_culled"] = bool(all(torch.equal(out_d[k], out[k]) for k in out if torch.is_tensor(out[k]) and k in out_d))
+            result["dense_equals_culled_outputs"] = sorted(k for k in out if torch.is_tensor(out[k]) and k in out_d)
         if not args.no_sweep:
             # the headline rides on how much of the frame the body fills: the same frame from nearer / farther cameras
             sweep = []
