@@ -33,7 +33,7 @@ class DanboEngine:
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
         # True: re-order the compacted rows by bone set in front of K2 (k_group.hip).  Off since the end of round 4: K2 gains 2 x 20 us
-        # from it, the grouping costs 2 x 27 us and scatters K3's rows (tools/ab_group_rows.py: 4.734 ms with, 4.712 ms without)
+        # from it, the grouping costs 2 x 27 us and scatters K3's rows (tools/ab_engine_switch.py: 4.734 ms with, 4.712 ms without)
         self.group_rows = False
 
     # ------------------------------------------------------------------ derived buffers
@@ -347,7 +347,7 @@ class DanboEngine:
                 ev_vols.record(self._side[1])
             vols.record_stream(cur)
         near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
-        z = ops.coarse_samples(near, far, S)
+        z = ops.coarse_samples(near, far, S)      # (on the pose stream beside the ray mask: measured, slower -- tools/ab_engine_switch.py)
         # candidate bones of every ray over [near, far] (coarse and importance depths both lie inside): the two culls skip the
         # rays, and whole workgroups, that miss every volume -- most of a frame
         ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far,

@@ -1,9 +1,11 @@
-"""dev tool: the bench frame with and without danbo_group_rows in front of K2, interleaved blocks in one process"""
+"""dev tool: the bench frame with and without one engine switch (default: group_rows -- danbo_group_rows in front of K2), interleaved
+blocks in one process.  usage: ab_engine_switch.py [attribute]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "danbo-pytorch_amd"))
 import numpy as np, torch
 import bench
+ATTR = sys.argv[1] if len(sys.argv) > 1 else "group_rows"
 eng, inp, _ = bench.build_workload(torch.device("cuda:0"), 0)
 for _ in range(100):
     bench.render(eng, inp)
@@ -11,7 +13,7 @@ torch.cuda.synchronize()
 res = {True: [], False: []}
 for rep in range(6):
     for flag in (True, False):
-        eng.group_rows = flag
+        setattr(eng, ATTR, flag)
         for _ in range(5):
             bench.render(eng, inp)
         torch.cuda.synchronize()
@@ -21,4 +23,4 @@ for rep in range(6):
         torch.cuda.synchronize()
         res[flag].append((time.perf_counter() - t0) / 20 * 1e3)
 for flag in (True, False):
-    print("group_rows", flag, "ms/frame median", round(float(np.median(res[flag])), 4), [round(x, 3) for x in res[flag]])
+    print(ATTR, flag, "ms/frame median", round(float(np.median(res[flag])), 4), [round(x, 3) for x in res[flag]])
