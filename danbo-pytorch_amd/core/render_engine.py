@@ -28,6 +28,10 @@ class DanboEngine:
         self.profile = None
         self._side = None            # side streams of render()
         self.k2_waits_for_view = False   # see forward_samples
+        # render(): True = pose volumes / view constants / rays of constants on side streams beside the bounds -> cull chain.  Off since
+        # the end of round 4: with those kernels at a fifth of their round-3 cost the overlap buys less than the contention and the
+        # events cost (tools/ab_engine_switch.py side_streams: 4.696 ms with, 4.634 ms without; danbo_render_frame, one stream, 4.625)
+        self.side_streams = False
         self.skip_flat_rays = True   # render(): no resampling for rays that cannot meet a volume (tests switch it off to compare)
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
@@ -330,7 +334,7 @@ class DanboEngine:
         # computes: each runs on its own side stream under that chain; the main stream waits for the volumes in front of K2 and
         # for the view constants in front of K3.  In flat mode the view constants follow the ray mask (they need the list of the
         # rays that are not rays of constants) and run beside the cull.  Inside a HIP-graph capture the chain stays linear.
-        use_side = rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
+        use_side = self.side_streams and rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
         ready = vols = view = flat = None
         if use_side:
             cur = torch.cuda.current_stream()
