@@ -342,7 +342,7 @@ def importance_samples(z, weights, Sf, u=None):
     return zs, zf, idx
 
 
-def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False, rows_later=False):
+def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False, rows_later=False, cnt=None):
     """the rays of constants (danbo_flat_rays, include/danbo_hip.h -- the caller vouches for the model's empty-space density and
     colour): allocates the outputs of BOTH fused composites, writes them for every flagged ray, and lists the other rays ->
     dict(out0=..., out=..., z_fine=..., ray_list=..., ray_count=...) for view_consts(ray_list=...),
@@ -357,7 +357,9 @@ def flat_rays(t_lo, ray_flat, S, Sf, want_weights=False, rows_later=False):
     out = dict(rgb_map=f(R, 3), disp_map=f(R), acc_map=f(R), weights=f(R, S + Sf), alpha=f(R, S + Sf))
     zf = f(R, Sf)
     lst = torch.empty(R, device=dev, dtype=torch.int32)
-    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    if cnt is None:          # (render() hands over a zeroed word of the buffer it fills once per frame)
+        cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    assert cnt.dtype == torch.int32 and cnt.numel() == 1
     def launch(parts):
         _call("danbo_flat_rays", _p(t_lo), _p(ray_flat), R, int(S), int(Sf), _p(out0["rgb_map"]), _p(out0["disp_map"]),
               _p(out0["acc_map"]), _p(out0["weights"]), _p(out0["alpha"]), _p(zf), _p(out["rgb_map"]), _p(out["disp_map"]),

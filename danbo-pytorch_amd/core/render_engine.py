@@ -356,14 +356,15 @@ class DanboEngine:
         # rays, and whole workgroups, that miss every volume -- most of a frame
         ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far,
                                                         want_flat=flat_mode)
+        counts = torch.zeros(3, device=rays_o.device, dtype=torch.int32)       # rows of the two passes, listed rays: one fill
         if use_side:
             side = self._side[0]
             if flat_mode:
                 side.wait_stream(cur)
-                for t in (ray_mask[1], ray_mask[3]):
+                for t in (ray_mask[1], ray_mask[3], counts):
                     t.record_stream(side)
                 with torch.cuda.stream(side):
-                    flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, rows_later=True)
+                    flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, rows_later=True, cnt=counts[2:3])
                     view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
                 for t in list(flat["out0"].values()) + list(flat["out"].values()) + [flat[k] for k in ("z_fine", "ray_list", "ray_count")]:
                     if t is not None:
@@ -381,13 +382,12 @@ class DanboEngine:
         else:
             vols = self.volumes(bones)
             if flat_mode:
-                flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf)
+                flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, cnt=counts[2:3])
                 view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
             else:
                 view = self.view_constants(rays_d, skts, cam_idx)
         if ray_mask is not None:
             ray_mask = ray_mask[:3]
-        counts = torch.zeros(2, device=rays_o.device, dtype=torch.int32)       # rows of the two passes: one fill
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
                                        fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1])
         if flat_mode and use_side:
