@@ -228,18 +228,21 @@ def _block(fn, steps, dist, device, cpu_dist):
 def timed(fn, steps, warmup, dist, device, cpu_dist, settle_block=10, on_timed_start=None):
     """The number must not depend on where in the process it is taken (the first tens of milliseconds after idle
     run ~10 % slower -- clocks, caches, the allocator's pool -- and a 0.12 s timed region sat inside them):
-      1. settle: blocks of `settle_block` steps until >= SETTLE_MIN_S of work has run AND two consecutive blocks agree within
+      1. settle: blocks of `settle_block` steps until >= SETTLE_MIN_S of work has run BEHIND THE FIRST BLOCK (which carries the
+         one-time initialisations: round 4 saw it take 1 s and satisfy the criterion alone) AND two consecutive blocks agree within
          SETTLE_TOL (give up after SETTLE_MAX_S and say so); block times are max-over-ranks, so every rank takes the same
          decisions and runs the same number of steps (the training step contains collectives);
       2. the CLI's `warmup` untimed steps;
       3. N_BLOCKS timed blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize, each the MAX over the ranks.
     -> (median block seconds, last output, info for the JSON line)"""
-    spent, prev, settled, n_settle = 0.0, None, False, 0
+    spent, steady, prev, settled, n_settle = 0.0, 0.0, None, False, 0
     while spent < SETTLE_MAX_S:
         dt, _ = _block(fn, settle_block, dist, device, cpu_dist)
         spent += dt
+        if n_settle > 0:
+            steady += dt            # the first block carries the one-time initialisations (a second of them on a fresh box): not "work"
         n_settle += 1
-        if prev is not None and spent >= SETTLE_MIN_S and abs(dt - prev) <= SETTLE_TOL * max(dt, prev):
+        if prev is not None and steady >= SETTLE_MIN_S and abs(dt - prev) <= SETTLE_TOL * max(dt, prev):
             settled = True
             break
         prev = dt
