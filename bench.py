@@ -306,7 +306,7 @@ def bench_render(args, rank, world, device, dist):
     # constants when the weights allow it (include/danbo_hip.h: danbo_flat_rays) -- no view constants, resampling or composite for them
     rm = ops_mod().ray_bone_mask(inp["rays_o"], inp["rays_d"], inp["skts"], eng.align, eng.axis_scale, keep["near"], keep["far"], want_flat=True)
     sparsity = dict(rays=H * W, rays_with_a_candidate_bone=int((rm[0] != 0).sum()), rays_with_an_in_volume_coarse_sample=rays_hit,
-                    rays_of_constants=int(rm[3].sum()) if (eng.flat_rays_ok and eng.skip_flat_rays and N_SAMPLES <= 64 and N_IMPORTANCE <= 64) else 0,
+                    rays_of_constants=int(rm[3].sum()) if (eng.flat_rays_ok and eng.skip_flat_rays and N_SAMPLES <= 256 and N_IMPORTANCE <= 64) else 0,
                     note="every output of the timed frame is compared bitwise with the render that evaluates every sample of every ray "
                          "(dense_equals_culled)")
     keep = dict(raw_coarse=keep["raw_coarse"], valid_bits=keep["valid_bits"])         # for the parity block below

@@ -590,11 +590,14 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __res
 // ======================================================================================
 // raw fill / merge
 // ======================================================================================
+// skip (optional): per-ray flags -- the rows of a flagged ray (a ray of constants: nobody reads them) are left alone
 __global__ __launch_bounds__(256) void k_fill_raw(const float4* __restrict__ raw_empty, int R, int S,
-                                                  float4* __restrict__ raw) {
+                                                  const uint32_t* __restrict__ skip, float4* __restrict__ raw) {
     const long M = (long)R * S;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x)
-        raw[m] = raw_empty[m / S];
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const long r = m / S;
+        if (skip == nullptr || skip[r] == 0u) raw[m] = raw_empty[r];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_merge_samples(const float* __restrict__ a, const float* __restrict__ b,
@@ -679,11 +682,14 @@ __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ ra
                                                    const float* __restrict__ rays_d, int R, int S, float B,
                                                    const float* __restrict__ noise, float* __restrict__ rgb_map,
                                                    float* __restrict__ disp, float* __restrict__ acc_out,
-                                                   float* __restrict__ weights, float* __restrict__ alpha_out) {
+                                                   float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                   const int32_t* __restrict__ ray_list, const int32_t* __restrict__ ray_count) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int r = wave; r < R; r += nwaves) {
+    const int n = ray_list ? min(max(*ray_count, 0), R) : R;        // (a list: k_flat_rays' -- only the listed rays are composited)
+    for (int i = wave; i < n; i += nwaves) {
+        const int r = ray_list ? min(max(ray_list[i], 0), R - 1) : i;
         const float dn = ray_norm(rays_d, r);
         CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < S; c0 += 64) {
@@ -783,7 +789,9 @@ __global__ __launch_bounds__(256) void k_composite_merged(const float4* __restri
         }
         return;
     }
-    for (int r = wave; r < R; r += nwaves) {
+    const int n_all = ray_list ? min(max(*ray_count, 0), R) : R;
+    for (int i = wave; i < n_all; i += nwaves) {
+        const int r = ray_list ? min(max(ray_list[i], 0), R - 1) : i;
         const float dn = ray_norm(rays_d, r);
         CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < St; c0 += 64) {
@@ -957,7 +965,9 @@ template <bool DET>
 __global__ __launch_bounds__(256) void k_importance_wave_long(const float* __restrict__ z, const float* __restrict__ weights,
                                                               int R, int S, int Sf, const float* __restrict__ u,
                                                               float* __restrict__ z_fine, float* __restrict__ z_sorted,
-                                                              int32_t* __restrict__ sorted_idx, unsigned scatter) {
+                                                              int32_t* __restrict__ sorted_idx, unsigned scatter,
+                                                              const int32_t* __restrict__ ray_list,
+                                                              const int32_t* __restrict__ ray_count) {
     __shared__ float s_all[4][3 * IMPB_MAX_S + 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_z = s_all[wv];                   // [S] coarse depths
@@ -968,8 +978,9 @@ __global__ __launch_bounds__(256) void k_importance_wave_long(const float* __res
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int nb = S - 2, ncdf = S - 1;
     const int nchunk = (S + 63) >> 6;
-    for (int i = wave; i < R; i += nwaves) {
-        const int r = scattered_ray(i, scatter, R);
+    const int n = ray_list ? min(max(*ray_count, 0), R) : R;
+    for (int i = wave; i < n; i += nwaves) {
+        const int r = ray_list ? min(max(ray_list[i], 0), R - 1) : scattered_ray(i, scatter, R);
         const size_t o = (size_t)r * S;
         for (int c = 0; c < nchunk; ++c) {
             const int s0 = 64 * c + lane;
@@ -1195,11 +1206,12 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_flat_rays(const float* __restric
         const int b = (int)__builtin_ctzll(rows);
         rows &= rows - 1ull;
         const size_t rr = (size_t)(blockIdx.x * FLAT_BLOCK + wave * 64 + b);
-        if (lane < S) {
-            if (weights0) weights0[rr * S + lane] = 0.f;
-            if (alpha0) alpha0[rr * S + lane] = 0.f;
+        for (int c = lane; c < S; c += 64) {
+            if (weights0) weights0[rr * S + c] = 0.f;
+            if (alpha0) alpha0[rr * S + c] = 0.f;
         }
-        if (lane < Sf) z_fine[rr * Sf + lane] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), b));
+        const float lo_b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), b));
+        for (int c = lane; c < Sf; c += 64) z_fine[rr * Sf + c] = lo_b;
         for (int c = lane; c < St; c += 64) {
             if (weights) weights[rr * St + c] = 0.f;
             if (alpha_out) alpha_out[rr * St + c] = 0.f;
@@ -1321,11 +1333,17 @@ extern "C" int danbo_bone_gather_fwd(const float* rays_o, const float* rays_d, c
     DANBO_LAUNCH_RET();
 }
 
-extern "C" int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream) {
+static int fill_raw_impl(const float* raw_empty, int R, int S, const uint32_t* skip, float* raw, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0);
     hipLaunchKernelGGL(k_fill_raw, dim3(stream_grid((long)R * S, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(raw_empty), R, S, reinterpret_cast<float4*>(raw));
+                       reinterpret_cast<const float4*>(raw_empty), R, S, skip, reinterpret_cast<float4*>(raw));
     DANBO_LAUNCH_RET();
+}
+extern "C" int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream) {
+    return fill_raw_impl(raw_empty, R, S, nullptr, raw, stream);
+}
+extern "C" int danbo_fill_raw_rays(const float* raw_empty, int R, int S, const uint32_t* skip, float* raw, void* stream) {
+    return fill_raw_impl(raw_empty, R, S, skip, raw, stream);
 }
 
 extern "C" int danbo_merge_samples(const float* a, const float* b, const int32_t* sorted_idx, int R, int S, int Sf,
@@ -1336,20 +1354,33 @@ extern "C" int danbo_merge_samples(const float* a, const float* b, const int32_t
     DANBO_LAUNCH_RET();
 }
 
-extern "C" int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
-                                    const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
-                                    float* alpha, void* stream) {
+static int composite_impl(const float* raw, const float* z, const float* rays_d, int R, int S, float B, const float* noise,
+                          float* rgb_map, float* disp, float* acc, float* weights, float* alpha, const int32_t* ray_list,
+                          const int32_t* ray_count, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && B > 0.f);
+    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
     static const int per_launch = resident_grid(k_composite, 1L << 40, 256);
     const int grid = (int)std::min<long>(ceil_div((long)R * 64, 256), per_launch);
     hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(raw), z,
-                       rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha);
+                       rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, ray_list, ray_count);
     DANBO_LAUNCH_RET();
 }
+extern "C" int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
+                                    const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
+                                    float* alpha, void* stream) {
+    return composite_impl(raw, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, nullptr, nullptr, stream);
+}
+extern "C" int danbo_composite_rays_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
+                                         const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
+                                         float* alpha, const int32_t* ray_list, const int32_t* ray_count, void* stream) {
+    return composite_impl(raw, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, ray_list, ray_count, stream);
+}
 
-extern "C" int danbo_importance_samples(const float* z, const float* weights, int R, int S, int Sf, const float* u,
-                                         float* z_fine, float* z_sorted, int32_t* sorted_idx, void* stream) {
+static int importance_impl(const float* z, const float* weights, int R, int S, int Sf, const float* u, float* z_fine,
+                           float* z_sorted, int32_t* sorted_idx, const int32_t* ray_list, const int32_t* ray_count, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S >= 3 && Sf > 0);
+    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
+    DANBO_CHECK_ARG(ray_list == nullptr || (S > 64 && S <= IMPB_MAX_S && Sf <= 64));      // (the list: the long-ray kernel only)
     if (S <= 64 && Sf <= 64) {
         if (u)
             hipLaunchKernelGGL(k_importance_wave<false>, dim3(stream_grid((long)R * 64, 256)), dim3(256), 0,
@@ -1361,15 +1392,24 @@ extern "C" int danbo_importance_samples(const float* z, const float* weights, in
         const dim3 grid(stream_grid((long)R * 64, 256));
         if (u)
             hipLaunchKernelGGL(k_importance_wave_long<false>, grid, dim3(256), 0, (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine,
-                               z_sorted, sorted_idx, ray_scatter(R));
+                               z_sorted, sorted_idx, ray_scatter(R), ray_list, ray_count);
         else
             hipLaunchKernelGGL(k_importance_wave_long<true>, grid, dim3(256), 0, (hipStream_t)stream, z, weights, R, S, Sf, u, z_fine,
-                               z_sorted, sorted_idx, ray_scatter(R));
+                               z_sorted, sorted_idx, ray_scatter(R), ray_list, ray_count);
     } else {
         hipLaunchKernelGGL(k_importance, dim3(stream_grid(R, 64)), dim3(64), 0, (hipStream_t)stream, z, weights, R, S, Sf,
                            u, z_fine, z_sorted, sorted_idx);
     }
     DANBO_LAUNCH_RET();
+}
+extern "C" int danbo_importance_samples(const float* z, const float* weights, int R, int S, int Sf, const float* u,
+                                         float* z_fine, float* z_sorted, int32_t* sorted_idx, void* stream) {
+    return importance_impl(z, weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx, nullptr, nullptr, stream);
+}
+extern "C" int danbo_importance_samples_rays(const float* z, const float* weights, int R, int S, int Sf, const float* u,
+                                              float* z_fine, float* z_sorted, int32_t* sorted_idx, const int32_t* ray_list,
+                                              const int32_t* ray_count, void* stream) {
+    return importance_impl(z, weights, R, S, Sf, u, z_fine, z_sorted, sorted_idx, ray_list, ray_count, stream);
 }
 
 extern "C" int danbo_composite_importance_fwd(const float* raw, const float* raw_empty, const uint32_t* valid_bits,
@@ -1400,7 +1440,7 @@ extern "C" int danbo_composite_importance_fwd(const float* raw, const float* raw
 extern "C" int danbo_flat_rays(const float* t_lo, const uint32_t* ray_flat, int R, int S, int Sf, float* rgb0, float* disp0, float* acc0, float* weights0, float* alpha0, float* z_fine,
                                 float* rgb_map, float* disp, float* acc, float* weights, float* alpha, int32_t* ray_list,
                                 int32_t* ray_count, int parts, void* stream) {
-    DANBO_CHECK_ARG(R > 0 && S >= 3 && S <= 64 && Sf > 0 && Sf <= 64);
+    DANBO_CHECK_ARG(R > 0 && S >= 3 && Sf > 0);
     DANBO_CHECK_ARG(t_lo && ray_flat && rgb0 && disp0 && acc0 && z_fine && rgb_map && disp && acc && ray_list && ray_count);
     DANBO_CHECK_ARG(parts >= 1 && parts <= 3);
     hipLaunchKernelGGL(k_flat_rays, dim3(ceil_div(R, FLAT_BLOCK)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,

@@ -249,6 +249,9 @@ int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count
 
 /* raw[r,s,:] = raw_empty[r,:] (broadcast fill before K3 scatters the in-volume rows) */
 int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream);
+/* the same, leaving alone the rows of the rays with skip[r] != 0 (danbo_ray_bone_mask's ray_flat: the rays of constants, whose
+ * raw rows nobody reads -- danbo_flat_rays); skip NULL = danbo_fill_raw */
+int danbo_fill_raw_rays(const float* raw_empty, int R, int S, const uint32_t* skip /*[R]*/, float* raw, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K4  NeRF.raw2outputs (core/networks/nerf.py:281-347), relu density, one wavefront per ray.
@@ -258,6 +261,12 @@ int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* strea
 int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
                         const float* noise, float* rgb_map, float* disp, float* acc,
                         float* weights, float* alpha, void* stream);
+/* the same over a list of rays (ray_list / ray_count together, or both NULL = danbo_composite_fwd): only the listed rays
+ * (danbo_flat_rays' list; *ray_count is read on the device) are composited, every output row of an unlisted ray is left
+ * untouched -- the path of rays too long for danbo_composite_importance_fwd (S > 64) */
+int danbo_composite_rays_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
+                             const float* noise, float* rgb_map, float* disp, float* acc, float* weights, float* alpha,
+                             const int32_t* ray_list, const int32_t* ray_count, void* stream);
 
 /* K4 backward: gradients of rgb_map [R,3] and acc_map [R] -> d raw [R,S,4] (S <= 256).  disp_map,
  * weights and alpha carry no gradient in the reference's losses (core/trainer.py:396-422,507-536). */
@@ -283,6 +292,11 @@ int danbo_bone_gather_bwd(const float* rays_o, const float* rays_d, const float*
 int danbo_importance_samples(const float* z, const float* weights, int R, int S, int Sf, const float* u,
                              float* z_fine /*[R,Sf]*/, float* z_sorted /*[R,S+Sf]*/,
                              int32_t* sorted_idx /*[R,S+Sf]*/, void* stream);
+/* the same over a list of rays (64 < S <= 256 and Sf <= 64 with a list; both NULL = danbo_importance_samples): the rows of
+ * unlisted rays are left untouched (danbo_flat_rays wrote their z_fine; nobody reads their z_sorted / sorted_idx) */
+int danbo_importance_samples_rays(const float* z, const float* weights, int R, int S, int Sf, const float* u,
+                                  float* z_fine, float* z_sorted, int32_t* sorted_idx, const int32_t* ray_list,
+                                  const int32_t* ray_count, void* stream);
 
 /* merge_samples (core/raycasters.py:745-761): out[r,i,:] = cat(a[r],b[r])[sorted_idx[r,i],:] */
 int danbo_merge_samples(const float* a /*[R,S,C]*/, const float* b /*[R,Sf,C]*/, const int32_t* sorted_idx,
@@ -313,7 +327,8 @@ int danbo_composite_importance_fwd(const float* raw /*[R,S,4]*/, const float* ra
  * alpha0 rows, may be NULL) and the merged composite's (rgb_map, disp, acc, weights / alpha rows, may be NULL) -- sets their z_fine
  * row to t_lo (so that the importance pass's danbo_bone_cull drops them on their mask; their z_sorted / sorted_idx rows are never
  * made), and appends every OTHER ray to ray_list / *ray_count (zeroed by the caller), to be passed to danbo_view_consts,
- * danbo_composite_importance_fwd and danbo_composite_merged_fwd.  All maps / alphas / weights of the frame are then bit-identical
+ * danbo_composite_importance_fwd and danbo_composite_merged_fwd (any S, Sf; rays of more than 64 coarse samples:
+ * danbo_fill_raw_rays with the flags, danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_composite_merged_fwd).  All maps / alphas / weights of the frame are then bit-identical
  * to evaluating every ray; a caller that wants z_fine / z_sorted / sorted_idx / cview / raw_empty of every ray, density noise, or
  * cannot state (a) and (b), must not use it.
  * parts: 1 = the list and the per-ray outputs (a few us: what danbo_view_consts waits for), 2 = the per-sample rows (weights0 /

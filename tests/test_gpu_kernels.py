@@ -634,6 +634,54 @@ def test_render_without_resampling_of_rays_that_miss_every_volume_is_bitwise_the
     assert torch.equal(bits2, c["valid_bits"]) and int(rm_far[3].sum()) == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,Sf", [(96, 32), (130, 64), (256, 16)])
+def test_rays_of_constants_of_long_rays_are_bitwise_the_full_render(stage, S, Sf):
+    """rays of more than 64 coarse samples (BASELINE config 3: 96 + 32) go through the unfused composites; the rays of constants
+    skip the raw pre-fill, the coarse composite, the resampling and the final composite there too -- every output equals the
+    render that evaluates every ray and the keep=True render, bit for bit; the listed kernels one by one against the full ones"""
+    from core.utils import synthetic as syn
+    eng = stage["eng"]
+    scene = syn.make_scene(n_poses=2, H=64, W=64, n_views=2, pose_seed=7)
+    ro = np.concatenate([scene["rays"][0][0], scene["rays"][1][0]])
+    rd = np.concatenate([scene["rays"][0][1], scene["rays"][1][1]])
+    args = (T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(scene["cyls"]), torch.zeros(len(ro), dtype=torch.int64, device=DEV))
+    assert eng.skip_flat_rays is True and eng.flat_rays_ok
+    a = eng.render(*args, S, Sf)
+    eng.skip_flat_rays = False
+    try:
+        b = eng.render(*args, S, Sf)
+    finally:
+        eng.skip_flat_rays = True
+    c = eng.render(*args, S, Sf, keep=True)
+    d = eng.render(*args, S, Sf, dense=True)
+    for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0"):
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
+        assert torch.equal(a[k], d[k]), k
+    ops_ = eng_ops(eng)
+    near, far = eng.near_far(args[0], args[1], args[4], args[2])
+    rm = ops_.ray_bone_mask(args[0], args[1], args[2], eng.align, eng.axis_scale, near, far, want_flat=True)
+    R = rm[0].numel()
+    fr = ops_.flat_rays(rm[1], rm[3], S, Sf, want_weights=True)
+    flat = rm[3] != 0
+    assert int(flat.sum()) > R // 2 and int(fr["ray_count"].item()) == R - int(flat.sum())
+    view = eng.view_constants(args[1], args[2], args[5])
+    B = eng.cfg["density_scale"]
+    raw = ops_.fill_raw(view[1], S, skip=rm[3])
+    full = ops_.fill_raw(view[1], S)
+    assert torch.equal(raw[~flat], full[~flat])
+    out0 = ops_.composite(c["raw_coarse"], c["z_coarse"], args[1], B, flat=fr)
+    for k, k0 in (("rgb_map", "rgb0"), ("disp_map", "disp0"), ("acc_map", "acc0"), ("alpha", "alpha0"), ("weights", "weights_coarse")):
+        assert torch.equal(out0[k], c[k0]), k
+    z_all, z_fine, order = ops_.importance_samples(c["z_coarse"], out0["weights"], Sf, flat=fr)
+    assert torch.equal(z_fine[~flat], c["z_fine"][~flat]) and torch.equal(z_all[~flat], c["z_sorted"][~flat]) and torch.equal(order[~flat], c["sorted_idxs"][~flat])
+    assert torch.equal(z_fine[flat], near.reshape(-1, 1)[flat].expand(-1, Sf))
+    out = ops_.composite_merged(c["raw_coarse"], c["raw_fine"], order, z_all, args[1], B, flat=fr)
+    for k, k0 in (("rgb_map", "rgb_map"), ("disp_map", "disp_map"), ("acc_map", "acc_map"), ("alpha", "alpha"), ("weights", "T_i")):
+        assert torch.equal(out[k], c[k0]), k
+
+
 def eng_ops(eng):
     from core import hip_ops
     return hip_ops

@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: prof_config.sh TAG N  -> rocprofv3 kernel statistics of `bench.py --config N` (render configs 1 - 3), per-kernel table per frame
+TAG=$1; CFG=${2:-3}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o $TAG -- python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-dense --no-sweep > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_bench.log 2>&1
+grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"achieved": [0-9.]*\|"avg_launch_ms": [0-9.]*' $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_bench.log | tr '\n' ' '; echo
+python3 - <<PY
+import csv,os
+rows=list(csv.DictReader(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv")))
+frames = max([int(r["Calls"]) for r in rows if "k_composite_merged" in r["Name"]] + [1])
+for r in rows[:16]:
+    print(r["Name"][:48].ljust(48), r["Calls"].rjust(4), "avg_us", str(round(float(r["AverageNs"])/1e3,1)).rjust(8), "ms/frame", str(round(int(r["TotalDurationNs"])/1e6/frames,3)).rjust(7), r["Percentage"])
+print("frames", frames, " sum of all kernels per frame ms", round(sum(int(r["TotalDurationNs"]) for r in rows)/1e6/frames,3),
+      " without k_pe_mlp16:", round(sum(int(r["TotalDurationNs"]) for r in rows if "k_pe_mlp16" not in r["Name"])/1e6/frames,3))
+PY
