@@ -32,7 +32,8 @@ extern "C" {
 /* library / device identification (host only).
  * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
  * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, danbo_flat_rays;
- * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable). */
+ * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
+ * danbo_fill_raw_rays, danbo_composite_rays_fwd, danbo_importance_samples_rays. */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
