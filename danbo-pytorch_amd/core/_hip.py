@@ -37,8 +37,7 @@ SIGNATURES = {
     "danbo_pe_mlp16_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P],
     "danbo_pe_mlp_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P, P],
     "danbo_fill_raw": [P, I, I, P, P],
-    "danbo_fill_raw_rays": [P, I, I, P, P, P],
-    "danbo_composite_rays_fwd": [P, P, P, I, I, F, P, P, P, P, P, P, P, P, P],
+    "danbo_composite_rays_fwd": [P, P, P, P, P, I, I, F, P, P, P, P, P, P, P, P, P],
     "danbo_importance_samples_rays": [P, P, I, I, I, P, P, P, P, P, P, P],
     "danbo_composite_fwd": [P, P, P, I, I, F, P, P, P, P, P, P, P],
     "danbo_composite_bwd": [P, P, P, I, I, F, P, P, P, P, P],

@@ -310,21 +310,16 @@ def pe_mlp16(h, S, packed16, pts_b, alpha_w, alpha_b, cview, rgb_w, rgb_b, raw_o
     return aux_out
 
 
-def fill_raw(raw_empty, S, skip=None):
-    """raw [R,S,4] with every row of ray r = raw_empty[r]; skip: ray_bone_mask()'s flags -- the rows of a flagged ray (a ray of
-    constants: nobody reads them) stay unwritten"""
+def fill_raw(raw_empty, S):
     R = raw_empty.shape[0]
     raw = torch.empty(R, S, 4, device=raw_empty.device, dtype=torch.float32)
-    if skip is None:
-        _call("danbo_fill_raw", _p(raw_empty), R, S, _p(raw), _stream())
-    else:
-        assert skip.dtype == torch.int32 and skip.shape[0] == R
-        _call("danbo_fill_raw_rays", _p(raw_empty), R, S, _p(skip), _p(raw), _stream())
+    _call("danbo_fill_raw", _p(raw_empty), R, S, _p(raw), _stream())
     return raw
 
 
-def composite(raw, z, rays_d, B=1.0, noise=None, flat=None):
-    """flat: flat_rays(want_weights=True)'s result -- only its listed rays are composited, into its buffers"""
+def composite(raw, z, rays_d, B=1.0, noise=None, bits=None, raw_empty=None, flat=None):
+    """bits / raw_empty: un-filled raw (samples with in-volume word 0 take raw_empty[ray]: danbo_hip.h);
+    flat: flat_rays(want_weights=True)'s result -- only its listed rays are composited, into its buffers"""
     raw, z, rays_d = _f32(raw, "raw"), _f32(z, "z"), _f32(rays_d, "rays_d")
     R, S = z.shape
     dev = raw.device
@@ -332,16 +327,19 @@ def composite(raw, z, rays_d, B=1.0, noise=None, flat=None):
         o0 = flat["out0"]
         rgb, disp, acc, w, al = o0["rgb_map"], o0["disp_map"], o0["acc_map"], o0["weights"], o0["alpha"]
         assert w is not None and w.shape == (R, S) and al.shape == (R, S)
-        _call("danbo_composite_rays_fwd", _p(raw), _p(z), _p(rays_d), R, S, float(B), _p(_f32(noise, "noise")),
-              _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _p(flat["ray_list"]), _p(flat["ray_count"]), _stream())
-        return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
-    rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
-    disp = torch.empty(R, device=dev, dtype=torch.float32)
-    acc = torch.empty(R, device=dev, dtype=torch.float32)
-    w = torch.empty(R, S, device=dev, dtype=torch.float32)
-    al = torch.empty(R, S, device=dev, dtype=torch.float32)
-    _call("danbo_composite_fwd", _p(raw), _p(z), _p(rays_d), R, S, float(B), _p(_f32(noise, "noise")),
-          _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _stream())
+    else:
+        rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+        disp = torch.empty(R, device=dev, dtype=torch.float32)
+        acc = torch.empty(R, device=dev, dtype=torch.float32)
+        w = torch.empty(R, S, device=dev, dtype=torch.float32)
+        al = torch.empty(R, S, device=dev, dtype=torch.float32)
+    if flat is not None or bits is not None:
+        _call("danbo_composite_rays_fwd", _p(raw), _p(_f32(raw_empty, "raw_empty")), _p(bits), _p(z), _p(rays_d), R, S, float(B),
+              _p(_f32(noise, "noise")), _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _p(flat["ray_list"] if flat else None),
+              _p(flat["ray_count"] if flat else None), _stream())
+    else:
+        _call("danbo_composite_fwd", _p(raw), _p(z), _p(rays_d), R, S, float(B), _p(_f32(noise, "noise")),
+              _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _stream())
     return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, weights=w, alpha=al)
 
 

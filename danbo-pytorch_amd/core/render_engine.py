@@ -197,8 +197,7 @@ class DanboEngine:
                                self.code_table, ray_list, ray_count)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None,
-                        fill_skip=None):
+                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
@@ -206,8 +205,7 @@ class DanboEngine:
         dense=True : every sample goes through every kernel (the reference's executed work).
         ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used.
         ray_mask: ops.ray_bone_mask() of these rays over an interval that holds every depth of z (render: [near, far]).
-        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once).
-        fill_skip: per-ray flags of the rays whose raw rows nobody will read (render(): the rays of constants)."""
+        count: zeroed [1] int32 for the row count (render() fills both passes' counters at once)."""
         self.refresh()
         geo = ops.Geometry(rays_o, rays_d, skts, self.align, self.axis_scale, z=z, pts=pts, ray_mask=ray_mask)
         vols = self.volumes(bones) if volumes is None else volumes
@@ -231,7 +229,7 @@ class DanboEngine:
         if ready is not None and not self.k2_waits_for_view:
             torch.cuda.current_stream().wait_event(ready[1])
         # fill=False: rows outside every volume stay unwritten; the consumer reads raw_empty for them (valid_bits == 0)
-        raw = ops.fill_raw(raw_empty, S, fill_skip) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
+        raw = ops.fill_raw(raw_empty, S) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -325,16 +323,15 @@ class DanboEngine:
         B = cfg["density_scale"]
         self.refresh()
         fused = S <= 64 and Sf <= 64
-        lazy = fused and not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
+        lazy = not dense and not keep      # skip the raw pre-fill: consumers read raw_empty where bits == 0
         # lazy: nobody outside this function sees z_fine, the sorted order or the per-ray view constants.  If the weights allow it
         # (_flat_rays_ok), the rays that cannot meet a volume anywhere in [near, far] -- flagged with the ray mask -- get their
         # constants from ops.flat_rays and nothing else: no view constants, no resampling, no composite (danbo_hip.h).  The
         # coarse depths are this function's own: near (1 - t) + far t lies in [near, far] up to a few ulps, far inside the slack
         # the flags allow, so they need no confirmation by the cull.
-        # Longer rays (S > 64, up to 256 with Sf <= 64: the unfused composites) take the same constants: the raw pre-fill leaves
-        # the rows of those rays alone, and the coarse composite, the resampling and the final composite walk the list.
-        flat_mode = (lazy or (not fused and S <= 256 and Sf <= 64 and not dense and not keep)) and self.skip_flat_rays \
-            and self.flat_rays_ok
+        # Longer rays (S > 64, up to 256 with Sf <= 64: the unfused composites) take the same constants: the coarse composite,
+        # the resampling and the final composite walk the list there too.
+        flat_mode = lazy and (fused or (S <= 256 and Sf <= 64)) and self.skip_flat_rays and self.flat_rays_ok
         # The per-pose volumes (4 small launches) and the per-ray view constants depend on nothing the depths / cull chain
         # computes: each runs on its own side stream under that chain; the main stream waits for the volumes in front of K2 and
         # for the view constants in front of K3.  In flat mode the view constants follow the ray mask (they need the list of the
@@ -391,11 +388,10 @@ class DanboEngine:
                 view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
             else:
                 view = self.view_constants(rays_d, skts, cam_idx)
-        skip = ray_mask[3] if flat_mode and not fused else None
         if ray_mask is not None:
             ray_mask = ray_mask[:3]
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1], fill_skip=skip)
+                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1])
         if flat_mode and use_side:
             torch.cuda.current_stream().wait_event(ev_rows)
         if fused:
@@ -403,11 +399,12 @@ class DanboEngine:
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
                 want_weights=keep, flat=flat)
         else:
-            out0 = ops.composite(raw, z, rays_d, B, flat=flat)
+            out0 = ops.composite(raw, z, rays_d, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
+                                 flat=flat)
             z_all, z_fine, order = ops.importance_samples(z, out0["weights"], Sf, flat=flat)
         raw_f, ex_f = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z_fine, dense=dense,
                                            volumes=vols, view=view, fill=not lazy,
-                                           ray_mask=ray_mask, count=counts[1:2], fill_skip=skip)
+                                           ray_mask=ray_mask, count=counts[1:2])
         out = ops.composite_merged(raw, raw_f, order, z_all, rays_d, B, bits_a=ex["valid_bits"] if lazy else None,
                                    bits_b=ex_f["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,
                                    want_raw=keep, flat=flat)

@@ -1,6 +1,7 @@
 // danbo_render_frame: the whole eval chain of one ray batch (RayCaster.render_rays, reference core/raycasters.py:245-377, with
 // the DANBO network) behind ONE C call -- bounds, coarse samples, per-pose volumes, per-ray view constants, [cull -> gather /
-// assignment / blend -> PE + MLP] for the coarse and for the importance samples, fused composite + resampling, final composite.
+// assignment / blend -> PE + MLP] for the coarse and for the importance samples, composite + resampling (one launch up to 64 + 64
+// samples per ray, two beyond), final composite.
 // Host code only: it enqueues the kernels of the other translation units on `stream` in the order core/render_engine.py does,
 // carving every intermediate out of a caller-provided workspace; no allocation, no synchronisation.
 #include "common.hpp"
@@ -21,7 +22,7 @@ struct Carver {
 };
 
 struct FrameBuffers {
-    float *near, *far, *cyl_scratch, *z, *vol_scratch, *volumes, *cview, *raw_empty, *h, *raw_a, *raw_b, *z_fine, *z_sorted;
+    float *near, *far, *cyl_scratch, *z, *vol_scratch, *volumes, *cview, *raw_empty, *h, *raw_a, *raw_b, *z_fine, *z_sorted, *weights0;
     uint32_t *bits_a, *bits_b, *ray_mask, *ray_flat;
     int32_t *list, *count, *order, *ray_list;
 };
@@ -51,6 +52,7 @@ FrameBuffers carve(Carver& c, int R, int G, int S, int Sf, int chunk, int Wg) {
     b.z_sorted = c.take<float>(M + Mf);
     b.order = c.take<int32_t>(M + Mf);
     if (Mf > M) b.list = c.take<int32_t>(Mf);
+    b.weights0 = (S <= 64 && Sf <= 64) ? nullptr : c.take<float>(M);     // the coarse weights between the two unfused launches
     return b;
 }
 }  // namespace
@@ -66,7 +68,7 @@ extern "C" size_t danbo_render_frame_workspace(int R, int G, int S, int Sf, int 
 
 extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S, int Sf, const DanboFrameOut* o, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-    DANBO_CHECK_ARG(m && r && o && workspace && S >= 1 && S <= 64 && Sf >= 1 && Sf <= 64);
+    DANBO_CHECK_ARG(m && r && o && workspace && S >= 3 && S <= 256 && Sf >= 1 && Sf <= 64);
     DANBO_CHECK_ARG(r->R >= 1 && r->G >= 1 && r->R % r->G == 0 && r->chunk >= 1);
     DANBO_CHECK_ARG(r->rays_o && r->rays_d && r->skts && r->bones && r->cyls);
     DANBO_CHECK_ARG(o->rgb_map && o->disp_map && o->acc_map && o->alpha && o->weights && o->rgb0 && o->disp0 && o->acc0 && o->alpha0);
@@ -100,7 +102,7 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     // composites take the list of the others
     const int32_t *ray_list = nullptr, *ray_count = nullptr;
     if (flat_rays) {
-        DANBO_TRY(danbo_flat_rays(b.near, b.ray_flat, R, S, Sf, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, o->rgb_map,
+        DANBO_TRY(danbo_flat_rays(b.near, b.ray_flat, R, S, Sf, o->rgb0, o->disp0, o->acc0, b.weights0, o->alpha0, b.z_fine, o->rgb_map,
                                   o->disp_map, o->acc_map, o->weights, o->alpha, b.ray_list, b.count + 3, 3, stream));
         ray_list = b.ray_list;
         ray_count = b.count + 3;
@@ -123,9 +125,16 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     };
     DANBO_TRY(cull(b.z, S, b.bits_a, b.count));
     DANBO_TRY(network(b.z, S, b.bits_a, b.count, b.raw_a));
-    DANBO_TRY(danbo_composite_importance_fwd(b.raw_a, b.raw_empty, b.bits_a, b.z, r->rays_d, R, S, Sf, m->density_scale, nullptr, nullptr,
-                                             o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order, ray_list,
-                                             ray_count, stream));
+    if (S <= 64) {
+        DANBO_TRY(danbo_composite_importance_fwd(b.raw_a, b.raw_empty, b.bits_a, b.z, r->rays_d, R, S, Sf, m->density_scale, nullptr,
+                                                 nullptr, o->rgb0, o->disp0, o->acc0, nullptr, o->alpha0, b.z_fine, b.z_sorted, b.order,
+                                                 ray_list, ray_count, stream));
+    } else {     // rays of more than 64 coarse samples: the same two steps as two launches, the weights in between
+        DANBO_TRY(danbo_composite_rays_fwd(b.raw_a, b.raw_empty, b.bits_a, b.z, r->rays_d, R, S, m->density_scale, nullptr, o->rgb0,
+                                           o->disp0, o->acc0, b.weights0, o->alpha0, ray_list, ray_count, stream));
+        DANBO_TRY(danbo_importance_samples_rays(b.z, b.weights0, R, S, Sf, nullptr, b.z_fine, b.z_sorted, b.order, ray_list, ray_count,
+                                                stream));
+    }
     DANBO_TRY(cull(b.z_fine, Sf, b.bits_b, b.count + 1));
     DANBO_TRY(network(b.z_fine, Sf, b.bits_b, b.count + 1, b.raw_b));
     return danbo_composite_merged_fwd(b.raw_a, b.raw_b, b.raw_empty, b.bits_a, b.bits_b, b.order, b.z_sorted, r->rays_d, R, S, Sf,

@@ -590,14 +590,11 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __res
 // ======================================================================================
 // raw fill / merge
 // ======================================================================================
-// skip (optional): per-ray flags -- the rows of a flagged ray (a ray of constants: nobody reads them) are left alone
 __global__ __launch_bounds__(256) void k_fill_raw(const float4* __restrict__ raw_empty, int R, int S,
-                                                  const uint32_t* __restrict__ skip, float4* __restrict__ raw) {
+                                                  float4* __restrict__ raw) {
     const long M = (long)R * S;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
-        const long r = m / S;
-        if (skip == nullptr || skip[r] == 0u) raw[m] = raw_empty[r];
-    }
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x)
+        raw[m] = raw_empty[m / S];
 }
 
 __global__ __launch_bounds__(256) void k_merge_samples(const float* __restrict__ a, const float* __restrict__ b,
@@ -678,7 +675,10 @@ __device__ __forceinline__ float ray_norm(const float* __restrict__ rays_d, int 
     return sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz_, dz_)));
 }
 
-__global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ raw, const float* __restrict__ z,
+// raw_empty / bits (optional, together): samples whose in-volume word is 0 were never written by K3 and take the ray's
+// empty-space raw (the convention of the fused composites); ray_list / ray_count (optional): only the listed rays
+__global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ raw, const float4* __restrict__ raw_empty,
+                                                   const uint32_t* __restrict__ bits, const float* __restrict__ z,
                                                    const float* __restrict__ rays_d, int R, int S, float B,
                                                    const float* __restrict__ noise, float* __restrict__ rgb_map,
                                                    float* __restrict__ disp, float* __restrict__ acc_out,
@@ -691,6 +691,7 @@ __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ ra
     for (int i = wave; i < n; i += nwaves) {
         const int r = ray_list ? min(max(ray_list[i], 0), R - 1) : i;
         const float dn = ray_norm(rays_d, r);
+        const float4 re = bits ? raw_empty[r] : float4{0.f, 0.f, 0.f, 0.f};
         CompositeState st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int s = c0 + lane;
@@ -698,8 +699,10 @@ __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ ra
             const size_t m = (size_t)r * S + (act ? s : S - 1);
             const float zs = z[m];
             const float gap = (s + 1 < S) ? sub_rn(z[m + 1], zs) : 1e10f;
+            float4 rw = re;
+            if (bits == nullptr || bits[m] != 0u) rw = raw[m];
             float al;
-            const float w = composite_chunk(st, raw[m], zs, gap, dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
+            const float w = composite_chunk(st, rw, zs, gap, dn, B, noise != nullptr, noise ? noise[m] : 0.f, act, lane, al);
             if (act) {
                 if (weights) weights[m] = w;
                 if (alpha_out) alpha_out[m] = al;
@@ -1333,17 +1336,11 @@ extern "C" int danbo_bone_gather_fwd(const float* rays_o, const float* rays_d, c
     DANBO_LAUNCH_RET();
 }
 
-static int fill_raw_impl(const float* raw_empty, int R, int S, const uint32_t* skip, float* raw, void* stream) {
+extern "C" int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0);
     hipLaunchKernelGGL(k_fill_raw, dim3(stream_grid((long)R * S, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(raw_empty), R, S, skip, reinterpret_cast<float4*>(raw));
+                       reinterpret_cast<const float4*>(raw_empty), R, S, reinterpret_cast<float4*>(raw));
     DANBO_LAUNCH_RET();
-}
-extern "C" int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream) {
-    return fill_raw_impl(raw_empty, R, S, nullptr, raw, stream);
-}
-extern "C" int danbo_fill_raw_rays(const float* raw_empty, int R, int S, const uint32_t* skip, float* raw, void* stream) {
-    return fill_raw_impl(raw_empty, R, S, skip, raw, stream);
 }
 
 extern "C" int danbo_merge_samples(const float* a, const float* b, const int32_t* sorted_idx, int R, int S, int Sf,
@@ -1354,26 +1351,29 @@ extern "C" int danbo_merge_samples(const float* a, const float* b, const int32_t
     DANBO_LAUNCH_RET();
 }
 
-static int composite_impl(const float* raw, const float* z, const float* rays_d, int R, int S, float B, const float* noise,
-                          float* rgb_map, float* disp, float* acc, float* weights, float* alpha, const int32_t* ray_list,
-                          const int32_t* ray_count, void* stream) {
+static int composite_impl(const float* raw, const float* raw_empty, const uint32_t* bits, const float* z, const float* rays_d, int R,
+                          int S, float B, const float* noise, float* rgb_map, float* disp, float* acc, float* weights, float* alpha,
+                          const int32_t* ray_list, const int32_t* ray_count, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && B > 0.f);
-    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
+    DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr) && (bits == nullptr || raw_empty != nullptr));
     static const int per_launch = resident_grid(k_composite, 1L << 40, 256);
     const int grid = (int)std::min<long>(ceil_div((long)R * 64, 256), per_launch);
-    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(raw), z,
-                       rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, ray_list, ray_count);
+    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(raw),
+                       reinterpret_cast<const float4*>(raw_empty), bits, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha,
+                       ray_list, ray_count);
     DANBO_LAUNCH_RET();
 }
 extern "C" int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
                                     const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
                                     float* alpha, void* stream) {
-    return composite_impl(raw, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, nullptr, nullptr, stream);
+    return composite_impl(raw, nullptr, nullptr, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, nullptr, nullptr, stream);
 }
-extern "C" int danbo_composite_rays_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
-                                         const float* noise, float* rgb_map, float* disp, float* acc, float* weights,
-                                         float* alpha, const int32_t* ray_list, const int32_t* ray_count, void* stream) {
-    return composite_impl(raw, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, ray_list, ray_count, stream);
+extern "C" int danbo_composite_rays_fwd(const float* raw, const float* raw_empty, const uint32_t* valid_bits, const float* z,
+                                         const float* rays_d, int R, int S, float B, const float* noise, float* rgb_map,
+                                         float* disp, float* acc, float* weights, float* alpha, const int32_t* ray_list,
+                                         const int32_t* ray_count, void* stream) {
+    return composite_impl(raw, raw_empty, valid_bits, z, rays_d, R, S, B, noise, rgb_map, disp, acc, weights, alpha, ray_list, ray_count,
+                          stream);
 }
 
 static int importance_impl(const float* z, const float* weights, int R, int S, int Sf, const float* u, float* z_fine,

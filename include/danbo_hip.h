@@ -33,7 +33,7 @@ extern "C" {
  * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
  * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, danbo_flat_rays;
  * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
- * danbo_fill_raw_rays, danbo_composite_rays_fwd, danbo_importance_samples_rays. */
+ * danbo_composite_rays_fwd, danbo_importance_samples_rays; danbo_render_frame takes up to 256 + 64 samples per ray. */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -250,9 +250,6 @@ int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count
 
 /* raw[r,s,:] = raw_empty[r,:] (broadcast fill before K3 scatters the in-volume rows) */
 int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream);
-/* the same, leaving alone the rows of the rays with skip[r] != 0 (danbo_ray_bone_mask's ray_flat: the rays of constants, whose
- * raw rows nobody reads -- danbo_flat_rays); skip NULL = danbo_fill_raw */
-int danbo_fill_raw_rays(const float* raw_empty, int R, int S, const uint32_t* skip /*[R]*/, float* raw, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K4  NeRF.raw2outputs (core/networks/nerf.py:281-347), relu density, one wavefront per ray.
@@ -262,12 +259,14 @@ int danbo_fill_raw_rays(const float* raw_empty, int R, int S, const uint32_t* sk
 int danbo_composite_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
                         const float* noise, float* rgb_map, float* disp, float* acc,
                         float* weights, float* alpha, void* stream);
-/* the same over a list of rays (ray_list / ray_count together, or both NULL = danbo_composite_fwd): only the listed rays
- * (danbo_flat_rays' list; *ray_count is read on the device) are composited, every output row of an unlisted ray is left
- * untouched -- the path of rays too long for danbo_composite_importance_fwd (S > 64) */
-int danbo_composite_rays_fwd(const float* raw, const float* z, const float* rays_d, int R, int S, float B,
-                             const float* noise, float* rgb_map, float* disp, float* acc, float* weights, float* alpha,
-                             const int32_t* ray_list, const int32_t* ray_count, void* stream);
+/* the same with danbo_composite_importance_fwd's two conventions, for rays too long for that call (S > 64):
+ * valid_bits / raw_empty (optional, together): samples whose in-volume word is 0 were not written to raw and take raw_empty[ray];
+ * ray_list / ray_count (optional, together): only the listed rays (danbo_flat_rays' list; *ray_count is read on the device) are
+ * composited, every output row of an unlisted ray is left untouched.  All four NULL = danbo_composite_fwd. */
+int danbo_composite_rays_fwd(const float* raw, const float* raw_empty /*[R,4]*/, const uint32_t* valid_bits /*[R,S]*/, const float* z,
+                             const float* rays_d, int R, int S, float B, const float* noise, float* rgb_map, float* disp,
+                             float* acc, float* weights, float* alpha, const int32_t* ray_list, const int32_t* ray_count,
+                             void* stream);
 
 /* K4 backward: gradients of rgb_map [R,3] and acc_map [R] -> d raw [R,S,4] (S <= 256).  disp_map,
  * weights and alpha carry no gradient in the reference's losses (core/trainer.py:396-422,507-536). */
@@ -329,7 +328,7 @@ int danbo_composite_importance_fwd(const float* raw /*[R,S,4]*/, const float* ra
  * row to t_lo (so that the importance pass's danbo_bone_cull drops them on their mask; their z_sorted / sorted_idx rows are never
  * made), and appends every OTHER ray to ray_list / *ray_count (zeroed by the caller), to be passed to danbo_view_consts,
  * danbo_composite_importance_fwd and danbo_composite_merged_fwd (any S, Sf; rays of more than 64 coarse samples:
- * danbo_fill_raw_rays with the flags, danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_composite_merged_fwd).  All maps / alphas / weights of the frame are then bit-identical
+ * danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_composite_merged_fwd).  All maps / alphas / weights of the frame are then bit-identical
  * to evaluating every ray; a caller that wants z_fine / z_sorted / sorted_idx / cview / raw_empty of every ray, density noise, or
  * cannot state (a) and (b), must not use it.
  * parts: 1 = the list and the per-ray outputs (a few us: what danbo_view_consts waits for), 2 = the per-sample rows (weights0 /
@@ -694,7 +693,7 @@ typedef struct DanboFrameOut {   /* the dict of render_rays: final maps, then th
 } DanboFrameOut;
 
 size_t danbo_render_frame_workspace(int R, int G, int S, int Sf, int chunk, int graph_width);
-/* S, Sf <= 64.  Enqueues ~25 kernels on `stream`; workspace: danbo_render_frame_workspace bytes of device memory. */
+/* 3 <= S <= 256, Sf <= 64 (S <= 64: the fused composite + resampling launch).  Enqueues ~25 kernels on `stream`; workspace: danbo_render_frame_workspace bytes of device memory. */
 int danbo_render_frame(const DanboModel* model, const DanboRays* rays, int S, int Sf, const DanboFrameOut* out, void* workspace,
                        size_t workspace_bytes, void* stream);
 

@@ -492,6 +492,17 @@ def test_render_frame_c_entry_point_equals_the_python_chain():
     want, got = eng.render(*args, 32, 16, chunk=4096), eng.render_frame_c(*args, 32, 16, chunk=4096)
     assert all(torch.equal(want[k], got[k]) for k in want)
     eng.cfg["use_volume_near_far"] = False
+    # rays of more than 64 coarse samples (BASELINE config 3: 96 + 32): the unfused composite / resampling pair, also behind the call
+    for S, Sf in ((96, 32), (200, 64)):
+        want, got = eng.render(*args, S, Sf, chunk=4096), eng.render_frame_c(*args, S, Sf, chunk=4096)
+        assert all(torch.equal(want[k], got[k]) for k in want), (S, Sf)
+    eng.skip_flat_rays = False
+    try:
+        want, got = eng.render(*args, 96, 32, chunk=4096), eng.render_frame_c(*args, 96, 32, chunk=4096)
+    finally:
+        eng.skip_flat_rays = True
+    assert all(torch.equal(want[k], got[k]) for k in want)
+    assert _hip.lib().danbo_render_frame(None, None, 257, 16, None, None, 0, None) == -22
     assert _hip.lib().danbo_render_frame_workspace(6000, 1, 48, 16, 4096, 128) > 6000 * 64 * 16
     assert _hip.lib().danbo_render_frame(None, None, 48, 16, None, None, 0, None) == -22
 
@@ -668,9 +679,6 @@ def test_rays_of_constants_of_long_rays_are_bitwise_the_full_render(stage, S, Sf
     assert int(flat.sum()) > R // 2 and int(fr["ray_count"].item()) == R - int(flat.sum())
     view = eng.view_constants(args[1], args[2], args[5])
     B = eng.cfg["density_scale"]
-    raw = ops_.fill_raw(view[1], S, skip=rm[3])
-    full = ops_.fill_raw(view[1], S)
-    assert torch.equal(raw[~flat], full[~flat])
     out0 = ops_.composite(c["raw_coarse"], c["z_coarse"], args[1], B, flat=fr)
     for k, k0 in (("rgb_map", "rgb0"), ("disp_map", "disp0"), ("acc_map", "acc0"), ("alpha", "alpha0"), ("weights", "weights_coarse")):
         assert torch.equal(out0[k], c[k0]), k
@@ -680,6 +688,14 @@ def test_rays_of_constants_of_long_rays_are_bitwise_the_full_render(stage, S, Sf
     out = ops_.composite_merged(c["raw_coarse"], c["raw_fine"], order, z_all, args[1], B, flat=fr)
     for k, k0 in (("rgb_map", "rgb_map"), ("disp_map", "disp_map"), ("acc_map", "acc_map"), ("alpha", "alpha"), ("weights", "T_i")):
         assert torch.equal(out[k], c[k0]), k
+    # un-filled raw (rows outside every volume hold garbage: NaN here) + the in-volume words: the same composite, with and without a list
+    junk = torch.where((c["valid_bits"].view(R, S, 1) != 0), c["raw_coarse"], torch.full_like(c["raw_coarse"], float("nan")))
+    lazy = ops_.composite(junk, c["z_coarse"], args[1], B, bits=c["valid_bits"], raw_empty=view[1])
+    fr2 = ops_.flat_rays(rm[1], rm[3], S, Sf, want_weights=True)
+    lazy_l = ops_.composite(junk, c["z_coarse"], args[1], B, bits=c["valid_bits"], raw_empty=view[1], flat=fr2)
+    for k, k0 in (("rgb_map", "rgb0"), ("disp_map", "disp0"), ("acc_map", "acc0"), ("alpha", "alpha0"), ("weights", "weights_coarse")):
+        assert torch.equal(lazy[k], c[k0]), k
+        assert torch.equal(lazy_l[k], c[k0]), k
 
 
 def eng_ops(eng):
