@@ -646,6 +646,52 @@ def test_render_without_resampling_of_rays_that_miss_every_volume_is_bitwise_the
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S,Sf", [(24, 12), (96, 32)])
+def test_frames_of_only_rays_of_constants_and_of_none(stage, S, Sf):
+    """the two ends of the ray list: a batch in which EVERY ray is a ray of constants (empty list, no in-volume row in either pass:
+    every per-row kernel is launched on a device-side count of 0) and a batch in which NONE is (the list holds every ray), ragged
+    batch sizes (1, 63, 257 rays) included -- each bit-identical to the render that evaluates every ray, in Python and behind the
+    C call"""
+    from core.utils import synthetic as syn
+    eng = stage["eng"]
+    scene = syn.make_scene(n_poses=1, H=80, W=80, n_views=1, pose_seed=11)
+    ro, rd = T(scene["rays"][0][0]), T(scene["rays"][0][1])
+    skts, bones, cyls = T(scene["skts"]), T(scene["bones"]), T(scene["cyls"])
+    ops_ = eng_ops(eng)
+    eng.refresh()
+    near, far = eng.near_far(ro, rd, cyls, skts)
+    rm = ops_.ray_bone_mask(ro, rd, skts, eng.align, eng.axis_scale, near, far, want_flat=True)
+    flat = rm[3] != 0
+    assert int(flat.sum()) > 300 and int((~flat).sum()) > 300
+    keys = ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "disp0", "acc0", "alpha0")
+    for sel, n_flat_of in ((flat, lambda n: n), (~flat, lambda n: 0)):
+        idx_all = torch.nonzero(sel).reshape(-1)
+        for n in (1, 63, 257, len(idx_all)):
+            idx = idx_all[:n]
+            args = (ro[idx].contiguous(), rd[idx].contiguous(), skts, bones, cyls, torch.zeros(n, dtype=torch.int64, device=DEV))
+            nf = (near[idx].contiguous(), far[idx].contiguous())        # the frame's bounds (a sub-batch has another chunk nan-mean)
+            a = eng.render(*args, S, Sf, near_far=nf)
+            eng.skip_flat_rays = False
+            try:
+                b = eng.render(*args, S, Sf, near_far=nf)
+            finally:
+                eng.skip_flat_rays = True
+            c = eng.render(*args, S, Sf, near_far=nf, keep=True)
+            for k in keys:
+                assert torch.equal(a[k], b[k]), (k, n)
+                assert torch.equal(a[k], c[k]), (k, n)
+            want, got = eng.render(*args, S, Sf), eng.render_frame_c(*args, S, Sf)       # (their own bounds of the sub-batch)
+            assert all(torch.equal(want[k], got[k]) for k in want), n
+            rm_n = ops_.ray_bone_mask(args[0], args[1], skts, eng.align, eng.axis_scale, nf[0], nf[1], want_flat=True)
+            assert int(rm_n[3].sum()) == n_flat_of(n)
+            if n_flat_of(n) == n:
+                assert int(c["count_coarse"].item()) == 0 and int(c["count_fine"].item()) == 0
+                assert float(a["acc_map"].abs().max()) == 0.0 and float(a["alpha"].abs().max()) == 0.0
+            elif n == len(idx_all):        # (a candidate bone is not yet an in-volume sample: not asked of the small batches)
+                assert int(c["count_coarse"].item()) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S,Sf", [(96, 32), (130, 64), (256, 16)])
 def test_rays_of_constants_of_long_rays_are_bitwise_the_full_render(stage, S, Sf):
     """rays of more than 64 coarse samples (BASELINE config 3: 96 + 32) go through the unfused composites; the rays of constants
