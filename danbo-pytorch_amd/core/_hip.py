@@ -73,6 +73,8 @@ SIGNATURES = {
     "danbo_assign_blend_bwd": [P, P],
     "danbo_pose_volumes_bwd": [P, I, I, I] + [P] * 24,
     "danbo_adam_step": [P, P, P, P, c_long, F, F, F, F, F, F, F, P],
+    "danbo_random_draws": [P, c_long, P, c_long, F, P, P],
+    "danbo_gather_rows": [P, I, P, P],
     "danbo_trunk_pack": [P, P],
     "danbo_trunk_fwd": [P, P, I, P],
     "danbo_trunk_bwd": [P, P, P],
@@ -101,6 +103,13 @@ class DanboModel(ctypes.Structure):
                                     "mean_code", "code_table", "empty_consts")]
                 + [(n, I) for n in ("n_codes", "code_size", "L_view", "ray_mode", "normalise")]
                 + [("density_scale", F), ("use_volume_near_far", I), ("flat_rays_ok", I)])
+
+
+MAX_ROW_SPANS = 12
+
+
+class DanboRowSpan(ctypes.Structure):
+    _fields_ = [("src", P), ("dst_word", c_long), ("src_row_stride_words", c_long), ("rows", I), ("row_words", I)]
 
 
 class DanboRays(ctypes.Structure):

@@ -449,6 +449,47 @@ def composite_merged(raw_a, raw_b, idx, z_sorted, rays_d, B=1.0, noise=None, bit
     return out
 
 
+def random_draws(state, n_uniform, n_normal, normal_std=1.0):
+    """danbo_random_draws (include/danbo_hip.h): -> (uniform [n_uniform] in [0, 1), normal [n_normal] ~ N(0, std^2)), either None
+    for a count of 0; state: int64 [3] device tensor (seed, counter, 0) that the kernel advances"""
+    assert state.dtype == torch.int64 and state.numel() == 3 and state.is_cuda
+    dev = state.device
+    u = torch.empty(n_uniform, device=dev, dtype=torch.float32) if n_uniform else None
+    nz = torch.empty(n_normal, device=dev, dtype=torch.float32) if n_normal else None
+    _call("danbo_random_draws", _p(state), int(n_uniform), _p(u), int(n_normal), float(normal_std), _p(nz), _stream())
+    return u, nz
+
+
+def row_span(t):
+    """(tensor to keep alive, rows, words per row, row stride in words) of a tensor whose rows (dim 0) may be strided but are
+    contiguous inside (4- or 8-byte elements); anything else is made contiguous first"""
+    assert t.element_size() in (4, 8)
+    k = t.element_size() // 4
+    if t.dim() == 0:
+        t = t.reshape(1)
+    inner = t[0] if t.shape[0] > 0 else t
+    if not (t.shape[0] > 0 and inner.is_contiguous() and t.stride(0) >= 0):
+        t = t.contiguous()
+        inner = t[0]
+    return t, t.shape[0], inner.numel() * k, t.stride(0) * k
+
+
+def gather_rows(dst, items):
+    """danbo_gather_rows: items = [(tensor, first 32-bit word in dst), ...] (<= 12; rows of any stride, see row_span) -> dst,
+    a contiguous 4-byte-element buffer, in one launch"""
+    assert dst.is_contiguous() and dst.element_size() == 4 and len(items) <= _hip.MAX_ROW_SPANS
+    spans = (_hip.DanboRowSpan * len(items))()
+    keep = []
+    for i, (t, off) in enumerate(items):
+        t, rows, words, stride = row_span(t)
+        assert off + rows * words <= dst.numel()
+        keep.append(t)
+        spans[i] = _hip.DanboRowSpan(src=t.data_ptr(), dst_word=int(off), src_row_stride_words=int(stride), rows=int(rows),
+                                     row_words=int(words))
+    _call("danbo_gather_rows", spans, len(items), _p(dst), _stream())
+    return dst
+
+
 def merge_samples(a, b, idx):
     """a [R,S,C], b [R,Sf,C], idx int32 [R,S+Sf] -> [R,S+Sf,C]"""
     R, S = a.shape[:2]

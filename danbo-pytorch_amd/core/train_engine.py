@@ -126,6 +126,7 @@ class DanboTrainEngine:
         self.t = self._optimizer_step_count()
         self._buffers = {}
         self._ws = None
+        self._rng_state, self._rng_seed = None, None     # danbo_random_draws' device-side state (see _rng)
         self._model_struct = None
         self.graph = None           # (key, CUDAGraph, static inputs, outputs)
         self.use_graph = True
@@ -211,14 +212,19 @@ class DanboTrainEngine:
                 raise ValueError("fixed_draws without t_rand / u_rand while perturb > 0: the step would run unperturbed")
             if raw_noise_std > 0. and ('noise_c' not in rnd or 'noise_f' not in rnd):
                 raise ValueError("fixed_draws without noise_c / noise_f while raw_noise_std > 0: the step would run without noise")
-        elif perturb > 0.:
-            u = torch.rand(R * (S + Sf), device=dev)
-            rnd['_u'] = u
-            rnd['t_rand'], rnd['u_rand'] = u[:R * S].view(R, S), u[R * S:].view(R, Sf)
-        if self.fixed_draws is None and raw_noise_std > 0.:
-            nz = torch.empty(R * (2 * S + Sf), device=dev).normal_(0.0, raw_noise_std * B)      # randn * std * B in one launch
-            rnd['_n'] = nz
-            rnd['noise_c'], rnd['noise_f'] = nz[:R * S].view(R, S), nz[R * S:].view(R, S + Sf)
+        elif perturb > 0. or raw_noise_std > 0.:
+            # ONE launch (danbo_random_draws: Philox4x32-10, its counter on the device, advanced by the kernel -- a replayed graph
+            # draws fresh numbers by itself; torch's generators in a captured graph cost two fill launches per replay + a launch
+            # per distribution, all in front of the step's first kernel): uniforms [R, S + Sf], normals * std * B [R, 2 S + Sf]
+            from . import hip_ops
+            u, nz = hip_ops.random_draws(self._rng(), R * (S + Sf) if perturb > 0. else 0,
+                                         R * (2 * S + Sf) if raw_noise_std > 0. else 0, raw_noise_std * B)
+            if u is not None:
+                rnd['_u'] = u
+                rnd['t_rand'], rnd['u_rand'] = u[:R * S].view(R, S), u[R * S:].view(R, Sf)
+            if nz is not None:
+                rnd['_n'] = nz
+                rnd['noise_c'], rnd['noise_f'] = nz[:R * S].view(R, S), nz[R * S:].view(R, S + Sf)
         out = dict(rgb_map=(R, 3), disp_map=(R,), acc_map=(R,), alpha=(R, S + Sf), weights=(R, S + Sf), rgb0=(R, 3), disp0=(R,),
                    acc0=(R,), alpha0=(R, S), loss=(4,))
         out = {k: torch.empty(v, device=dev, dtype=torch.float32) for k, v in out.items()}
@@ -246,9 +252,35 @@ class DanboTrainEngine:
                                                      self._ws.numel(), int(phase),
                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_train_step")
 
+    def _rng(self):
+        """the device-side generator state of danbo_random_draws (seed, counter, 0).  Seeded from torch's CUDA generator of this
+        device the first time it is needed -- torch.manual_seed / torch.cuda.manual_seed before that (run_nerf.py: rank + 1) give
+        every rank its own stream -- and again whenever that seed has CHANGED since; reseed() restarts it explicitly."""
+        seed = int(torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()].initial_seed())
+        if self._rng_state is None:
+            self._rng_state = torch.zeros(3, device=self.device, dtype=torch.int64)
+            self._rng_seed = None
+        if seed != self._rng_seed:
+            self.reseed(seed)
+        return self._rng_state
+
+    def reseed(self, seed):
+        """restart the step's random stream at (seed, counter 0); the state tensor stays where it is (captured graphs hold it)"""
+        seed = int(seed) & ((1 << 64) - 1)
+        if self._rng_state is None:
+            self._rng_state = torch.zeros(3, device=self.device, dtype=torch.int64)
+        self._rng_seed = seed
+        self._rng_state.copy_(torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, 0, 0], dtype=torch.int64))
+
     @staticmethod
-    def _static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx, target, bgs, near_in, far_in):
-        f = lambda x: None if x is None else x.detach().float().contiguous()  # noqa: E731
+    def _static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx, target, bgs, near_in, far_in, contiguous=True):
+        # contiguous=False: rows (dim 0) may stay strided -- the graph path gathers them itself (danbo_gather_rows), e.g. the
+        # trainer's per-pose slices x[::R / G] of the loader's per-ray tensors
+        def f(x):
+            if x is None:
+                return None
+            x = x.detach().float()
+            return x.contiguous() if contiguous else x
         t = dict(rays_o=f(rays_o), rays_d=f(rays_d), skts=f(skts), bones=f(bones), cyls=f(cyls), target=f(target), bgs=f(bgs),
                  near_in=f(near_in), far_in=f(far_in))
         t['cam_idx'] = None if cam_idx is None else cam_idx.reshape(-1).to(torch.int64).contiguous()
@@ -258,28 +290,33 @@ class DanboTrainEngine:
                          near_in=None, far_in=None, split=False):
         """One batch: per-pose skts [G,24,4,4] / bones [G,24,3] / cyls [G,5]; per-ray everything else.  Gradients land in
         `flat_grad` (the parameters' .grad views); -> dict(rgb_map, ..., loss [4], counts [8])."""
+        graphed = self.use_graph and self.fixed_draws is None    # supplied draws are per-step inputs: never captured into a graph
+        if self.fixed_draws is None and (perturb > 0. or raw_noise_std > 0.):
+            self._rng()                                          # (re)seeding copies host -> device: never inside a capture
         t = self._static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx if self.net.use_framecode else None, target, bgs,
-                                near_in, far_in)
+                                near_in, far_in, contiguous=not graphed)
         if t.get('bgs') is not None and t['bgs'].numel() != t['target'].numel():
             t['bgs'] = t['bgs'].expand_as(t['target']).contiguous()
-        if not self.use_graph or self.fixed_draws is not None:   # supplied draws are per-step inputs: never captured into a graph
+        if not graphed:
             out = self._launch(t, S, Sf, perturb, raw_noise_std, split)
             self._pending = (out, None) if split else None
             return out
         key = (tuple((k, tuple(v.shape)) for k, v in sorted(t.items())), S, Sf, float(perturb), float(raw_noise_std), bool(split))
         if self.graph is None or self.graph[0] != key:
             # the graph's static inputs are views of ONE flat buffer: a replay is preceded by a single gather of the caller's
-            # tensors (torch.cat, one launch; cam_idx travels as raw 32-bit words) instead of one copy per tensor
-            words = {k: v.reshape(-1).view(torch.float32).numel() for k, v in t.items()}
+            # tensors (danbo_gather_rows, one launch, rows of any stride; cam_idx travels as raw 32-bit words) instead of one
+            # copy per tensor
+            words = {k: v.numel() * (v.element_size() // 4) for k, v in t.items()}
             flat = torch.empty(sum((n + 63) // 64 * 64 for n in words.values()), device=self.device, dtype=torch.float32)
             static, spans, o = {}, [], 0
             for k, v in t.items():
-                static[k] = flat[o:o + words[k]].view(v.dtype).view(v.shape)
+                static[k] = flat[o:o + words[k]].view(v.dtype).view(v.shape)           # (contiguous whatever v's strides are)
                 spans.append((k, o, words[k]))
                 o += (words[k] + 63) // 64 * 64
-            static['_flat'], static['_spans'], static['_pad'] = flat, spans, torch.zeros(64, device=self.device)
+            static['_flat'], static['_spans'] = flat, spans
             self._gather_inputs(static, t)
             cur = torch.cuda.current_stream()
+            rng_before = None if self._rng_state is None else self._rng_state.clone()    # the warm-up's draws are given back
             side = torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):        # eager warm-up off the capture: lazy initialisations, workspace allocation
@@ -296,6 +333,8 @@ class DanboTrainEngine:
                 with torch.cuda.graph(g2):
                     self._step_phase(outs, 2)
             self.graph = (key, g, static, outs, g2)
+            if rng_before is not None:            # a run's random stream does not depend on when (or how often) a graph was built
+                self._rng_state.copy_(rng_before)
         _, g, static, outs, g2 = self.graph
         self._gather_inputs(static, t)
         g.replay()
@@ -304,16 +343,8 @@ class DanboTrainEngine:
 
     @staticmethod
     def _gather_inputs(static, t):
-        flat, spans = static['_flat'], static['_spans']
-        parts, o = [], 0
-        for k, off, n in spans:
-            if off > o:
-                parts.append(static['_pad'][:off - o])            # alignment gap
-            parts.append(t[k].reshape(-1).view(torch.float32))
-            o = off + n
-        if o < flat.numel():
-            parts.append(static['_pad'][:flat.numel() - o])
-        torch.cat(parts, out=flat)
+        from . import hip_ops
+        hip_ops.gather_rows(static['_flat'], [(t[k], off) for k, off, _ in static['_spans']])
 
     def finish_backward(self):
         """second half of a split step (forward_backward(..., split=True)): the dense layers' weight gradients"""

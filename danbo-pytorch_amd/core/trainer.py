@@ -127,7 +127,8 @@ class Trainer:
         kw = self.render_kwargs_train
         batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         G = int(batch['N_uniques'])
-        pp = caster._per_pose
+        # per-pose rows of the loader's per-ray tensors as strided VIEWS: the engine gathers them (one launch for all inputs)
+        pp = lambda x, g: x if x.shape[0] == g else x[::max(x.shape[0] // g, 1)]  # noqa: E731
         S, Sf = int(kw['N_samples']), int(kw['N_importance'])
         grouped = dist.is_available() and dist.is_initialized()
         world = dist.get_world_size() if grouped else 1

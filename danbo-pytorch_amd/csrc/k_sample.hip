@@ -83,6 +83,65 @@ __global__ __launch_bounds__(256) void k_cylinder_pass2(int R, float near0, floa
     }
 }
 
+// Both passes in ONE launch when a chunk fits a workgroup's loop (chunk <= CYL_FUSED_MAX rays): workgroup c owns chunk c, its
+// threads keep their rays' bounds, the chunk's sums are a block reduction (no atomics, no zeroed scratch, a fixed order) and the
+// back-fill follows behind a barrier.  Three launches of ~5 us became one: they sit in front of everything else of a frame / step.
+constexpr int CYL_BLOCK = 1024, CYL_FUSED_MAX = 16 * CYL_BLOCK;
+__global__ __launch_bounds__(CYL_BLOCK) void k_cylinder_chunk(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                              const float* __restrict__ cyl, int R, int G, float near0, float far0,
+                                                              const float* __restrict__ near_in, const float* __restrict__ far_in,
+                                                              int chunk, float* __restrict__ near_out, float* __restrict__ far_out) {
+    __shared__ double s_part[CYL_BLOCK / 64][3];
+    __shared__ double s_sum[3];
+    const int rays_per_pose = R / G;
+    const int r_begin = blockIdx.x * chunk, r_end = min(r_begin + chunk, R);
+    constexpr int PER = CYL_FUSED_MAX / CYL_BLOCK;
+    float nr[PER], fr[PER];
+    double sn = 0.0, sf = 0.0, sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int r = r_begin + k * CYL_BLOCK + (int)threadIdx.x;
+        nr[k] = 0.f; fr[k] = 0.f;
+        if (r < r_end) {
+            const int g = min(r / rays_per_pose, G - 1);
+            const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+            const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+            const float c[3] = {cyl[5 * g], cyl[5 * g + 1], cyl[5 * g + 2]};
+            if (cylinder_bounds(o, d, c, near_in ? near_in[r] : near0, far_in ? far_in[r] : far0, &nr[k], &fr[k])) {
+                sn += (double)nr[k]; sf += (double)fr[k]; sc += 1.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sn += __shfl_xor(sn, off, 64);
+        sf += __shfl_xor(sf, off, 64);
+        sc += __shfl_xor(sc, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = sn; s_part[threadIdx.x >> 6][1] = sf; s_part[threadIdx.x >> 6][2] = sc; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int w = 0; w < CYL_BLOCK / 64; ++w) t += s_part[w][threadIdx.x];
+        s_sum[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const double cnt = s_sum[2];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int r = r_begin + k * CYL_BLOCK + (int)threadIdx.x;
+        if (r < r_end) {
+            float n = nr[k], f = fr[k];
+            if (n != n) {  // ray missed the cylinder: chunk-wide nan-mean (ray_utils.py:330-344)
+                n = cnt > 0.0 ? (float)(s_sum[0] / cnt) : (near_in ? near_in[r] : near0);
+                f = cnt > 0.0 ? (float)(s_sum[1] / cnt) : (far_in ? far_in[r] : far0);
+            }
+            near_out[r] = n;
+            far_out[r] = f;
+        }
+    }
+}
+
 // ======================================================================================
 // per-bone box near / far (fast configs)
 // ======================================================================================
@@ -1257,6 +1316,11 @@ extern "C" int danbo_near_far_cylinder(const float* rays_o, const float* rays_d,
     DANBO_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && chunk > 0 && scratch != nullptr);
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ceil_div(R, chunk);
+    if (chunk <= CYL_FUSED_MAX) {       // (the scratch stays untouched)
+        hipLaunchKernelGGL(k_cylinder_chunk, dim3(nchunk), dim3(CYL_BLOCK), 0, st, rays_o, rays_d, cyl, R, G, near0, far0, near_in,
+                           far_in, chunk, near_out, far_out);
+        DANBO_LAUNCH_RET();
+    }
     zero_words(scratch, 8L * nchunk, nullptr, 0, st);
     const int grid = stream_grid(R, 256);
     hipLaunchKernelGGL(k_cylinder_pass1, dim3(grid), dim3(256), 0, st, rays_o, rays_d, cyl, R, G, near0, far0, near_in,

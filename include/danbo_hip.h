@@ -33,7 +33,8 @@ extern "C" {
  * ABI history: 2 = danbo_adam_step takes the step's scalars by value; 3 = DanboAssignBwd.d_p; 4 = danbo_train_workspace_view,
  * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, danbo_flat_rays;
  * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
- * danbo_composite_rays_fwd, danbo_importance_samples_rays; danbo_render_frame takes up to 256 + 64 samples per ray. */
+ * danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_random_draws, danbo_gather_rows; danbo_render_frame takes up to
+ * 256 + 64 samples per ray. */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -502,6 +503,27 @@ int danbo_pose_volumes_bwd(const float* bones, int G, int L_graph, int W, const 
                            const float* w2, const float* w3, const float* fwd_scratch, const float* d_volumes, float* g_w0,
                            float* g_adj_w0, float* g_b0, float* g_w1, float* g_adj_w1, float* g_b1, float* g_w2, float* g_b2,
                            float* g_w3, float* g_b3, float* bwd_scratch /*>= 2 G 24 W floats*/, void* stream);
+
+/* The random draws of a training step in one launch (csrc/k_step_io.hip) -- what the reference draws with torch.rand
+ * (sample_from_lineseg / isample_from_lineseg, core/utils/ray_utils.py:206-291) and torch.randn * raw_noise_std (NeRF.raw2outputs,
+ * core/networks/nerf.py:316): n_uniform floats in [0, 1) (24 bits) and n_normal floats ~ N(0, normal_std^2) from Philox4x32-10.
+ * state (device, 3 x uint64): [0] seed, [1] counter of the next call, [2] 0 between calls.  The KERNEL advances the counter, so a
+ * captured HIP graph draws fresh numbers on every replay; word j of either stream is a pure function of (seed, counter, j):
+ * uniform[4 i + e] = (philox(counter + i, 0 | seed)[e] >> 8) * 2^-24 (tests/test_gpu_train_engine.py restates it). */
+int danbo_random_draws(uint64_t* state, long n_uniform, float* uniform, long n_normal, float normal_std, float* normal,
+                       void* stream);
+
+/* Rows of up to DANBO_MAX_ROW_SPANS tensors gathered into one flat buffer in one launch (the captured training step's static
+ * inputs; the reference's loader hands over per-ray copies of the per-pose tensors, core/trainer.py:257-302, of which every
+ * (R / G)-th row is taken): span i copies rows x row_words 32-bit words, row r from src + r * src_row_stride_words, to
+ * dst + dst_word (contiguous).  `spans` is a HOST array, read during the call. */
+#define DANBO_MAX_ROW_SPANS 12
+typedef struct DanboRowSpan {
+    const void* src;
+    long dst_word, src_row_stride_words;
+    int rows, row_words;
+} DanboRowSpan;
+int danbo_gather_rows(const DanboRowSpan* spans, int n_spans, void* dst, void* stream);
 
 /* torch.optim.Adam's update (amsgrad = False, weight_decay = 0; core/raycasters.py:75) on a flat parameter buffer.
  * The step's scalars travel BY VALUE as kernel arguments (ABI 2; ABI 1 read them from a device buffer the host had to keep

@@ -80,3 +80,23 @@ def raw_rel_unfloored(a, b, frac=0.1):
     e = float(np.max((np.abs(a - b) / np.maximum(np.abs(b), 1e-300))[big])) if big.any() else 0.0
     print(f"raw_rel_unfloored(|b| > {frac:g} x channel max) = {e:.3e} over {int(big.sum())} of {a.size} values")
     return e
+
+
+# ---- Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), restated for the checks of
+# danbo_random_draws (include/danbo_hip.h): counters [n,4] uint32, key (2,) uint32 -> [n,4] uint32
+def philox4x32_10(ctr, key):
+    c = np.array(ctr, dtype=np.uint64).reshape(-1, 4)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        c = np.stack([((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & mask, p0 & mask], 1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def philox_stream_words(seed, counter, n_quads, stream):
+    """words [n_quads, 4] of danbo_random_draws' stream `stream` (0 uniform, 1 normal) for quads counter .. counter + n_quads"""
+    idx = (np.uint64(counter) + np.arange(n_quads, dtype=np.uint64))
+    ctr = np.stack([idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32), np.full(n_quads, stream, np.uint64), np.zeros(n_quads, np.uint64)], 1)
+    return philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))

@@ -93,6 +93,17 @@ def test_cylinder_nan_backfill_and_box_near_far(ops):
     rb = np.concatenate([ro, rd, np.zeros((len(ro), 1), np.float32), np.ones((len(ro), 1), np.float32)], -1)
     on, of = o.near_far_cylinder(rb[:, 0:3], rb[:, 3:6], scene["cyls"][z], rb[:, 6:7], rb[:, 7:8], chunk=2048)
     assert max_err(N(n2), on[:, 0]) < 3e-6 and max_err(N(f2), of[:, 0]) < 3e-6
+    # ragged chunks of the one-launch kernel (a workgroup per chunk) and a chunk beyond it (the three-launch path, atomics): the
+    # same frame tiled 5 x so that chunks of 20 000 rays exist; a miss anywhere is back-filled with ITS chunk's mean
+    ro5, rd5 = np.tile(ro, (5, 1)), np.tile(rd, (5, 1))
+    rb5 = np.concatenate([ro5, rd5, np.zeros((len(ro5), 1), np.float32), np.ones((len(ro5), 1), np.float32)], -1)
+    assert int(np.isnan(o.near_far_cylinder(rb5[:, 0:3], rb5[:, 3:6], scene["cyls"][np.zeros(len(ro5), dtype=np.int64)],
+                                            rb5[:, 6:7], rb5[:, 7:8], chunk=10 ** 9)[0]).sum()) == 0
+    for chunk in (1000, 1024, 3000, 16384, 20000):
+        n5, f5 = ops.near_far_cylinder(T(ro5), T(rd5), T(scene["cyls"]), 0.0, 1.0, chunk)
+        on, of = o.near_far_cylinder(rb5[:, 0:3], rb5[:, 3:6], scene["cyls"][np.zeros(len(ro5), dtype=np.int64)], rb5[:, 6:7], rb5[:, 7:8],
+                                     chunk=chunk)
+        assert max_err(N(n5), on[:, 0]) < 3e-6 and max_err(N(f5), of[:, 0]) < 3e-6, chunk
     eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(orc.align))
     nb, fb = eng.near_far(T(ro), T(rd), T(scene["cyls"]), T(scene["skts"]))
     assert max_err(N(nb), g["near"][:, 0]) < 3e-5 and max_err(N(fb), g["far"][:, 0]) < 3e-5

@@ -536,3 +536,95 @@ def test_fused_step_flag_variants_equal_the_autograd_path(fixture, extra):
     for n, r in grads["autograd"].items():      # 5e-3 of the tensor's max, as against the reference's autograd (axis_scale: 2e-3)
         a = grads["fused"][n]
         assert float((a - r).abs().max()) <= 5e-3 * float(r.abs().max()) + 1e-10, (n, float((a - r).abs().max()), float(r.abs().max()))
+
+
+def test_random_draws_are_the_philox_streams_and_the_kernel_advances_its_counter():
+    """danbo_random_draws: uniforms bit for bit the restated Philox4x32-10 stream (tests/helpers.py, pinned to the Random123
+    known answers on the CPU), normals its Box-Muller pairs; the device-side counter moves by the quads drawn, so the next call
+    -- or the next replay of a captured graph -- continues the stream; ragged counts; moments of a large draw"""
+    from core import hip_ops as ops
+    from helpers import philox_stream_words
+    seed = 0x1234_5678_9ABC_DEF0
+    state = torch.tensor([seed, 5, 0], dtype=torch.int64, device="cuda")
+    counter = 5
+    for nu, nn, std in ((1003, 2050, 1.5), (4096, 0, 1.0), (0, 777, 0.25), (3, 1, 1.0)):
+        u, z = ops.random_draws(state, nu, nn, std)
+        quads = (max(nu, nn) + 3) // 4
+        if nu:
+            want = (philox_stream_words(seed, counter, quads, 0).reshape(-1)[:nu] >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+            assert np.array_equal(u.cpu().numpy(), want)
+            assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+        if nn:
+            w = philox_stream_words(seed, counter, quads, 1).reshape(-1, 2).astype(np.float64)
+            u1, u2 = ((w[:, 0].astype(np.uint64) >> 8) + 1) * 2.0 ** -24, (w[:, 1].astype(np.uint64) >> 8) * 2.0 ** -24
+            rad = np.sqrt(-2.0 * np.log(u1)) * std
+            want = np.stack([rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)], 1).reshape(-1)[:nn]
+            assert np.abs(z.cpu().numpy() - want).max() < 2e-5 * std * 6
+        counter += quads
+        assert state.cpu().tolist() == [seed, counter, 0]
+    state = torch.tensor([7, 0, 0], dtype=torch.int64, device="cuda")
+    u, z = ops.random_draws(state, 1 << 22, 1 << 22, 2.0)
+    u, z = u.double(), z.double()
+    assert abs(float(u.mean()) - 0.5) < 1e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.var()) - 4.0) < 2e-2 and abs(float((z ** 4).mean()) / 16.0 - 3.0) < 5e-2
+    assert len(torch.unique(u)) > (1 << 22) * 0.85            # (24-bit grid: birthday collisions only)
+    u2, _ = ops.random_draws(state, 1 << 22, 0, 1.0)
+    assert not torch.equal(u2.double(), u) and state.cpu().tolist() == [7, 2 * (1 << 20), 0]
+    assert ops._hip.lib().danbo_random_draws(None, 4, None, 0, 1.0, None, None) == -22
+
+
+def test_gather_rows_collects_strided_rows_of_several_tensors():
+    """danbo_gather_rows: one launch gathers rows of any stride (the trainer's per-pose slices of per-ray tensors), 8-byte elements
+    as word pairs, broadcast rows (stride 0), into one flat buffer at the given word offsets"""
+    from core import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(3072, 24, 4, 4, generator=g).cuda()
+    b = torch.randn(3072, 24, 3, generator=g).cuda()
+    c = torch.randn(3072, 5, generator=g).cuda()
+    d = torch.randint(0, 1 << 40, (3072,), generator=g).cuda()
+    e = torch.randn(1, 3, generator=g).cuda().expand(3072, 3)
+    f = torch.randn(50, 7, generator=g).cuda().t()                     # inner dim not contiguous: copied by the wrapper
+    items = [a[::192], b[::192], c[::192], d, e, f, a[5:6]]
+    offs, o = [], 0
+    for t in items:
+        offs.append(o)
+        o += (t.numel() * (t.element_size() // 4) + 63) // 64 * 64
+    dst = torch.full((o,), float("nan"), device="cuda")
+    ops.gather_rows(dst, list(zip(items, offs)))
+    for t, off in zip(items, offs):
+        n = t.numel() * (t.element_size() // 4)
+        got = dst[off:off + n].view(t.dtype).view(t.shape)
+        assert torch.equal(got, t.contiguous())
+        pad = dst[off + n:off + (n + 63) // 64 * 64]
+        assert bool(torch.isnan(pad).all())                             # gaps are left alone
+    assert ops._hip.lib().danbo_gather_rows(None, 1, None, None) == -22
+
+
+def test_captured_step_draws_fresh_numbers_every_replay_and_follows_the_seed():
+    """the step's random numbers come from danbo_random_draws inside the captured graph: every replay perturbs differently, the
+    same seed gives the same sequence of steps (reseed), another seed another one"""
+    g = golden("danbo_perfcap_train")
+    args, caster, trainer, opt = build_trainer(g, extra=["--raw_noise_std", "1.0", "--perturb", "1.0"])
+    assert trainer.fused_engine() is not None
+    eng = trainer.engine
+    b = batch_of(g)
+
+    def steps(n):
+        seq = []
+        for i in range(n):
+            trainer.train_batch(b, i=i, global_step=i, sync_stats=False)
+            rnd = trainer.last_preds["_keep"][0]
+            seq.append((rnd["t_rand"].clone(), rnd["noise_f"].clone(), trainer.last_preds["rgb_map"].clone()))
+        return seq
+    torch.manual_seed(3)
+    s1 = steps(4)
+    assert eng.graph is not None
+    for i in range(1, 4):
+        assert not torch.equal(s1[i][0], s1[i - 1][0]) and not torch.equal(s1[i][1], s1[i - 1][1])
+    assert float(s1[0][0].min()) >= 0 and float(s1[0][0].max()) < 1 and 0.5 < float(s1[0][1].std()) < 2.0
+    eng.reseed(torch.cuda.initial_seed())
+    s2 = steps(2)
+    assert torch.equal(s2[0][0], s1[0][0]) and torch.equal(s2[1][1], s1[1][1])          # the same draws (the weights have moved on)
+    torch.manual_seed(4)
+    s3 = steps(1)
+    assert not torch.equal(s3[0][0], s1[0][0])

@@ -535,3 +535,13 @@ def test_fused_engine_adam_state_resumes_under_plain_adam(tmp_path):
     assert all(float(s) == t + 1 for s in steps2) and len({s.data_ptr() for s in steps2}) == len(params)
     assert torch.equal(flat_m2[offsets[1]:offsets[1] + 7], opt2.state[params2[1]]["exp_avg"].reshape(-1))
     assert flat_m2.abs().sum() > 0 and opt2.state[params2[0]]["exp_avg"].data_ptr() == flat_m2.data_ptr()
+
+
+def test_philox_restatement_known_answers():
+    """the numpy Philox4x32-10 the GPU draw kernel is checked against (tests/helpers.py), on the Random123 known-answer vectors"""
+    from helpers import philox4x32_10
+    kat = [([0, 0, 0, 0], (0, 0), [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, (0xffffffff, 0xffffffff), [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0), [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert [int(x) for x in philox4x32_10([ctr], key)[0]] == want
