@@ -460,6 +460,9 @@ def bench_train(args, rank, world, device, dist):
                                "danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
                    "rays": R_global, "rays_per_rank": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
         "rows_per_step": rows, "in_volume_fraction": in_vol / (R_global * S), "loss": float(loss["total_loss"]),
+        "rows_note": "the model TRAINS through the settle phase and the timed blocks (every step is a real Adam update on the same batch), and the "
+                     "bone volumes it learns change how many samples lie inside them: rows_per_step is what the last timed step saw (50 k at "
+                     "the initial weights -- tools/bench_train.py's 25 steps stay there -- 64 k after ~500 steps); the step time follows the rows",
         "roofline": dict(bound="mfma", kernel="k_train_mlp_fwd x 2 + k_train_mlp_bwd + k_dw16 (whole step)", achieved=achieved / 1e12,
                          peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak, traffic=traffic, flop_per_row=2 * (2 * mac_fwd + mac_dx),
                          flop_per_row_reference=2 * (3 * mac_ref),

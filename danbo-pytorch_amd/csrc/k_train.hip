@@ -530,7 +530,9 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                      m->g[DANBO_T_VIEWS_W], b.vg_part, s0));
     auto side1_tail = [&]() -> int {
         DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, s1));
-        if (hipEventRecord(ss->join[0], ss->s[0]) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->join[0], 0) != hipSuccess)
+        // (waiting for side 0's camera sums HERE costs ~12 us of an idle device in front of the head chain although the event
+        // completed long ago; the same wait in front of the weight gradients moved the gap there: measured, no gain)
+        if (hipEventRecord(ss->join[0], ss->s[0]) != hipSuccess || hipStreamWaitEvent((hipStream_t)s1, ss->join[0], 0) != hipSuccess)
             return (int)hipGetLastError();
         DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W],
                                          m->view_ch, m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B],
@@ -555,8 +557,19 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // The weight-gradient kernel waits for the K2 adjoint: side by side the two just share the compute units (their LDS footprints
     // exclude each other per CU) and the pose-GNN adjoint -- six small launches -- then ran on an otherwise idle device; behind it,
     // those launches hide under the weight gradients (1.71 -> 1.68 ms per step, 0.98 -> 0.94 at 384 rays)
+    // Which of the two continues on the caller's stream (round 4, tools/timeline_train.sh): the successor of the K2 adjoint that
+    // has to cross to another queue starts 20 - 35 us after it (the cross-queue wait of a replayed graph), the one on its own
+    // queue at once.  The weight gradients are the critical path (0.29 ms, the head chain and Adam behind them); the pose-GNN
+    // adjoint's six launches have 0.1 ms of slack under them: DANBO_TRAIN_DW_ON_MAIN=1 (default) keeps the former on the
+    // caller's stream and sends the latter across.
+    static const int dw_on_main = [] { const char* e = getenv("DANBO_TRAIN_DW_ON_MAIN"); return e ? atoi(e) : 1; }();
+    void* pose_stream = stream;
     if (phase == 0 && ss) {
         if (hipEventRecord(ss->mid, st) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->mid, 0) != hipSuccess) return (int)hipGetLastError();
+        if (dw_on_main) {
+            pose_stream = s1;
+            s1 = stream;
+        }
         DANBO_TRY(side1_tail());
     }
     DANBO_STAGE(11);
@@ -564,9 +577,9 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                      m->p[DANBO_T_G_B0], m->p[DANBO_T_G_W1], m->p[DANBO_T_G_ADJW1], m->g_adj1, m->p[DANBO_T_G_B1],
                                      m->p[DANBO_T_G_W2], m->p[DANBO_T_G_W3], b.vol_scratch, b.g_vol, m->g[DANBO_T_G_W0], m->g[DANBO_T_G_ADJW0],
                                      m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
-                                     m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, stream));
+                                     m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, pose_stream));
     DANBO_STAGE(12);
-    if (phase == 0 && ss) {                        // (side 1 has waited for side 0: joining it joins both)
+    if (phase == 0 && ss) {                        // (the head chain's stream has waited for side 0: joining side 1 joins both)
         DANBO_TRY(join(1));
         guard.pending[0] = false;
     } else {
