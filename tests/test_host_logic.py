@@ -545,3 +545,24 @@ def test_philox_restatement_known_answers():
            ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0), [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
     for ctr, key, want in kat:
         assert [int(x) for x in philox4x32_10([ctr], key)[0]] == want
+
+
+def test_row_spans_of_strided_tensors():
+    """hip_ops.row_span (what danbo_gather_rows is told about a tensor): strided rows stay views, 8-byte elements count as word
+    pairs, broadcast rows have stride 0, anything whose rows are not contiguous inside is copied first; the ctypes mirror of
+    DanboRowSpan has the C struct's size"""
+    import ctypes
+    import torch
+    from core import _hip, hip_ops
+    assert ctypes.sizeof(_hip.DanboRowSpan) == 32 and _hip.MAX_ROW_SPANS == 12
+    a = torch.arange(3072 * 24 * 16, dtype=torch.float32).reshape(3072, 24, 4, 4)
+    t, rows, words, stride = hip_ops.row_span(a[::192])
+    assert t.data_ptr() == a.data_ptr() and (rows, words, stride) == (16, 384, 192 * 384)
+    d = torch.arange(10, dtype=torch.int64)
+    assert hip_ops.row_span(d)[1:] == (10, 2, 2) and hip_ops.row_span(d[::3])[1:] == (4, 2, 6)
+    e = torch.ones(1, 3).expand(7, 3)
+    assert hip_ops.row_span(e)[1:] == (7, 3, 0)
+    f = torch.arange(50 * 7, dtype=torch.float32).reshape(50, 7).t()
+    t, rows, words, stride = hip_ops.row_span(f)
+    assert t.is_contiguous() and (rows, words, stride) == (7, 50, 50) and torch.equal(t, f)
+    assert hip_ops.row_span(torch.tensor(3.0))[1:] == (1, 1, 1)
