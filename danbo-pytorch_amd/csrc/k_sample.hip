@@ -775,7 +775,10 @@ __global__ __launch_bounds__(256) void k_composite(const float4* __restrict__ ra
 // order is fetched from the coarse (src < S) or the importance (src >= S) pass through sorted_idx
 // (merge_samples, core/raycasters.py:745-761, folded into raw2outputs).  bits_* / raw_empty (optional): samples
 // whose in-volume word is 0 were never written by K3 and take the ray's empty-space raw instead.
-__global__ __launch_bounds__(256) void k_composite_merged(const float4* __restrict__ raw_a, const float4* __restrict__ raw_b,
+// (amdgpu_waves_per_eu(8, 8): the compiler's 103 - 106 SGPRs allowed seven wavefronts per SIMD; a ray is a chain of dependent memory
+// round trips that only other wavefronts cover -- with 78 SGPRs and eight: 201 -> 164 us over a whole frame, 303 -> 277 for
+// k_composite_importance, the frame -0.4 %)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_composite_merged(const float4* __restrict__ raw_a, const float4* __restrict__ raw_b,
                                                           const float4* __restrict__ raw_empty,
                                                           const uint32_t* __restrict__ bits_a,
                                                           const uint32_t* __restrict__ bits_b,
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_importance_wave_long(const float* __res
 // wavefront's registers unless the caller asks for them.  Item i of the launch is the i-th listed ray (ray_list / ray_count:
 // k_flat_rays' list of the rays that are NOT rays of constants) or, without a list, ray scattered_ray(i).
 template <bool DET>
-__global__ __launch_bounds__(256) void k_composite_importance(const float4* __restrict__ raw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_composite_importance(const float4* __restrict__ raw,
                                                               const float4* __restrict__ raw_empty,
                                                               const uint32_t* __restrict__ bits,
                                                               const float* __restrict__ z, const float* __restrict__ rays_d,
