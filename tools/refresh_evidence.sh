@@ -18,5 +18,7 @@ python bench.py --config 4 --gpus 2 --scaling strong --debug-single-device > $E/
 tail -1 $E/bench4s.log | python -c "import sys, json; print(json.dumps(json.loads(sys.stdin.read()), indent=1))" > $E/${TAG}_bench_config4_strong_2ranks_1gpu_debug.json
 bash tools/prof.sh ev_$TAG > $E/prof_frame.log 2>&1; cp gpurun_out/prof_ev_$TAG/ev_${TAG}_kernel_stats.csv $E/${TAG}_kernel_stats.csv
 bash tools/prof_train.sh ev_$TAG > $E/prof_train.log 2>&1; cp gpurun_out/prof_ev_$TAG/ev_${TAG}_kernel_stats.csv $E/${TAG}_train_kernel_stats.csv
+bash tools/prof_config.sh ev3_$TAG 3 > $E/prof_config3.log 2>&1; cp gpurun_out/prof_ev3_$TAG/ev3_${TAG}_kernel_stats.csv $E/${TAG}_config3_kernel_stats.csv
+bash tools/timeline_train.sh ev_$TAG > /dev/null 2>&1; cp gpurun_out/tl_ev_$TAG.txt $E/${TAG}_train_timeline.txt
 grep -h '"ms_per_step"' $E/*_bench_config*.json
 tail -3 $E/${TAG}_parity_measured.txt
