@@ -286,7 +286,7 @@ def pe_mlp(h, S, packed, pts_b, alpha_w, alpha_b, feature_b, cview, rgb_w, rgb_b
     return aux_out
 
 
-MLP16_PACKED_BYTES = 2424832
+MLP16_PACKED_BYTES = 2424832 + 128 + 128 * 256 * 4      # 74 chunks + trailer (winv, wmax, W_fv): include/danbo_hip.h
 
 
 def mlp16_pack(pts_w, feature_w, feature_b, views_w, views_b):

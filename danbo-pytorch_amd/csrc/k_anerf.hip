@@ -59,7 +59,7 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
 #pragma unroll
             for (int i = 0; i < 12; ++i) sk[i] = src[i];
             bone_local(sk, s_align + 16 * j, p, pt);
-            const float v = sqrtf(add_rn(add_rn(mul_rn(pt[0], pt[0]), mul_rn(pt[1], pt[1])), mul_rn(pt[2], pt[2])));
+            const float v = norm3_torch(pt[0], pt[1], pt[2]);
             const float den = fmaxf(v, 1e-12f);
             float* out = s_row + sl * in_ch;
             const float w = sub_rn(1.0f, sigmoidf_(mul_rn(tau, sub_rn(v, c))));
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_anerf_view_pe(const float* __restrict__
 #pragma unroll
         for (int a = 0; a < 3; ++a)
             q[a] = add_rn(add_rn(mul_rn(M[4 * a], d[0]), mul_rn(M[4 * a + 1], d[1])), mul_rn(M[4 * a + 2], d[2]));
-        const float nrm = sqrtf(add_rn(add_rn(mul_rn(q[0], q[0]), mul_rn(q[1], q[1])), mul_rn(q[2], q[2])));
+        const float nrm = norm3_torch(q[0], q[1], q[2]);
         const float den = fmaxf(nrm, 1e-12f);
         float* out = E + (size_t)r * stride + 3 * j;
 #pragma unroll

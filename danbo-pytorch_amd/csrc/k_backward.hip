@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
     const int nchunk = (S + 63) >> 6;
     for (int r = wave; r < R; r += nwaves) {
         const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
-        const float dn = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz_, dz_)));
+        const float dn = norm3_torch(dx, dy, dz_);
         const float gr = g_rgb[3 * r], gg = g_rgb[3 * r + 1], gb = g_rgb[3 * r + 2];
         // ---- forward sweep: per-chunk quantities kept in registers (<= 4 chunks) ----
         float al[4], T[4], dist[4], sig[4], cr[4], cg[4], cb[4], rr[4], rg[4], rb[4];

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
                 d[0] = t[0]; d[1] = t[1]; d[2] = t[2];
             }
             if (normalise) {
-                const float nrm = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
+                const float nrm = norm3_torch(d[0], d[1], d[2]);
                 const float den = fmaxf(nrm, 1e-12f);
                 d[0] = div_rn(d[0], den); d[1] = div_rn(d[1], den); d[2] = div_rn(d[2], den);
             }

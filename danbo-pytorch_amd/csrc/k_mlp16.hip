@@ -31,77 +31,19 @@ constexpr int NCH_VIEW = 4;            // 8 k-steps, 8 output tiles -> 2 k-steps
 // merged into ONE 256->128 GEMM at pack time: W_fv = W_v[:, :256] W_f, bias W_v[:, :256] b_f folded into
 // the per-ray view constants (65 536 fewer MACs per row than the reference's 677 376)
 constexpr int NCH_TOTAL = NCH_X0 + 4 * NCH_ACT + (NCH_X0 + NCH_ACT) + 2 * NCH_ACT + NCH_VIEW;  // 74
-static_assert(NCH_TOTAL * CHUNK_BYTES == DANBO_MLP16_PACKED_BYTES, "header constant out of date");
+static_assert(NCH_TOTAL * CHUNK_BYTES + DANBO_MLP16_TRAILER_BYTES == DANBO_MLP16_PACKED_BYTES, "header constant out of date");
 constexpr int X0_KSTEPS = 7;
 constexpr int IN_CH = 195, W_ = 256, VW_ = 128;
 
 // ---------------------------------------------------------------------------------------------
-// weight packing: one thread per half element
-// ---------------------------------------------------------------------------------------------
-struct Pack16Args {
-    const float* pts_w[8];
-    const float* feature_w;
-    const float* feature_b;
-    const float* views_w;
-    const float* views_b;
-    int Cv;
-    float* views_b_eff;  // [128] = views_b + W_v[:, :256] feature_b
-};
-
-__global__ __launch_bounds__(256) void k_mlp16_pack(Pack16Args a, _Float16* __restrict__ packed) {
-    const long total = (long)NCH_TOTAL * (CHUNK_BYTES / 2);
-    if (blockIdx.x == 0 && threadIdx.x < VW_) {
-        const int n = threadIdx.x;
-        double acc = 0.0;
-        for (int c = 0; c < W_; ++c) acc += (double)a.views_w[(size_t)n * (W_ + a.Cv) + c] * (double)a.feature_b[c];
-        a.views_b_eff[n] = (float)((double)a.views_b[n] + acc);
-    }
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int chunk = (int)(idx / (CHUNK_BYTES / 2));
-        const int within = (int)(idx % (CHUNK_BYTES / 2));
-        const int piece = within >> 9, lane = (within >> 3) & 63, e = within & 7;
-        const int q = lane >> 4;
-        // which GEMM / which part does this chunk belong to
-        int layer, cl, kind;  // kind 0: x0 part, 1: act part, 2: view layer
-        if (chunk < 7) { layer = 0; cl = chunk; kind = 0; }
-        else if (chunk < 39) { layer = 1 + (chunk - 7) / 8; cl = (chunk - 7) % 8; kind = 1; }
-        else if (chunk < 46) { layer = 5; cl = chunk - 39; kind = 0; }
-        else if (chunk < 54) { layer = 5; cl = chunk - 46; kind = 1; }
-        else if (chunk < 70) { layer = 6 + (chunk - 54) / 8; cl = (chunk - 54) % 8; kind = 1; }
-        else { layer = 9; cl = chunk - 70; kind = 2; }
-        int s, T, hl;
-        if (kind == 2) { s = 2 * cl + (piece >> 4); T = (piece >> 1) & 7; hl = piece & 1; }
-        else { s = cl; T = piece >> 1; hl = piece & 1; }
-        const int n = 16 * T + (lane & 15);
-        float w = 0.f;
-        if (kind == 0) {
-            const int j = 8 * s + e;
-            const int c = j / 13, t = j % 13, kk = q + 4 * c;
-            if (j < 52 && kk < FEAT) {
-                const int col = FEAT * t + kk;  // [x | sin 2^0 | cos 2^0 | ...] blocks of 15
-                w = layer == 0 ? a.pts_w[0][(size_t)n * IN_CH + col] : a.pts_w[5][(size_t)n * (IN_CH + W_) + col];
-            }
-        } else {
-            const int f = 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3);
-            if (layer == 5) w = a.pts_w[5][(size_t)n * (IN_CH + W_) + IN_CH + f];
-            else if (layer <= 7) w = a.pts_w[layer][(size_t)n * W_ + f];
-            else {  // merged feature + view layer: W_fv[n][f] = sum_c W_v[n][c] W_f[c][f]
-                double acc = 0.0;
-                const float* wv = a.views_w + (size_t)n * (W_ + a.Cv);
-                for (int c = 0; c < W_; ++c) acc += (double)wv[c] * (double)a.feature_w[(size_t)c * W_ + f];
-                w = (float)acc;
-            }
-        }
-        const _Float16 hi = (_Float16)w;
-        packed[idx] = hl ? (_Float16)(w - (float)hi) : hi;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight packing for the fused trunk of the TRAINING step (danbo_trunk_pack), once per optimizer step, two launches:
+// weight packing, two launches -- for K3 (danbo_mlp16_pack, once per weight update: the 74 forward chunks) and for the fused trunk of
+// the TRAINING step (danbo_trunk_pack, once per optimizer step: forward + backward chunks):
 //   k_trunk_prep  W_fv = W_v[:, :256] W_f (fp64 dot products), b_eff = b_v + W_v[:, :256] b_f, max |w| of the nine matrices
-//   k_trunk_pack  74 forward chunks in K3's order + 76 chunks of the input-gradient chain (k_mlp16_bwd.hip: the same matrices
-//                 transposed), every matrix times the power of two that puts its largest entry into [2^13, 2^14)
+//   k_trunk_pack  74 forward chunks + 76 chunks of the input-gradient chain (k_mlp16_bwd.hip: the same matrices
+//                 transposed), every matrix times the power of two that puts its largest entry into [2^13, 2^14): unscaled, the
+//                 lo half of every weight below 2^-3 is an fp16 SUBNORMAL (absolute error 2^-25 whatever the weight -- the largest
+//                 single contribution to the split products' distance from fp32, tools/diag/f16split_emulation.py); the consumer's
+//                 epilogue multiplies by the exact inverse inside the fma that adds the bias
 // Backward chunk order: W_fv^T (4) | W_7^T (8) | W_6^T (8) | W_5[:, :195]^T (8, PE-ordered output rows, 13 tiles) |
 // W_5[:, 195:]^T (8) | W_4^T .. W_1^T (8 each) | W_0^T (8, PE-ordered output rows).
 // PE-ordered rows: output tile T, row 4 q + i of the tile = d pe_j of lane group q's channel kk = q + 4 c, j = 4 T + i = 13 c + t
@@ -116,6 +58,7 @@ struct TrunkPackArgs {
     int Cv;
     float *wfv, *b_eff, *wmax, *winv;
     _Float16* packed;
+    int n_chunks;      // NCH_TOTAL (forward only: K3) or NCH_TOTAL + NCH_BWD
 };
 
 // grid: 8 x 32 workgroups for the max |w| of pts_linears.0..7, then 128 workgroups -- one per row n of W_fv, thread = column f
@@ -174,7 +117,7 @@ __global__ __launch_bounds__(256) void k_trunk_pack(TrunkPackArgs a) {
         weight_pow2_scale(a.wmax[threadIdx.x], s, inv);
         a.winv[threadIdx.x] = inv;
     }
-    const long total = (long)(NCH_TOTAL + NCH_BWD) * (CHUNK_BYTES / 2);
+    const long total = (long)a.n_chunks * (CHUNK_BYTES / 2);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int chunk = (int)(idx / (CHUNK_BYTES / 2));
         const int within = (int)(idx % (CHUNK_BYTES / 2));
@@ -182,7 +125,7 @@ __global__ __launch_bounds__(256) void k_trunk_pack(TrunkPackArgs a) {
         const int q = lane >> 4, ma = lane & 15;
         int mat;
         float w = 0.f;
-        if (chunk < NCH_TOTAL) {            // ---------------- forward: k_mlp16_pack's order
+        if (chunk < NCH_TOTAL) {            // ---------------- forward (K3's order)
             int layer, cl, kind;            // kind 0: x0 part, 1: act part, 2: view layer
             if (chunk < 7) { layer = 0; cl = chunk; kind = 0; }
             else if (chunk < 39) { layer = 1 + (chunk - 7) / 8; cl = (chunk - 7) % 8; kind = 1; }
@@ -289,7 +232,7 @@ struct TrainFwd {
 
 // B fragments of k-step s of the next GEMM from the previous layer's accumulators: tiles 2s and 2s+1,
 // bias + ReLU, hi/lo split.  ALPHA: also accumulate this lane's part of the density logit.
-// TRAIN: acc * winv first; the eight activations are stored (ybase: wave-uniform address of this k-step's 2 KB)
+// acc * winv + bias (one fma).  TRAIN: the eight activations are stored (ybase: wave-uniform address of this k-step's 2 KB)
 // and their signs as byte S of the lane's 8 bytes at rbase (bit e of byte S <-> bit 8 S + e of the 64-bit word the
 // input-gradient chain loads: column 16 (2 S + e / 4) + 4 q + e % 4).
 template <bool ALPHA, bool TRAIN = false, int S = 0>
@@ -301,17 +244,11 @@ __device__ __forceinline__ void act_fragment(const f32x4& a0, const f32x4& a1, c
     // load of the weight ring in flight first (it cannot tell the tables from the ring), i.e. drain the ring once per k-step
     float4 b0, b1;
     lds_table_read2(bias, b0, b1);
-    if (TRAIN) {
-        v[0] = fmaxf(fmaf(a0[0], winv, b0.x), 0.f); v[1] = fmaxf(fmaf(a0[1], winv, b0.y), 0.f);
-        v[2] = fmaxf(fmaf(a0[2], winv, b0.z), 0.f); v[3] = fmaxf(fmaf(a0[3], winv, b0.w), 0.f);
-        v[4] = fmaxf(fmaf(a1[0], winv, b1.x), 0.f); v[5] = fmaxf(fmaf(a1[1], winv, b1.y), 0.f);
-        v[6] = fmaxf(fmaf(a1[2], winv, b1.z), 0.f); v[7] = fmaxf(fmaf(a1[3], winv, b1.w), 0.f);
-    } else {
-        v[0] = fmaxf(a0[0] + b0.x, 0.f); v[1] = fmaxf(a0[1] + b0.y, 0.f);
-        v[2] = fmaxf(a0[2] + b0.z, 0.f); v[3] = fmaxf(a0[3] + b0.w, 0.f);
-        v[4] = fmaxf(a1[0] + b1.x, 0.f); v[5] = fmaxf(a1[1] + b1.y, 0.f);
-        v[6] = fmaxf(a1[2] + b1.z, 0.f); v[7] = fmaxf(a1[3] + b1.w, 0.f);
-    }
+    // acc * winv (the exact inverse of the matrix' pack scale, a power of two) + bias in ONE fma: the scale costs no instruction
+    v[0] = fmaxf(fmaf(a0[0], winv, b0.x), 0.f); v[1] = fmaxf(fmaf(a0[1], winv, b0.y), 0.f);
+    v[2] = fmaxf(fmaf(a0[2], winv, b0.z), 0.f); v[3] = fmaxf(fmaf(a0[3], winv, b0.w), 0.f);
+    v[4] = fmaxf(fmaf(a1[0], winv, b1.x), 0.f); v[5] = fmaxf(fmaf(a1[1], winv, b1.y), 0.f);
+    v[6] = fmaxf(fmaf(a1[2], winv, b1.z), 0.f); v[7] = fmaxf(fmaf(a1[3], winv, b1.w), 0.f);
     if (ALPHA) {
         float4 w0, w1;
         lds_table_read2(aw, w0, w1);
@@ -365,6 +302,8 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, qq = lane >> 4;
+    // exact inverses of the nine matrices' pack scales: the training step's own table, K3: the trailer of the packed buffer
+    const float* winv_tab = TRAIN ? tr.winv : reinterpret_cast<const float*>(a.packed + (size_t)NCH_TOTAL * CHUNK_BYTES);
     for (int i = tid; i < 8 * W_; i += M16_THREADS) s_bias[i] = a.pts_b[i >> 8][i & 255];
     if (tid < W_) s_aw[tid] = a.alpha_w[tid];
     for (int i = tid; i < 3 * VW_; i += M16_THREADS) s_rgbw[i] = a.rgb_w[i];
@@ -480,12 +419,12 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
             int zero = 0;
             asm volatile("" : "+s"(zero));  // keeps the two mbcnt ops inside the loop (no hoist + spill)
             const int q4 = (int)((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) >> 4) & 3) * 4;
-            // TRAIN: prev holds layer step-1's accumulators: its pack scale, its activation buffer
+            // prev holds layer step-1's accumulators: its pack scale; TRAIN: its activation buffer
             float winv = 1.f;
             const float* yg = nullptr;
             const unsigned long long* rg = nullptr;
+            if (step != 0) winv = winv_tab[step - 1];
             if (TRAIN && step != 0) {
-                winv = tr.winv[step - 1];
                 yg = tr.y + (long)(step - 1) * tr.y_stride + grp * 4096;
                 rg = tr.relu + (long)(step - 1) * tr.relu_stride + grp * 64;
             }
@@ -557,7 +496,7 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
         // ------------------------------------------------------------------ colour head + output
         float pr = 0.f, pg = 0.f, pb = 0.f;
         float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (VW_ + 1) + 4 * qq : nullptr;
-        const float winv_v = TRAIN ? tr.winv[8] : 1.f;
+        const float winv_v = winv_tab[8];
         const float* hvg = TRAIN ? tr.hv + grp * 2048 : nullptr;
         unsigned hvb = 0u;
 #pragma unroll
@@ -565,11 +504,13 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
             const int nn = 16 * T;  // + 4*qq + i
             f32x4 c4 = cvq[T];
             if (!a.cview) c4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float pre[4] = {TRAIN ? accv[T][0] * winv_v : accv[T][0], TRAIN ? accv[T][1] * winv_v : accv[T][1],
-                                  TRAIN ? accv[T][2] * winv_v : accv[T][2], TRAIN ? accv[T][3] * winv_v : accv[T][3]};
+            // TRAIN keeps round 3's two roundings (pre = acc * winv, pre + c): its recorded fixtures; K3: one fma
+            const float pre[4] = {accv[T][0] * winv_v, accv[T][1] * winv_v, accv[T][2] * winv_v, accv[T][3] * winv_v};
             if (aux) *reinterpret_cast<float4*>(aux + nn) = make_float4(pre[0], pre[1], pre[2], pre[3]);
-            const float x[4] = {fmaxf(pre[0] + c4[0], 0.f), fmaxf(pre[1] + c4[1], 0.f), fmaxf(pre[2] + c4[2], 0.f),
-                                fmaxf(pre[3] + c4[3], 0.f)};
+            const float x[4] = {fmaxf(TRAIN ? pre[0] + c4[0] : fmaf(accv[T][0], winv_v, c4[0]), 0.f),
+                                fmaxf(TRAIN ? pre[1] + c4[1] : fmaf(accv[T][1], winv_v, c4[1]), 0.f),
+                                fmaxf(TRAIN ? pre[2] + c4[2] : fmaf(accv[T][2], winv_v, c4[2]), 0.f),
+                                fmaxf(TRAIN ? pre[3] + c4[3] : fmaf(accv[T][3], winv_v, c4[3]), 0.f)};
             if (TRAIN) {
                 if (T < 4) store16_s<0>(hvg + T * 256, (unsigned)lane * 16u, f32x4{x[0], x[1], x[2], x[3]});
                 else store16_s<0>(hvg + 1024 + (T - 4) * 256, (unsigned)lane * 16u, f32x4{x[0], x[1], x[2], x[3]});
@@ -615,19 +556,21 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_fwd(Mlp16Args a, T
 
 using namespace danbo;
 
+// trailer of the packed buffer behind the 74 chunks: winv [16] | wmax [16] | W_fv [128 x 256] (scratch of the pack kernels)
 extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
                                  const float* views_w, const float* views_b, int Cv, void* packed16,
                                  float* views_b_eff, void* stream) {
     DANBO_CHECK_ARG(pts_w && feature_w && feature_b && views_w && views_b && packed16 && views_b_eff && Cv >= 0);
-    Pack16Args a;
-    for (int i = 0; i < 8; ++i) a.pts_w[i] = pts_w[i];
-    a.feature_w = feature_w;
-    a.feature_b = feature_b;
-    a.views_w = views_w;
-    a.views_b = views_b;
-    a.Cv = Cv;
-    a.views_b_eff = views_b_eff;
-    hipLaunchKernelGGL(k_mlp16_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a, reinterpret_cast<_Float16*>(packed16));
+    TrunkPackArgs a;
+    for (int i = 0; i < 8; ++i) { DANBO_CHECK_ARG(pts_w[i]); a.pts_w[i] = pts_w[i]; }
+    a.feature_w = feature_w; a.feature_b = feature_b; a.views_w = views_w; a.views_b = views_b; a.Cv = Cv;
+    float* trailer = reinterpret_cast<float*>(reinterpret_cast<char*>(packed16) + (size_t)NCH_TOTAL * CHUNK_BYTES);
+    a.winv = trailer; a.wmax = trailer + 16; a.wfv = trailer + 32; a.b_eff = views_b_eff;
+    a.packed = reinterpret_cast<_Float16*>(packed16);
+    a.n_chunks = NCH_TOTAL;
+    { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+    hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
 
@@ -659,6 +602,7 @@ extern "C" int danbo_trunk_pack(const DanboTrunkWeights* w, void* stream) {
     for (int i = 0; i < 8; ++i) { DANBO_CHECK_ARG(w->pts_w[i]); a.pts_w[i] = w->pts_w[i]; }
     a.feature_w = w->feature_w; a.feature_b = w->feature_b; a.views_w = w->views_w; a.views_b = w->views_b; a.Cv = w->view_ch;
     a.wfv = w->wfv; a.b_eff = w->b_eff; a.wmax = w->wmax; a.winv = w->winv; a.packed = reinterpret_cast<_Float16*>(w->packed);
+    a.n_chunks = NCH_TOTAL + NCH_BWD;
     hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();

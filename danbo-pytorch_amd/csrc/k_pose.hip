@@ -11,7 +11,7 @@ namespace danbo {
 // pytorch3d.transforms.axis_angle_to_matrix (via quaternion; Taylor branch below 1e-6 rad);
 // rot6d = first two columns, row-major (core/utils/skeleton_utils.py:408-418)
 __device__ __forceinline__ void axis_angle_to_rot6d(const float* aa, float* r6) {
-    const float ang = sqrtf(add_rn(add_rn(mul_rn(aa[0], aa[0]), mul_rn(aa[1], aa[1])), mul_rn(aa[2], aa[2])));
+    const float ang = norm3_torch(aa[0], aa[1], aa[2]);
     const float half = mul_rn(ang, 0.5f);
     const float s = fabsf(ang) < 1e-6f ? sub_rn(0.5f, div_rn(mul_rn(ang, ang), 48.0f)) : div_rn(sinf(half), ang);
     const float qr = cosf(half), qi = mul_rn(aa[0], s), qj = mul_rn(aa[1], s), qk = mul_rn(aa[2], s);

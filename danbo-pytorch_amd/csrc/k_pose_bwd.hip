@@ -16,7 +16,7 @@
 namespace danbo {
 
 __device__ void axis_angle_to_rot6d_b(const float* aa, float* r6) {   // same arithmetic as k_pose.hip
-    const float ang = sqrtf(add_rn(add_rn(mul_rn(aa[0], aa[0]), mul_rn(aa[1], aa[1])), mul_rn(aa[2], aa[2])));
+    const float ang = norm3_torch(aa[0], aa[1], aa[2]);
     const float half = mul_rn(ang, 0.5f);
     const float s = fabsf(ang) < 1e-6f ? sub_rn(0.5f, div_rn(mul_rn(ang, ang), 48.0f)) : div_rn(sinf(half), ang);
     const float qr = cosf(half), qi = mul_rn(aa[0], s), qj = mul_rn(aa[1], s), qk = mul_rn(aa[2], s);

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_ray_bone_mask(const float* __restrict__
             // depths inside [zl, zh] can produce -- |gap| * |d|, 1e10 * |d| for the last sample -- is finite, and every input the
             // view layer can see of this ray (its direction, raw or turned by the root bone's matrix; sines and cosines are
             // <= 1 anyway) is at most RAY_FLAT_VMAX in magnitude: what the caller's bound on the empty-space colour assumes
-            const float dn = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
+            const float dn = norm3_torch(d[0], d[1], d[2]);
             const float span = mul_rn(add_rn(sub_rn(zh, zl), mul_rn(1e-3f, fmaxf(fabsf(zl), fabsf(zh)))), dn);
             const float tail = mul_rn(1e10f, dn);
             const float* m0 = POSES_IN_LDS ? s_skt + (size_t)(g - g0) * J * 16 : skts + (size_t)g * J * 16;     // the root bone
@@ -763,7 +763,7 @@ __device__ __forceinline__ void composite_finish(const CompositeState& st, int r
 
 __device__ __forceinline__ float ray_norm(const float* __restrict__ rays_d, int r) {
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
-    return sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz_, dz_)));
+    return norm3_torch(dx, dy, dz_);
 }
 
 // raw_empty / bits (optional, together): samples whose in-volume word is 0 were never written by K3 and take the ray's

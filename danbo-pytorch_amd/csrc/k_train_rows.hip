@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_train_view_inputs(const float* __restri
                 d[0] = t[0]; d[1] = t[1]; d[2] = t[2];
             }
             if (normalise) {       // F.normalize(p = 2, eps = 1e-12)
-                const float nrm = fmaxf(sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2]))), 1e-12f);
+                const float nrm = fmaxf(norm3_torch(d[0], d[1], d[2]), 1e-12f);
                 d[0] = div_rn(d[0], nrm); d[1] = div_rn(d[1], nrm); d[2] = div_rn(d[2], nrm);
             }
             if (c < 3) out = d[c];

@@ -34,7 +34,7 @@ extern "C" {
  * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, danbo_flat_rays;
  * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
  * danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_random_draws, danbo_gather_rows; danbo_render_frame takes up to
- * 256 + 64 samples per ray. */
+ * 256 + 64 samples per ray; 6 = DANBO_MLP16_PACKED_BYTES grows by a trailer (power-of-two pack scales of danbo_mlp16_pack). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -238,8 +238,12 @@ int danbo_pe_mlp_fwd(const float* h, const int32_t* list, const int32_t* count, 
  * DANBO_MLP16_PACKED_BYTES bytes of fp16 fragments; it also merges feature_linear with the
  * per-sample part of views_linears.0 (no activation in between, nerf.py:200-204) into one
  * 256->128 GEMM and returns the matching view bias views_b_eff = views_b + W_v[:, :256] feature_b,
- * which the caller passes to danbo_view_consts in place of views_b. */
-#define DANBO_MLP16_PACKED_BYTES 2424832
+ * which the caller passes to danbo_view_consts in place of views_b.
+ * ABI 6: every matrix is packed times the power of two that puts its largest |entry| into [2^13, 2^14) (unscaled, the lo half of
+ * every weight below 2^-3 is an fp16 subnormal); the exact inverses travel in the buffer's trailer and the kernel applies them
+ * inside the fma that adds the bias -- the caller sees nothing but the larger DANBO_MLP16_PACKED_BYTES. */
+#define DANBO_MLP16_TRAILER_BYTES (128 + 128 * 256 * 4)   /* winv [16] | wmax [16] | W_fv [128,256]: written by danbo_mlp16_pack */
+#define DANBO_MLP16_PACKED_BYTES (2424832 + DANBO_MLP16_TRAILER_BYTES)
 int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
                      const float* views_w, const float* views_b, int Cv,
                      void* packed16, float* views_b_eff /*[128]*/, void* stream);

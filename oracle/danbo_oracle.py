@@ -28,6 +28,20 @@ JOINT_TREES = np.array([0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8,
                         9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21])
 
 
+def torch_norm(x, keepdims=False):
+    """torch.norm(x, p=2, dim=-1) on fp32: ATen's reduction step is acc + x*x contracted to ONE fma (NormTwoOps), so the result is
+    sqrt(fma(x2, x2, fma(x1, x1, x0*x0))) -- pinned on the imported reference: bit-equal to torch on every row of the box-bound, cylinder
+    and direction norms tried, where the separately rounded sum differs on ~5 % of them.  The fma is emulated in float64 (the product
+    of two fp32 values is exact there; the double rounding of the sum can only matter on an exact tie of the 53-bit sum)."""
+    x64 = np.asarray(x, dtype=F32).astype(np.float64)
+    acc = (x64[..., 0] * x64[..., 0]).astype(F32)
+    for k in range(1, x64.shape[-1]):
+        acc = (x64[..., k] * x64[..., k] + acc.astype(np.float64)).astype(F32)
+    with np.errstate(invalid='ignore'):
+        n = np.sqrt(acc).astype(F32)
+    return n[..., None] if keepdims else n
+
+
 # =============================================================================
 # a1 / a2  skeleton constants
 # =============================================================================
@@ -106,8 +120,8 @@ def near_far_cylinder(rays_o, rays_d, cyl, near, far, chunk=None):
     center = cyl[:, :2]
     nc = center - r_near
     nf = r_far - r_near
-    nf_norm = np.sqrt((nf * nf).sum(-1, dtype=F32)).astype(F32)
-    scale = np.sqrt((rays_d[:, g] ** 2).sum(-1, dtype=F32)).astype(F32)[:, None]
+    nf_norm = torch_norm(nf)
+    scale = torch_norm(rays_d[:, g])[:, None]
     cross = nc[:, 0] * nf[:, 1] - nc[:, 1] * nf[:, 0]
     dist = (np.abs(cross) / nf_norm)[:, None]
     with np.errstate(invalid='ignore'):
@@ -148,16 +162,18 @@ def near_far_boxes(rays_o, rays_d, skts, align, axis_scale, near, far, bound=1.3
     `bound` is always training_bound=1.3 (raycasters.py:671-675).
     """
     R = rays_o.shape[0]
-    Rs = skts[:, :, :3, :3]
-    ot = (Rs @ rays_o[:, None, :, None])[..., 0] + skts[:, :, :3, 3]
-    dt = (Rs @ rays_d[:, None, :, None])[..., 0]
-    A = align[None, :, :3, :3]
-    ot = ((A @ ot[..., None])[..., 0] + align[None, :, :3, 3]).astype(F32)
-    dt = (A @ dt[..., None])[..., 0].astype(F32)
+    # torch's batched 3x3 @ 3x1 products sum k = 0, 1, 2 in order with separately rounded mul / add (bit-equal to the reference's
+    # rays_ot / rays_dt on 98 304 rows; numpy's matmul is not), i.e. the arithmetic of _affine_unfused
+    zero = np.zeros((1, J, 3, 1), F32)
+    ot = _affine_unfused(skts[:, :, :3, :], rays_o[:, None, :])
+    dt = _affine_unfused(np.concatenate([skts[:, :, :3, :3], np.broadcast_to(zero, skts[:, :, :3, :1].shape)], -1), rays_d[:, None, :])
+    ot = _affine_unfused(align[None, :, :3, :], ot)
+    dt = _affine_unfused(np.concatenate([align[None, :, :3, :3], zero], -1), dt)
     sc = np.abs(axis_scale)[None].astype(F32)
     o_s = (ot / sc).astype(F32)
     d_s = (dt / sc).astype(F32)
-    bounds = np.stack([-bound * np.ones(3), bound * np.ones(3)], 0)[None, None]  # [1,1,2,3]
+    # bound_range * torch.ones(...) is a FLOAT32 tensor (1.3f = 1.2999999523...) before its .double() (ray_utils.py:394-397)
+    bounds = np.stack([-F32(bound) * np.ones(3, F32), F32(bound) * np.ones(3, F32)], 0)[None, None]  # [1,1,2,3]
     with np.errstate(divide='ignore', invalid='ignore'):
         t = (bounds.astype(np.float64) - o_s[:, :, None, :].astype(np.float64)) / d_s[:, :, None, :].astype(np.float64)
         t = t.reshape(R, J, 6, 1)
@@ -168,7 +184,7 @@ def near_far_boxes(rays_o, rays_d, skts, align, axis_scale, near, far, bound=1.3
     p_unscaled = p * sc[:, :, None, :]
     diff = p_unscaled - ot[:, :, None, :]
     with np.errstate(invalid='ignore'):
-        steps = np.sqrt((diff * diff).sum(-1, dtype=F32)) / np.sqrt((dt * dt).sum(-1, dtype=F32))[..., None]
+        steps = (torch_norm(diff) / torch_norm(dt)[..., None]).astype(F32)
     big = F32(100000.0)
     s_min = np.where(p_valid, steps, np.inf).min(-1)
     s_max = np.where(p_valid, steps, -np.inf).max(-1)
@@ -324,7 +340,7 @@ def factorised_gather(volumes, x, pose_of_ray, voxel_feat=5, voxel_res=16):
 def axis_angle_to_matrix(aa):
     """pytorch3d.transforms.axis_angle_to_matrix (v0.6): via quaternion, Taylor for small angles."""
     aa = aa.astype(F32)
-    ang = np.sqrt((aa * aa).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    ang = torch_norm(aa, keepdims=True)
     half = (ang * F32(0.5)).astype(F32)
     small = np.abs(ang) < 1e-6
     with np.errstate(divide='ignore', invalid='ignore'):
@@ -431,7 +447,7 @@ def view_dirs(cfg, rays_d, skts):
     else:
         raise NotImplementedError(cfg['ray_tr_type'])
     if cfg['view_type'] == 'relray':
-        n = np.sqrt((d * d).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+        n = torch_norm(d, keepdims=True)
         d = (d / np.maximum(n, F32(1e-12))).astype(F32)
     return d
 
@@ -470,7 +486,7 @@ def composite(raw, z, rays_d, B=1.0, noise=None):
     """NeRF.raw2outputs with relu density (core/networks/nerf.py:281-347)."""
     d = (z[:, 1:] - z[:, :-1]).astype(F32)
     d = np.concatenate([d, np.full_like(d[:, :1], 1e10)], -1)
-    d = (d * np.sqrt((rays_d * rays_d).sum(-1, dtype=F32)).astype(F32)[:, None]).astype(F32)
+    d = (d * torch_norm(rays_d)[:, None]).astype(F32)
     rgb = (sigmoid(raw[..., :3]) * F32(1.002) - F32(0.001)).astype(F32)
     s = (raw[..., 3] / F32(B)).astype(F32)
     if noise is not None:
@@ -524,13 +540,15 @@ def cutoff_pe_view(d, v, cutoff, tau, L=4):
 
 def unit_vectors(x):
     """F.normalize(x, dim=-1, p=2): x / max(|x|, 1e-12)  (VecNormEncoder, core/encoders.py:774-795)."""
-    n = np.sqrt((x * x).sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    n = torch_norm(x, keepdims=True)
     return (x / np.maximum(n, F32(1e-12))).astype(F32)
 
 
 def bone_local_rays(rays_d, skts):
-    """transform_batch_rays (core/encoders.py:305-317): rotation part of every bone transform -> [R,24,3]."""
-    return (skts[:, :, :3, :3] @ rays_d[:, None, :, None])[..., 0].astype(F32)
+    """transform_batch_rays (core/encoders.py:305-317): rotation part of every bone transform -> [R,24,3] (k = 0, 1, 2 summed in
+    order, each op rounded: torch's small batched matmul, see near_far_boxes)."""
+    M = np.concatenate([skts[:, :, :3, :3], np.zeros_like(skts[:, :, :3, :1])], -1)
+    return _affine_unfused(M, rays_d[:, None, :])
 
 
 class AnerfOracle:
@@ -548,7 +566,7 @@ class AnerfOracle:
         R, S = pts.shape[:2]
         M = R * S
         pts_t = bone_local(pts, skts, self.align)
-        v = np.sqrt((pts_t * pts_t).sum(-1, dtype=F32)).astype(F32)                       # RelDist
+        v = torch_norm(pts_t)                                                              # RelDist
         r = unit_vectors(pts_t).reshape(R, S, -1)                                          # VecNorm, [R,S,72]
         tau = float(sd['pe_fn.tau'])
         v_pe, w = cutoff_pe_dist(v.reshape(M, J), sd['pe_fn.cutoff_dist'], tau, cfg['multires'])

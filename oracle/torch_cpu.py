@@ -149,7 +149,7 @@ class DanboTorchCPU:
             if stages:
                 raw, _, valid = raw
                 st.append((raw.numpy(), valid.numpy(), (ro[:, None] + rd[:, None] * zt[..., None]).numpy(), pose_of_ray.numpy(),
-                           bones[sl][::skip]))
+                           bones[sl][::skip], near, far))
             out0 = self._composite(raw, zt, rd, self.cfg['density_scale'])
             z_all, z_fine, order = o.importance_z(z, out0['weights'].numpy(), Sf)
             zf = t(z_fine)
@@ -161,7 +161,8 @@ class DanboTorchCPU:
                    rgb0=np.concatenate([x[2] for x in outs]))
         if stages:
             ret.update(raw_coarse=np.concatenate([x[0] for x in st]), valid_coarse=np.concatenate([x[1] for x in st]),
-                       pts_coarse=np.concatenate([x[2] for x in st]), chunks=[(len(x[0]), x[3], x[4]) for x in st])
+                       pts_coarse=np.concatenate([x[2] for x in st]), chunks=[(len(x[0]), x[3], x[4]) for x in st],
+                       near=np.concatenate([x[5] for x in st]), far=np.concatenate([x[6] for x in st]))
         return ret
 
 

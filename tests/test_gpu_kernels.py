@@ -50,7 +50,7 @@ def test_library_and_device(ops):
     import ctypes
     from core import _hip
     l = _hip.lib()
-    assert l.danbo_abi_version() == 5
+    assert l.danbo_abi_version() == 6
     cu, lds = ctypes.c_int(), ctypes.c_int()
     arch = ctypes.create_string_buffer(64)
     assert l.danbo_device_info(ctypes.byref(cu), ctypes.byref(lds), arch, 64) == 0
@@ -86,7 +86,12 @@ def test_cylinder_nan_backfill_and_box_near_far(ops):
     from core.render_engine import DanboEngine
     g, orc, cfg, sd, scene, ro, rd = _surreal_inputs()
     near, far = ops.near_far_cylinder(T(ro), T(rd), T(scene["cyls"]), 0.0, 1.0, 4096)
-    assert max_err(N(near), g["cyl_near"][:, 0]) < 3e-6 and max_err(N(far), g["cyl_far"][:, 0]) < 3e-6
+    assert max_err(N(near), g["cyl_near"][:, 0]) < 2e-6 and max_err(N(far), g["cyl_far"][:, 0]) < 2e-6
+    # rays that hit the cylinder: bit-equal to the reference (only the back-filled mean is summed in another order)
+    vals, counts = np.unique(g["cyl_near"][:, 0], return_counts=True)
+    hit = g["cyl_near"][:, 0] != vals[np.argmax(counts)]           # the back-fill value is the one that repeats
+    assert 1000 < hit.sum() < len(ro) and counts.max() > 50
+    assert np.array_equal(N(near)[hit], g["cyl_near"][hit, 0]) and np.array_equal(N(far)[hit], g["cyl_far"][hit, 0])
     # two chunks: each half gets its own nan-mean, exactly like two calls of the reference
     n2, f2 = ops.near_far_cylinder(T(ro), T(rd), T(scene["cyls"]), 0.0, 1.0, 2048)
     z = np.zeros(len(ro), dtype=np.int64)
@@ -106,8 +111,12 @@ def test_cylinder_nan_backfill_and_box_near_far(ops):
         assert max_err(N(n5), on[:, 0]) < 3e-6 and max_err(N(f5), of[:, 0]) < 3e-6, chunk
     eng = DanboEngine(cfg, {k: T(v) for k, v in sd.items()}, T(orc.align))
     nb, fb = eng.near_far(T(ro), T(rd), T(scene["cyls"]), T(scene["skts"]))
-    assert max_err(N(nb), g["near"][:, 0]) < 3e-5 and max_err(N(fb), g["far"][:, 0]) < 3e-5
-    assert (np.abs(N(nb) - g["near"][:, 0]) > 3e-6).sum() < 10
+    # box bounds: the reference's tensors bit for bit (round 5: torch.norm's fma chain, the float32 bound 1.3f); rays without a box
+    # keep the cylinder's bounds, rays that miss the cylinder too the chunk's nan-mean (another summation order: a few ulp)
+    boxed = g["near"][:, 0] != g["cyl_near"][:, 0]
+    assert boxed.sum() > 1000
+    assert np.array_equal(N(nb)[boxed], g["near"][boxed, 0]) and np.array_equal(N(fb)[boxed], g["far"][boxed, 0])
+    assert max_err(N(nb), g["near"][:, 0]) < 2e-6 and max_err(N(fb), g["far"][:, 0]) < 2e-6
 
 
 def _stage_geo(ops, stage, z=None):
