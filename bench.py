@@ -397,6 +397,8 @@ def bench_render(args, rank, world, device, dist):
         "in_volume_fraction": rows / (N_BLOCKS * args.steps * samples_per_frame), "sparsity": sparsity,
         "roofline": roofline, **tinfo,
     }
+    if rank == 0 and world == 1 and not args.no_api:
+        result.update(bench_through_caster(args, device, extra, inp, out))
     if rank == 0 and world == 1:
         if not args.no_dense:
             render(eng, inp, dense=True)
@@ -437,6 +439,45 @@ def bench_render(args, rank, world, device, dist):
     return result
 
 
+def bench_through_caster(args, device, extra, inp, engine_out):
+    """The same frame through the DROP-IN call path (missing 1): `core.trainer.render(H, W, focal, chunk=4096,
+    rays=..., kp_batch=..., skts=..., **render_kwargs_test)` exactly as run_render.py / render_path call it (reference
+    run_nerf.py:64-91 -> core/trainer.py:96-161 -> batchify_rays -> ray_caster(...)), on a caster built by create_raycaster from the
+    shipped config file and loaded with the same weights.  -> api_ms_per_step / api_value (median of N_BLOCKS blocks of --steps
+    frames, same bracketing as the headline) and whether its maps are bit-identical to the engine-level frame that was timed."""
+    from core import trainer
+    from core.config import parse_args
+    from core.raycasters import create_raycaster
+    from core.utils.skeleton_utils import SMPLSkeleton
+    cfg, sd, rest, scene, ro, rd = extra
+    cfg_file = "danbo_fast.txt" if args.config == 2 else "danbo_base.txt"
+    targs = parse_args(["--no_reload"], config=os.path.join(ROOT, "danbo-pytorch_amd", "configs", "h36m_zju", cfg_file))
+    da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=100, rest_pose=rest, hwf=(H, W, 0.))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the constructors print; stdout carries the JSON line only
+        _, te_kw, *_ = create_raycaster(targs, da, device=device)
+    caster = te_kw["ray_caster"].eval()
+    caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    caster.use_volume_near_far = bool(args.box_near_far)
+    kw = {k: v for k, v in te_kw.items() if k not in ("N_samples", "N_importance")}
+    n = H * W
+    exp = lambda x: x[:1].expand(n, *x.shape[1:])  # noqa: E731   (render_path's reuse_input(x, expand): one pose behind every ray)
+    kps = torch.tensor(np.ascontiguousarray(scene["kps"]), dtype=torch.float32, device=device)
+    call = dict(chunk=4096, rays=(inp["rays_o"], inp["rays_d"]), kp_batch=exp(kps), skts=exp(inp["skts"]), cyls=exp(inp["cyls"]),
+                bones=exp(inp["bones"]), cams=inp["cam_idx"][:1].expand(n), N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, **kw)
+
+    def frame():
+        return trainer.render(H, W, scene.get("focal", 0.), **call)
+    elapsed, out, tinfo = timed(frame, args.steps, args.warmup, None, device, False)
+    same = all(torch.equal(out[k].reshape(engine_out[k].shape), engine_out[k]) for k in engine_out if torch.is_tensor(engine_out[k]) and k in out)
+    del caster
+    return dict(api_ms_per_step=1e3 * elapsed / args.steps, api_value=args.steps * n * (N_SAMPLES + N_IMPORTANCE) / elapsed,
+                api_spread=tinfo["spread"], api_equals_engine=bool(same),
+                api_note="the same frame through core.trainer.render(H, W, focal, chunk=4096, rays=..., **render_kwargs_test) on a caster "
+                         "from create_raycaster(configs/h36m_zju/" + cfg_file + "): the call run_render.py makes per image; the caster "
+                         "takes the image's rays in one cast (RayCaster.render_rays_whole), bit-identical to the 64-chunk loop")
+
+
 # ---------------------------------------------------------------------------------------------- config 4: training step
 def bench_train(args, rank, world, device, dist):
     from core.config import parse_args
@@ -448,7 +489,9 @@ def bench_train(args, rank, world, device, dist):
     rest = syn.rest_pose(0.48)
     da = dict(skel_type=SMPLSkeleton, near=0., far=100., n_views=20, rest_pose=rest, hwf=(128, 128, 160.))
     torch.manual_seed(0)
-    tr_kw, te_kw, start, grad_vars, opt, _ = create_raycaster(targs, da, device=device)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the constructors print; stdout carries the JSON line only
+        tr_kw, te_kw, start, grad_vars, opt, _ = create_raycaster(targs, da, device=device)
     caster = tr_kw["ray_caster"]
     sd = syn.make_state_dict(syn.model_config("danbo_perfcap"), 3, 20, rest)
     caster.network.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
@@ -725,6 +768,7 @@ def main():
                          "split by whole poses over the ranks (SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the timing of the same frame through core.trainer.render (api_value)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the occupancy sweep (camera distance) of the render configs")
     ap.add_argument("--coarse", type=int, default=None, help="dev: coarse samples per ray")
     ap.add_argument("--fine", type=int, default=None, help="dev: importance samples per ray")

@@ -246,6 +246,33 @@ class RayCaster(nn.Module):
             return self._graphs.run(eng, key, chain, ray_batch, skts_g, bones_g, cyls_g, cams)
         return chain(ray_batch, skts_g, bones_g, cyls_g, cams)
 
+    @staticmethod
+    def _one_pose(x):
+        """x [R, ...] is ONE row behind every ray: an expanded view (stride 0, what render_path builds) or R == 1"""
+        return x is not None and (x.shape[0] == 1 or x.stride(0) == 0)
+
+    @torch.no_grad()
+    def render_rays_whole(self, ray_batch, chunk, N_samples=None, kp_batch=None, skts=None, cyls=None, bones=None, cams=None,
+                          lindisp=False, perturb=0., N_importance=0, raw_noise_std=0., ray_noise_std=0., N_uniques=1,
+                          preproc_kwargs={}, fwd_type='', **kwargs):
+        """`trainer.batchify_rays`' loop over `chunk`-ray casts as ONE cast of all rays, when that is the same computation, else
+        None (the caller loops).  It is the same when every ray belongs to one pose (so a chunk's N_uniques = 1 whatever the
+        chunking) and the engine is the DANBO engine: every stage is per ray or per sample except the cylinder bounds' nan-mean
+        back-fill, which the bounds kernel takes per `chunk` rays -- exactly one reference call each (ray_utils.py:330-344)."""
+        if (self.training or fwd_type or N_importance <= 0 or perturb or raw_noise_std or ray_noise_std or lindisp
+                or int(N_uniques) != 1 or not all(self._one_pose(x) for x in (skts, bones, cyls))):
+            return None
+        eng = self._engine()
+        if not isinstance(eng, DanboEngine) or N_samples > 256 or N_importance > 64:
+            return None
+        eng.cfg['density_scale'] = preproc_kwargs.get('density_scale', eng.cfg['density_scale'])
+        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+        skts_g, bones_g, cyls_g = skts[:1].contiguous(), bones[:1].contiguous(), cyls[:1].contiguous()
+        near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., int(chunk), ray_batch[:, 6], ray_batch[:, 7])
+        if eng.cfg['use_volume_near_far']:
+            ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
+        return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance, near_far=(near, far))
+
     def render_rays_train(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
                           subject_idxs=None, lindisp=False, perturb=0., N_importance=0, raw_noise_std=0.,
                           ray_noise_std=0., N_uniques=1, preproc_kwargs={}, netchunk=1024 * 64, **kwargs):

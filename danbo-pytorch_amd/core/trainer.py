@@ -24,7 +24,17 @@ from .utils.lazy import LazyDict
 
 def batchify_rays(rays_flat, chunk=1024 * 64, ray_caster=None, **kwargs):
     """Cast rays chunk by chunk and concatenate every returned tensor (reference :75-90).  Per-ray tensors in `kwargs` are
-    sliced with the rays; everything else is passed through."""
+    sliced with the rays; everything else is passed through.
+
+    A caster of this package in eval mode takes the WHOLE ray set in one call when that is the same computation
+    (`RayCaster.render_rays_whole`: one pose behind all rays, DANBO engine; the only thing `chunk` decides in the reference's
+    chain -- the chunk-wide nan-mean of the cylinder bounds -- is handed to the bounds kernel): bit-identical to the loop, without
+    its per-chunk slicing, replay and concatenation (tests/test_gpu_modules.py)."""
+    whole = getattr(ray_caster, 'render_rays_whole', None)
+    if whole is not None and rays_flat.shape[0] > chunk:
+        out = whole(rays_flat, chunk, **kwargs)
+        if out is not None:
+            return out
     parts = {}
     for i in range(0, rays_flat.shape[0], chunk):
         kw = {k: (v[i:i + chunk] if torch.is_tensor(v) else v) for k, v in kwargs.items()}

@@ -20,6 +20,7 @@
 // One workgroup = 8 wavefronts x 16 samples = 128 rows, TWO wavefronts per SIMD (<= 256 VGPRs
 // each): while one wavefront waits on the weight ring, LDS or its epilogue VALU work, the other
 // keeps the matrix pipe busy (a one-wavefront-per-SIMD version spent half its time stalled).
+#include <cstdlib>
 #include "mlp16_core.hpp"
 
 namespace danbo {
@@ -570,6 +571,9 @@ extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_
     a.n_chunks = NCH_TOTAL;
     { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
+    // dev A/B (tools/micro_mlp16.py --noscale): maxima of 0 pack every matrix times 1 -- round 4's packing
+    static const bool noscale = getenv("DANBO_MLP16_NOSCALE") != nullptr;
+    if (noscale) { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }

@@ -29,7 +29,13 @@ def test_config2_h36m_danbo_fast_caster_matches_reference():
     # stage-wise with the engine: bounds, then raw logits on the reference's own bounds (1 ulp of a bound moves every sample)
     eng = caster._engine()
     near, far = eng.near_far(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["cyls"]), T(g["skts"]), chunk=len(rb))
-    assert np.array_equal(N(near), g["near"][:, 0]) and np.array_equal(N(far), g["far"][:, 0])     # every ray of the fixture meets a box
+    # rays that meet a box: the reference's bounds bit for bit; the 48 that keep the cylinder's: <= 1 ulp (the reference's CPU
+    # `.pow(0.5)` is Sleef's pow, not sqrt, on 1 % of the rays -- ray_utils.py:318; its GPU form is sqrt)
+    nc, fc = o.near_far_cylinder(rb[:, 0:3], rb[:, 3:6], g["cyls"][pose], rb[:, 6:7], rb[:, 7:8])
+    boxed = (np.abs(g["near"][:, 0] - nc[:, 0]) > 1e-6) | (np.abs(g["far"][:, 0] - fc[:, 0]) > 1e-6)
+    assert boxed.sum() >= 200
+    assert np.array_equal(N(near)[boxed], g["near"][boxed, 0]) and np.array_equal(N(far)[boxed], g["far"][boxed, 0])
+    assert max_err(N(near), g["near"][:, 0]) < 2.4e-7 and max_err(N(far), g["far"][:, 0]) < 2.4e-7
     nf = (T(g["near"][:, 0]), T(g["far"][:, 0]))
     ret = eng.render(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cyls"]), T(g["cam_idx"], torch.int64), S, Sf,
                      near_far=nf, keep=True)

@@ -208,3 +208,41 @@ def test_small_chunks_replay_a_hip_graph_and_equal_the_eager_chain():
     caster.use_graphs = True
     got = caster(*args, **kwargs)
     assert all(torch.equal(want[k], got[k]) for k in want) and not torch.equal(want["acc_map"], eager["acc_map"])
+
+
+@pytest.mark.parametrize("cfg_file,fixture", [("h36m_zju/danbo_base.txt", "danbo_stages"), ("surreal/danbo_fast.txt", "danbo_surreal")])
+def test_render_of_a_whole_image_equals_the_chunk_loop_bitwise(cfg_file, fixture):
+    """core.trainer.render(..., chunk=c, rays=...) as run_render.py / render_path call it (reference run_nerf.py:64-91,
+    core/trainer.py:96-161): the caster takes the whole ray set in ONE cast (RayCaster.render_rays_whole) -- every output
+    bit-identical to the reference-shaped loop of chunk-sized casts, incl. the chunk-wide nan-mean of the cylinder bounds (the
+    SURREAL frame has rays that miss the cylinder; chunk sizes that do and do not divide the ray count)"""
+    from core import trainer
+    from core.utils import synthetic as syn
+    g = golden(fixture)
+    rest_scale = syn.model_config(str(g["cfg_name"]))["rest_scale"]
+    caster, kw = build(cfg_file, g, rest_scale=rest_scale)
+    scene = syn.make_scene(n_poses=1, H=64, W=64, n_views=3, pose_seed=2, rest_scale=rest_scale, cam_dist=5.0)
+    ro, rd = (T(x) for x in scene["rays"][1])
+    n = len(ro)
+    exp = lambda x, dt=torch.float32: T(x, dt)[:1].expand(n, *x.shape[1:])  # noqa: E731
+    kwargs = dict(kp_batch=exp(scene["kps"]), skts=exp(scene["skts"]), cyls=exp(scene["cyls"]), bones=exp(scene["bones"]),
+                  cams=torch.zeros(1, dtype=torch.int64, device=DEV).expand(n), ray_caster=caster, N_samples=24, N_importance=12, **kw)
+    for chunk in (1024, 1000):
+        whole = trainer.render(64, 64, 80., chunk=chunk, rays=(ro, rd), **kwargs)
+        calls = []
+        orig = caster.render_rays_whole
+        caster.render_rays_whole = lambda *a, **k: calls.append(1)       # returns None: batchify_rays falls back to its loop
+        try:
+            loop = trainer.render(64, 64, 80., chunk=chunk, rays=(ro, rd), **kwargs)
+        finally:
+            caster.render_rays_whole = orig
+        assert calls and set(whole) == set(loop)
+        for k in loop:
+            assert whole[k].shape == loop[k].shape and torch.equal(whole[k], loop[k]), (chunk, k)
+    # per-ray pose tensors that are not ONE expanded row (several poses may hide behind them): the caster declines, the loop runs
+    kwargs["skts"] = T(np.repeat(scene["skts"], n, 0))
+    rb = torch.cat([ro, rd, torch.zeros(n, 1, device=DEV), torch.ones(n, 1, device=DEV)], 1)
+    assert caster.render_rays_whole(rb, 1024, **{k: v for k, v in kwargs.items() if k != "ray_caster"}) is None
+    again = trainer.render(64, 64, 80., chunk=1024, rays=(ro, rd), **kwargs)
+    whole = trainer.render(64, 64, 80., chunk=1024, rays=(ro, rd), **dict(kwargs, skts=exp(scene["skts"])))
+    assert all(torch.equal(again[k], whole[k]) for k in whole)
