@@ -392,7 +392,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                     }
-                    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yf + 256 * T), "v"(v) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(yf + 256 * T), "v"(v) : "memory");   // wait states: see mlp16_core.hpp store16_s
                 }
             }
         } else
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                     // inline asm like the loads: no compiler-inserted waits.  The hand-over waits stay valid with stores in
                     // flight even if stores and loads complete out of order with respect to each other: they allow no more
                     // outstanding operations than there are younger LOADS, and loads return in order.
-                    if (col + 4 <= a.N) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yrow + col), "v"(v) : "memory");
+                    if (col + 4 <= a.N) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(yrow + col), "v"(v) : "memory");
                     else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)

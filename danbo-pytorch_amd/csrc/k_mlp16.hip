@@ -344,32 +344,39 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
     prefetch_rows(src, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ring chunks 0-2 and the first rows (tables: the same barrier)
     __syncthreads();
+    agroup_prefetch0(ring_lane_addr());               // group 0 of chunk 0 (slot 0): every later chunk is prefetched by its predecessor
 
     for (int tile = tile0 + blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ------------------------------------------------------------------ inputs (staged during the previous tile)
-        const int row = tile * M16_BM + wave * 16 + m;
-        const bool row_ok = row < n;
-        const float* sh = reinterpret_cast<const float*>(src.stage) + m * DANBO_H_STRIDE + qq;
+        // lane constants of the tile's prologue, re-derived per tile (see the head below)
+        int zero_t = 0;
+        asm volatile("" : "+s"(zero_t));
+        const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_t));
+        const int m = lane_t & 15, qq_t = lane_t >> 4;
+        const int row0 = tile * M16_BM + wave * 16 + m;
+        const bool row_ok = row0 < n;
+        const float* sh = reinterpret_cast<const float*>(src.stage) + m * DANBO_H_STRIDE + qq_t;
         const int staged_dst = reinterpret_cast<const int*>(src.stage + STAGE_H_BYTES)[m];
         int dst, ray;
         bool has_h = row_ok;
         if (TRAIN) {
             // rows [0, R): the ray's empty-space row (h = 0); [R, first_f): coarse samples; [first_f, n): importance samples
-            const bool empty = row < tr.R;
-            dst = row_ok ? (empty ? row : staged_dst) : -1;
+            const bool empty = row0 < tr.R;
+            dst = row_ok ? (empty ? row0 : staged_dst) : -1;
             ray = 0;           // derived from dst behind the layer loop
             has_h = row_ok && !empty;
             asm volatile("" : "+v"(dst));
         } else {
-            dst = row_ok ? (a.list ? staged_dst : row) : -1;
+            dst = row_ok ? (a.list ? staged_dst : row0) : -1;
             asm volatile("" : "+v"(dst));  // materialised now: the staging area is overwritten during this tile's view layer
-            ray = dst >= 0 ? dst / a.S : 0;
+            ray = 0;                       // = dst / S, formed in the head: ONE register (dst) crosses the layer loop, not the 64-bit
+                                           // offset of the ray's view constants the compiler would make of it here (and spill)
         }
         // this lane's 4 channels: kk = qq + 4c  (kk = 15 is padding)
         float hv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) hv[c] = has_h ? sh[4 * c] : 0.f;
-        if (qq == 3) hv[3] = 0.f;
+        if (qq_t == 3) hv[3] = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(hv[c]));
         float alpha_part = 0.f;
@@ -403,8 +410,9 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
                     split8(v8, xh, xl);                                            \
                     /* TRAIN: layer 0 stores 2 per chunk (the wait may leave this chunk's and the previous one's in flight); the \
                        skip layer's pass over the same code stores nothing */     \
-                    chunk_mfma<NCH_TOTAL, 16, false, FIRST_, TRAIN ? ((KS) == 0 ? 6 : 8) : 4, NoExtra, 4>(acc, p, xh, xl, xh, xl, NoExtra(), \
-                                                                                                         step != 0);     \
+                    /* (KS == 6 drains the MFMAs also in the skip layer, whose act chunks follow: 21 idle cycles per tile) */ \
+                    chunk_mfma2<NCH_TOTAL, 16, false, FIRST_, (KS) == 6, TRAIN ? ((KS) == 0 ? 6 : 8) : 4, NoExtra, 4>(         \
+                        acc, p, ring_lane_addr(), xh, xl, xh, xl, NoExtra(), step != 0);                                  \
                 }
                 DANBO_X0_STEP(0, true)
                 DANBO_X0_STEP(1, false)
@@ -436,8 +444,8 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
                     act_fragment<false, TRAIN, 0>(prev[0], prev[1], bias, nullptr, alpha_part, bh, bl, winv, yg, rg);
                     // TRAIN: 3 stores here (two halves of a k-step + its sign byte) and >= 2 in the previous chunk -- except behind the
                     // skip layer's PE chunks, which store nothing
-                    if (step == 5) chunk_mfma<NCH_TOTAL, 16, false, false, TRAIN ? 7 : 4>(acc, p, bh, bl, bh, bl);
-                    else chunk_mfma<NCH_TOTAL, 16, false, true, TRAIN ? 9 : 4>(acc, p, bh, bl, bh, bl);
+                    if (step == 5) chunk_mfma2<NCH_TOTAL, 16, false, false, false, TRAIN ? 7 : 4>(acc, p, ring_lane_addr(), bh, bl, bh, bl);
+                    else chunk_mfma2<NCH_TOTAL, 16, false, true, false, TRAIN ? 9 : 4>(acc, p, ring_lane_addr(), bh, bl, bh, bl);
                 }
 #define DANBO_ACT_STEP(s)                                                                                               \
                 {                                                                                                       \
@@ -447,7 +455,7 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
                     const float* bias_s = bias + off_s;  /* the pointer must stay an LDS pointer) */                     \
                     act_fragment<false, TRAIN, (s)>(prev[2 * (s)], prev[2 * (s) + 1], bias_s, nullptr, alpha_part, bh, bl, winv,       \
                                                         yg + (s) * 512, rg);                                            \
-                    chunk_mfma<NCH_TOTAL, 16, false, false, TRAIN ? 10 : 4>(acc, p, bh, bl, bh, bl);                    \
+                    chunk_mfma2<NCH_TOTAL, 16, false, false, (s) == 7, TRAIN ? 10 : 4>(acc, p, ring_lane_addr(), bh, bl, bh, bl); \
                 }
                 DANBO_ACT_STEP(1) DANBO_ACT_STEP(2) DANBO_ACT_STEP(3) DANBO_ACT_STEP(4) DANBO_ACT_STEP(5) DANBO_ACT_STEP(6) DANBO_ACT_STEP(7)
 #undef DANBO_ACT_STEP
@@ -469,9 +477,9 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
                     act_fragment<true, TRAIN, 2 * (c) + 1>(prev[4 * (c) + 2], prev[4 * (c) + 3], bias_c + 32, aw_c + 32, alpha_part,   \
                                                             b1h, b1l, winv, yg + (2 * (c) + 1) * 512, rg);              \
                     /* TRAIN: 6 stores per chunk here; chunk 0 follows layer 7's last chunk (3 stores) */               \
-                    if ((c) == 0) chunk_mfma<NCH_TOTAL, 8, true, true, TRAIN ? 13 : 4, StageRows>(accv, p, b0h, b0l, b1h, b1l, StageRows{src, lane});  \
-                    else if ((c) == 1) chunk_mfma<NCH_TOTAL, 8, true, false, TRAIN ? 18 : 6>(accv, p, b0h, b0l, b1h, b1l);   \
-                    else chunk_mfma<NCH_TOTAL, 8, true, false, TRAIN ? 16 : 4>(accv, p, b0h, b0l, b1h, b1l);            \
+                    if ((c) == 0) chunk_mfma2<NCH_TOTAL, 8, true, true, false, TRAIN ? 13 : 4, StageRows>(accv, p, ring_lane_addr(), b0h, b0l, b1h, b1l, StageRows{src, lane});  \
+                    else if ((c) == 1) chunk_mfma2<NCH_TOTAL, 8, true, false, false, TRAIN ? 18 : 6>(accv, p, ring_lane_addr(), b0h, b0l, b1h, b1l);   \
+                    else chunk_mfma2<NCH_TOTAL, 8, true, false, (c) == 3, TRAIN ? 16 : 4>(accv, p, ring_lane_addr(), b0h, b0l, b1h, b1l); \
                 }
                 DANBO_VIEW_STEP(0) DANBO_VIEW_STEP(1) DANBO_VIEW_STEP(2) DANBO_VIEW_STEP(3)
 #undef DANBO_VIEW_STEP
@@ -482,7 +490,16 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
             for (int T = 0; T < 16; ++T) prev[T] = acc[T];
         }
         f32x4 (&accv)[8] = *reinterpret_cast<f32x4 (*)[8]>(&prev[0]);
+        // the head's lane constants are re-derived HERE (two mbcnt operations): computed once at the top of the kernel they live --
+        // i.e. are spilled and reloaded, each reload a VMEM operation whose wait drains the weight ring -- across the layer loop
+        int zero_h = 0;
+        asm volatile("" : "+s"(zero_h));
+        const int lane_h = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_h));
+        const int qq = lane_h >> 4, lane = lane_h;
+        const int row = tile * M16_BM + wave * 16 + (lane_h & 15);       // as at the top of the tile
+        asm volatile("" : "+v"(dst));
         if (TRAIN) ray = dst < 0 ? 0 : (row < tr.R ? dst : dst / (row < first_f ? tr.S_c : tr.S_f));
+        else ray = dst >= 0 ? dst / a.S : 0;
         // this tile's per-ray view constants: eight untracked loads and ONE wait (a compiler-tracked load per column tile
         // would each wait with vmcnt(0)); the trunk's registers are free here
         f32x4 cvq[8];
@@ -545,13 +562,15 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
             if (a.aux_out) a.aux_out[(size_t)row * (VW_ + 1) + VW_] = al;
         }
     }
-    // every wavefront executed the same number of hand-overs; drain the ring before the LDS is released
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // every wavefront executed the same number of hand-overs; drain the ring (and the last chunk's fragment prefetch) before the
+    // LDS is released
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(M16_THREADS, 2) void k_pe_mlp16(Mlp16Args a) { mlp16_body<false>(a, TrainFwd{}); }
-__global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_fwd(Mlp16Args a, TrainFwd t) { mlp16_body<true>(a, t); }
+// amdgpu_num_vgpr(224): v224..v255 belong to chunk_mfma2's fragment buffers (mlp16_core.hpp)
+__global__ __launch_bounds__(M16_THREADS, 2) __attribute__((amdgpu_num_vgpr(224))) void k_pe_mlp16(Mlp16Args a) { mlp16_body<false>(a, TrainFwd{}); }
+__global__ __launch_bounds__(M16_THREADS, 2) __attribute__((amdgpu_num_vgpr(224))) void k_train_mlp_fwd(Mlp16Args a, TrainFwd t) { mlp16_body<true>(a, t); }
 
 }  // namespace danbo
 

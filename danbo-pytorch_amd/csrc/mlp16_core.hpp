@@ -30,15 +30,27 @@ struct Pipe {
     bool early;
 };
 
-// every wavefront loads 4 of the 32 pieces of a chunk
+// lane * 16, re-derived where it is used (two VALU operations) instead of living in a register across the layer loop
+__device__ __forceinline__ unsigned lane_off16() {
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) << 4;
+}
+
+
+// every wavefront loads 4 of the 32 pieces of a chunk: ONE wave-uniform base (SGPR pair) + the lane's 32-bit offset, and the
+// instruction's immediate offset -- which LDS-DMA applies to the global AND the LDS address -- for the four pieces: one M0 write and
+// no 64-bit VALU address arithmetic per hand-over (round 4's form: 3 v_lshl_add_u64 + 3 M0 updates per hand-over)
 template <int NCH>
 __device__ __forceinline__ void pipe_issue(Pipe& p) {
-    const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 4096 + p.lane * 16;
+    const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 4096;     // wave-uniform
     char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 4096;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+    const char* lane_src = src + (size_t)lane_off16();
+#define DANBO_PIECE(Q)                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)lane_src,            \
+                                     (__attribute__((address_space(3))) void*)dst, 16, (Q) * 1024, 0)
+    DANBO_PIECE(0); DANBO_PIECE(1); DANBO_PIECE(2); DANBO_PIECE(3);
+#undef DANBO_PIECE
     p.issue_chunk = p.issue_chunk + 1 == NCH ? 0 : p.issue_chunk + 1;
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
 }
@@ -125,13 +137,161 @@ __device__ __forceinline__ void chunk_mfma(f32x4 (&acc)[NACC], Pipe& p, const ha
     }
 }
 
-__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)v[e];
-        hi[e] = hh;
-        lo[e] = (_Float16)(v[e] - (float)hh);
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the chunk as hand-scheduled inline asm (chunk_mfma2).  What the compiler made of chunk_mfma (ISA of round 4, one
+// 2-tile batch): 4 ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 6 MFMAs, each the accumulator successor of the one before and every
+// result landing in the register of its A operand -> `s_nop 5` until the last MFMA has retired before the next batch's reads may
+// overwrite those registers.  A wavefront alternated between an LDS round trip with an idle matrix pipe and 6 dependent MFMAs;
+// only its SIMD partner covered the gaps (matrix pipe 58 % busy, profiles/r03_pmc_sq.txt).  Here:
+//   * accumulators in place (v_mfma acc, A, B, acc): no result ever lands in a fragment register;
+//   * A fragments in PINNED registers v224..v255 (two buffers of one 2-tile group: hi0 lo0 hi1 lo1), written by ds_read_b128 and read
+//     as the MFMAs' SrcA -- the kernels are compiled with amdgpu_num_vgpr(224), so the compiler allocates none of them (it sees
+//     them as clobbers only) and a fragment in flight across compiler-generated code cannot be copied or overwritten (AccVGPRs
+//     would do too, but one AccVGPR in a clobber list makes this compiler split the 256 registers 128 + 128: 164 B of spills);
+//   * true double buffering: the reads of group g+1 are issued between the MFMAs of group g, the wait in front of a group's
+//     MFMAs is for ITS reads only; the last group of a chunk reads the first group of the NEXT chunk (the ring hand-over that
+//     publishes chunk c+1 lies inside or before chunk c for every wavefront), so a chunk starts with its fragments in registers;
+//   * the two tiles of a group interleaved (hh0 hh1 hl0 hl1 lh0 lh1): no MFMA is the accumulator successor of its predecessor.
+// Per accumulator the products are added in the order hh, hl, lh of k-step s as before: results are bit-identical to chunk_mfma.
+// Software wait states the compiler cannot see: `s_nop 1` in front of a chunk's first MFMA (the B fragments come from VALU
+// instructions), MFMA_DRAIN behind the last MFMA of a GEMM (its accumulators are read by VALU instructions next).
+// ---------------------------------------------------------------------------------------------------------------------------
+#define DANBO_A_CLOBBERS                                                                                                       \
+    "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", \
+        "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "memory"
+#define DANBO_MFMA_DRAIN "s_nop 15\n\ts_nop 5\n\t"
+
+// the four fragments (pieces 4 G .. 4 G + 3) of group G of the chunk at LDS byte address `base` (lane * 16 included) -> buffer 0
+__device__ __forceinline__ void agroup_prefetch0(unsigned base) {
+    asm volatile("ds_read_b128 v[224:227], %0\n\tds_read_b128 v[228:231], %0 offset:1024\n\t"
+                 "ds_read_b128 v[232:235], %0 offset:2048\n\tds_read_b128 v[236:239], %0 offset:3072" ::"v"(base) : DANBO_A_CLOBBERS);
+}
+
+// One group: wait for its fragments (buffer G & 1), 6 MFMAs on two in-place accumulators, and between them the 4 reads of the
+// NEXT group (G + 1 of this chunk, or group 0 of the next chunk: `nbase`, offset 0) into the other buffer.
+//   H0/L0/H1/L1: this group's fragment registers; N0..N3: the other buffer's; FIRST: the accumulators start from zero;
+//   HEAD: first group of a chunk (wait state behind the VALU that made the B fragments); DRAIN: last MFMA of a GEMM.
+#ifndef DANBO_M16_READS_AT
+#define DANBO_M16_READS_AT 1     // the next group's 4 reads: 0 = in front of the group's MFMAs, 1 = behind the first, 2 = two behind the second + two behind the fourth
+#endif
+#if DANBO_M16_READS_AT == 0
+#define DANBO_GROUP_BODY(H0, L0, H1, L1, N0, N1, N2, N3, C0, C1)                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
+    "ds_read_b128 " N0 ", %[nb] offset:%[o0]\n\t"                                                                              \
+    "ds_read_b128 " N1 ", %[nb] offset:%[o1]\n\t"                                                                              \
+    "ds_read_b128 " N2 ", %[nb] offset:%[o2]\n\t"                                                                              \
+    "ds_read_b128 " N3 ", %[nb] offset:%[o3]\n\t"                                                                              \
+    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bh], " C0 "\n\t"                                                                 \
+    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bh], " C1 "\n\t"                                                                 \
+    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bl], %[a0]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bl], %[a1]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
+#elif DANBO_M16_READS_AT == 1
+#define DANBO_GROUP_BODY(H0, L0, H1, L1, N0, N1, N2, N3, C0, C1)                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
+    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bh], " C0 "\n\t"                                                                 \
+    "ds_read_b128 " N0 ", %[nb] offset:%[o0]\n\t"                                                                              \
+    "ds_read_b128 " N1 ", %[nb] offset:%[o1]\n\t"                                                                              \
+    "ds_read_b128 " N2 ", %[nb] offset:%[o2]\n\t"                                                                              \
+    "ds_read_b128 " N3 ", %[nb] offset:%[o3]\n\t"                                                                              \
+    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bh], " C1 "\n\t"                                                                 \
+    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bl], %[a0]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bl], %[a1]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
+#else
+#define DANBO_GROUP_BODY(H0, L0, H1, L1, N0, N1, N2, N3, C0, C1)                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
+    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bh], " C0 "\n\t"                                                                 \
+    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bh], " C1 "\n\t"                                                                 \
+    "ds_read_b128 " N0 ", %[nb] offset:%[o0]\n\t"                                                                              \
+    "ds_read_b128 " N1 ", %[nb] offset:%[o1]\n\t"                                                                              \
+    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bl], %[a0]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bl], %[a1]\n\t"                                                                  \
+    "ds_read_b128 " N2 ", %[nb] offset:%[o2]\n\t"                                                                              \
+    "ds_read_b128 " N3 ", %[nb] offset:%[o3]\n\t"                                                                              \
+    "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
+    "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
+#endif
+
+template <int G, bool FIRST, bool HEAD, bool DRAIN>
+__device__ __forceinline__ void group_mfma(f32x4& a0, f32x4& a1, const half8& bh, const half8& bl, unsigned cbase, unsigned nbase) {
+    constexpr int NO = G == 7 ? 0 : (G + 1) * 4096;      // byte offset of the next group's first fragment
+    const unsigned nb = G == 7 ? nbase : cbase;
+#define DANBO_GROUP_ASM(BODY, ACC_CONSTRAINT)                                                                                   \
+    asm volatile(BODY : [a0] ACC_CONSTRAINT(a0), [a1] ACC_CONSTRAINT(a1)                                                        \
+                 : [bh] "v"(bh), [bl] "v"(bl), [nb] "v"(nb), [o0] "n"(NO), [o1] "n"(NO + 1024), [o2] "n"(NO + 2048), [o3] "n"(NO + 3072) \
+                 : DANBO_A_CLOBBERS)
+#define DANBO_GROUP_VARIANT(PRE, POST)                                                                                          \
+    if ((G & 1) == 0) {                                                                                                        \
+        if (FIRST) DANBO_GROUP_ASM(PRE DANBO_GROUP_BODY("v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", "v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", "0", "0") POST, "=&v"); \
+        else DANBO_GROUP_ASM(PRE DANBO_GROUP_BODY("v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", "v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", "%[a0]", "%[a1]") POST, "+v"); \
+    } else {                                                                                                                   \
+        if (FIRST) DANBO_GROUP_ASM(PRE DANBO_GROUP_BODY("v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", "v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", "0", "0") POST, "=&v"); \
+        else DANBO_GROUP_ASM(PRE DANBO_GROUP_BODY("v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", "v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", "%[a0]", "%[a1]") POST, "+v"); \
     }
+    if (HEAD) { DANBO_GROUP_VARIANT("s_nop 1\n\t", "") }
+    else if (DRAIN) { DANBO_GROUP_VARIANT("", DANBO_MFMA_DRAIN) }
+    else { DANBO_GROUP_VARIANT("", "") }
+#undef DANBO_GROUP_VARIANT
+#undef DANBO_GROUP_ASM
+}
+
+// LDS byte address of the ring (dynamic shared memory starts at the workgroup's LDS base) + lane * 16, re-derived where it is used
+__device__ __forceinline__ unsigned ring_lane_addr() {
+    extern __shared__ __attribute__((aligned(16))) char smem_ring[];
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_ring + lane_off16();
+}
+
+// chunk_mfma with the hand-scheduled groups.  `lds_ring`: LDS byte address of the ring + lane * 16 (a VGPR).  On entry buffer 0
+// holds (or is receiving) group 0 of this chunk; on exit, group 0 of the next one.  LAST: the GEMM's last chunk.
+template <int NCH, int NACC, bool VIEW, bool FIRST, bool LAST, int WAIT = 4, class Extra = NoExtra, int WAIT_ALT = WAIT>
+__device__ __forceinline__ void chunk_mfma2(f32x4 (&acc)[NACC], Pipe& p, unsigned lds_ring, const half8& b0h, const half8& b0l,
+                                            const half8& b1h, const half8& b1l, const Extra& extra = Extra(), bool alt = false) {
+    static_assert(NACC == (VIEW ? 8 : 16), "dense layers: 16 output tiles; view layer: 2 k-steps of 8");
+    if (!p.early) pipe_handover<NCH, WAIT, Extra, WAIT_ALT>(p, extra, alt);
+    const unsigned cbase = lds_ring + (unsigned)p.cons_slot * CHUNK_BYTES;
+    p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
+    const unsigned nbase = lds_ring + (unsigned)p.cons_slot * CHUNK_BYTES;
+    group_mfma<0, FIRST, true, false>(acc[0], acc[1], b0h, b0l, cbase, nbase);
+    group_mfma<1, FIRST, false, false>(acc[2], acc[3], b0h, b0l, cbase, nbase);
+    group_mfma<2, FIRST, false, false>(acc[4], acc[5], b0h, b0l, cbase, nbase);
+    group_mfma<3, FIRST, false, false>(acc[6], acc[7], b0h, b0l, cbase, nbase);
+    if (p.early) pipe_handover<NCH, WAIT, Extra, WAIT_ALT>(p, extra, alt);
+    if (VIEW) {
+        group_mfma<4, false, false, false>(acc[0], acc[1], b1h, b1l, cbase, nbase);
+        group_mfma<5, false, false, false>(acc[2], acc[3], b1h, b1l, cbase, nbase);
+        group_mfma<6, false, false, false>(acc[4], acc[5], b1h, b1l, cbase, nbase);
+        group_mfma<7, false, false, LAST>(acc[6], acc[7], b1h, b1l, cbase, nbase);
+    } else {
+        group_mfma<4, FIRST, false, false>(acc[NACC == 16 ? 8 : 0], acc[NACC == 16 ? 9 : 1], b0h, b0l, cbase, nbase);
+        group_mfma<5, FIRST, false, false>(acc[NACC == 16 ? 10 : 2], acc[NACC == 16 ? 11 : 3], b0h, b0l, cbase, nbase);
+        group_mfma<6, FIRST, false, false>(acc[NACC == 16 ? 12 : 4], acc[NACC == 16 ? 13 : 5], b0h, b0l, cbase, nbase);
+        group_mfma<7, FIRST, false, LAST>(acc[NACC == 16 ? 14 : 6], acc[NACC == 16 ? 15 : 7], b0h, b0l, cbase, nbase);
+    }
+}
+
+// hi = fp16(x), lo = fp16(x - float(hi)) of eight values as THREE instructions per pair: v_cvt_pk_f16_f32 for the two hi halves,
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 (fma(x, 1.0, -hi) with the fp16 operand widened inside the instruction, the fp32 result -- exact:
+// x - hi has at most 13 significant bits -- rounded once to fp16 into the low / high half of the destination) for the two lo halves.
+// What the compiler makes of the plain C++ form is ~7 per pair (cvt, cvt back, sub -- partly as v_pk_add_f32, an anti-lever beside
+// MFMAs -- and a second cvt_pk): 43 VALU instructions per k-step epilogue, 28 with this.  Bit-identical on 33.5 M random pairs of
+// every exponent incl. the fp16 subnormal and overflow ranges (tools/probe/split_probe.hip).
+__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned hp, lp;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(v[2 * p]), "v"(hp));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(v[2 * p + 1]), "v"(hp));
+        h[p] = hp;
+        l[p] = lp;
+    }
+    hi = __builtin_bit_cast(half8, h);
+    lo = __builtin_bit_cast(half8, l);
 }
 
 // sum of the four lane-group partials of a sample; identical in all four groups
@@ -162,7 +322,10 @@ __device__ __forceinline__ void weight_pow2_scale(float maxabs, float& s, float&
 // 64-bit pointers in the register-starved MLP kernels.  `off` < 4096 (the instruction's immediate).
 template <int OFF>
 __device__ __forceinline__ void store16_s(const void* base, unsigned lane_off, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(lane_off), "v"(v), "s"(base), "i"(OFF) : "memory");
+    // + 2 wait states: a store of more than 8 bytes reads its data registers AFTER issue, and a VALU instruction that overwrites one
+    // of them within 2 wait states changes what is stored (gfx940+; the compiler inserts these for its own stores, it cannot see
+    // that this statement is one: round 5 met `v_mul v147, ...` straight behind `global_store_dwordx4 ..., v[146:149]`)
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(base), "i"(OFF) : "memory");
 }
 
 // Tile-boundary prefetch, so that no wavefront waits on HBM between two row tiles:
@@ -182,9 +345,10 @@ struct TileSrc {
     char* stage;           // this wavefront's staging area (wave-uniform)
 };
 
-__device__ __forceinline__ void prefetch_rows(const TileSrc& t, int lane) {
+__device__ __forceinline__ void prefetch_rows(const TileSrc& t, int /*lane*/) {
     int row0 = t.next_row0;
     asm volatile("" : "+s"(row0));  // addresses are formed here, not hoisted out of the layer loop and spilled
+    const int lane = (int)(lane_off16() >> 4);      // re-derived for the same reason
     const int rh = min(row0 + (lane >> 2), t.n - 1);
     const float* src_h = t.h + (size_t)rh * DANBO_H_STRIDE + 4 * (lane & 3);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_h,
@@ -199,11 +363,4 @@ struct StageRows {      // pipe_handover's `extra`: the two staging loads of the
     int lane;
     __device__ __forceinline__ void operator()() const { prefetch_rows(t, lane); }
 };
-// lane * 16, re-derived where it is used (two VALU operations) instead of living in a register across the layer loop
-__device__ __forceinline__ unsigned lane_off16() {
-    int zero = 0;
-    asm volatile("" : "+s"(zero));
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero)) << 4;
-}
-
 }  // namespace danbo
