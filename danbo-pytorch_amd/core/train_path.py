@@ -1,20 +1,24 @@
-"""Differentiable (training) forward of DANBO on the MI355X path.
+"""Differentiable (training) forward of DANBO / A-NeRF on the MI355X path: the AUTOGRAD path (`caster.train(); caster(...)` ->
+predictions with `grad_fn`, what the reference's trainer expects; the fused step of core/train_engine.py is the default for
+the shipped DANBO configurations).
 
-Work split:
-  * hand-written HIP, forward AND backward: world->bone transform + in-volume cull (K1a, no
-    gradient), factorised gather (K1b: d volumes / d axis_scale by atomics), alpha compositing
-    (K4), sampling / importance sampling / merge order (no gradient: the reference detaches them);
-  * plain GEMMs through rocBLAS (torch.addmm / einsum) on the COMPACTED in-volume rows only:
-    the per-bone linears of the two GNNs and the 12 linear layers of the MLP, recorded by
-    autograd;
-  * small element-wise glue (PE, masked sigmoid, blend) as torch ops.
-Samples outside every bone volume share, per ray, one "empty-space" MLP evaluation (h = 0),
-which keeps the gradient path of the reference (every sample reaches the MLP weights) at a
-fraction of the rows.
+Every stage runs on the library's kernels in both directions, as torch.library custom operators (core/custom_ops.py):
+  torch.ops.danbo.pose_volumes   rot6d + PE + skeleton GNN -> per-bone volumes            (k_pose_layer / k_pose_*_bwd)
+  torch.ops.danbo.assign_blend   gather + assignment GNN + masked sigmoid + blend          (k_assign_blend / k_assign_bwd)
+  torch.ops.danbo.pe_mlp         voxel PE + density trunk + colour head                     (k_train_mlp_fwd / _bwd, k_dw16)
+  torch.ops.danbo.composite      NeRF.raw2outputs                                           (k_composite / k_composite_bwd)
+  Linear16Fn                     A-NeRF's W = 448 dense layers                              (k_linear16 both ways, k_dw16)
+and the in-volume cull, sampling, importance sampling and merge order without gradient (the reference detaches them).
+What torch computes here: element-wise glue, the matrix-VECTOR heads of A-NeRF (alpha_linear N = 1, rgb_linear N = 3: `LinearFn`)
+and A-NeRF's per-ray view products.  A network of ANOTHER shape than the shipped ones is not evaluated by a library fallback:
+`forward_train` raises (the constructors raise for those shapes already).  The layer-by-layer torch restatement the operators are
+tested against lives with the tests (tests/torch_layerwise.py).
 
-Gradient semantics follow the reference: `window` is detached and `invalid` is not
-differentiable (core/networks/gnn_backbone.py:802-808); sample depths are detached
-(core/utils/ray_utils.py:287); no gradient reaches pts / skts / bones (opt_pose is off).
+Samples outside every bone volume share, per ray, one "empty-space" MLP evaluation (h = 0), which keeps the gradient path of
+the reference (every sample reaches the MLP weights) at a fraction of the rows.
+Gradient semantics follow the reference: `window` is detached and `invalid` is not differentiable
+(core/networks/gnn_backbone.py:802-808); sample depths are detached (core/utils/ray_utils.py:287); no gradient reaches
+pts / skts / bones (opt_pose is off).
 """
 import ctypes
 
@@ -176,15 +180,17 @@ def _linear16_ok(layer, K):
 
 
 def linear16(layer, x, relu=False, x2=None, x_grad=True):
-    """layer([x | x2]) (+ ReLU) on the HIP kernels both ways when the shape allows, else the library route"""
+    """layer([x | x2]) (+ ReLU) on the HIP kernels both ways; a shape they do not take (widths not multiples of 4, N > 512) raises"""
     K = x.shape[1] + (0 if x2 is None else x2.shape[1])
-    if _linear16_ok(layer, K) and x.shape[1] % 4 == 0 and x.shape[0] > 0:
-        return Linear16Fn.apply(x, x2, layer.weight, layer.bias, relu, x_grad)
-    y = linear(layer, x if x2 is None else torch.cat([x, x2], -1))
-    return F.relu(y) if relu else y
+    if not (_linear16_ok(layer, K) and x.shape[1] % 4 == 0):
+        raise NotImplementedError(f"k_linear16 / k_dw16 take 16-byte aligned rows, N <= 512: layer {tuple(layer.weight.shape)} on K = {K}")
+    if x.shape[0] == 0:
+        return x.new_zeros(0, layer.weight.shape[0]) + 0.0 * (layer.weight.sum() + layer.bias.sum())     # keeps the graph connected
+    return Linear16Fn.apply(x, x2, layer.weight, layer.bias, relu, x_grad)
 
 
 def linear(layer, x):
+    """a matrix-VECTOR head (A-NeRF's alpha_linear N = 1, rgb_linear N = 3) through torch"""
     return LinearFn.apply(x, layer.weight, layer.bias)
 
 
@@ -196,7 +202,7 @@ def composite(raw, z, rays_d, B=1.0, noise=None):
 
 
 # --------------------------------------------------------------------------------------
-# small differentiable pieces (GEMMs via rocBLAS, element-wise glue)
+# small differentiable pieces (element-wise glue)
 # --------------------------------------------------------------------------------------
 _PE_FREQS = {}
 
@@ -246,77 +252,17 @@ def _pose_op_params(model):
 
 def pose_volumes(model, bones_g):
     """FactorizeGNN forward (reference gnn_backbone.py:683-704) -> [G,24,240], differentiable: torch.ops.danbo.pose_volumes
-    (k_pose_layer both ways, core/custom_ops.py); a graph net of another structure is recorded layer by layer with torch ops."""
+    (k_pose_layer both ways, core/custom_ops.py)"""
     params = _pose_op_params(model)
-    if params is not None and bones_g.is_cuda:
-        return torch.ops.danbo.pose_volumes(bones_g.contiguous().float(), int(model.graph_pe_fn.num_freqs), params)[0]
-    return pose_volumes_layerwise(model, bones_g)
-
-
-def pose_volumes_layerwise(model, bones_g):
-    """the same with torch ops (any layer structure; the comparison of tests/test_gpu_training.py)"""
-    gn = model.graph_net
-    n = positional_encoding(axis_angle_to_rot6d(bones_g), model.graph_pe_fn.num_freqs)
-    mask = torch.ones(1, 24, 1, device=n.device)
-    mask[:, 0] = 0.
-    n = n * mask
-    last = len(gn.layers) - 1
-    for i, l in enumerate(gn.layers):
-        if hasattr(l, "adj_w"):  # graph conv: per-bone linear, weighted adjacency, shared bias
-            out = torch.einsum("bkl,klj->bkj", n, l.lin.weight)
-            out = torch.matmul(l.get_adjw(), out) + l.bias
-        else:
-            out = torch.einsum("bkl,klj->bkj", n, l.weight) + l.bias
-        if i == 0:
-            out = out + out  # skip_gcn=False quirk: first layer doubled (gnn_backbone.py:698-699)
-        n = F.relu(out) if i < last else out
-    return n
-
-
-class AdjacencyMixFn(torch.autograd.Function):
-    """out[n] = A y[n] for every row n (A [24,24] the learned adjacency, y [n,24,C]).  As a broadcast matmul its adjacency
-    gradient dA = sum_n g[n] y[n]^T is one 24 x 24 GEMM with K = n C (0.8 ms in the library); here it is summed over 64 row
-    slices as one batched GEMM."""
-
-    @staticmethod
-    def forward(ctx, A, y):
-        ctx.save_for_backward(A, y)
-        return torch.matmul(A, y)
-
-    @staticmethod
-    def backward(ctx, g):
-        A, y = ctx.saved_tensors
-        g = g.contiguous()
-        dy = torch.matmul(A.transpose(-1, -2), g) if ctx.needs_input_grad[1] else None
-        dA = None
-        if ctx.needs_input_grad[0]:
-            n, J, C = y.shape
-            slices = min(64, n // 256)
-            if slices >= 2:
-                ch = (n // slices) * slices
-                gs = g[:ch].view(slices, -1, J, C).permute(0, 2, 1, 3).reshape(slices, J, -1)
-                ys = y.contiguous()[:ch].view(slices, -1, J, C).permute(0, 2, 1, 3).reshape(slices, J, -1)
-                dA = torch.bmm(gs, ys.transpose(1, 2)).sum(0)
-                if ch < n:
-                    dA = dA + torch.einsum("nic,njc->ij", g[ch:], y[ch:])
-            else:
-                dA = torch.einsum("nic,njc->ij", g, y)
-            dA = dA.reshape(A.shape)      # the adjacency is stored [1,24,24]
-        return dA, dy
-
-
-def assignment_logits(model, part_feat):
-    """MixGNN forward (reference gnn_backbone.py:567-629): [n,24,15] -> [n,24]."""
-    l0, l1, l2 = model.prob_linears.layers
-    y = torch.einsum("bkl,klj->bkj", part_feat, l0.lin.weight)
-    y = F.relu(AdjacencyMixFn.apply(l0.get_adjw(), y) + l0.bias)
-    y = F.relu(torch.einsum("bkl,klj->bkj", y, l1.weight) + l1.bias)
-    return (torch.einsum("bkl,klj->bkj", y, l2.weight) + l2.bias)[..., 0]
+    if params is None:
+        raise NotImplementedError("the pose-GNN kernels cover two graph convolutions + two per-bone linears -> 240 outputs, width <= 256 "
+                                  "(every shipped DANBO config); this graph_net has another structure")
+    return torch.ops.danbo.pose_volumes(bones_g.contiguous().float(), int(model.graph_pe_fn.num_freqs), params)[0]
 
 
 def _assign_op_applies(model):
     """torch.ops.danbo.assign_blend covers the shipped assignment net (MixGNN: one graph convolution 15 -> 32, two per-bone
-    linears 32 -> 32 -> 1); anything else takes the layer-by-layer route on a materialised part_feat"""
+    linears 32 -> 32 -> 1)"""
     try:
         l0, l1, l2 = model.prob_linears.layers
         return (tuple(l0.lin.weight.shape) == (24, ops.FEAT, 32) and tuple(l1.weight.shape) == (24, 32, 32)
@@ -327,7 +273,7 @@ def _assign_op_applies(model):
 
 def _fused_mlp_params(model):
     """the 24 parameter tensors of torch.ops.danbo.pe_mlp if the network has the shape the fused trunk kernels are built for
-    (D = 8, W = 256, skip after layer 4, 6 voxel octaves, view_W = 128), else None (-> the library-GEMM path below)"""
+    (D = 8, W = 256, skip after layer 4, 6 voxel octaves, view_W = 128), else None (forward_train raises)"""
     try:
         ok = (len(model.pts_linears) == 8 and list(model.skips) == [4] and model.voxel_pe_fn.num_freqs == 6
               and model.pts_linears[0].weight.shape == (256, 195) and model.views_linears[0].weight.shape[0] == 128
@@ -340,18 +286,6 @@ def _fused_mlp_params(model):
     return ([l.weight for l in model.pts_linears] + [l.bias for l in model.pts_linears]
             + [model.alpha_linear.weight, model.alpha_linear.bias, model.feature_linear.weight, model.feature_linear.bias,
                model.views_linears[0].weight, model.views_linears[0].bias, model.rgb_linear.weight, model.rgb_linear.bias])
-
-
-def mlp(model, dens_in, view_in):
-    h = dens_in
-    for i, l in enumerate(model.pts_linears):
-        h = F.relu(linear(l, h))
-        if i in model.skips:
-            h = torch.cat([dens_in, h], -1)
-    alpha = linear(model.alpha_linear, h)
-    feat = linear(model.feature_linear, h)
-    hv = F.relu(linear(model.views_linears[0], torch.cat([feat, view_in], -1)))
-    return torch.cat([linear(model.rgb_linear, hv), alpha], -1)
 
 
 def view_inputs(model, rays_d, skts_g, cam_idxs, rays_per_pose):
@@ -399,43 +333,34 @@ def forward_train(model, inputs):
         shared["vols"] = pose_volumes(model, bones_g)
     vols = shared["vols"]
     shifts = torch.arange(24, device=pts.device, dtype=torch.int32)
-    if n > 0 and _assign_op_applies(model):
-        # torch.ops.danbo.assign_blend: gather + assignment GNN + masked sigmoid + blend in one HIP kernel each way (core/custom_ops.py);
-        # part_feat [n,24,15] is never materialised
-        from . import custom_ops  # noqa: F401  (registers the operator)
-        l0, l1, l2 = model.prob_linears.layers
+    fused = _fused_mlp_params(model)
+    if not _assign_op_applies(model) or fused is None:
+        raise NotImplementedError("the autograd path evaluates the shipped network shapes on the HIP operators (assignment net 15 -> 32 "
+                                  "-> 32 -> 1; D = 8, W = 256, skip after layer 4, 6 voxel octaves, view_W = 128); there is no library "
+                                  "fallback for another shape")
+    # torch.ops.danbo.assign_blend: gather + assignment GNN + masked sigmoid + blend in one HIP kernel each way (core/custom_ops.py);
+    # part_feat [n,24,15] is never materialised
+    l0, l1, l2 = model.prob_linears.layers
+    if n > 0:
         h16, p_rows, logits = torch.ops.danbo.assign_blend(vols, axis_scale, pts, skts_g, align, rows, bits,
                                                            [l0.lin.weight, l0.adj_w, l0.adj, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias])
         h = h16[:, :15]
-    else:
-        part_feat = torch.ops.danbo.bone_gather(vols, axis_scale, pts, skts_g, align, rows)
-        logits = assignment_logits(model, part_feat)
-        valid_rows = ((bits[rows.long()].unsqueeze(-1) >> shifts) & 1).float()
-        p = (torch.sigmoid(logits) * 1.002 - 0.001) * valid_rows
-        h = (part_feat * p[..., None]).sum(-2)
-        p_rows = p                            # (both routes hand the loss the same differentiable masked probabilities)
+    else:     # no sample of the batch inside a volume: only the per-ray empty-space rows below reach the MLP
+        h = pts.new_zeros(0, 15)
+        p_rows = logits = pts.new_zeros(0, 24)
     if "vin" not in shared:
         shared["vin"] = view_inputs(model, rays_d, skts_g, inputs.get("cam_idxs"), R // G)
     vin = shared["vin"]
     ray_of_row = (rows // S).long()
-    L = model.voxel_pe_fn.num_freqs
-    # in-volume rows and the one empty-space row per ray through the MLP in ONE batch: half the GEMM launches and half the
-    # gradient accumulations of two separate calls
-    # (a caller that runs several passes over the same rays -- coarse and importance samples -- shares the empty-space rows)
-    fused = _fused_mlp_params(model)
+    # in-volume rows and the one empty-space row per ray through torch.ops.danbo.pe_mlp (encoding + trunk + heads on the fused HIP
+    # kernels) in ONE batch; a caller that runs several passes over the same rays -- coarse and importance samples -- shares the
+    # empty-space rows
     if "raw_empty" in shared:
         raw_empty = shared["raw_empty"]
-        if fused is not None:   # torch.ops.danbo.pe_mlp: encoding + trunk + heads on the fused HIP kernels (core/custom_ops.py)
-            raw_rows = torch.ops.danbo.pe_mlp(h, ray_of_row.int(), vin, fused) if n > 0 else h.new_zeros(0, 4)
-        else:
-            raw_rows = mlp(model, positional_encoding(h, L), vin[ray_of_row])
+        raw_rows = torch.ops.danbo.pe_mlp(h, ray_of_row.int(), vin, fused) if n > 0 else h.new_zeros(0, 4)
     else:
-        if fused is not None:
-            raw_both = torch.ops.danbo.pe_mlp(torch.cat([h, h.new_zeros(R, h.shape[1])], 0),
-                                              torch.cat([ray_of_row.int(), torch.arange(R, device=pts.device, dtype=torch.int32)]), vin, fused)
-        else:
-            pe_empty = positional_encoding(torch.zeros(1, h.shape[1], device=pts.device), L).expand(R, -1)
-            raw_both = mlp(model, torch.cat([positional_encoding(h, L), pe_empty], 0), torch.cat([vin[ray_of_row], vin], 0))
+        raw_both = torch.ops.danbo.pe_mlp(torch.cat([h, h.new_zeros(R, h.shape[1])], 0),
+                                          torch.cat([ray_of_row.int(), torch.arange(R, device=pts.device, dtype=torch.int32)]), vin, fused)
         raw_rows, raw_empty = raw_both[:n], raw_both[n:]
         shared["raw_empty"] = raw_empty
     raw = raw_empty[:, None, :].expand(R, S, 4).reshape(R * S, 4).index_copy(0, rows.long(), raw_rows)

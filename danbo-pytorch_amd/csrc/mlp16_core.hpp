@@ -171,23 +171,8 @@ __device__ __forceinline__ void agroup_prefetch0(unsigned base) {
 // NEXT group (G + 1 of this chunk, or group 0 of the next chunk: `nbase`, offset 0) into the other buffer.
 //   H0/L0/H1/L1: this group's fragment registers; N0..N3: the other buffer's; FIRST: the accumulators start from zero;
 //   HEAD: first group of a chunk (wait state behind the VALU that made the B fragments); DRAIN: last MFMA of a GEMM.
-#ifndef DANBO_M16_READS_AT
-#define DANBO_M16_READS_AT 1     // the next group's 4 reads: 0 = in front of the group's MFMAs, 1 = behind the first, 2 = two behind the second + two behind the fourth
-#endif
-#if DANBO_M16_READS_AT == 0
-#define DANBO_GROUP_BODY(H0, L0, H1, L1, N0, N1, N2, N3, C0, C1)                                                                \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
-    "ds_read_b128 " N0 ", %[nb] offset:%[o0]\n\t"                                                                              \
-    "ds_read_b128 " N1 ", %[nb] offset:%[o1]\n\t"                                                                              \
-    "ds_read_b128 " N2 ", %[nb] offset:%[o2]\n\t"                                                                              \
-    "ds_read_b128 " N3 ", %[nb] offset:%[o3]\n\t"                                                                              \
-    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bh], " C0 "\n\t"                                                                 \
-    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bh], " C1 "\n\t"                                                                 \
-    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bl], %[a0]\n\t"                                                                  \
-    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bl], %[a1]\n\t"                                                                  \
-    "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
-    "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
-#elif DANBO_M16_READS_AT == 1
+// (the next group's 4 reads behind the group's first MFMA; in front of the MFMAs or spread behind the second and fourth: the same
+// 2.00 - 2.03 ms per launch, round 5)
 #define DANBO_GROUP_BODY(H0, L0, H1, L1, N0, N1, N2, N3, C0, C1)                                                                \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
     "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bh], " C0 "\n\t"                                                                 \
@@ -200,20 +185,6 @@ __device__ __forceinline__ void agroup_prefetch0(unsigned base) {
     "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bl], %[a1]\n\t"                                                                  \
     "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
     "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
-#else
-#define DANBO_GROUP_BODY(H0, L0, H1, L1, N0, N1, N2, N3, C0, C1)                                                                \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
-    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bh], " C0 "\n\t"                                                                 \
-    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bh], " C1 "\n\t"                                                                 \
-    "ds_read_b128 " N0 ", %[nb] offset:%[o0]\n\t"                                                                              \
-    "ds_read_b128 " N1 ", %[nb] offset:%[o1]\n\t"                                                                              \
-    "v_mfma_f32_16x16x32_f16 %[a0], " H0 ", %[bl], %[a0]\n\t"                                                                  \
-    "v_mfma_f32_16x16x32_f16 %[a1], " H1 ", %[bl], %[a1]\n\t"                                                                  \
-    "ds_read_b128 " N2 ", %[nb] offset:%[o2]\n\t"                                                                              \
-    "ds_read_b128 " N3 ", %[nb] offset:%[o3]\n\t"                                                                              \
-    "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
-    "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
-#endif
 
 template <int G, bool FIRST, bool HEAD, bool DRAIN>
 __device__ __forceinline__ void group_mfma(f32x4& a0, f32x4& a1, const half8& bh, const half8& bl, unsigned cbase, unsigned nbase) {

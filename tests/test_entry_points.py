@@ -107,6 +107,29 @@ def test_psnr_ssim_identities():
     assert abs(m["psnr"] - 20.0) < 1e-3
 
 
+def test_ssim_map_known_answer():
+    """ssim_map against an INDEPENDENT float64 scipy evaluation of the published algorithm on committed images
+    (oracle/gen_ssim_golden.py -> tests/golden/ssim_known_answer.npz): the zero-padded image-sized map, and -- its interior -- the
+    un-padded map of upstream pytorch-msssim, computed here a second way (valid convolutions)."""
+    import torch.nn.functional as F
+    from core.utils.evaluation_helpers import ssim_map, _gauss
+    from helpers import golden
+    g = golden("ssim_known_answer")
+    x, y = torch.tensor(g["pred"]), torch.tensor(g["gt"])
+    m = ssim_map(x, y).numpy()
+    assert m.shape == g["map_same"].shape and np.abs(m - g["map_same"]).max() < 2e-5
+    assert np.abs(m[:, :, 5:-5, 5:-5] - g["map_valid"]).max() < 2e-5
+    assert float(np.abs(m[0, :, :4, :] - 1.0).max()) < 1e-5                 # the error-free rows, a window away from the others
+    # the interior again through VALID convolutions (no padding anywhere in the computation)
+    w = _gauss().double()
+    blur = lambda t: F.conv2d(F.conv2d(t, w.view(1, 1, -1, 1).expand(3, 1, -1, 1), groups=3), w.view(1, 1, 1, -1).expand(3, 1, 1, -1), groups=3)  # noqa: E731
+    xd, yd = x.double(), y.double()
+    mu1, mu2 = blur(xd), blur(yd)
+    s1, s2, s12 = blur(xd * xd) - mu1 * mu1, blur(yd * yd) - mu2 * mu2, blur(xd * yd) - mu1 * mu2
+    v = (2 * mu1 * mu2 + 1e-4) / (mu1 * mu1 + mu2 * mu2 + 1e-4) * (2 * s12 + 9e-4) / (s1 + s2 + 9e-4)
+    assert np.abs(v.numpy() - g["map_valid"]).max() < 1e-12
+
+
 def test_evaluate_metric_masks(tmp_path):
     from core.utils.evaluation_helpers import evaluate_metric
     rng = np.random.default_rng(1)

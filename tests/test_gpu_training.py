@@ -266,18 +266,18 @@ def test_pose_volumes_custom_op_forward_backward_and_opcheck():
 
 def test_autograd_path_operators_equal_the_layerwise_torch_route():
     """core/train_path.py's differentiable caster forward on the three HIP operators (danbo.pose_volumes, danbo.assign_blend,
-    danbo.pe_mlp) against the same forward recorded layer by layer with torch / library GEMMs (the route a network of another
-    shape takes): loss terms and the gradient of EVERY parameter on the config-4 network.  (Round 3 kept this comparison as
-    DANBO_AUTOGRAD_*=library switches inside the product.)"""
+    danbo.pe_mlp) against the same forward recorded layer by layer with torch / library GEMMs (tests/torch_layerwise.py: test
+    infrastructure since round 5 -- the product has no library route any more and raises for a network of another shape): loss
+    terms and the gradient of EVERY parameter on the config-4 network."""
     from core import train_path
     g = golden("danbo_perfcap_train")
 
+    import torch_layerwise
+
     def run(layerwise):
-        saved = (train_path._pose_op_params, train_path._assign_op_applies, train_path._fused_mlp_params)
+        saved = train_path.forward_train
         if layerwise:
-            train_path._pose_op_params = lambda m: None
-            train_path._assign_op_applies = lambda m: False
-            train_path._fused_mlp_params = lambda m: None
+            train_path.forward_train = torch_layerwise.forward_train
         try:
             args, caster, trainer, opt = build_trainer(g)
             caster.train()
@@ -289,7 +289,7 @@ def test_autograd_path_operators_equal_the_layerwise_torch_route():
             caster.zero_grad()
             loss["total_loss"].backward()
         finally:
-            train_path._pose_op_params, train_path._assign_op_applies, train_path._fused_mlp_params = saved
+            train_path.forward_train = saved
         return ({n: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for n, p in caster.network.named_parameters()},
                 {k: float(v.detach()) for k, v in loss.items()})
     g_op, l_op = run(False)

@@ -420,6 +420,32 @@ def test_ring_kernels_do_not_spill(tmp_path):
         mf = [i for i, l in enumerate(body) if "v_mfma" in l]
         inside = [l for i, l in enumerate(body) if "scratch_" in l and mf[0] < i < mf[-1]]
         assert len(inside) <= max_in_loop, (k, inside)
+    # Round 5: K3 and the training forward keep the weight fragments of chunk_mfma2 in the PINNED registers v224..v255 across
+    # compiler-generated code (mlp16_core.hpp; the kernels are compiled with amdgpu_num_vgpr(224)).  No instruction outside the
+    # inline asm may name one of them, the kernels use no scratch at all, and every MFMA of theirs is inside the asm.
+    text = open(str(tmp_path / "k_mlp16.hip.s")).read()
+    high = re.compile(r"\bv(22[4-9]|2[34]\d|25[0-5])\b|v\[(\d+):(\d+)\]")
+    for k in ("k_pe_mlp16", "k_train_mlp_fwd"):
+        meta = re.search(r"\.name:\s+\S*" + k + r"\S*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
+        assert int(meta.group(1)) == 0, (k, meta.group(1))
+        body = text[text.index(re.search(r"^(_ZN5danbo\S*" + k + r"\S*):", text, re.M).group(1) + ":"):]
+        body = body[:body.index(".Lfunc_end")].split("\n")
+        in_asm, foreign, mfma_outside, mfma_inside = False, [], 0, 0
+        for l in body:
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif in_asm:
+                mfma_inside += "v_mfma" in l
+            else:
+                code = l.split(";")[0]
+                mfma_outside += "v_mfma" in code
+                for m in high.finditer(code):
+                    if m.group(1) or (m.group(3) and int(m.group(3)) >= 224):
+                        foreign.append(code.strip())
+        assert not foreign, (k, foreign[:4])
+        assert mfma_outside == 0 and mfma_inside == 960, (k, mfma_outside, mfma_inside)     # 20 chunk sites x 48
 
 
 def test_fragment_order_buffer_layout_on_cpu():

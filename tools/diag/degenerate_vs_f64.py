@@ -40,7 +40,8 @@ for case in (sys.argv[1:] or ["overlapping_volumes", "every_volume"]):
     print("====", case)
     edit, model_edit = edits(case)
     from core import train_path
-    saved_sw = (train_path._assign_op_applies, train_path._fused_mlp_params)
+    import torch_layerwise                       # tests/torch_layerwise.py: the layer-by-layer torch route (test infrastructure)
+    saved_fwd = train_path.forward_train
     orig_comp = train_path.composite
     kept = []
 
@@ -62,8 +63,7 @@ for case in (sys.argv[1:] or ["overlapping_volumes", "every_volume"]):
     train_path.positional_encoding = pe_spy
     for assign in ("library",):
         for mlp in ("library",):
-            train_path._assign_op_applies = (lambda m: False) if assign == "library" else saved_sw[0]
-            train_path._fused_mlp_params = (lambda m: None) if mlp == "library" else saved_sw[1]
+            train_path.forward_train = torch_layerwise.forward_train if assign == "library" else saved_fwd
             samp = {}
             ref, preds, loss = tt._autograd_grads("danbo_perfcap_train", edit, model_edit, sampling=samp)
             g = golden("danbo_perfcap_train")
@@ -101,7 +101,7 @@ for case in (sys.argv[1:] or ["overlapping_volumes", "every_volume"]):
             report("grads vs f64", ref, r64)
     train_path.composite = orig_comp
     train_path.positional_encoding = orig_pe
-    train_path._assign_op_applies, train_path._fused_mlp_params = saved_sw
+    train_path.forward_train = saved_fwd
     g, args, caster, trainer, eng, out = tt.fused_step("danbo_perfcap_train", edit=edit, model_edit=model_edit)
     b = batch_of(g)
     R, G = b["rays_o"].shape[0], int(b["N_uniques"])
