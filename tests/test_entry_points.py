@@ -127,7 +127,7 @@ def test_ssim_map_known_answer():
     mu1, mu2 = blur(xd), blur(yd)
     s1, s2, s12 = blur(xd * xd) - mu1 * mu1, blur(yd * yd) - mu2 * mu2, blur(xd * yd) - mu1 * mu2
     v = (2 * mu1 * mu2 + 1e-4) / (mu1 * mu1 + mu2 * mu2 + 1e-4) * (2 * s12 + 9e-4) / (s1 + s2 + 9e-4)
-    assert np.abs(v.numpy() - g["map_valid"]).max() < 1e-12
+    assert np.abs(v.numpy() - g["map_valid"]).max() < 5e-6            # (the product's window is built in float32)
 
 
 def test_evaluate_metric_masks(tmp_path):
