@@ -26,12 +26,8 @@ class DanboEngine:
         self.mean_code = None
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, count_tensor)
         self.profile = None
-        self._side = None            # side streams of render()
-        self.k2_waits_for_view = False   # see forward_samples
-        # render(): True = pose volumes / view constants / rays of constants on side streams beside the bounds -> cull chain.  Off since
-        # the end of round 4: with those kernels at a fifth of their round-3 cost the overlap buys less than the contention and the
-        # events cost (tools/ab_engine_switch.py side_streams: 4.696 ms with, 4.634 ms without; danbo_render_frame, one stream, 4.625)
-        self.side_streams = False
+        # render() is ONE stream-ordered chain (round 4 measured the side-stream form -- pose volumes / view constants beside the
+        # bounds -> cull chain -- slower: 4.696 vs 4.634 ms; round 5 removed it: nothing of the frame runs beside K2)
         self.skip_flat_rays = True   # render(): no resampling for rays that cannot meet a volume (tests switch it off to compare)
         # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
         assert mlp_mode in ("f16split", "fp32")
@@ -197,13 +193,12 @@ class DanboEngine:
                                self.code_table, ray_list, ray_count)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
-                        want_confd=False, volumes=None, view=None, fill=True, ready=None, ray_mask=None, count=None):
+                        want_confd=False, volumes=None, view=None, fill=True, ray_mask=None, count=None):
         """DANBO.forward on R x S samples -> raw [R,S,4] (+ dict of extras).
 
         dense=False: only samples inside >= 1 bone volume go through K1b/K2/K3; all others take
                      the per-ray empty-space raw (identical values).
         dense=True : every sample goes through every kernel (the reference's executed work).
-        ready: (event, event) -- `volumes` / `view` are being produced on another stream (render): waited for where first used.
         ray_mask: ops.ray_bone_mask() of these rays over an interval that holds every depth of z (render: [near, far]).
         count: zeroed [1] int32 for the row count (render() fills both passes' counters at once)."""
         self.refresh()
@@ -214,20 +209,10 @@ class DanboEngine:
         bits, lst, cnt = ops.bone_cull(geo, compact=not dense, cnt=count)
         if lst is not None and self.mlp_mode == "f16split" and self.group_rows:
             ops.group_rows(bits, lst, cnt)
-        if ready is not None:
-            # the volumes (K2 reads them); the view constants (K3 reads them) are waited for behind K2.  k2_waits_for_view = True
-            # orders K2 behind the view-constant kernel as well (~30 us per frame): in the TRAINING step K2 beside that path's
-            # view-constant kernel was the one combination that produced a wrong sum once in 200 steps; here
-            # the two do overlap (flat mode, ~30 us per frame) and 6 000 frames are bit-identical (tools/stress_render.py --overlap)
-            torch.cuda.current_stream().wait_event(ready[0])
-            if self.k2_waits_for_view:
-                torch.cuda.current_stream().wait_event(ready[1])
         if self.mlp_mode == "f16split":
             h, confd = ops.gather_assign_blend16(geo, vols, bits, self.aw, self.assign16, lst, cnt, geo.M, want_confd)
         else:
             h, confd = ops.gather_assign_blend(geo, vols, bits, self.aw, lst, cnt, geo.M, want_confd)
-        if ready is not None and not self.k2_waits_for_view:
-            torch.cuda.current_stream().wait_event(ready[1])
         # fill=False: rows outside every volume stay unwritten; the consumer reads raw_empty for them (valid_bits == 0)
         raw = ops.fill_raw(raw_empty, S) if fill or dense else torch.empty(geo.R, S, 4, device=raw_empty.device)
         if self.profile is not None:
@@ -332,68 +317,24 @@ class DanboEngine:
         # Longer rays (S > 64, up to 256 with Sf <= 64: the unfused composites) take the same constants: the coarse composite,
         # the resampling and the final composite walk the list there too.
         flat_mode = lazy and (fused or (S <= 256 and Sf <= 64)) and self.skip_flat_rays and self.flat_rays_ok
-        # The per-pose volumes (4 small launches) and the per-ray view constants depend on nothing the depths / cull chain
-        # computes: each runs on its own side stream under that chain; the main stream waits for the volumes in front of K2 and
-        # for the view constants in front of K3.  In flat mode the view constants follow the ray mask (they need the list of the
-        # rays that are not rays of constants) and run beside the cull.  Inside a HIP-graph capture the chain stays linear.
-        use_side = self.side_streams and rays_o.is_cuda and not torch.cuda.is_current_stream_capturing()
-        ready = vols = view = flat = None
-        if use_side:
-            cur = torch.cuda.current_stream()
-            if self._side is None or self._side[0].device != rays_o.device:
-                self._side = (torch.cuda.Stream(device=rays_o.device), torch.cuda.Stream(device=rays_o.device))
-            for side in self._side:
-                side.wait_stream(cur)
-            if not flat_mode:
-                with torch.cuda.stream(self._side[0]):
-                    view = self.view_constants(rays_d, skts, cam_idx)
-            with torch.cuda.stream(self._side[1]):
-                vols = self.volumes(bones)
-                ev_vols = torch.cuda.Event()
-                ev_vols.record(self._side[1])
-            vols.record_stream(cur)
         near, far = self.near_far(rays_o, rays_d, cyls, skts, 0.0, 1.0, chunk) if near_far is None else near_far
-        z = ops.coarse_samples(near, far, S)      # (on the pose stream beside the ray mask: measured, slower -- tools/ab_engine_switch.py)
+        z = ops.coarse_samples(near, far, S)
         # candidate bones of every ray over [near, far] (coarse and importance depths both lie inside): the two culls skip the
         # rays, and whole workgroups, that miss every volume -- most of a frame
         ray_mask = None if dense else ops.ray_bone_mask(rays_o, rays_d, skts, self.align, self.axis_scale, near, far,
                                                         want_flat=flat_mode)
         counts = torch.zeros(3, device=rays_o.device, dtype=torch.int32)       # rows of the two passes, listed rays: one fill
-        if use_side:
-            side = self._side[0]
-            if flat_mode:
-                side.wait_stream(cur)
-                for t in (ray_mask[1], ray_mask[3], counts):
-                    t.record_stream(side)
-                with torch.cuda.stream(side):
-                    flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, want_weights=not fused, rows_later=True, cnt=counts[2:3])
-                    view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
-                for t in list(flat["out0"].values()) + list(flat["out"].values()) + [flat[k] for k in ("z_fine", "ray_list", "ray_count")]:
-                    if t is not None:
-                        t.record_stream(cur)
-            ev_view = torch.cuda.Event()
-            ev_view.record(side)
-            for t in view:
-                t.record_stream(cur)
-            ready = (ev_vols, ev_view)
-            if flat_mode:          # the constant rows: nobody needs them before the coarse composite
-                with torch.cuda.stream(side):
-                    flat.pop("rows")()
-                    ev_rows = torch.cuda.Event()
-                    ev_rows.record(side)
+        flat = None
+        vols = self.volumes(bones)
+        if flat_mode:
+            flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, want_weights=not fused, cnt=counts[2:3])
+            view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
         else:
-            vols = self.volumes(bones)
-            if flat_mode:
-                flat = ops.flat_rays(ray_mask[1], ray_mask[3], S, Sf, want_weights=not fused, cnt=counts[2:3])
-                view = self.view_constants(rays_d, skts, cam_idx, flat["ray_list"], flat["ray_count"])
-            else:
-                view = self.view_constants(rays_d, skts, cam_idx)
+            view = self.view_constants(rays_d, skts, cam_idx)
         if ray_mask is not None:
             ray_mask = ray_mask[:3]
         raw, ex = self.forward_samples(rays_o, rays_d, skts, bones, cam_idx, z=z, dense=dense, volumes=vols, view=view,
-                                       fill=not lazy, ready=ready, ray_mask=ray_mask, count=counts[0:1])
-        if flat_mode and use_side:
-            torch.cuda.current_stream().wait_event(ev_rows)
+                                       fill=not lazy, ray_mask=ray_mask, count=counts[0:1])
         if fused:
             out0, z_all, z_fine, order = ops.composite_importance(
                 raw, z, rays_d, Sf, B, bits=ex["valid_bits"] if lazy else None, raw_empty=view[1] if lazy else None,

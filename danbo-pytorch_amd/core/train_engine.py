@@ -257,12 +257,38 @@ class DanboTrainEngine:
         device the first time it is needed -- torch.manual_seed / torch.cuda.manual_seed before that (run_nerf.py: rank + 1) give
         every rank its own stream -- and again whenever that seed has CHANGED since; reseed() restarts it explicitly."""
         seed = int(torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()].initial_seed())
+        # ... mixed with the RANK (ADVICE r4): ranks that were seeded alike -- a caller without a per-rank torch.manual_seed -- would
+        # otherwise draw the same stratified offsets and density noise for their different rays
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() > 0:
+            seed = (seed ^ (0x9E3779B97F4A7C15 * dist.get_rank())) & ((1 << 64) - 1)
         if self._rng_state is None:
             self._rng_state = torch.zeros(3, device=self.device, dtype=torch.int64)
             self._rng_seed = None
+        if getattr(self, "_rng_restored_for", None) is not None:
+            if int(torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()].initial_seed()) == self._rng_restored_for:
+                return self._rng_state               # a stream restored from a checkpoint: continue it
+            self._rng_restored_for = None
         if seed != self._rng_seed:
             self.reseed(seed)
         return self._rng_state
+
+    def rng_state_dict(self):
+        """(seed, counter) of the step's random stream for a checkpoint (Trainer.save_nerf): a resumed run continues the stream
+        instead of replaying the draws of step 0.  One host sync; None before the first draw."""
+        if self._rng_state is None or self._rng_seed is None:
+            return None
+        st = self._rng_state.cpu()
+        return dict(seed=int(self._rng_seed), counter=int(st[1]))
+
+    def load_rng_state_dict(self, d):
+        if not d:
+            return
+        self.reseed(int(d["seed"]))
+        self._rng_state[1] = int(d["counter"])
+        # the torch generator's seed of THIS process is whatever the resuming script set: keep the restored stream until it changes
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._rng_restored_for = int(torch.cuda.default_generators[dev].initial_seed())
 
     def reseed(self, seed):
         """restart the step's random stream at (seed, counter 0); the state tensor stays where it is (captured graphs hold it)"""

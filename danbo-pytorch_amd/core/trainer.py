@@ -128,6 +128,7 @@ class Trainer:
                                  else train_engine.supported(self.args, caster))
             if self.fused_reason is None:
                 self.engine = train_engine.DanboTrainEngine(self.args, caster, self.optimizer)
+                self.engine.load_rng_state_dict(getattr(self, 'resume_rng_state', None))
         return self.engine
 
     def train_batch_fused(self, batch, i=0, global_step=0, sync_stats=True):
@@ -229,7 +230,11 @@ class Trainer:
         """checkpoint in the reference's layout (:597-618): step, optimizer and one state dict per caster sub-module; the
         pose-optimisation entries the reference writes as None are kept so its loader finds every key"""
         caster = self.render_kwargs_train['ray_caster']
+        extra = {}
+        if self.engine is not None and self.engine.rng_state_dict() is not None:
+            # one key more than the reference writes (its loader ignores unknown keys): the fused step's random stream
+            extra['danbo_rng_state'] = self.engine.rng_state_dict()
         torch.save({'global_step': global_step, 'optimizer_state_dict': self.optimizer.state_dict(),
                     'poseopt_layer_state_dict': None, 'pose_optimizer_state_dict': None, 'poseopt_anchors': None,
-                    **caster.state_dict()}, path)
+                    **caster.state_dict(), **extra}, path)
         print('Saved checkpoints at', path)

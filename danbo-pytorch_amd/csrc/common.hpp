@@ -32,6 +32,15 @@ namespace danbo {
 constexpr int WAVE = 64;
 // Compute units of the calling thread's current device (hipDeviceAttributeMultiprocessorCount, cached per device): the
 // persistent kernels size their grids from it.  256 on a full MI355X; partitioned (CPX / DPX) or harvested parts report less.
+// Development switches (fault bisection, stream-order experiments, A/B of a packing) read the environment only in a
+// -DDANBO_DEV_SWITCHES build (make DEV=1); the product build compiles every one of them to its default: no environment variable
+// changes what the shipped library computes or in which order it enqueues it.
+#ifdef DANBO_DEV_SWITCHES
+static inline int dev_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static constexpr int dev_env(const char*, int dflt) { return dflt; }
+#endif
+
 static inline int num_cu() {
     static std::atomic<int> cached_[64];
     int dev = 0;
@@ -40,7 +49,7 @@ static inline int num_cu() {
     int n = c.load(std::memory_order_relaxed);
     if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        if (const char* e = getenv("DANBO_NUM_CU")) { const int v = atoi(e); if (v > 0 && v <= n) n = v; }   // dev: size the grids for a CU-masked stream
+        { const int v = dev_env("DANBO_NUM_CU", 0); if (v > 0 && v <= n) n = v; }   // dev: size the grids for a CU-masked stream
         c.store(n, std::memory_order_relaxed);
     }
     return n;

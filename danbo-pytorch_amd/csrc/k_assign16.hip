@@ -536,7 +536,7 @@ using namespace danbo;
 
 static long long* g_a16_trace = nullptr;
 static int a16_no_skip() {
-    static const int v = [] { const char* e = getenv("DANBO_A16_NOSKIP"); return e ? atoi(e) : 0; }();
+    static const int v = dev_env("DANBO_A16_NOSKIP", 0);
     return v;
 }
 /* dev tool: a buffer of 256 int64 that receives (tag, s_memtime) stamps of one wavefront of k_assign16 (tags: 0 tile start, 1 inputs

@@ -577,6 +577,8 @@ extern "C" int danbo_view_consts(const float* rays_d, const float* skts, int R, 
     DANBO_CHECK_ARG((ray_list == nullptr) == (ray_count == nullptr));
     DANBO_CHECK_ARG(Cf == 0 || (mean_code != nullptr && (cam_idx == nullptr || framecodes != nullptr)));
     DANBO_CHECK_ARG((empty_consts == nullptr) == (raw_empty == nullptr));
+    // k_view_consts reads these three as float4: a 4-byte aligned slice of a packed parameter blob would fault
+    DANBO_CHECK_ARG((uintptr_t)views_b % 16 == 0 && (uintptr_t)empty_consts % 16 == 0 && (uintptr_t)code_table % 16 == 0);
     const int Cv = 3 * (1 + 2 * L_view) + (code_table ? 0 : Cf);
     const int rpb = R >= 16384 ? 64 : 16;      // (32 and 16 rays per iteration on the 512 x 512 frame: 95 and 117 us against 74)
     const size_t lds = sizeof(float) * ((size_t)Cv * MLP_VW + (size_t)rpb * Cv + (size_t)rpb * MLP_VW + 3 * MLP_VW + 2 * rpb);

@@ -591,7 +591,7 @@ extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_
     { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
     // dev A/B (tools/micro_mlp16.py --noscale): maxima of 0 pack every matrix times 1 -- round 4's packing
-    static const bool noscale = getenv("DANBO_MLP16_NOSCALE") != nullptr;
+    static const bool noscale = dev_env("DANBO_MLP16_NOSCALE", 0) != 0;
     if (noscale) { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();

@@ -380,7 +380,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
 
     // dev aid: DANBO_TRAIN_STOP_AFTER=<stage> makes the call return after that stage (bisecting a fault inside a captured graph)
     // (the environment is read ONCE per process, not per step)
-    static const int stop_after = [] { const char* e = getenv("DANBO_TRAIN_STOP_AFTER"); return e ? atoi(e) : 1000; }();
+    static const int stop_after = dev_env("DANBO_TRAIN_STOP_AFTER", 1000);
 #define DANBO_STAGE(n) do { if (stop_after <= (n)) { DANBO_LAUNCH_RET(); } } while (0)
     bool fused_tail = false;
     if (phase != 2) {
@@ -391,7 +391,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     //   side 0: trunk weight packing -> per-ray view inputs -> view constants (needs b_eff)
     //   side 1: adjacency products + volume-scale loss -> assignment-net packing -> pose GNN (volumes)
     //   main  : ray bounds -> stratified depths -> coarse cull
-    static const int fork_mask = [] { const char* e = getenv("DANBO_TRAIN_FORK"); return e ? atoi(e) : 3; }();   // dev: 1 prologue, 2 backward
+    static const int fork_mask = dev_env("DANBO_TRAIN_FORK", 3);   // dev: 1 prologue, 2 backward
     SideStreams* ss = side_streams();
     void* s0 = stream;
     void* s1 = stream;
@@ -464,8 +464,9 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
         // (0 of 6 000 against 9 of 6 000) but is four times slower (71 vs 18 us), so the packed code stays and this join is the
         // fence.  Not established: why (other kernels use packed FMAs beside MFMA all the time, K3 itself does, and are
         // bit-stable).  K2 runs beside nothing in the training step -- which also is 0.7 % faster (1.628 vs 1.640 ms).
-        // DANBO_TRAIN_LATE_JOIN=1 restores the old order for experiments.
-        static const int late_join = [] { const char* e = getenv("DANBO_TRAIN_LATE_JOIN"); return e ? atoi(e) : 0; }();   // dev: the round-3 order
+        // The order is structural: the product has no switch for the old one (round 4's DANBO_TRAIN_LATE_JOIN exists only in a
+        // -DDANBO_DEV_SWITCHES build, for tools/stress_replay.py).
+        static const int late_join = dev_env("DANBO_TRAIN_LATE_JOIN", 0);
         if (pass == 0 && !late_join) DANBO_TRY(join(0));
         DANBO_TRY(danbo_gather_assign_blend16_train(bt->rays_o, bt->rays_d, zz, R, s, G, bt->skts, m->align, axis_scale, b.volumes, bits,
                                                     b.row_sample + R, b.cnt, pass == 0 ? nullptr : b.cnt + 1, ncap - R, b.assign16,
@@ -562,7 +563,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // queue at once.  The weight gradients are the critical path (0.29 ms, the head chain and Adam behind them); the pose-GNN
     // adjoint's six launches have 0.1 ms of slack under them: DANBO_TRAIN_DW_ON_MAIN=1 (default) keeps the former on the
     // caller's stream and sends the latter across.
-    static const int dw_on_main = [] { const char* e = getenv("DANBO_TRAIN_DW_ON_MAIN"); return e ? atoi(e) : 1; }();
+    static const int dw_on_main = dev_env("DANBO_TRAIN_DW_ON_MAIN", 1);
     void* pose_stream = stream;
     if (phase == 0 && ss) {
         if (hipEventRecord(ss->mid, st) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->mid, 0) != hipSuccess) return (int)hipGetLastError();

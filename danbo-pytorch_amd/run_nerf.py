@@ -149,10 +149,12 @@ def train(argv=None):
             with open(os.path.join(logdir, 'config.txt'), 'w') as f:
                 f.write(open(args.config).read())
 
-    kw_train, kw_test, start, grad_vars, optimizer, _ = create_raycaster(args, data_attrs, device=device)
+    kw_train, kw_test, start, grad_vars, optimizer, loaded = create_raycaster(args, data_attrs, device=device)
     sync_replicas(kw_train['ray_caster'])
     torch.manual_seed(rank + 1)
     trainer = Trainer(args, data_attrs, optimizer, None, kw_train, kw_test, None, device=device)
+    if isinstance(loaded, dict) and rank == 0:      # a resumed run continues the fused step's random stream (rank 0 wrote it)
+        trainer.resume_rng_state = loaded.get('danbo_rng_state')
     global_step = start
     log = open(os.path.join(logdir, 'scalars.jsonl'), 'a') if rank == 0 else None
     t0 = time.time()

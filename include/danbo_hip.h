@@ -201,7 +201,8 @@ int danbo_mlp_pack(const float* const* pts_w /*8 ptrs [256,195|256|451]*/, const
  * of every sample of ray r that lies in no bone volume (blended feature h = 0).
  *   ray_mode 0: 'world' raw rays_d; 1: 'root_local' (skts[g,0,:3,:3] . d);  normalise: relray
  *   ray_list / ray_count (optional, together): only the listed rays' rows are computed and written
- *   (danbo_flat_rays' list: nobody reads the rows of a ray of constants). */
+ *   (danbo_flat_rays' list: nobody reads the rows of a ray of constants).
+ *   views_b, empty_consts and code_table are read 16 bytes at a time: each must be 16-byte aligned (DANBO_EINVAL otherwise). */
 int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int ray_mode, int normalise,
                       int L_view, const float* framecodes /*[n_codes,Cf] or NULL*/, int n_codes, int Cf,
                       const float* mean_code /*[Cf]: codes.mean(0), used where cam_idx < 0*/,

@@ -79,6 +79,12 @@ def test_train_checkpoint_render_round_trip(tmp_path):
     trainer2 = run_nerf.train(common + ["--n_iters", "22"])
     st = trainer2.optimizer.state[trainer2.optimizer.param_groups[0]["params"][0]]["step"]
     assert int(st) == 23
+    # the fused step's random stream is part of the checkpoint: the resumed run continued it -- it did not restart at
+    # counter 0 -- with the seed the first run drew from
+    if trainer.engine is not None and "danbo_rng_state" in ckpt:
+        saved = ckpt["danbo_rng_state"]
+        assert saved["counter"] > 0 and trainer2.engine.rng_state_dict()["seed"] == saved["seed"]
+        assert trainer2.engine.rng_state_dict()["counter"] > saved["counter"]
     base = ["--nerf_args", str(log / "args.txt"), "--ckptpath", str(log / "000020.tar"), "--dataset", "synthetic", "--entry", "val",
             "--outputdir", str(tmp_path / "out")]
     rgbs, accs, boxes, _ = run_render.run_render(base + ["--render_type", "bullet", "--n_bullet", "3", "--selected_idxs", "0", "3",

@@ -44,9 +44,9 @@ def test_culled_render_equals_dense_render_bitwise(frame):
     for k in ("rgb_map", "disp_map", "acc_map", "alpha", "T_i", "rgb0", "acc0", "alpha0"):
         assert torch.equal(fast[k], dense[k]), k
         assert torch.equal(fast[k], out[k]), k          # and the materialising (keep=True) path
-    # run-to-run deterministic (compaction order is free): 40 more frames -- the chain's kernels overlap on three streams in ways that
-    # shift from frame to frame, and the arithmetic has no atomics; a frame that differs is a race (tools/stress_render.py: the long
-    # form; round 4 found one in the training step this way)
+    # run-to-run deterministic (compaction order is free): 40 more frames of the linear chain -- the arithmetic has no atomics; a
+    # frame that differs is a race or a missed wait state (tools/stress_render.py: the long form; round 4 found a race in the
+    # training step this way, round 5 a store whose data register was overwritten too early)
     for _ in range(40):
         again = eng.render(*args, S, Sf)
         assert all(torch.equal(fast[k], again[k]) for k in fast)

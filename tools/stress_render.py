@@ -8,8 +8,6 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 eng, inp, _ = bench.build_workload(torch.device("cuda:0"), 0)
-if "--overlap" in sys.argv:      # K2 beside the view-constant kernel (the engine orders them by default)
-    eng.k2_waits_for_view = False
 args = (inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"], 48, 16)
 ref = {k: v.clone() for k, v in eng.render(*args).items()}
 torch.cuda.synchronize()
