@@ -258,31 +258,45 @@ def cpu_baseline_render(extra, box_bounds, frame=None, stages=None, budget_s=6.0
 
 # ---------------------------------------------------------------------------------------------- timing harness
 N_BLOCKS = 5               # timed blocks of --steps steps each; ms_per_step = their MEDIAN
+RANK_TIMES = []            # per block (settle blocks included): the seconds every rank measured for it
 SETTLE_MIN_S, SETTLE_MAX_S, SETTLE_TOL = 0.5, 8.0, 0.02
 
 
-def _block(fn, steps, dist, device, cpu_dist):
-    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> (seconds, MAX over the ranks; last output)"""
-    torch.cuda.synchronize()
+def _sync():
+    if torch.cuda.is_available():          # (--dry-run runs the same harness where there is no GPU)
+        torch.cuda.synchronize()
+
+
+def _block(fn, steps, dist, device, cpu_dist, before=None):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> (seconds, MAX over the ranks; last output).
+    before(): untimed preparation of the block (the training bench restores its weights there)"""
+    if before is not None:
+        before()
+    _sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
         out = fn()
-    torch.cuda.synchronize()
+    _sync()
+    own = time.perf_counter() - t0          # this rank's steps alone, before it waits for the others
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if cpu_dist else device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # what counts: the MAX over the ranks of the bracketed time; beside it every rank's OWN time (before the closing barrier),
+        # gathered so that the line shows which rank was slow
+        mine = torch.tensor([elapsed, own], device="cpu" if cpu_dist else device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        RANK_TIMES.append([float(x[1].item()) for x in every])
+        elapsed = max(float(x[0].item()) for x in every)
     return elapsed, out
 
 
-def timed(fn, steps, warmup, dist, device, cpu_dist, settle_block=10, on_timed_start=None):
+def timed(fn, steps, warmup, dist, device, cpu_dist, settle_block=10, on_timed_start=None, before_block=None, after_block=None):
     """The number must not depend on where in the process it is taken (the first tens of milliseconds after idle
     run ~10 % slower -- clocks, caches, the allocator's pool -- and a 0.12 s timed region sat inside them):
       1. settle: blocks of `settle_block` steps until >= SETTLE_MIN_S of work has run BEHIND THE FIRST BLOCK (which carries the
@@ -305,16 +319,25 @@ def timed(fn, steps, warmup, dist, device, cpu_dist, settle_block=10, on_timed_s
             settled = True
             break
         prev = dt
+    if before_block is not None:
+        before_block()
     for _ in range(warmup):
         fn()
     if on_timed_start is not None:
         on_timed_start()
     blocks, out = [], None
     for _ in range(N_BLOCKS):
-        dt, out = _block(fn, steps, dist, device, cpu_dist)
+        dt, out = _block(fn, steps, dist, device, cpu_dist, before=before_block)
         blocks.append(dt)
+        if after_block is not None:
+            after_block(out)
     med = float(np.median(blocks))
-    info = dict(block_ms=[1e3 * b / steps for b in blocks], spread=(max(blocks) - min(blocks)) / med, settle_ms=settle_ms,
+    per_rank = {}
+    if dist is not None and len(RANK_TIMES) >= N_BLOCKS:      # the timed blocks are the last N_BLOCKS entries
+        last = np.array(RANK_TIMES[-N_BLOCKS:])               # [block, rank]
+        per_rank = dict(ms_per_step_ranks=[float(x) for x in 1e3 * np.median(last, 0) / steps],
+                        slowest_rank_per_block=[int(i) for i in last.argmax(1)])
+    info = dict(block_ms=[1e3 * b / steps for b in blocks], spread=(max(blocks) - min(blocks)) / med, settle_ms=settle_ms, **per_rank,
                 timing=f"median of {N_BLOCKS} blocks of --steps steps (each: barrier + synchronize on both sides, max over ranks) after "
                        f"a settle phase of {n_settle} x {settle_block} steps = {spent:.2f} s "
                        f"({'two consecutive blocks within 2 %' if settled else 'NOT settled within %.0f s' % SETTLE_MAX_S}) and "
@@ -532,7 +555,44 @@ def bench_train(args, rank, world, device, dist):
         out = trainer.train_batch(batch, i=step[0], global_step=step[0], sync_stats=False)
         step[0] += 1
         return out
-    elapsed, (loss, stats), tinfo = timed(one, args.steps, args.warmup, dist, device, args.debug_single_device, settle_block=50)
+    # The workload must not depend on how long a box takes to settle (every step is a real Adam update, the bone volumes
+    # the model learns change the row count, and the settle phase runs a box-dependent number of steps): one step builds the engine,
+    # its state is snapshotted, and the snapshot is restored in front of the warm-up steps and of EVERY timed block -- each block
+    # trains steps 1 .. K from the same weights, moments and random stream.  rows_per_block: what the last step of each block saw.
+    one()
+    torch.cuda.synchronize()
+    eng = trainer.engine
+    snap = eng.snapshot() if eng is not None else None
+    rows_per_block = []
+
+    def restore():
+        if snap is not None:
+            eng.restore(snap)
+
+    def note_rows(_):
+        rows_per_block.append(int(trainer.last_preds["counts"][4].item()))
+    coll = []
+
+    def start_coll():                      # HIP events around the two all-reduces of every step of the timed blocks
+        if dist is not None or args.nccl_world_1:
+            trainer.collective_events = coll
+    elapsed, (loss, stats), tinfo = timed(one, args.steps, args.warmup, dist, device, args.debug_single_device, settle_block=50,
+                                          before_block=restore, after_block=note_rows, on_timed_start=start_coll)
+    trainer.collective_events = None
+    collective = None
+    if coll:
+        torch.cuda.synchronize()
+        e_ms = np.array([[a.elapsed_time(b), c.elapsed_time(d), a.elapsed_time(d)] for a, b, c, d in coll])
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as exc:  # noqa: BLE001
+            rccl = f"unknown ({exc})"
+        collective = dict(early_allreduce_ms=float(np.median(e_ms[:, 0])), late_allreduce_ms=float(np.median(e_ms[:, 1])),
+                          first_start_to_last_end_ms=float(np.median(e_ms[:, 2])), steps_measured=len(coll), rccl_version=rccl,
+                          bytes=[int(x.numel() * 4) for x in trainer.engine.grad_buckets()],
+                          note="HIP events on the streams the collectives run on (the early one on the comm side stream under the "
+                               "weight-gradient kernels: its duration includes waiting for nothing but the wire and the other ranks); "
+                               "medians over the steps of the timed blocks, this rank")
     S = targs.N_samples + targs.N_importance
     counts = trainer.last_preds["counts"].cpu().tolist()
     rows, in_vol = counts[4], counts[5]
@@ -572,9 +632,10 @@ def bench_train(args, rank, world, device, dist):
                                "danbo_adam_step, HIP graph; flat-gradient all-reduce (RCCL) for N > 1",
                    "rays": R_global, "rays_per_rank": R, "samples_per_ray": S, "parallelism": f"rays-dp{world}"},
         "rows_per_step": rows, "in_volume_fraction": in_vol / (R_global * S), "loss": float(loss["total_loss"]),
-        "rows_note": "the model TRAINS through the settle phase and the timed blocks (every step is a real Adam update on the same batch), and the "
-                     "bone volumes it learns change how many samples lie inside them: rows_per_step is what the last timed step saw (50 k at "
-                     "the initial weights -- tools/bench_train.py's 25 steps stay there -- 64 k after ~500 steps); the step time follows the rows",
+        "rows_per_block": rows_per_block,
+        "rows_note": "every timed block (and the warm-up) starts from the SAME snapshot of weights, Adam moments and random stream, taken "
+                     "after the engine's first step: each block trains steps 2 .. K + 1 of the same run, whatever the settle phase did "
+                     "(round 4 timed a model that had trained through a box-dependent number of settle steps: 50 k .. 64 k rows)",
         "roofline": dict(bound="mfma", kernel="k_train_mlp_fwd x 2 + k_train_mlp_bwd + k_dw16 (whole step)", achieved=achieved / 1e12,
                          peak=peak / 1e12, unit="TFLOP/s", frac=achieved / peak, traffic=traffic, flop_per_row=2 * (2 * mac_fwd + mac_dx),
                          flop_per_row_reference=2 * (3 * mac_ref),
@@ -583,6 +644,7 @@ def bench_train(args, rank, world, device, dist):
                               "gradients on the compacted rows) divided by the WHOLE step time incl. every non-GEMM kernel and Adam; "
                               "per-kernel durations: profiles/r04_train_kernel_stats.csv"),
         **tinfo,
+        "collective_ms": collective,
         "collectives": ("none (one rank, no process group)" if dist is None and not args.nccl_world_1 else
                         f"two in-place all-reduces of the flat gradient per step ({'gloo' if args.debug_single_device else 'nccl = RCCL'}, "
                         f"world {world}{', forced at world 1: --nccl-world-1' if args.nccl_world_1 else ''}), the first on a side stream "
@@ -731,28 +793,22 @@ def launch_ranks(args, argv):
 
 
 def bench_dry_run(args, rank, world, device, dist):
-    """--dry-run: the launch / rendezvous / timing harness with a host no-op in place of the step (no HIP call at all).  Exists so
-    that the N-rank command path can be exercised where there is no GPU; its line says so and is not a measurement."""
+    """--dry-run: the launch / rendezvous / timing harness -- timed() itself: settle phase, barriers, max over the ranks, per-rank
+    times -- with a host sleep in place of the step (no HIP call at all).  --dry-run-ms a,b,..: the sleep of rank 0, 1, .. in
+    milliseconds (unequal rank speeds: tests/test_multiprocess.py checks value = N x K x units / MAX-over-ranks time with them).
+    Its line says so and is not a measurement: `units` per step and rank are a made-up 1000."""
+    ms = [float(x) for x in args.dry_run_ms.split(",")]
+    mine = ms[rank % len(ms)] * 1e-3
+
     def one():
-        time.sleep(0.001)
-    for _ in range(args.warmup):
-        one()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return {"metric": "DRY RUN of the launch path (no GPU work, not a measurement)", "value": 0.0, "unit": "ray-samples/s", "n_gpus": world,
+        time.sleep(mine)
+    elapsed, _, tinfo = timed(one, args.steps, args.warmup, dist, "cpu", True, settle_block=5)
+    units = 1000
+    return {"metric": "DRY RUN of the launch path (no GPU work, not a measurement)", "value": world * args.steps * units / elapsed,
+            "unit": "made-up units/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": args.scaling or "weak", "vs_baseline": None, "dtype": "none", "data": "none",
-            "config": {"workload": f"dry run of --config {args.config}", "parallelism": f"rays-dp{world}"}}
+            "scaling": args.scaling or "weak", "vs_baseline": None, "dtype": "none", "data": "none", **tinfo,
+            "config": {"workload": f"dry run of --config {args.config}", "parallelism": f"rays-dp{world}", "units_per_step_and_rank": units}}
 
 
 def main():
@@ -778,6 +834,7 @@ def main():
     ap.add_argument("--nccl-world-1", action="store_true",
                     help="config 4 with --gpus 1: create a ONE-rank nccl (= RCCL) process group and run the data-parallel form of the "
                          "step (split phases, both in-place all-reduces, comm side stream) -- everything of the N > 1 path but the wire")
+    ap.add_argument("--dry-run-ms", default="1", help="--dry-run: milliseconds the step of rank 0, 1, .. sleeps (comma separated)")
     ap.add_argument("--dry-run", action="store_true",
                     help="dev: launch / rendezvous / timing harness only, a host no-op as the step (gloo, no GPU needed); not a measurement")
     ap.add_argument("--mlp", choices=["f16split", "fp32"], default="f16split",

@@ -273,6 +273,27 @@ class DanboTrainEngine:
             self.reseed(seed)
         return self._rng_state
 
+    # ------------------------------------------------------------------ snapshot / restore of the whole training state
+    def snapshot(self):
+        """parameters, Adam moments and step count, the random stream: everything a step reads AND writes (bench.py restores it in
+        front of every timed block, so that each block trains the same steps from the same weights -- ADVICE r4)"""
+        return dict(p=self.flat_p.clone(), m=self.flat_m.clone(), v=self.flat_v.clone(), t=self.t,
+                    steps=[float(x) for x in self._step_tensors],
+                    rng=None if self._rng_state is None else self._rng_state.clone(), rng_seed=self._rng_seed)
+
+    def restore(self, snap):
+        self.flat_p.copy_(snap["p"])
+        self.flat_m.copy_(snap["m"])
+        self.flat_v.copy_(snap["v"])
+        self.flat_g.zero_()
+        self.t = snap["t"]
+        for x, v in zip(self._step_tensors, snap["steps"]):
+            x.fill_(v)
+        if snap["rng"] is not None and self._rng_state is not None:
+            self._rng_state.copy_(snap["rng"])
+            self._rng_seed = snap["rng_seed"]
+        torch._C._increment_version(self._param_list)      # packed weights of the eval path are keyed by the versions
+
     def rng_state_dict(self):
         """(seed, counter) of the step's random stream for a checkpoint (Trainer.save_nerf): a resumed run continues the stream
         instead of replaying the draws of step 0.  One host sync; None before the first draw."""

@@ -118,6 +118,7 @@ class Trainer:
         # run the data-parallel form of the step (split phases, both in-place all-reduces, the comm side stream) whenever a
         # process group exists, also at world size 1: how the RCCL branch is exercised on a one-GPU box
         self.collectives_at_world_1 = False
+        self.collective_events = None      # a list: train_batch_fused appends the HIP events around its two all-reduces (bench.py)
 
     def fused_engine(self):
         """the HIP training engine for this caster / optimizer, or None with `self.fused_reason` saying why not"""
@@ -157,10 +158,21 @@ class Trainer:
                 self._comm_stream = torch.cuda.Stream()
             cur = torch.cuda.current_stream()
             self._comm_stream.wait_stream(cur)
+            prof = self.collective_events            # bench.py: a list -> (start, end) events of both all-reduces, per step
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof is not None else None
             with torch.cuda.stream(self._comm_stream):
+                if ev:
+                    ev[0].record()
                 dist.all_reduce(early, op=dist.ReduceOp.SUM)
+                if ev:
+                    ev[1].record()
             eng.finish_backward()
+            if ev:
+                ev[2].record()
             dist.all_reduce(late, op=dist.ReduceOp.SUM)
+            if ev:
+                ev[3].record()
+                prof.append(ev)
             cur.wait_stream(self._comm_stream)
         lr = self.optimizer.param_groups[0]['lr']
         eng.adam_step(lr, 1.0 / world)

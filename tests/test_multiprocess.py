@@ -204,6 +204,21 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert r1["n_gpus"] == 1 and r1["ranks_seen"] == 1
 
 
+def test_bench_value_is_units_over_the_slowest_ranks_time():
+    """with UNEQUAL rank speeds (rank 0 sleeps 2 ms per step, rank 1 6 ms; gloo, world 2, no GPU) the line's
+    ms_per_step is the MAX over the ranks, value = N x K x units / that time, and the line says which rank was slow:
+    ms_per_step_ranks lists every rank's own time, slowest_rank_per_block names the rank behind each block's maximum."""
+    r = _run_bench("--gpus", "2", "--dry-run", "--dry-run-ms", "2,6", "--steps", "10", "--warmup", "1")
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and len(r["block_ms"]) == 5
+    fast, slow = r["ms_per_step_ranks"]
+    assert 2.0 <= fast < 4.5 and 6.0 <= slow < 8.5, r["ms_per_step_ranks"]          # each rank's OWN time (sleep + overhead)
+    assert r["slowest_rank_per_block"] == [1] * 5
+    assert abs(r["ms_per_step"] - slow) <= 0.05 * slow                                # the job's time is the slowest rank's
+    units = r["config"]["units_per_step_and_rank"]
+    assert abs(r["value"] - 2 * units / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]   # whole-job units over max-over-ranks time
+    assert all(b >= 6.0 for b in r["block_ms"])
+
+
 @pytest.mark.gpu
 def test_bench_config4_strong_scaling_on_two_ranks_of_one_gpu():
     """the real thing on the GPU box: two ranks (both on cuda:0, gloo collectives) split the reference's 16-pose / 3072-ray batch by
