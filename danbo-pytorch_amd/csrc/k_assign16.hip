@@ -170,14 +170,7 @@ __device__ __forceinline__ void a16_bone_features(const float* __restrict__ skt,
     a16_bone_gather(vol, x, win, out);
 }
 
-__device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)v[e];
-        hi[e] = hh;
-        lo[e] = (_Float16)(v[e] - (float)hh);
-    }
-}
+__device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo) { split8_mix(&v[0], hi, lo); }   // three instructions per pair: common.hpp
 
 // Round 4 structure.  A wavefront = 32 rows (lane = row + 32 * half) and loops, at RUN time, over the bones valid for at least
 // one of them (grouped rows: 1.7 on the bench frame).  Per bone j: the features of j and its tree neighbours are gathered for

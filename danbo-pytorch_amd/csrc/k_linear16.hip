@@ -138,6 +138,8 @@ __device__ __forceinline__ void lin_handover(LinPipe& p, const Stamp& stamp) {
     stamp();
 }
 
+// (NOT common.hpp's three-instruction split8_mix: measured on this kernel it buys nothing -- 0.159 vs 0.160 ms at 256 -> 256 -- and its
+// inline asm shifts the register allocation onto v240..v255, which belong to the in-flight row loads below)
 __device__ __forceinline__ void lin_split8(const float (&v)[8], half8& hi, half8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
