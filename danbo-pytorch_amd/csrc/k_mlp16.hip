@@ -327,8 +327,22 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
             }
         }
     } else n = resolve_count(a.count, a.n_cap);
-    const int ntiles = (n + M16_BM - 1) / M16_BM;
-    if (tile0 + (int)blockIdx.x >= ntiles) return;
+    // Rounds (round 5).  The rows are [16 * G0, n) in groups of 16 (one group = one wavefront's samples).  A FULL round gives every
+    // workgroup 8 groups (a 128-row tile); what is left over -- `rem` groups, up to 8 * gridDim.x - 1 -- is spread over ALL
+    // workgroups, `gpw` groups each, instead of filling a few workgroups' tiles: a wavefront's chain through the 74 chunks takes as
+    // long whatever its tile holds, but the wavefronts of a sparse tile have their SIMD's matrix pipe to themselves (no partner:
+    // ~half the time per chunk), and the wavefronts WITHOUT a group only keep the weight ring's hand-overs going (idle_tile) instead
+    // of pushing zeros through the MFMAs.  The training step's 320 + 141 tiles were 2 + 1 rounds of 256 with the last one 25 % /
+    // 55 % full; the frame's 5 229 tiles 20.4 rounds in 21.
+    const int G0 = tile0 * 8, G = (n + 15) >> 4;
+    const int per_round = 8 * (int)gridDim.x;
+    const int full = (G - G0) / per_round, rem = (G - G0) - full * per_round;
+    const int gpw = (rem + (int)gridDim.x - 1) / (int)gridDim.x;                       // 0: no partial round
+    const int my_rounds = full + ((int)blockIdx.x * gpw < rem ? 1 : 0);
+    if (my_rounds == 0) return;
+    // first group of this workgroup in round r, and how many of its wavefronts have one
+    auto round_base = [&](int r) { return r < full ? G0 + (r * (int)gridDim.x + (int)blockIdx.x) * 8 : G0 + full * per_round + (int)blockIdx.x * gpw; };
+    auto round_waves = [&](int r) { return r < full ? 8 : min(gpw, G - round_base(r)); };
 
     Pipe p;
     p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave; p.lane = lane;
@@ -340,20 +354,25 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
     TileSrc src;
     src.h = a.h; src.list = TRAIN ? tr.row_sample : a.list; src.dummy = a.packed; src.n = n;
     src.stage = smem + RING_SLOTS * CHUNK_BYTES + M16_TABLE_FLOATS * 4 + wave * STAGE_BYTES;
-    src.next_row0 = (tile0 + blockIdx.x) * M16_BM + wave * 16;
+    src.next_row0 = (round_base(0) + wave) * 16;
     prefetch_rows(src, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ring chunks 0-2 and the first rows (tables: the same barrier)
     __syncthreads();
     agroup_prefetch0(ring_lane_addr());               // group 0 of chunk 0 (slot 0): every later chunk is prefetched by its predecessor
 
-    for (int tile = tile0 + blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int rnd = 0; rnd < my_rounds; ++rnd) {
+        const int grp_i = round_base(rnd) + wave;            // this wavefront's row group
+        if (wave >= round_waves(rnd)) {                      // no group for this wavefront (partial round only: the last one)
+            idle_tile<NCH_TOTAL>(p);
+            continue;
+        }
         // ------------------------------------------------------------------ inputs (staged during the previous tile)
         // lane constants of the tile's prologue, re-derived per tile (see the head below)
         int zero_t = 0;
         asm volatile("" : "+s"(zero_t));
         const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_t));
         const int m = lane_t & 15, qq_t = lane_t >> 4;
-        const int row0 = tile * M16_BM + wave * 16 + m;
+        const int row0 = grp_i * 16 + m;
         const bool row_ok = row0 < n;
         const float* sh = reinterpret_cast<const float*>(src.stage) + m * DANBO_H_STRIDE + qq_t;
         const int staged_dst = reinterpret_cast<const int*>(src.stage + STAGE_H_BYTES)[m];
@@ -381,9 +400,9 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(hv[c]));
         float alpha_part = 0.f;
         f32x4 prev[16];  // pre-bias outputs of the previous layer
-        src.next_row0 = (tile + (int)gridDim.x) * M16_BM + wave * 16;
+        src.next_row0 = (round_base(rnd + 1) + wave) * 16;       // (clamped to the last row where there is no next round)
         // TRAIN: wave-uniform base addresses of this wavefront's row group (16 rows) in the fragment-order buffers
-        const long grp = (long)tile * 8 + wave;
+        const long grp = grp_i;
         // steps 0..7: the density trunk; step 8: the merged feature + view layer (128 outputs, tiles 0..7 of acc)
 #pragma unroll 1
         for (int step = 0; step < 9; ++step) {
@@ -496,7 +515,7 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
         asm volatile("" : "+s"(zero_h));
         const int lane_h = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_h));
         const int qq = lane_h >> 4, lane = lane_h;
-        const int row = tile * M16_BM + wave * 16 + (lane_h & 15);       // as at the top of the tile
+        const int row = grp_i * 16 + (lane_h & 15);               // as at the top of the tile
         asm volatile("" : "+v"(dst));
         if (TRAIN) ray = dst < 0 ? 0 : (row < tr.R ? dst : dst / (row < first_f ? tr.S_c : tr.S_f));
         else ray = dst >= 0 ? dst / a.S : 0;
@@ -609,8 +628,9 @@ extern "C" int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int
     a.alpha_w = alpha_w; a.alpha_b = alpha_b; a.cview = cview;
     a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.raw_out = raw_out; a.aux_out = aux_out;
     DANBO_ENSURE_LDS(k_pe_mlp16, M16_LDS_BYTES);
-    const int ntiles = ceil_div(n, M16_BM);
-    const int grid = ntiles < num_cu() ? ntiles : num_cu();
+    // one workgroup per CU as soon as there is a row group (16 rows) for each: a partial round is spread over all of them
+    const int groups = ceil_div(n, 16);
+    const int grid = groups < num_cu() ? groups : num_cu();
     hipLaunchKernelGGL(k_pe_mlp16, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
@@ -649,8 +669,8 @@ extern "C" int danbo_trunk_fwd(const DanboTrunkWeights* w, const DanboTrunkRows*
     t.hv = r->hv; t.hv_bits = r->hv_bits; t.raw_rows = r->raw_rows; t.raw_c = r->raw_c; t.raw_f = r->raw_f; t.raw_empty = r->raw_empty;
     t.row_ray = r->row_ray;
     DANBO_ENSURE_LDS(k_train_mlp_fwd, M16_LDS_BYTES);
-    const int ntiles = ceil_div(r->rows_cap, M16_BM);
-    const int grid = ntiles < num_cu() ? ntiles : num_cu();
+    const int groups = ceil_div(r->rows_cap, 16);
+    const int grid = groups < num_cu() ? groups : num_cu();
     hipLaunchKernelGGL(k_train_mlp_fwd, dim3(grid), dim3(M16_THREADS), M16_LDS_BYTES, (hipStream_t)stream, a, t);
     DANBO_LAUNCH_RET();
 }

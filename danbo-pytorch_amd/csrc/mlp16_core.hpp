@@ -88,6 +88,15 @@ __device__ __forceinline__ void pipe_handover(Pipe& p, const Extra& extra, bool 
     pipe_issue<NCH>(p);
 }
 
+// A wavefront without rows in a (partial) tile: it still owns an eighth of every chunk's LDS-DMA loads and takes part in every
+// hand-over barrier -- 74 hand-overs, nothing else (no fragment reads, no MFMAs, no stores: WAIT = 4 counts its ring loads only).
+template <int NCH>
+__device__ __forceinline__ void idle_tile(Pipe& p) {
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) pipe_handover<NCH, 4, NoExtra>(p, NoExtra());
+    p.cons_slot = (p.cons_slot + NCH) % RING_SLOTS;
+}
+
 __device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
     return *reinterpret_cast<const half8*>(base + piece * 1024);
 }
