@@ -334,7 +334,9 @@ __device__ __forceinline__ void mlp16_body(const Mlp16Args& a, const TrainFwd& t
     // ~half the time per chunk), and the wavefronts WITHOUT a group only keep the weight ring's hand-overs going (idle_tile) instead
     // of pushing zeros through the MFMAs.  The training step's 320 + 141 tiles were 2 + 1 rounds of 256 with the last one 25 % /
     // 55 % full; the frame's 5 229 tiles 20.4 rounds in 21.
-    const int G0 = tile0 * 8, G = (n + 15) >> 4;
+    // (TRAIN: up to the 128-row boundary -- the backward and the weight-gradient kernel walk whole 128-row tiles of the fragment-order
+    // buffers, and a padding row's activations must be this step's finite values, not what the memory held: 0 x NaN is NaN)
+    const int G0 = tile0 * 8, G = TRAIN ? ((n + M16_BM - 1) / M16_BM) * 8 : (n + 15) >> 4;
     const int per_round = 8 * (int)gridDim.x;
     const int full = (G - G0) / per_round, rem = (G - G0) - full * per_round;
     const int gpw = (rem + (int)gridDim.x - 1) / (int)gridDim.x;                       // 0: no partial round

@@ -124,7 +124,8 @@ struct StageRowsIf {      // pipe_handover's `extra`: the staging loads of the n
     }
 };
 
-__global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
+// amdgpu_num_vgpr(224): v224..v255 belong to chunk_mfma2's fragment buffers (mlp16_core.hpp)
+__global__ __launch_bounds__(M16_THREADS, 2) __attribute__((amdgpu_num_vgpr(224))) void k_train_mlp_bwd(TrainBwd a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_aw = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);   // [256]
     float* s_rgbw = s_aw + BW_;                                                // [3][128]
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
     prefetch_rows(src, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    agroup_prefetch0(ring_lane_addr());          // group 0 of chunk 0; every later chunk is prefetched by its predecessor
 
     unsigned run_max[10];          // running max |.| of this wavefront per output tensor (bit patterns, SGPRs)
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
                                     prev[2 * (s) + 1][0] * sc, prev[2 * (s) + 1][1] * sc, prev[2 * (s) + 1][2] * sc, prev[2 * (s) + 1][3] * sc};   \
                 half8 bh, bl;                                                                                           \
                 split8(v, bh, bl);                                                                                      \
-                chunk_mfma<B_NCH, 16, false, FIRST_, WAIT_>(acc, p, bh, bl, bh, bl);                                    \
+                chunk_mfma2<B_NCH, 16, false, FIRST_, (s) == 3, WAIT_>(acc, p, ring_lane_addr(), bh, bl, bh, bl);       \
             }
             DANBO_B0_STEP(0, true, 12)
             DANBO_B0_STEP(1, false, 12)
@@ -295,8 +297,9 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
                 {                                                                                                       \
                     half8 bh, bl;                                                                                       \
                     grad_fragment<(s), true>(prev[2 * (s)], prev[2 * (s) + 1], bits, sc, zg + (s) * 512, bh, bl);        \
-                    if ((s) == 0) chunk_mfma<B_NCH, 16, false, FIRST_, 8, StageRowsIf, 8, 13>(acc, p, bh, bl, bh, bl, StageRowsIf{src, step == 9}); \
-                    else chunk_mfma<B_NCH, 16, false, FIRST_, 8, NoExtra, 8, 13>(acc, p, bh, bl, bh, bl);                \
+                    /* 13 of the chunk's 16 tiles: 7 fragment groups, so the buffer parity alternates over these 8 chunks (mlp16_core.hpp) */ \
+                    if ((s) == 0) chunk_mfma2<B_NCH, 16, false, FIRST_, false, 8, StageRowsIf, 8, 13, 0>(acc, p, ring_lane_addr(), bh, bl, bh, bl, StageRowsIf{src, step == 9}); \
+                    else chunk_mfma2<B_NCH, 16, false, FIRST_, (s) == 7, 8, NoExtra, 8, 13, (s) & 1>(acc, p, ring_lane_addr(), bh, bl, bh, bl); \
                 }
                 DANBO_PE_STEP(0, true)
                 DANBO_PE_STEP(1, false) DANBO_PE_STEP(2, false) DANBO_PE_STEP(3, false) DANBO_PE_STEP(4, false) DANBO_PE_STEP(5, false)
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
                     half8 bh, bl;                                                                                       \
                     if (quiet) grad_fragment<(s), false>(prev[2 * (s)], prev[2 * (s) + 1], bits, sc, nullptr, bh, bl);   \
                     else grad_fragment<(s), true>(prev[2 * (s)], prev[2 * (s) + 1], bits, sc, zg + (s) * 512, bh, bl);   \
-                    chunk_mfma<B_NCH, 16, false, FIRST_, W0, NoExtra, 4>(acc, p, bh, bl, bh, bl, NoExtra(), quiet);      \
+                    chunk_mfma2<B_NCH, 16, false, FIRST_, (s) == 7, W0, NoExtra, 4>(acc, p, ring_lane_addr(), bh, bl, bh, bl, NoExtra(), quiet); \
                 }
                 DANBO_DX_STEP(0, true, 6)
                 DANBO_DX_STEP(1, false, 8) DANBO_DX_STEP(2, false, 8) DANBO_DX_STEP(3, false, 8) DANBO_DX_STEP(4, false, 8)
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(M16_THREADS, 2) void k_train_mlp_bwd(TrainBwd a) {
         }
     }
     // ------------------------------------------------------------------ running maxima: one atomic per workgroup and tensor
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (lane < 10) {
         unsigned v = 0u;

@@ -195,16 +195,16 @@ __device__ __forceinline__ void agroup_prefetch0(unsigned base) {
     "v_mfma_f32_16x16x32_f16 %[a0], " L0 ", %[bh], %[a0]\n\t"                                                                  \
     "v_mfma_f32_16x16x32_f16 %[a1], " L1 ", %[bh], %[a1]\n\t"
 
-template <int G, bool FIRST, bool HEAD, bool DRAIN>
+template <int G, bool FIRST, bool HEAD, bool DRAIN, int NG = 8, int PAR = 0>
 __device__ __forceinline__ void group_mfma(f32x4& a0, f32x4& a1, const half8& bh, const half8& bl, unsigned cbase, unsigned nbase) {
-    constexpr int NO = G == 7 ? 0 : (G + 1) * 4096;      // byte offset of the next group's first fragment
-    const unsigned nb = G == 7 ? nbase : cbase;
+    constexpr int NO = G == NG - 1 ? 0 : (G + 1) * 4096;      // byte offset of the next group's first fragment
+    const unsigned nb = G == NG - 1 ? nbase : cbase;
 #define DANBO_GROUP_ASM(BODY, ACC_CONSTRAINT)                                                                                   \
     asm volatile(BODY : [a0] ACC_CONSTRAINT(a0), [a1] ACC_CONSTRAINT(a1)                                                        \
                  : [bh] "v"(bh), [bl] "v"(bl), [nb] "v"(nb), [o0] "n"(NO), [o1] "n"(NO + 1024), [o2] "n"(NO + 2048), [o3] "n"(NO + 3072) \
                  : DANBO_A_CLOBBERS)
 #define DANBO_GROUP_VARIANT(PRE, POST)                                                                                          \
-    if ((G & 1) == 0) {                                                                                                        \
+    if (((G + PAR) & 1) == 0) {                                                                                                \
         if (FIRST) DANBO_GROUP_ASM(PRE DANBO_GROUP_BODY("v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", "v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", "0", "0") POST, "=&v"); \
         else DANBO_GROUP_ASM(PRE DANBO_GROUP_BODY("v[224:227]", "v[228:231]", "v[232:235]", "v[236:239]", "v[240:243]", "v[244:247]", "v[248:251]", "v[252:255]", "%[a0]", "%[a1]") POST, "+v"); \
     } else {                                                                                                                   \
@@ -226,29 +226,41 @@ __device__ __forceinline__ unsigned ring_lane_addr() {
 
 // chunk_mfma with the hand-scheduled groups.  `lds_ring`: LDS byte address of the ring + lane * 16 (a VGPR).  On entry buffer 0
 // holds (or is receiving) group 0 of this chunk; on exit, group 0 of the next one.  LAST: the GEMM's last chunk.
-template <int NCH, int NACC, bool VIEW, bool FIRST, bool LAST, int WAIT = 4, class Extra = NoExtra, int WAIT_ALT = WAIT>
+template <int NCH, int NACC, bool VIEW, bool FIRST, bool LAST, int WAIT = 4, class Extra = NoExtra, int WAIT_ALT = WAIT, int NT = 16, int PAR = 0>
 __device__ __forceinline__ void chunk_mfma2(f32x4 (&acc)[NACC], Pipe& p, unsigned lds_ring, const half8& b0h, const half8& b0l,
                                             const half8& b1h, const half8& b1l, const Extra& extra = Extra(), bool alt = false) {
     static_assert(NACC == (VIEW ? 8 : 16), "dense layers: 16 output tiles; view layer: 2 k-steps of 8");
+    // NT < 16 (the training backward's PE-ordered outputs: 13 tiles): the chunk's last pairs are padding; a group both of whose
+    // tiles are padding is skipped (the group before it then reads the next chunk's first fragments)
+    // PAR: which fragment buffer holds group 0 on entry.  A chunk of 8 groups leaves the next chunk's group 0 where it found its
+    // own (buffer PAR); a chunk of 7 groups in the OTHER buffer: the caller alternates PAR over such chunks (an even number of them
+    // in a row, so that the GEMM behind them starts at PAR = 0 again).
+    constexpr int NG = (NT + 1) / 2;
+    static_assert(NG == 8 || (NG == 7 && !VIEW), "16 tiles, or 13 / 14 in a dense layer");
     if (!p.early) pipe_handover<NCH, WAIT, Extra, WAIT_ALT>(p, extra, alt);
     const unsigned cbase = lds_ring + (unsigned)p.cons_slot * CHUNK_BYTES;
     p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
     const unsigned nbase = lds_ring + (unsigned)p.cons_slot * CHUNK_BYTES;
-    group_mfma<0, FIRST, true, false>(acc[0], acc[1], b0h, b0l, cbase, nbase);
-    group_mfma<1, FIRST, false, false>(acc[2], acc[3], b0h, b0l, cbase, nbase);
-    group_mfma<2, FIRST, false, false>(acc[4], acc[5], b0h, b0l, cbase, nbase);
-    group_mfma<3, FIRST, false, false>(acc[6], acc[7], b0h, b0l, cbase, nbase);
+    group_mfma<0, FIRST, true, false, NG, PAR>(acc[0], acc[1], b0h, b0l, cbase, nbase);
+    group_mfma<1, FIRST, false, false, NG, PAR>(acc[2], acc[3], b0h, b0l, cbase, nbase);
+    group_mfma<2, FIRST, false, false, NG, PAR>(acc[4], acc[5], b0h, b0l, cbase, nbase);
+    group_mfma<3, FIRST, false, false, NG, PAR>(acc[6], acc[7], b0h, b0l, cbase, nbase);
     if (p.early) pipe_handover<NCH, WAIT, Extra, WAIT_ALT>(p, extra, alt);
     if (VIEW) {
-        group_mfma<4, false, false, false>(acc[0], acc[1], b1h, b1l, cbase, nbase);
-        group_mfma<5, false, false, false>(acc[2], acc[3], b1h, b1l, cbase, nbase);
-        group_mfma<6, false, false, false>(acc[4], acc[5], b1h, b1l, cbase, nbase);
-        group_mfma<7, false, false, LAST>(acc[6], acc[7], b1h, b1l, cbase, nbase);
+        group_mfma<4, false, false, false, 8, PAR>(acc[0], acc[1], b1h, b1l, cbase, nbase);
+        group_mfma<5, false, false, false, 8, PAR>(acc[2], acc[3], b1h, b1l, cbase, nbase);
+        group_mfma<6, false, false, false, 8, PAR>(acc[4], acc[5], b1h, b1l, cbase, nbase);
+        group_mfma<7, false, false, LAST, 8, PAR>(acc[6], acc[7], b1h, b1l, cbase, nbase);
     } else {
-        group_mfma<4, FIRST, false, false>(acc[NACC == 16 ? 8 : 0], acc[NACC == 16 ? 9 : 1], b0h, b0l, cbase, nbase);
-        group_mfma<5, FIRST, false, false>(acc[NACC == 16 ? 10 : 2], acc[NACC == 16 ? 11 : 3], b0h, b0l, cbase, nbase);
-        group_mfma<6, FIRST, false, false>(acc[NACC == 16 ? 12 : 4], acc[NACC == 16 ? 13 : 5], b0h, b0l, cbase, nbase);
-        group_mfma<7, FIRST, false, LAST>(acc[NACC == 16 ? 14 : 6], acc[NACC == 16 ? 15 : 7], b0h, b0l, cbase, nbase);
+        group_mfma<4, FIRST, false, false, NG, PAR>(acc[NACC == 16 ? 8 : 0], acc[NACC == 16 ? 9 : 1], b0h, b0l, cbase, nbase);
+        group_mfma<5, FIRST, false, false, NG, PAR>(acc[NACC == 16 ? 10 : 2], acc[NACC == 16 ? 11 : 3], b0h, b0l, cbase, nbase);
+        if (NG == 8) {
+            group_mfma<6, FIRST, false, false, NG, PAR>(acc[NACC == 16 ? 12 : 4], acc[NACC == 16 ? 13 : 5], b0h, b0l, cbase, nbase);
+            group_mfma<7, FIRST, false, LAST, NG, PAR>(acc[NACC == 16 ? 14 : 6], acc[NACC == 16 ? 15 : 7], b0h, b0l, cbase, nbase);
+        } else {
+            group_mfma<6, FIRST, false, LAST, NG, PAR>(acc[NACC == 16 ? 12 : 4], acc[NACC == 16 ? 13 : 5], b0h, b0l, cbase, nbase);
+            if (FIRST) acc[14] = acc[15] = f32x4{0.f, 0.f, 0.f, 0.f};      // defined values (never read)
+        }
     }
 }
 

@@ -410,7 +410,7 @@ def test_ring_kernels_do_not_spill(tmp_path):
     # The training trunk's kernels run the same ring with stores in between.  They may spill a few tile-level values (pointers of
     # the row outputs) -- but no scratch access between the first and the last MFMA of the forward's layer loop, and in the
     # backward only in the once-per-tile staging branch.
-    for src, k, max_in_loop in (("k_mlp16.hip", "k_train_mlp_fwd", 0), ("k_mlp16_bwd.hip", "k_train_mlp_bwd", 16)):
+    for src, k, max_in_loop in (("k_mlp16.hip", "k_train_mlp_fwd", 0), ("k_mlp16_bwd.hip", "k_train_mlp_bwd", 0)):
         out = str(tmp_path / (src + ".t.s"))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out,
                         os.path.join(ROOT, "danbo-pytorch_amd", "csrc", src)], check=True, capture_output=True)
@@ -421,11 +421,12 @@ def test_ring_kernels_do_not_spill(tmp_path):
         inside = [l for i, l in enumerate(body) if "scratch_" in l and mf[0] < i < mf[-1]]
         assert len(inside) <= max_in_loop, (k, inside)
     # Round 5: K3 and the training forward keep the weight fragments of chunk_mfma2 in the PINNED registers v224..v255 across
-    # compiler-generated code (mlp16_core.hpp; the kernels are compiled with amdgpu_num_vgpr(224)).  No instruction outside the
+    # compiler-generated code (mlp16_core.hpp; the kernels are compiled with amdgpu_num_vgpr(224)); the training backward too.  No instruction outside the
     # inline asm may name one of them, the kernels use no scratch at all, and every MFMA of theirs is inside the asm.
-    text = open(str(tmp_path / "k_mlp16.hip.s")).read()
     high = re.compile(r"\bv(22[4-9]|2[34]\d|25[0-5])\b|v\[(\d+):(\d+)\]")
-    for k in ("k_pe_mlp16", "k_train_mlp_fwd"):
+    for k, n_mfma, asm_file in (("k_pe_mlp16", 960, "k_mlp16.hip.s"), ("k_train_mlp_fwd", 960, "k_mlp16.hip.s"),
+                                ("k_train_mlp_bwd", 912, "k_mlp16_bwd.hip.t.s")):      # 20 chunk sites x 48; 4 + 8 x 48 + 8 x 42
+        text = open(str(tmp_path / asm_file)).read()
         meta = re.search(r"\.name:\s+\S*" + k + r"\S*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
         assert int(meta.group(1)) == 0, (k, meta.group(1))
         body = text[text.index(re.search(r"^(_ZN5danbo\S*" + k + r"\S*):", text, re.M).group(1) + ":"):]
@@ -445,7 +446,7 @@ def test_ring_kernels_do_not_spill(tmp_path):
                     if m.group(1) or (m.group(3) and int(m.group(3)) >= 224):
                         foreign.append(code.strip())
         assert not foreign, (k, foreign[:4])
-        assert mfma_outside == 0 and mfma_inside == 960, (k, mfma_outside, mfma_inside)     # 20 chunk sites x 48
+        assert mfma_outside == 0 and mfma_inside == n_mfma, (k, mfma_outside, mfma_inside)
 
 
 def test_fragment_order_buffer_layout_on_cpu():
