@@ -28,7 +28,12 @@ def oracle_for(g):
 
 
 def max_err(a, b):
-    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    e = float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    if os.environ.get("DANBO_PRINT_MAXERR"):        # dev: the measured value beside every bound (pytest -s), with the calling line
+        import inspect
+        f = inspect.stack()[1]
+        print(f"max_err {os.path.basename(f.filename)}:{f.lineno} = {e:.3e}")
+    return e
 
 
 # north_star: "RGB / sigma within 1e-4 rel of reference".  Raw logits cross zero, so a relative measure needs a floor, and the

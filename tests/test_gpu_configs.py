@@ -24,8 +24,8 @@ def test_config2_h36m_danbo_fast_caster_matches_reference():
                  bones=T(g["bones"][pose]), cams=T(g["cam_idx"], torch.int64), N_importance=Sf, N_uniques=2, **kw)
     # the whole chain incl. our own box bounds: the final maps of the reference's caster
     for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
-        assert max_err(N(out[k]), g["final_" + k]) < 1e-3, k
-    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 65.0
+        assert max_err(N(out[k]), g["final_" + k]) < 1e-5, k            # measured 1.4e-6: the bounds are the reference's, bit for bit
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 100.0
     # stage-wise with the engine: bounds, then raw logits on the reference's own bounds (1 ulp of a bound moves every sample)
     eng = caster._engine()
     near, far = eng.near_far(T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["cyls"]), T(g["skts"]), chunk=len(rb))
@@ -43,8 +43,8 @@ def test_config2_h36m_danbo_fast_caster_matches_reference():
     frac = float((ret["valid_bits"] != 0).float().mean())
     assert abs(frac - float(g["in_volume_fraction"])) < 1e-6                               # the in-volume mask, sample for sample
     for k in ("rgb_map", "acc_map", "alpha", "T_i", "rgb0", "acc0"):
-        assert max_err(N(ret[k]), g["final_" + k]) < 1e-3, k
-    assert o.psnr(N(ret["rgb_map"]), g["final_rgb_map"]) > 70.0
+        assert max_err(N(ret[k]), g["final_" + k]) < 3e-5, k            # measured 7.7e-6
+    assert o.psnr(N(ret["rgb_map"]), g["final_rgb_map"]) > 100.0
     # and against the on-box oracle
     orc, cfg, sd, rest = oracle_for(g)
     ref = orc.render(rb, g["skts"][pose], g["bones"][pose], g["cyls"][pose], g["cam_idx"], 2, S, Sf, stages=True,
@@ -104,7 +104,7 @@ def test_fp16_split_kernels_on_checkpoints_outside_fp16_range(case):
     assert np.isfinite(exact).all() and np.isfinite(fast).all()
     assert np.abs(exact[..., 3]).max() > 1e-3 and np.ptp(exact[..., :3]) > 1e-3          # a non-trivial network output
     assert raw_err(fast, exact) < 1e-4
-    assert max_err(N(outs["f16split"]["rgb_map"]), N(outs["fp32"]["rgb_map"])) < 1e-3
+    assert max_err(N(outs["f16split"]["rgb_map"]), N(outs["fp32"]["rgb_map"])) < 1e-5       # measured 6e-7
 
 
 def test_custom_ops_through_torch_ops_namespace():

@@ -46,8 +46,8 @@ def test_render_path_matches_reference(tag):
     assert np.array_equal(np.array([[b[0], b[1]] for b in boxes]), g["boxes"])
     assert [len(i) for i in idxs] == list(g["n_valid"])
     assert rgbs.shape == (4, 40, 32, 3) and disps.shape == accs.shape == (4, 40, 32, 1)
-    assert max_err(accs, g[f"{tag}_accs"]) < 5e-4 and max_err(rgbs, g[f"{tag}_rgbs"]) < 5e-4
-    assert o.psnr(rgbs, g[f"{tag}_rgbs"]) > 70.0
+    assert max_err(accs, g[f"{tag}_accs"]) < 5e-5 and max_err(rgbs, g[f"{tag}_rgbs"]) < 5e-5       # measured 1.1e-5
+    assert o.psnr(rgbs, g[f"{tag}_rgbs"]) > 90.0
     d = g[f"{tag}_disps"]
     assert np.max(np.abs(disps - d) / np.maximum(np.abs(d), 1.0)) < 2e-3
     # outside the boxes the image is exactly the background

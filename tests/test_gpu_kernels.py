@@ -337,8 +337,8 @@ def test_render_stage_fixture_end_to_end(stage):
     assert np.array_equal(N(out["z_coarse"]), g["z_coarse"])
     assert raw_err(N(out["raw_coarse"]), g["raw_coarse"]) < 1e-4
     for k in ("rgb_map", "acc_map", "alpha", "T_i", "rgb0", "acc0", "alpha0"):
-        assert max_err(N(out[k]), g["final_" + k]) < 5e-4, k
-    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 70.0
+        assert max_err(N(out[k]), g["final_" + k]) < 3e-5, k   # (bounds = ~4 x measured, round 5: with bit-exact bounds and the pack scales the maps sit at 1e-6 .. 1e-5 of the reference's)
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 95.0
 
 
 def test_render_surreal_full_frame(ops):
@@ -350,8 +350,8 @@ def test_render_surreal_full_frame(ops):
     out = eng.render(T(ro), T(rd), T(scene["skts"]), T(scene["bones"]), T(scene["cyls"]), None,
                      int(g["N_samples"]), int(g["N_importance"]), near_far=nf)
     for k in ("rgb_map", "acc_map", "rgb0", "acc0"):
-        assert max_err(N(out[k]), g["final_" + k]) < 1e-3, k
-    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 70.0
+        assert max_err(N(out[k]), g["final_" + k]) < 2e-4, k            # measured 4.7e-5 (a 4 096-ray frame: more resampled depths at a kink)
+    assert o.psnr(N(out["rgb_map"]), g["final_rgb_map"]) > 85.0
 
 
 def test_render_perfcap_view_branch():
