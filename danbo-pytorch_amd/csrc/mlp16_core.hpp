@@ -11,10 +11,6 @@
 
 namespace danbo {
 
-#ifndef DANBO_M16_BT
-#define DANBO_M16_BT 2   // output tiles per batch of A-fragment reads (2 / 4 / 8 measured within 2 %)
-#endif
-
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -95,55 +91,6 @@ __device__ __forceinline__ void idle_tile(Pipe& p) {
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) pipe_handover<NCH, 4, NoExtra>(p, NoExtra());
     p.cons_slot = (p.cons_slot + NCH) % RING_SLOTS;
-}
-
-__device__ __forceinline__ half8 lds_frag(const char* base, int piece) {
-    return *reinterpret_cast<const half8*>(base + piece * 1024);
-}
-
-// hi*hi + hi*lo + lo*hi into acc; FIRST: the accumulator starts from zero (no separate clear)
-template <bool FIRST>
-__device__ __forceinline__ void mfma3(f32x4& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-}
-
-// One 32 KB chunk = 16 (tile, hi/lo) fragment pairs.  DENSE layers: one k-step, output tiles 0..NT-1 (NT < 16: the chunk's
-// last pairs are padding and skipped), B = (b0h, b0l).  VIEW layer: two k-steps of 8 output tiles, B = b0 for pairs 0..7 and
-// b1 for pairs 8..15.
-template <int NCH, int NACC, bool VIEW, bool FIRST, int WAIT = 4, class Extra = NoExtra, int WAIT_ALT = WAIT, int NT = 16>
-__device__ __forceinline__ void chunk_mfma(f32x4 (&acc)[NACC], Pipe& p, const half8& b0h, const half8& b0l,
-                                           const half8& b1h, const half8& b1l, const Extra& extra = Extra(), bool alt = false) {
-    if (!p.early) pipe_handover<NCH, WAIT, Extra, WAIT_ALT>(p, extra, alt);
-    const char* base = p.ring + p.cons_slot * CHUNK_BYTES + p.lane * 16;
-    p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
-    // batches of BT tiles: 2 BT ds_read_b128, then their 3 BT MFMAs.  (Reading a batch ahead buys nothing with
-    // compiler-tracked LDS loads -- the compiler waits with lgkmcnt(0), i.e. for the look-ahead batch too; the other
-    // wavefront of the SIMD covers the read latency.)
-    constexpr int BT = DANBO_M16_BT;
-#pragma unroll
-    for (int b = 0; b < 16 / BT; ++b) {
-        half8 ah[BT], al[BT];
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            if (BT * b + t < NT) {
-                ah[t] = lds_frag(base, 2 * (BT * b + t));
-                al[t] = lds_frag(base, 2 * (BT * b + t) + 1);
-            }
-        }
-        if (BT * b == 8 && p.early) pipe_handover<NCH, WAIT, Extra, WAIT_ALT>(p, extra, alt);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < BT; ++t) {
-            const int T = BT * b + t;
-            if (T < NT) {
-                if (VIEW && T >= 8) mfma3<false>(acc[T - 8], ah[t], al[t], b1h, b1l);
-                else mfma3<FIRST>(acc[T], ah[t], al[t], b0h, b0l);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
