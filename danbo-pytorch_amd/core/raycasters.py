@@ -254,7 +254,7 @@ class RayCaster(nn.Module):
     @torch.no_grad()
     def render_rays_whole(self, ray_batch, chunk, N_samples=None, kp_batch=None, skts=None, cyls=None, bones=None, cams=None,
                           lindisp=False, perturb=0., N_importance=0, raw_noise_std=0., ray_noise_std=0., N_uniques=1,
-                          preproc_kwargs={}, fwd_type='', **kwargs):
+                          preproc_kwargs={}, fwd_type='', rays=None, near_far0=None, **kwargs):
         """`trainer.batchify_rays`' loop over `chunk`-ray casts as ONE cast of all rays, when that is the same computation, else
         None (the caller loops).  It is the same when every ray belongs to one pose (so a chunk's N_uniques = 1 whatever the
         chunking) and the engine is the DANBO engine: every stage is per ray or per sample except the cylinder bounds' nan-mean
@@ -266,9 +266,13 @@ class RayCaster(nn.Module):
         if not isinstance(eng, DanboEngine) or N_samples > 256 or N_importance > 64:
             return None
         eng.cfg['density_scale'] = preproc_kwargs.get('density_scale', eng.cfg['density_scale'])
-        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
         skts_g, bones_g, cyls_g = skts[:1].contiguous(), bones[:1].contiguous(), cyls[:1].contiguous()
-        near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., int(chunk), ray_batch[:, 6], ray_batch[:, 7])
+        if rays is not None:           # trainer.render hands the rays over as they are (scalar placeholder bounds near_far0)
+            rays_o, rays_d = rays[0].contiguous(), rays[1].contiguous()
+            near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, near_far0[0], near_far0[1], int(chunk))
+        else:
+            rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+            near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., int(chunk), ray_batch[:, 6], ray_batch[:, 7])
         if eng.cfg['use_volume_near_far']:
             ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
         return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance, near_far=(near, far))

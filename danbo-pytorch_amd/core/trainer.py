@@ -53,6 +53,14 @@ def render(H, W, focal, chunk=1024 * 64, rays=None, c2w=None, near=0., far=1., c
         rays_o, rays_d = rays
     sh = rays_d.shape
     rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    # a caster of this package in eval mode takes the image's rays as they are -- no [R, 8 | 11] ray batch to build and to slice
+    # apart again (four strided copies per image): RayCaster.render_rays_whole(..., rays=(o, d), near_far0=(near, far))
+    whole = getattr(kwargs.get('ray_caster'), 'render_rays_whole', None)
+    if whole is not None and rays_o.shape[0] > chunk and not torch.is_tensor(near) and not torch.is_tensor(far):
+        out = whole(None, chunk, rays=(rays_o, rays_d), near_far0=(float(near), float(far)),
+                    **{k: v for k, v in kwargs.items() if k != 'ray_caster'})
+        if out is not None:
+            return {k: (v if v.dim() >= 4 else v.reshape(list(sh[:-1]) + list(v.shape[1:]))) for k, v in out.items()}
     cols = [rays_o, rays_d, near * torch.ones_like(rays_d[:, :1]), far * torch.ones_like(rays_d[:, :1])]
     if use_viewdirs:
         cols.append(rays_d / torch.norm(rays_d, dim=-1, keepdim=True))
