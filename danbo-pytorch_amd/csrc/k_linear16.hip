@@ -9,7 +9,10 @@
 //   Y^T [N x rows] = W [N x K] * X^T [K x rows]
 //   A operand = weights: pre-packed in MFMA fragment order (danbo_linear16_pack), streamed once per 128-row tile through
 //               a 4-slot x 32 KB LDS ring by global_load_lds; one chunk = one k-step of 32 inputs x 16 output tiles;
-//               fragments are read from LDS one batch (two tiles) ahead of the MFMAs that use them;
+//               fragments are read from LDS one group (two tiles) ahead of the MFMAs that use them, across chunk boundaries too
+//               (round 5: mlp16_core.hpp group_mfma -- pinned fragment registers v224 .. v255, in-place interleaved MFMAs;
+//               448 -> 448 at 1 M rows 1.36 -> 1.33 ms, the A-NeRF frame 193.7 -> 189.2 ms on one box.  The half-chunk stagger of
+//               the two wavefronts of a SIMD that K3 lives on was measured again on this form: 1.39 ms, it still does not pay here);
 //   B operand = this wavefront's 16 rows: lane (n, q) loads the 8 inputs 32 s + 8 q .. + 7 of row n straight from HBM
 //               (32 B per lane, 128 B contiguous per row and k-step), two k-steps ahead, and splits them in registers;
 //   D         = up to 32 output tiles of 16 features x 16 rows in registers (128 VGPRs); lane (n, q) owns features
@@ -23,6 +26,7 @@
 // bookkeeping; the end of a row tile (drain + 28 stores per lane) costs ~15 000 cycles per 80 000.
 #include <type_traits>
 #include "common.hpp"
+#include "mlp16_core.hpp"
 
 namespace danbo {
 
@@ -138,8 +142,7 @@ __device__ __forceinline__ void lin_handover(LinPipe& p, const Stamp& stamp) {
     stamp();
 }
 
-// (NOT common.hpp's three-instruction split8_mix: measured on this kernel it buys nothing -- 0.159 vs 0.160 ms at 256 -> 256 -- and its
-// inline asm shifts the register allocation onto v240..v255, which belong to the in-flight row loads below)
+// (NOT common.hpp's three-instruction split8_mix: measured on this kernel it buys nothing -- 0.159 vs 0.160 ms at 256 -> 256)
 __device__ __forceinline__ void lin_split8(const float (&v)[8], half8& hi, half8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -153,8 +156,8 @@ __device__ __forceinline__ void lin_split8(const float (&v)[8], half8& hi, half8
 // Input rows.  Lane (n, q) needs the 8 inputs 32 s + 8 q .. + 7 of its row in every k-step; they are requested two k-steps
 // ahead.  A register that is the target of a load in flight must never be copied or spilled by the compiler, and across a
 // loop back-edge it does exactly that with ordinary (even inline-asm "+v") values.  So the two row sets live in fixed
-// physical registers v[240:247] / v[248:255] that only the inline asm below names: the compiler, which needs ~215
-// registers for this kernel and allocates from v0 upwards, never touches them (tests/test_host_logic.py checks the ISA), and
+// physical registers v[208:215] / v[216:223] that only the inline asm below names: the kernel is compiled with
+// amdgpu_num_vgpr(208), so the compiler never touches them (tests/test_host_logic.py checks the ISA), and
 // it adds no waits of its own because it does not see the loads.  The ring hand-over's wait covers them (lin_handover).
 // Columns past the end of a part are read from the clamped address, i.e. they repeat earlier columns of the same row:
 // their packed weights are zero, so the (finite) values do not matter, nothing outside the row is touched, and every
@@ -163,22 +166,22 @@ __device__ __forceinline__ void lin_split8(const float (&v)[8], half8& hi, half8
 template <int SET>
 __device__ __forceinline__ void lin_request_rows(const float* pa, const float* pb) {
     if (SET == 0) {
-        asm volatile("global_load_dwordx4 v[240:243], %0, off\n\tglobal_load_dwordx4 v[244:247], %1, off" ::"v"(pa), "v"(pb)
-                     : "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+        asm volatile("global_load_dwordx4 v[208:211], %0, off\n\tglobal_load_dwordx4 v[212:215], %1, off" ::"v"(pa), "v"(pb)
+                     : "memory", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215");
     } else {
-        asm volatile("global_load_dwordx4 v[248:251], %0, off\n\tglobal_load_dwordx4 v[252:255], %1, off" ::"v"(pa), "v"(pb)
-                     : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+        asm volatile("global_load_dwordx4 v[216:219], %0, off\n\tglobal_load_dwordx4 v[220:223], %1, off" ::"v"(pa), "v"(pb)
+                     : "memory", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223");
     }
 }
 template <int SET>
 __device__ __forceinline__ void lin_take_rows(float (&v)[8]) {
     if (SET == 0)
-        asm volatile("v_mov_b32 %0, v240\n\tv_mov_b32 %1, v241\n\tv_mov_b32 %2, v242\n\tv_mov_b32 %3, v243\n\t"
-                     "v_mov_b32 %4, v244\n\tv_mov_b32 %5, v245\n\tv_mov_b32 %6, v246\n\tv_mov_b32 %7, v247"
+        asm volatile("v_mov_b32 %0, v208\n\tv_mov_b32 %1, v209\n\tv_mov_b32 %2, v210\n\tv_mov_b32 %3, v211\n\t"
+                     "v_mov_b32 %4, v212\n\tv_mov_b32 %5, v213\n\tv_mov_b32 %6, v214\n\tv_mov_b32 %7, v215"
                      : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
     else
-        asm volatile("v_mov_b32 %0, v248\n\tv_mov_b32 %1, v249\n\tv_mov_b32 %2, v250\n\tv_mov_b32 %3, v251\n\t"
-                     "v_mov_b32 %4, v252\n\tv_mov_b32 %5, v253\n\tv_mov_b32 %6, v254\n\tv_mov_b32 %7, v255"
+        asm volatile("v_mov_b32 %0, v216\n\tv_mov_b32 %1, v217\n\tv_mov_b32 %2, v218\n\tv_mov_b32 %3, v219\n\t"
+                     "v_mov_b32 %4, v220\n\tv_mov_b32 %5, v221\n\tv_mov_b32 %6, v222\n\tv_mov_b32 %7, v223"
                      : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
 }
 
@@ -211,10 +214,26 @@ __device__ __forceinline__ void lin_enc_joint(float inp, float sh, float w, floa
     o[3] = mul_rn(on2 ? c2 : 0.f, w);
 }
 
+// a group whose two tiles lie past N (known at run time only): no MFMAs, but the next group's fragments are still requested
+template <int G>
+__device__ __forceinline__ void lin_group_skip(unsigned cbase, unsigned nbase) {
+    constexpr int NO = G == 7 ? 0 : (G + 1) * 4096;
+    const unsigned nb = G == 7 ? nbase : cbase;
+    if ((G & 1) == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 v[240:243], %0 offset:%1\n\tds_read_b128 v[244:247], %0 offset:%2\n\t"
+                     "ds_read_b128 v[248:251], %0 offset:%3\n\tds_read_b128 v[252:255], %0 offset:%4"
+                     ::"v"(nb), "n"(NO), "n"(NO + 1024), "n"(NO + 2048), "n"(NO + 3072) : DANBO_A_CLOBBERS);
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 v[224:227], %0 offset:%1\n\tds_read_b128 v[228:231], %0 offset:%2\n\t"
+                     "ds_read_b128 v[232:235], %0 offset:%3\n\tds_read_b128 v[236:239], %0 offset:%4"
+                     ::"v"(nb), "n"(NO), "n"(NO + 1024), "n"(NO + 2048), "n"(NO + 3072) : DANBO_A_CLOBBERS);
+}
+
 // NP: tile pairs in the last chunk of a k-step known at compile time (no branches in the batch loop), 0 = taken from N
 // FRAG: Lin16Args::frag as a compile-time constant (a run-time choice costs the registers this kernel does not have)
+// amdgpu_num_vgpr(208): v208 .. v223 belong to the row loads in flight, v224 .. v255 to group_mfma's fragment buffers
 template <int NH, int NP, bool TRACE, int FRAG = 0>
-__global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
+__global__ __launch_bounds__(L16_THREADS, 1) __attribute__((amdgpu_num_vgpr(208))) void k_linear16(Lin16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + L16_SLOTS * L16_CHUNK);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -266,6 +285,7 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
     request(std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_waitcnt(0xF70);  // vmcnt(0): chunks 0-2 and the first rows are here (p.skip = 2 relies on it)
     __syncthreads();
+    agroup_prefetch0((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)lane * 16u);   // group 0 of chunk 0
     half8 bh, bl;   // B fragments of the current k-step; those of the next one are prepared under this one's MFMAs
     {
         float x[8];
@@ -296,57 +316,41 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         stamp();
         half8 nbh, nbl;
         float nx[8];
-#pragma unroll
-        for (int hf = 0; hf < NH; ++hf) {
+        // one chunk (k-step s, output tiles 16 hf .. 16 hf + 15) as eight hand-scheduled groups of two tiles (mlp16_core.hpp group_mfma:
+        // round 5 of K3): A fragments in the pinned registers v224 .. v255, the reads of group b + 1 behind the first MFMA of group b,
+        // the last group of a chunk reads group 0 of the NEXT chunk -- published by the hand-over in front of this one -- so a chunk's
+        // MFMAs start right behind the barrier instead of an LDS round trip that all eight wavefronts make at the same moment.
+        auto chunk = [&](auto hfc) {
+            constexpr int hf = decltype(hfc)::value;
+            // groups with MFMAs in this chunk when that is known at compile time (whole pairs of tiles past N are skipped)
+            constexpr int NGC = (NP && hf == NH - 1) ? NP : 8;
+            static_assert(NGC % 2 == 0, "an odd number of groups would leave the next chunk's fragments in the other buffer");
             stamp();
             lin_handover(p, stamp);
             stamp();
-            const int slot = p.cons_slot;
+            const unsigned cbase = lds_base + (unsigned)(p.cons_slot * L16_CHUNK);
             p.cons_slot = p.cons_slot + 1 == L16_SLOTS ? 0 : p.cons_slot + 1;
-            // A fragments one batch (two tiles = 4 reads) ahead of the MFMAs that use them.  The reads are inline asm with a
-            // manual s_waitcnt: LDS reads return in order, so "at most 4 outstanding" means batch b has arrived while the
-            // reads of batch b + 1 stay in flight under batch b's six MFMAs.  (Reads the compiler tracks are always waited
-            // for with lgkmcnt(0), which exposes the full LDS latency once per batch: 38 % -> measured below.)
-            half8 fr[2][4];
-            const unsigned la = lds_base + (unsigned)(slot * L16_CHUNK);
-#define DANBO_L16_READ(B, F)                                                                                              \
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                                      \
-                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                                           \
-                 : "=v"(F[0]), "=v"(F[1]), "=v"(F[2]), "=v"(F[3])                                                           \
-                 : "v"(la), "i"((4 * (B)) * 1024), "i"((4 * (B) + 1) * 1024), "i"((4 * (B) + 2) * 1024), "i"((4 * (B) + 3) * 1024))
-            DANBO_L16_READ(0, fr[0]);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                half8 (&f)[4] = fr[b & 1];   // hi, lo of tile 2b; hi, lo of tile 2b + 1
-                half8 (&fn)[4] = fr[(b + 1) & 1];
-                switch (b) {                 // the offsets are instruction immediates
-                    case 0: DANBO_L16_READ(1, fn); break;
-                    case 1: DANBO_L16_READ(2, fn); break;
-                    case 2: DANBO_L16_READ(3, fn); break;
-                    case 3: DANBO_L16_READ(4, fn); break;
-                    case 4: DANBO_L16_READ(5, fn); break;
-                    case 5: DANBO_L16_READ(6, fn); break;
-                    case 6: DANBO_L16_READ(7, fn); break;
-                    default: break;
-                }
-                // Work that is not MFMA is spread over the batches, a few VALU / scalar instructions under each batch's six
+            const unsigned nbase = lds_base + (unsigned)(p.cons_slot * L16_CHUNK);
+            auto group = [&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                // Work that is not MFMA is spread over the groups, a few VALU / scalar instructions under each group's six
                 // MFMAs: the ring refill (the slot of chunk c-1 is free once the barrier has been passed), and in the first
                 // chunk of a k-step the next k-step's rows (requested two k-steps ago, arrived: see lin_handover) become B
                 // fragments and their registers are re-used for the request after next.
                 if (b == 1) lin_issue(p);
                 if (hf == 0 && b == 2) lin_take_rows<decltype(set)::value>(nx);
                 if ((FRAG & 8) && hf == 0 && (b == 3 || b == 4)) {
-                    // rows of k-step s + 1 (0 behind the last one): the recomputed inputs, one joint under each of two batches
+                    // rows of k-step s + 1 (0 behind the last one): the recomputed inputs, one joint under each of two groups
                     const int s_next = s + 1 < KS ? s + 1 : 0;
                     if (s_next < 12) {
                         float o[4];
-                        const int e0 = 4 * (b - 3);
+                        constexpr int e0 = 4 * (b == 4);
                         lin_enc_joint(nx[e0], nx[e0 + 1], nx[e0 + 2], nx[e0 + 3], q, a.enc_L, o);
                         nx[e0] = o[0]; nx[e0 + 1] = o[1]; nx[e0 + 2] = o[2]; nx[e0 + 3] = o[3];
                     }
                 }
                 if ((FRAG & 8) ? (hf == 1 && b <= 3) : (hf == 0 && b >= 3 && b <= 6)) {
-                    const int b0 = (FRAG & 8) ? b : b - 3;
+                    constexpr int b0 = (FRAG & 8) ? (b & 3) : ((b + 1) & 3);      // b resp. b - 3 where the condition holds
 #pragma unroll
                     for (int e = 2 * b0; e < 2 * b0 + 2; ++e) {
                         const float xe = nx[e];
@@ -356,21 +360,20 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
                     }
                 }
                 if (hf == 0 && b == 7) request(set);
-                if (b < 7) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-                if (NP ? (hf < NH - 1 || b < NP) : (16 * hf + 2 * b < nt)) {  // whole pairs of tiles past N are skipped
+                if (b < NGC) {
                     f32x4& c0 = acc[16 * hf + 2 * b];
                     f32x4& c1 = acc[16 * hf + 2 * b + 1];
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], bh, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[2], bh, c1, 0, 0, 0);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[0], bl, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[2], bl, c1, 0, 0, 0);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[1], bh, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[3], bh, c1, 0, 0, 0);
+                    if (NP || 16 * hf + 2 * b < nt) group_mfma<b, false, b == 0, false, NGC>(c0, c1, bh, bl, cbase, nbase);
+                    else lin_group_skip<b>(cbase, nbase);     // N known at run time only: the reads keep the double buffer going
                 }
-            }
-#undef DANBO_L16_READ
-        }
+            };
+            group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{});
+            group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+            group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+            group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+        };
+        chunk(std::integral_constant<int, 0>{});
+        if (NH == 2) chunk(std::integral_constant<int, NH - 1>{});
         bh = nbh;
         bl = nbl;
         stamp();
@@ -382,6 +385,12 @@ __global__ __launch_bounds__(L16_THREADS, 1) void k_linear16(Lin16Args a) {
         const long row = (long)(blockIdx.x + it * gridDim.x) * L16_BM + wave * 16 + n;
         __builtin_amdgcn_s_waitcnt(0xF70);
         p.skip = 2;
+        // the MFMAs are inline asm: the wait states between the last of them and the VALU instructions that read the accumulators
+        // are written out (the vmcnt wait above usually covers them, but does not have to), and every accumulator is re-defined
+        // behind them so that no read is scheduled in front
+        asm volatile(DANBO_MFMA_DRAIN ::: "memory");
+#pragma unroll
+        for (int T = 0; T < 16 * NH; ++T) asm volatile("" : "+v"(acc[T]));
         if (FRAG & 4) {
             // fragment-order output: tile T of this wavefront's 16 rows is one contiguous KB (rows past M: padding of the buffer)
             const long g16 = (long)(blockIdx.x + it * gridDim.x) * (L16_BM / 16) + wave;

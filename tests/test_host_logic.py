@@ -300,10 +300,11 @@ def test_kp_to_valid_rays_matches_reference():
 
 
 def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
-    """k_linear16 requests its input rows two k-steps ahead into fixed physical registers v[240:255] that only its inline asm
-    names; nothing the compiler generates may touch them (a copy or spill of a register whose load is in flight reads stale
-    data), and the compiler must not add vmcnt waits of its own inside the k-step loop (they would drain the weight ring).
-    Checked on the gfx950 ISA of both instantiations."""
+    """k_linear16 requests its input rows two k-steps ahead into fixed physical registers v[208:223] and keeps the weight fragments
+    of two groups in v[224:255] (mlp16_core.hpp group_mfma), all of which only its inline asm names: the kernel is compiled with
+    amdgpu_num_vgpr(208).  Nothing the compiler generates may touch them (a copy or spill of a register whose load is in flight
+    reads stale data), every MFMA sits inside the asm, and the compiler must not add vmcnt waits of its own inside the k-step loop
+    (they would drain the weight ring).  Checked on the gfx950 ISA of every instantiation."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -313,7 +314,8 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out, src],
                    check=True, capture_output=True)
     text = open(out).read()
-    high = re.compile(r"\bv(24\d|25[0-5])\b|v\[(24\d|25[0-5]):")
+    pinned = r"(20[89]|21\d|22\d|23\d|24\d|25[0-5])"
+    high = re.compile(r"\bv" + pinned + r"\b|v\[" + pinned + ":")
     # every instantiation <NH, NP, TRACE, FRAG>; FRAG = activations in fragment order (danbo_linear16_fwd_frag)
     names = re.findall(r"^(_ZN5danbo10k_linear16ILi(\d)ELi(\d)ELb(\d)ELi(\d+)EEEvNS_9Lin16ArgsE):", text, re.M)
     seen = set()
@@ -323,20 +325,24 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
         body = text[text.index(name + ":"):]
         body = body[:body.index(".Lfunc_end")].split("\n")
         assert not any("scratch_" in l for l in body), ("register spills", name)
-        # outside the inline asm nothing names v240 .. v255
-        in_asm, foreign = False, []
+        # outside the inline asm nothing names v208 .. v255 and there is no MFMA
+        in_asm, foreign, mfma = False, [], 0
         for l in body:
             in_asm = True if "ASMSTART" in l else (False if "ASMEND" in l else in_asm)
-            if not in_asm and high.search(l):
+            if not in_asm and (high.search(l) or "v_mfma" in l):
                 foreign.append(l.strip())
+            mfma += "v_mfma_f32_16x16x32_f16" in l
         assert not foreign, (name, foreign[:4])
+        # two unrolled k-steps of NH chunks, 8 groups of 6 (NP = 6: the last chunk of a k-step has 6 groups)
+        assert mfma == 2 * 6 * (8 * (nh - 1) + (np_ or 8)), (name, mfma)
         touching = [l.strip() for l in body if high.search(l)]
         loads = [l for l in touching if l.startswith("global_load_dwordx4 v[2")]
-        takes = [l for l in touching if re.match(r"v_mov_b32 v\d+, v2[45]\d$", l)]
+        takes = [l for l in touching if re.match(r"v_mov_b32 v\d+, v2(0[89]|1\d|2[0-3])$", l)]
+        frags = [l for l in touching if l.startswith("ds_read_b128 v[2") or l.startswith("v_mfma")]
         # requests: three in the prologue + one per unrolled k-step, 2 loads each (a kernel with one part in rows and one in
         # fragment order carries both address forms); takes: 8 registers in the prologue and in each of the two k-steps
         mixed = frag in (1, 5, 6, 12, 14)   # (12 / 14: the A-NeRF encoder table instead of rows, danbo_linear16_fwd_enc)
-        assert len(loads) == (20 if mixed else 10) and len(takes) == 24 and len(touching) == len(loads) + len(takes), (name, touching)
+        assert len(loads) == (20 if mixed else 10) and len(takes) == 24 and len(touching) == len(loads) + len(takes) + len(frags), (name, touching)
         waits = sorted(re.search(r"vmcnt\(\d+\)", l).group(0) for l in body if "s_waitcnt" in l and "vmcnt" in l)
         # bias table, prologue, one per row-tile end in each of the two unrolled k-steps, final drain; one per hand-over
         assert waits == sorted(["vmcnt(0)"] * 5 + ["vmcnt(6)"] * (2 * nh)), (name, waits)
