@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     # two frames were rendered (one warm-up: weight packing, engine refresh, allocator fills; one steady-state): only the SECOND
     # is attributed -- a frame starts at its cylinder-bounds kernel
-    starts = [i for i, r in enumerate(rows) if "k_cylinder_pass1" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "k_cylinder_chunk" in r["Kernel_Name"] or "k_cylinder_pass1" in r["Kernel_Name"]]
     assert len(starts) >= 2, len(starts)
     for r in rows[starts[-1]:]:
         acc[r["Kernel_Name"].split("(")[0]][c].append(float(r["Counter_Value"]))
