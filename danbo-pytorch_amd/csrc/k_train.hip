@@ -382,7 +382,7 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // (the environment is read ONCE per process, not per step)
     static const int stop_after = dev_env("DANBO_TRAIN_STOP_AFTER", 1000);
 #define DANBO_STAGE(n) do { if (stop_after <= (n)) { DANBO_LAUNCH_RET(); } } while (0)
-    bool fused_tail = false;
+    bool fused_tail = false, losses_reported = false;
     if (phase != 2) {
     // ---- zero: counters, running maxima, loss terms, volume / per-ray gradients; the flat parameter gradient
     zero_words(b.zero_begin, (long)((b.zero_end - b.zero_begin) / 4), m->g_flat, (long)m->n_flat, st);
@@ -509,6 +509,10 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_TRY(danbo_train_draw_unmerge(b.d_raw_c, b.d_raw_sorted, b.order, b.bits_c, b.bits_f, o->weights, o->alpha, R, S, Sf, b.d_raw_f,
                                        b.d_raw_rows, b.label_c, b.label_f, b.loss, b.maxabs + MX_RAW, stream));
     DANBO_STAGE(7);
+    // per-bone row lists of the K2 adjoint: they need the cull's bits and the forward's row counters only, so they are made HERE, in
+    // front of the chain, and the K2 adjoint is the chain's direct successor on the caller's stream (round 5; they used to sit
+    // between the two: 9 us on the critical path behind a 15 us cross-queue wait, tools/timeline_train.sh)
+    DANBO_TRY(danbo_train_bone_lists(b.bits_c, b.bits_f, b.row_sample, b.cnt, R, ncap, b.lists, b.cntb, stream));
     // ---- the input-gradient chain over the rows of both passes: d raw -> d pre_v -> dz_7 .. dz_0 -> d h
     DANBO_TRY(danbo_trunk_bwd(&tw, &trw, stream));
     DANBO_STAGE(9);
@@ -519,28 +523,35 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     //   main  : K2 / K1b adjoint -> pose GNN adjoint
     ss = (fork_mask & 2) ? ss_all : nullptr;
     if (ss) { s0 = ss->s[0]; s1 = ss->s[1]; } else { s0 = stream; s1 = stream; }
+    // Whole step: the view gradients go IN FRONT OF the pose-GNN adjoint on side 1 (they follow the chain, the adjoint follows K2's):
+    // two side branches behind the chain ended up on ONE hardware queue in the replayed graph, the view gradients behind the pose
+    // adjoint's six launches, and the head chain waited for them (tools/timeline_train.sh, round 5).  Split steps keep side 0.
+    static const int dw_on_main = dev_env("DANBO_TRAIN_DW_ON_MAIN", 1);
+    const bool vg_on_side1 = ss && phase == 0 && dw_on_main;
+    void* vg_stream = vg_on_side1 ? (void*)ss->s[1] : s0;
     if (ss) {
-        if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
-        guard.pending[0] = true;
+        if (hipEventRecord(ss->fork, st) != hipSuccess) return (int)hipGetLastError();
+        if (!vg_on_side1) {
+            if (hipStreamWaitEvent(ss->s[0], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
+            guard.pending[0] = true;
+        }
         if (phase == 0) {
             if (hipStreamWaitEvent(ss->s[1], ss->fork, 0) != hipSuccess) return (int)hipGetLastError();
             guard.pending[1] = true;
         }
     }
-    DANBO_TRY(danbo_train_view_grads(b.dpre_v, b.row_ray, b.cnt, ncap, R, b.vin, LD_VIN, m->view_ch, bt->cam_idx, m->n_codes, b.d_cview, b.csum,
-                                     m->g[DANBO_T_VIEWS_W], b.vg_part, s0));
-    auto side1_tail = [&]() -> int {
-        DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, s1));
-        // (waiting for side 0's camera sums HERE costs ~12 us of an idle device in front of the head chain although the event
-        // completed long ago; the same wait in front of the weight gradients moved the gap there: measured, no gain)
-        if (hipEventRecord(ss->join[0], ss->s[0]) != hipSuccess || hipStreamWaitEvent((hipStream_t)s1, ss->join[0], 0) != hipSuccess)
-            return (int)hipGetLastError();
-        DANBO_TRY(danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W],
+    auto head_chain = [&]() -> int {
+        return danbo_train_head_chain(b.g_wfv, b.g_beff, b.csum, m->p[DANBO_T_FEAT_W], m->p[DANBO_T_FEAT_B], m->p[DANBO_T_VIEWS_W],
                                          m->view_ch, m->n_codes, m->code_size, nd, m->g[DANBO_T_FEAT_W], m->g[DANBO_T_FEAT_B],
-                                         m->g[DANBO_T_VIEWS_W], m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, b.vg_part, s1));
-        return 0;
+                                         m->g[DANBO_T_VIEWS_W], m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, b.vg_part, s1);
     };
-    DANBO_TRY(danbo_train_bone_lists(b.bits_c, b.bits_f, b.row_sample, b.cnt, R, ncap, b.lists, b.cntb, stream));
+    auto pose_adjoint = [&](void* on) -> int {
+        return danbo_pose_volumes_bwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], m->p[DANBO_T_G_ADJW0], m->g_adj0,
+                                      m->p[DANBO_T_G_B0], m->p[DANBO_T_G_W1], m->p[DANBO_T_G_ADJW1], m->g_adj1, m->p[DANBO_T_G_B1],
+                                      m->p[DANBO_T_G_W2], m->p[DANBO_T_G_W3], b.vol_scratch, b.g_vol, m->g[DANBO_T_G_W0], m->g[DANBO_T_G_ADJW0],
+                                      m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
+                                      m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, on);
+    };
     DANBO_STAGE(10);
     DanboAssignBwd ab{};
     ab.rays_o = bt->rays_o; ab.rays_d = bt->rays_d; ab.z_c = b.z_c; ab.z_f = b.z_f; ab.skts = bt->skts; ab.align = m->align;
@@ -555,6 +566,11 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     ab.c_ss = 2.0f * m->soft_softmax_coef / ((float)R * (float)(S + Sf));
     ab.loss = b.loss;
     DANBO_TRY(danbo_assign_blend_bwd(&ab, stream));
+    // (enqueued BEHIND the K2 adjoint: of the chain's two successors the one captured first continues on the chain's queue, the other
+    // starts 15 - 35 us later on another one -- the view gradients have 0.3 ms of slack, the K2 adjoint is the critical path)
+    DANBO_TRY(danbo_train_view_grads(b.dpre_v, b.row_ray, b.cnt, ncap, R, b.vin, LD_VIN, m->view_ch, bt->cam_idx, m->n_codes, b.d_cview, b.csum,
+                                     m->g[DANBO_T_VIEWS_W], b.vg_part, vg_stream));
+    if (ss && phase == 0 && hipEventRecord(ss->join[0], (hipStream_t)vg_stream) != hipSuccess) return (int)hipGetLastError();   // the camera sums
     // The weight-gradient kernel waits for the K2 adjoint: side by side the two just share the compute units (their LDS footprints
     // exclude each other per CU) and the pose-GNN adjoint -- six small launches -- then ran on an otherwise idle device; behind it,
     // those launches hide under the weight gradients (1.71 -> 1.68 ms per step, 0.98 -> 0.94 at 384 rays)
@@ -563,24 +579,39 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // queue at once.  The weight gradients are the critical path (0.29 ms, the head chain and Adam behind them); the pose-GNN
     // adjoint's six launches have 0.1 ms of slack under them: DANBO_TRAIN_DW_ON_MAIN=1 (default) keeps the former on the
     // caller's stream and sends the latter across.
-    static const int dw_on_main = dev_env("DANBO_TRAIN_DW_ON_MAIN", 1);
     void* pose_stream = stream;
+    bool pose_done = false;
+    // loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
+    auto report_losses = [&](void* on) {
+        hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, (hipStream_t)on, reinterpret_cast<const uint32_t*>(b.loss),
+                           reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),
+                           reinterpret_cast<uint32_t*>(o->counts), o->counts ? 8 : 0);
+        losses_reported = true;
+    };
     if (phase == 0 && ss) {
         if (hipEventRecord(ss->mid, st) != hipSuccess || hipStreamWaitEvent(ss->s[1], ss->mid, 0) != hipSuccess) return (int)hipGetLastError();
         if (dw_on_main) {
             pose_stream = s1;
             s1 = stream;
         }
-        DANBO_TRY(side1_tail());
+        DANBO_TRY(danbo_dw16(dwl, N_DW, ncap, b.cnt + 4, DW_SLICES, b.dw_scratch, s1));
+        if (vg_on_side1) {
+            // side 1 carries the view gradients AND the pose adjoint: ONE cross-queue wait in front of the head chain covers the
+            // camera sums and ends the fork (round 4 waited for side 0 here and for side 1 behind the head chain: every such wait
+            // costs 6 - 12 us of an idle device in the replayed graph although its event completed long ago)
+            DANBO_TRY(pose_adjoint(pose_stream));
+            pose_done = true;
+            report_losses(pose_stream);      // final since the K2 adjoint: off the critical path
+            DANBO_TRY(join(1));
+        } else if (hipStreamWaitEvent((hipStream_t)s1, ss->join[0], 0) != hipSuccess) {      // recorded behind the view gradients
+            return (int)hipGetLastError();
+        }
+        DANBO_TRY(head_chain());
     }
     DANBO_STAGE(11);
-    DANBO_TRY(danbo_pose_volumes_bwd(bt->bones, G, m->L_graph, m->graph_width, m->p[DANBO_T_G_W0], m->p[DANBO_T_G_ADJW0], m->g_adj0,
-                                     m->p[DANBO_T_G_B0], m->p[DANBO_T_G_W1], m->p[DANBO_T_G_ADJW1], m->g_adj1, m->p[DANBO_T_G_B1],
-                                     m->p[DANBO_T_G_W2], m->p[DANBO_T_G_W3], b.vol_scratch, b.g_vol, m->g[DANBO_T_G_W0], m->g[DANBO_T_G_ADJW0],
-                                     m->g[DANBO_T_G_B0], m->g[DANBO_T_G_W1], m->g[DANBO_T_G_ADJW1], m->g[DANBO_T_G_B1], m->g[DANBO_T_G_W2],
-                                     m->g[DANBO_T_G_B2], m->g[DANBO_T_G_W3], m->g[DANBO_T_G_B3], b.pose_bwd_scratch, pose_stream));
+    if (!pose_done) DANBO_TRY(pose_adjoint(pose_stream));
     DANBO_STAGE(12);
-    if (phase == 0 && ss) {                        // (the head chain's stream has waited for side 0: joining side 1 joins both)
+    if (phase == 0 && ss) {                        // (the head chain's stream has waited for the view gradients' stream: joining side 1 joins both)
         DANBO_TRY(join(1));
         guard.pending[0] = false;
     } else {
@@ -599,9 +630,10 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
                                          m->g[DANBO_T_VIEWS_B], m->n_codes > 0 ? m->g[DANBO_T_CODES] : nullptr, b.vg_part, stream));
     }
     // ---- loss terms for the caller: [0] rgb fine, [1] rgb coarse, [2] sum (label - q)^2, [3] volume scale, [4..6] row counters
-    hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),
-                       reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),
-                       reinterpret_cast<uint32_t*>(o->counts), o->counts ? 8 : 0);
+    if (!losses_reported)
+        hipLaunchKernelGGL(k_copy_words_, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint32_t*>(b.loss),
+                           reinterpret_cast<uint32_t*>(o->loss), 4, reinterpret_cast<const uint32_t*>(b.cnt),
+                           reinterpret_cast<uint32_t*>(o->counts), o->counts ? 8 : 0);
     DANBO_LAUNCH_RET();
 }
 

@@ -187,12 +187,90 @@ struct HeadChainArgs {
     const float* vg_part;                        // [VG_SLICES][128][VG_PART_LD] partial d W_v[:, 256:] of k_train_view_grad, or nullptr
 };
 
+// The two parameter-sized products run as 64 x 64 output tiles through LDS (round 5; one thread per output element with its
+// operand row read straight from memory was 30 us on the step's critical path: d W_v's threads walked 256 rows of W_f side by side,
+// 64 cache lines per load instruction).  Every output is still ONE fmaf chain over k = 0, 1, 2, ... from the same start value:
+// the results are the former kernel's bit for bit.
+constexpr int HC_T = 64, HC_K = 64;
+constexpr int HC_TILES_VA = (HVW / HC_T) * (HW / HC_T), HC_TILES_F = (HW / HC_T) * (HW / HC_T), HC_REST_BLOCKS = 192;
+
+// C[m, n] (m0.., n0..) = start + sum_k A(m, k) B(n, k);  KMAJOR: A(m, k) = A[k * lda + m], B(n, k) = B[k * ldb + n], else A[m * lda + k], B[n * ldb + k]
+// K-steps of 64 through LDS, the next step's operands fetched into registers under the current one's arithmetic (a K-step of 16
+// without that prefetch paid one global round trip per step: 16 of them made the kernel as slow as the one it replaced).
+template <bool KMAJOR, class Start, class Store>
+__device__ __forceinline__ void hc_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int K, int m0, int n0,
+                                        const Start& start, const Store& store) {
+    __shared__ float s_a[HC_K][HC_T + 1], s_b[HC_K][HC_T + 1];
+    constexpr int PER = HC_K * HC_T / 256;
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    float acc[4][4], ra[PER], rb[PER];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = start(m0 + 4 * ty + i, n0 + 4 * tx + j);
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            // consecutive threads read consecutive addresses of the operand
+            const int e = t + 256 * u;
+            const int kk = KMAJOR ? e / HC_T : e % HC_K, mm = KMAJOR ? e % HC_T : e / HC_K;
+            ra[u] = KMAJOR ? A[(size_t)(k0 + kk) * lda + m0 + mm] : A[(size_t)(m0 + mm) * lda + k0 + kk];
+            rb[u] = KMAJOR ? B[(size_t)(k0 + kk) * ldb + n0 + mm] : B[(size_t)(n0 + mm) * ldb + k0 + kk];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += HC_K) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + 256 * u;
+            const int kk = KMAJOR ? e / HC_T : e % HC_K, mm = KMAJOR ? e % HC_T : e / HC_K;
+            s_a[kk][mm] = ra[u];
+            s_b[kk][mm] = rb[u];
+        }
+        __syncthreads();
+        if (k0 + HC_K < K) fetch(k0 + HC_K);
+#pragma unroll 8
+        for (int kk = 0; kk < HC_K; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = s_a[kk][4 * ty + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = s_b[kk][4 * tx + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store(m0 + 4 * ty + i, n0 + 4 * tx + j, acc[i][j]);
+}
+
 __global__ __launch_bounds__(256) void k_train_head_chain(HeadChainArgs a) {
     const int ld = HW + a.Cv;
-    const long n_va = (long)HVW * HW, n_f = (long)HW * HW, n_fb = HW, n_vb = HVW, n_c = (long)a.n_codes * a.code_size;
+    int blk = blockIdx.x;
+    if (blk < HC_TILES_VA) {          // d W_v[f, c] = d b_eff[f] b_f[c] + sum_j d W_fv[f, j] W_f[c, j]
+        const int m0 = (blk / (HW / HC_T)) * HC_T, n0 = (blk % (HW / HC_T)) * HC_T;
+        hc_tile<false>(a.g_wfv, HW, a.feature_w, HW, HW, m0, n0, [&](int f, int c) { return a.g_beff[f] * a.feature_b[c]; },
+                       [&](int f, int c, float v) { a.g_views_w[(size_t)f * ld + c] = v; });
+        return;
+    }
+    blk -= HC_TILES_VA;
+    if (blk < HC_TILES_F) {           // d W_f[c, j] = sum_f W_v[f, c] d W_fv[f, j]
+        const int m0 = (blk / (HW / HC_T)) * HC_T, n0 = (blk % (HW / HC_T)) * HC_T;
+        hc_tile<true>(a.views_w, ld, a.g_wfv, HW, HVW, m0, n0, [](int, int) { return 0.f; },
+                      [&](int c, int j, float v) { a.g_feature_w[(size_t)c * HW + j] = v; });
+        return;
+    }
+    blk -= HC_TILES_F;
+    // the vector-sized rest, one thread per output element
+    const long n_fb = HW, n_vb = HVW, n_c = (long)a.n_codes * a.code_size;
     const long n_vk = a.vg_part ? (long)HVW * a.Cv : 0;
-    const long total = n_va + n_f + n_fb + n_vb + n_c + n_vk;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long total = n_fb + n_vb + n_c + n_vk;
+    for (long idx = (long)blk * blockDim.x + threadIdx.x; idx < total; idx += (long)HC_REST_BLOCKS * blockDim.x) {
         long i = idx;
         if (i >= total - n_vk) {      // d W_v[f, 256 + k] = sum over the ray slices of k_train_view_grad's partial sums (fixed order)
             i -= total - n_vk;
@@ -203,24 +281,6 @@ __global__ __launch_bounds__(256) void k_train_head_chain(HeadChainArgs a) {
             a.g_views_w[(size_t)f * ld + HW + k] += acc;
             continue;
         }
-        if (i < n_va) {               // d W_v[f, c] = sum_j d W_fv[f, j] W_f[c, j] + d b_eff[f] b_f[c]
-            const int f = (int)(i / HW), c = (int)(i % HW);
-            float acc = a.g_beff[f] * a.feature_b[c];
-            const float* gw = a.g_wfv + (size_t)f * HW;
-            const float* wf = a.feature_w + (size_t)c * HW;
-            for (int j = 0; j < HW; ++j) acc = fmaf(gw[j], wf[j], acc);
-            a.g_views_w[(size_t)f * ld + c] = acc;
-            continue;
-        }
-        i -= n_va;
-        if (i < n_f) {                // d W_f[c, j] = sum_f W_v[f, c] d W_fv[f, j]
-            const int c = (int)(i / HW), j = (int)(i % HW);
-            float acc = 0.f;
-            for (int f = 0; f < HVW; ++f) acc = fmaf(a.views_w[(size_t)f * ld + c], a.g_wfv[(size_t)f * HW + j], acc);
-            a.g_feature_w[i] = acc;
-            continue;
-        }
-        i -= n_f;
         if (i < n_fb) {               // d b_f[c] = sum_f W_v[f, c] d b_eff[f]
             float acc = 0.f;
             for (int f = 0; f < HVW; ++f) acc = fmaf(a.views_w[(size_t)f * ld + i], a.g_beff[f], acc);
@@ -277,6 +337,6 @@ extern "C" int danbo_train_head_chain(const float* g_wfv, const float* g_beff, c
     DANBO_CHECK_ARG(view_ch >= 0 && (n_codes == 0 || (csum && g_codes && code_size > 0 && code_col0 >= 0 && code_col0 + code_size <= view_ch)));
     HeadChainArgs a{g_wfv, g_beff, csum, feature_w, feature_b, views_w, view_ch, n_codes, code_size, code_col0,
                     g_feature_w, g_feature_b, g_views_w, g_views_b, g_codes, vg_part};
-    hipLaunchKernelGGL(k_train_head_chain, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_train_head_chain, dim3(HC_TILES_VA + HC_TILES_F + HC_REST_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
 }
