@@ -69,6 +69,7 @@ SIGNATURES = {
     "danbo_train_view_inputs": [P, P, I, I, I, I, I, P, I, I, P, P, I, P],
     "danbo_train_loss_grad": [P, P, P, P, P, P, I, I, I, F, F, P, P, P, P, P, P],
     "danbo_train_draw_unmerge": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P],
+    "danbo_train_mid": [P, P, P, P, P, P, I, I, I, I, I, F, F, F] + [P] * 25,
     "danbo_train_bone_lists": [P, P, P, P, I, I, P, P, P],
     "danbo_assign_blend_bwd": [P, P],
     "danbo_pose_volumes_bwd": [P, I, I, I] + [P] * 24,

@@ -4,6 +4,7 @@
 // The linear layers of the training path are plain GEMMs and go through rocBLAS (torch.addmm /
 // bmm on the compacted in-volume rows); see core/train_path.py.  gfx950 only.
 #include "common.hpp"
+#include "composite_bwd.hpp"
 
 namespace danbo {
 
@@ -110,77 +111,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int nchunk = (S + 63) >> 6;
-    for (int r = wave; r < R; r += nwaves) {
-        const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
-        const float dn = norm3_torch(dx, dy, dz_);
-        const float gr = g_rgb[3 * r], gg = g_rgb[3 * r + 1], gb = g_rgb[3 * r + 2];
-        // ---- forward sweep: per-chunk quantities kept in registers (<= 4 chunks) ----
-        float al[4], T[4], dist[4], sig[4], cr[4], cg[4], cb[4], rr[4], rg[4], rb[4];
-        float carry = 1.0f, acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            al[c] = 0.f; T[c] = 0.f; dist[c] = 0.f; sig[c] = 0.f; cr[c] = cg[c] = cb[c] = 0.f; rr[c] = rg[c] = rb[c] = 0.f;
-            if (c >= nchunk) continue;
-            const int s = c * 64 + lane;
-            const bool act = s < S;
-            const size_t m = (size_t)r * S + (act ? s : S - 1);
-            // lazily filled raw: samples outside every volume were never written and take the ray's empty-space raw
-            const float4 rw = (bits != nullptr && bits[m] == 0u) ? raw_empty[r] : raw[m];
-            const float zs = z[m];
-            const float zn = (s + 1 < S) ? z[m + 1] : zs;
-            dist[c] = mul_rn((s + 1 < S) ? sub_rn(zn, zs) : 1e10f, dn);
-            float sg = div_rn(rw.w, B);
-            if (noise) sg = add_rn(sg, noise[m]);
-            sig[c] = act ? sg : -1.f;
-            const float a = act ? sub_rn(1.0f, expf(-mul_rn(fmaxf(sg, 0.f), dist[c]))) : 0.f;
-            al[c] = a;
-            float p = act ? add_rn(sub_rn(1.0f, a), 1e-10f) : 1.0f;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float q = __shfl_up(p, off, 64);
-                if (lane >= off) p = mul_rn(p, q);
-            }
-            float excl = __shfl_up(p, 1, 64);
-            if (lane == 0) excl = 1.0f;
-            T[c] = mul_rn(carry, excl);
-            carry = mul_rn(carry, __shfl(p, 63, 64));
-            rr[c] = sigmoidf_(rw.x); rg[c] = sigmoidf_(rw.y); rb[c] = sigmoidf_(rw.z);
-            cr[c] = rr[c] * 1.002f - 0.001f; cg[c] = rg[c] * 1.002f - 0.001f; cb[c] = rb[c] * 1.002f - 0.001f;
-            acc += wave_sum(act ? a * T[c] : 0.f);
-        }
-        const float ga = acc < 1.0f ? g_acc[r] : 0.f;
-        // ---- backward sweep: suffix sums of dL/dw_k * w_k, chunks in reverse ----
-        float tail = 0.f;
-#pragma unroll
-        for (int c = 3; c >= 0; --c) {
-            if (c >= nchunk) continue;
-            const int s = c * 64 + lane;
-            const bool act = s < S;
-            const float w = al[c] * T[c];
-            const float dLdw = gr * cr[c] + gg * cg[c] + gb * cb[c] + ga;
-            float v = act ? dLdw * w : 0.f;
-            // inclusive suffix scan inside the chunk
-            float suf = v;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float q = __shfl_down(suf, off, 64);
-                if (lane + off < 64) suf += q;
-            }
-            const float after = suf - v + tail;  // strictly later samples
-            tail += __shfl(suf, 0, 64);
-            if (act) {
-                const float dLda = dLdw * T[c] - after / (1.0f - al[c] + 1e-10f);
-                const float dads = sig[c] > 0.f ? dist[c] * expf(-sig[c] * dist[c]) : 0.f;
-                float4 o;
-                o.x = gr * w * 1.002f * rr[c] * (1.0f - rr[c]);
-                o.y = gg * w * 1.002f * rg[c] * (1.0f - rg[c]);
-                o.z = gb * w * 1.002f * rb[c] * (1.0f - rb[c]);
-                o.w = dLda * dads / B;
-                d_raw[(size_t)r * S + s] = o;
-            }
-        }
-    }
+    for (int r = wave; r < R; r += nwaves)
+        composite_bwd_ray(raw, z, rays_d, r, S, B, noise, g_rgb[3 * r], g_rgb[3 * r + 1], g_rgb[3 * r + 2], g_acc[r], raw_empty, bits, lane,
+                          [&](int s, const float4& o) { d_raw[(size_t)r * S + s] = o; });
 }
 
 }  // namespace danbo

@@ -500,14 +500,11 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
 
     DANBO_STAGE(6);
     // ---- losses and the adjoints of the two composites
-    DANBO_TRY(danbo_train_loss_grad(o->rgb_map, o->acc_map, o->rgb0, o->acc0, bt->target, bt->bgs, m->use_background, R, m->loss_mse,
-                                    m->rgb_loss_coef, m->rgb_loss_coef * m->coarse_weight, b.g_rgb, b.g_acc, b.g_rgb0, b.g_acc0, b.loss, stream));
-    DANBO_TRY(danbo_composite_bwd_lazy(b.raw_c, b.raw_empty, b.bits_c, b.z_c, bt->rays_d, R, S, B, bt->noise_c, b.g_rgb0, b.g_acc0, b.d_raw_c,
-                                       stream));
-    DANBO_TRY(danbo_composite_bwd_lazy(b.raw_sorted, nullptr, nullptr, b.z_sorted, bt->rays_d, R, S + Sf, B, bt->noise_f, b.g_rgb, b.g_acc,
-                                       b.d_raw_sorted, stream));
-    DANBO_TRY(danbo_train_draw_unmerge(b.d_raw_c, b.d_raw_sorted, b.order, b.bits_c, b.bits_f, o->weights, o->alpha, R, S, Sf, b.d_raw_f,
-                                       b.d_raw_rows, b.label_c, b.label_f, b.loss, b.maxabs + MX_RAW, stream));
+    DANBO_TRY(danbo_train_mid(o->rgb_map, o->acc_map, o->rgb0, o->acc0, bt->target, bt->bgs, m->use_background, R, S, Sf, m->loss_mse,
+                              m->rgb_loss_coef, m->rgb_loss_coef * m->coarse_weight, B, b.g_rgb, b.g_acc, b.g_rgb0, b.g_acc0, b.raw_c,
+                              b.raw_empty, b.raw_sorted, b.bits_c, b.bits_f, b.z_c, b.z_sorted, bt->rays_d, bt->noise_c, bt->noise_f, b.order,
+                              o->weights, o->alpha, b.d_raw_c, b.d_raw_f, b.d_raw_rows, b.label_c, b.label_f, b.loss, b.maxabs + MX_RAW,
+                              stream));
     DANBO_STAGE(7);
     // per-bone row lists of the K2 adjoint: they need the cull's bits and the forward's row counters only, so they are made HERE, in
     // front of the chain, and the K2 adjoint is the chain's direct successor on the caller's stream (round 5; they used to sit

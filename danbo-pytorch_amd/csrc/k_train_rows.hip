@@ -14,6 +14,7 @@
 //   [1] n_c, [2] R + n_c, [3] n_f, [4] R + n_c + n_f, [5] n_c + n_f, [6] (R + n_c) rounded down to 128, [7] n_f + (R + n_c) % 128
 //   ([1] .. [7] are derived by block 0 of the trunk's forward kernel of each pass, k_mlp16.hip)
 #include "common.hpp"
+#include "composite_bwd.hpp"
 
 namespace danbo {
 
@@ -175,6 +176,157 @@ __global__ __launch_bounds__(256) void k_train_draw_unmerge(float4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The step's four launches between the final composite and the input-gradient chain as ONE (round 5): per ray and wavefront the
+// loss gradients (k_train_loss_grad's arithmetic on lane 0), the adjoints of the coarse and of the merged composite
+// (composite_bwd_ray: k_composite_bwd's), and k_train_draw_unmerge -- the two composites' d raw stay in LDS between them instead
+// of making a round trip through memory.  Every output is the four kernels' bit for bit; the loss SUMS are formed per wavefront
+// instead of per thread (atomics either way).
+// ------------------------------------------------------------------------------------------------------------------
+struct MidArgs {
+    const float *rgb, *acc, *rgb0, *acc0, *target, *bgs;
+    int use_bg, R, S, Sf, mse;
+    float w_fine, w_coarse, B;
+    float *g_rgb, *g_acc, *g_rgb0, *g_acc0;                    // [R,3], [R]: kept (the workspace view exposes them)
+    const float4 *raw_c, *raw_empty, *raw_sorted;
+    const uint32_t *bits_c, *bits_f;
+    const float *z_c, *z_sorted, *rays_d, *noise_c, *noise_f;
+    const int32_t* order;
+    const float *weights, *alpha;
+    float4 *d_raw_c, *d_raw_f, *d_raw_rows;
+    uint8_t *label_c, *label_f;
+    float *loss, *maxabs;
+};
+constexpr int MID_MAX = 256;     // samples per ray and composite
+__host__ __device__ inline int mid_lds_per_wave(int S, int Sf) { return ((2 * S + Sf) * 16 + (S + Sf) + 15) & ~15; }
+
+// 16 wavefronts per workgroup: every workgroup ends in four atomics on the same four words (same-address atomics retire one after
+// the other, ~17 ns each: with one wavefront per ray in workgroups of four the 768 x 4 atomics of a 3 072-ray batch were a third
+// of the kernel), and the per-wavefront LDS rows are sized by the launch (S, S + Sf), not by the 256-sample maximum.
+constexpr int MID_WAVES = 16;
+template <int NC>
+__global__ __launch_bounds__(64 * MID_WAVES) void k_train_mid(MidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char mid_smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int R = a.R, S = a.S, Sf = a.Sf, St = a.S + a.Sf;
+    // this wavefront's rows: d raw of the coarse / merged samples, volume flags of the coarse / importance samples
+    char* mine = mid_smem + (size_t)wv * mid_lds_per_wave(S, Sf);
+    float4* const s_c_w = reinterpret_cast<float4*>(mine);
+    float4* const s_m_w = s_c_w + S;
+    uint8_t* const s_in_c_w = reinterpret_cast<uint8_t*>(s_m_w + St);
+    uint8_t* const s_in_f_w = s_in_c_w + S;
+    const float inv = 1.0f / (3.0f * (float)R);
+    float l_f = 0.f, l_c = 0.f, lsum = 0.f, mx = 0.f;
+    for (int r = wave; r < R; r += nwaves) {
+        // ---- everything the ray needs from memory is requested up front (ONE round trip per ray instead of one per stage: the ray's
+        //      chain of four dependent stages IS the kernel's duration, 12 wavefronts per CU): the loss inputs (every lane the same
+        //      addresses), the un-merge's order / weights / alpha, the importance samples' volume bits, and -- inside the forward
+        //      sweeps -- the two composites' raw, depths and noise
+        float in_c[2][3], in_a[2], tg[3], bg[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in_c[0][k] = a.rgb[3 * r + k];
+            in_c[1][k] = a.rgb0[3 * r + k];
+            tg[k] = a.target[3 * r + k];
+            bg[k] = a.use_bg ? (a.bgs ? a.bgs[3 * r + k] : 1.0f) : 0.f;
+        }
+        in_a[0] = a.acc[r];
+        in_a[1] = a.acc0[r];
+        int ord[NC];
+        float wal[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = c * 64 + lane;
+            ord[c] = 0;
+            wal[c] = 0.f;
+            if (i < St) {
+                const size_t ms = (size_t)r * St + i;
+                ord[c] = a.order[ms];
+                wal[c] = a.weights[ms] * a.alpha[ms];
+            }
+            if (i < Sf) s_in_f_w[i] = a.bits_f[(size_t)r * Sf + i] != 0u;
+        }
+        CompositeState<NC> st;          // ONE state at a time: coarse forward + backward sweep, then the merged composite's
+        composite_fwd_sweep(a.raw_c, a.z_c, a.rays_d, r, S, a.B, a.noise_c, a.raw_empty, a.bits_c, lane, st);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c * 64 + lane < S) s_in_c_w[c * 64 + lane] = st.inside[c];
+        // ---- loss gradients of the ray (reference trainer.py:396-422; k_train_loss_grad's arithmetic, every lane the same values)
+        float g[2][4];      // [pass][rgb, acc]
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float wgt = p ? a.w_coarse : a.w_fine;
+            float ga = 0.f, ls = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = in_c[p][k] + (a.use_bg ? (1.0f - in_a[p]) * bg[k] : 0.f) - tg[k];
+                const float gk = (a.mse ? 2.0f * e : (e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.f))) * inv * wgt;
+                ls += a.mse ? e * e : fabsf(e);
+                g[p][k] = gk;
+                ga -= gk * bg[k];
+            }
+            g[p][3] = ga;
+            if (lane == 0) {
+                float* gc = p ? a.g_rgb0 : a.g_rgb;
+                gc[3 * r] = g[p][0]; gc[3 * r + 1] = g[p][1]; gc[3 * r + 2] = g[p][2];
+                (p ? a.g_acc0 : a.g_acc)[r] = ga;
+                if (p) l_c += ls * inv * wgt; else l_f += ls * inv * wgt;
+            }
+        }
+        // ---- adjoints of the two composites: d raw of the coarse samples and of the merged (sorted) samples, into LDS
+        composite_bwd_sweep(st, S, a.B, g[1][0], g[1][1], g[1][2], g[1][3], lane, [&](int s, const float4& o) { s_c_w[s] = o; });
+        composite_fwd_sweep(a.raw_sorted, a.z_sorted, a.rays_d, r, St, a.B, a.noise_f, nullptr, nullptr, lane, st);
+        composite_bwd_sweep(st, St, a.B, g[0][0], g[0][1], g[0][2], g[0][3], lane, [&](int s, const float4& o) { s_m_w[s] = o; });
+        // the LDS rows are this wavefront's own: its DS operations execute in order, the fence keeps the compiler from reordering them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- un-merge (k_train_draw_unmerge)
+        float ex = 0.f, ey = 0.f, ez = 0.f, ew = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = c * 64 + lane;
+            if (i >= St) continue;
+            const int src = min(max(ord[c], 0), St - 1);
+            float4 d = s_m_w[i];
+            const uint8_t lab = (wal[c] > 0.f) ? 1 : 0;
+            bool inside;
+            if (src < S) {
+                const size_t q = (size_t)r * S + src;
+                const float4 cc = s_c_w[src];
+                d.x += cc.x; d.y += cc.y; d.z += cc.z; d.w += cc.w;
+                a.d_raw_c[q] = d;
+                a.label_c[q] = lab;
+                inside = s_in_c_w[src] != 0;
+            } else {
+                const size_t q = (size_t)r * Sf + (src - S);
+                a.d_raw_f[q] = d;
+                a.label_f[q] = lab;
+                inside = s_in_f_w[src - S] != 0;
+            }
+            if (!inside) { ex += d.x; ey += d.y; ez += d.z; ew += d.w; lsum += (float)lab; }
+            else mx = fmaxf(mx, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+        }
+        ex = wave_total(ex); ey = wave_total(ey); ez = wave_total(ez); ew = wave_total(ew);
+        if (lane == 0) a.d_raw_rows[r] = make_float4(ex, ey, ez, ew);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fmaxf(fabsf(ez), fabsf(ew))));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // workgroup totals, then one atomic per word and workgroup
+    __shared__ float s_red[4][MID_WAVES];
+    l_f = wave_total(l_f); l_c = wave_total(l_c); lsum = wave_total(lsum); mx = wave_max(mx);
+    if (lane == 0) { s_red[0][wv] = l_f; s_red[1][wv] = l_c; s_red[2][wv] = lsum; s_red[3][wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = s_red[threadIdx.x][0];
+#pragma unroll
+        for (int w = 1; w < MID_WAVES; ++w) t = threadIdx.x == 3 ? fmaxf(t, s_red[3][w]) : t + s_red[threadIdx.x][w];
+        if (threadIdx.x == 3) atomic_max_abs(a.maxabs, t);
+        else if (t != 0.f) atomicAdd(a.loss + threadIdx.x, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // per-bone lists of (row) pairs: bone j's list holds every in-volume row whose sample lies inside bone j's volume
 // (wave-aggregated appends: one atomic per wavefront and bone)
 // ------------------------------------------------------------------------------------------------------------------
@@ -274,6 +426,38 @@ extern "C" int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorte
                        reinterpret_cast<float4*>(d_raw_c), reinterpret_cast<const float4*>(d_raw_sorted), order, bits_c, bits_f, weights,
                        alpha, R, S, Sf, reinterpret_cast<float4*>(d_raw_f), reinterpret_cast<float4*>(d_raw_rows), label_c, label_f, loss,
                        maxabs);
+    DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_train_mid(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target, const float* bgs,
+                               int use_bg, int R, int S, int Sf, int mse, float w_fine, float w_coarse, float B, float* g_rgb, float* g_acc,
+                               float* g_rgb0, float* g_acc0, const float* raw_c, const float* raw_empty, const float* raw_sorted,
+                               const uint32_t* bits_c, const uint32_t* bits_f, const float* z_c, const float* z_sorted, const float* rays_d,
+                               const float* noise_c, const float* noise_f, const int32_t* order, const float* weights, const float* alpha,
+                               float* d_raw_c, float* d_raw_f, float* d_raw_rows, uint8_t* label_c, uint8_t* label_f, float* loss,
+                               float* maxabs, void* stream) {
+    DANBO_CHECK_ARG(rgb && acc && rgb0 && acc0 && target && g_rgb && g_acc && g_rgb0 && g_acc0 && loss && maxabs);
+    DANBO_CHECK_ARG(raw_c && raw_empty && raw_sorted && bits_c && bits_f && z_c && z_sorted && rays_d && order && weights && alpha);
+    DANBO_CHECK_ARG(d_raw_c && d_raw_f && d_raw_rows && label_c && label_f && R > 0 && S > 0 && Sf > 0 && S + Sf <= MID_MAX && B > 0.f);
+    MidArgs a{rgb, acc, rgb0, acc0, target, bgs, use_bg, R, S, Sf, mse, w_fine, w_coarse, B, g_rgb, g_acc, g_rgb0, g_acc0,
+              reinterpret_cast<const float4*>(raw_c), reinterpret_cast<const float4*>(raw_empty), reinterpret_cast<const float4*>(raw_sorted),
+              bits_c, bits_f, z_c, z_sorted, rays_d, noise_c, noise_f, order, weights, alpha, reinterpret_cast<float4*>(d_raw_c),
+              reinterpret_cast<float4*>(d_raw_f), reinterpret_cast<float4*>(d_raw_rows), label_c, label_f, loss, maxabs};
+    const int lds = MID_WAVES * mid_lds_per_wave(S, Sf);        // <= 16 x 8.5 KB
+    const dim3 grid(stream_grid((long)R * 64, 64 * MID_WAVES)), block(64 * MID_WAVES);
+    // (the LDS attribute is set once per instantiation: its largest launch)
+#define DANBO_MID_LAUNCH(NC)                                                                           \
+    do {                                                                                               \
+        DANBO_ENSURE_LDS(k_train_mid<NC>, MID_WAVES * mid_lds_per_wave(64 * (NC), 0));                 \
+        hipLaunchKernelGGL(k_train_mid<NC>, grid, block, lds, (hipStream_t)stream, a);                 \
+    } while (0)
+    switch ((S + Sf + 63) / 64) {
+        case 1: DANBO_MID_LAUNCH(1); break;
+        case 2: DANBO_MID_LAUNCH(2); break;
+        case 3: DANBO_MID_LAUNCH(3); break;
+        default: DANBO_MID_LAUNCH(4); break;
+    }
+#undef DANBO_MID_LAUNCH
     DANBO_LAUNCH_RET();
 }
 

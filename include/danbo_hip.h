@@ -34,7 +34,8 @@ extern "C" {
  * danbo_group_rows (additive); 5 = danbo_ray_bone_mask, danbo_flat_rays;
  * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
  * danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_random_draws, danbo_gather_rows; danbo_render_frame takes up to
- * 256 + 64 samples per ray; 6 = DANBO_MLP16_PACKED_BYTES grows by a trailer (power-of-two pack scales of danbo_mlp16_pack). */
+ * 256 + 64 samples per ray; 6 = DANBO_MLP16_PACKED_BYTES grows by a trailer (power-of-two pack scales of danbo_mlp16_pack);
+ * 7 = danbo_train_mid (additive). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -481,6 +482,16 @@ int danbo_train_draw_unmerge(float* d_raw_c, const float* d_raw_sorted, const in
                              const uint32_t* bits_f, const float* weights, const float* alpha, int R, int S, int Sf,
                              float* d_raw_f, float* d_raw_rows, uint8_t* label_c, uint8_t* label_f, float* loss, float* maxabs,
                              void* stream);
+/* ABI 7: the three calls above -- loss gradients, the adjoints of the coarse and of the merged composite (danbo_composite_bwd_lazy
+ * twice) and the un-merge -- as ONE launch, one wavefront per ray, the composites' d raw held in LDS in between; every output is the
+ * separate calls' bit for bit (the loss sums are atomics either way).  S + Sf <= 256.  This is what danbo_train_step runs. */
+int danbo_train_mid(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target, const float* bgs,
+                    int use_bg, int R, int S, int Sf, int mse, float w_fine, float w_coarse, float density_scale, float* g_rgb,
+                    float* g_acc, float* g_rgb0, float* g_acc0, const float* raw_c, const float* raw_empty, const float* raw_sorted,
+                    const uint32_t* bits_c, const uint32_t* bits_f, const float* z_c, const float* z_sorted, const float* rays_d,
+                    const float* noise_c /*or NULL*/, const float* noise_f /*or NULL*/, const int32_t* order, const float* weights,
+                    const float* alpha, float* d_raw_c, float* d_raw_f, float* d_raw_rows, uint8_t* label_c, uint8_t* label_f,
+                    float* loss, float* maxabs, void* stream);
 int danbo_train_bone_lists(const uint32_t* bits_c, const uint32_t* bits_f, const int32_t* row_sample, const int32_t* cnt, int R,
                            int rows_cap, int32_t* lists /*[24, rows_cap]*/, int32_t* cntb /*[24], zeroed by the caller*/, void* stream);
 

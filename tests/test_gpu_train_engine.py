@@ -632,3 +632,62 @@ def test_captured_step_draws_fresh_numbers_every_replay_and_follows_the_seed():
     torch.manual_seed(4)
     s3 = steps(1)
     assert not torch.equal(s3[0][0], s1[0][0])
+
+
+@pytest.mark.parametrize("S,Sf,mse,use_bg", [(48, 16, 0, 1), (32, 16, 1, 0), (96, 48, 0, 1), (200, 56, 1, 1)])
+def test_fused_mid_step_equals_its_four_launches_bitwise(S, Sf, mse, use_bg):
+    """danbo_train_mid (ABI 7: loss gradients + both composite adjoints + un-merge in one launch, what danbo_train_step runs) against
+    danbo_train_loss_grad, danbo_composite_bwd_lazy x 2 and danbo_train_draw_unmerge on the same inputs: every tensor bit for bit,
+    the loss sums (atomics in both) to rounding.  Several 64-sample chunks per ray, MSE / L1, with and without backgrounds."""
+    from core import _hip
+    lib = _hip.lib()
+    g = torch.Generator(device="cpu").manual_seed(S * 131 + Sf)
+    R, St, B = 157, S + Sf, 7.5
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)          # noqa: E731
+    uni = lambda *s: torch.rand(*s, generator=g).to(DEV)           # noqa: E731
+    rgb, rgb0, target, bgs = uni(R, 3), uni(R, 3), uni(R, 3), uni(R, 3)
+    acc, acc0 = uni(R) * 1.2, uni(R) * 1.2                          # some rays saturate: acc >= 1 switches g_acc off
+    raw_c, raw_empty, raw_sorted = rnd(R, S, 4) * 3, rnd(R, 4), rnd(R, St, 4) * 3
+    bits_c = (torch.rand(R, S, generator=g) < 0.6).to(torch.int32).to(DEV) * 5
+    bits_f = (torch.rand(R, Sf, generator=g) < 0.6).to(torch.int32).to(DEV) * 3
+    z_c = torch.sort(uni(R, S) * 4 + 1, dim=1).values.contiguous()
+    z_sorted = torch.sort(uni(R, St) * 4 + 1, dim=1).values.contiguous()
+    rays_d = rnd(R, 3)
+    noise_c, noise_f = rnd(R, S), rnd(R, St)
+    order = torch.stack([torch.randperm(St, generator=g) for _ in range(R)]).to(torch.int32).to(DEV)
+    weights = (uni(R, St) * (torch.rand(R, St, generator=g) < 0.7).to(DEV)).contiguous()
+    alpha = uni(R, St)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())                    # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def outputs():
+        return dict(g_rgb=torch.zeros(R, 3, device=DEV), g_acc=torch.zeros(R, device=DEV), g_rgb0=torch.zeros(R, 3, device=DEV),
+                    g_acc0=torch.zeros(R, device=DEV), d_raw_c=torch.zeros(R, S, 4, device=DEV), d_raw_f=torch.zeros(R, Sf, 4, device=DEV),
+                    d_raw_rows=torch.zeros(R, 4, device=DEV), label_c=torch.zeros(R, S, dtype=torch.uint8, device=DEV),
+                    label_f=torch.zeros(R, Sf, dtype=torch.uint8, device=DEV), loss=torch.zeros(8, device=DEV), maxabs=torch.zeros(4, device=DEV))
+
+    a, b = outputs(), outputs()
+    d_sorted = torch.zeros(R, St, 4, device=DEV)
+    wf, wc = 1.0, 0.5
+    _hip.check(lib.danbo_train_loss_grad(P(rgb), P(acc), P(rgb0), P(acc0), P(target), P(bgs), use_bg, R, mse, wf, wc, P(a["g_rgb"]), P(a["g_acc"]),
+                                         P(a["g_rgb0"]), P(a["g_acc0"]), P(a["loss"]), st), "loss_grad")
+    _hip.check(lib.danbo_composite_bwd_lazy(P(raw_c), P(raw_empty), P(bits_c), P(z_c), P(rays_d), R, S, B, P(noise_c), P(a["g_rgb0"]),
+                                            P(a["g_acc0"]), P(a["d_raw_c"]), st), "composite_bwd coarse")
+    _hip.check(lib.danbo_composite_bwd_lazy(P(raw_sorted), None, None, P(z_sorted), P(rays_d), R, St, B, P(noise_f), P(a["g_rgb"]), P(a["g_acc"]),
+                                            P(d_sorted), st), "composite_bwd merged")
+    _hip.check(lib.danbo_train_draw_unmerge(P(a["d_raw_c"]), P(d_sorted), P(order), P(bits_c), P(bits_f), P(weights), P(alpha), R, S, Sf,
+                                            P(a["d_raw_f"]), P(a["d_raw_rows"]), P(a["label_c"]), P(a["label_f"]), P(a["loss"]), P(a["maxabs"]), st),
+               "draw_unmerge")
+    _hip.check(lib.danbo_train_mid(P(rgb), P(acc), P(rgb0), P(acc0), P(target), P(bgs), use_bg, R, S, Sf, mse, wf, wc, B, P(b["g_rgb"]), P(b["g_acc"]),
+                                   P(b["g_rgb0"]), P(b["g_acc0"]), P(raw_c), P(raw_empty), P(raw_sorted), P(bits_c), P(bits_f), P(z_c), P(z_sorted),
+                                   P(rays_d), P(noise_c), P(noise_f), P(order), P(weights), P(alpha), P(b["d_raw_c"]), P(b["d_raw_f"]),
+                                   P(b["d_raw_rows"]), P(b["label_c"]), P(b["label_f"]), P(b["loss"]), P(b["maxabs"]), st), "train_mid")
+    torch.cuda.synchronize()
+    for k in a:
+        if k == "loss":
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), (k, a[k], b[k])
+        else:
+            assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
+    assert float(a["d_raw_c"].abs().max()) > 0 and float(a["d_raw_f"].abs().max()) > 0 and int(a["label_c"].sum()) > 0
+    assert float(a["loss"][2]) > 0 and float(a["maxabs"][0]) > 0
+    assert lib.danbo_train_mid(*([None] * 6), 0, R, 200, 100, *([0] * 1), 1.0, 1.0, 1.0, *([None] * 25)) == -22
