@@ -174,7 +174,9 @@ class DanboTrainModel(ctypes.Structure):
 class DanboTrainBatch(ctypes.Structure):
     _fields_ = ([(n, P) for n in ("rays_o", "rays_d", "skts", "bones", "cyls", "near_in", "far_in", "cam_idx", "target", "bgs",
                                   "t_rand", "u_rand", "noise_c", "noise_f")]
-                + [(n, I) for n in ("R", "G", "S", "Sf", "chunk")])
+                + [(n, I) for n in ("R", "G", "S", "Sf", "chunk")]
+                + [(n, P) for n in ("rng_state", "rng_uniform", "rng_normal")]
+                + [("n_uniform", ctypes.c_longlong), ("n_normal", ctypes.c_longlong), ("normal_std", F)])
 
 
 class DanboTrainOut(ctypes.Structure):

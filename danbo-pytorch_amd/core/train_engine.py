@@ -216,9 +216,11 @@ class DanboTrainEngine:
             # ONE launch (danbo_random_draws: Philox4x32-10, its counter on the device, advanced by the kernel -- a replayed graph
             # draws fresh numbers by itself; torch's generators in a captured graph cost two fill launches per replay + a launch
             # per distribution, all in front of the step's first kernel): uniforms [R, S + Sf], normals * std * B [R, 2 S + Sf]
-            from . import hip_ops
-            u, nz = hip_ops.random_draws(self._rng(), R * (S + Sf) if perturb > 0. else 0,
-                                         R * (2 * S + Sf) if raw_noise_std > 0. else 0, raw_noise_std * B)
+            # (ABI 7: launched BY the step, behind the fork of its prologue branches -- DanboTrainBatch.rng_*)
+            n_u, n_n = (R * (S + Sf) if perturb > 0. else 0), (R * (2 * S + Sf) if raw_noise_std > 0. else 0)
+            u = torch.empty(n_u, device=dev, dtype=torch.float32) if n_u else None
+            nz = torch.empty(n_n, device=dev, dtype=torch.float32) if n_n else None
+            rnd['_rng'] = (self._rng(), n_u, n_n, raw_noise_std * B)
             if u is not None:
                 rnd['_u'] = u
                 rnd['t_rand'], rnd['u_rand'] = u[:R * S].view(R, S), u[R * S:].view(R, Sf)
@@ -240,6 +242,10 @@ class DanboTrainEngine:
             near_in=_P(t.get('near_in')), far_in=_P(t.get('far_in')), cam_idx=_P(t.get('cam_idx')), target=_P(t['target']),
             bgs=_P(t.get('bgs')), t_rand=_P(rnd.get('t_rand')), u_rand=_P(rnd.get('u_rand')), noise_c=_P(rnd.get('noise_c')),
             noise_f=_P(rnd.get('noise_f')), R=R, G=G, S=S, Sf=Sf, chunk=chunk)
+        if '_rng' in rnd:
+            state, n_u, n_n, std = rnd['_rng']
+            bt.rng_state, bt.rng_uniform, bt.rng_normal = _P(state), _P(rnd.get('_u')), _P(rnd.get('_n'))
+            bt.n_uniform, bt.n_normal, bt.normal_std = n_u, n_n, float(std)
         o = _hip.DanboTrainOut(**{k: _P(v) for k, v in out.items()})
         out['_keep'] = (rnd, bt, o)
         self._step_phase(out, 1 if split else 0)

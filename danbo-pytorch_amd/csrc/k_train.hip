@@ -356,6 +356,8 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     DANBO_CHECK_ARG(R >= 1 && G >= 1 && R % G == 0 && S >= 3 && Sf >= 1 && S <= 256 && S + Sf <= 256 && bt->chunk >= 1);
     DANBO_CHECK_ARG(bt->rays_o && bt->rays_d && bt->skts && bt->bones && bt->cyls && bt->target);
     DANBO_CHECK_ARG(m->n_codes == 0 || bt->cam_idx);
+    DANBO_CHECK_ARG(bt->rng_state == nullptr || (bt->n_uniform >= 0 && bt->n_normal >= 0 && bt->n_uniform + bt->n_normal > 0 &&
+                                                 (bt->n_uniform == 0 || bt->rng_uniform) && (bt->n_normal == 0 || bt->rng_normal)));
     DANBO_CHECK_ARG(o->rgb_map && o->disp_map && o->acc_map && o->alpha && o->weights && o->rgb0 && o->disp0 && o->acc0 && o->alpha0 && o->loss);
     DANBO_CHECK_ARG(workspace_bytes >= danbo_train_workspace(m, R, G, S, Sf, bt->chunk));
     hipStream_t st = (hipStream_t)stream;
@@ -416,6 +418,9 @@ static int train_step_impl(const DanboTrainModel* m, const DanboTrainBatch* bt, 
     // packing -> pose GNN).  Round 4's timeline (tools/timeline_train.sh): with side 1 enqueued first, side 0's first kernel started
     // only when side 1's last one had ended (129 us into the step) and K2 at 187; in this order all three run side by side and K2
     // starts at 137.
+    // ---- the step's random numbers, behind the fork (ABI 7): nothing in front of the stratified depths needs them
+    if (bt->rng_state != nullptr)
+        DANBO_TRY(danbo_random_draws(bt->rng_state, (long)bt->n_uniform, bt->rng_uniform, (long)bt->n_normal, bt->normal_std, bt->rng_normal, stream));
     // ---- bounds, depths (reference raycasters.py:310-311), coarse cull
     DANBO_TRY(danbo_near_far_cylinder(bt->rays_o, bt->rays_d, bt->cyls, R, G, 0.f, 1.f, bt->near_in, bt->far_in, bt->chunk, b.cyl_scratch,
                                       b.near, b.far, stream));

@@ -35,7 +35,7 @@ extern "C" {
  * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
  * danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_random_draws, danbo_gather_rows; danbo_render_frame takes up to
  * 256 + 64 samples per ray; 6 = DANBO_MLP16_PACKED_BYTES grows by a trailer (power-of-two pack scales of danbo_mlp16_pack);
- * 7 = danbo_train_mid (additive). */
+ * 7 = danbo_train_mid (additive); DanboTrainBatch.rng_* (appended: a caller of an older header must be rebuilt). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -660,6 +660,14 @@ typedef struct DanboTrainBatch {
      * density noise of the two composites [R,S] / [R,S+Sf], already multiplied by raw_noise_std * B (nerf.py:316) */
     const float *t_rand, *u_rand, *noise_c, *noise_f;
     int R, G, S, Sf, chunk;
+    /* ABI 7: rng_state != NULL makes the step draw its own numbers -- danbo_random_draws(rng_state, n_uniform, rng_uniform, n_normal,
+     * normal_std, rng_normal) on the caller's stream BEHIND the fork of its prologue branches (launched by the caller in front of the
+     * step, the 13 us of the generator delayed every branch); t_rand / u_rand / noise_c / noise_f then point into rng_uniform /
+     * rng_normal.  Phase 2 of a split step draws nothing. */
+    uint64_t* rng_state;
+    float *rng_uniform, *rng_normal;
+    long long n_uniform, n_normal;
+    float normal_std;
 } DanboTrainBatch;
 
 typedef struct DanboTrainOut {
