@@ -634,7 +634,7 @@ def test_captured_step_draws_fresh_numbers_every_replay_and_follows_the_seed():
     assert not torch.equal(s3[0][0], s1[0][0])
 
 
-@pytest.mark.parametrize("S,Sf,mse,use_bg", [(48, 16, 0, 1), (32, 16, 1, 0), (96, 48, 0, 1), (200, 56, 1, 1)])
+@pytest.mark.parametrize("S,Sf,mse,use_bg", [(48, 16, 0, 1), (32, 16, 1, 0), (64, 32, 0, 0), (96, 48, 0, 1), (200, 56, 1, 1)])
 def test_fused_mid_step_equals_its_four_launches_bitwise(S, Sf, mse, use_bg):
     """danbo_train_mid (ABI 7: loss gradients + both composite adjoints + un-merge in one launch, what danbo_train_step runs) against
     danbo_train_loss_grad, danbo_composite_bwd_lazy x 2 and danbo_train_draw_unmerge on the same inputs: every tensor bit for bit,
