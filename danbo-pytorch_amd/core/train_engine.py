@@ -129,6 +129,7 @@ class DanboTrainEngine:
         self._rng_state, self._rng_seed = None, None     # danbo_random_draws' device-side state (see _rng)
         self._model_struct = None
         self.graph = None           # (key, CUDAGraph, static inputs, outputs)
+        self.generation = 0         # forward_backward calls so far: a replayed graph's outputs are STATIC buffers, valid until the next call
         self.use_graph = True
         self.fixed_draws = None     # dict(t_rand, u_rand, noise_c, noise_f) replaces the step's random draws (parity tests)
 
@@ -344,6 +345,7 @@ class DanboTrainEngine:
         """One batch: per-pose skts [G,24,4,4] / bones [G,24,3] / cyls [G,5]; per-ray everything else.  Gradients land in
         `flat_grad` (the parameters' .grad views); -> dict(rgb_map, ..., loss [4], counts [8])."""
         graphed = self.use_graph and self.fixed_draws is None    # supplied draws are per-step inputs: never captured into a graph
+        self.generation += 1
         if self.fixed_draws is None and (perturb > 0. or raw_noise_std > 0.):
             self._rng()                                          # (re)seeding copies host -> device: never inside a capture
         t = self._static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx if self.net.use_framecode else None, target, bgs,

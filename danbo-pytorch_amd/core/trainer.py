@@ -104,8 +104,15 @@ class LazyLossDict(LazyDict):
     coarse rgb, sum (label - q)^2, volume scale); a loop that does not look at them (every iteration that does not print)
     launches nothing for them."""
 
-    def __init__(self, ls, ss_coef, with_ss, with_vol):
+    def __init__(self, ls_in, ss_coef, with_ss, with_vol, still_valid=None):
         def fill():
+            # `ls` may be the step's STATIC output (a replayed HIP graph writes the same buffer every step): it is snapshotted
+            # here, at the first look -- a loop that never looks launches nothing -- and a look AFTER the next step fails loudly
+            # instead of returning that step's numbers
+            if still_valid is not None and not still_valid():
+                raise RuntimeError("the loss terms of this training step were not read before the next step overwrote them: "
+                                   "read them (or pass sync_stats=True) before the next train_batch call")
+            ls = ls_in.clone() if still_valid is not None else ls_in
             terms = {'rgb_loss': ls[0], 'rgb_loss0': ls[1]}
             if with_ss:
                 terms['soft_softmax_loss'] = ls[2] * ss_coef
@@ -187,8 +194,11 @@ class Trainer:
         lr, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, self.optimizer, global_step, args.decay_unit)
         caster.update_embed_fns(global_step, args)
         R = out['rgb_map'].shape[0]
-        # a snapshot (one tiny launch): out['loss'] is the HIP graph's static output, overwritten by the next replay
-        loss = LazyLossDict(out['loss'].clone(), args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale))
+        # out['loss'] is the HIP graph's static output, overwritten by the next replay: snapshotted at the first look (an 11 us copy
+        # between every two steps until round 5: 0.8 % of the step for a dictionary the loop reads once in i_print iterations)
+        gen = eng.generation
+        loss = LazyLossDict(out['loss'], args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale),
+                            still_valid=lambda: eng.generation == gen)
         stats = dict(lrate=lr)
         if sync_stats:      # one device-to-host copy; the loop asks for it only when it prints
             bgs = batch.get('bgs', 1.0)

@@ -10,8 +10,9 @@ class LazyDict(dict):
 
     def _fill(self):
         if self._fill_fn is not None:
-            fn, self._fill_fn = self._fill_fn, None
-            dict.update(self, fn())
+            entries = self._fill_fn()          # (a fill that raises stays pending: the next look raises again)
+            self._fill_fn = None
+            dict.update(self, entries)
 
     def __getitem__(self, k):
         self._fill()

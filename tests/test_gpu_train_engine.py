@@ -691,3 +691,28 @@ def test_fused_mid_step_equals_its_four_launches_bitwise(S, Sf, mse, use_bg):
     assert float(a["d_raw_c"].abs().max()) > 0 and float(a["d_raw_f"].abs().max()) > 0 and int(a["label_c"].sum()) > 0
     assert float(a["loss"][2]) > 0 and float(a["maxabs"][0]) > 0
     assert lib.danbo_train_mid(*([None] * 6), 0, R, 200, 100, *([0] * 1), 1.0, 1.0, 1.0, *([None] * 25)) == -22
+
+
+def test_loss_terms_are_snapshotted_at_the_first_look_and_refuse_a_late_one():
+    """Trainer.train_batch(sync_stats=False) returns the loss terms lazily: the replayed graph writes them into ONE static buffer, the
+    dictionary snapshots it when somebody looks (no launch otherwise) -- and a look after the next step raises instead of handing out
+    that step's numbers."""
+    g = golden("danbo_perfcap_train")
+    args, caster, trainer, opt = build_trainer(g)
+    assert trainer.fused_engine() is not None
+    b = batch_of(g)
+    for i in range(3):                                       # graph built, steady state
+        trainer.train_batch(b, i=i, global_step=i)
+    loss_a, _ = trainer.train_batch(b, i=3, global_step=3, sync_stats=False)
+    seen = float(loss_a['total_loss'])                       # first look: snapshot
+    loss_b, _ = trainer.train_batch(b, i=4, global_step=4, sync_stats=False)
+    assert float(loss_a['total_loss']) == seen               # the snapshot, not step 4's value
+    assert float(loss_b['total_loss']) != seen
+    loss_c, _ = trainer.train_batch(b, i=5, global_step=5, sync_stats=False)
+    trainer.train_batch(b, i=6, global_step=6, sync_stats=False)
+    with pytest.raises(RuntimeError, match="before the next step"):
+        loss_c['total_loss']
+    with pytest.raises(RuntimeError, match="before the next step"):     # still pending, still refusing
+        len(loss_c)
+    _, stats = trainer.train_batch(b, i=7, global_step=7, sync_stats=True)
+    assert np.isfinite(stats['total_loss']) and np.isfinite(stats['psnr'])
