@@ -193,6 +193,10 @@ __device__ __forceinline__ int resolve_count(const int32_t* count, int n_cap) {
 // What the compiler makes of the plain C++ form is ~7 per pair (cvt, cvt back, sub -- partly as v_pk_add_f32, an anti-lever beside
 // MFMAs -- and a second cvt_pk): 43 VALU instructions per k-step epilogue of K3, 28 with this.  Bit-identical on 33.5 M random pairs of
 // every exponent incl. the fp16 subnormal and overflow ranges (tools/probe/split_probe.hip).
+// HAZARD: these are inline-asm statements, which the compiler's hazard recognizer does not see as VALU writes -- an MFMA *builtin*
+// that reads hi / lo within a couple of instructions of the split gets stale registers (K2, round 5: h wrong by 1e-2 when its
+// layer-0 MFMAs moved right behind the split).  A consumer that close writes the wait states out (k_assign16.hip a16_split8;
+// the asm MFMA chunks of mlp16_core.hpp start with `s_nop 1` for the same reason).
 template <class H8>
 __device__ __forceinline__ void split8_mix(const float* v, H8& hi, H8& lo) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -170,7 +170,13 @@ __device__ __forceinline__ void a16_bone_features(const float* __restrict__ skt,
     a16_bone_gather(vol, x, win, out);
 }
 
-__device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo) { split8_mix(&v[0], hi, lo); }   // three instructions per pair: common.hpp
+// three instructions per pair: common.hpp.  They are inline asm, which the compiler's hazard recognizer does not see as VALU writes:
+// where an MFMA reads the fragments right behind the split (layer 0 since round 5) the wait states are written out, tied to the
+// two registers so that the statement stays between the split and the MFMAs.
+__device__ __forceinline__ void a16_split8(const float* v, half8& hi, half8& lo) {
+    split8_mix(&v[0], hi, lo);
+    asm volatile("s_nop 1" : "+v"(hi), "+v"(lo));
+}
 
 // Round 4 structure.  A wavefront = 32 rows (lane = row + 32 * half) and loops, at RUN time, over the bones valid for at least
 // one of them (grouped rows: 1.7 on the bench frame).  Per bone j: the features of j and its tree neighbours are gathered for
@@ -302,8 +308,6 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
     }
 
     // the weight fragments of the bone this wavefront evaluated last: layer 0 (<= 5 neighbour terms x hi, lo), layer 1 (2 k-steps x hi, lo)
-    half8 w0[10], w1[4];
-    int w_bone = -1;
 
     int tr = 0, it = 0;
     auto stamp = [&](int tag) {    // workgroup 7, wavefront 1, its tiles 2 .. 5: (tag, s_memtime) pairs
@@ -378,25 +382,26 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
             todo &= todo - 1u;
             const int nq = __builtin_amdgcn_readfirstlane(s_nbi[j * A16_NBI + 5]);
             stamp(100 + j);
-            // ---- the bone's weight fragments (L2-resident stream, 1 KB per piece = 16 B per lane) ----
-            if (j != w_bone) {
-                const char* src = a.packed + (size_t)__builtin_amdgcn_readfirstlane(s_nbi[j * A16_NBI + 6]) * 1024 + lane * 16;
+            // ---- the bone's weight fragments (L2-resident stream, 1 KB per piece = 16 B per lane), requested where their latency has
+            //      cover and held no longer than needed (round 5: ten layer-0 fragments resident per bone + all six neighbours' B
+            //      fragments kept for one block of MFMAs were 88 of the kernel's 216 registers): layer 1's four here, used behind the
+            //      whole feature phase; layer 0's four per neighbour PAIR behind that pair's window test, used behind its gather
+            const char* src = a.packed + (size_t)__builtin_amdgcn_readfirstlane(s_nbi[j * A16_NBI + 6]) * 1024 + lane * 16;
+            half8 w1[4];
 #pragma unroll
-                for (int q = 0; q < 5; ++q)
-                    if (q < nq) {
-                        w0[2 * q] = *reinterpret_cast<const half8*>(src + (2 * q) * 1024);
-                        w0[2 * q + 1] = *reinterpret_cast<const half8*>(src + (2 * q + 1) * 1024);
-                    }
+            for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const half8*>(src + (2 * nq + i) * 1024);
+            // ---- layer 0 with the adjacency folded in; accumulator starts at the shared bias, every pair adds its terms as soon as
+            //      its features exist (the same order q = 0, 1, 2, ... as one block behind the loop: the same bits) ----
+            f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const half8*>(src + (2 * nq + i) * 1024);
-                w_bone = j;
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 b = *reinterpret_cast<const float4*>(s_b0 + 8 * jj + 4 * hh);
+                acc[4 * jj] = b.x; acc[4 * jj + 1] = b.y; acc[4 * jj + 2] = b.z; acc[4 * jj + 3] = b.w;
             }
             // ---- features of the bone and its tree neighbours ----
             // lane half h evaluates neighbour 2t + h completely (transform, window, 15-feature gather -- the same
             // gather_bone_features() as K1b), then the halves trade 8 values so that lane (m, h) ends up with features
             // 8h .. 8h+7 of BOTH bones: the B-fragment layout.
-            half8 fh[6], fl[6];
-            bool pair_off[3] = {false, false, false};
             float fself[8];         // this lane's 8 features of the bone ITSELF in fp32: the blend h = sum_j p_j f_j uses these, not the
                                     // 22-bit hi + lo reconstruction (2.4e-7 of f, which sin(32 h) turns into 8e-6 of the MLP's inputs)
 #pragma unroll
@@ -419,10 +424,11 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
                     const bool used = row_ok && (a.confd != nullptr || ((bits >> j) & 1u) != 0u);
                     needed = used && !(mul_rn(win, s_vmax[jb]) < 0x1p-26f);
                 }
-                if (t >= 1 && !a.no_skip && !__any(needed)) {         // wave-uniform
-                    pair_off[t] = true;
-                    continue;
-                }
+                if (t >= 1 && !a.no_skip && !__any(needed)) continue;         // wave-uniform
+                half8 wq[4];        // w0 of neighbours 2t and 2t + 1 (hi | lo each)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * t + i < 2 * nq) wq[i] = *reinterpret_cast<const half8*>(src + (4 * t + i) * 1024);
                 if (lds_route) {
                     a16_bone_gather(s_vol + jb * VOL, x, win, f);
                 } else {  // through L1 / L2
@@ -446,28 +452,23 @@ __global__ __launch_bounds__(256, 2) void k_assign16(A16Args a) {
                     even[e] = hh ? recv[e] : keep[e];
                     odd[e] = hh ? keep[e] : recv[e];
                 }
-                a16_split8(even, fh[2 * t], fl[2 * t]);
-                a16_split8(odd, fh[2 * t + 1], fl[2 * t + 1]);
                 if (t == 0) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) fself[e] = even[e];
                 }
+                half8 fh, fl;
+                a16_split8(even, fh, fl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0], fh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0], fl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[1], fh, acc, 0, 0, 0);
+                if (2 * t + 1 < nq) {                                   // wave-uniform
+                    a16_split8(odd, fh, fl);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[2], fh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[2], fl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[3], fh, acc, 0, 0, 0);
+                }
             }
             stamp(200 + j);
-            // ---- layer 0 with the adjacency folded in; accumulator starts at the shared bias ----
-            f32x16 acc;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float4 b = *reinterpret_cast<const float4*>(s_b0 + 8 * jj + 4 * hh);
-                acc[4 * jj] = b.x; acc[4 * jj + 1] = b.y; acc[4 * jj + 2] = b.z; acc[4 * jj + 3] = b.w;
-            }
-#pragma unroll
-            for (int q = 0; q < 5; ++q)
-                if (q < nq && !pair_off[q >> 1]) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q], fh[q], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q], fl[q], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[2 * q + 1], fh[q], acc, 0, 0, 0);
-                }
             // ---- relu -> layer-1 B fragments ----
             float v[16];
 #pragma unroll
