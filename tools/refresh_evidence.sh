@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: refresh_evidence.sh TAG : everything profiles/ holds for a round, measured from the current tree in one go --
-# PMC HBM traffic (training step, K3), the GPU test-suite's measured parity values, the bench line of every config,
+# PMC HBM traffic (training step, K3, A-NeRF frame), the GPU test-suite's measured parity values, the bench line of every config,
 # rocprofv3 kernel stats of the render frame and of the training step.  Outputs under gpurun_out/evidence_TAG/.
 TAG=$1
 R=$GRAFT_REPO_ROOT
@@ -9,6 +9,7 @@ mkdir -p $E
 cd $R
 bash tools/pmc_train.sh $TAG > $E/pmc_train.log 2>&1 && cp gpurun_out/pmc_train_$TAG.json profiles/${TAG}_pmc_train.json && cp gpurun_out/pmc_train_$TAG.json $E/${TAG}_pmc_train.json
 bash tools/pmc_hbm.sh $TAG > $E/pmc_hbm.log 2>&1 && cp gpurun_out/pmc_hbm_$TAG.json profiles/${TAG}_pmc_hbm.json && cp gpurun_out/pmc_hbm_$TAG.json $E/${TAG}_pmc_hbm.json
+bash tools/pmc_anerf.sh $TAG > $E/pmc_anerf.log 2>&1 && cp gpurun_out/pmc_anerf_$TAG.json profiles/${TAG}_pmc_anerf.json && cp gpurun_out/pmc_anerf_$TAG.json $E/${TAG}_pmc_anerf.json
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "raw_err|vs oracle|deviation|worst|passed|failed" > $E/${TAG}_parity_measured.txt
 for c in 1 2 3 4 5; do
   python bench.py --config $c > $E/bench$c.log 2>&1
