@@ -6,6 +6,9 @@ PSNR is the reference's formula.  SSIM: the reference imports a pinned fork of a
 per-pixel SSIM *map* -- the package is not in this image, so `ssim_map` restates the published algorithm (Wang et al. 2004 as
 implemented by pytorch-msssim: 11-tap Gaussian window, sigma 1.5, K1 = 0.01, K2 = 0.03, separable filtering) with zero padding
 so the map has the image's size.  **SSIM parity is unpinned** (no reference output to compare with); PSNR needs no third-party code.
+What the reference's call sites fix about the fork (4-D image-sized map, default window, unit data range) and what they leave open
+(the padding mode: only the 5-pixel border of the map depends on it) is written out in oracle/gen_ssim_golden.py, whose
+known-answer vector pins this function's arithmetic (tests/test_host_logic.py).
 """
 import numpy as np
 import torch

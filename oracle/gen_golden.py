@@ -204,9 +204,10 @@ def gen_danbo_perfcap():
     print("danbo_perfcap: acc mean", fin["acc_map"].mean())
 
 
-def gen_danbo_train():
+def gen_danbo_train(stochastic=False):
     """one deterministic training forward/backward (perturb = 0, raw_noise_std = 0) of the reference:
-    loss terms of Trainer.compute_loss and gradients of a representative parameter subset"""
+    loss terms of Trainer.compute_loss and gradients of a representative parameter subset (stochastic=True would record the
+    reference's draws as gen_danbo_perfcap_train does; no committed fixture uses it)"""
     seed = 14
     cfg, args, caster, kw_test, rest = build("danbo_base", seed)
     import types
@@ -684,44 +685,49 @@ def gen_confd_colours():
                         confidence_rgb=get_confidence_rgb(T(confd), None).numpy(), entropy_rgb=get_entropy_rgb(T(confd), None).numpy())
 
 
-if __name__ == "__main__":
+# target name -> generator, in the default order (`python oracle/gen_golden.py` runs every one; tests/test_golden_recipe.py does the
+# same into a scratch directory and compares the files with the committed ones)
+TARGETS = {
+    "stages": lambda: gen_danbo_stages(),
+    "surreal": lambda: gen_danbo_surreal(),
+    "perfcap": lambda: gen_danbo_perfcap(),
+    "rot6d": lambda: gen_pose_rot6d(),
+    "train": lambda: gen_danbo_train(),
+    "anerf": lambda: gen_anerf_stages(),
+    "anerf_train": lambda: gen_anerf_train(),
+    "perfcap_train": lambda: gen_danbo_perfcap_train(),
+    "confd_colours": lambda: gen_confd_colours(),
+    "perfcap_train_noise": lambda: gen_danbo_perfcap_train(stochastic=True),
+    "mesh": lambda: gen_danbo_mesh(),
+    "h36m_fast": lambda: gen_danbo_h36m_fast(),
+    "ckpt": lambda: gen_ckpt_manifest(),
+    "args": lambda: gen_args_txt(),
+    "valid_rays": lambda: gen_valid_rays(),
+    "sequences": lambda: gen_sequences(),
+    "render_path": lambda: gen_render_path(),
+}
+
+
+def main(argv):
+    """python oracle/gen_golden.py [--out DIR] [target ...]   (no target: all of TARGETS)"""
+    global OUT
+    argv = list(argv)
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
     assert rh.reference_available(), "needs /root/reference (build container only)"
+    unknown = [t for t in argv if t not in TARGETS]
+    if unknown:
+        raise SystemExit(f"unknown target(s) {unknown}; known: {list(TARGETS)}")
     os.makedirs(OUT, exist_ok=True)
-    torch.manual_seed(0)
-    which = sys.argv[1:] or ["stages", "surreal", "perfcap", "rot6d", "train", "perfcap_train", "perfcap_train_noise", "confd_colours", "mesh", "h36m_fast", "anerf", "anerf_train", "ckpt", "args", "valid_rays", "sequences", "render_path"]
-    if "stages" in which:
-        gen_danbo_stages()
-    if "surreal" in which:
-        gen_danbo_surreal()
-    if "perfcap" in which:
-        gen_danbo_perfcap()
-    if "rot6d" in which:
-        gen_pose_rot6d()
-    if "train" in which:
-        gen_danbo_train()
-    if "anerf" in which:
-        gen_anerf_stages()
-    if "anerf_train" in which:
-        gen_anerf_train()
-    if "perfcap_train" in which:
-        gen_danbo_perfcap_train()
-    if "confd_colours" in which:
-        gen_confd_colours()
-    if "perfcap_train_noise" in which:
-        gen_danbo_perfcap_train(stochastic=True)
-    if "mesh" in which:
-        gen_danbo_mesh()
-    if "h36m_fast" in which:
-        gen_danbo_h36m_fast()
-    if "ckpt" in which:
-        gen_ckpt_manifest()
-    if "args" in which:
-        gen_args_txt()
-    if "valid_rays" in which:
-        gen_valid_rays()
-    if "sequences" in which:
-        gen_sequences()
-    if "render_path" in which:
-        gen_render_path()
+    for name, fn in TARGETS.items():
+        if not argv or name in argv:
+            torch.manual_seed(0)
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -8,8 +8,21 @@ sigma 1.5, K1 = 0.01, K2 = 0.03, local moments by separable filtering): this scr
 float64, scipy.ndimage.correlate1d, no torch -- on seeded images, and commits inputs + outputs:
   * `map_same`: the per-pixel map with zero padding (the image-sized map the reference multiplies with its H x W masks);
   * `map_valid`: the un-padded ("valid") map of upstream pytorch-msssim, = the interior of `map_same`.
-The fork's padding mode and data_range default remain unverified: SSIM parity against the reference stays "unpinned" in that sense
-(DESIGN.md section 9); the arithmetic of the published algorithm is pinned by this vector."""
+What the reference's CALL SITES (core/utils/evaluation_helpers.py:307-353, run_render.py:1178-1263) fix about the fork, and what this
+vector therefore assumes:
+  * constructor `SSIM(size_average=False)` and nothing else: every other argument is the fork's default.  Upstream's defaults at the
+    fork point are win_size = 11, win_sigma = 1.5, K = (0.01, 0.03), channel = 3 -- assumed unchanged;
+  * the result is used as `th_ssim.permute(0, 2, 3, 1)` and multiplied with [N, H, W, 1] masks (:321, :331, :342): it is a 4-D
+    per-pixel, per-channel map OF THE IMAGE'S SIZE.  Upstream returns a per-image scalar from an un-padded ("valid") filter, so
+    the fork both skips the spatial mean and pads; WHICH padding (zeros / reflect / replicate) the call sites cannot tell.
+    `map_same` assumes zeros (F.conv2d's `padding=`), and `map_valid` -- the interior, 5 pixels from every border -- does not
+    depend on that choice;
+  * the images handed over are float RGB in [0, 1] (:308-315).  Upstream's `data_range` default is 255; with it C1, C2 would be
+    6.5 / 58.5 on unit-range images and every score ~1, which the scores the reference's README / paper report (0.8 - 0.9 range)
+    rule out: `data_range = 1.0` assumed.
+The fork's padding mode and data_range default therefore remain unverified (the repository at the pinned commit is not reachable
+from here): SSIM parity against the reference stays "unpinned" in that sense; the arithmetic of the
+published algorithm, and the interior of the map whatever the padding, is pinned by this vector."""
 import os
 
 import numpy as np
