@@ -113,6 +113,7 @@ def best_of(fn, reps=3):
 
 
 PARITY_BOUND = 1e-4         # north_star: RGB / sigma logits within 1e-4 relative of the reference
+MAPS_BOUND = 5e-5           # final rgb / acc maps of the TIMED frame against the oracle's (measured 1e-6 .. 1e-5: resampled depths amplify round-off)
 BOUNDS_BOUND = 2e-6         # near / far against the oracle (the box bounds are bit-equal to the reference's; the cylinder's nan-mean
                             # back-fill is a sum in another order)
 
@@ -194,6 +195,20 @@ def parity_block(model, extra, sl, ref, frame, stages, eng_inp=None):
             own = parity["own_depths"]
             ok = ok and own["mask_mismatches"] == 0 and own["max_rel_raw_floored_5pct"] <= PARITY_BOUND \
                 and own["max_rel_raw_floored_5pct_vs_float64"] <= PARITY_BOUND
+    # ... and the TIMED frame itself (`decided` may be the re-run at the oracle's bounds): its logits on the rays whose bounds
+    # are bit-equal to the oracle's -- there the own-depths comparison is the same statement -- and its final maps on every ray
+    timed_ok = parity["max_abs_rgb"] <= MAPS_BOUND and parity["max_abs_acc"] <= MAPS_BOUND
+    if "near" in stages:
+        if same.any():
+            own_raw = sides["own_depths"][0]
+            t32, _ = raw_measures(own_raw[same], rr[same])
+            t64, _ = raw_measures(own_raw[same], r64[same])
+            parity["timed_frame_bit_equal_bound_rays"] = dict(rays=int(same.sum()), max_rel_raw_floored_5pct=t32, max_rel_raw_floored_5pct_vs_float64=t64,
+                                                              mask_mismatches=int((valid[same] != ref["valid_coarse"][same]).sum()))
+            timed_ok = timed_ok and t32 <= PARITY_BOUND and t64 <= PARITY_BOUND and parity["timed_frame_bit_equal_bound_rays"]["mask_mismatches"] == 0
+        timed_ok = timed_ok and int(same.sum()) >= n // 2      # a frame most of whose bounds differ is not the oracle's frame
+    parity.update(parity_ok_timed_frame=bool(timed_ok), maps_bound=MAPS_BOUND)
+    ok = ok and timed_ok
     parity.update(mask_entries=int(valid.size), restatement_fp32_vs_float64_floored_5pct=raw_measures(rr, r64)[0],
                   # top-level copies of the deciding comparison (the names earlier rounds' lines carry)
                   mask_mismatches=decided["mask_mismatches"], max_rel_raw=decided["max_rel_raw"],

@@ -6,8 +6,6 @@ layer fed from two buffers without a concatenated copy) -> k_anerf_color (HIP). 
 compositing and importance resampling are the kernels the DANBO path uses.  A-NeRF has no in-volume mask:
 every sample is evaluated, exactly as in the reference (core/networks/nerf.py:107-122).
 """
-import os
-
 import torch
 
 from . import hip_ops as ops
@@ -39,7 +37,7 @@ class AnerfEngine:
         self.frag = W % 32 == 0 and VW + 1 <= 256
         # the density inputs recomputed inside the first and the skip layer from the encoder's compact table (576 instead of
         # 1 728 B per sample, written once and read twice): the kernel instantiation exists for the shipped width
-        self.fused_enc = os.environ.get("DANBO_ANERF_FUSED_ENC", "1") != "0" and self.frag and W == 448 and 1 <= self.L <= 7 and tuple(cfg["skips"]) == (4,) and self.in_ch == 24 * (1 + 2 * self.L) + 72
+        self.fused_enc = self.frag and W == 448 and 1 <= self.L <= 7 and tuple(cfg["skips"]) == (4,) and self.in_ch == 24 * (1 + 2 * self.L) + 72
         self.layers = [ops.linear16_pack_enc(p[f"pts_linears.{i}.weight"], self.L) if self.fused_enc and (i == 0 or i in self.skip_into)
                        else ops.linear16_pack(p[f"pts_linears.{i}.weight"], K1=self.in_ch if i in self.skip_into else None,
                                               frag_in=(self.frag and i > 0 and i not in self.skip_into, self.frag and i in self.skip_into))

@@ -139,6 +139,7 @@ class RayCaster(nn.Module):
     # ---- HIP-graph replay of the eval chain for small chunks (see render_rays) ----
     use_graphs = True
     graph_max_rays = 8192
+    whole_cast_max_samples = 1 << 26      # ray-samples per cast of render_rays_whole (512 x 512 x 64 is 1 << 24)
 
     @property
     def _graphs(self):
@@ -267,15 +268,30 @@ class RayCaster(nn.Module):
             return None
         eng.cfg['density_scale'] = preproc_kwargs.get('density_scale', eng.cfg['density_scale'])
         skts_g, bones_g, cyls_g = skts[:1].contiguous(), bones[:1].contiguous(), cyls[:1].contiguous()
-        if rays is not None:           # trainer.render hands the rays over as they are (scalar placeholder bounds near_far0)
-            rays_o, rays_d = rays[0].contiguous(), rays[1].contiguous()
-            near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, near_far0[0], near_far0[1], int(chunk))
-        else:
-            rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
-            near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., int(chunk), ray_batch[:, 6], ray_batch[:, 7])
-        if eng.cfg['use_volume_near_far']:
-            ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
-        return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, cams, N_samples, N_importance, near_far=(near, far))
+        chunk = int(chunk)
+        R = rays[0].shape[0] if rays is not None else ray_batch.shape[0]
+        # `chunk` bounds the reference's memory; here it only sets the nan-mean group, so the cast itself is bounded: super-chunks
+        # of whole `chunk`s with at most `whole_cast_max_samples` ray-samples each (the engine keeps ~100 B per ray-sample alive:
+        # 6.4 GB at the default) -- bit-identical to one cast, every stage being per ray, per sample or per `chunk`
+        sub = max(chunk, self.whole_cast_max_samples // (int(N_samples) + int(N_importance)) // chunk * chunk)
+
+        def cast(a, b):
+            if rays is not None:       # trainer.render hands the rays over as they are (scalar placeholder bounds near_far0)
+                rays_o, rays_d = rays[0][a:b].contiguous(), rays[1][a:b].contiguous()
+                near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, near_far0[0], near_far0[1], chunk)
+            else:
+                rb = ray_batch[a:b]
+                rays_o, rays_d = rb[:, 0:3].contiguous(), rb[:, 3:6].contiguous()
+                near, far = ops.near_far_cylinder(rays_o, rays_d, cyls_g, 0., 1., chunk, rb[:, 6], rb[:, 7])
+            if eng.cfg['use_volume_near_far']:
+                ops.near_far_boxes(rays_o, rays_d, skts_g, eng.align, eng.axis_scale, near, far)
+            return eng.render(rays_o, rays_d, skts_g, bones_g, cyls_g, None if cams is None else cams[a:b], N_samples, N_importance,
+                              near_far=(near, far))
+
+        if R <= sub:
+            return cast(0, R)
+        parts = [cast(a, min(a + sub, R)) for a in range(0, R, sub)]
+        return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
 
     def render_rays_train(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
                           subject_idxs=None, lindisp=False, perturb=0., N_importance=0, raw_noise_std=0.,

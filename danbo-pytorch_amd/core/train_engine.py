@@ -129,6 +129,7 @@ class DanboTrainEngine:
         self._rng_state, self._rng_seed = None, None     # danbo_random_draws' device-side state (see _rng)
         self._model_struct = None
         self.graph = None           # (key, CUDAGraph, static inputs, outputs)
+        self.outputs_static = False
         self.generation = 0         # forward_backward calls so far: a replayed graph's outputs are STATIC buffers, valid until the next call
         self.use_graph = True
         self.fixed_draws = None     # dict(t_rand, u_rand, noise_c, noise_f) replaces the step's random draws (parity tests)
@@ -259,16 +260,21 @@ class DanboTrainEngine:
                                                      self._ws.numel(), int(phase),
                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_train_step")
 
+    def _own_seed(self):
+        """the seed of THIS rank's stream: torch's CUDA generator seed of the device, mixed with the RANK: ranks that were
+        seeded alike -- a caller without a per-rank torch.manual_seed -- would otherwise draw the same stratified offsets and
+        density noise for their different rays"""
+        seed = int(torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()].initial_seed())
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() > 0:
+            seed = (seed ^ (0x9E3779B97F4A7C15 * dist.get_rank())) & ((1 << 64) - 1)
+        return seed
+
     def _rng(self):
         """the device-side generator state of danbo_random_draws (seed, counter, 0).  Seeded from torch's CUDA generator of this
         device the first time it is needed -- torch.manual_seed / torch.cuda.manual_seed before that (run_nerf.py: rank + 1) give
         every rank its own stream -- and again whenever that seed has CHANGED since; reseed() restarts it explicitly."""
-        seed = int(torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()].initial_seed())
-        # ... mixed with the RANK (ADVICE r4): ranks that were seeded alike -- a caller without a per-rank torch.manual_seed -- would
-        # otherwise draw the same stratified offsets and density noise for their different rays
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_rank() > 0:
-            seed = (seed ^ (0x9E3779B97F4A7C15 * dist.get_rank())) & ((1 << 64) - 1)
+        seed = self._own_seed()
         if self._rng_state is None:
             self._rng_state = torch.zeros(3, device=self.device, dtype=torch.int64)
             self._rng_seed = None
@@ -310,9 +316,15 @@ class DanboTrainEngine:
         return dict(seed=int(self._rng_seed), counter=int(st[1]))
 
     def load_rng_state_dict(self, d):
+        """continue the checkpointed stream.  The checkpoint holds RANK 0's (seed, counter); every rank draws the same number of
+        values per step, so the counter is common to all of them, while the seed is each rank's own: rank 0 takes the saved one,
+        rank r > 0 its rank-mixed seed of this run (with only rank 0 restored, the other ranks replayed the draws of
+        step 0 after a resume)"""
         if not d:
             return
-        self.reseed(int(d["seed"]))
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.reseed(int(d["seed"]) if rank == 0 else self._own_seed())
         self._rng_state[1] = int(d["counter"])
         # the torch generator's seed of THIS process is whatever the resuming script set: keep the restored stream until it changes
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -346,6 +358,7 @@ class DanboTrainEngine:
         `flat_grad` (the parameters' .grad views); -> dict(rgb_map, ..., loss [4], counts [8])."""
         graphed = self.use_graph and self.fixed_draws is None    # supplied draws are per-step inputs: never captured into a graph
         self.generation += 1
+        self.outputs_static = graphed        # a replayed graph writes the SAME output buffers every step; an eager step fresh ones
         if self.fixed_draws is None and (perturb > 0. or raw_noise_std > 0.):
             self._rng()                                          # (re)seeding copies host -> device: never inside a capture
         t = self._static_inputs(rays_o, rays_d, skts, bones, cyls, cam_idx if self.net.use_framecode else None, target, bgs,

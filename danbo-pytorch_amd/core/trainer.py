@@ -195,10 +195,11 @@ class Trainer:
         caster.update_embed_fns(global_step, args)
         R = out['rgb_map'].shape[0]
         # out['loss'] is the HIP graph's static output, overwritten by the next replay: snapshotted at the first look (an 11 us copy
-        # between every two steps until round 5: 0.8 % of the step for a dictionary the loop reads once in i_print iterations)
+        # between every two steps until round 5: 0.8 % of the step for a dictionary the loop reads once in i_print iterations).  An
+        # EAGER step (fixed_draws, use_graph off) returns fresh tensors: its terms stay readable for good, like the reference's
         gen = eng.generation
         loss = LazyLossDict(out['loss'], args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale),
-                            still_valid=lambda: eng.generation == gen)
+                            still_valid=(lambda: eng.generation == gen) if eng.outputs_static else None)
         stats = dict(lrate=lr)
         if sync_stats:      # one device-to-host copy; the loop asks for it only when it prints
             bgs = batch.get('bgs', 1.0)

@@ -153,8 +153,8 @@ def train(argv=None):
     sync_replicas(kw_train['ray_caster'])
     torch.manual_seed(rank + 1)
     trainer = Trainer(args, data_attrs, optimizer, None, kw_train, kw_test, None, device=device)
-    if isinstance(loaded, dict) and rank == 0:      # a resumed run continues the fused step's random stream (rank 0 wrote it)
-        trainer.resume_rng_state = loaded.get('danbo_rng_state')
+    if isinstance(loaded, dict):     # a resumed run continues the fused step's random stream: rank 0 wrote its (seed, counter); the
+        trainer.resume_rng_state = loaded.get('danbo_rng_state')     # counter is every rank's, the seed each rank's own (load_rng_state_dict)
     global_step = start
     log = open(os.path.join(logdir, 'scalars.jsonl'), 'a') if rank == 0 else None
     t0 = time.time()

@@ -685,6 +685,41 @@ def gen_confd_colours():
                         confidence_rgb=get_confidence_rgb(T(confd), None).numpy(), entropy_rgb=get_entropy_rgb(T(confd), None).numpy())
 
 
+def torch_norm_probe(n=200000, seed=3):
+    """does torch.norm(x, dim=-1) of THIS torch build on THIS CPU equal the fma chain the oracle and the kernels restate
+    (danbo_oracle.torch_norm, csrc/sample_math.hpp norm3_torch)?  ATen's contraction is compiler / ISA dependent:
+    -> (rows equal, rows, max ulp distance)"""
+    import danbo_oracle as o
+    rng = np.random.default_rng(seed)
+    x = (rng.normal(size=(n, 3)) * np.exp(rng.uniform(-6, 6, size=(n, 1)))).astype(np.float32)
+    a = torch.norm(torch.tensor(x), dim=-1).numpy()
+    b = o.torch_norm(x)
+    ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    return int((ulp == 0).sum()), n, int(ulp.max())
+
+
+def gen_provenance():
+    """what the fixtures were generated WITH: the near / far goldens are bit-exact statements about torch.norm's fma contraction
+    on the generating host"""
+    import platform
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    eq, n, ulp = torch_norm_probe()
+    doc = dict(torch=torch.__version__, numpy=np.__version__, python=platform.python_version(), machine=platform.machine(), cpu=cpu,
+               torch_norm_equals_fma_chain=dict(rows_equal=eq, rows=n, max_ulp=ulp),
+               note="tests/golden/*.npz were written by oracle/gen_golden.py importing /root/reference with this torch build on this "
+                    "CPU; where torch.norm is not the fma chain (another build / ISA) regenerated near / far bounds may differ from "
+                    "these by <= 1 ulp, which this network amplifies (DESIGN.md section 4)")
+    import json
+    with open(os.path.join(OUT, "PROVENANCE.json"), "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    print("provenance:", doc["torch"], doc["cpu"], doc["torch_norm_equals_fma_chain"])
+
+
 # target name -> generator, in the default order (`python oracle/gen_golden.py` runs every one; tests/test_golden_recipe.py does the
 # same into a scratch directory and compares the files with the committed ones)
 TARGETS = {
@@ -705,6 +740,7 @@ TARGETS = {
     "valid_rays": lambda: gen_valid_rays(),
     "sequences": lambda: gen_sequences(),
     "render_path": lambda: gen_render_path(),
+    "provenance": lambda: gen_provenance(),
 }
 
 

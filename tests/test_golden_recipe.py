@@ -41,7 +41,34 @@ def test_every_golden_target_regenerates_the_committed_fixture_bitwise(tmp_path)
             _same_npz(os.path.join(out, f), os.path.join(GOLDEN, f))
         else:
             with open(os.path.join(out, f)) as fa, open(os.path.join(GOLDEN, f)) as fb:
-                assert json.load(fa) == json.load(fb), f
+                a, b = json.load(fa), json.load(fb)
+            if f == "PROVENANCE.json":      # a statement about the generating host: the build the fixtures were made with is this one
+                assert a["torch"] == b["torch"] and a["torch_norm_equals_fma_chain"] == b["torch_norm_equals_fma_chain"], (a, b)
+            else:
+                assert a == b, f
+
+
+def test_torch_norm_of_this_build_is_the_fma_chain_the_bounds_restate():
+    """near / far are asserted BIT-equal between kernel bodies, oracle and the reference's tensors; that rests on torch.norm's
+    reduction step being one fma on the host that generated the goldens (compiler / ISA dependent).  The committed
+    PROVENANCE.json records it for the generating host; on any other host this probe says whether REGENERATED goldens could differ
+    (by <= 1 ulp) -- the committed fixtures themselves are data and do not depend on it."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    with open(os.path.join(GOLDEN, "PROVENANCE.json")) as f:
+        prov = json.load(f)
+    assert prov["torch_norm_equals_fma_chain"]["rows_equal"] == prov["torch_norm_equals_fma_chain"]["rows"]
+    import danbo_oracle as o
+    import torch
+    rng = np.random.default_rng(3)
+    x = (rng.normal(size=(50000, 3)) * np.exp(rng.uniform(-6, 6, size=(50000, 1)))).astype(np.float32)
+    a = torch.norm(torch.tensor(x), dim=-1).numpy()
+    b = o.torch_norm(x)
+    ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, "torch.norm is further than one ulp from the restated chain"
+    if ulp.max() != 0:
+        pytest.xfail(f"torch.norm of this build ({torch.__version__}) is not the fma chain on {int((ulp != 0).sum())} of 50000 rows: goldens "
+                     "regenerated HERE would move near / far by <= 1 ulp against the committed ones")
 
 
 def test_ssim_known_answer_regenerates_bitwise(tmp_path):

@@ -59,6 +59,6 @@ def test_oracle_on_the_bench_frame(config):
         assert q["max_rel_raw_floored_5pct"] <= 1e-4, (side, q)
         assert q["max_rel_raw_floored_5pct_vs_float64"] <= 1e-4, (side, q)
         assert q["max_rel_raw"] <= 1e-4 and q["max_rel_raw_vs_float64"] <= 1e-4, (side, q)
-    assert p["parity_ok"] is True
+    assert p["parity_ok"] is True and p["parity_ok_timed_frame"] is True
     # the maps of the timed frame against the oracle's, after importance resampling
     assert p["max_abs_rgb"] < 1e-4 and p["max_abs_acc"] < 1e-4 and p["psnr_rgb_db"] > 90.0

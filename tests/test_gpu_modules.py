@@ -240,6 +240,14 @@ def test_render_of_a_whole_image_equals_the_chunk_loop_bitwise(cfg_file, fixture
         assert calls and set(whole) == set(loop)
         for k in loop:
             assert whole[k].shape == loop[k].shape and torch.equal(whole[k], loop[k]), (chunk, k)
+        # the cast is bounded: with a budget of two chunks' worth of ray-samples the image goes through as super-chunks
+        # of whole chunks -- the same bits
+        caster.whole_cast_max_samples = 2 * chunk * 36
+        try:
+            capped = trainer.render(64, 64, 80., chunk=chunk, rays=(ro, rd), **kwargs)
+        finally:
+            del caster.whole_cast_max_samples
+        assert all(torch.equal(capped[k], loop[k]) for k in loop), chunk
     # per-ray pose tensors that are not ONE expanded row (several poses may hide behind them): the caster declines, the loop runs
     kwargs["skts"] = T(np.repeat(scene["skts"], n, 0))
     rb = torch.cat([ro, rd, torch.zeros(n, 1, device=DEV), torch.ones(n, 1, device=DEV)], 1)
@@ -247,3 +255,37 @@ def test_render_of_a_whole_image_equals_the_chunk_loop_bitwise(cfg_file, fixture
     again = trainer.render(64, 64, 80., chunk=1024, rays=(ro, rd), **kwargs)
     whole = trainer.render(64, 64, 80., chunk=1024, rays=(ro, rd), **dict(kwargs, skts=exp(scene["skts"])))
     assert all(torch.equal(again[k], whole[k]) for k in whole)
+
+
+def test_render_of_a_megapixel_image_is_bounded_and_equals_the_chunk_loop_bitwise():
+    """1000 x 1000 rays x (48 + 16) through core.trainer.render: one cast at the default budget (64 M ray-samples <= 1 << 26), four
+    super-chunks at a quarter of it, and the reference-shaped loop of 245 casts of 4 096 rays -- all bit-identical (the
+    whole-image cast must not grow without limit, and the identity was only checked at 64 x 64)"""
+    from core import trainer
+    from core.utils import synthetic as syn
+    g = golden("danbo_stages")
+    rest_scale = syn.model_config(str(g["cfg_name"]))["rest_scale"]
+    caster, kw = build("h36m_zju/danbo_base.txt", g, rest_scale=rest_scale)
+    H = W = 1000
+    scene = syn.make_scene(n_poses=1, H=H, W=W, n_views=2, pose_seed=5, rest_scale=rest_scale, cam_dist=3.5)
+    ro, rd = (T(x) for x in scene["rays"][1])
+    n = len(ro)
+    assert n == H * W
+    exp = lambda x, dt=torch.float32: T(x, dt)[:1].expand(n, *x.shape[1:])  # noqa: E731
+    kwargs = dict(kp_batch=exp(scene["kps"]), skts=exp(scene["skts"]), cyls=exp(scene["cyls"]), bones=exp(scene["bones"]),
+                  cams=torch.zeros(1, dtype=torch.int64, device=DEV).expand(n), ray_caster=caster, N_samples=48, N_importance=16, **kw)
+    whole = trainer.render(H, W, 800., chunk=4096, rays=(ro, rd), **kwargs)
+    assert float(whole["acc_map"].max()) > 0.5
+    caster.whole_cast_max_samples = (1 << 26) // 4
+    try:
+        capped = trainer.render(H, W, 800., chunk=4096, rays=(ro, rd), **kwargs)
+    finally:
+        del caster.whole_cast_max_samples
+    orig = caster.render_rays_whole
+    caster.render_rays_whole = lambda *a, **k: None
+    try:
+        loop = trainer.render(H, W, 800., chunk=4096, rays=(ro, rd), **kwargs)
+    finally:
+        caster.render_rays_whole = orig
+    for k in loop:
+        assert torch.equal(whole[k], loop[k]) and torch.equal(capped[k], loop[k]), k

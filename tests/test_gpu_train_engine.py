@@ -716,3 +716,9 @@ def test_loss_terms_are_snapshotted_at_the_first_look_and_refuse_a_late_one():
         len(loss_c)
     _, stats = trainer.train_batch(b, i=7, global_step=7, sync_stats=True)
     assert np.isfinite(stats['total_loss']) and np.isfinite(stats['psnr'])
+    # an EAGER step (no graph) returns fresh tensors: its terms stay readable after later steps, like the reference's
+    trainer.engine.use_graph = False
+    loss_d, _ = trainer.train_batch(b, i=8, global_step=8, sync_stats=False)
+    trainer.train_batch(b, i=9, global_step=9, sync_stats=False)
+    trainer.train_batch(b, i=10, global_step=10, sync_stats=False)
+    assert np.isfinite(float(loss_d['total_loss'])) and len(loss_d) >= 3

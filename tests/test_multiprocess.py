@@ -160,7 +160,16 @@ def _fused_worker(rank, world, port, q):
         losses.append(stats["total_loss"])
     assert trainer.engine is not None, trainer.fused_reason
     torch.cuda.synchronize()
-    q.put((rank, trainer.engine.flat_p.detach().cpu().numpy().copy(), losses))
+    # resume: the checkpoint holds RANK 0's (seed, counter); restored on every rank it must give each rank ITS stream back
+    # at the common counter -- not rank 0's seed, not counter 0
+    eng = trainer.engine
+    own = eng.rng_state_dict()
+    box = [own]
+    dist.broadcast_object_list(box, src=0)
+    eng.reseed(12345)
+    eng.load_rng_state_dict(box[0])
+    resumed = eng.rng_state_dict()
+    q.put((rank, eng.flat_p.detach().cpu().numpy().copy(), losses, own, resumed))
     dist.destroy_process_group()
 
 
@@ -179,6 +188,9 @@ def test_fused_training_world2_on_one_gpu_keeps_replicas_bit_identical():
     import numpy as np
     assert np.array_equal(res[0][1], res[1][1])              # every parameter, bit for bit, after 3 steps
     assert all(np.isfinite(l) for r in res for l in r[2]) and res[0][2] != res[1][2]    # the shards (and their losses) differ
+    (own0, res0), (own1, res1) = res[0][3:5], res[1][3:5]
+    assert own0["seed"] != own1["seed"] and own0["counter"] == own1["counter"] > 0
+    assert res0 == own0 and res1 == own1                     # every rank continues its own stream from rank 0's checkpoint entry
 
 
 def _run_bench(*flags, timeout=900):
