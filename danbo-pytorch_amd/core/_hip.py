@@ -88,11 +88,30 @@ SIGNATURES = {
     "danbo_train_step_phase": [P, P, P, P, c_size_t, I, P],
     "danbo_train_workspace_view": [P, I, I, I, I, I, P, P],
     "danbo_group_rows": [P, P, P, I, P],
+    # ---- A-NeRF on own kernels end to end (ABI 8)
+    "danbo_small_matmul": [P, c_long, c_long, P, c_long, c_long, P, I, I, I, P, c_long, P],
+    "danbo_anerf_view_wj_pack": [P, I, I, I, I, P, P],
+    "danbo_anerf_view_consts_fwd": [P, P, I, I, I, P, I, P, P],
+    "danbo_anerf_view_consts_bwd_scratch_floats": [I, I, I],
+    "danbo_anerf_view_consts_bwd": [P, P, I, I, I, P, I, P, I, I, P, P],
+    "danbo_anerf_color_train_fwd": [P, I, P, P, P, I, I, I, I, P, P, P, I, P, P, P],
+    "danbo_anerf_color_bwd_part_floats": [I, I],
+    "danbo_anerf_color_bwd": [P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P],
+    "danbo_anerf_rgb_reduce": [P, c_long, I, P, P, P],
+    "danbo_anerf_ray_table": [P, I, I, I, P, P, I, P, I, I, P, P],
+    "danbo_anerf_code_grads": [P, P, I, I, I, P, I, P, I, I, P, P, P, P, P],
+    "danbo_anerf_relu_mask": [P, P, c_long, P, P, P, P, P, P],
+    "danbo_anerf_unmerge": [P, P, P, I, I, I, P, P, P],
+    "danbo_anerf_encode_fwd_dtau": [P, P, P, P, I, I, I, P, P, P, P, I, c_long, I, P, P, P],
+    "danbo_anerf_train_workspace": [P, I, I, I, I, I],
+    "danbo_anerf_train_step": [P, P, P, P, c_size_t, P],
+    "danbo_anerf_train_workspace_view": [P, I, I, I, I, I, P, P],
     "danbo_assign16_set_trace": [P],
 }
 # everything else returns int (0 = ok)
 RESTYPES = {"danbo_render_frame_workspace": c_size_t, "danbo_train_workspace": c_size_t,
-            "danbo_dw16_scratch_floats": c_long}
+            "danbo_dw16_scratch_floats": c_long, "danbo_anerf_train_workspace": c_size_t,
+            "danbo_anerf_view_consts_bwd_scratch_floats": c_long, "danbo_anerf_color_bwd_part_floats": c_long}
 
 
 class DanboModel(ctypes.Structure):
@@ -182,6 +201,21 @@ class DanboTrainBatch(ctypes.Structure):
 class DanboTrainOut(ctypes.Structure):
     _fields_ = [(n, P) for n in ("rgb_map", "disp_map", "acc_map", "alpha", "weights", "rgb0", "disp0", "acc0", "alpha0", "loss",
                                  "counts")]
+
+
+ANERF_MAX_D = 8
+
+
+class DanboAnerfTrainModel(ctypes.Structure):
+    """mirror of `struct DanboAnerfTrainModel` in include/danbo_hip.h"""
+    _fields_ = ([(n, I) for n in ("D", "W", "VW", "skip", "L", "L_view", "n_codes", "code_size")]
+                + [("pts_w", P * ANERF_MAX_D), ("pts_b", P * ANERF_MAX_D)]
+                + [(n, P) for n in ("alpha_w", "alpha_b", "feature_w", "feature_b", "views_w", "views_b", "rgb_w", "rgb_b", "codes")]
+                + [("g_pts_w", P * ANERF_MAX_D), ("g_pts_b", P * ANERF_MAX_D)]
+                + [(n, P) for n in ("g_alpha_w", "g_alpha_b", "g_feature_w", "g_feature_b", "g_views_w", "g_views_b", "g_rgb_w", "g_rgb_b",
+                                    "g_codes", "g_flat")]
+                + [("n_flat", c_long)] + [(n, P) for n in ("align", "cutoff", "tau")]
+                + [("loss_mse", I), ("use_background", I)] + [(n, F) for n in ("density_scale", "rgb_loss_coef", "coarse_weight")])
 
 
 class DanboTrainView(ctypes.Structure):

@@ -43,25 +43,28 @@ class AnerfEngine:
                                               frag_in=(self.frag and i > 0 and i not in self.skip_into, self.frag and i in self.skip_into))
                        for i in range(cfg["D"])]
         self._frag_store = None
-        wv = p["views_linears.0.weight"].double()                       # [VW, W + view_ch + code]
-        wf, bf = p["feature_linear.weight"].double(), p["feature_linear.bias"].double()
+        wv = p["views_linears.0.weight"].float()                        # [VW, W + view_ch + code]
+        wf, bf = p["feature_linear.weight"].float(), p["feature_linear.bias"].float()
         view_ch = (1 + 2 * self.Lv) * 72
         # feature_linear (no activation) folded into the view layer: one W -> VW GEMM per sample
         # ... and stacked on alpha_linear: rows [0, VW) = view features, row VW = density logit
-        head_w = torch.cat([(wv[:, :W] @ wf).float(), p["alpha_linear.weight"].float()], 0).contiguous()
+        # (the parameter-sized products of this refresh on danbo_small_matmul -- float64 accumulation, operands read through their
+        # strides -- instead of float64 torch matmuls: no library GEMM anywhere on the A-NeRF path)
+        head_w = torch.empty(VW + 1, W, device=wv.device, dtype=torch.float32)
+        ops.small_matmul(wv[:, :W], wf, out=head_w[:VW])
+        head_w[VW:].copy_(p["alpha_linear.weight"].float())
         self.head = ops.linear16_pack(head_w, frag_in=(self.frag, False))
         self.head_b = torch.cat([torch.zeros(VW, device=head_w.device), p["alpha_linear.bias"].float()]).contiguous()
         self.VW = VW
-        b_eff = wv[:, :W] @ bf + p["views_linears.0.bias"].double()
-        # per-joint slices of the view weights: [24, 27, VW] with k = block*3 + axis
-        nb = 1 + 2 * self.Lv
-        self.w_view_j = wv[:, W:W + view_ch].float().reshape(VW, nb, 24, 3).permute(2, 1, 3, 0).reshape(24, nb * 3, VW).contiguous()
+        b_eff = ops.small_matmul(bf[None, :], wv[:, :W].t(), bias=p["views_linears.0.bias"].float())      # [1, VW]
+        # per-joint slices of the view weights: [24, 3 nb, VW] with k = block * 3 + axis (danbo_anerf_view_wj_pack)
+        self.w_view_j = ops.anerf_view_wj(p["views_linears.0.weight"], W, self.Lv)
         if cfg["use_framecode"]:
-            codes = p["framecodes.codes.weight"].double()
-            codes = torch.cat([codes, codes.mean(0, keepdim=True)], 0)  # last row: mean code (eval, idx < 0)
-            self.table = (codes @ wv[:, W + view_ch:].t() + b_eff).float().contiguous()
+            codes = p["framecodes.codes.weight"].float()
+            codes = torch.cat([codes, codes.double().mean(0, keepdim=True).float()], 0)  # last row: mean code (eval, idx < 0)
+            self.table = ops.small_matmul(codes, wv[:, W + view_ch:].t(), bias=b_eff[0])
         else:
-            self.table = b_eff.float().reshape(1, VW).contiguous()
+            self.table = b_eff.reshape(1, VW).contiguous()
         self.rgb_w = p["rgb_linear.weight"].contiguous()
         self.rgb_b = p["rgb_linear.bias"].contiguous()
         self.cutoff = p["pe_fn.cutoff_dist"].contiguous()
@@ -80,11 +83,9 @@ class AnerfEngine:
     def view_constants(self, rays_d, skts):
         """C [24, R, VW]: per-ray, per-joint part of the view layer (before the per-sample cutoff weight)."""
         self.refresh()
-        E = ops.anerf_view_pe(rays_d, skts, self.Lv)                    # [R, nb*72], block-major
-        R = E.shape[0]
-        nb = 1 + 2 * self.Lv
-        Ej = E.reshape(R, nb, 24, 3).permute(2, 0, 1, 3).reshape(24, R, nb * 3)
-        return torch.bmm(Ej, self.w_view_j)
+        # one kernel: the cutoff view encoding of (ray, joint) is formed in LDS and multiplied with the joint's [3 nb, VW] weight
+        # slice (round 5: danbo_anerf_view_pe_fwd + a permuted copy + torch.bmm, 3.1 ms of library kernels per frame)
+        return ops.anerf_view_consts(rays_d, skts, self.Lv, self.w_view_j)
 
     def _trunk(self, x0):
         if self.frag:
@@ -131,7 +132,10 @@ class AnerfEngine:
         raw = torch.empty(R, S, 4, device=dev, dtype=torch.float32)
         dens = torch.empty(R * S, 1, device=dev, dtype=torch.float32) if density_only else None
         C = None if density_only else (self.view_constants(rays_d, skts) if view is None else view)
-        rays_per_chunk = max(1, self.rows_per_chunk // S)
+        # whole rays per chunk, the chunks equally long: 262 144 rays x 48 samples at 1 M rows per chunk are 12.0002 chunks -- thirteen
+        # with a last one of 4 rays, each a full chain of launches, when the chunk is simply rows_per_chunk // S rays
+        n_chunks = max(1, -(-(R * S) // self.rows_per_chunk))
+        rays_per_chunk = max(1, -(-R // n_chunks))
         n_max = min(R, rays_per_chunk) * S
         buf = (torch.empty(n_max, ops.ANERF_ENC_FLOATS if self.fused_enc else self.in_ch, device=dev), torch.empty(n_max, 24, device=dev))
         head_buf = torch.empty(n_max, (self.VW + 4) // 4 * 4, device=dev)     # [view features | density logit | pad to 16 B]

@@ -489,7 +489,7 @@ def pe_mlp_bwd(h: torch.Tensor, row_ray: torch.Tensor, vin: torch.Tensor, params
                                           None, _p(g[20]), None, st), "danbo_train_view_grads")
     _hip.check(lib.danbo_train_head_chain(_p(g_wfv), _p(g_beff), None, _p(params[18]), _p(params[19]), _p(params[20]), C, 0, 0, 0,
                                           _p(g[18]), _p(g[19]), _p(g[20]), _p(g[21]), None, None, st), "danbo_train_head_chain")
-    d_vin = d_cview @ params[20][:, 256:]              # [R,128] x [128, view_ch]: per RAY, tiny
+    d_vin = ops.small_matmul(d_cview, params[20][:, 256:])     # [R,128] x [128, view_ch]: per RAY, tiny (danbo_small_matmul)
     return [buf["d_h"][:, :15].contiguous(), d_vin] + g
 
 

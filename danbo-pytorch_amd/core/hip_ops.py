@@ -561,6 +561,59 @@ def anerf_view_pe(rays_d, skts, L):
     return E
 
 
+def small_matmul(a, b, bias=None, out=None):
+    """a [M, K] @ b [K, N] (+ bias [N]) -> float32 [M, N]; a, b: float32 CUDA tensors of ANY strides (slices and .t() views are read
+    in place); the sum over k accumulated in float64 and rounded once (danbo_small_matmul: one thread per output -- the
+    parameter-sized products of a weight refresh, which were float64 torch matmuls, i.e. library GEMMs, until round 5)"""
+    for t, nm in ((a, "a"), (b, "b")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
+            raise RuntimeError(f"small_matmul {nm}: expected a 2-D float32 CUDA/HIP tensor -- libdanbo_hip has no CPU fallback")
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2:
+        raise ValueError(f"small_matmul: {tuple(a.shape)} @ {tuple(b.shape)}")
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    _call("danbo_small_matmul", _p(a), a.stride(0), a.stride(1), _p(b), b.stride(0), b.stride(1), _p(bias), M, N, K, _p(out), out.stride(0),
+          _stream())
+    return out
+
+
+def anerf_view_wj(views_w, col0, L):
+    """views_linears.0.weight [VW, ld] -> wj [24, 3 (1 + 2 L), VW]: its view columns regrouped per joint (danbo_anerf_view_wj_pack)"""
+    views_w = _f32(views_w, "views_w")
+    VW, ld = views_w.shape
+    wj = torch.empty(J, 3 * (1 + 2 * L), VW, device=views_w.device, dtype=torch.float32)
+    _call("danbo_anerf_view_wj_pack", _p(views_w), ld, int(col0), VW, int(L), _p(wj), _stream())
+    return wj
+
+
+def anerf_view_consts(rays_d, skts, L, wj, out=None):
+    """C [24, R, VW]: per-ray, per-joint part of A-NeRF's view layer (danbo_anerf_view_consts_fwd: the cutoff view encoding formed in
+    the kernel, one fmaf chain per output)"""
+    rays_d, skts, wj = _f32(rays_d, "rays_d"), _f32(skts, "skts"), _f32(wj, "wj")
+    R, G, VW = rays_d.shape[0], skts.shape[0], wj.shape[2]
+    if wj.shape[0] != J or wj.shape[1] != 3 * (1 + 2 * L):
+        raise ValueError(f"wj {tuple(wj.shape)} for L = {L}")
+    C = out if out is not None else torch.empty(J, R, VW, device=rays_d.device, dtype=torch.float32)
+    _call("danbo_anerf_view_consts_fwd", _p(rays_d), _p(skts), R, G, int(L), _p(wj), VW, _p(C), _stream())
+    return C
+
+
+def anerf_view_consts_bwd(rays_d, skts, L, dC, g_views_w, col0):
+    """g_views_w[:, col0 : col0 + 72 (1 + 2 L)] = the adjoint of anerf_view_consts with respect to the view columns (overwritten)"""
+    rays_d, skts, dC = _f32(rays_d, "rays_d"), _f32(skts, "skts"), _f32(dC, "dC")
+    R, G, VW = rays_d.shape[0], skts.shape[0], dC.shape[2]
+    g_views_w = _f32(g_views_w, "g_views_w")
+    n = _hip.lib().danbo_anerf_view_consts_bwd_scratch_floats(R, int(L), VW)
+    scratch = torch.empty(n, device=rays_d.device, dtype=torch.float32)
+    _call("danbo_anerf_view_consts_bwd", _p(rays_d), _p(skts), R, G, int(L), _p(dC), VW, _p(g_views_w), g_views_w.shape[1], int(col0),
+          _p(scratch), _stream())
+    return g_views_w
+
+
 def _rows(t, name):
     """fp32 CUDA matrix whose rows may be strided (a column slice of a wider buffer) -> (tensor, row stride in floats)"""
     if not t.is_cuda or t.dtype != torch.float32:

@@ -117,7 +117,7 @@ class DanboEngine:
         else:
             a_max = a_max + self.views_b16.abs()
         hidden = ec[:128].abs() + a_max
-        logit = (self.rgb_w.abs() @ hidden + self.rgb_b.abs()).max()
+        logit = ((self.rgb_w.abs() * hidden[None, :]).sum(-1) + self.rgb_b.abs()).max()
         ok = (ec[128] / float(cfg["density_scale"]) <= 0) & (logit < 1e30)
         return bool(ok.item())
 

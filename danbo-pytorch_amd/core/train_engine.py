@@ -234,9 +234,9 @@ class DanboTrainEngine:
         out = {k: torch.empty(v, device=dev, dtype=torch.float32) for k, v in out.items()}
         out['counts'] = torch.empty(8, device=dev, dtype=torch.int32)
         chunk = R
-        nbytes = _hip.lib().danbo_train_workspace(ctypes.byref(m), R, G, S, Sf, chunk)
+        nbytes = self._c_workspace(m, R, G, S, Sf, chunk)
         if nbytes == 0:
-            raise RuntimeError("danbo_train_workspace rejected the model / batch shape")
+            raise RuntimeError("the training step's workspace query rejected the model / batch shape")
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         bt = _hip.DanboTrainBatch(
@@ -256,9 +256,15 @@ class DanboTrainEngine:
     def _step_phase(self, out, phase):
         """phase 0: the whole step; 1: up to the pose-GNN adjoint (every gradient but the dense layers' final); 2: the rest"""
         _, bt, o = out['_keep']
-        _hip.check(_hip.lib().danbo_train_step_phase(ctypes.byref(self._model()), ctypes.byref(bt), ctypes.byref(o), _P(self._ws),
-                                                     self._ws.numel(), int(phase),
-                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "danbo_train_step")
+        self._c_step(self._model(), bt, o, int(phase), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    # the two C entry points of the step (core/anerf_train_engine.py overrides them with danbo_anerf_train_*)
+    def _c_workspace(self, m, R, G, S, Sf, chunk):
+        return _hip.lib().danbo_train_workspace(ctypes.byref(m), R, G, S, Sf, chunk)
+
+    def _c_step(self, m, bt, o, phase, stream):
+        _hip.check(_hip.lib().danbo_train_step_phase(ctypes.byref(m), ctypes.byref(bt), ctypes.byref(o), _P(self._ws), self._ws.numel(),
+                                                     phase, stream), "danbo_train_step")
 
     def _own_seed(self):
         """the seed of THIS rank's stream: torch's CUDA generator seed of the device, mixed with the RANK: ranks that were

@@ -7,10 +7,12 @@ Every stage runs on the library's kernels in both directions, as torch.library c
   torch.ops.danbo.assign_blend   gather + assignment GNN + masked sigmoid + blend          (k_assign_blend / k_assign_bwd)
   torch.ops.danbo.pe_mlp         voxel PE + density trunk + colour head                     (k_train_mlp_fwd / _bwd, k_dw16)
   torch.ops.danbo.composite      NeRF.raw2outputs                                           (k_composite / k_composite_bwd)
-  Linear16Fn                     A-NeRF's W = 448 dense layers                              (k_linear16 both ways, k_dw16)
+  Linear16Fn                     A-NeRF's dense layers                                      (k_linear16 both ways, k_dw16)
+  AnerfViewConstsFn, AnerfColorFn  A-NeRF's per-ray view constants, cutoff-weighted view sum + colour head (k_anerf_train.hip)
 and the in-volume cull, sampling, importance sampling and merge order without gradient (the reference detaches them).
-What torch computes here: element-wise glue, the matrix-VECTOR heads of A-NeRF (alpha_linear N = 1, rgb_linear N = 3: `LinearFn`)
-and A-NeRF's per-ray view products.  A network of ANOTHER shape than the shipped ones is not evaluated by a library fallback:
+What torch computes here: element-wise glue (no GEMM: A-NeRF's heads and per-ray view products, library routes until round 5, are
+`Linear16Fn` on stacked / sliced weights, `AnerfViewConstsFn` and `AnerfColorFn`).  A network of ANOTHER shape than the shipped ones is
+not evaluated by a library fallback:
 `forward_train` raises (the constructors raise for those shapes already).  The layer-by-layer torch restatement the operators are
 tested against lives with the tests (tests/torch_layerwise.py).
 
@@ -63,38 +65,6 @@ class GatherFn(torch.autograd.Function):
                 _p(geo.align), _p(axis_scale), _p(volumes.contiguous()), _p(rows), ctx.n, _p(g), _p(d_vol), _p(d_sc),
                 ops._stream()), "danbo_bone_gather_bwd")
         return d_vol, d_sc, None, None
-
-
-class LinearFn(torch.autograd.Function):
-    """nn.Linear whose weight gradient dW = dY^T X is computed split-K: the library's single GEMM with K = 70 000 rows and a
-    256 x 256 output fills a fraction of the GPU (measured 239 us; 683 us for the 451-wide skip layer), 64 row slices as one
-    batched GEMM plus a sum take 93 / 165 us.  Forward and dX are the plain library GEMMs."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
-
-    @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g = g.contiguous()
-        dx = g @ weight if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            n, N, K = g.shape[0], g.shape[1], x.shape[1]
-            slices = min(64, n // 512)
-            if slices >= 2:
-                xc = x.contiguous()
-                ch = (n // slices) * slices
-                dw = torch.bmm(g[:ch].view(slices, -1, N).transpose(1, 2), xc[:ch].view(slices, -1, K)).sum(0)
-                if ch < n:
-                    dw = dw + g[ch:].t() @ xc[ch:]
-            else:
-                dw = g.t() @ x
-        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
 
 
 def _packed(weight, K1=None, transposed=False, cols=None):
@@ -189,9 +159,70 @@ def linear16(layer, x, relu=False, x2=None, x_grad=True):
     return Linear16Fn.apply(x, x2, layer.weight, layer.bias, relu, x_grad)
 
 
-def linear(layer, x):
-    """a matrix-VECTOR head (A-NeRF's alpha_linear N = 1, rgb_linear N = 3) through torch"""
-    return LinearFn.apply(x, layer.weight, layer.bias)
+class AnerfViewConstsFn(torch.autograd.Function):
+    """C [24, R, VW]: the per-ray, per-joint part of A-NeRF's view layer, views_linears.0[:, view columns of joint j] . PE(unit local
+    ray direction) (reference nerf.py:252-279 + cutoff_embedder.py:156-166 before the per-sample cutoff weight) on
+    danbo_anerf_view_consts_fwd; backward: the view columns' gradient on danbo_anerf_view_consts_bwd (ray slices added in a fixed
+    order).  No gradient reaches the ray directions or the skeleton (opt_pose is off)."""
+
+    @staticmethod
+    def forward(ctx, views_w, rays_d, skts, col0, Lv):
+        wj = ops.anerf_view_wj(views_w.detach().contiguous(), col0, Lv)
+        ctx.save_for_backward(rays_d, skts)
+        ctx.col0, ctx.Lv, ctx.shape = col0, Lv, tuple(views_w.shape)
+        return ops.anerf_view_consts(rays_d, skts, Lv, wj)
+
+    @staticmethod
+    def backward(ctx, dC):
+        rays_d, skts = ctx.saved_tensors
+        g = torch.zeros(ctx.shape, device=dC.device, dtype=torch.float32)
+        ops.anerf_view_consts_bwd(rays_d, skts, ctx.Lv, dC.contiguous().float(), g, ctx.col0)
+        return g, None, None, None, None
+
+
+class AnerfColorFn(torch.autograd.Function):
+    """raw [R, S, 4] = (rgb_linear(relu(featv + table_ray[ray] + sum_j w_j C[j, ray])), alpha): the view layer's cutoff-weighted sum,
+    its ReLU and the colour head (reference nerf.py:196-209) on danbo_anerf_color_train_fwd / danbo_anerf_color_bwd -- one wavefront
+    per ray both ways.  The cutoff weights w carry no gradient (the encoders have no trainable parameter)."""
+
+    @staticmethod
+    def forward(ctx, featv, alpha, C, table_ray, rgb_w, rgb_b, w, R, S):
+        VW = featv.shape[1]
+        n = R * S
+        head = torch.empty(n, VW + 4, device=featv.device, dtype=torch.float32)
+        head[:, :VW] = featv
+        head[:, VW] = alpha.reshape(-1)
+        hv = torch.empty(n, VW, device=featv.device, dtype=torch.float32)
+        raw = torch.empty(R, S, 4, device=featv.device, dtype=torch.float32)
+        lib = _hip.lib()
+        _hip.check(lib.danbo_anerf_color_train_fwd(_p(head), VW + 4, _p(w), _p(C.contiguous()), _p(table_ray.contiguous()), R, R, S, VW,
+                                                   _p(rgb_w.detach().contiguous()), _p(rgb_b.detach().contiguous()), head[:, VW:].data_ptr(), VW + 4,
+                                                   _p(hv), _p(raw), ops._stream()), "danbo_anerf_color_train_fwd")
+        ctx.save_for_backward(hv, w, rgb_w.detach().contiguous())
+        ctx.R, ctx.S, ctx.VW = R, S, VW
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        hv, w, rgb_w = ctx.saved_tensors
+        R, S, VW = ctx.R, ctx.S, ctx.VW
+        n = R * S
+        dev = d_raw.device
+        d_raw = d_raw.contiguous().float()
+        mx = d_raw.abs().max().reshape(1)
+        sig = torch.empty(1, device=dev)
+        d_featv = torch.empty(n, VW, device=dev)
+        d_alpha4 = torch.empty(n, 4, device=dev)
+        dC = torch.empty(24, R, VW, device=dev)
+        d_pre_ray = torch.empty(R, VW, device=dev)
+        lib = _hip.lib()
+        nf = lib.danbo_anerf_color_bwd_part_floats(R, VW)
+        part = torch.empty(nf, device=dev)
+        _hip.check(lib.danbo_anerf_color_bwd(_p(d_raw), _p(hv), _p(w), R, R, S, VW, _p(rgb_w), _p(mx), _p(sig), _p(d_featv), _p(d_alpha4), 4,
+                                             _p(dC), _p(d_pre_ray), 0, _p(part), ops._stream()), "danbo_anerf_color_bwd")
+        g_rgb_w, g_rgb_b = torch.empty(3, VW, device=dev), torch.empty(3, device=dev)
+        _hip.check(lib.danbo_anerf_rgb_reduce(_p(part), nf, VW, _p(g_rgb_w), _p(g_rgb_b), ops._stream()), "danbo_anerf_rgb_reduce")
+        return d_featv / sig, (d_alpha4[:, 0] / sig).reshape(n, 1), dC, d_pre_ray, g_rgb_w, g_rgb_b, None, None, None
 
 
 def composite(raw, z, rays_d, B=1.0, noise=None):
@@ -380,9 +411,13 @@ def forward_train_anerf(model, inputs):
 
     The encoders have no trainable parameter (`cutoff_dist` is `requires_grad=False`, core/cutoff_embedder.py:139) and
     no gradient flows to the sample positions (`z_samples` detached, core/utils/ray_utils.py:287), so the HIP encode
-    kernels run as they do in evaluation; the trunk, the view layer and the colour head are dense layers recorded by
-    autograd.  The view layer uses the same factorisation as the eval kernel: per-ray, per-joint products of
-    views_linears.0 with the direction encoding, then a 24-term cutoff-weighted sum per sample (a batched matmul)."""
+    kernels run as they do in evaluation; every dense layer is `Linear16Fn` (k_linear16 both ways, k_dw16): the trunk, feature_linear
+    and alpha_linear stacked as ONE W + 1 wide layer, views_linears.0's feature columns, its frame-code columns on the rays' code rows.
+    The view layer uses the factorisation of the eval kernels: per-ray, per-joint products of views_linears.0 with the direction
+    encoding (`AnerfViewConstsFn`), then the 24-term cutoff-weighted sum, the ReLU and rgb_linear per sample (`AnerfColorFn`).
+    No torch / rocBLAS GEMM: the library route of rounds 1 - 5 (alpha_linear, rgb_linear, the view products) is gone.  (The fused
+    step, core/anerf_train_engine.py, is what Trainer.train_batch runs; this is `caster.train(); caster(...)` for a caller that
+    wants predictions with a grad_fn.)"""
     pts = inputs["pts"].contiguous().float()
     R, S = pts.shape[:2]
     G = int(inputs.get("N_uniques", 1))
@@ -392,11 +427,11 @@ def forward_train_anerf(model, inputs):
     rays_d = inputs["rays_d"].reshape(R, 3).contiguous().float()
     L, Lv = model.pe_fn.num_freqs, model.dirs_pe_fn.num_freqs
     tau = float(model.pe_fn.tau)
+    W = model.W
+    if model.feature_linear.weight.shape[0] != W or len(model.skips) > 1:
+        raise NotImplementedError("the A-NeRF training kernels take feature_linear of width W (the reference: 2 view_W = W) and one skip")
     with torch.no_grad():
         x0, w = ops.anerf_encode(None, None, skts_g, align, model.pe_fn.cutoff_dist.detach(), tau, L, 0, R * S, pts=pts)
-        E = ops.anerf_view_pe(rays_d, skts_g, Lv)                                  # [R, nb*72], block-major
-    # the W-wide trunk and feature_linear on k_linear16 both ways (Linear16Fn); alpha_linear (N = 1) and rgb_linear (N = 3) are
-    # matrix-vector products: library route
     h, skip_in = x0, None
     for i, l in enumerate(model.pts_linears):
         if skip_in is not None:       # the layer behind a skip: [input | h] as two operands, no concatenated copy
@@ -406,23 +441,23 @@ def forward_train_anerf(model, inputs):
             h = linear16(l, h, relu=True, x_grad=i > 0)
         if i in model.skips:
             skip_in = h
-    if skip_in is not None:           # (a skip after the last layer: the heads see the concatenation)
-        h = torch.cat([x0, h], -1)
-    alpha = linear(model.alpha_linear, h)
-    feat = linear16(model.feature_linear, h)
-    W, nb = model.W, 1 + 2 * Lv
-    wv, bv = model.views_linears[0].weight, model.views_linears[0].bias           # [VW, W + nb*72 + code]
-    view_ch = nb * 72
-    wj = wv[:, W:W + view_ch].reshape(-1, nb, 24, 3).permute(2, 1, 3, 0).reshape(24, nb * 3, -1)   # [24, 27, VW]
-    Ej = E.reshape(R, nb, 24, 3).permute(2, 0, 1, 3).reshape(24, R, nb * 3)
-    C = torch.bmm(Ej, wj).permute(1, 0, 2)                                         # [R, 24, VW]
-    pre = feat @ wv[:, :W].t() + torch.bmm(w.reshape(R, S, 24), C).reshape(R * S, -1) + bv
+    if skip_in is not None:
+        raise NotImplementedError("a skip after the last trunk layer")
+    # [feature_linear ; alpha_linear ; 0 0 0] as one layer of W + 4 outputs (16-byte rows): column W is the density logit
+    pad = h.new_zeros(3, W)
+    w_head = torch.cat([model.feature_linear.weight, model.alpha_linear.weight, pad], 0)
+    b_head = torch.cat([model.feature_linear.bias, model.alpha_linear.bias, h.new_zeros(3)])
+    head = Linear16Fn.apply(h, None, w_head, b_head, False, True)                  # [n, W + 4]
+    wv, bv = model.views_linears[0].weight, model.views_linears[0].bias           # [VW, W + 72 nb + code]
+    view_ch = 72 * (1 + 2 * Lv)
+    featv = Linear16Fn.apply(head[:, :W], None, wv[:, :W].contiguous(), None, False, True)
+    C = AnerfViewConstsFn.apply(wv, rays_d, skts_g, W, Lv)                          # [24, R, VW]
     if model.use_framecode:
         idx = inputs.get("cam_idxs").reshape(-1).long()
-        code = model.framecodes.codes(idx) @ wv[:, W + view_ch:].t()               # [R, VW]
-        pre = pre + code.repeat_interleave(S, 0)
-    rgb = linear(model.rgb_linear, F.relu(pre))
-    return torch.cat([rgb, alpha], -1).reshape(R, S, 4), {}
+        table_ray = Linear16Fn.apply(model.framecodes.codes(idx), None, wv[:, W + view_ch:].contiguous(), bv, False, True)   # [R, VW]
+    else:
+        table_ray = bv[None, :].expand(R, -1)
+    return AnerfColorFn.apply(featv, head[:, W:W + 1], C, table_ray, model.rgb_linear.weight, model.rgb_linear.bias, w, R, S), {}
 
 
 # --------------------------------------------------------------------------------------

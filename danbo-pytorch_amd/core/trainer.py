@@ -138,12 +138,15 @@ class Trainer:
     def fused_engine(self):
         """the HIP training engine for this caster / optimizer, or None with `self.fused_reason` saying why not"""
         if self.engine is None and self.fused_reason is None:
-            from . import train_engine
+            from . import anerf_train_engine, train_engine
             caster = self.render_kwargs_train['ray_caster']
+            # DANBO -> danbo_train_step, A-NeRF (NeRF with the cutoff encoders) -> danbo_anerf_train_step
+            mod, cls = ((anerf_train_engine, anerf_train_engine.AnerfTrainEngine) if type(caster.network).__name__ == 'NeRF'
+                        else (train_engine, train_engine.DanboTrainEngine))
             self.fused_reason = ('DANBO_TRAIN_PATH=autograd' if os.environ.get('DANBO_TRAIN_PATH') == 'autograd'
-                                 else train_engine.supported(self.args, caster))
+                                 else mod.supported(self.args, caster))
             if self.fused_reason is None:
-                self.engine = train_engine.DanboTrainEngine(self.args, caster, self.optimizer)
+                self.engine = cls(self.args, caster, self.optimizer)
                 self.engine.load_rng_state_dict(getattr(self, 'resume_rng_state', None))
         return self.engine
 
@@ -184,7 +187,8 @@ class Trainer:
             eng.finish_backward()
             if ev:
                 ev[2].record()
-            dist.all_reduce(late, op=dist.ReduceOp.SUM)
+            if late.numel():         # (the A-NeRF step is one phase: its whole gradient travels in the first collective)
+                dist.all_reduce(late, op=dist.ReduceOp.SUM)
             if ev:
                 ev[3].record()
                 prof.append(ev)
@@ -198,7 +202,9 @@ class Trainer:
         # between every two steps until round 5: 0.8 % of the step for a dictionary the loop reads once in i_print iterations).  An
         # EAGER step (fixed_draws, use_graph off) returns fresh tensors: its terms stay readable for good, like the reference's
         gen = eng.generation
-        loss = LazyLossDict(out['loss'], args.soft_softmax_loss_coef / (R * (S + Sf)), args.agg_type == 'sigmoid', bool(args.opt_vol_scale),
+        danbo = type(caster.network).__name__ == 'DANBO'       # (A-NeRF has neither an assignment nor a volume-scale term)
+        loss = LazyLossDict(out['loss'], args.soft_softmax_loss_coef / (R * (S + Sf)), danbo and args.agg_type == 'sigmoid',
+                            danbo and bool(args.opt_vol_scale),
                             still_valid=(lambda: eng.generation == gen) if eng.outputs_static else None)
         stats = dict(lrate=lr)
         if sync_stats:      # one device-to-host copy; the loop asks for it only when it prints

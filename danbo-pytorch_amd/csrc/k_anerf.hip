@@ -28,9 +28,12 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
                                                            const float* __restrict__ z, const float* __restrict__ pts,
                                                            int R, int S, int G, const float* __restrict__ skts,
                                                            const float* __restrict__ align,
-                                                           const float* __restrict__ cutoff, float tau, int L,
+                                                           const float* __restrict__ cutoff, float tau_arg, int L,
                                                            long row0, int nrows, float* __restrict__ x0,
-                                                           float* __restrict__ wout) {
+                                                           float* __restrict__ wout, const float* __restrict__ tau_dev = nullptr) {
+    // tau as a DEVICE scalar (the module's `tau` buffer) when the launch is part of a captured graph: update_tau changes it
+    // every step (core/cutoff_embedder.py:221-223) and a kernel argument would be frozen at capture time
+    const float tau = tau_dev ? *tau_dev : tau_arg;
     extern __shared__ __attribute__((aligned(16))) float s_row[];  // [AN_TS][in_ch]
     __shared__ float s_align[J * 16];
     const int in_ch = COMPACT ? AN_ENC_FLOATS : (1 + 2 * L) * J + 3 * J;
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(256) void k_anerf_color(const float* __restrict__ f
 
 using namespace danbo;
 
-extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
-                                 int S, int G, const float* skts, const float* align, const float* cutoff, float tau,
-                                 int L, long row0, int nrows, float* x0, float* w_out, void* stream) {
+static int anerf_encode_impl(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
+                             int S, int G, const float* skts, const float* align, const float* cutoff, float tau, const float* tau_dev,
+                             int L, long row0, int nrows, float* x0, float* w_out, void* stream) {
     DANBO_CHECK_ARG(R > 0 && S > 0 && G > 0 && R % G == 0 && L >= 0 && L <= AN_MAXL && nrows >= 0 && row0 >= 0);
     DANBO_CHECK_ARG(row0 + nrows <= (long)R * S && skts && align && cutoff && x0 && w_out);
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr) && (pts || (rays_o && rays_d)));
@@ -223,8 +226,22 @@ extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, 
     const int ntiles = ceil_div(nrows, AN_TS);
     const int grid = ntiles < num_cu() * 8 ? ntiles : num_cu() * 8;
     hipLaunchKernelGGL(k_anerf_encode<false>, dim3(grid), dim3(AN_BLOCK), AN_TS * in_ch * sizeof(float), (hipStream_t)stream,
-                       rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, L, row0, nrows, x0, w_out);
+                       rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, L, row0, nrows, x0, w_out, tau_dev);
     DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_anerf_encode_fwd(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
+                                 int S, int G, const float* skts, const float* align, const float* cutoff, float tau,
+                                 int L, long row0, int nrows, float* x0, float* w_out, void* stream) {
+    return anerf_encode_impl(rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, nullptr, L, row0, nrows, x0, w_out, stream);
+}
+
+/* the same with tau read from DEVICE memory when the kernel runs (a launch inside a captured graph: the training step) */
+extern "C" int danbo_anerf_encode_fwd_dtau(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R,
+                                 int S, int G, const float* skts, const float* align, const float* cutoff, const float* tau_dev,
+                                 int L, long row0, int nrows, float* x0, float* w_out, void* stream) {
+    DANBO_CHECK_ARG(tau_dev != nullptr);
+    return anerf_encode_impl(rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, 0.f, tau_dev, L, row0, nrows, x0, w_out, stream);
 }
 
 /* the encoder's inputs instead of its output: table [nrows, 144] for danbo_linear16_fwd_enc (k_linear16.hip) + the cutoff weights */

@@ -95,9 +95,35 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherArgs a, uint32_t* __r
     }
 }
 
+
+
+// Parameter-sized products of a weight refresh (a folded head matrix, a per-camera table, a bias pushed through a layer): one
+// thread per output, the sum over k in ascending order accumulated in float64 and rounded once -- what the hosts computed with
+// float64 torch matmuls (library GEMMs) until round 5.  Not for per-sample work.
+__global__ __launch_bounds__(256) void k_small_matmul(const float* __restrict__ A, long sa_m, long sa_k, const float* __restrict__ Bm, long sb_k,
+                                                      long sb_n, const float* __restrict__ bias, int M, int N, int K, float* __restrict__ C,
+                                                      long ldc) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * N; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        double acc = bias ? (double)bias[n] : 0.0;
+        const float* a = A + m * sa_m;
+        const float* b = Bm + n * sb_n;
+        for (int k = 0; k < K; ++k) acc += (double)a[k * sa_k] * (double)b[k * sb_k];
+        C[m * ldc + n] = (float)acc;
+    }
+}
+
 }  // namespace danbo
 
 using namespace danbo;
+
+extern "C" int danbo_small_matmul(const float* A, long sa_m, long sa_k, const float* B, long sb_k, long sb_n, const float* bias, int M, int N,
+                                  int K, float* C, long ldc, void* stream) {
+    DANBO_CHECK_ARG(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N);
+    hipLaunchKernelGGL(k_small_matmul, dim3(stream_grid((long)M * N, 256)), dim3(256), 0, (hipStream_t)stream, A, sa_m, sa_k, B, sb_k, sb_n, bias,
+                       M, N, K, C, ldc);
+    DANBO_LAUNCH_RET();
+}
 
 extern "C" int danbo_gather_rows(const DanboRowSpan* spans, int n_spans, void* dst, void* stream) {
     DANBO_CHECK_ARG(spans != nullptr && dst != nullptr && n_spans >= 1 && n_spans <= DANBO_MAX_ROW_SPANS);

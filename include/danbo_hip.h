@@ -35,7 +35,9 @@ extern "C" {
  * danbo_bone_cull takes the mask and the flags, the two fused composites a ray list (all nullable); additive since:
  * danbo_composite_rays_fwd, danbo_importance_samples_rays, danbo_random_draws, danbo_gather_rows; danbo_render_frame takes up to
  * 256 + 64 samples per ray; 6 = DANBO_MLP16_PACKED_BYTES grows by a trailer (power-of-two pack scales of danbo_mlp16_pack);
- * 7 = danbo_train_mid (additive); DanboTrainBatch.rng_* (appended: a caller of an older header must be rebuilt). */
+ * 7 = danbo_train_mid (additive); DanboTrainBatch.rng_* (appended: a caller of an older header must be rebuilt);
+ * 8 = A-NeRF on the library's own kernels end to end (additive): danbo_anerf_view_consts_fwd / _bwd, danbo_anerf_train_step and its
+ * building blocks. */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -698,6 +700,95 @@ typedef struct DanboTrainView {
     const uint32_t *bits_coarse /*[R,S]*/, *bits_fine /*[R,Sf]*/;
 } DanboTrainView;
 int danbo_train_workspace_view(const DanboTrainModel* model, int R, int G, int S, int Sf, int chunk, void* workspace, DanboTrainView* view);
+
+/* ---------------------------------------------------------------------------------------------
+ * A-NeRF (nerf_type = nerf) on this library's kernels end to end (ABI 8; csrc/k_anerf_train.hip).
+ * Render: the per-ray, per-joint view constants.  Training: Trainer.train_batch (core/trainer.py:257-302) for NeRF with the
+ * cutoff encoders (core/networks/nerf.py:107-122,176-209,222-279; core/cutoff_embedder.py:151-214) -- every dense W-wide layer on
+ * danbo_linear16_fwd both ways and danbo_dw16, everything else on the kernels declared here; no library GEMM.
+ * ------------------------------------------------------------------------------------------- */
+
+/* wj [24][3 (1 + 2 L)][VW]: the view columns of views_linears.0.weight ([VW, ld]; columns col0 + 72 b + 3 j + a, b = encoding
+ * block, a = axis) regrouped per joint, wj[j][3 b + a][c] */
+int danbo_anerf_view_wj_pack(const float* views_w, int ld, int col0, int VW, int L, float* wj, void* stream);
+/* C [24, R, VW]: C[j, ray, :] = sum_kk wj[j][kk][:] E[ray, j, kk] with E = the cutoff view encoding before its per-sample weight
+ * (danbo_anerf_view_pe_fwd's values: transform_batch_rays + VecNormEncoder + sin / cos, core/encoders.py:305-317,774-795,
+ * core/cutoff_embedder.py:156-166), formed in the kernel -- what core/anerf_engine.py computed with torch.bmm until round 5.
+ * One fmaf chain per output, kk ascending. */
+int danbo_anerf_view_consts_fwd(const float* rays_d, const float* skts, int R, int G, int L, const float* wj, int VW, float* C,
+                                void* stream);
+/* adjoint: g_views_w[c * ld + col0 + 72 b + 3 j + a] = sum_rays E[ray, j, 3 b + a] dC[j, ray, c] (OVERWRITTEN; ray slices summed in
+ * a fixed order); scratch: danbo_anerf_view_consts_bwd_scratch_floats(R, L, VW) floats */
+long danbo_anerf_view_consts_bwd_scratch_floats(int R, int L, int VW);
+int danbo_anerf_view_consts_bwd(const float* rays_d, const float* skts, int R, int G, int L, const float* dC, int VW, float* g_views_w,
+                                int ld, int col0, float* scratch, void* stream);
+/* danbo_anerf_color_fwd for the rays [0, nrays) of a training pass (rows ray * S + s): table_ray [R_total, VW] holds each ray's own
+ * bias + frame-code row (danbo_anerf_ray_table), hv [rows, VW] = relu(pre_v) is kept for the backward */
+int danbo_anerf_color_train_fwd(const float* featv, int ld_featv, const float* w, const float* C, const float* table_ray, int R_total,
+                                int nrays, int S, int VW, const float* rgb_w, const float* rgb_b, const float* alpha, int ld_alpha,
+                                float* hv, float* raw_out, void* stream);
+/* its adjoint.  d_raw [rows, 4] -> d_featv [rows, VW] and (d alpha, 0, 0, 0) at d_alpha_out + row * ld_dalpha (16-byte blocks), both
+ * MULTIPLIED by the power of two sigma that brings *raw_max (device: max |d raw|) to [64, 128) -- the operands of the fp16-split
+ * backward GEMMs -- with sigma written to *sig_top; dC [24, R_total, VW] and d_pre_ray [R_total, VW] (sums over the ray's samples of
+ * w_j g and of g, g = d pre_v) unscaled, overwritten or (accumulate) added to; part: danbo_anerf_color_bwd_part_floats(nrays, VW)
+ * floats of per-wavefront sums for danbo_anerf_rgb_reduce (-> d rgb_linear.weight / .bias, passes concatenated) */
+long danbo_anerf_color_bwd_part_floats(int nrays, int VW);
+int danbo_anerf_color_bwd(const float* d_raw, const float* hv, const float* w, int R_total, int nrays, int S, int VW, const float* rgb_w,
+                          const float* raw_max, float* sig_top, float* d_featv, float* d_alpha_out, int ld_dalpha, float* dC,
+                          float* d_pre_ray, int accumulate, float* part, void* stream);
+int danbo_anerf_rgb_reduce(const float* part, long part_floats, int VW, float* g_rgb_w, float* g_rgb_b, void* stream);
+/* table_ray[ray] = views_linears.0.bias + views_linears.0.weight[:, code0 : code0 + code_size] codes[cam_idx[ray]] (Optcodes in
+ * training mode, core/networks/embedding.py:24-39; code_size = 0: the bias) and the adjoint: the code columns' and the bias'
+ * gradient, framecodes.codes.weight's rows (g_codes zero on entry; rays of one camera added in ray order, no atomics) */
+int danbo_anerf_ray_table(const float* views_w, int ld, int code0, int code_size, const float* views_b, const float* codes, int n_codes,
+                          const int64_t* cam_idx, int R, int VW, float* table_ray, void* stream);
+int danbo_anerf_code_grads(const float* d_pre_ray, const float* views_w, int ld, int code0, int code_size, const float* codes,
+                           int n_codes, const int64_t* cam_idx, int R, int VW, float* g_views_w, float* g_views_b, float* g_codes,
+                           float* v_scratch /*[R, code_size]*/, void* stream);
+/* dz = t . [y > 0] . rho, n floats (n % 4 == 0): rho = 1 (prev_max NULL) or the power of two that brings *prev_max to [64, 128);
+ * *sig_out = *sig_in * rho; *max_out = max(*max_out, max |dz|) */
+int danbo_anerf_relu_mask(const float* t, const float* y, long n, const float* prev_max, const float* sig_in, float* sig_out,
+                          float* max_out, float* dz, void* stream);
+/* d_all [R (S + Sf), 4]: rows r S + s (coarse) then R S + r Sf + s (importance) <- d_sorted [R, S + Sf, 4] through `order`
+ * (+ d_c0 [R, S, 4], the coarse composite's own gradient); *max_out = max |d_all| */
+int danbo_anerf_unmerge(const float* d_sorted, const float* d_c0, const int32_t* order, int R, int S, int Sf, float* d_all,
+                        float* max_out, void* stream);
+/* danbo_anerf_encode_fwd with tau read from DEVICE memory when the kernel runs (the module's `tau` buffer: update_tau changes it
+ * every step, core/cutoff_embedder.py:221-223, and a by-value argument is frozen inside a captured graph) */
+int danbo_anerf_encode_fwd_dtau(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
+                                const float* skts, const float* align, const float* cutoff, const float* tau_dev, int L, long row0,
+                                int nrows, float* x0, float* w_out, void* stream);
+
+/* C [M, N] (row stride ldc) = A B (+ bias[n]) with A[m, k] = A[m sa_m + k sa_k], B[k, n] = B[k sb_k + n sb_n]: float32 operands,
+ * the sum over k in ascending order accumulated in float64, rounded once.  For the parameter-sized products of a weight refresh
+ * (folded head matrices, per-camera tables); one thread per output. */
+int danbo_small_matmul(const float* A, long sa_m, long sa_k, const float* B, long sb_k, long sb_n, const float* bias, int M, int N, int K,
+                       float* C, long ldc, void* stream);
+
+#define DANBO_ANERF_MAX_D 8
+typedef struct DanboAnerfTrainModel {
+    int D, W, VW, skip /* pts_linears[skip + 1] takes [density inputs | h]; -1: none */, L, L_view, n_codes, code_size /*0: no frame codes*/;
+    const float *pts_w[DANBO_ANERF_MAX_D], *pts_b[DANBO_ANERF_MAX_D];
+    const float *alpha_w, *alpha_b, *feature_w, *feature_b, *views_w /*[VW, W + 72 (1 + 2 L_view) + code_size]*/, *views_b, *rgb_w, *rgb_b,
+        *codes;
+    float *g_pts_w[DANBO_ANERF_MAX_D], *g_pts_b[DANBO_ANERF_MAX_D];
+    float *g_alpha_w, *g_alpha_b, *g_feature_w, *g_feature_b, *g_views_w, *g_views_b, *g_rgb_w, *g_rgb_b, *g_codes;
+    float* g_flat;                 /* the flat gradient buffer all g_* point into: zeroed at the start of the step */
+    long n_flat;
+    const float *align /*[24,4,4]*/, *cutoff /*[24]: pe_fn.cutoff_dist*/, *tau /*DEVICE scalar: pe_fn.tau*/;
+    int loss_mse /*0: L1*/, use_background;
+    float density_scale, rgb_loss_coef, coarse_weight;
+} DanboAnerfTrainModel;
+/* One A-NeRF training batch: forward (bounds, stratified depths, encoders, trunk, heads, composite, importance depths, second pass,
+ * merged composite), the two rgb losses, backward into g_flat.  DanboTrainBatch / DanboTrainOut as danbo_train_step (bones unused;
+ * loss[2] = loss[3] = 0; counts ignored).  Enqueues ~110 kernels on `stream`, nothing synchronises: the step can be captured into
+ * a HIP graph.  S >= 3, S + Sf <= 256, W % 4 == 0, W <= 508, VW % 4 == 0, VW <= 256. */
+size_t danbo_anerf_train_workspace(const DanboAnerfTrainModel* model, int R, int G, int S, int Sf, int chunk);
+int danbo_anerf_train_step(const DanboAnerfTrainModel* model, const DanboTrainBatch* batch, const DanboTrainOut* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* the step's sampling decisions inside `workspace` (as danbo_train_workspace_view; bits_* are NULL: A-NeRF has no in-volume mask) */
+int danbo_anerf_train_workspace_view(const DanboAnerfTrainModel* model, int R, int G, int S, int Sf, int chunk, void* workspace,
+                                     DanboTrainView* view);
 
 /* ---------------------------------------------------------------------------------------------
  * The whole eval chain of one ray batch behind one call: RayCaster.render_rays (core/raycasters.py:245-377) with the DANBO

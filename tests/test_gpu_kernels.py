@@ -50,7 +50,7 @@ def test_library_and_device(ops):
     import ctypes
     from core import _hip
     l = _hip.lib()
-    assert l.danbo_abi_version() == 7
+    assert l.danbo_abi_version() == 8
     cu, lds = ctypes.c_int(), ctypes.c_int()
     arch = ctypes.create_string_buffer(64)
     assert l.danbo_device_info(ctypes.byref(cu), ctypes.byref(lds), arch, 64) == 0

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/danbo_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
-    assert lib.danbo_abi_version() == 7
+    assert lib.danbo_abi_version() == 8
     # argument counts of the ctypes table match the header
     for name in declared:
         m = re.search(r"(?:int|size_t|long)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
