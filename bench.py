@@ -453,6 +453,25 @@ def bench_render(args, rank, world, device, dist):
             # every output of the timed (culled, rays-of-constants) frame against the frame that evaluates every sample of every ray
             result["dense_equals_culled"] = bool(all(torch.equal(out_d[k], out[k]) for k in out if torch.is_tensor(out[k]) and k in out_d))
             result["dense_equals_culled_outputs"] = sorted(k for k in out if torch.is_tensor(out[k]) and k in out_d)
+        if sparsity["rays_of_constants"] > 0:
+            # the headline leans on a property of the weights (empty-space density <= 0 makes 63 % of the rays "rays of
+            # constants").  The same frame with that shortcut OFF -- what a checkpoint whose PE(0) density is slightly positive costs:
+            # every ray gets view constants, resampling and both composites (DanboEngine.skip_flat_rays; bit-identical outputs)
+            eng.skip_flat_rays = False
+            for _ in range(5):
+                out_nf = render(eng, inp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out_nf = render(eng, inp)
+            torch.cuda.synchronize()
+            tnf = (time.perf_counter() - t1) / args.steps
+            eng.skip_flat_rays = True
+            result["ms_no_flat_rays"] = 1e3 * tnf
+            result["value_no_flat_rays"] = samples_per_frame / tnf
+            result["no_flat_rays_equals_timed"] = bool(all(torch.equal(out_nf[k], out[k]) for k in out if torch.is_tensor(out[k]) and k in out_nf))
+            result["no_flat_rays_note"] = ("the same frame with DanboEngine.skip_flat_rays = False (one block of --steps frames): every ray is "
+                                           "resampled and composited, as for weights whose empty-space density is positive")
         if not args.no_sweep:
             # the headline rides on how much of the frame the body fills: the same frame from nearer / farther cameras
             sweep = []
@@ -673,7 +692,79 @@ def bench_train(args, rank, world, device, dist):
         result["hbm"] = hbm
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_train(targs, caster, batch, poses)
+        restore()
+        result["parity"] = train_parity_block(targs, caster, trainer, batch, poses, device)
+        result["parity_ok"] = result["parity"]["parity_ok"]
+        restore()
     return result
+
+
+def train_parity_block(targs, caster, trainer, batch, poses, device, n_poses=2):
+    """Config 4 against the float64 arbiter (the line had no parity field): ONE fused step (danbo_train_step, eager,
+    the snapshot's weights) on a 2-pose / 384-ray shard of the bench batch with the step's random draws supplied (fixed_draws: the
+    arbiter needs the same stratified offsets, inverse-CDF uniforms and density noise), and oracle/torch_f64_train.py on the same
+    shard at the depths / merge order / min(sum w, 1) branches the step took: the four loss terms and the gradient norms of one tensor
+    per sub-network, plus the worst entry-wise gradient error over ALL tensors relative to the tensor's largest entry (one float64
+    evaluation, ReLU kinks not bracketed: a unit within fp32 round-off of zero moves a tensor by ~1e-3 of its max at this batch size).
+    Checker code: the float64 graph runs as torch kernels on the GPU beside the path under test; nothing here is timed."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_f64_train as t64
+    from core import _hip
+    from core.utils import synthetic as syn
+    eng = trainer.engine
+    R = n_poses * 192
+    S, Sf = int(targs.N_samples), int(targs.N_importance)
+    b = {k: (v[:R] if torch.is_tensor(v) else v) for k, v in batch.items()}
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    B = float(targs.density_scale)
+    dr = lambda *shape: torch.rand(*shape, generator=gen).to(device)  # noqa: E731
+    dn = lambda *shape: (torch.randn(*shape, generator=gen) * float(targs.raw_noise_std) * B).to(device)  # noqa: E731
+    draws = dict(t_rand=dr(R, S), u_rand=dr(R, Sf), noise_c=dn(R, S), noise_f=dn(R, S + Sf))
+    pp = lambda x: x[::192]  # noqa: E731
+    eng.fixed_draws = draws
+    try:
+        out = eng.forward_backward(b["rays_o"], b["rays_d"], pp(b["skts"]), pp(b["bones"]), pp(b["cyls"]), b["cam_idxs"], b["target_s"], b["bgs"],
+                                   S, Sf, perturb=float(targs.perturb), raw_noise_std=float(targs.raw_noise_std))
+        torch.cuda.synchronize()
+    finally:
+        eng.fixed_draws = None
+    grads = {n: p.grad.detach().double().cpu().numpy() for n, p in caster.network.named_parameters() if p.requires_grad}
+    v = _hip.DanboTrainView()
+    _hip.check(_hip.lib().danbo_train_workspace_view(ctypes.byref(eng._model()), R, n_poses, S, Sf, R, ctypes.c_void_p(eng._ws.data_ptr()),
+                                                     ctypes.byref(v)), "danbo_train_workspace_view")
+    base = eng._ws.data_ptr()
+    at = lambda ptr, shape, dt: eng._ws[ptr - base:ptr - base + 4 * int(np.prod(shape))].view(dt).view(shape).cpu().numpy()  # noqa: E731
+    z_c, z_f, order = at(v.z_coarse, (R, S), torch.float32), at(v.z_fine, (R, Sf), torch.float32), at(v.order, (R, S + Sf), torch.int32)
+    sd = {k: t.detach().cpu().numpy() for k, t in caster.network.state_dict().items()}
+    coef = dict(loss_fn=targs.loss_fn, use_background=bool(targs.use_background), rgb_loss_coef=float(targs.rgb_loss_coef),
+                coarse_weight=float(targs.coarse_weight), soft_softmax_loss_coef=float(targs.soft_softmax_loss_coef),
+                vol_scale_penalty=float(targs.vol_scale_penalty) if targs.opt_vol_scale else 0.0)
+    nb = {k: b[k].detach().cpu().numpy() for k in ("rays_o", "rays_d", "skts", "bones", "target_s", "bgs", "cam_idxs")}
+    ref = t64.step(syn.model_config("danbo_perfcap"), coef, sd, caster.transforms[0].cpu().numpy(), caster.network.graph_net.init_scale.cpu().numpy(),
+                   nb, z_c, z_f, order, n_poses, noise_c=draws["noise_c"].cpu().numpy(), noise_f=draws["noise_f"].cpu().numpy(), device=str(device),
+                   clamped_c=out["acc0"].cpu().numpy() >= 1.0, clamped_f=out["acc_map"].cpu().numpy() >= 1.0)
+    ls = out["loss"].double().cpu().numpy()
+    ours = {"rgb_loss": ls[0], "rgb_loss0": ls[1], "soft_softmax_loss": ls[2] * coef["soft_softmax_loss_coef"] / (R * (S + Sf)), "vol_scale_loss": ls[3]}
+    loss = {k: dict(hip=float(ours[k]), float64=float(ref["loss"][k]), rel=float(abs(ours[k] - ref["loss"][k]) / max(abs(ref["loss"][k]), 1e-12)))
+            for k in ours if k in ref["loss"]}
+    norms = {}
+    for n in ("pts_linears.4.weight", "graph_net.layers.3.weight", "prob_linears.layers.1.weight"):
+        a, r = float(np.sqrt((grads[n] ** 2).sum())), float(np.sqrt((ref["grads"][n] ** 2).sum()))
+        norms[n] = dict(hip=a, float64=r, rel=abs(a - r) / max(r, 1e-30))
+    worst, worst_name = 0.0, None
+    for n, r in ref["grads"].items():
+        if n in grads and np.abs(r).max() > 0:
+            e = float(np.abs(grads[n] - r).max() / np.abs(r).max())
+            if e > worst:
+                worst, worst_name = e, n
+    LOSS_BOUND, NORM_BOUND, TENSOR_BOUND = 2e-4, 2e-3, 2e-2
+    ok = all(x["rel"] <= LOSS_BOUND for x in loss.values()) and all(x["rel"] <= NORM_BOUND for x in norms.values()) and worst <= TENSOR_BOUND
+    return dict(against="oracle/torch_f64_train.py (float64 autograd, the reference's graph) on a 2-pose / 384-ray shard of the bench batch, at the "
+                        "fused step's own depths, merge order and random draws", rays=R, loss_terms=loss, gradient_norms=norms,
+                worst_gradient_entry_rel_to_tensor_max=worst, worst_gradient_tensor=worst_name,
+                max_abs_rgb=float(np.abs(out["rgb_map"].cpu().numpy() - ref["rgb_map"]).max()),
+                bounds=dict(loss_rel=LOSS_BOUND, gradient_norm_rel=NORM_BOUND, gradient_entry_rel_to_max=TENSOR_BOUND), parity_ok=bool(ok))
 
 
 def cpu_baseline_train(targs, caster, batch, poses, n_poses=2):
@@ -774,13 +865,65 @@ def bench_anerf(args, rank, world, device, dist):
         n_rays = 4096
         dt, (r0, ref) = best_of(lambda: run(n_rays))
         rgb = out["rgb_map"][r0:r0 + n_rays].cpu().numpy()
+        parity5 = anerf_parity_block(cfg, sd, rest, scene, ro, rd, r0, n_rays, S, Sf, eng, inp, out, model)
         result["cpu_baseline"] = dict(value=n_rays * (S + Sf) / dt, unit="ray-samples/s", cores=int(torch.get_num_threads()),
                                       host_cpu_count=os.cpu_count(), kind="port",
                                       sample=f"{n_rays} centre rays x {S}+{Sf} samples of the same frame through oracle/torch_cpu.AnerfTorchCPU "
                                              f"(torch CPU kernels, {torch.get_num_threads()} threads), 4096-ray chunks, best of 3: {dt:.2f} s")
         result["parity"] = dict(against="oracle/torch_cpu.AnerfTorchCPU on the cpu_baseline sample", rays=n_rays,
-                                psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])), max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()))
+                                psnr_rgb_db=float(o.psnr(rgb, ref["rgb_map"])), max_abs_rgb=float(np.abs(rgb - ref["rgb_map"]).max()), **parity5)
+        result["parity_ok"] = parity5["parity_ok"]
     return result
+
+
+def anerf_parity_block(cfg, sd, rest, scene, ro, rd, r0, n_rays, S, Sf, eng, inp, frame, model):
+    """Config 5 at the RAW level (its line carried maps only): the HIP path's coarse-pass logits on the cpu_baseline
+    sample against oracle/torch_cpu.AnerfTorchCPU in float32 and in float64 (the same graph on the float32 points), at the HIP path's
+    own depths and with the oracle's near / far fed in -- the dictionary configs 1 - 3 carry (parity_block), minus the in-volume mask
+    A-NeRF does not have.  Checker code: nothing here is timed."""
+    import torch_cpu
+    from core.utils import synthetic as syn
+    sl = slice(r0, r0 + n_rays)
+    z0 = np.zeros(n_rays, dtype=np.int64)
+    rb = syn.ray_batch(ro[sl], rd[sl])
+    ref = model.render(rb, scene["skts"][z0], scene["bones"][z0], scene["cyls"][z0], np.zeros(n_rays, np.int64), 1, S, Sf, stages=True)
+    m64 = torch_cpu.AnerfTorchCPU(cfg, sd, rest, dtype=torch.float64)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v, dtype=np.float32))  # noqa: E731
+    with torch.no_grad():
+        r64 = np.concatenate([m64.forward(t(ref["pts_coarse"][a:a + 1024]), t(rb[a:a + 1024, 3:6]), t(scene["skts"][z0[a:a + 1024]]),
+                                          np.zeros(min(1024, n_rays - a), np.int64)).numpy() for a in range(0, n_rays, 1024)])
+    rr = ref["raw_coarse"]
+    dev = inp["rays_o"].device
+    args5 = (inp["rays_o"][sl], inp["rays_d"][sl], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"][sl], S, Sf)
+    own = eng.render(*args5, keep=True)
+    near_o, far_o = ref["near"][:, 0], ref["far"][:, 0]
+    near_g, far_g = own["near"].cpu().numpy().reshape(-1), own["far"].cpu().numpy().reshape(-1)
+    same = (near_g == near_o) & (far_g == far_o)
+    at_oracle = eng.render(*args5, near_far=(torch.tensor(near_o, device=dev), torch.tensor(far_o, device=dev)), keep=True)
+    p = dict(max_abs_near=float(np.abs(near_g - near_o).max()), max_abs_far=float(np.abs(far_g - far_o).max()),
+             bounds_bit_equal_rays=int(same.sum()),
+             max_abs_acc=float(np.abs(frame["acc_map"][sl].cpu().numpy() - ref["acc_map"]).max()),
+             sample_render_equals_frame=bool(torch.equal(own["rgb_map"], frame["rgb_map"][sl])))
+    for tag, o_ in (("own_depths", own), ("oracle_depths", at_oracle)):
+        raw = o_["raw_coarse"].cpu().numpy()
+        f32_fl, f32_un = raw_measures(raw, rr)
+        f64_fl, f64_un = raw_measures(raw, r64)
+        p[tag] = dict(max_rel_raw_floored_5pct=f32_fl, max_rel_raw=f32_un, max_rel_raw_floored_5pct_vs_float64=f64_fl, max_rel_raw_vs_float64=f64_un)
+    d = p["oracle_depths"]
+    ok = d["max_rel_raw_floored_5pct"] <= PARITY_BOUND and d["max_rel_raw_floored_5pct_vs_float64"] <= PARITY_BOUND \
+        and p["max_abs_near"] <= BOUNDS_BOUND and p["max_abs_far"] <= BOUNDS_BOUND
+    timed_ok = float(np.abs(frame["rgb_map"][sl].cpu().numpy() - ref["rgb_map"]).max()) <= MAPS_BOUND and p["max_abs_acc"] <= MAPS_BOUND
+    if same.any():
+        t32, _ = raw_measures(own["raw_coarse"].cpu().numpy()[same], rr[same])
+        t64_, _ = raw_measures(own["raw_coarse"].cpu().numpy()[same], r64[same])
+        p["timed_frame_bit_equal_bound_rays"] = dict(rays=int(same.sum()), max_rel_raw_floored_5pct=t32, max_rel_raw_floored_5pct_vs_float64=t64_)
+        timed_ok = timed_ok and t32 <= PARITY_BOUND and t64_ <= PARITY_BOUND
+    p.update(restatement_fp32_vs_float64_floored_5pct=raw_measures(rr, r64)[0], max_rel_raw=d["max_rel_raw"],
+             max_rel_raw_floored_5pct=d["max_rel_raw_floored_5pct"], max_rel_raw_vs_float64=d["max_rel_raw_vs_float64"],
+             max_rel_raw_floored_5pct_vs_float64=d["max_rel_raw_floored_5pct_vs_float64"], decided_by="oracle_depths", bound=PARITY_BOUND,
+             bounds_bound=BOUNDS_BOUND, maps_bound=MAPS_BOUND, parity_ok_timed_frame=bool(timed_ok), parity_ok=bool(ok and timed_ok),
+             raw_note="coarse-pass logits of every sample (A-NeRF has no in-volume mask); measures as configs 1 - 3 (bench.parity_block)")
+    return p
 
 
 def launch_ranks(args, argv):

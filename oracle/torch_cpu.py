@@ -172,11 +172,13 @@ class AnerfTorchCPU:
     core/cutoff_embedder.py:151-214) on torch's CPU kernels -- bench.py's timed cpu_baseline of config 5.  Every sample is
     evaluated (A-NeRF has no in-volume mask).  Checked against the numpy AnerfOracle in tests/test_oracle_anerf.py."""
 
-    def __init__(self, cfg, sd, rest_pose, netchunk=65536):
-        self.cfg, self.netchunk = cfg, netchunk
+    def __init__(self, cfg, sd, rest_pose, netchunk=65536, dtype=torch.float32):
+        """dtype=torch.float64: the same graph evaluated in float64 on the float32 inputs (bench.py's parity block: the exact result
+        of the reference's arithmetic on those points)"""
+        self.cfg, self.netchunk, self.dtype = cfg, netchunk, dtype
         self.np_oracle = o.AnerfOracle(cfg, sd, rest_pose)
-        self.sd = {k: torch.tensor(np.asarray(v, dtype=np.float32)) for k, v in sd.items() if np.asarray(v).dtype != np.int64}
-        self.align = torch.tensor(self.np_oracle.align.astype(np.float32))
+        self.sd = {k: torch.tensor(np.asarray(v, dtype=np.float32)).to(dtype) for k, v in sd.items() if np.asarray(v).dtype != np.int64}
+        self.align = torch.tensor(self.np_oracle.align.astype(np.float32)).to(dtype)
 
     def _cutoff_pe(self, x, v, cutoff, tau, L, dist):
         """dist: x = v -> [cutoff - v, sin / cos of 2^l (shifted)] * w;  else x = directions [M,72], w from v repeated x 3"""
@@ -211,6 +213,7 @@ class AnerfTorchCPU:
 
     def forward(self, pts, rays_d, skts, cam_idxs):
         cfg, sd = self.cfg, self.sd
+        pts, rays_d, skts = pts.to(self.dtype), rays_d.to(self.dtype), skts.to(self.dtype)
         R, S = pts.shape[:2]
         M = R * S
         pl = torch.einsum('rjab,rsb->rsja', skts[:, :, :3, :3], pts) + skts[:, None, :, :3, 3]
@@ -229,8 +232,9 @@ class AnerfTorchCPU:
         return self._mlp(dens_in, vin).reshape(R, S, 4)
 
     @torch.no_grad()
-    def render(self, ray_batch, skts, bones, cyls, cam_idxs, n_uniques, S, Sf, chunk=4096):
-        outs = []
+    def render(self, ray_batch, skts, bones, cyls, cam_idxs, n_uniques, S, Sf, chunk=4096, stages=False):
+        """stages: also near / far [R,1], z_coarse [R,S], pts_coarse [R,S,3] (float32) and the coarse pass' raw [R,S,4]"""
+        outs, st = [], []
         t = lambda v: torch.tensor(np.ascontiguousarray(v, dtype=np.float32))  # noqa: E731
         for a in range(0, ray_batch.shape[0], chunk):
             sl = slice(a, min(a + chunk, ray_batch.shape[0]))
@@ -239,13 +243,20 @@ class AnerfTorchCPU:
             z = o.coarse_z(near, far, S)
             ro, rd, sk, zt = t(rb[:, 0:3]), t(rb[:, 3:6]), t(skts[sl]), t(z)
             cam = None if cam_idxs is None else cam_idxs[sl]
-            raw = self.forward(ro[:, None] + rd[:, None] * zt[..., None], rd, sk, cam)
+            pts_c = ro[:, None] + rd[:, None] * zt[..., None]
+            raw = self.forward(pts_c, rd, sk, cam).float()
+            if stages:
+                st.append((near, far, z, pts_c.numpy(), raw.numpy()))
             out0 = DanboTorchCPU._composite(raw, zt, rd, self.cfg['density_scale'])
             z_all, z_fine, order = o.importance_z(z, out0['weights'].numpy(), Sf)
             zf = t(z_fine)
-            raw_f = self.forward(ro[:, None] + rd[:, None] * zf[..., None], rd, sk, cam)
+            raw_f = self.forward(ro[:, None] + rd[:, None] * zf[..., None], rd, sk, cam).float()
             raw_all = torch.gather(torch.cat([raw, raw_f], 1), 1, torch.as_tensor(order)[..., None].expand(-1, -1, 4).long())
             out = DanboTorchCPU._composite(raw_all, t(z_all), rd, self.cfg['density_scale'])
             outs.append((out['rgb_map'].numpy(), out['acc_map'].numpy(), out0['rgb_map'].numpy()))
-        return dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
-                    rgb0=np.concatenate([x[2] for x in outs]))
+        ret = dict(rgb_map=np.concatenate([x[0] for x in outs]), acc_map=np.concatenate([x[1] for x in outs]),
+                   rgb0=np.concatenate([x[2] for x in outs]))
+        if stages:
+            for i, k in enumerate(("near", "far", "z_coarse", "pts_coarse", "raw_coarse")):
+                ret[k] = np.concatenate([x[i] for x in st])
+        return ret

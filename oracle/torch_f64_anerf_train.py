@@ -56,7 +56,7 @@ def network(cfg, p, pt, rays_d, skts_ray, cam_idx, tau, kinks=None):
     d = torch.nn.functional.normalize(torch.einsum('rjab,rb->rja', skts_ray[:, :, :3, :3], rays_d), dim=-1).reshape(R, 3 * J)
     vin = _cutoff_pe(d.repeat_interleave(S, 0), v, p['dirs_pe_fn.cutoff_dist'], tau, cfg['multires_views'], False)
     if cfg['use_framecode']:
-        code = p['framecodes.codes.weight'][torch.as_tensor(np.asarray(cam_idx).reshape(-1)).long()]
+        code = p['framecodes.codes.weight'][torch.as_tensor(np.asarray(cam_idx).reshape(-1), device=pt.device).long()]
         vin = torch.cat([vin, code.repeat_interleave(S, 0)], -1)
     h = x0
     for i in range(cfg['D']):
@@ -68,8 +68,10 @@ def network(cfg, p, pt, rays_d, skts_ray, cam_idx, tau, kinks=None):
     return torch.cat([lin('rgb_linear', hv), alpha], -1).reshape(R, S, 4).to(dt)
 
 
-def composite(raw, z, rays_d, B, noise=None):
-    """NeRF.raw2outputs (nerf.py:281-347) -> rgb_map, acc_map (the two outputs with a gradient), weights, alpha"""
+def composite(raw, z, rays_d, B, noise=None, clamped=None):
+    """NeRF.raw2outputs (nerf.py:281-347) -> rgb_map, acc_map (the two outputs with a gradient), weights, alpha.  clamped [R] bool or
+    None: the branch of acc = min(sum w, 1) the path under test took per ray (an opaque ray sits exactly on that kink, see
+    torch_f64_train.step); None: float64's own min()"""
     d = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1) * torch.norm(rays_d, dim=-1, keepdim=True)
     rgb = torch.sigmoid(raw[..., :3]) * 1.002 - 0.001
     dens = raw[..., 3] / B
@@ -77,16 +79,19 @@ def composite(raw, z, rays_d, B, noise=None):
         dens = dens + noise
     alpha = 1.0 - torch.exp(-torch.relu(dens) * d)
     w = alpha * torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
-    acc = w.sum(-1)
-    return dict(rgb_map=(w[..., None] * rgb).sum(-2), acc_map=torch.clamp(acc, max=1.0), weights=w, alpha=alpha)
+    sw = w.sum(-1)
+    acc = torch.clamp(sw, max=1.0) if clamped is None else torch.where(clamped, torch.ones_like(sw), sw)
+    return dict(rgb_map=(w[..., None] * rgb).sum(-2), acc_map=acc, weights=w, alpha=alpha)
 
 
-def step(cfg, sd, rest_pose, batch, z_c, z_f, order, args, noise_c=None, noise_f=None, kinks=None):
+def step(cfg, sd, rest_pose, batch, z_c, z_f, order, args, noise_c=None, noise_f=None, kinks=None, device='cpu', clamped_c=None,
+         clamped_f=None):
     """batch: dict(rays_o, rays_d [R,3], skts [G,24,4,4] per pose, cam_idx [R], target [R,3], bgs [R,3] or None); z_c [R,S],
     z_f [R,Sf], order [R,S+Sf] from the path under test; args: dict(loss_fn, use_background, rgb_loss_coef, coarse_weight,
     density_scale, tau) -> dict(loss={rgb_loss, rgb_loss0, total_loss}, grads={name: float64 array}, rgb_map, acc_map, rgb0)"""
     dt = _dtype()
-    T = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=dt)  # noqa: E731
+    T = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=dt, device=device)  # noqa: E731
+    as_mask = lambda m: None if m is None else torch.as_tensor(np.asarray(m, dtype=bool), device=device)  # noqa: E731
     names = [k for k, v in sd.items() if np.asarray(v).dtype.kind == 'f' and not k.endswith('.tau') and 'cutoff_dist' not in k]
     p = {k: T(sd[k]).requires_grad_(True) for k in names}
     p['pe_fn.cutoff_dist'], p['dirs_pe_fn.cutoff_dist'] = T(sd['pe_fn.cutoff_dist']), T(sd['dirs_pe_fn.cutoff_dist'])
@@ -105,13 +110,13 @@ def step(cfg, sd, rest_pose, batch, z_c, z_f, order, args, noise_c=None, noise_f
         return network(cfg, p, T(pt), T(rd), T(skts_ray), batch.get('cam_idx'), tau, kinks)
 
     raw_c, raw_f = pass_(z_c), pass_(z_f)
-    out0 = composite(raw_c, T(z_c), T(rd), B, None if noise_c is None else T(noise_c))
-    idx = torch.as_tensor(np.asarray(order)).long()
+    out0 = composite(raw_c, T(z_c), T(rd), B, None if noise_c is None else T(noise_c), as_mask(clamped_c))
+    idx = torch.as_tensor(np.asarray(order), device=device).long()
     raw_all = torch.gather(torch.cat([raw_c, raw_f], 1), 1, idx[..., None].expand(-1, -1, 4))
     z_all = torch.gather(torch.cat([T(z_c), T(z_f)], 1), 1, idx)
-    out = composite(raw_all, z_all, T(rd), B, None if noise_f is None else T(noise_f))
+    out = composite(raw_all, z_all, T(rd), B, None if noise_f is None else T(noise_f), as_mask(clamped_f))
     target = T(batch['target'])
-    bgs = T(batch['bgs']) if batch.get('bgs') is not None else torch.ones((), dtype=dt)
+    bgs = T(batch['bgs']) if batch.get('bgs') is not None else torch.ones((), dtype=dt, device=device)
 
     def nerf_loss(rgb, acc, w):
         if args['use_background']:
@@ -122,9 +127,9 @@ def step(cfg, sd, rest_pose, batch, z_c, z_f, order, args, noise_c=None, noise_f
             'rgb_loss0': nerf_loss(out0['rgb_map'], out0['acc_map'], float(args['coarse_weight']))}
     loss['total_loss'] = loss['rgb_loss'] + loss['rgb_loss0']
     loss['total_loss'].backward()
-    grads = {k: (v.grad.numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)) for k, v in p.items() if v.requires_grad}
-    return dict(loss={k: float(v.detach()) for k, v in loss.items()}, grads=grads, rgb_map=out['rgb_map'].detach().numpy(),
-                acc_map=out['acc_map'].detach().numpy(), rgb0=out0['rgb_map'].detach().numpy())
+    grads = {k: (v.grad.cpu().numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)) for k, v in p.items() if v.requires_grad}
+    return dict(loss={k: float(v.detach()) for k, v in loss.items()}, grads=grads, rgb_map=out['rgb_map'].detach().cpu().numpy(),
+                acc_map=out['acc_map'].detach().cpu().numpy(), rgb0=out0['rgb_map'].detach().cpu().numpy())
 
 
 def step_bracketed(*args, **kw):

@@ -242,6 +242,26 @@ def test_bench_config4_strong_scaling_on_two_ranks_of_one_gpu():
     assert r["value"] > 0 and r["loss"] == r["loss"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["1", "4"])
+def test_bench_weak_scaling_on_two_ranks_of_one_gpu(config):
+    """the N > 1 path of the HEADLINE config (1: the frame, every rank its own camera view, no collective) and of
+    config 4 weak (every rank its own 3072-ray batch, two in-place all-reduces per step) through the real launcher with two ranks that
+    share cuda:0 (gloo carries the collectives): one line, ranks_seen = 2, per-rank lists present, and -- two ranks taking turns on one
+    device -- a whole-job value close to what one rank alone reaches."""
+    flags = ("--config", config, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-dense", "--no-sweep", "--no-api")
+    two = _run_bench("--gpus", "2", "--debug-single-device", *flags)
+    one = _run_bench("--gpus", "1", *flags)
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    assert len(two["ms_per_step_ranks"]) == 2 and len(two["slowest_rank_per_block"]) == 5 and all(r in (0, 1) for r in two["slowest_rank_per_block"])
+    assert two["config"]["parallelism"].endswith("dp2") and two["config"]["rays"] == 2 * one["config"]["rays"] if config == "4" else True
+    # the device is shared: each rank's step takes about twice as long, the job processes twice the units -> about the one-rank rate
+    assert 0.6 * one["value"] <= two["value"] <= 1.35 * one["value"], (one["value"], two["value"])
+    assert 1.5 * one["ms_per_step"] <= two["ms_per_step"] <= 3.4 * one["ms_per_step"], (one["ms_per_step"], two["ms_per_step"])
+    if config == "4":
+        assert two["collective_ms"] is not None and two["collective_ms"]["steps_measured"] >= 5 and "gloo" in two["collectives"]
+
+
 def _nccl_world1_worker(port, q):
     """ONE rank, backend "nccl" (= RCCL on ROCm), cuda:0: the data-parallel form of Trainer.train_batch -- split step as two HIP
     graphs, the first in-place all-reduce on the comm side stream under phase 2, the second behind it, 1 / world folded into Adam --
