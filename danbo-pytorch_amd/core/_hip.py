@@ -59,6 +59,7 @@ SIGNATURES = {
     "danbo_linear16_fwd_frag": [P, I, I, P, I, I, P, P, I, I, P, I, I, P, I, P],
     "danbo_linear16_pack_enc": [P, c_long, c_long, I, I, I, I, P, P],
     "danbo_linear16_fwd_enc": [P, I, P, I, P, P, I, I, P, I, P, P],
+    "danbo_linear16_fwd_color": [P, I, P, P, I, I, P, P, P, P, I, I, I, I, P, P, P, P],
     "danbo_render_frame_workspace": [I, I, I, I, I, I],
     "danbo_render_frame": [P, P, I, I, P, P, c_size_t, P],
     # ---- training step

@@ -148,6 +148,12 @@ class AnerfEngine:
                 x0, w = ops.anerf_encode(rays_o, rays_d, skts, self.align, self.cutoff, tau, self.L, r0 * S, n, z=z, pts=pts,
                                          out=buf)
             h = self._trunk(x0)
+            if self.frag and not density_only and S % 16 == 0 and self.VW % 16 == 0 and self.VW <= 240:
+                # the colour head as the EPILOGUE of the head layer: its (VW + 1)-wide rows never reach memory (round 5: written by
+                # the layer and read back by k_anerf_color, 1.8 GB per 1 M-row chunk and 6 % of the frame)
+                ops.linear16_color(h, self.head[0], self.head[1], self.head_b, w, C, self.table,
+                                   cam_idx if self.cfg["use_framecode"] else None, r0, S, self.rgb_w, self.rgb_b, raw)
+                continue
             head = ops.linear16(h, self.head[0], self.head[1], self.head_b, out=head_buf[:n, :self.VW + 1])
             if density_only:
                 dens[r0 * S:r0 * S + n] = head[:, self.VW:]

@@ -642,6 +642,22 @@ def anerf_color(featv, w, C, table, cam_idx, ray0, nrays, S, rgb_w, rgb_b, alpha
     return raw_out
 
 
+def linear16_color(h, packed, shape, bias, w, C, table, cam_idx, ray0, S, rgb_w, rgb_b, raw_out):
+    """A-NeRF's head layer with the colour head as its epilogue (danbo_linear16_fwd_color): h = FragBuffer [M, K1] (the trunk's last
+    activation), (packed, shape) = the (VW + 1)-wide head layer packed with frag_in 1; writes raw_out [R_total, S, 4] for the rays
+    [ray0, ray0 + M / S)"""
+    N, K1, K2 = shape
+    if not isinstance(h, FragBuffer) or h.C != K1 or K2:
+        raise ValueError("linear16_color: h must be the FragBuffer the layer was packed for")
+    VW, M = N - 1, h.M
+    if cam_idx is not None:
+        cam_idx = cam_idx.reshape(-1).to(torch.int64).contiguous()
+    _call("danbo_linear16_fwd_color", _p(h.data), K1, _p(packed), _p(_f32(bias, "bias")), VW, M, _p(_f32(w, "w")), _p(_f32(C, "C")),
+          _p(_f32(table, "table")), _p(cam_idx), table.shape[0] - 1, C.shape[1], int(ray0), int(S), _p(_f32(rgb_w, "rgb_w")),
+          _p(_f32(rgb_b, "rgb_b")), _p(raw_out), _stream())
+    return raw_out
+
+
 # -------------------------------------------------------------------------------------- dense layer (fp16-split MFMA)
 def linear16_pack(weight, K1=None, transposed=False, frag_in=(False, False)):
     """nn.Linear weight [N, K] (or, `transposed`, a [K, N] matrix used as W^T) -> packed fragment buffer.

@@ -398,7 +398,8 @@ class DanboTrainEngine:
                 if split:
                     self._step_phase(w, 2)
             cur.wait_stream(side)
-            g = torch.cuda.CUDAGraph()
+            # keep_graph: the captured hipGraph_t stays inspectable (raw_cuda_graph(); tests walk its edges: nothing may run beside K2)
+            g = torch.cuda.CUDAGraph(keep_graph=True) if getattr(self, 'keep_graph', False) else torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = self._launch(static, S, Sf, perturb, raw_noise_std, split)
             g2 = None

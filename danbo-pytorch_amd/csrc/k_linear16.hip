@@ -35,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int L16_CHUNK = 32768, L16_SLOTS = 4, L16_BM = 128, L16_THREADS = 512, L16_MAX_N = 512;
 constexpr int L16_LDS_BYTES = L16_SLOTS * L16_CHUNK + L16_MAX_N * 4;
+constexpr int L16_COLOR_LD = 256, L16_COLOR_LDS_BYTES = L16_LDS_BYTES + 3 * L16_COLOR_LD * 4;   // + rgb_linear.weight for the colour epilogue
 
 // ---------------------------------------------------------------------------------------------------------------
 // packing: chunk c = s * NH + hf holds k-step s of output tiles 16 hf .. 16 hf + 15:
@@ -105,6 +106,12 @@ struct Lin16Args {
     int frag;
     int enc_L;         // FRAG & 8: x1 is the A-NeRF encoder table [rows, 144] (k_anerf.hip), K1 = 448 slots of recomputed inputs, L levels
     long long* trace;  // dev tool (tools/micro_linear16.py --trace): s_memtime stamps of one wavefront, or nullptr
+    // FRAG & 16: A-NeRF's colour head as the EPILOGUE of its head layer (danbo_linear16_fwd_color): the layer's N = VW + 1 outputs
+    // (VW view features, then the density logit) never reach memory -- see the epilogue below
+    const float *c_w, *c_C, *c_table, *c_rgb_w, *c_rgb_b;
+    const int64_t* c_cam;
+    float* c_raw;
+    int c_ncodes, c_Rtot, c_ray0, c_S, c_VW;
 };
 
 struct LinPipe {
@@ -229,6 +236,46 @@ __device__ __forceinline__ void lin_group_skip(unsigned cbase, unsigned nbase) {
                      ::"v"(nb), "n"(NO), "n"(NO + 1024), "n"(NO + 2048), "n"(NO + 3072) : DANBO_A_CLOBBERS);
 }
 
+// FRAG & 16 (the colour epilogue below): tiles T0 .. T0 + NT - 1 of acc += A_T . B with A_T = this lane's 8 gathered values of tile T
+// (hi / lo split here), B = (wh, wl).  The gathers of the batch are requested together: one memory round trip per batch instead of
+// one per tile (the compiler waits for ITS loads by count; nothing else is in flight at that point).  The MFMAs are inline asm like
+// every MFMA of this kernel (a builtin makes the compiler budget AccVGPRs and leave the 208 registers it may use); `s_nop 1`: the
+// operands come from VALU instructions the hazard recognizer cannot pair with an asm statement; the three products accumulate in
+// place (back-to-back SrcC = vDst is interlocked by the hardware); MFMA_DRAIN: VALU instructions read the accumulators next.
+template <int T0, int NT, int NACC>
+__device__ __forceinline__ void lin_color_batch(f32x4 (&acc)[NACC], const float* const (&src)[8], int VW, int q, const half8& wh,
+                                                const half8& wl) {
+    // asm loads (immediate offsets on eight per-lane pointers) + ONE explicit wait: volatile asm statements keep their order, so at
+    // most this batch's 8 NT values are in flight -- the compiler's own scheduler would hoist every gather of the epilogue to the top
+    // (120 registers) and spill.  Tiles past VW (wave-uniform) are not loaded.
+    float cv[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (16 * (T0 + t) < VW) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(cv[t][e]) : "v"(src[e]), "n"(64 * (T0 + t)) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (16 * (T0 + t) < VW) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(cv[t][e]));      // defined by the loads above, not before
+            // (lane quarter 3: k-slots 25 .. 31 carry the table value again -- finite -- against weights that are exactly 0)
+            half8 ch, cl;
+            split8_mix(cv[t], ch, cl);
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
+                         : "+v"(acc[T0 + t]) : "v"(ch), "v"(cl), "v"(wh), "v"(wl));
+        }
+    }
+    asm volatile(DANBO_MFMA_DRAIN ::: "memory");
+}
+
 // NP: tile pairs in the last chunk of a k-step known at compile time (no branches in the batch loop), 0 = taken from N
 // FRAG: Lin16Args::frag as a compile-time constant (a run-time choice costs the registers this kernel does not have)
 // amdgpu_num_vgpr(208): v208 .. v223 belong to the row loads in flight, v224 .. v255 to group_mfma's fragment buffers
@@ -246,6 +293,9 @@ __global__ __launch_bounds__(L16_THREADS, 1) __attribute__((amdgpu_num_vgpr(208)
     const int G = my_tiles * KS;  // k-steps this workgroup runs
 
     for (int i = tid; i < L16_MAX_N; i += L16_THREADS) s_bias[i] = (a.bias != nullptr && i < a.N) ? a.bias[i] : 0.f;
+    float* s_rgb = s_bias + L16_MAX_N;                      // FRAG & 16: rgb_linear.weight [3][256] (columns >= VW zero)
+    if (FRAG & 16)
+        for (int i = tid; i < 3 * L16_COLOR_LD; i += L16_THREADS) s_rgb[i] = (i % L16_COLOR_LD) < a.c_VW ? a.c_rgb_w[(i / L16_COLOR_LD) * a.c_VW + i % L16_COLOR_LD] : 0.f;
 
     LinPipe p{a.packed + wave * 4096 + lane * 16, smem + wave * 4096, 0, 0, 0, KS * NH, 2};
     lin_issue(p);
@@ -391,6 +441,83 @@ __global__ __launch_bounds__(L16_THREADS, 1) __attribute__((amdgpu_num_vgpr(208)
         asm volatile(DANBO_MFMA_DRAIN ::: "memory");
 #pragma unroll
         for (int T = 0; T < 16 * NH; ++T) asm volatile("" : "+v"(acc[T]));
+        if (FRAG & 16) {
+            // A-NeRF's colour head as the epilogue of its head layer (reference nerf.py:196-209; what k_anerf_color did on the
+            // head's rows until round 5: 0.91 GB written and read back per 1 M-row chunk, 6 % of the frame).  The 16 rows of this
+            // wavefront are 16 consecutive samples of ONE ray (S % 16 == 0, chunks of whole rays), so the view layer's
+            // cutoff-weighted sum over the joints is one more k-step of the same GEMM:
+            //     pre_v^T [VW x 16] += C_ray^T [VW x 24] . w^T [24 x 16]
+            // A = the ray's joint vectors (lane (m, q): C[8 q + e][ray][16 T + m], gathered from [24][R][VW]: 64 contiguous bytes
+            // per joint and tile), B = the rows' cutoff weights (lane (n, q): w[row n][8 q + e]), both split hi / lo like every
+            // other operand; table[code(ray)] enters as k-slot 24 with weight 1.  Then ReLU, rgb_linear as 3 x 60 FMAs per lane and a sum over the four lane
+            // quarters, and lane (n, 0) stores the sample's raw (rgb, density logit = feature VW of its own accumulators).
+            const long row0g = (long)(blockIdx.x + it * gridDim.x) * L16_BM + wave * 16;       // wave-uniform
+            if (row0g < M) {
+                const int VW = a.c_VW, ray = a.c_ray0 + (int)(row0g / a.c_S);
+                long code = a.c_ncodes;                                  // the mean code (Optcodes eval with idx < 0)
+                if (a.c_cam) {
+                    const long idx = a.c_cam[ray];
+                    if (idx >= 0) code = idx < a.c_ncodes ? idx : a.c_ncodes - 1;
+                }
+                // ... and the table row rides along as a 25th "joint" with weight 1 (k-slot 24 = element 0 of lane quarter 3): its
+                // loads are part of the same gathers instead of fifteen more round trips
+                float wv[8];
+                {
+                    const float* wr = a.c_w + (row0g + n) * J + 8 * min(q, 2);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { wv[e] = q < 3 ? w0[e] : 0.f; wv[4 + e] = q < 3 ? w1[e] : 0.f; }
+                    if (q == 3) wv[0] = 1.0f;
+                }
+                half8 wh, wl;
+                lin_split8(wv, wh, wl);
+                const size_t jstride = q < 3 ? (size_t)a.c_Rtot * VW : 0;
+                const float* Cb = q < 3 ? a.c_C + (size_t)ray * VW + n + (size_t)(8 * q) * jstride : a.c_table + (size_t)code * VW + n;
+                // the gathers of eight (then seven) tiles are requested together: one memory round trip per batch instead of one per
+                // tile (the compiler waits for ITS loads by count; nothing else is in flight here)
+                const float* src[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) src[e] = Cb + (size_t)e * jstride;
+                // (batches of five tiles: 40 gathers in flight.  v208 .. v255 hold the row loads and weight fragments of the NEXT k-step
+                // across this epilogue and this toolchain does not enforce amdgpu_num_vgpr: the compiler has to stay below v208 by
+                // itself -- 179 here, tests/test_host_logic.py checks the ISA of every build)
+                lin_color_batch<0, 5>(acc, src, VW, q, wh, wl);
+                lin_color_batch<5, 5>(acc, src, VW, q, wh, wl);
+                lin_color_batch<10, 5>(acc, src, VW, q, wh, wl);
+                float pr = 0.f, pg = 0.f, pb = 0.f;
+                // ONE per-lane LDS address, compile-time offsets from it (left to itself the compiler keeps 60 hoisted addresses alive
+                // across the k-step loop: the registers this epilogue needs)
+                const float* lq = s_bias + 4 * q;
+                asm volatile("" : "+v"(lq));
+#pragma unroll
+                for (int T = 0; T < 15; ++T) {
+                    if (16 * T < VW) {
+                        const f32x4 v = acc[T] + *reinterpret_cast<const f32x4*>(lq + 16 * T);
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(lq + L16_MAX_N + 16 * T),
+                                    r1 = *reinterpret_cast<const f32x4*>(lq + L16_MAX_N + L16_COLOR_LD + 16 * T),
+                                    r2 = *reinterpret_cast<const f32x4*>(lq + L16_MAX_N + 2 * L16_COLOR_LD + 16 * T);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float h = fmaxf(v[i], 0.f);
+                            pr = fmaf(h, r0[i], pr);
+                            pg = fmaf(h, r1[i], pg);
+                            pb = fmaf(h, r2[i], pb);
+                        }
+                        if (T & 1) asm volatile("" ::: "memory");       // (two tiles' table reads in flight, not all fifteen: registers)
+                    }
+                }
+                pr += lane_xor16(pr); pg += lane_xor16(pg); pb += lane_xor16(pb);
+                pr += lane_xor32(pr); pg += lane_xor32(pg); pb += lane_xor32(pb);
+                // the density logit: feature VW = element 0 of tile VW / 16 in the lanes of quarter 0
+                float al = 0.f;
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    if (16 * T == VW) al = acc[T][0] + s_bias[VW];
+                if (q == 0)
+                    reinterpret_cast<f32x4*>(a.c_raw)[(size_t)a.c_ray0 * a.c_S + row0g + n] =
+                        f32x4{pr + a.c_rgb_b[0], pg + a.c_rgb_b[1], pb + a.c_rgb_b[2], al};
+            }
+        } else
         if (FRAG & 4) {
             // fragment-order output: tile T of this wavefront's 16 rows is one contiguous KB (rows past M: padding of the buffer)
             const long g16 = (long)(blockIdx.x + it * gridDim.x) * (L16_BM / 16) + wave;
@@ -542,6 +669,34 @@ extern "C" int danbo_linear16_fwd_frag(const float* x1, int ld1, int K1, const f
 /* y (fragment order) = act([enc(table) | x2] W^T + bias): the first / the skip layer of the A-NeRF trunk with the 24 (1 + 2 L) + 72
  * density inputs recomputed from the encoder's table [M, 144] (danbo_anerf_encode_compact) instead of read (W packed by
  * danbo_linear16_pack_enc).  x2: NULL, or the second input [M, K2] in fragment order.  N = 448 (the shipped A-NeRF width). */
+/* A-NeRF's head layer with the colour head as its epilogue: x1 = the trunk's last activation in fragment order [M, K1]; packed / bias:
+ * the (VW + 1)-wide layer [views_linears.0[:, :W] feature_linear ; alpha_linear] (frag_in 1); rows = the samples of rays
+ * [ray0, ray0 + M / S) in ray-major order; w [M, 24], C [24, R_total, VW], table, cam_idx, rgb_*: as danbo_anerf_color_fwd.
+ * raw_out [R_total, S, 4].  S % 16 == 0, VW % 16 == 0, VW <= 240. */
+extern "C" int danbo_linear16_fwd_color(const float* x1, int K1, const void* packed, const float* bias, int VW, int M, const float* w,
+                                        const float* C, const float* table, const int64_t* cam_idx, int n_codes, int R_total, int ray0,
+                                        int S, const float* rgb_w, const float* rgb_b, float* raw_out, void* stream) {
+    DANBO_CHECK_ARG(x1 && packed && bias && w && C && table && rgb_w && rgb_b && raw_out && K1 >= 32 && K1 % 32 == 0 && M >= 0);
+    DANBO_CHECK_ARG(VW >= 16 && VW % 16 == 0 && VW <= 240 && S >= 16 && S % 16 == 0 && M % S == 0 && n_codes >= 0 && ray0 >= 0);
+    DANBO_CHECK_ARG(ray0 + M / S <= R_total && (uintptr_t)x1 % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)table % 16 == 0 &&
+                    (uintptr_t)raw_out % 16 == 0);
+    if (M == 0) return 0;
+    const int N = VW + 1;
+    Lin16Args a{x1, nullptr, 0, 0, K1, 0, (const char*)packed, bias, nullptr, 0, N, 0, M, nullptr, 1 | 16, 0, nullptr,
+                w, C, table, rgb_w, rgb_b, cam_idx, raw_out, n_codes, R_total, ray0, S, VW};
+    const int tiles = (M + L16_BM - 1) / L16_BM;
+    const dim3 grid(tiles < num_cu() ? tiles : num_cu()), block(L16_THREADS);
+    const int np = ((N + 15) / 16 + 1) / 2;
+    if (np == 8) {
+        DANBO_ENSURE_LDS((k_linear16<1, 8, false, 17>), L16_COLOR_LDS_BYTES);
+        hipLaunchKernelGGL((k_linear16<1, 8, false, 17>), grid, block, L16_COLOR_LDS_BYTES, (hipStream_t)stream, a);
+    } else {
+        DANBO_ENSURE_LDS((k_linear16<1, 0, false, 17>), L16_COLOR_LDS_BYTES);
+        hipLaunchKernelGGL((k_linear16<1, 0, false, 17>), grid, block, L16_COLOR_LDS_BYTES, (hipStream_t)stream, a);
+    }
+    DANBO_LAUNCH_RET();
+}
+
 extern "C" int danbo_linear16_fwd_enc(const float* table, int L, const float* x2, int K2, const void* packed, const float* bias, int N,
                                       int act, float* y, int M, const int32_t* count, void* stream) {
     DANBO_CHECK_ARG(table && packed && y && N == 448 && L >= 1 && L <= 7 && K2 >= 0 && (K2 == 0) == (x2 == nullptr) && M >= 0);

@@ -430,6 +430,18 @@ int danbo_linear16_fwd_enc(const float* table, int L, const float* x2, int K2, c
 int danbo_anerf_encode_compact(const float* rays_o, const float* rays_d, const float* z, const float* pts, int R, int S, int G,
                                const float* skts, const float* align, const float* cutoff, float tau, long row0, int nrows,
                                float* table, float* w_out, void* stream);
+/* A-NeRF's head layer with the COLOUR HEAD AS ITS EPILOGUE (round 6; replaces danbo_linear16_fwd_frag + danbo_anerf_color_fwd: the
+ * (VW + 1)-wide head rows are never written).  x1: the trunk's last activation in fragment order [M, K1]; packed / bias: the layer
+ * [views_linears.0[:, :W] feature_linear ; alpha_linear] packed with frag_in 1 (N = VW + 1: VW view features, then the density
+ * logit); its M rows are the samples of rays [ray0, ray0 + M / S), ray-major -- the 16 rows of a wavefront are 16 samples of ONE
+ * ray, so the cutoff-weighted sum over the joints is one more k-step of the same GEMM (A = the ray's joint vectors C[:, ray, :],
+ * B = the rows' cutoff weights w [M, 24]; the row of `table` the ray's camera selects rides along as a 25th joint of weight 1),
+ * followed by ReLU, rgb_linear and the store of raw_out [R_total, S, 4] (reference core/networks/nerf.py:196-209).
+ * w, C [24, R_total, VW], table [n_codes + 1, VW], cam_idx, rgb_w, rgb_b: as danbo_anerf_color_fwd.  S % 16 == 0, VW % 16 == 0,
+ * VW <= 240, K1 % 32 == 0. */
+int danbo_linear16_fwd_color(const float* x1, int K1, const void* packed, const float* bias, int VW, int M, const float* w,
+                             const float* C, const float* table, const int64_t* cam_idx, int n_codes, int R_total, int ray0, int S,
+                             const float* rgb_w, const float* rgb_b, float* raw_out, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

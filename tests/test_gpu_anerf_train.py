@@ -92,6 +92,48 @@ def test_view_consts_kernel_and_its_adjoint_match_float64(Lv, VW):
     assert torch.equal(g, g2)                                                  # fixed summation order
 
 
+@pytest.mark.parametrize("S,VW,codes", [(48, 224, True), (16, 224, False), (32, 64, True), (16, 240, True)])
+def test_head_layer_with_colour_epilogue_equals_head_layer_plus_colour_kernel(S, VW, codes):
+    """danbo_linear16_fwd_color (round 6: A-NeRF's colour head as the EPILOGUE of its head layer -- the cutoff-weighted sum over the
+    joints as one more k-step of the GEMM, table row as a 25th joint, ReLU, rgb_linear, raw stored) against the two launches it
+    replaces (danbo_linear16_fwd_frag -> rows, danbo_anerf_color_fwd) and against float64; chunks that start at ray0 > 0, a partial
+    last 128-row tile, rays without / with frame codes (the mean code for a negative index)"""
+    from core import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    W, R_total, ray0, nrays = 448, 50, 7, 37
+    n = nrays * S
+    rnd = lambda *sh, sc=1.0: (torch.randn(*sh, generator=gen) * sc).to(DEV)  # noqa: E731
+    h_rows = torch.relu(rnd(n, W))
+    head_w, head_b = rnd(VW + 1, W, sc=0.05), rnd(VW + 1, sc=0.1)
+    w = torch.rand(n, 24, generator=gen).to(DEV)
+    C = rnd(24, R_total, VW, sc=0.3)
+    n_codes = 5
+    table = rnd(n_codes + 1, VW, sc=0.3)
+    cam = torch.tensor([(i % 7) - 1 for i in range(R_total)], dtype=torch.int64, device=DEV) if codes else None    # -1: the mean row; 5: clamped
+    rgb_w, rgb_b = rnd(3, VW, sc=0.2), rnd(3, sc=0.1)
+    packed, shape = ops.linear16_pack(head_w, frag_in=(True, False))
+    h = ops.FragBuffer.from_rows(h_rows)
+    raw = torch.full((R_total, S, 4), 7.0, device=DEV)
+    ops.linear16_color(h, packed, shape, head_b, w, C, table, cam, ray0, S, rgb_w, rgb_b, raw)
+    # the two launches it replaces
+    head = ops.linear16(h, packed, shape, head_b)
+    raw2 = torch.full((R_total, S, 4), 7.0, device=DEV)
+    ops.anerf_color(head[:, :VW], w, C, table, cam, ray0, nrays, S, rgb_w, rgb_b, head[:, VW], raw2)
+    assert bool((raw[:ray0] == 7.0).all()) and bool((raw[ray0 + nrays:] == 7.0).all())         # only the chunk's rays are written
+    # float64
+    code = torch.full((R_total,), n_codes, dtype=torch.int64, device=DEV) if cam is None else torch.where(cam < 0, torch.full_like(cam, n_codes), cam.clamp(max=n_codes - 1))
+    ray = ray0 + torch.arange(n, device=DEV) // S
+    pre = h_rows.double() @ head_w.double().t() + head_b.double()
+    Cr = C.double()[:, ray].permute(1, 0, 2)                                       # [n, 24, VW]
+    x = torch.relu(pre[:, :VW] + table.double()[code[ray]] + torch.einsum("nj,njc->nc", w.double(), Cr))
+    want = torch.cat([x @ rgb_w.double().t() + rgb_b.double(), pre[:, VW:]], 1).reshape(nrays, S, 4)
+    scale = float(want.abs().max())
+    got, old = raw[ray0:ray0 + nrays].double(), raw2[ray0:ray0 + nrays].double()
+    assert float((got - want).abs().max()) <= 3e-6 * scale, float((got - want).abs().max()) / scale
+    assert float((got - old).abs().max()) <= 3e-6 * scale
+    assert torch.equal(got[..., 3], old[..., 3])                                   # the density logit: the same GEMM, the same bits
+
+
 def test_small_matmul_reads_strided_operands_and_accumulates_in_float64():
     from core import hip_ops as ops
     gen = torch.Generator(device="cpu").manual_seed(9)

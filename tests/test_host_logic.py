@@ -333,23 +333,31 @@ def test_linear16_isa_keeps_its_hands_off_the_in_flight_row_registers(tmp_path):
                 foreign.append(l.strip())
             mfma += "v_mfma_f32_16x16x32_f16" in l
         assert not foreign, (name, foreign[:4])
-        # two unrolled k-steps of NH chunks, 8 groups of 6 (NP = 6: the last chunk of a k-step has 6 groups)
-        assert mfma == 2 * 6 * (8 * (nh - 1) + (np_ or 8)), (name, mfma)
+        # two unrolled k-steps of NH chunks, 8 groups of 6 (NP = 6: the last chunk of a k-step has 6 groups); FRAG & 16 (the colour
+        # epilogue of A-NeRF's head layer, round 6): + 15 tiles x 3 products in each of the two unrolled tile ends -- inline asm too
+        color = bool(frag & 16)
+        assert mfma == 2 * 6 * (8 * (nh - 1) + (np_ or 8)) + (2 * 45 if color else 0), (name, mfma)
         touching = [l.strip() for l in body if high.search(l)]
         loads = [l for l in touching if l.startswith("global_load_dwordx4 v[2")]
         takes = [l for l in touching if re.match(r"v_mov_b32 v\d+, v2(0[89]|1\d|2[0-3])$", l)]
         frags = [l for l in touching if l.startswith("ds_read_b128 v[2") or l.startswith("v_mfma")]
         # requests: three in the prologue + one per unrolled k-step, 2 loads each (a kernel with one part in rows and one in
         # fragment order carries both address forms); takes: 8 registers in the prologue and in each of the two k-steps
-        mixed = frag in (1, 5, 6, 12, 14)   # (12 / 14: the A-NeRF encoder table instead of rows, danbo_linear16_fwd_enc)
+        mixed = frag in (1, 5, 6, 12, 14, 17)   # (12 / 14: the A-NeRF encoder table instead of rows, danbo_linear16_fwd_enc)
         assert len(loads) == (20 if mixed else 10) and len(takes) == 24 and len(touching) == len(loads) + len(takes) + len(frags), (name, touching)
         waits = sorted(re.search(r"vmcnt\(\d+\)", l).group(0) for l in body if "s_waitcnt" in l and "vmcnt" in l)
         # bias table, prologue, one per row-tile end in each of the two unrolled k-steps, final drain; one per hand-over
-        assert waits == sorted(["vmcnt(0)"] * 5 + ["vmcnt(6)"] * (2 * nh)), (name, waits)
+        if color:
+            # the colour epilogue sits at the row-tile end, behind the vmcnt(0) that has drained ring and row loads: its own loads
+            # (cutoff weights, camera index, the batched gathers) are waited for there with vmcnt(0); the k-step loop's hand-over
+            # waits stay the counted ones
+            assert waits.count("vmcnt(6)") == 2 * nh and set(waits) == {"vmcnt(0)", "vmcnt(6)"}, (name, waits)
+        else:
+            assert waits == sorted(["vmcnt(0)"] * 5 + ["vmcnt(6)"] * (2 * nh)), (name, waits)
     # what the launcher dispatches to
     shapes = {(1, 0), (1, 8), (2, 0), (2, 6), (2, 8)}
     want = ({(nh, np_, 0, fr) for nh, np_ in shapes for fr in (0, 4, 5, 6)} | {(1, 0, 0, 1), (1, 8, 0, 1), (2, 0, 1, 0)}
-            | {(2, 6, 0, 12), (2, 6, 0, 14)})
+            | {(2, 6, 0, 12), (2, 6, 0, 14)} | {(1, 8, 0, 17), (1, 0, 0, 17)})
     assert seen == want, (seen ^ want)
 
 
