@@ -12,7 +12,7 @@ from . import hip_ops as ops
 
 
 class AnerfEngine:
-    def __init__(self, cfg, params, align, rows_per_chunk=1 << 20):
+    def __init__(self, cfg, params, align, rows_per_chunk=1 << 22):
         self.cfg, self.p = cfg, params
         self.align = align.float().contiguous()
         self.rows_per_chunk = rows_per_chunk

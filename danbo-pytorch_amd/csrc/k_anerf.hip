@@ -22,6 +22,7 @@ constexpr int AN_MAXL = 8;
 //   [24][4] floats (inp_j, sh_j, w_j, dir_j.x) = cutoff - distance, the shifted distance the sin / cos take, the cutoff weight, the
 //   x component of the unit direction to joint j; then [24][2] floats (dir_j.y, dir_j.z)
 constexpr int AN_ENC_FLOATS = 144;
+constexpr int AN_SUB = 4;                     // COMPACT: sub-tiles per copy-out (32 rows x 576 B = 18 KB of LDS)
 template <bool COMPACT>
 __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d,
@@ -43,10 +44,15 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
     const int sl = tid / J, j = tid % J;
     const float c = cutoff[j];
     const float two_over_c = div_rn(2.0f, c);
-    const int ntiles = (nrows + AN_TS - 1) / AN_TS;
+    // COMPACT: AN_SUB sub-tiles of AN_TS rows are staged before ONE copy-out (round 6: a 4.6 KB copy between two barriers per eight
+    // rows left the kernel at 2.7 TB/s); the 432-wide rows of the other form fill the LDS tile with one sub-tile
+    constexpr int SUB = COMPACT ? AN_SUB : 1;
+    const int ntiles = (nrows + AN_TS * SUB - 1) / (AN_TS * SUB);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        const int row = tile * AN_TS + sl;
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+        const int row = (tile * SUB + sub) * AN_TS + sl;
         if (row < nrows) {
             const long m = row0 + row;
             const int g = (int)min(m / spp, (long)G - 1);
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
             bone_local(sk, s_align + 16 * j, p, pt);
             const float v = norm3_torch(pt[0], pt[1], pt[2]);
             const float den = fmaxf(v, 1e-12f);
-            float* out = s_row + sl * in_ch;
+            float* out = s_row + (sub * AN_TS + sl) * in_ch;
             const float w = sub_rn(1.0f, sigmoidf_(mul_rn(tau, sub_rn(v, c))));
             const float inp = sub_rn(c, v);
             const float sh = sub_rn(mul_rn(inp, two_over_c), 1.0f);
@@ -86,12 +92,17 @@ __global__ __launch_bounds__(AN_BLOCK) void k_anerf_encode(const float* __restri
             }
             wout[(size_t)row * J + j] = w;
         }
+        }
         __syncthreads();
         // coalesced copy-out of the finished rows
-        const int base = tile * AN_TS;
-        const int live = min(AN_TS, nrows - base) * in_ch;
+        const int base = tile * AN_TS * SUB;
+        const int live = min(AN_TS * SUB, nrows - base) * in_ch;
         float* dst = x0 + (size_t)base * in_ch;
-        for (int i = tid; i < live; i += AN_BLOCK) dst[i] = s_row[i];
+        if (COMPACT) {
+            for (int i = tid; i < live / 4; i += AN_BLOCK) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(s_row)[i];
+        } else {
+            for (int i = tid; i < live; i += AN_BLOCK) dst[i] = s_row[i];
+        }
     }
 }
 
@@ -252,9 +263,9 @@ extern "C" int danbo_anerf_encode_compact(const float* rays_o, const float* rays
     DANBO_CHECK_ARG(row0 + nrows <= (long)R * S && skts && align && cutoff && table && w_out && (uintptr_t)table % 16 == 0);
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr) && (pts || (rays_o && rays_d)));
     if (nrows == 0) return 0;
-    const int ntiles = ceil_div(nrows, AN_TS);
+    const int ntiles = ceil_div(nrows, AN_TS * AN_SUB);
     const int grid = ntiles < num_cu() * 8 ? ntiles : num_cu() * 8;
-    hipLaunchKernelGGL(k_anerf_encode<true>, dim3(grid), dim3(AN_BLOCK), AN_TS * AN_ENC_FLOATS * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(k_anerf_encode<true>, dim3(grid), dim3(AN_BLOCK), AN_SUB * AN_TS * AN_ENC_FLOATS * sizeof(float), (hipStream_t)stream,
                        rays_o, rays_d, z, pts, R, S, G, skts, align, cutoff, tau, 0, row0, nrows, table, w_out);
     DANBO_LAUNCH_RET();
 }

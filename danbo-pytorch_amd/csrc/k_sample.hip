@@ -614,10 +614,9 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __res
                                                               const int32_t* __restrict__ count, int n_cap,
                                                               float* __restrict__ part_feat) {
     __shared__ __attribute__((aligned(16))) float s_vol[J * VOL];          // 23040 B
-    // two tiles of output: tile i's rows are stored while tile i + 1 is computed into the other buffer, ONE barrier per tile (round
-    // 6; a single buffer needed one in front of the stores and one behind them: every wavefront of the workgroup idled through the
-    // other's phase)
-    __shared__ __attribute__((aligned(16))) float s_out2[2][GATHER_TS * J * FEAT];  // 2 x 23040 B
+    // (round 6 measured the output tile double-buffered -- tile i stored while tile i + 1 is computed, one barrier per tile instead
+    // of two: 72 KB of LDS leave two workgroups per CU instead of three and the launch drops from 3.6 to 2.7 TB/s; not kept)
+    __shared__ __attribute__((aligned(16))) float s_out[GATHER_TS * J * FEAT];  // 23040 B
     __shared__ __attribute__((aligned(16))) float s_skt[J * 16];
     __shared__ __attribute__((aligned(16))) float s_align[J * 16];
     __shared__ float s_scale[J * 4];
@@ -632,21 +631,19 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __res
     for (int i = tid; i < J * 4; i += GATHER_BLOCK) s_scale[i] = (i & 3) < 3 ? fabsf(axis_scale[(i >> 2) * 3 + (i & 3)]) : 1.f;
     int g_lds = -1;
 
-    int buf = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        float* s_out = s_out2[buf];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * GATHER_TS;
         const int first = list ? list[row0] : row0;
         const int g_tile = (int)min((long)first / spp, (long)G - 1);
+        __syncthreads();  // previous tile's s_out fully stored, s_vol no longer read
         if (g_tile != g_lds) {
-            __syncthreads();  // s_vol no longer read (pose changes only: multi-pose chunks)
             const float4* src = reinterpret_cast<const float4*>(volumes + (size_t)g_tile * J * VOL);
             float4* dst = reinterpret_cast<float4*>(s_vol);
             for (int i = tid; i < J * VOL / 4; i += GATHER_BLOCK) dst[i] = src[i];
             for (int i = tid; i < J * 16; i += GATHER_BLOCK) s_skt[i] = skts[(size_t)g_tile * J * 16 + i];
             g_lds = g_tile;
-            __syncthreads();
         }
+        __syncthreads();
         const int row = row0 + sl;
         float* o_ = s_out + (sl * J + j) * FEAT;
         if (row < n) {
@@ -671,8 +668,6 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_bone_gather(const float* __res
 #pragma unroll
             for (int k = 0; k < FEAT; ++k) o_[k] = 0.f;
         }
-        // the one barrier of the tile: this buffer is complete -- and every thread has finished storing the OTHER buffer (the
-        // previous tile's stores precede this point in its program order), which the next tile overwrites
         __syncthreads();
         // coalesced 16-B stores of the 16 x 1440 B tile
         const int rows_here = min(GATHER_TS, n - row0);
@@ -1440,7 +1435,7 @@ extern "C" int danbo_bone_gather_fwd(const float* rays_o, const float* rays_d, c
     DANBO_CHECK_ARG((z == nullptr) != (pts == nullptr));
     if (n == 0) return 0;
     const int ntiles = ceil_div(n, GATHER_TS);
-    const int grid = ntiles < num_cu() * 2 ? ntiles : num_cu() * 2;       // 72 KB of LDS: two resident workgroups per CU
+    const int grid = ntiles < num_cu() * 3 ? ntiles : num_cu() * 3;
     hipLaunchKernelGGL(k_bone_gather, dim3(grid), dim3(GATHER_BLOCK), 0, (hipStream_t)stream, rays_o, rays_d, z, pts, R, S,
                        G, skts, align, axis_scale, volumes, list, count, n, part_feat);
     DANBO_LAUNCH_RET();

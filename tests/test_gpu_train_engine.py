@@ -347,7 +347,7 @@ def test_nothing_in_the_captured_step_can_run_beside_k2():
     torch.cuda.synchronize()
     names, edges = _hip_graph_dag(eng.graph[1].raw_cuda_graph())
     n = len(names)
-    assert n >= 40, names
+    assert n >= 30, names
     succ = [[] for _ in range(n)]
     for a, c in edges:
         succ[a].append(c)

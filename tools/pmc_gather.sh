@@ -28,7 +28,7 @@ plain = [json.loads(l) for l in open(root + ".plain.log") if l.startswith("{")]
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/micro_gather.py on the bench frame "
                "(512 x 512 x 48 coarse samples): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch, the gfx950 correction of "
                "MI355X_MICROARCH.md; GB/s = counter bytes / the launch's duration UNDER THE PROFILER (kernel trace of the same pass); the "
-               "un-profiled timings of the same script: `unprofiled`", "kernels": {}, "unprofiled": plain}
+               "un-profiled timings of the same script: unprofiled", "kernels": {}, "unprofiled": plain}
 for k in sorted(cnt):
     if "k_bone_cull" not in k and "k_bone_gather" not in k:
         continue
