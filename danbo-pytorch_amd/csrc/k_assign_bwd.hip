@@ -98,7 +98,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(AB_THREADS, 2) void k_assign_bwd(ABArgs a, int target_wgs) {
+__global__ __launch_bounds__(AB_THREADS, 2) DANBO_NO_PK_F32 void k_assign_bwd(ABArgs a, int target_wgs) {
     // s_w0, s_w1, s_pdh and s_vol0 are carved from one region: they are dead once the pair loop is over, and the flush re-uses the
     // region as its fp64 accumulators (AbAcc)
     __shared__ __attribute__((aligned(16))) char s_over[AB_OVER_BYTES];

@@ -13,7 +13,7 @@ namespace danbo {
 // ======================================================================================
 // near / far in the bounding cylinder
 // ======================================================================================
-__global__ __launch_bounds__(256) void k_cylinder_pass1(const float* __restrict__ rays_o,
+__global__ __launch_bounds__(256) DANBO_NO_PK_F32 void k_cylinder_pass1(const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ cyl, int R, int G,
                                                         float near0, float far0,
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_cylinder_pass2(int R, float near0, floa
 // threads keep their rays' bounds, the chunk's sums are a block reduction (no atomics, no zeroed scratch, a fixed order) and the
 // back-fill follows behind a barrier.  Three launches of ~5 us became one: they sit in front of everything else of a frame / step.
 constexpr int CYL_BLOCK = 1024, CYL_FUSED_MAX = 16 * CYL_BLOCK;
-__global__ __launch_bounds__(CYL_BLOCK) void k_cylinder_chunk(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+__global__ __launch_bounds__(CYL_BLOCK) DANBO_NO_PK_F32 void k_cylinder_chunk(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                               const float* __restrict__ cyl, int R, int G, float near0, float far0,
                                                               const float* __restrict__ near_in, const float* __restrict__ far_in,
                                                               int chunk, float* __restrict__ near_out, float* __restrict__ far_out) {
@@ -377,7 +377,7 @@ constexpr int CULL_BLOCK = 256;
 constexpr int CULL_SPT = 4;  // samples per thread -> 1024 consecutive samples per workgroup
 constexpr int CULL_MAX_RAYS = 130;  // rays a workgroup may span (S >= 8) for the ray-level bone rejection
 
-__global__ __launch_bounds__(CULL_BLOCK) void k_bone_cull(const float* __restrict__ rays_o,
+__global__ __launch_bounds__(CULL_BLOCK) DANBO_NO_PK_F32 void k_bone_cull(const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d,
                                                           const float* __restrict__ z,
                                                           const float* __restrict__ pts, int R, int S, int G,

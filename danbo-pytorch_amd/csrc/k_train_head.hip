@@ -20,7 +20,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // cview[r, f] = b_eff[f] + sum_k vin[r, k] W_v[f, 256 + k]:  128 threads = features, 8 rays per workgroup
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int CV_RAYS = 8;
-__global__ __launch_bounds__(128) void k_train_cview(const float* __restrict__ vin, int ldv, int Cv, const float* __restrict__ views_w,
+__global__ __launch_bounds__(128) DANBO_NO_PK_F32 void k_train_cview(const float* __restrict__ vin, int ldv, int Cv, const float* __restrict__ views_w,
                                                      const float* __restrict__ b_eff, int R, float* __restrict__ cview) {
     __shared__ float s_v[CV_RAYS][160];
     const int f = threadIdx.x;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void hc_tile(const float* __restrict__ A, int lda, co
         for (int j = 0; j < 4; ++j) store(m0 + 4 * ty + i, n0 + 4 * tx + j, acc[i][j]);
 }
 
-__global__ __launch_bounds__(256) void k_train_head_chain(HeadChainArgs a) {
+__global__ __launch_bounds__(256) DANBO_NO_PK_F32 void k_train_head_chain(HeadChainArgs a) {
     const int ld = HW + a.Cv;
     int blk = blockIdx.x;
     if (blk < HC_TILES_VA) {          // d W_v[f, c] = d b_eff[f] b_f[c] + sum_j d W_fv[f, j] W_f[c, j]
