@@ -21,5 +21,10 @@ bash tools/prof.sh ev_$TAG > $E/prof_frame.log 2>&1; cp gpurun_out/prof_ev_$TAG/
 bash tools/prof_train.sh ev_$TAG > $E/prof_train.log 2>&1; cp gpurun_out/prof_ev_$TAG/ev_${TAG}_kernel_stats.csv $E/${TAG}_train_kernel_stats.csv
 bash tools/prof_config.sh ev3_$TAG 3 > $E/prof_config3.log 2>&1; cp gpurun_out/prof_ev3_$TAG/ev3_${TAG}_kernel_stats.csv $E/${TAG}_config3_kernel_stats.csv
 bash tools/timeline_train.sh ev_$TAG > /dev/null 2>&1; cp gpurun_out/tl_ev_$TAG.txt $E/${TAG}_train_timeline.txt
+bash tools/prof_anerf.sh eva_$TAG > $E/prof_anerf.log 2>&1; cp gpurun_out/prof_eva_$TAG/eva_${TAG}_kernel_stats.csv $E/${TAG}_anerf_kernel_stats.csv
+bash tools/pmc_gather.sh $TAG > $E/pmc_gather.log 2>&1; cp gpurun_out/gather_hbm_$TAG.json $E/${TAG}_gather_hbm.json
+PMC_FRAME=1 bash tools/pmc_kernel.sh k2_$TAG k_assign16 > $E/${TAG}_pmc_sq_k2_frame.txt 2>&1
+bash tools/pmc_kernel.sh k2b_$TAG k_assign_bwd > $E/${TAG}_pmc_sq_k2_bwd.txt 2>&1
+(cd tools/probe && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Wno-unused-value -o cview_probe cview_probe.hip 2>/dev/null; timeout 600 ./cview_probe 2000) > $E/${TAG}_pk_f32_erratum.txt 2>&1
 grep -h '"ms_per_step"' $E/*_bench_config*.json
 tail -3 $E/${TAG}_parity_measured.txt
