@@ -289,23 +289,23 @@ def pe_mlp(h, S, packed, pts_b, alpha_w, alpha_b, feature_b, cview, rgb_w, rgb_b
 MLP16_PACKED_BYTES = 2424832 + 128 + 128 * 256 * 4      # 74 chunks + trailer (winv, wmax, W_fv): include/danbo_hip.h
 
 
-def mlp16_pack(pts_w, feature_w, feature_b, views_w, views_b):
-    """fp16 hi/lo fragment packing for pe_mlp16 -> (uint8 buffer [MLP16_PACKED_BYTES], views_b_eff [128])."""
+def mlp16_pack(pts_w, feature_w, feature_b, views_w, views_b, form=16):
+    """fp16 hi/lo fragment packing for pe_mlp16 (form 16) / pe_mlp32 (form 32) -> (uint8 buffer [MLP16_PACKED_BYTES], views_b_eff [128])."""
     dev = feature_w.device
     Cv = views_w.shape[1] - 256
     packed = torch.empty(MLP16_PACKED_BYTES, device=dev, dtype=torch.uint8)
     vb = torch.empty(VIEW_W, device=dev, dtype=torch.float32)
     pts_w = [_f32(w, "pts_w") for w in pts_w]
-    _call("danbo_mlp16_pack", _ptr_array(pts_w), _p(_f32(feature_w, "feature_w")), _p(_f32(feature_b, "feature_b")),
+    _call({16: "danbo_mlp16_pack", 32: "danbo_mlp32_pack"}[form], _ptr_array(pts_w), _p(_f32(feature_w, "feature_w")), _p(_f32(feature_b, "feature_b")),
           _p(_f32(views_w, "views_w")), _p(_f32(views_b, "views_b")), Cv, _p(packed), _p(vb), _stream())
     return packed, vb
 
 
 def pe_mlp16(h, S, packed16, pts_b, alpha_w, alpha_b, cview, rgb_w, rgb_b, raw_out,
-             lst=None, cnt=None, n=None, aux=False):
+             lst=None, cnt=None, n=None, aux=False, form=16):
     n = h.shape[0] if n is None else n
     aux_out = torch.empty(n, VIEW_W + 1, device=h.device, dtype=torch.float32) if aux else None
-    _call("danbo_pe_mlp16_fwd", _p(h), _p(lst), _p(cnt), n, S, _p(packed16), _ptr_array(pts_b), _p(alpha_w),
+    _call({16: "danbo_pe_mlp16_fwd", 32: "danbo_pe_mlp32_fwd"}[form], _p(h), _p(lst), _p(cnt), n, S, _p(packed16), _ptr_array(pts_b), _p(alpha_w),
           _p(alpha_b), _p(cview), _p(rgb_w), _p(rgb_b), _p(raw_out), _p(aux_out), _stream())
     return aux_out
 

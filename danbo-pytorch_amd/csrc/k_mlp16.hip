@@ -60,6 +60,7 @@ struct TrunkPackArgs {
     float *wfv, *b_eff, *wmax, *winv;
     _Float16* packed;
     int n_chunks;      // NCH_TOTAL (forward only: K3) or NCH_TOTAL + NCH_BWD
+    int form;          // 16: fragments of v_mfma_f32_16x16x32_f16 (k_pe_mlp16, the training trunk); 32: of v_mfma_f32_32x32x16_f16 (k_mlp32.hip)
 };
 
 // grid: 8 x 32 workgroups for the max |w| of pts_linears.0..7, then 128 workgroups -- one per row n of W_fv, thread = column f
@@ -134,11 +135,29 @@ __global__ __launch_bounds__(256) void k_trunk_pack(TrunkPackArgs a) {
             else if (chunk < 54) { layer = 5; cl = chunk - 46; kind = 1; }
             else if (chunk < 70) { layer = 6 + (chunk - 54) / 8; cl = (chunk - 54) % 8; kind = 1; }
             else { layer = 8; cl = chunk - 70; kind = 2; }
+            mat = layer;
+            if (a.form == 32) {
+                // k_mlp32.hip: a chunk = two k-substeps of 16 (view layer: four) x 8 (4) output tiles of 32 x (hi, lo); lane (m, g = lane / 32)
+                // holds row 32 T + m, k-slots 8 g .. 8 g + 7 of k-substep U.  Slot -> input feature: the order in which the lanes of
+                // a 32 x 32 result tile hold the previous layer's outputs (feature 16 U + 8 (e / 4) + 4 g + e % 4), resp. the
+                // encoding's slot j = 8 U + e = 13 c + t of channel 8 g + c
+                const int g = lane >> 5, m32 = lane & 31;
+                int U, T;
+                if (kind == 2) { U = 4 * cl + (piece >> 3); T = (piece >> 1) & 3; }
+                else { U = 2 * cl + (piece >> 4); T = (piece >> 1) & 7; }
+                const int n = 32 * T + m32;
+                if (kind == 0) {
+                    const int j = 8 * U + e, c = j / 13, t = j % 13, kk = 8 * g + c;
+                    if (j < 104 && kk < FEAT) w = trunk_w(a, layer, n, FEAT * t + kk);
+                } else {
+                    const int f = 16 * U + 8 * (e >> 2) + 4 * g + (e & 3);
+                    w = trunk_w(a, layer, n, layer == 5 ? IN_CH + f : f);
+                }
+            } else {
             int s, T;
             if (kind == 2) { s = 2 * cl + (piece >> 4); T = (piece >> 1) & 7; }
             else { s = cl; T = piece >> 1; }
             const int n = 16 * T + ma;
-            mat = layer;
             if (kind == 0) {
                 const int j = 8 * s + e;
                 const int c = j / 13, t = j % 13, kk = q + 4 * c;
@@ -146,6 +165,7 @@ __global__ __launch_bounds__(256) void k_trunk_pack(TrunkPackArgs a) {
             } else {
                 const int f = 16 * (2 * s + (e >> 2)) + 4 * q + (e & 3);
                 w = trunk_w(a, layer, n, layer == 5 ? IN_CH + f : f);
+            }
             }
         } else {                            // ---------------- backward: transposed
             chunk -= NCH_TOTAL;
@@ -598,9 +618,9 @@ __global__ __launch_bounds__(M16_THREADS, 2) __attribute__((amdgpu_num_vgpr(224)
 using namespace danbo;
 
 // trailer of the packed buffer behind the 74 chunks: winv [16] | wmax [16] | W_fv [128 x 256] (scratch of the pack kernels)
-extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
-                                 const float* views_w, const float* views_b, int Cv, void* packed16,
-                                 float* views_b_eff, void* stream) {
+static int mlp_pack_form(int form, const float* const* pts_w, const float* feature_w, const float* feature_b,
+                         const float* views_w, const float* views_b, int Cv, void* packed16,
+                         float* views_b_eff, void* stream) {
     DANBO_CHECK_ARG(pts_w && feature_w && feature_b && views_w && views_b && packed16 && views_b_eff && Cv >= 0);
     TrunkPackArgs a;
     for (int i = 0; i < 8; ++i) { DANBO_CHECK_ARG(pts_w[i]); a.pts_w[i] = pts_w[i]; }
@@ -609,6 +629,7 @@ extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_
     a.winv = trailer; a.wmax = trailer + 16; a.wfv = trailer + 32; a.b_eff = views_b_eff;
     a.packed = reinterpret_cast<_Float16*>(packed16);
     a.n_chunks = NCH_TOTAL;
+    a.form = form;
     { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
     // dev A/B (tools/micro_mlp16.py --noscale): maxima of 0 pack every matrix times 1 -- round 4's packing
@@ -616,6 +637,19 @@ extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_
     if (noscale) { const hipError_t e = hipMemsetAsync(a.wmax, 0, 16 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();
+}
+
+extern "C" int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
+                                 const float* views_w, const float* views_b, int Cv, void* packed16,
+                                 float* views_b_eff, void* stream) {
+    return mlp_pack_form(16, pts_w, feature_w, feature_b, views_w, views_b, Cv, packed16, views_b_eff, stream);
+}
+
+// the same 74 chunks in the fragment order of k_mlp32.hip
+extern "C" int danbo_mlp32_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
+                                 const float* views_w, const float* views_b, int Cv, void* packed32,
+                                 float* views_b_eff, void* stream) {
+    return mlp_pack_form(32, pts_w, feature_w, feature_b, views_w, views_b, Cv, packed32, views_b_eff, stream);
 }
 
 extern "C" int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
@@ -648,6 +682,7 @@ extern "C" int danbo_trunk_pack(const DanboTrunkWeights* w, void* stream) {
     a.feature_w = w->feature_w; a.feature_b = w->feature_b; a.views_w = w->views_w; a.views_b = w->views_b; a.Cv = w->view_ch;
     a.wfv = w->wfv; a.b_eff = w->b_eff; a.wmax = w->wmax; a.winv = w->winv; a.packed = reinterpret_cast<_Float16*>(w->packed);
     a.n_chunks = NCH_TOTAL + NCH_BWD;
+    a.form = 16;
     hipLaunchKernelGGL(k_trunk_prep, dim3(8 * PREP_MAX_WGS + VW_), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_trunk_pack, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
     DANBO_LAUNCH_RET();

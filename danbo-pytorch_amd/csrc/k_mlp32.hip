@@ -1,0 +1,601 @@
+// K3 in the 32x32x16 form: the DANBO density/colour MLP of k_mlp16.hip (same arithmetic: fp32-accurate products as hi*hi + hi*lo +
+// lo*hi on fp16 MFMAs with fp32 accumulation, the same 74 weight chunks through the same LDS ring) on v_mfma_f32_32x32x16_f16 with
+// ONE wavefront per SIMD and 32 samples per wavefront.  gfx950 only.
+//
+// Why: k_pe_mlp16 runs two wavefronts of 16 samples per SIMD; each reads every A fragment of the weight stream for itself (16 KB of
+// ds_read_b128 per k-step of 32 and wavefront) and owns half a register file (acc 64 + prev 64 + fragments).  Here a wavefront owns
+// the whole file -- 256 AccVGPRs = two banks of 8 result tiles [32 features x 32 samples], 256 VGPRs for the rest -- and every A
+// fragment feeds twice the flops: half the LDS reads per flop, one instead of two copies of the epilogue's scalar overhead.  With no
+// partner wavefront to cover its latencies the k-substep is hand-interleaved: each group of 6 MFMAs carries, between its MFMAs, the
+// ds_reads of the next group's fragments and a slice of the NEXT k-substep's epilogue (AccVGPR reads of the previous layer's outputs
+// from the other bank, bias fma, ReLU, hi/lo split) -- the matrix pipe never waits for VALU work except at layer and tile boundaries.
+//
+// Registers the assembly names itself (mlp32_regs.inc lists them as clobbers, so the compiler keeps nothing there across a block):
+//   a[0:127] / a[128:255]  result banks: a layer accumulates into one and reads its input (the previous layer's result) from the other
+//   v[224:239], v[240:255] A-fragment double buffer (hi0 lo0 hi1 lo1 of a two-tile group), as in mlp16_core.hpp
+//   v[216:223], v[208:215] B-fragment double buffer (hi, lo) of k-substeps U even / odd
+//   v[200:207] t0..t7 (epilogue values), v[192:199] bias, v[184:191] alpha weights (view layer)
+// Layout: result tile T of a layer, lane (m = lane % 32, g = lane / 32), register r holds feature 32 T + 8 (r / 4) + 4 g + r % 4 of
+// sample m; k-substep U of the next layer takes registers 8 (U % 2) .. + 7 of tile U / 2 = features 16 U + {0..3, 8..11} + 4 g: the
+// B-fragment k-slots 8 g + e the pack kernel (k_mlp16.hip, form 32) permutes the weight columns to.
+#include <cstdlib>
+#include "mlp16_core.hpp"
+#include "mlp32_regs.inc"
+
+namespace danbo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int M32_THREADS = 256;
+constexpr int M32_NCH = 74;
+constexpr int M32_W = 256, M32_VW = 128;
+constexpr int M32_TABLE_FLOATS = 8 * M32_W + M32_W + 3 * M32_VW + 4 + 12;     // biases, alpha_w, rgb_w, (alpha_b, rgb_b), winv [9]
+constexpr int M32_STAGE_H = 2048, M32_STAGE = 2048 + 256;      // per wavefront: h [32][16] floats, list [64] ints
+constexpr int M32_LDS_BYTES = RING_SLOTS * CHUNK_BYTES + M32_TABLE_FLOATS * 4 + 4 * M32_STAGE;
+
+struct Mlp32Args {
+    const float* h;
+    const int32_t* list;
+    const int32_t* count;
+    int n_cap;
+    int S;
+    const char* packed;
+    const float* pts_b[8];
+    const float* alpha_w;
+    const float* alpha_b;
+    const float* cview;
+    const float* rgb_w;
+    const float* rgb_b;
+    float* raw_out;
+    float* aux_out;
+};
+
+struct Pipe32 {
+    const char* packed;
+    char* ring;
+    int issue_chunk, issue_slot, cons_slot, wave;
+};
+
+// every wavefront loads 8 of the 32 pieces of a chunk (two bases: the instruction's immediate offset reaches 4 KB)
+__device__ __forceinline__ void pipe32_issue(Pipe32& p) {
+    const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192;     // wave-uniform
+    char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192;
+    const char* lane_src = src + (size_t)lane_off16();
+#define DANBO_PIECE(SRC, DST, Q)                                                                           \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                \
+                                     (__attribute__((address_space(3))) void*)(DST), 16, (Q) * 1024, 0)
+    DANBO_PIECE(lane_src, dst, 0); DANBO_PIECE(lane_src, dst, 1); DANBO_PIECE(lane_src, dst, 2); DANBO_PIECE(lane_src, dst, 3);
+    DANBO_PIECE(lane_src + 4096, dst + 4096, 0); DANBO_PIECE(lane_src + 4096, dst + 4096, 1);
+    DANBO_PIECE(lane_src + 4096, dst + 4096, 2); DANBO_PIECE(lane_src + 4096, dst + 4096, 3);
+#undef DANBO_PIECE
+    p.issue_chunk = p.issue_chunk + 1 == M32_NCH ? 0 : p.issue_chunk + 1;
+    p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
+}
+
+// hand-over #c (in front of chunk c): my share of chunk c+1 has landed (<= 8 + EXTRA younger loads outstanding), barrier: everybody's
+// has and everybody is past chunk c-1; refill that slot with chunk c+3.  See pipe_handover (mlp16_core.hpp) for the accounting.
+template <int EXTRA, class Extra>
+__device__ __forceinline__ void pipe32_handover(Pipe32& p, const Extra& extra) {
+    wait_vm<8 + EXTRA>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    extra();
+    pipe32_issue(p);
+}
+
+__device__ __forceinline__ void idle_tile32(Pipe32& p) {
+#pragma unroll 1
+    for (int c = 0; c < M32_NCH; ++c) pipe32_handover<0>(p, NoExtra());
+    p.cons_slot = (p.cons_slot + M32_NCH) % RING_SLOTS;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the hand-interleaved groups.  Operands (numbers are template constants, printed into the register names):
+//   ca, cb   first AccVGPR of the group's two result tiles        ha / na  this group's / the next group's A-fragment buffer
+//   bq / nq  B-fragment buffer of this / the next k-substep        pb       first AccVGPR of the next k-substep's 8 inputs
+//   nb + o0  LDS address of the next group's first fragment        ba + bo  LDS address of the next k-substep's bias (aa: alpha weights)
+//   w        exact inverse of the previous layer's pack scale      al       this lane's part of the density logit (view layer)
+// ---------------------------------------------------------------------------------------------------------------------------
+#define M32_DRAIN "s_nop 15\n\ts_nop 15\n\ts_nop 7\n\t"
+#define M32_ACC_A "a[%[ca]:%[ca]+15]"
+#define M32_ACC_B "a[%[cb]:%[cb]+15]"
+#define M32_MF(ACC, AOFF, B, C) "v_mfma_f32_32x32x16_f16 " ACC ", v[%[ha]+" AOFF ":%[ha]+" AOFF "+3], " B ", " C "\n\t"
+#define M32_BH "v[%[bq]:%[bq]+3]"
+#define M32_BL "v[%[bq]+4:%[bq]+7]"
+#define M32_READS                                                \
+    "ds_read_b128 v[%[na]:%[na]+3], %[nb] offset:%[o0]\n\t"       \
+    "ds_read_b128 v[%[na]+4:%[na]+7], %[nb] offset:%[o0]+1024\n\t" \
+    "ds_read_b128 v[%[na]+8:%[na]+11], %[nb] offset:%[o0]+2048\n\t" \
+    "ds_read_b128 v[%[na]+12:%[na]+15], %[nb] offset:%[o0]+3072\n\t"
+// six MFMAs on two in-place accumulators (hh0 hh1 hl0 hl1 lh0 lh1: per accumulator the order hh, hl, lh of k_pe_mlp16); E0 sits in front
+// of the next group's fragment reads (what it reads from LDS is older than they are), E1..E5 behind the following MFMAs
+#define M32_GROUP_ON(ACC0, ACC1, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+    M32_MF(ACC0, "0", BH, C0) E0 READS                                           \
+    M32_MF(ACC1, "8", BH, C1) E1                                                 \
+    M32_MF(ACC0, "0", BL, ACC0) E2                                               \
+    M32_MF(ACC1, "8", BL, ACC1) E3                                               \
+    M32_MF(ACC0, "4", BH, ACC0) E4                                               \
+    M32_MF(ACC1, "12", BH, ACC1) E5
+#define M32_GROUP(BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
+    M32_GROUP_ON(M32_ACC_A, M32_ACC_B, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5)
+
+// epilogue pieces: value e of the next k-substep lives in t_e = v(200 + e)
+#define M32_RD(E) "v_accvgpr_read_b32 v20" #E ", a[%[pb]+" #E "]\n\t"
+#define M32_FMA(E) "v_fma_f32 v20" #E ", v20" #E ", %[w], v19" M32_BIAS_##E "\n\t"
+#define M32_BIAS_0 "2"
+#define M32_BIAS_1 "3"
+#define M32_BIAS_2 "4"
+#define M32_BIAS_3 "5"
+#define M32_BIAS_4 "6"
+#define M32_BIAS_5 "7"
+#define M32_BIAS_6 "8"
+#define M32_BIAS_7 "9"
+#define M32_MAX(E) "v_max_f32 v20" #E ", 0, v20" #E "\n\t"
+#define M32_AL(E) "v_fma_f32 %[al], v20" #E ", v18" M32_AW_##E ", %[al]\n\t"
+#define M32_AW_0 "4"
+#define M32_AW_1 "5"
+#define M32_AW_2 "6"
+#define M32_AW_3 "7"
+#define M32_AW_4 "8"
+#define M32_AW_5 "9"
+/* (values 6 and 7: v190, v191 -- written out, "v18" "10" would name v1810) */
+#define M32_AL6 "v_fma_f32 %[al], v206, v190, %[al]\n\t"
+#define M32_AL7 "v_fma_f32 %[al], v207, v191, %[al]\n\t"
+// hi/lo split of the pair (t_2P, t_2P+1) into dword P of the next B fragments (split8_mix, common.hpp)
+#define M32_CVT(P, E0_, E1_) "v_cvt_pk_f16_f32 v[%[nq]+" #P "], v20" #E0_ ", v20" #E1_ "\n\t"
+#define M32_MIX(P, E0_, E1_)                                                                                                  \
+    "v_fma_mixlo_f16 v[%[nq]+4+" #P "], v20" #E0_ ", 1.0, -v[%[nq]+" #P "] op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"               \
+    "v_fma_mixhi_f16 v[%[nq]+4+" #P "], v20" #E1_ ", 1.0, -v[%[nq]+" #P "] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+#define M32_BIAS_READS                                                  \
+    "ds_read_b128 v[192:195], %[ba] offset:%[bo]\n\t"                   \
+    "ds_read_b128 v[196:199], %[ba] offset:%[bo]+32\n\t"
+#define M32_ALPHA_READS                                                 \
+    "ds_read_b128 v[184:187], %[aa] offset:%[bo]\n\t"                   \
+    "ds_read_b128 v[188:191], %[aa] offset:%[bo]+32\n\t"
+
+#define M32_ASM(TEXT)                                                                                                        \
+    asm volatile(TEXT : [al] "+v"(al)                                                                                        \
+                 : [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ),              \
+                   [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), \
+                   [w] "v"(w)                                                                                                \
+                 : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
+#define M32_EMIT(READS, E0, E1, E2, E3, E4, E5)                                                          \
+    do {                                                                                                 \
+        if constexpr (FIRST) M32_ASM(M32_GROUP(M32_BH, M32_BL, "0", "0", READS, E0, E1, E2, E3, E4, E5)); \
+        else M32_ASM(M32_GROUP(M32_BH, M32_BL, M32_ACC_A, M32_ACC_B, READS, E0, E1, E2, E3, E4, E5));    \
+    } while (0)
+
+// EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep.  PF: prefetch the next group's fragments.
+template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO>
+__device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w) {
+    static_assert(PF && EPI >= 0 && EPI <= 4, "");
+    if constexpr (EPI == 0) M32_EMIT(M32_READS, "", "", "", "", "", "");
+    else if constexpr (EPI == 1)
+        M32_EMIT(M32_READS, M32_BIAS_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");
+    else if constexpr (EPI == 2)
+        M32_EMIT(M32_READS, M32_FMA(0) M32_FMA(1) M32_FMA(2), M32_FMA(3) M32_FMA(4) M32_FMA(5), M32_FMA(6) M32_FMA(7) M32_MAX(0),
+                 M32_MAX(1) M32_MAX(2) M32_MAX(3), M32_MAX(4) M32_MAX(5) M32_MAX(6), M32_MAX(7));
+    else if constexpr (EPI == 3)
+        M32_EMIT(M32_READS, M32_CVT(0, 0, 1) M32_CVT(1, 2, 3), M32_CVT(2, 4, 5) M32_CVT(3, 6, 7), M32_MIX(0, 0, 1), M32_MIX(1, 2, 3),
+                 M32_MIX(2, 4, 5), M32_MIX(3, 6, 7));
+    else M32_EMIT(M32_READS, "", "", "", "", "", "");
+}
+
+// The view layer's groups: their two accumulators are OPERANDS (compiler variables in AccVGPRs), not pinned registers -- the colour
+// head that follows is compiler-generated code, and this compiler takes every AccVGPR it does not know to be live for its own
+// values (it read the head's colour weights into a[0:59]).  EPI 5 / 6: the two groups of a k-substep (6 also without a prefetch:
+// never -- the tile's last group has no epilogue); the table reads of EPI 5 are OLDER than the fragment reads: lgkmcnt(4) = tables landed.
+template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO>
+__device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w) {
+#define M32_VIEW_ASM(TEXT, CONSTRAINT)                                                                                       \
+    asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1)                                              \
+                 : [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ), [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), \
+                   [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), [w] "v"(w)                           \
+                 : M32_V_CLOBBERS, M32_A1_CLOBBERS, "memory")
+#define M32_VIEW_EMIT(READS, E0, E1, E2, E3, E4, E5)                                                                          \
+    do {                                                                                                                     \
+        if constexpr (FIRST) M32_VIEW_ASM(M32_GROUP_ON("%[c0]", "%[c1]", M32_BH, M32_BL, "0", "0", READS, E0, E1, E2, E3, E4, E5), "=&a"); \
+        else M32_VIEW_ASM(M32_GROUP_ON("%[c0]", "%[c1]", M32_BH, M32_BL, "%[c0]", "%[c1]", READS, E0, E1, E2, E3, E4, E5), "+a"); \
+    } while (0)
+    static_assert(EPI == 0 || (PF && (EPI == 5 || EPI == 6)), "");
+    if constexpr (EPI == 0 && !PF) M32_VIEW_EMIT("", "", "", "", "", "", "");
+    else if constexpr (EPI == 0) M32_VIEW_EMIT(M32_READS, "", "", "", "", "", "");
+    else if constexpr (EPI == 5)
+        M32_VIEW_EMIT(M32_READS, M32_BIAS_READS M32_ALPHA_READS, M32_RD(0) M32_RD(1) M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5) M32_RD(6) M32_RD(7),
+                      "s_waitcnt lgkmcnt(4)\n\t" M32_FMA(0) M32_FMA(1) M32_FMA(2) M32_FMA(3), M32_FMA(4) M32_FMA(5) M32_FMA(6) M32_FMA(7),
+                      M32_MAX(0) M32_MAX(1) M32_MAX(2) M32_MAX(3));
+    else
+        M32_VIEW_EMIT(M32_READS, M32_MAX(4) M32_MAX(5) M32_MAX(6) M32_MAX(7), M32_AL(0) M32_AL(1) M32_AL(2) M32_AL(3),
+                      M32_AL(4) M32_AL(5) M32_AL6 M32_AL7, M32_CVT(0, 0, 1) M32_CVT(1, 2, 3) M32_CVT(2, 4, 5) M32_CVT(3, 6, 7),
+                      M32_MIX(0, 0, 1) M32_MIX(1, 2, 3), M32_MIX(2, 4, 5) M32_MIX(3, 6, 7) "s_nop 1\n\t");
+#undef M32_VIEW_EMIT
+#undef M32_VIEW_ASM
+}
+
+// the same group with the B fragments in compiler registers (the positional-encoding k-substeps: no epilogue rides on them)
+template <bool FIRST, int CA, int HA, int O0>
+__device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb) {
+#define M32_PE_ASM(C0, C1)                                                                                                   \
+    asm volatile("s_nop 1\n\t" M32_GROUP("%[xh]", "%[xl]", C0, C1, M32_READS, "", "", "", "", "", "")                                    \
+                 :: [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl),  \
+                    [nb] "v"(nb), [o0] "n"(O0)                                                                               \
+                 : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
+    if constexpr (FIRST) M32_PE_ASM("0", "0");
+    else M32_PE_ASM(M32_ACC_A, M32_ACC_B);
+#undef M32_PE_ASM
+}
+
+// the first group's fragments of the chunk at `base` (LDS address, lane * 16 included) -> buffer 0
+__device__ __forceinline__ void m32_prefetch0(unsigned base) {
+    asm volatile("ds_read_b128 v[224:227], %0\n\tds_read_b128 v[228:231], %0 offset:1024\n\t"
+                 "ds_read_b128 v[232:235], %0 offset:2048\n\tds_read_b128 v[236:239], %0 offset:3072" ::"v"(base)
+                 : M32_V_CLOBBERS, "memory");
+}
+
+// B fragments of k-substep 0 of the next layer from the layer just finished (bank PBANK), into buffer 0; VIEW: + the density logit
+template <int PBANK, bool VIEW>
+__device__ __forceinline__ void m32_layer_end(float& al, unsigned ba, unsigned aa, float w) {
+#define M32_END_ASM(TEXT)                                                                                  \
+    asm volatile(TEXT : [al] "+v"(al) : [nq] "n"(216), [pb] "n"(PBANK * 128), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(0), [w] "v"(w) \
+                 : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
+#define M32_END_HEAD M32_DRAIN M32_BIAS_READS
+#define M32_END_VALUES                                                                                                        \
+    M32_RD(0) M32_RD(1) M32_RD(2) M32_RD(3) M32_RD(4) M32_RD(5) M32_RD(6) M32_RD(7) "s_waitcnt lgkmcnt(0)\n\t"               \
+    M32_FMA(0) M32_FMA(1) M32_FMA(2) M32_FMA(3) M32_FMA(4) M32_FMA(5) M32_FMA(6) M32_FMA(7)                                   \
+    M32_MAX(0) M32_MAX(1) M32_MAX(2) M32_MAX(3) M32_MAX(4) M32_MAX(5) M32_MAX(6) M32_MAX(7)
+#define M32_END_SPLIT                                                                                                         \
+    M32_CVT(0, 0, 1) M32_CVT(1, 2, 3) M32_CVT(2, 4, 5) M32_CVT(3, 6, 7) M32_MIX(0, 0, 1) M32_MIX(1, 2, 3) M32_MIX(2, 4, 5) M32_MIX(3, 6, 7) \
+    "s_nop 2\n\t"
+    if constexpr (VIEW)
+        M32_END_ASM(M32_END_HEAD M32_ALPHA_READS M32_END_VALUES M32_AL(0) M32_AL(1) M32_AL(2) M32_AL(3) M32_AL(4) M32_AL(5) M32_AL6 M32_AL7
+                    M32_END_SPLIT);
+    else M32_END_ASM(M32_END_HEAD M32_END_VALUES M32_END_SPLIT);
+#undef M32_END_ASM
+}
+
+// one float of a table that is written before the first barrier and never again, by a read the compiler does not track (a tracked
+// read -- or a global load, which the "memory" clobbers of the groups would make it repeat per group -- waits with vmcnt(0): the ring)
+__device__ __forceinline__ float m32_lds_f32(unsigned addr) {
+    float x;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(addr) : "memory");
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k-substeps and layers
+// ---------------------------------------------------------------------------------------------------------------------------
+// dense layer, k-substep U (chunk U / 2, half U % 2): 4 groups; the epilogue of k-substep U + 1 rides on them (none on U = 15)
+template <int BANK, int U, bool FIRST>
+__device__ __forceinline__ void m32_dense_ksub(float& al, unsigned cbase, unsigned nbase, unsigned ba, float w) {
+    constexpr int H = U & 1, BQ = H ? 208 : 216, PB = (1 - BANK) * 128 + 8 * (U + 1), BO = 64 * (U + 1);
+    constexpr bool EPI = U < 15;
+    m32_group<EPI ? 1 : 0, FIRST, true, BANK * 128 + 0, 224, BQ, PB, (H * 4 + 1) * 4096, BO>(al, cbase, ba, ba, w);
+    m32_group<EPI ? 2 : 0, FIRST, true, BANK * 128 + 32, 240, BQ, PB, (H * 4 + 2) * 4096, BO>(al, cbase, ba, ba, w);
+    m32_group<EPI ? 3 : 0, FIRST, true, BANK * 128 + 64, 224, BQ, PB, (H * 4 + 3) * 4096, BO>(al, cbase, ba, ba, w);
+    // the chunk's last group reads the first group of the NEXT chunk (published by the hand-over in front of this one)
+    m32_group<EPI ? 4 : 0, FIRST, true, BANK * 128 + 96, 240, BQ, PB, H ? 0 : 4 * 4096, BO>(al, H ? nbase : cbase, ba, ba, w);
+}
+
+struct RingPos {
+    unsigned cbase, nbase;
+};
+__device__ __forceinline__ RingPos m32_next_chunk(Pipe32& p, unsigned lds_ring) {
+    RingPos r;
+    r.cbase = lds_ring + (unsigned)p.cons_slot * CHUNK_BYTES;
+    p.cons_slot = p.cons_slot + 1 == RING_SLOTS ? 0 : p.cons_slot + 1;
+    r.nbase = lds_ring + (unsigned)p.cons_slot * CHUNK_BYTES;
+    return r;
+}
+
+// 256 -> 256 layer into bank BANK from the other bank's result.  first: the accumulators start from zero (false: the skip layer,
+// whose encoding part has been accumulated already).  On entry B buffer 0 holds k-substep 0 (m32_layer_end).
+template <int BANK>
+__device__ __forceinline__ void m32_dense_layer(Pipe32& p, float& al, unsigned ba, float w, bool first) {
+#define M32_CHUNK(C)                                                                            \
+    {                                                                                           \
+        pipe32_handover<0>(p, NoExtra());                                                       \
+        const RingPos r = m32_next_chunk(p, ring_lane_addr());                                  \
+        m32_dense_ksub<BANK, 2 * (C), false>(al, r.cbase, r.nbase, ba, w);                      \
+        m32_dense_ksub<BANK, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba, w);                  \
+    }
+    {
+        pipe32_handover<0>(p, NoExtra());
+        const RingPos r = m32_next_chunk(p, ring_lane_addr());
+        if (first) m32_dense_ksub<BANK, 0, true>(al, r.cbase, r.nbase, ba, w);
+        else m32_dense_ksub<BANK, 0, false>(al, r.cbase, r.nbase, ba, w);
+        m32_dense_ksub<BANK, 1, false>(al, r.cbase, r.nbase, ba, w);
+    }
+    M32_CHUNK(1) M32_CHUNK(2) M32_CHUNK(3) M32_CHUNK(4) M32_CHUNK(5) M32_CHUNK(6) M32_CHUNK(7)
+#undef M32_CHUNK
+}
+
+// the 13 k-substeps of the positional encoding (7 chunks, the second half of the last one is padding) into bank BANK, from zero
+template <int BANK>
+__device__ __forceinline__ void m32_pe_layer(Pipe32& p, const half8 (&xh)[13], const half8 (&xl)[13]) {
+#define M32_PE_KSUB(U, FIRST_, LASTOFF, LASTBASE)                                                                \
+    m32_group_pe<FIRST_, BANK * 128 + 0, 224, (((U) & 1) * 4 + 1) * 4096>(xh[U], xl[U], r.cbase);                \
+    m32_group_pe<FIRST_, BANK * 128 + 32, 240, (((U) & 1) * 4 + 2) * 4096>(xh[U], xl[U], r.cbase);               \
+    m32_group_pe<FIRST_, BANK * 128 + 64, 224, (((U) & 1) * 4 + 3) * 4096>(xh[U], xl[U], r.cbase);               \
+    m32_group_pe<FIRST_, BANK * 128 + 96, 240, LASTOFF>(xh[U], xl[U], LASTBASE);
+#define M32_PE_CHUNK(C)                                                                                          \
+    {                                                                                                            \
+        pipe32_handover<0>(p, NoExtra());                                                                        \
+        const RingPos r = m32_next_chunk(p, ring_lane_addr());                                                   \
+        M32_PE_KSUB(2 * (C), (C) == 0, 4 * 4096, r.cbase)                                                        \
+        M32_PE_KSUB(2 * (C) + 1, false, 0, r.nbase)                                                              \
+    }
+    M32_PE_CHUNK(0) M32_PE_CHUNK(1) M32_PE_CHUNK(2) M32_PE_CHUNK(3) M32_PE_CHUNK(4) M32_PE_CHUNK(5)
+    {
+        pipe32_handover<0>(p, NoExtra());
+        const RingPos r = m32_next_chunk(p, ring_lane_addr());
+        M32_PE_KSUB(12, false, 0, r.nbase)
+    }
+#undef M32_PE_CHUNK
+#undef M32_PE_KSUB
+}
+
+// view layer (256 -> 128: four result tiles `accv` from bank 1): k-substep U = 2 groups, 4 k-substeps per chunk
+template <int U>
+__device__ __forceinline__ void m32_view_ksub(f32x16 (&accv)[4], float& al, unsigned cbase, unsigned nbase, unsigned ba, unsigned aa, float w) {
+    constexpr int UC = U & 3, BQ = (U & 1) ? 208 : 216, PB = 128 + 8 * (U + 1), BO = 64 * (U + 1);
+    constexpr bool EPI = U < 15, FIRST = U == 0;
+    m32_view_group<EPI ? 5 : 0, FIRST, true, 224, BQ, PB, (UC * 2 + 1) * 4096, BO>(accv[0], accv[1], al, cbase, ba, aa, w);
+    // the tile's very last group prefetches nothing: the fragment buffers are dead across the head and the next tile's prologue
+    if constexpr (U == 15) m32_view_group<0, false, false, 240, BQ, PB, 0, BO>(accv[2], accv[3], al, cbase, ba, aa, w);
+    else m32_view_group<6, FIRST, true, 240, BQ, PB, UC == 3 ? 0 : (UC * 2 + 2) * 4096, BO>(accv[2], accv[3], al, UC == 3 ? nbase : cbase, ba, aa, w);
+}
+
+// the 8 positional-encoding values of k-substep U held by this lane: slot j = 8 U + e = 13 c + t of the lane's channel c (kk = 8 g + c):
+// t = 0: x, t = 1 + 2 l: sin(2^l x), t = 2 + 2 l: cos(2^l x); j >= 104 is padding (pe_kstep of k_mlp16.hip with 8 channels per lane)
+template <int U>
+__device__ __forceinline__ void pe32_ksub(const float (&hv)[8], float& cs_keep, float (&v8)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = 8 * U + e, c = j / 13, t = j % 13;
+        float val = 0.f;
+        if (j < 104) {
+            if (t == 0) val = hv[c];
+            else if (t & 1) {
+                float sn;
+                pe_sincos(hv[c] * (float)(1 << ((t - 1) >> 1)), &sn, &cs_keep);
+                val = sn;
+            } else val = cs_keep;
+        }
+        v8[e] = val;
+    }
+}
+
+struct TileSrc32 {
+    const float* h;
+    const int32_t* list;
+    const char* dummy;
+    int next_row0, n;
+    char* stage;
+};
+// the next tile's 32 rows of this wavefront (blended features, list entries) -> its staging area: three LDS-DMA loads
+struct StageRows32 {
+    const TileSrc32& t;
+    __device__ __forceinline__ void operator()() const {
+        int row0 = t.next_row0;
+        asm volatile("" : "+s"(row0));
+        const int lane = (int)(lane_off16() >> 4);
+        const int r0 = min(row0 + (lane >> 2), t.n - 1), r1 = min(row0 + 16 + (lane >> 2), t.n - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.h + (size_t)r0 * DANBO_H_STRIDE + 4 * (lane & 3)),
+                                         (__attribute__((address_space(3))) void*)t.stage, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.h + (size_t)r1 * DANBO_H_STRIDE + 4 * (lane & 3)),
+                                         (__attribute__((address_space(3))) void*)(t.stage + 1024), 16, 0, 0);
+        const int rl = min(row0 + (lane & 31), t.n - 1);
+        const void* src_l = t.list ? (const void*)(t.list + rl) : (const void*)(t.dummy + 4 * lane);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_l,
+                                         (__attribute__((address_space(3))) void*)(t.stage + M32_STAGE_H), 4, 0, 0);
+    }
+};
+
+__global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_bias = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);  // [8][256]
+    float* s_aw = s_bias + 8 * M32_W;                                           // [256]
+    float* s_rgbw = s_aw + M32_W;                                               // [3][128]
+    float* s_misc = s_rgbw + 3 * M32_VW;                                        // alpha_b, rgb_b[3]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // exact inverses of the nine matrices' pack scales (trailer of the packed buffer) -> LDS
+    if (tid < 9) s_misc[4 + tid] = reinterpret_cast<const float*>(a.packed + (size_t)M32_NCH * CHUNK_BYTES)[tid];
+    for (int i = tid; i < 8 * M32_W; i += M32_THREADS) s_bias[i] = a.pts_b[i >> 8][i & 255];
+    if (tid < M32_W) s_aw[tid] = a.alpha_w[tid];
+    for (int i = tid; i < 3 * M32_VW; i += M32_THREADS) s_rgbw[i] = a.rgb_w[i];
+    if (tid < 4) s_misc[tid] = tid == 0 ? a.alpha_b[0] : a.rgb_b[tid - 1];
+
+    const int n = resolve_count(a.count, a.n_cap);
+    // rounds as in k_pe_mlp16: row groups of 32 (one wavefront's samples), 4 per workgroup and full round, the partial round spread
+    // over all workgroups (`gpw` groups each; wavefronts without one only keep the ring's hand-overs going)
+    const int G = (n + 31) >> 5;
+    const int per_round = 4 * (int)gridDim.x;
+    const int full = G / per_round, rem = G - full * per_round;
+    const int gpw = (rem + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int my_rounds = full + ((int)blockIdx.x * gpw < rem ? 1 : 0);
+    if (my_rounds == 0) return;
+    auto round_base = [&](int r) { return r < full ? (r * (int)gridDim.x + (int)blockIdx.x) * 4 : full * per_round + (int)blockIdx.x * gpw; };
+    auto round_waves = [&](int r) { return r < full ? 4 : min(gpw, G - round_base(r)); };
+
+    Pipe32 p;
+    p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave;
+    pipe32_issue(p);
+    pipe32_issue(p);
+    pipe32_issue(p);
+    TileSrc32 src;
+    src.h = a.h; src.list = a.list; src.dummy = a.packed; src.n = n;
+    src.stage = smem + RING_SLOTS * CHUNK_BYTES + M32_TABLE_FLOATS * 4 + wave * M32_STAGE;
+    src.next_row0 = (round_base(0) + wave) * 32;
+    StageRows32{src}();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int rnd = 0; rnd < my_rounds; ++rnd) {
+        const int grp_i = round_base(rnd) + wave;
+        if (wave >= round_waves(rnd)) {
+            idle_tile32(p);
+            continue;
+        }
+        // ------------------------------------------------------------------ inputs (staged during the previous tile's view layer)
+        int zero_t = 0;
+        asm volatile("" : "+s"(zero_t));
+        const int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_t));
+        const int m = lane_t & 31, g_t = lane_t >> 5;
+        const int row0 = grp_i * 32 + m;
+        const bool row_ok = row0 < n;
+        const float* sh = reinterpret_cast<const float*>(src.stage) + m * DANBO_H_STRIDE + 8 * g_t;
+        const int staged_dst = reinterpret_cast<const int*>(src.stage + M32_STAGE_H)[m];
+        int dst = row_ok ? (a.list ? staged_dst : row0) : -1;
+        asm volatile("" : "+v"(dst));       // materialised now: the staging area is overwritten during this tile's view layer
+        float hv[8];
+        {
+            const float4 h0 = *reinterpret_cast<const float4*>(sh), h1 = *reinterpret_cast<const float4*>(sh + 4);
+            hv[0] = h0.x; hv[1] = h0.y; hv[2] = h0.z; hv[3] = h0.w; hv[4] = h1.x; hv[5] = h1.y; hv[6] = h1.z; hv[7] = h1.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) hv[c] = row_ok ? hv[c] : 0.f;
+        if (g_t == 1) hv[7] = 0.f;                                   // channel 15 is padding
+        src.next_row0 = (round_base(rnd + 1) + wave) * 32;
+        // the encoding's B fragments, made once per tile and kept for the skip layer
+        half8 xh[13], xl[13];
+        {
+            float cs_keep = 0.f;
+#define M32_PE(U) { float v8[8]; pe32_ksub<U>(hv, cs_keep, v8); split8_mix(v8, xh[U], xl[U]); }
+            M32_PE(0) M32_PE(1) M32_PE(2) M32_PE(3) M32_PE(4) M32_PE(5) M32_PE(6) M32_PE(7) M32_PE(8) M32_PE(9) M32_PE(10) M32_PE(11) M32_PE(12)
+#undef M32_PE
+        }
+        float al = 0.f;
+        f32x16 accv[4];          // the view layer's result tiles (features 32 T + 8 (r / 4) + 4 g + r % 4)
+        const unsigned tab = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)s_bias;
+        const unsigned g16 = (lane_off16() >> 9) << 4;        // 16 g bytes: the lane group's 4 floats inside a block of 8 features
+        const unsigned winv_at = tab + (unsigned)(M32_TABLE_FLOATS - 12) * 4u;
+#define M32_WINV(L_) m32_lds_f32(winv_at + 4u * (unsigned)(L_))
+        m32_prefetch0(ring_lane_addr() + (unsigned)p.cons_slot * CHUNK_BYTES);
+        // layer 0: the encoding into bank 0
+        m32_pe_layer<0>(p, xh, xl);
+        m32_layer_end<0, false>(al, tab + g16, 0u, M32_WINV(0));
+#pragma unroll 1
+        for (int pr = 0; pr < 3; ++pr) {
+            // odd layer L = 2 pr + 1: bank 1 <- bank 0 (L = 5: the encoding first); even layer L + 1: bank 0 <- bank 1
+            const int L = 2 * pr + 1;
+            const unsigned ba_in = tab + (unsigned)(L - 1) * 1024u + g16;
+            if (pr == 2) m32_pe_layer<1>(p, xh, xl);
+            m32_dense_layer<1>(p, al, ba_in, M32_WINV(L - 1), pr != 2);
+            const float w_l = M32_WINV(L);
+            m32_layer_end<1, false>(al, ba_in + 1024u, 0u, w_l);
+            m32_dense_layer<0>(p, al, ba_in + 1024u, w_l, true);
+            m32_layer_end<0, false>(al, ba_in + 2048u, 0u, M32_WINV(L + 1));
+        }
+        // (outside the loop: the view layer's accumulators are compiler variables, and every statement of the loop clobbers every AccVGPR)
+        {
+            // layer 7: bank 1 <- bank 0
+            m32_dense_layer<1>(p, al, tab + 6u * 1024u + g16, M32_WINV(6), true);
+            // view layer (feature_linear merged into views_linears.0): accv <- bank 1, + the density logit
+            const unsigned ba_out = tab + 7u * 1024u + g16, aa = tab + 8u * 1024u + g16;
+            const float w_7 = M32_WINV(7);
+            m32_layer_end<1, true>(al, ba_out, aa, w_7);
+            const StageRows32 stage{src};
+#define M32_VCHUNK(C, EXTRA_, STAGE_)                                                              \
+            {                                                                                      \
+                pipe32_handover<EXTRA_>(p, STAGE_);                                                \
+                const RingPos r = m32_next_chunk(p, ring_lane_addr());                             \
+                m32_view_ksub<4 * (C)>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);               \
+                m32_view_ksub<4 * (C) + 1>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);           \
+                m32_view_ksub<4 * (C) + 2>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);           \
+                m32_view_ksub<4 * (C) + 3>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);           \
+            }
+            M32_VCHUNK(0, 0, stage)            // the staging loads sit between the barrier and the refill:
+            M32_VCHUNK(1, 3, NoExtra())        // older than chunk c + 3, younger than what the next hand-over waits for
+            M32_VCHUNK(2, 0, NoExtra())
+            M32_VCHUNK(3, 0, NoExtra())
+#undef M32_VCHUNK
+        }
+        asm volatile(M32_DRAIN : "+a"(accv[0]), "+a"(accv[1]), "+a"(accv[2]), "+a"(accv[3])::"memory");
+        // ------------------------------------------------------------------ colour head + output
+        int zero_h = 0;
+        asm volatile("" : "+s"(zero_h));
+        const int lane_h = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_h));
+        const int g = lane_h >> 5;
+        const int row = grp_i * 32 + (lane_h & 31);
+        asm volatile("" : "+v"(dst));
+        int S_ = a.S;
+        asm volatile("" : "+s"(S_));       // the division's reciprocal is formed here, not hoisted out of the tile loop and spilled
+        const int ray = dst >= 0 ? dst / S_ : 0;
+        f32x4 cv[16];
+        {
+            const float* cvb = a.cview ? a.cview + (size_t)ray * M32_VW + 4 * g : reinterpret_cast<const float*>(a.packed);
+#define M32_CV(T, Q) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(cv[4 * (T) + (Q)]) : "v"(cvb), "i"((T) * 128 + (Q) * 32) : "memory");
+#define M32_CV4(T) M32_CV(T, 0) M32_CV(T, 1) M32_CV(T, 2) M32_CV(T, 3)
+            M32_CV4(0) M32_CV4(1) M32_CV4(2) M32_CV4(3)
+#undef M32_CV4
+#undef M32_CV
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(cv[i]));
+        }
+        float pr_ = 0.f, pg_ = 0.f, pb_ = 0.f;
+        float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (M32_VW + 1) + 4 * g : nullptr;
+        const float winv_v = M32_WINV(8);
+#undef M32_WINV
+#define M32_HEAD(T, Q)                                                                                                          \
+        {                                                                                                                       \
+            constexpr int nn = 32 * (T) + 8 * (Q);                                                                              \
+            const float a0 = accv[T][4 * (Q) + 0], a1 = accv[T][4 * (Q) + 1], a2 = accv[T][4 * (Q) + 2], a3 = accv[T][4 * (Q) + 3]; \
+            f32x4 c4 = cv[4 * (T) + (Q)];                                                                                       \
+            if (!a.cview) c4 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                       \
+            if (aux) *reinterpret_cast<float4*>(aux + nn) = make_float4(a0 * winv_v, a1 * winv_v, a2 * winv_v, a3 * winv_v);    \
+            const float x0 = fmaxf(fmaf(a0, winv_v, c4[0]), 0.f), x1 = fmaxf(fmaf(a1, winv_v, c4[1]), 0.f);                     \
+            const float x2 = fmaxf(fmaf(a2, winv_v, c4[2]), 0.f), x3 = fmaxf(fmaf(a3, winv_v, c4[3]), 0.f);                     \
+            const float4 wr = *reinterpret_cast<const float4*>(s_rgbw + 0 * M32_VW + nn + 4 * g);                               \
+            const float4 wg = *reinterpret_cast<const float4*>(s_rgbw + 1 * M32_VW + nn + 4 * g);                               \
+            const float4 wb = *reinterpret_cast<const float4*>(s_rgbw + 2 * M32_VW + nn + 4 * g);                               \
+            pr_ = fmaf(x0, wr.x, pr_); pr_ = fmaf(x1, wr.y, pr_); pr_ = fmaf(x2, wr.z, pr_); pr_ = fmaf(x3, wr.w, pr_);         \
+            pg_ = fmaf(x0, wg.x, pg_); pg_ = fmaf(x1, wg.y, pg_); pg_ = fmaf(x2, wg.z, pg_); pg_ = fmaf(x3, wg.w, pg_);         \
+            pb_ = fmaf(x0, wb.x, pb_); pb_ = fmaf(x1, wb.y, pb_); pb_ = fmaf(x2, wb.z, pb_); pb_ = fmaf(x3, wb.w, pb_);         \
+        }
+#define M32_HEAD4(T) M32_HEAD(T, 0) M32_HEAD(T, 1) M32_HEAD(T, 2) M32_HEAD(T, 3)
+        M32_HEAD4(0) M32_HEAD4(1) M32_HEAD4(2) M32_HEAD4(3)
+#undef M32_HEAD4
+#undef M32_HEAD
+        // the other lane group's half (lane ^ 32): v_permlane32_swap, selected by the lane group re-derived above
+        auto other = [&](float x) {
+            const unsigned u = __builtin_bit_cast(unsigned, x);
+            const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            return __builtin_bit_cast(float, g ? r[0] : r[1]);
+        };
+        const float r_ = pr_ + other(pr_) + s_misc[1];
+        const float g_ = pg_ + other(pg_) + s_misc[2];
+        const float b_ = pb_ + other(pb_) + s_misc[3];
+        const float al_ = al + other(al) + s_misc[0];
+        if (g == 0 && dst >= 0) {
+            reinterpret_cast<float4*>(a.raw_out)[dst] = make_float4(r_, g_, b_, al_);
+            if (a.aux_out) a.aux_out[(size_t)row * (M32_VW + 1) + M32_VW] = al_;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace danbo
+
+using namespace danbo;
+
+// danbo_pe_mlp16_fwd's contract on weights packed by danbo_mlp32_pack
+extern "C" int danbo_pe_mlp32_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
+                                   const void* packed32, const float* const* pts_b, const float* alpha_w,
+                                   const float* alpha_b, const float* cview, const float* rgb_w,
+                                   const float* rgb_b, float* raw_out, float* aux_out, void* stream) {
+    DANBO_CHECK_ARG(n >= 0 && S > 0 && h && packed32 && pts_b && raw_out);
+    if (n == 0) return 0;
+    Mlp32Args a;
+    a.h = h; a.list = list; a.count = count; a.n_cap = n; a.S = S; a.packed = reinterpret_cast<const char*>(packed32);
+    for (int i = 0; i < 8; ++i) a.pts_b[i] = pts_b[i];
+    a.alpha_w = alpha_w; a.alpha_b = alpha_b; a.cview = cview;
+    a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.raw_out = raw_out; a.aux_out = aux_out;
+    DANBO_ENSURE_LDS(k_pe_mlp32, M32_LDS_BYTES);
+    const int groups = ceil_div(n, 32);
+    const int grid = groups < num_cu() ? groups : num_cu();
+    hipLaunchKernelGGL(k_pe_mlp32, dim3(grid), dim3(M32_THREADS), M32_LDS_BYTES, (hipStream_t)stream, a);
+    DANBO_LAUNCH_RET();
+}
