@@ -83,6 +83,38 @@ __device__ __forceinline__ void pipe32_handover(Pipe32& p, const Extra& extra) {
     pipe32_issue(p);
 }
 
+// A wavefront WITH rows spreads its 8 loads of chunk c + 3 over the 8 groups of chunk c (one LDS-DMA instruction behind each group's
+// second MFMA): issued in one piece by the hand-over they cost ~ 500 cycles per chunk in which the matrix pipe has nothing to do --
+// there is no partner wavefront on the SIMD to cover them.  The hand-over itself is then a wait and a barrier.
+struct Dma32 {
+    const char* src;      // this wavefront's 8 KB of the chunk to load (wave-uniform)
+    unsigned dst;         // LDS byte address of the same 8 KB in the slot being refilled (M0)
+    unsigned v0, v1;      // lane * 16, lane * 16 + 4096
+};
+template <int EXTRA, class Extra>
+__device__ __forceinline__ Dma32 pipe32_sync(Pipe32& p, const Extra& extra) {
+    wait_vm<8 + EXTRA>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    extra();
+    Dma32 d;
+    d.src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192;
+    d.dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192);
+    d.v0 = lane_off16();
+    d.v1 = d.v0 + 4096u;
+    p.issue_chunk = p.issue_chunk + 1 == M32_NCH ? 0 : p.issue_chunk + 1;
+    p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
+    return d;
+}
+// pieces 0 .. 3 of a refill by the hand-over itself (the encoding's last chunk has four groups for eight pieces)
+__device__ __forceinline__ void pipe32_issue_half(const Dma32& d) {
+#define DANBO_PIECE(Q)                                                                                                  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(d.src + d.v0),                     \
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)d.dst, 16, (Q) * 1024, 0)
+    DANBO_PIECE(0); DANBO_PIECE(1); DANBO_PIECE(2); DANBO_PIECE(3);
+#undef DANBO_PIECE
+}
+
 __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 #pragma unroll 1
     for (int c = 0; c < M32_NCH; ++c) pipe32_handover<0>(p, NoExtra());
@@ -110,13 +142,21 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 // six MFMAs on two in-place accumulators (hh0 hh1 hl0 hl1 lh0 lh1: per accumulator the order hh, hl, lh of k_pe_mlp16); E0 sits in front
 // of the next group's fragment reads (what it reads from LDS is older than they are), E1..E5 behind the following MFMAs
 #define M32_GROUP_ON(ACC0, ACC1, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
+    M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, M32_DMA, E0, E1, E2, E3, E4, E5)
+#define M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, DMA, E0, E1, E2, E3, E4, E5) \
     "s_waitcnt lgkmcnt(0)\n\t"                                                   \
     M32_MF(ACC0, "0", BH, C0) E0 READS                                           \
-    M32_MF(ACC1, "8", BH, C1) E1                                                 \
+    M32_MF(ACC1, "8", BH, C1) DMA E1                                             \
     M32_MF(ACC0, "0", BL, ACC0) E2                                               \
     M32_MF(ACC1, "8", BL, ACC1) E3                                               \
     M32_MF(ACC0, "4", BH, ACC0) E4                                               \
     M32_MF(ACC1, "12", BH, ACC1) E5
+// piece Q of this wavefront's share of the chunk being refilled: M0 = LDS destination, one wait state in front of its use.  M0 is
+// SAVED AND RESTORED: the compiler does not see an asm statement's write to it ("m0" is not accepted as a clobber) and hoists / merges
+// its own M0 initialisations across statements -- the staging loads of the next tile's rows then went to wherever the last piece had
+// pointed M0 (into the ring: a view-layer chunk; found as wrong colours beside correct densities)
+#define M32_DMA "s_mov_b32 %[ms], m0\n\ts_mov_b32 m0, %[gm]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[gv], %[gs] offset:%[gq]\n\ts_mov_b32 m0, %[ms]\n\t"
+#define M32_DMA_OPERANDS [gm] "s"(Q >= 4 ? d.dst + 4096u : d.dst), [gv] "v"(Q >= 4 ? d.v1 : d.v0), [gs] "s"(d.src), [gq] "n"((Q & 3) * 1024)
 #define M32_GROUP(BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
     M32_GROUP_ON(M32_ACC_A, M32_ACC_B, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5)
 
@@ -155,10 +195,10 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
     "ds_read_b128 v[188:191], %[aa] offset:%[bo]+32\n\t"
 
 #define M32_ASM(TEXT)                                                                                                        \
-    asm volatile(TEXT : [al] "+v"(al)                                                                                        \
+    asm volatile(TEXT : [al] "+v"(al), [ms] "=&s"(m0_save)                                                                   \
                  : [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ),              \
                    [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), \
-                   [w] "v"(w)                                                                                                \
+                   [w] "v"(w), M32_DMA_OPERANDS                                                                              \
                  : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
 #define M32_EMIT(READS, E0, E1, E2, E3, E4, E5)                                                          \
     do {                                                                                                 \
@@ -167,8 +207,9 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
     } while (0)
 
 // EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep.  PF: prefetch the next group's fragments.
-template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO>
-__device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w) {
+template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO, int Q>
+__device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
+    unsigned m0_save;
     static_assert(PF && EPI >= 0 && EPI <= 4, "");
     if constexpr (EPI == 0) M32_EMIT(M32_READS, "", "", "", "", "", "");
     else if constexpr (EPI == 1)
@@ -186,12 +227,13 @@ __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, u
 // head that follows is compiler-generated code, and this compiler takes every AccVGPR it does not know to be live for its own
 // values (it read the head's colour weights into a[0:59]).  EPI 5 / 6: the two groups of a k-substep (6 also without a prefetch:
 // never -- the tile's last group has no epilogue); the table reads of EPI 5 are OLDER than the fragment reads: lgkmcnt(4) = tables landed.
-template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO>
-__device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w) {
+template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO, int Q>
+__device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
+    unsigned m0_save;
 #define M32_VIEW_ASM(TEXT, CONSTRAINT)                                                                                       \
-    asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1)                                              \
+    asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1), [ms] "=&s"(m0_save)                         \
                  : [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ), [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), \
-                   [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), [w] "v"(w)                           \
+                   [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), [w] "v"(w), M32_DMA_OPERANDS         \
                  : M32_V_CLOBBERS, M32_A1_CLOBBERS, "memory")
 #define M32_VIEW_EMIT(READS, E0, E1, E2, E3, E4, E5)                                                                          \
     do {                                                                                                                     \
@@ -214,12 +256,14 @@ __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al
 }
 
 // the same group with the B fragments in compiler registers (the positional-encoding k-substeps: no epilogue rides on them)
-template <bool FIRST, int CA, int HA, int O0>
-__device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb) {
+template <bool FIRST, int CA, int HA, int O0, int Q>
+__device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb, const Dma32& d) {
+    unsigned m0_save;
 #define M32_PE_ASM(C0, C1)                                                                                                   \
     asm volatile("s_nop 1\n\t" M32_GROUP("%[xh]", "%[xl]", C0, C1, M32_READS, "", "", "", "", "", "")                                    \
-                 :: [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl),  \
-                    [nb] "v"(nb), [o0] "n"(O0)                                                                               \
+                 : [ms] "=&s"(m0_save)                                                                                       \
+                 : [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl),   \
+                    [nb] "v"(nb), [o0] "n"(O0), M32_DMA_OPERANDS                                                             \
                  : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
     if constexpr (FIRST) M32_PE_ASM("0", "0");
     else M32_PE_ASM(M32_ACC_A, M32_ACC_B);
@@ -267,14 +311,14 @@ __device__ __forceinline__ float m32_lds_f32(unsigned addr) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // dense layer, k-substep U (chunk U / 2, half U % 2): 4 groups; the epilogue of k-substep U + 1 rides on them (none on U = 15)
 template <int BANK, int U, bool FIRST>
-__device__ __forceinline__ void m32_dense_ksub(float& al, unsigned cbase, unsigned nbase, unsigned ba, float w) {
+__device__ __forceinline__ void m32_dense_ksub(float& al, unsigned cbase, unsigned nbase, unsigned ba, float w, const Dma32& d) {
     constexpr int H = U & 1, BQ = H ? 208 : 216, PB = (1 - BANK) * 128 + 8 * (U + 1), BO = 64 * (U + 1);
     constexpr bool EPI = U < 15;
-    m32_group<EPI ? 1 : 0, FIRST, true, BANK * 128 + 0, 224, BQ, PB, (H * 4 + 1) * 4096, BO>(al, cbase, ba, ba, w);
-    m32_group<EPI ? 2 : 0, FIRST, true, BANK * 128 + 32, 240, BQ, PB, (H * 4 + 2) * 4096, BO>(al, cbase, ba, ba, w);
-    m32_group<EPI ? 3 : 0, FIRST, true, BANK * 128 + 64, 224, BQ, PB, (H * 4 + 3) * 4096, BO>(al, cbase, ba, ba, w);
+    m32_group<EPI ? 1 : 0, FIRST, true, BANK * 128 + 0, 224, BQ, PB, (H * 4 + 1) * 4096, BO, H * 4 + 0>(al, cbase, ba, ba, w, d);
+    m32_group<EPI ? 2 : 0, FIRST, true, BANK * 128 + 32, 240, BQ, PB, (H * 4 + 2) * 4096, BO, H * 4 + 1>(al, cbase, ba, ba, w, d);
+    m32_group<EPI ? 3 : 0, FIRST, true, BANK * 128 + 64, 224, BQ, PB, (H * 4 + 3) * 4096, BO, H * 4 + 2>(al, cbase, ba, ba, w, d);
     // the chunk's last group reads the first group of the NEXT chunk (published by the hand-over in front of this one)
-    m32_group<EPI ? 4 : 0, FIRST, true, BANK * 128 + 96, 240, BQ, PB, H ? 0 : 4 * 4096, BO>(al, H ? nbase : cbase, ba, ba, w);
+    m32_group<EPI ? 4 : 0, FIRST, true, BANK * 128 + 96, 240, BQ, PB, H ? 0 : 4 * 4096, BO, H * 4 + 3>(al, H ? nbase : cbase, ba, ba, w, d);
 }
 
 struct RingPos {
@@ -294,17 +338,17 @@ template <int BANK>
 __device__ __forceinline__ void m32_dense_layer(Pipe32& p, float& al, unsigned ba, float w, bool first) {
 #define M32_CHUNK(C)                                                                            \
     {                                                                                           \
-        pipe32_handover<0>(p, NoExtra());                                                       \
+        const Dma32 d = pipe32_sync<0>(p, NoExtra());                                           \
         const RingPos r = m32_next_chunk(p, ring_lane_addr());                                  \
-        m32_dense_ksub<BANK, 2 * (C), false>(al, r.cbase, r.nbase, ba, w);                      \
-        m32_dense_ksub<BANK, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba, w);                  \
+        m32_dense_ksub<BANK, 2 * (C), false>(al, r.cbase, r.nbase, ba, w, d);                   \
+        m32_dense_ksub<BANK, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba, w, d);               \
     }
     {
-        pipe32_handover<0>(p, NoExtra());
+        const Dma32 d = pipe32_sync<0>(p, NoExtra());
         const RingPos r = m32_next_chunk(p, ring_lane_addr());
-        if (first) m32_dense_ksub<BANK, 0, true>(al, r.cbase, r.nbase, ba, w);
-        else m32_dense_ksub<BANK, 0, false>(al, r.cbase, r.nbase, ba, w);
-        m32_dense_ksub<BANK, 1, false>(al, r.cbase, r.nbase, ba, w);
+        if (first) m32_dense_ksub<BANK, 0, true>(al, r.cbase, r.nbase, ba, w, d);
+        else m32_dense_ksub<BANK, 0, false>(al, r.cbase, r.nbase, ba, w, d);
+        m32_dense_ksub<BANK, 1, false>(al, r.cbase, r.nbase, ba, w, d);
     }
     M32_CHUNK(1) M32_CHUNK(2) M32_CHUNK(3) M32_CHUNK(4) M32_CHUNK(5) M32_CHUNK(6) M32_CHUNK(7)
 #undef M32_CHUNK
@@ -313,23 +357,24 @@ __device__ __forceinline__ void m32_dense_layer(Pipe32& p, float& al, unsigned b
 // the 13 k-substeps of the positional encoding (7 chunks, the second half of the last one is padding) into bank BANK, from zero
 template <int BANK>
 __device__ __forceinline__ void m32_pe_layer(Pipe32& p, const half8 (&xh)[13], const half8 (&xl)[13]) {
-#define M32_PE_KSUB(U, FIRST_, LASTOFF, LASTBASE)                                                                \
-    m32_group_pe<FIRST_, BANK * 128 + 0, 224, (((U) & 1) * 4 + 1) * 4096>(xh[U], xl[U], r.cbase);                \
-    m32_group_pe<FIRST_, BANK * 128 + 32, 240, (((U) & 1) * 4 + 2) * 4096>(xh[U], xl[U], r.cbase);               \
-    m32_group_pe<FIRST_, BANK * 128 + 64, 224, (((U) & 1) * 4 + 3) * 4096>(xh[U], xl[U], r.cbase);               \
-    m32_group_pe<FIRST_, BANK * 128 + 96, 240, LASTOFF>(xh[U], xl[U], LASTBASE);
+#define M32_PE_KSUB(U, FIRST_, LASTOFF, LASTBASE, Q0)                                                            \
+    m32_group_pe<FIRST_, BANK * 128 + 0, 224, (((U) & 1) * 4 + 1) * 4096, (Q0) + 0>(xh[U], xl[U], r.cbase, d);   \
+    m32_group_pe<FIRST_, BANK * 128 + 32, 240, (((U) & 1) * 4 + 2) * 4096, (Q0) + 1>(xh[U], xl[U], r.cbase, d);  \
+    m32_group_pe<FIRST_, BANK * 128 + 64, 224, (((U) & 1) * 4 + 3) * 4096, (Q0) + 2>(xh[U], xl[U], r.cbase, d);  \
+    m32_group_pe<FIRST_, BANK * 128 + 96, 240, LASTOFF, (Q0) + 3>(xh[U], xl[U], LASTBASE, d);
 #define M32_PE_CHUNK(C)                                                                                          \
     {                                                                                                            \
-        pipe32_handover<0>(p, NoExtra());                                                                        \
+        const Dma32 d = pipe32_sync<0>(p, NoExtra());                                                            \
         const RingPos r = m32_next_chunk(p, ring_lane_addr());                                                   \
-        M32_PE_KSUB(2 * (C), (C) == 0, 4 * 4096, r.cbase)                                                        \
-        M32_PE_KSUB(2 * (C) + 1, false, 0, r.nbase)                                                              \
+        M32_PE_KSUB(2 * (C), (C) == 0, 4 * 4096, r.cbase, 0)                                                     \
+        M32_PE_KSUB(2 * (C) + 1, false, 0, r.nbase, 4)                                                           \
     }
     M32_PE_CHUNK(0) M32_PE_CHUNK(1) M32_PE_CHUNK(2) M32_PE_CHUNK(3) M32_PE_CHUNK(4) M32_PE_CHUNK(5)
     {
-        pipe32_handover<0>(p, NoExtra());
+        const Dma32 d = pipe32_sync<0>(p, NoExtra());
+        pipe32_issue_half(d);           // four groups for eight pieces: pieces 0 .. 3 here, 4 .. 7 behind the groups
         const RingPos r = m32_next_chunk(p, ring_lane_addr());
-        M32_PE_KSUB(12, false, 0, r.nbase)
+        M32_PE_KSUB(12, false, 0, r.nbase, 4)
     }
 #undef M32_PE_CHUNK
 #undef M32_PE_KSUB
@@ -337,13 +382,14 @@ __device__ __forceinline__ void m32_pe_layer(Pipe32& p, const half8 (&xh)[13], c
 
 // view layer (256 -> 128: four result tiles `accv` from bank 1): k-substep U = 2 groups, 4 k-substeps per chunk
 template <int U>
-__device__ __forceinline__ void m32_view_ksub(f32x16 (&accv)[4], float& al, unsigned cbase, unsigned nbase, unsigned ba, unsigned aa, float w) {
+__device__ __forceinline__ void m32_view_ksub(f32x16 (&accv)[4], float& al, unsigned cbase, unsigned nbase, unsigned ba, unsigned aa, float w,
+                                              const Dma32& d) {
     constexpr int UC = U & 3, BQ = (U & 1) ? 208 : 216, PB = 128 + 8 * (U + 1), BO = 64 * (U + 1);
     constexpr bool EPI = U < 15, FIRST = U == 0;
-    m32_view_group<EPI ? 5 : 0, FIRST, true, 224, BQ, PB, (UC * 2 + 1) * 4096, BO>(accv[0], accv[1], al, cbase, ba, aa, w);
+    m32_view_group<EPI ? 5 : 0, FIRST, true, 224, BQ, PB, (UC * 2 + 1) * 4096, BO, 2 * UC>(accv[0], accv[1], al, cbase, ba, aa, w, d);
     // the tile's very last group prefetches nothing: the fragment buffers are dead across the head and the next tile's prologue
-    if constexpr (U == 15) m32_view_group<0, false, false, 240, BQ, PB, 0, BO>(accv[2], accv[3], al, cbase, ba, aa, w);
-    else m32_view_group<6, FIRST, true, 240, BQ, PB, UC == 3 ? 0 : (UC * 2 + 2) * 4096, BO>(accv[2], accv[3], al, UC == 3 ? nbase : cbase, ba, aa, w);
+    if constexpr (U == 15) m32_view_group<0, false, false, 240, BQ, PB, 0, BO, 2 * UC + 1>(accv[2], accv[3], al, cbase, ba, aa, w, d);
+    else m32_view_group<6, FIRST, true, 240, BQ, PB, UC == 3 ? 0 : (UC * 2 + 2) * 4096, BO, 2 * UC + 1>(accv[2], accv[3], al, UC == 3 ? nbase : cbase, ba, aa, w, d);
 }
 
 // the 8 positional-encoding values of k-substep U held by this lane: slot j = 8 U + e = 13 c + t of the lane's channel c (kk = 8 g + c):
@@ -498,12 +544,12 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
             const StageRows32 stage{src};
 #define M32_VCHUNK(C, EXTRA_, STAGE_)                                                              \
             {                                                                                      \
-                pipe32_handover<EXTRA_>(p, STAGE_);                                                \
+                const Dma32 d = pipe32_sync<EXTRA_>(p, STAGE_);                                    \
                 const RingPos r = m32_next_chunk(p, ring_lane_addr());                             \
-                m32_view_ksub<4 * (C)>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);               \
-                m32_view_ksub<4 * (C) + 1>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);           \
-                m32_view_ksub<4 * (C) + 2>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);           \
-                m32_view_ksub<4 * (C) + 3>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7);           \
+                m32_view_ksub<4 * (C)>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);               \
+                m32_view_ksub<4 * (C) + 1>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
+                m32_view_ksub<4 * (C) + 2>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
+                m32_view_ksub<4 * (C) + 3>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
             }
             M32_VCHUNK(0, 0, stage)            // the staging loads sit between the barrier and the refill:
             M32_VCHUNK(1, 3, NoExtra())        // older than chunk c + 3, younger than what the next hand-over waits for
