@@ -45,7 +45,7 @@ N_SAMPLES, N_IMPORTANCE = 48, 16
 MAC_PER_ROW_REF = 677376       # reference network: trunk 558592 + alpha 256 + feature 65536 + view 52608 + rgb 384
 # executed by each kernel (per-ray part of the view layer is hoisted into k_view_consts in both):
 MAC_PER_ROW = {"fp32": 558592 + 256 + 65536 + 32768 + 384,      # k_pe_mlp : trunk, alpha, feature, view[:, :256], rgb
-               "f16split": 558592 + 256 + 32768 + 384}          # k_pe_mlp16: feature+view merged into one 256->128
+               "f16split": 558592 + 256 + 32768 + 384}          # k_pe_mlp32 / k_pe_mlp16: feature+view merged into one 256->128
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_FP16_MFMA = 2500e12       # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (2:1-sparse figures are not used)
 SPLIT_NOTE = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: every fp32-accurate product is three half-precision MFMA products "
@@ -76,6 +76,9 @@ def build_workload(device, view, mlp_mode="f16split", cam_dist=3.0):
 def render(eng, inp, dense=False):
     return eng.render(inp["rays_o"], inp["rays_d"], inp["skts"], inp["bones"], inp["cyls"], inp["cam_idx"],
                       N_SAMPLES, N_IMPORTANCE, chunk=4096, dense=dense)
+
+
+K3_SOURCES = ("k_mlp32.hip", "mlp32_regs.inc", "k_mlp16.hip", "mlp16_core.hpp", "common.hpp")     # tools/pmc_hbm.sh hashes the same list
 
 
 def pmc_record(kind, *files):
@@ -393,13 +396,13 @@ def bench_render(args, rank, world, device, dist):
     mac = MAC_PER_ROW[args.mlp]
     achieved = 2.0 * mac * rows / (ms * 1e-3)                # EXECUTED multiply-adds of in-volume rows only
     if args.mlp == "f16split":
-        kernel, peak, peak_note = "k_pe_mlp16", PEAK_FP16_MFMA / 3.0, SPLIT_NOTE
+        kernel, peak, peak_note = {16: "k_pe_mlp16", 32: "k_pe_mlp32"}[eng.mlp_form], PEAK_FP16_MFMA / 3.0, SPLIT_NOTE
     else:
         kernel, peak, peak_note = "k_pe_mlp", PEAK_FP32_MFMA, "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"
     traffic, traffic_note = None, "no PMC profile of this build of the kernel under profiles/ (tools/pmc_hbm.sh)"
-    rec = pmc_record("hbm", "k_mlp16.hip", "mlp16_core.hpp", "common.hpp") if (args.mlp == "f16split" and args.config == 1) else None
+    rec = pmc_record("hbm", *K3_SOURCES) if (args.mlp == "f16split" and args.config == 1) else None
     if rec is not None:
-        traffic = rec["kernels"].get("danbo::k_pe_mlp16", {}).get("hbm_bytes_per_launch")
+        traffic = rec["kernels"].get("danbo::" + kernel, {}).get("hbm_bytes_per_launch")
         traffic_note = f"HBM bytes per launch from rocprofv3 PMC passes of THIS kernel source ({rec['_file']})"
     # algorithmic HBM bytes of a launch: 84 B per row (64 B h + 4 B list entry + 16 B raw) + the 512-byte per-ray view constants of
     # every ray that owns >= 1 row (counted on the coarse pass of one extra, untimed frame)

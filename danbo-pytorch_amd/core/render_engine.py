@@ -29,7 +29,9 @@ class DanboEngine:
         # render() is ONE stream-ordered chain (round 4 measured the side-stream form -- pose volumes / view constants beside the
         # bounds -> cull chain -- slower: 4.696 vs 4.634 ms; round 5 removed it: nothing of the frame runs beside K2)
         self.skip_flat_rays = True   # render(): no resampling for rays that cannot meet a volume (tests switch it off to compare)
-        # "f16split": k_pe_mlp16 (3 fp16 MFMAs per fp32-accurate product); "fp32": k_pe_mlp (exact fp32 MFMA)
+        # "f16split": k_pe_mlp32 (3 fp16 MFMAs per fp32-accurate product; mlp_form 16: k_pe_mlp16, the 16x16x32 form of the same
+        # arithmetic -- kept for A/B, `render_frame_c` needs 32); "fp32": k_pe_mlp (exact fp32 MFMA)
+        self.mlp_form = 32
         assert mlp_mode in ("f16split", "fp32")
         self.mlp_mode = mlp_mode
         # True: re-order the compacted rows by bone set in front of K2 (k_group.hip).  Off since the end of round 4: K2 gains 2 x 20 us
@@ -42,7 +44,7 @@ class DanboEngine:
 
     def refresh(self):
         key = self._key()
-        if key == self._packed_key and getattr(self, "_built_mode", None) == self.mlp_mode:
+        if key == self._packed_key and getattr(self, "_built_mode", None) == (self.mlp_mode, self.mlp_form):
             return
         p = self.p
         dev = p["alpha_linear.weight"].device
@@ -52,7 +54,7 @@ class DanboEngine:
         self.packed, self.wrt = ops.mlp_pack(self.pts_w, q["feature_linear.weight"], q["views_linears.0.weight"])
         self.packed16, self.views_b16 = ops.mlp16_pack(self.pts_w, q["feature_linear.weight"],
                                                        q["feature_linear.bias"], q["views_linears.0.weight"],
-                                                       q["views_linears.0.bias"])
+                                                       q["views_linears.0.bias"], form=self.mlp_form)
         self.alpha_w = q["alpha_linear.weight"].reshape(-1).contiguous()
         self.alpha_b = q["alpha_linear.bias"].contiguous()
         self.feature_b = q["feature_linear.bias"].contiguous()
@@ -92,7 +94,7 @@ class DanboEngine:
         scratch_raw = torch.empty(1, 4, device=dev)
         self.empty_consts = self._mlp(h0, 1, None, scratch_raw, aux=True).reshape(-1).contiguous()
         self.flat_rays_ok = self._flat_rays_ok()
-        self._built_mode = self.mlp_mode
+        self._built_mode = (self.mlp_mode, self.mlp_form)
         self._packed_key = key
 
     def _flat_rays_ok(self):
@@ -172,7 +174,7 @@ class DanboEngine:
     def _mlp(self, h, S, cview, raw, lst=None, cnt=None, n=None, aux=False):
         if self.mlp_mode == "f16split":
             return ops.pe_mlp16(h, S, self.packed16, self.pts_b, self.alpha_w, self.alpha_b, cview,
-                                self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux)
+                                self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux, form=self.mlp_form)
         return ops.pe_mlp(h, S, self.packed, self.pts_b, self.alpha_w, self.alpha_b, self.feature_b, cview,
                           self.rgb_w, self.rgb_b, raw, lst, cnt, n, aux)
 
@@ -189,7 +191,7 @@ class DanboEngine:
         return ops.view_consts(rays_d, skts, ray_mode, normalise, cfg["multires_views"], self.framecodes,
                                self.mean_code, cam_idx, self.wrt,
                                self.views_b16 if self.mlp_mode == "f16split" else self.views_b, self.rgb_w,
-                               self.rgb_b, self.empty_consts, 1 if self.mlp_mode == "f16split" else 0,
+                               self.rgb_b, self.empty_consts, {16: 1, 32: 2}[self.mlp_form] if self.mlp_mode == "f16split" else 0,
                                self.code_table, ray_list, ray_count)
 
     def forward_samples(self, rays_o, rays_d, skts, bones, cam_idx=None, z=None, pts=None, dense=False,
@@ -250,7 +252,7 @@ class DanboEngine:
         one workspace buffer -- the entry point a C host binds.  Same kernels, same order: bit-identical outputs."""
         import ctypes
         from . import _hip
-        assert self.mlp_mode == "f16split"
+        assert self.mlp_mode == "f16split" and self.mlp_form == 32
         self.refresh()
         cfg = self.cfg
         S, Sf = N_samples or cfg["N_samples"], N_importance or cfg["N_importance"]

@@ -2,7 +2,7 @@
 #include <string.h>
 #include "common.hpp"
 
-extern "C" int danbo_abi_version(void) { return 8; }
+extern "C" int danbo_abi_version(void) { return 9; }
 
 extern "C" int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {
     int dev = 0;

@@ -94,7 +94,7 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
     const bool flat_rays = m->flat_rays_ok != 0;
     auto view_consts = [&](const int32_t* ray_list, const int32_t* ray_count) -> int {
         return danbo_view_consts(r->rays_d, r->skts, R, G, m->ray_mode, m->normalise, m->L_view, m->framecodes, m->n_codes, m->code_size,
-                                 m->mean_code, r->cam_idx, m->views_w_ray_t, m->views_b_eff, m->rgb_w, m->rgb_b, m->empty_consts, 1,
+                                 m->mean_code, r->cam_idx, m->views_w_ray_t, m->views_b_eff, m->rgb_w, m->rgb_b, m->empty_consts, 2,
                                  m->code_table, ray_list, ray_count, b.cview, b.raw_empty, stream);
     };
     // the rays of constants (model->flat_rays_ok: flagged by the ray mask; the coarse depths are made here from the same near / far,
@@ -120,7 +120,7 @@ extern "C" int danbo_render_frame(const DanboModel* m, const DanboRays* r, int S
         DANBO_TRY(danbo_gather_assign_blend16_fwd(r->rays_o, r->rays_d, zz, nullptr, R, s, G, r->skts, m->align, m->axis_scale, b.volumes,
                                                   bits, b.list, count, R * s, m->assign16, m->a_b0, m->a_b1, m->a_w2, m->a_b2, b.h,
                                                   nullptr, reinterpret_cast<uint32_t*>(b.count + 2), stream));
-        return danbo_pe_mlp16_fwd(b.h, b.list, count, R * s, s, m->mlp16, m->pts_b, m->alpha_w, m->alpha_b, b.cview, m->rgb_w,
+        return danbo_pe_mlp32_fwd(b.h, b.list, count, R * s, s, m->mlp16, m->pts_b, m->alpha_w, m->alpha_b, b.cview, m->rgb_w,
                                   m->rgb_b, raw, nullptr, stream);
     };
     DANBO_TRY(cull(b.z, S, b.bits_a, b.count));

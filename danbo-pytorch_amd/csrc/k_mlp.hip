@@ -282,7 +282,31 @@ __global__ __launch_bounds__(256) void k_view_consts(const float* __restrict__ r
         }
         if (empty_consts) {
             __syncthreads();
-            if (rgb_order) {
+            if (rgb_order == 2) {
+                // the summation order of k_pe_mlp32 (k_mlp32.hip): two lane-group partials per (ray, channel) -- group g walks the
+                // features 32 T + 8 Q + 4 g + i in the order T, Q, i -- then (p0 + p1) + b; one partial chain per thread, 16 rays per pass
+                for (int pass = 0; pass < RPB / 16; ++pass) {
+                    float part = 0.f;
+                    const int rl = pass * 16 + (tid >> 4), ch = (tid >> 2) & 3, q = tid & 3;
+                    if (ch < 3 && q < 2) {
+                        const float* x = s_x + rl * MLP_VW;
+                        const float* wv = s_rgbw + ch * MLP_VW;
+#pragma unroll
+                        for (int TQ = 0; TQ < 16; ++TQ) {
+                            const int n = 8 * TQ + 4 * q;
+                            const float4 xv = *reinterpret_cast<const float4*>(x + n);
+                            const float4 ww = *reinterpret_cast<const float4*>(wv + n);
+                            part = fmaf(xv.x, ww.x, part);
+                            part = fmaf(xv.y, ww.y, part);
+                            part = fmaf(xv.z, ww.z, part);
+                            part = fmaf(xv.w, ww.w, part);
+                        }
+                    }
+                    const float p1 = __shfl_xor(part, 1, 64);
+                    const int r = s_ray[rl];
+                    if (q == 0 && r >= 0) raw_empty[(size_t)r * 4 + ch] = ch < 3 ? (part + p1) + rgb_b[ch] : empty_consts[MLP_VW];
+                }
+            } else if (rgb_order) {
                 // the summation order of k_pe_mlp16: four lane-group partials per (ray, channel), then
                 // ((p0 + p1) + (p2 + p3)) + b -- one partial chain per thread, 16 rays per pass
                 for (int pass = 0; pass < RPB / 16; ++pass) {

@@ -56,18 +56,34 @@ struct Pipe32 {
     int issue_chunk, issue_slot, cons_slot, wave;
 };
 
-// every wavefront loads 8 of the 32 pieces of a chunk (two bases: the instruction's immediate offset reaches 4 KB)
+// EVERY LDS-DMA load of this kernel is an asm statement that writes M0 itself.  The groups below set M0 for the piece they carry, and
+// the compiler does not see an asm statement's write to M0 ("m0" is not accepted as a clobber): with builtin loads in the kernel it
+// hoisted / merged its own M0 initialisations across the groups, and the staging loads of the next tile's rows went to wherever the
+// last piece had pointed M0 -- into the ring (found as wrong colours beside correct densities).  With no builtin left the compiler
+// never relies on M0.
+// four 1 KB pieces: wave-uniform global base + 32-bit lane offset, LDS destination `dst` (the immediate offset applies to both)
+__device__ __forceinline__ void lds_dma_4k(const char* src, unsigned voff, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                 ::"v"(voff), "s"(src), "s"(dst) : "memory");
+}
+// one load of 16 / 4 bytes per lane from per-lane addresses
+__device__ __forceinline__ void lds_dma_lanes16(const void* lane_src, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(lane_src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma_lanes4(const void* lane_src, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lane_src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
+// every wavefront loads 8 of the 32 pieces of a chunk
 __device__ __forceinline__ void pipe32_issue(Pipe32& p) {
     const char* src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192;     // wave-uniform
-    char* dst = p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192;
-    const char* lane_src = src + (size_t)lane_off16();
-#define DANBO_PIECE(SRC, DST, Q)                                                                           \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),                \
-                                     (__attribute__((address_space(3))) void*)(DST), 16, (Q) * 1024, 0)
-    DANBO_PIECE(lane_src, dst, 0); DANBO_PIECE(lane_src, dst, 1); DANBO_PIECE(lane_src, dst, 2); DANBO_PIECE(lane_src, dst, 3);
-    DANBO_PIECE(lane_src + 4096, dst + 4096, 0); DANBO_PIECE(lane_src + 4096, dst + 4096, 1);
-    DANBO_PIECE(lane_src + 4096, dst + 4096, 2); DANBO_PIECE(lane_src + 4096, dst + 4096, 3);
-#undef DANBO_PIECE
+    const unsigned dst = lds_addr(p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192);
+    const unsigned l16 = lane_off16();
+    lds_dma_4k(src, l16, dst);
+    lds_dma_4k(src, l16 + 4096u, dst + 4096u);
     p.issue_chunk = p.issue_chunk + 1 == M32_NCH ? 0 : p.issue_chunk + 1;
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
 }
@@ -94,12 +110,14 @@ struct Dma32 {
 template <int EXTRA, class Extra>
 __device__ __forceinline__ Dma32 pipe32_sync(Pipe32& p, const Extra& extra) {
     wait_vm<8 + EXTRA>();
+#ifndef M32_EXP_NOBARRIER  // timing experiment (races)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
     extra();
     Dma32 d;
     d.src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192;
-    d.dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192);
+    d.dst = lds_addr(p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192);
     d.v0 = lane_off16();
     d.v1 = d.v0 + 4096u;
     p.issue_chunk = p.issue_chunk + 1 == M32_NCH ? 0 : p.issue_chunk + 1;
@@ -107,13 +125,7 @@ __device__ __forceinline__ Dma32 pipe32_sync(Pipe32& p, const Extra& extra) {
     return d;
 }
 // pieces 0 .. 3 of a refill by the hand-over itself (the encoding's last chunk has four groups for eight pieces)
-__device__ __forceinline__ void pipe32_issue_half(const Dma32& d) {
-#define DANBO_PIECE(Q)                                                                                                  \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(d.src + d.v0),                     \
-                                     (__attribute__((address_space(3))) void*)(uintptr_t)d.dst, 16, (Q) * 1024, 0)
-    DANBO_PIECE(0); DANBO_PIECE(1); DANBO_PIECE(2); DANBO_PIECE(3);
-#undef DANBO_PIECE
-}
+__device__ __forceinline__ void pipe32_issue_half(const Dma32& d) { lds_dma_4k(d.src, d.v0, d.dst); }
 
 __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 #pragma unroll 1
@@ -143,19 +155,55 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 // of the next group's fragment reads (what it reads from LDS is older than they are), E1..E5 behind the following MFMAs
 #define M32_GROUP_ON(ACC0, ACC1, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
     M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, M32_DMA, E0, E1, E2, E3, E4, E5)
+#ifndef M32_DMA_SLOT
+#define M32_DMA_SLOT 1      // behind which MFMA of the group (1 .. 5) the LDS-DMA piece sits
+#endif
+#define M32_DMA_AT(N, DMA) M32_DMA_AT_(N, M32_DMA_SLOT, DMA)
+#define M32_DMA_AT_(N, S, DMA) M32_DMA_AT__(N, S, DMA)
+#define M32_DMA_AT__(N, S, DMA) M32_DMA_##N##_##S(DMA)
+#define M32_DMA_1_1(D) D
+#define M32_DMA_2_2(D) D
+#define M32_DMA_3_3(D) D
+#define M32_DMA_4_4(D) D
+#define M32_DMA_5_5(D) D
+#define M32_DMA_1_2(D)
+#define M32_DMA_1_3(D)
+#define M32_DMA_1_4(D)
+#define M32_DMA_1_5(D)
+#define M32_DMA_2_1(D)
+#define M32_DMA_2_3(D)
+#define M32_DMA_2_4(D)
+#define M32_DMA_2_5(D)
+#define M32_DMA_3_1(D)
+#define M32_DMA_3_2(D)
+#define M32_DMA_3_4(D)
+#define M32_DMA_3_5(D)
+#define M32_DMA_4_1(D)
+#define M32_DMA_4_2(D)
+#define M32_DMA_4_3(D)
+#define M32_DMA_4_5(D)
+#define M32_DMA_5_1(D)
+#define M32_DMA_5_2(D)
+#define M32_DMA_5_3(D)
+#define M32_DMA_5_4(D)
 #define M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, DMA, E0, E1, E2, E3, E4, E5) \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+    M32_DMA_M0 "s_waitcnt lgkmcnt(0)\n\t"                                        \
     M32_MF(ACC0, "0", BH, C0) E0 READS                                           \
-    M32_MF(ACC1, "8", BH, C1) DMA E1                                             \
-    M32_MF(ACC0, "0", BL, ACC0) E2                                               \
-    M32_MF(ACC1, "8", BL, ACC1) E3                                               \
-    M32_MF(ACC0, "4", BH, ACC0) E4                                               \
-    M32_MF(ACC1, "12", BH, ACC1) E5
-// piece Q of this wavefront's share of the chunk being refilled: M0 = LDS destination, one wait state in front of its use.  M0 is
-// SAVED AND RESTORED: the compiler does not see an asm statement's write to it ("m0" is not accepted as a clobber) and hoists / merges
-// its own M0 initialisations across statements -- the staging loads of the next tile's rows then went to wherever the last piece had
-// pointed M0 (into the ring: a view-layer chunk; found as wrong colours beside correct densities)
-#define M32_DMA "s_mov_b32 %[ms], m0\n\ts_mov_b32 m0, %[gm]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[gv], %[gs] offset:%[gq]\n\ts_mov_b32 m0, %[ms]\n\t"
+    M32_MF(ACC1, "8", BH, C1) M32_DMA_AT(1, DMA) E1                              \
+    M32_MF(ACC0, "0", BL, ACC0) M32_DMA_AT(2, DMA) E2                            \
+    M32_MF(ACC1, "8", BL, ACC1) M32_DMA_AT(3, DMA) E3                            \
+    M32_MF(ACC0, "4", BH, ACC0) M32_DMA_AT(4, DMA) E4                            \
+    M32_MF(ACC1, "12", BH, ACC1) M32_DMA_AT(5, DMA) E5
+// piece Q of this wavefront's share of the chunk being refilled: M0 (the LDS destination) is written at the head of the group, the load
+// sits behind the second MFMA (a single wavefront issues one instruction per 4 cycles: 8 per MFMA, the MFMA included -- no slot of
+// a group carries more than 6 others)
+#ifdef M32_EXP_NODMA      // timing experiment (wrong results): what the pieces cost where they sit
+#define M32_DMA_M0 ""
+#define M32_DMA ""
+#else
+#define M32_DMA_M0 "s_mov_b32 m0, %[gm]\n\t"
+#define M32_DMA "global_load_lds_dwordx4 %[gv], %[gs] offset:%[gq]\n\t"
+#endif
 #define M32_DMA_OPERANDS [gm] "s"(Q >= 4 ? d.dst + 4096u : d.dst), [gv] "v"(Q >= 4 ? d.v1 : d.v0), [gs] "s"(d.src), [gq] "n"((Q & 3) * 1024)
 #define M32_GROUP(BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
     M32_GROUP_ON(M32_ACC_A, M32_ACC_B, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5)
@@ -195,7 +243,7 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
     "ds_read_b128 v[188:191], %[aa] offset:%[bo]+32\n\t"
 
 #define M32_ASM(TEXT)                                                                                                        \
-    asm volatile(TEXT : [al] "+v"(al), [ms] "=&s"(m0_save)                                                                   \
+    asm volatile(TEXT : [al] "+v"(al)                                                                                        \
                  : [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ),              \
                    [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), \
                    [w] "v"(w), M32_DMA_OPERANDS                                                                              \
@@ -209,17 +257,16 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 // EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep.  PF: prefetch the next group's fragments.
 template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO, int Q>
 __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
-    unsigned m0_save;
     static_assert(PF && EPI >= 0 && EPI <= 4, "");
     if constexpr (EPI == 0) M32_EMIT(M32_READS, "", "", "", "", "", "");
     else if constexpr (EPI == 1)
-        M32_EMIT(M32_READS, M32_BIAS_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");
+        M32_EMIT(M32_READS, M32_BIAS_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");      // 6 3 2 2 2 0
     else if constexpr (EPI == 2)
-        M32_EMIT(M32_READS, M32_FMA(0) M32_FMA(1) M32_FMA(2), M32_FMA(3) M32_FMA(4) M32_FMA(5), M32_FMA(6) M32_FMA(7) M32_MAX(0),
-                 M32_MAX(1) M32_MAX(2) M32_MAX(3), M32_MAX(4) M32_MAX(5) M32_MAX(6), M32_MAX(7));
+        M32_EMIT(M32_READS, M32_FMA(0) M32_FMA(1), M32_FMA(2) M32_FMA(3) M32_FMA(4), M32_FMA(5) M32_FMA(6) M32_FMA(7) M32_MAX(0),
+                 M32_MAX(1) M32_MAX(2) M32_MAX(3) M32_MAX(4), M32_MAX(5) M32_MAX(6) M32_MAX(7), "");                                       // 6 4 4 4 3 0
     else if constexpr (EPI == 3)
         M32_EMIT(M32_READS, M32_CVT(0, 0, 1) M32_CVT(1, 2, 3), M32_CVT(2, 4, 5) M32_CVT(3, 6, 7), M32_MIX(0, 0, 1), M32_MIX(1, 2, 3),
-                 M32_MIX(2, 4, 5), M32_MIX(3, 6, 7));
+                 M32_MIX(2, 4, 5), M32_MIX(3, 6, 7));                                                                                       // 6 3 2 2 2 2
     else M32_EMIT(M32_READS, "", "", "", "", "", "");
 }
 
@@ -229,9 +276,8 @@ __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, u
 // never -- the tile's last group has no epilogue); the table reads of EPI 5 are OLDER than the fragment reads: lgkmcnt(4) = tables landed.
 template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO, int Q>
 __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
-    unsigned m0_save;
 #define M32_VIEW_ASM(TEXT, CONSTRAINT)                                                                                       \
-    asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1), [ms] "=&s"(m0_save)                         \
+    asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1)                                              \
                  : [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ), [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), \
                    [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), [w] "v"(w), M32_DMA_OPERANDS         \
                  : M32_V_CLOBBERS, M32_A1_CLOBBERS, "memory")
@@ -258,11 +304,9 @@ __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al
 // the same group with the B fragments in compiler registers (the positional-encoding k-substeps: no epilogue rides on them)
 template <bool FIRST, int CA, int HA, int O0, int Q>
 __device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb, const Dma32& d) {
-    unsigned m0_save;
 #define M32_PE_ASM(C0, C1)                                                                                                   \
     asm volatile("s_nop 1\n\t" M32_GROUP("%[xh]", "%[xl]", C0, C1, M32_READS, "", "", "", "", "", "")                                    \
-                 : [ms] "=&s"(m0_save)                                                                                       \
-                 : [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl),   \
+                 :: [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl),   \
                     [nb] "v"(nb), [o0] "n"(O0), M32_DMA_OPERANDS                                                             \
                  : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
     if constexpr (FIRST) M32_PE_ASM("0", "0");
@@ -427,14 +471,12 @@ struct StageRows32 {
         asm volatile("" : "+s"(row0));
         const int lane = (int)(lane_off16() >> 4);
         const int r0 = min(row0 + (lane >> 2), t.n - 1), r1 = min(row0 + 16 + (lane >> 2), t.n - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.h + (size_t)r0 * DANBO_H_STRIDE + 4 * (lane & 3)),
-                                         (__attribute__((address_space(3))) void*)t.stage, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.h + (size_t)r1 * DANBO_H_STRIDE + 4 * (lane & 3)),
-                                         (__attribute__((address_space(3))) void*)(t.stage + 1024), 16, 0, 0);
+        const unsigned st = lds_addr(t.stage);
+        lds_dma_lanes16(t.h + (size_t)r0 * DANBO_H_STRIDE + 4 * (lane & 3), st);
+        lds_dma_lanes16(t.h + (size_t)r1 * DANBO_H_STRIDE + 4 * (lane & 3), st + 1024u);
         const int rl = min(row0 + (lane & 31), t.n - 1);
         const void* src_l = t.list ? (const void*)(t.list + rl) : (const void*)(t.dummy + 4 * lane);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_l,
-                                         (__attribute__((address_space(3))) void*)(t.stage + M32_STAGE_H), 4, 0, 0);
+        lds_dma_lanes4(src_l, st + (unsigned)M32_STAGE_H);
     }
 };
 
@@ -507,7 +549,11 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         half8 xh[13], xl[13];
         {
             float cs_keep = 0.f;
+#ifdef M32_EXP_NOPE        // timing experiment (wrong results): the encoding's VALU work
+#define M32_PE(U) { float v8[8]; for (int e = 0; e < 8; ++e) v8[e] = hv[e]; split8_mix(v8, xh[U], xl[U]); }
+#else
 #define M32_PE(U) { float v8[8]; pe32_ksub<U>(hv, cs_keep, v8); split8_mix(v8, xh[U], xl[U]); }
+#endif
             M32_PE(0) M32_PE(1) M32_PE(2) M32_PE(3) M32_PE(4) M32_PE(5) M32_PE(6) M32_PE(7) M32_PE(8) M32_PE(9) M32_PE(10) M32_PE(11) M32_PE(12)
 #undef M32_PE
         }

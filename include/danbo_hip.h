@@ -37,7 +37,8 @@ extern "C" {
  * 256 + 64 samples per ray; 6 = DANBO_MLP16_PACKED_BYTES grows by a trailer (power-of-two pack scales of danbo_mlp16_pack);
  * 7 = danbo_train_mid (additive); DanboTrainBatch.rng_* (appended: a caller of an older header must be rebuilt);
  * 8 = A-NeRF on the library's own kernels end to end (additive): danbo_anerf_view_consts_fwd / _bwd, danbo_anerf_train_step and its
- * building blocks. */
+ * building blocks; 9 = K3 in the 32x32x16 form (danbo_mlp32_pack, danbo_pe_mlp32_fwd: additive), danbo_view_consts' rgb_order 2;
+ * danbo_render_frame runs it: DanboModel.mlp16 is a buffer packed by danbo_mlp32_pack (a caller of ABI 8 must re-pack). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -213,7 +214,7 @@ int danbo_view_consts(const float* rays_d, const float* skts, int R, int G, int 
                       const float* views_w_ray_t /*[Cv,128]*/, const float* views_b /*[128]*/,
                       const float* rgb_w /*[3,128]*/, const float* rgb_b /*[3]*/,
                       const float* empty_consts /*[129] or NULL*/,
-                      int rgb_order /*0: summation order of danbo_pe_mlp_fwd, 1: of danbo_pe_mlp16_fwd*/,
+                      int rgb_order /*0: summation order of danbo_pe_mlp_fwd, 1: of danbo_pe_mlp16_fwd, 2: of danbo_pe_mlp32_fwd*/,
                       const float* code_table /*[n_codes+1,128] from danbo_view_code_table, or NULL*/,
                       const int32_t* ray_list /*[R] or NULL*/, const int32_t* ray_count /*[1] or NULL*/,
                       float* cview /*[R,128]*/, float* raw_empty /*[R,4] or NULL*/, void* stream);
@@ -253,6 +254,21 @@ int danbo_mlp16_pack(const float* const* pts_w, const float* feature_w, const fl
                      void* packed16, float* views_b_eff /*[128]*/, void* stream);
 int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
                        const void* packed16, const float* const* pts_b,
+                       const float* alpha_w, const float* alpha_b,
+                       const float* cview, const float* rgb_w, const float* rgb_b,
+                       float* raw_out, float* aux_out, void* stream);
+
+/* K3, 32x32x16 form (csrc/k_mlp32.hip, ABI 9): the contract, arithmetic and buffer size of the pair above on
+ * v_mfma_f32_32x32x16_f16 -- one wavefront of 32 samples per SIMD with both result banks in AccVGPRs, half the LDS fragment reads per
+ * flop, the k-substep's epilogue hand-interleaved into the MFMA stream (7 % faster per launch on the bench frame).  The fragment order
+ * differs: a buffer packed by danbo_mlp32_pack is for danbo_pe_mlp32_fwd only.  Results differ from danbo_pe_mlp16_fwd in the last
+ * bits (the products of a k-step are added in another order: 7e-7 of the channel range on the bench frame); a caller that needs
+ * the per-ray empty-space raw of danbo_view_consts bit-equal to this kernel's passes rgb_order = 2 there. */
+int danbo_mlp32_pack(const float* const* pts_w, const float* feature_w, const float* feature_b,
+                     const float* views_w, const float* views_b, int Cv,
+                     void* packed32 /*DANBO_MLP16_PACKED_BYTES*/, float* views_b_eff /*[128]*/, void* stream);
+int danbo_pe_mlp32_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
+                       const void* packed32, const float* const* pts_b,
                        const float* alpha_w, const float* alpha_b,
                        const float* cview, const float* rgb_w, const float* rgb_b,
                        float* raw_out, float* aux_out, void* stream);
@@ -816,7 +832,7 @@ typedef struct DanboModel {
     /* assignment net (danbo_assign16_pack) */
     const void* assign16;
     const float *a_b0, *a_b1, *a_w2, *a_b2;
-    /* density / colour MLP (danbo_mlp16_pack) */
+    /* density / colour MLP (ABI 9: packed by danbo_mlp32_pack -- danbo_render_frame runs danbo_pe_mlp32_fwd) */
     const void* mlp16;
     const float* pts_b[8];
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;

@@ -50,7 +50,7 @@ def test_library_and_device(ops):
     import ctypes
     from core import _hip
     l = _hip.lib()
-    assert l.danbo_abi_version() == 8
+    assert l.danbo_abi_version() == 9
     cu, lds = ctypes.c_int(), ctypes.c_int()
     arch = ctypes.create_string_buffer(64)
     assert l.danbo_device_info(ctypes.byref(cu), ctypes.byref(lds), arch, 64) == 0
@@ -213,8 +213,19 @@ def test_view_constants_and_empty_raw(ops, stage):
     assert raw_err(N(raw_empty), want_raw) < 1e-4
 
 
+def _packed_form(ops, eng, form):
+    """the engine's MLP weights as fragments of K3's 16x16x32 (k_pe_mlp16) / 32x32x16 (k_pe_mlp32) form"""
+    if form == eng.mlp_form:
+        return eng.packed16
+    q = eng._equalized(eng.p) if eng._built_mode[0] == "f16split" else eng.p      # the parameters of the engine's last refresh
+    packed, vb = ops.mlp16_pack(eng.pts_w, q["feature_linear.weight"], q["feature_linear.bias"], q["views_linears.0.weight"],
+                                q["views_linears.0.bias"], form=form)
+    assert torch.equal(vb, eng.views_b16)
+    return packed
+
+
 def test_pe_mlp_on_golden_features(ops, stage):
-    """both MLP kernels (exact fp32 MFMA, fp16x2-split MFMA) on the oracle's blended features"""
+    """the MLP kernels (exact fp32 MFMA; fp16x2-split MFMA in both forms) on the oracle's blended features"""
     g, eng, ret = stage["g"], stage["eng"], stage["ret"]
     rb = g["ray_batch"]
     S = int(g["N_samples"])
@@ -227,18 +238,23 @@ def test_pe_mlp_on_golden_features(ops, stage):
     ops.pe_mlp(T(h), S, eng.packed, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w, eng.rgb_b, raw)
     assert raw_err(N(raw), g["raw_coarse"]) < 1e-4      # north_star tolerance vs the reference
     assert raw_err(N(raw), ret["raw_coarse"]) < 1e-4
-    raw16 = torch.zeros(len(rb), S, 4, device=DEV)
     cview16 = cview + (eng.views_b16 - eng.views_b)               # merged feature+view layer: bias moves to cview
-    ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview16, eng.rgb_w, eng.rgb_b, raw16)
-    assert raw_err(N(raw16), g["raw_coarse"]) < 1e-4
-    assert raw_err(N(raw16), N(raw)) < 2e-5             # split products ~ fp32 round-off class
+    split = {}
+    for form in (16, 32):
+        raw16 = torch.zeros(len(rb), S, 4, device=DEV)
+        ops.pe_mlp16(T(h), S, _packed_form(ops, eng, form), eng.pts_b, eng.alpha_w, eng.alpha_b, cview16, eng.rgb_w, eng.rgb_b, raw16, form=form)
+        assert raw_err(N(raw16), g["raw_coarse"]) < 1e-4, form
+        assert raw_err(N(raw16), N(raw)) < 2e-5, form      # split products ~ fp32 round-off class
+        split[form] = raw16
+    # the two forms add the same products in another order: the same round-off class
+    assert raw_err(N(split[32]), N(split[16])) < 2e-5
 
 
 def test_pe_mlp16_random_rows_and_tails(ops, stage):
     """row counts that are not multiples of the 128-row tile, compacted scatter, large |h|"""
     eng = stage["eng"]
     rng = np.random.default_rng(5)
-    for n in (1, 31, 129, 1000):
+    for n in (1, 31, 33, 129, 1000, 4133):
         h = np.zeros((n, 16), np.float32)
         h[:, :15] = rng.normal(0, 1.5, size=(n, 15))
         S = 4
@@ -249,16 +265,22 @@ def test_pe_mlp16_random_rows_and_tails(ops, stage):
         b = torch.zeros(R * S, 4, device=DEV)
         ops.pe_mlp(T(h), S, eng.packed, eng.pts_b, eng.alpha_w, eng.alpha_b, eng.feature_b, cview, eng.rgb_w, eng.rgb_b,
                    a, lst=lst)
-        ops.pe_mlp16(T(h), S, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview + (eng.views_b16 - eng.views_b), eng.rgb_w,
-                     eng.rgb_b, b, lst=lst)
-        assert raw_err(N(b), N(a)) < 2e-5, n
+        for form in (16, 32):
+            b.zero_()
+            ops.pe_mlp16(T(h), S, _packed_form(ops, eng, form), eng.pts_b, eng.alpha_w, eng.alpha_b, cview + (eng.views_b16 - eng.views_b),
+                         eng.rgb_w, eng.rgb_b, b, lst=lst, form=form)
+            assert raw_err(N(b), N(a)) < 2e-5, (n, form)
+            # rows outside the list stay untouched
+            rest = torch.ones(R * S, dtype=torch.bool, device=DEV)
+            rest[lst.long()] = False
+            assert float(b[rest].abs().max()) == 0.0 if bool(rest.any()) else True
         assert float(N(a).__abs__().max()) > 0.1
 
 
-@pytest.mark.parametrize("mode", ["f16split", "fp32"])
+@pytest.mark.parametrize("mode", ["f16split", "f16split-16", "fp32"])
 def test_forward_dense_equals_culled_bitwise(stage, mode):
     g, eng = stage["g"], stage["eng"]
-    eng.mlp_mode = mode
+    eng.mlp_mode, eng.mlp_form = mode.split("-")[0], 16 if mode.endswith("-16") else 32
     rb = g["ray_batch"]
     args = (T(rb[:, 0:3]), T(rb[:, 3:6]), T(g["skts"]), T(g["bones"]), T(g["cam_idx"], torch.int64))
     raw_c, ex = eng.forward_samples(*args, z=T(g["z_coarse"]), dense=False)
@@ -267,7 +289,7 @@ def test_forward_dense_equals_culled_bitwise(stage, mode):
     assert raw_err(N(raw_c), g["raw_coarse"]) < 1e-4
     n = int(N(ex["count"])[0])
     assert 0 < n < raw_c.shape[0] * raw_c.shape[1]
-    eng.mlp_mode = "f16split"
+    eng.mlp_mode, eng.mlp_form = "f16split", 32
 
 
 def test_composite(ops, stage):

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/danbo_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
-    assert lib.danbo_abi_version() == 8
+    assert lib.danbo_abi_version() == 9
     # argument counts of the ctypes table match the header
     for name in declared:
         m = re.search(r"(?:int|size_t|long)\s+" + name + r"\s*\((.*?)\);", hdr, flags=re.S)
@@ -497,6 +497,55 @@ def test_ring_kernels_do_not_spill(tmp_path):
                         foreign.append(code.strip())
         assert not foreign, (k, foreign[:4])
         assert mfma_outside == 0 and mfma_inside == n_mfma, (k, mfma_outside, mfma_inside)
+
+
+def test_k3_32x32_form_register_discipline(tmp_path):
+    """k_pe_mlp32 (K3 in the 32x32x16 form) names its own registers in inline assembly: the two AccVGPR result banks, the fragment
+    double buffers, the epilogue temporaries (v184 .. v255).  The compiler only honours them ACROSS one asm statement; what keeps
+    them safe between statements is that it has no reason to take them.  Checked on the gfx950 ISA: between the first and the last
+    MFMA no compiler-generated instruction names v184+ or any AccVGPR (this compiler DID take a[0:59] for the colour head's weights
+    behind the last MFMA -- why the view layer's accumulators are asm operands, not pinned), none touches M0 (every LDS-DMA load
+    is an asm statement with its own M0 write: with builtin loads the compiler hoisted its M0 initialisation across the groups and
+    the staging loads went into the ring), there is no scratch, and every MFMA sits inside the asm."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "k_mlp32.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", out,
+                    os.path.join(ROOT, "danbo-pytorch_amd", "csrc", "k_mlp32.hip")], check=True, capture_output=True)
+    text = open(out).read()
+    k = "k_pe_mlp32"
+    meta = re.search(r"\.name:\s+\S*" + k + r"\S*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", text)
+    assert meta is not None and int(meta.group(1)) == 0, meta and meta.group(1)
+    body = text[text.index(re.search(r"^(_ZN5danbo\S*" + k + r"\S*):", text, re.M).group(1) + ":"):]
+    body = body[:body.index(".Lfunc_end")].split("\n")
+    assert not any("scratch_" in l for l in body)
+    mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+    # 2 x 13 k-substeps of the encoding x 24 | three dense-layer sites of 16 x 24 (+ the skip layer's second form of k-substep 0) | view 16 x 12
+    assert len(mf) == 2 * 13 * 24 + 3 * 16 * 24 + 24 + 16 * 12, len(mf)
+    vreg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    areg = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
+    in_asm, foreign, mfma_outside, m0_outside = False, [], 0, []
+    for i, l in enumerate(body):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif not in_asm:
+            code = l.split(";")[0]
+            mfma_outside += "v_mfma" in code
+            if re.search(r"\bm0\b", code):
+                m0_outside.append(code.strip())
+            if mf[0] < i < mf[-1]:
+                if areg.search(code):
+                    foreign.append(code.strip())
+                for m in vreg.finditer(code):
+                    if int(m.group(1) or m.group(3)) >= 184:
+                        foreign.append(code.strip())
+    assert mfma_outside == 0
+    assert not foreign, foreign[:4]
+    assert not m0_outside, m0_outside[:4]
 
 
 def test_fragment_order_buffer_layout_on_cpu():

@@ -22,7 +22,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) 
                "the coarse and fine launches of a frame", "kernels": {}}
 # bench.py only quotes these numbers for the kernel sources they were measured on
 h = hashlib.sha256()
-for f in ("k_mlp16.hip", "mlp16_core.hpp", "common.hpp"):
+for f in ("k_mlp32.hip", "mlp32_regs.inc", "k_mlp16.hip", "mlp16_core.hpp", "common.hpp"):      # = bench.py K3_SOURCES
     h.update(open(os.environ["GRAFT_REPO_ROOT"] + "/danbo-pytorch_amd/csrc/" + f, "rb").read())
 out["kernel_src_sha16"] = h.hexdigest()[:16]
 for k, d in acc.items():

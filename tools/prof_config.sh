@@ -11,5 +11,5 @@ frames = max([int(r["Calls"]) for r in rows if "k_composite_merged" in r["Name"]
 for r in rows[:16]:
     print(r["Name"][:48].ljust(48), r["Calls"].rjust(4), "avg_us", str(round(float(r["AverageNs"])/1e3,1)).rjust(8), "ms/frame", str(round(int(r["TotalDurationNs"])/1e6/frames,3)).rjust(7), r["Percentage"])
 print("frames", frames, " sum of all kernels per frame ms", round(sum(int(r["TotalDurationNs"]) for r in rows)/1e6/frames,3),
-      " without k_pe_mlp16:", round(sum(int(r["TotalDurationNs"]) for r in rows if "k_pe_mlp16" not in r["Name"])/1e6/frames,3))
+      " without K3 (k_pe_mlp32 / k_pe_mlp16):", round(sum(int(r["TotalDurationNs"]) for r in rows if "k_pe_mlp" not in r["Name"])/1e6/frames,3))
 PY
