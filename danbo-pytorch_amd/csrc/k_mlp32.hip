@@ -186,8 +186,13 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 #define M32_DMA_5_2(D)
 #define M32_DMA_5_3(D)
 #define M32_DMA_5_4(D)
+#ifdef M32_EXP_NOLGKM     // timing experiment (wrong results): what the groups wait for their fragments
+#define M32_HEAD_WAIT ""
+#else
+#define M32_HEAD_WAIT "s_waitcnt lgkmcnt(0)\n\t"
+#endif
 #define M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, DMA, E0, E1, E2, E3, E4, E5) \
-    M32_DMA_M0 "s_waitcnt lgkmcnt(0)\n\t"                                        \
+    M32_DMA_M0 M32_HEAD_WAIT                                                     \
     M32_MF(ACC0, "0", BH, C0) E0 READS                                           \
     M32_MF(ACC1, "8", BH, C1) M32_DMA_AT(1, DMA) E1                              \
     M32_MF(ACC0, "0", BL, ACC0) M32_DMA_AT(2, DMA) E2                            \
@@ -274,13 +279,18 @@ __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, u
 // head that follows is compiler-generated code, and this compiler takes every AccVGPR it does not know to be live for its own
 // values (it read the head's colour weights into a[0:59]).  EPI 5 / 6: the two groups of a k-substep (6 also without a prefetch:
 // never -- the tile's last group has no epilogue); the table reads of EPI 5 are OLDER than the fragment reads: lgkmcnt(4) = tables landed.
+#ifdef M32_EXP_A1
+#define M32_VIEW_A_CLOBBERS M32_A1_CLOBBERS
+#else
+#define M32_VIEW_A_CLOBBERS M32_A64_CLOBBERS
+#endif
 template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO, int Q>
 __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
 #define M32_VIEW_ASM(TEXT, CONSTRAINT)                                                                                       \
     asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1)                                              \
                  : [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [bq] "n"(BQ), [nq] "n"(BQ == 216 ? 208 : 216), [pb] "n"(PB), \
                    [nb] "v"(nb), [o0] "n"(O0), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(BO), [w] "v"(w), M32_DMA_OPERANDS         \
-                 : M32_V_CLOBBERS, M32_A1_CLOBBERS, "memory")
+                 : M32_V_CLOBBERS, M32_VIEW_A_CLOBBERS, "memory")
 #define M32_VIEW_EMIT(READS, E0, E1, E2, E3, E4, E5)                                                                          \
     do {                                                                                                                     \
         if constexpr (FIRST) M32_VIEW_ASM(M32_GROUP_ON("%[c0]", "%[c1]", M32_BH, M32_BL, "0", "0", READS, E0, E1, E2, E3, E4, E5), "=&a"); \
@@ -479,6 +489,26 @@ struct StageRows32 {
         lds_dma_lanes4(src_l, st + (unsigned)M32_STAGE_H);
     }
 };
+// ... and THIS tile's per-ray view constants (16 x 16 bytes per lane: features 32 T + 8 Q + 4 g .. + 3 of the lane's ray) into
+// a[64:127], four chunks before the colour head needs them: the result bank they land in is dead during the view layer (whose
+// accumulators the compiler keeps in a0 .. a63: the view groups clobber everything above), and loads issued at the head cost their
+// whole L2 / HBM latency there (2 % of the launch).  19 loads for the next hand-over's count.
+struct StageView32 {
+    const TileSrc32& t;
+    const float* cvb;
+    __device__ __forceinline__ void operator()() const {
+        StageRows32{t}();
+#ifdef M32_EXP_NOCVL
+        return;
+#endif
+#define M32_CVL(K, OFF) "global_load_dwordx4 a[" #K ":" #K "+3], %0, off offset:" #OFF "\n\t"
+        asm volatile(M32_CVL(64, 0) M32_CVL(68, 32) M32_CVL(72, 64) M32_CVL(76, 96) M32_CVL(80, 128) M32_CVL(84, 160) M32_CVL(88, 192)
+                     M32_CVL(92, 224) M32_CVL(96, 256) M32_CVL(100, 288) M32_CVL(104, 320) M32_CVL(108, 352) M32_CVL(112, 384)
+                     M32_CVL(116, 416) M32_CVL(120, 448) M32_CVL(124, 480)
+                     ::"v"(cvb) : M32_A64_CLOBBERS, "memory");
+#undef M32_CVL
+    }
+};
 
 __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -587,7 +617,14 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
             const unsigned ba_out = tab + 7u * 1024u + g16, aa = tab + 8u * 1024u + g16;
             const float w_7 = M32_WINV(7);
             m32_layer_end<1, true>(al, ba_out, aa, w_7);
-            const StageRows32 stage{src};
+            // the ray of this lane's sample and the address of its view constants (dst / S: formed here, not hoisted out of the tile loop)
+            int zero_v = 0, S_ = a.S;
+            asm volatile("" : "+s"(zero_v), "+s"(S_));
+            const int g_v = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_v)) >> 5);
+            asm volatile("" : "+v"(dst));
+            const int ray = dst >= 0 ? dst / S_ : 0;
+            const float* cvb = a.cview ? a.cview + (size_t)ray * M32_VW + 4 * g_v : reinterpret_cast<const float*>(a.packed);
+            const StageView32 stage{src, cvb};
 #define M32_VCHUNK(C, EXTRA_, STAGE_)                                                              \
             {                                                                                      \
                 const Dma32 d = pipe32_sync<EXTRA_>(p, STAGE_);                                    \
@@ -598,12 +635,16 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
                 m32_view_ksub<4 * (C) + 3>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
             }
             M32_VCHUNK(0, 0, stage)            // the staging loads sit between the barrier and the refill:
-            M32_VCHUNK(1, 3, NoExtra())        // older than chunk c + 3, younger than what the next hand-over waits for
+            M32_VCHUNK(1, 19, NoExtra())       // older than chunk c + 3, younger than what the next hand-over waits for
             M32_VCHUNK(2, 0, NoExtra())
             M32_VCHUNK(3, 0, NoExtra())
 #undef M32_VCHUNK
         }
         asm volatile(M32_DRAIN : "+a"(accv[0]), "+a"(accv[1]), "+a"(accv[2]), "+a"(accv[3])::"memory");
+#ifdef M32_EXP_NOHEAD      // timing experiment (wrong results): the colour head
+        if (dst >= 0 && (lane_off16() >> 9) == 0) reinterpret_cast<float4*>(a.raw_out)[dst] = make_float4(accv[0][0], accv[1][0], accv[2][0], al + accv[3][0]);
+        continue;
+#endif
         // ------------------------------------------------------------------ colour head + output
         int zero_h = 0;
         asm volatile("" : "+s"(zero_h));
@@ -611,21 +652,23 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         const int g = lane_h >> 5;
         const int row = grp_i * 32 + (lane_h & 31);
         asm volatile("" : "+v"(dst));
-        int S_ = a.S;
-        asm volatile("" : "+s"(S_));       // the division's reciprocal is formed here, not hoisted out of the tile loop and spilled
-        const int ray = dst >= 0 ? dst / S_ : 0;
+        // the view constants, landed in a[64:127] during the view layer (the hand-overs of its last two chunks waited for them)
         f32x4 cv[16];
-        {
-            const float* cvb = a.cview ? a.cview + (size_t)ray * M32_VW + 4 * g : reinterpret_cast<const float*>(a.packed);
-#define M32_CV(T, Q) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(cv[4 * (T) + (Q)]) : "v"(cvb), "i"((T) * 128 + (Q) * 32) : "memory");
-#define M32_CV4(T) M32_CV(T, 0) M32_CV(T, 1) M32_CV(T, 2) M32_CV(T, 3)
-            M32_CV4(0) M32_CV4(1) M32_CV4(2) M32_CV4(3)
-#undef M32_CV4
-#undef M32_CV
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(cv[i]));
-        }
+#define M32_CVR(T)                                                                                                              \
+        asm volatile("v_accvgpr_read_b32 %0, a[64+16*" #T "+0]\n\tv_accvgpr_read_b32 %1, a[64+16*" #T "+1]\n\t"                 \
+                     "v_accvgpr_read_b32 %2, a[64+16*" #T "+2]\n\tv_accvgpr_read_b32 %3, a[64+16*" #T "+3]\n\t"                 \
+                     "v_accvgpr_read_b32 %4, a[64+16*" #T "+4]\n\tv_accvgpr_read_b32 %5, a[64+16*" #T "+5]\n\t"                 \
+                     "v_accvgpr_read_b32 %6, a[64+16*" #T "+6]\n\tv_accvgpr_read_b32 %7, a[64+16*" #T "+7]\n\t"                 \
+                     "v_accvgpr_read_b32 %8, a[64+16*" #T "+8]\n\tv_accvgpr_read_b32 %9, a[64+16*" #T "+9]\n\t"                 \
+                     "v_accvgpr_read_b32 %10, a[64+16*" #T "+10]\n\tv_accvgpr_read_b32 %11, a[64+16*" #T "+11]\n\t"             \
+                     "v_accvgpr_read_b32 %12, a[64+16*" #T "+12]\n\tv_accvgpr_read_b32 %13, a[64+16*" #T "+13]\n\t"             \
+                     "v_accvgpr_read_b32 %14, a[64+16*" #T "+14]\n\tv_accvgpr_read_b32 %15, a[64+16*" #T "+15]"                  \
+                     : "=v"(cv[4 * T][0]), "=v"(cv[4 * T][1]), "=v"(cv[4 * T][2]), "=v"(cv[4 * T][3]), "=v"(cv[4 * T + 1][0]),   \
+                       "=v"(cv[4 * T + 1][1]), "=v"(cv[4 * T + 1][2]), "=v"(cv[4 * T + 1][3]), "=v"(cv[4 * T + 2][0]),           \
+                       "=v"(cv[4 * T + 2][1]), "=v"(cv[4 * T + 2][2]), "=v"(cv[4 * T + 2][3]), "=v"(cv[4 * T + 3][0]),           \
+                       "=v"(cv[4 * T + 3][1]), "=v"(cv[4 * T + 3][2]), "=v"(cv[4 * T + 3][3])::"memory");
+        M32_CVR(0) M32_CVR(1) M32_CVR(2) M32_CVR(3)
+#undef M32_CVR
         float pr_ = 0.f, pg_ = 0.f, pb_ = 0.f;
         float* aux = (a.aux_out && dst >= 0) ? a.aux_out + (size_t)row * (M32_VW + 1) + 4 * g : nullptr;
         const float winv_v = M32_WINV(8);

@@ -50,7 +50,7 @@ def main():
                         prm.zero_()
             eng.refresh()
             h.zero_(), cview.zero_()
-        fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n)
+        fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n, form=eng.mlp_form)
         flops = n * 611840 * 2 * 3
     elif what == "linear16":
         from core import hip_ops as ops

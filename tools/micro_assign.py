@@ -35,8 +35,8 @@ print("assign16 sorted ms", timeit(lambda: ops.gather_assign_blend16(geo, vols, 
 h = torch.zeros(n, 16, device="cuda")
 raw = torch.zeros(geo.M, 4, device="cuda")
 cview, raw_empty = eng.view_constants(inp["rays_d"], inp["skts"], inp["cam_idx"])
-print("mlp16           ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, ls, None, n)))
-print("mlp16 cap=M     ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, cnt, geo.M)))
+print("mlp16           ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, ls, None, n, form=eng.mlp_form)))
+print("mlp16 cap=M     ms", timeit(lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, cnt, geo.M, form=eng.mlp_form)))
 
 # grouped rows (k_group.hip) and the s_memtime trace of one wavefront
 lg = lst.clone()

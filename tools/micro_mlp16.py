@@ -32,7 +32,7 @@ if zeros:
 for a_ in sys.argv[1:]:
     if a_.startswith("--rows="):        # the same kernel on the first k in-volume rows only (the training step's sizes: 41 000 / 18 000)
         n = min(n, int(a_.split("=")[1]))
-fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n)
+fn = lambda: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw, lst, None, n, form=eng.mlp_form)
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

@@ -24,12 +24,13 @@ for a_ in sys.argv[1:]:
     if a_.startswith("--rows="):
         n = min(n, int(a_.split("=")[1]))
 q = eng._equalized(eng.p)
-packed32, vb32 = ops.mlp16_pack(eng.pts_w, q["feature_linear.weight"], q["feature_linear.bias"], q["views_linears.0.weight"],
-                                q["views_linears.0.bias"], form=32)
-print("views_b_eff equal:", bool(torch.equal(vb32, eng.views_b16)))
+pack = lambda form: ops.mlp16_pack(eng.pts_w, q["feature_linear.weight"], q["feature_linear.bias"], q["views_linears.0.weight"],
+                                   q["views_linears.0.bias"], form=form)
+(packed16, vb16), (packed32, vb32) = pack(16), pack(32)      # (the engine's own buffer is in the form of its mlp_form)
+print("views_b_eff equal:", bool(torch.equal(vb32, eng.views_b16) and torch.equal(vb16, vb32)))
 raw16 = torch.zeros(geo.M, 4, device="cuda")
 raw32 = torch.zeros(geo.M, 4, device="cuda")
-f16 = lambda aux=False: ops.pe_mlp16(h, 48, eng.packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw16, lst, None, n, aux)
+f16 = lambda aux=False: ops.pe_mlp16(h, 48, packed16, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw16, lst, None, n, aux)
 f32 = lambda aux=False: ops.pe_mlp16(h, 48, packed32, eng.pts_b, eng.alpha_w, eng.alpha_b, cview, eng.rgb_w, eng.rgb_b, raw32, lst, None, n, aux, form=32)
 a16 = f16(True); a32 = f32(True); torch.cuda.synchronize()
 rows = lst[:n].long()
@@ -70,3 +71,7 @@ if "--debug" in sys.argv:
     pk = packed32[:74 * 32768].view(torch.float16).view(74, 32, 64, 8).float()
     for ch in (0, 7, 62, 70, 71, 73):
         print("chunk", ch, "per-piece max |w|:", [round(float(v), 1) for v in pk[ch].abs().amax((1, 2))])
+if "--rows-diff" in sys.argv:
+    dd = (raw16[rows] - raw32[rows]).abs()
+    bad = (dd[:, 3] > 1e-4).nonzero().flatten()
+    print("rows with a wrong density:", int(bad.numel()), "of", n, " first:", bad[:16].tolist(), " row %32:", sorted(set((bad % 32).tolist()))[:40])
