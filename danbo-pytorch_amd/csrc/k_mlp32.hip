@@ -324,6 +324,138 @@ __device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, u
 #undef M32_PE_ASM
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Layer 0 with the encoding's VALU work under its MFMAs.  The 48 sine / cosine pairs of a row (8 channels x 6 levels per lane)
+// and the splits of the 13 B fragments are ~ 1 400 VALU instructions per tile; made in one piece in front of the layer they cost
+// 3.7 % of the launch (no partner wavefront covers them).  Here fragment U + 1 is made WHILE k-substep U runs: the 24 MFMAs of a
+// k-substep are single asm statements, and behind MFMA m sits slice m of the next fragment's work -- compiler-generated code, held
+// in its slot by empty volatile asm statements on the values that cross the slot's borders (volatile statements keep their order,
+// so the slice can move neither above the MFMA in front of it nor below the one behind it).  The arithmetic is pe_sincos' (common.hpp),
+// operation for operation: the fragments are bit-identical to pe32_ksub's.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int pe_t(int U, int e) { return (8 * U + e) % 13; }
+constexpr int pe_c(int U, int e) { return (8 * U + e) / 13; }
+constexpr bool pe_is_job(int U, int e) { return 8 * U + e < 104 && (pe_t(U, e) & 1) != 0; }      // a sine: one sincos job (its cosine is the next value)
+constexpr int pe_njobs(int U) { int n = 0; for (int e = 0; e < 8; ++e) n += pe_is_job(U, e) ? 1 : 0; return n; }
+constexpr int pe_job_e(int U, int n) { int k = 0; for (int e = 0; e < 8; ++e) if (pe_is_job(U, e)) { if (k == n) return e; ++k; } return 0; }
+
+struct PeJob { float a, k, r, r2, sp, cp, sn, cs; };
+struct PeFrag {
+    float v8[8];
+    float cs_in, cs_out;          // the cosine of a pair whose sine is a fragment's last value: first value of the next fragment
+    unsigned h[4], l[4];
+};
+#define M32_FENCE2(A, B) asm volatile("" : "+v"(A), "+v"(B))
+#define M32_FENCE3(A, B, C) asm volatile("" : "+v"(A), "+v"(B), "+v"(C))
+#define M32_FENCE5(A, B, C, D, E) asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E))
+
+template <int STAGE>
+__device__ __forceinline__ void pe_job_stage(PeJob& j, float x, float scale, float& out_s, float& out_c) {
+    if constexpr (STAGE == 0) {
+        asm volatile("" : "+v"(x));
+        j.a = x * scale;
+        j.k = rintf(j.a * 0.636619772367581343f);
+        j.r = fmaf(j.k, -1.57079601287841796875f, j.a);
+        M32_FENCE2(j.k, j.r);
+    } else if constexpr (STAGE == 1) {
+        j.r = fmaf(j.k, -3.1391647326017846353352069854736328125e-7f, j.r);
+        j.r = fmaf(j.k, -5.390302529957764765544681040410068817436695098876953125e-15f, j.r);
+        j.r2 = j.r * j.r;
+        M32_FENCE3(j.k, j.r, j.r2);
+    } else if constexpr (STAGE == 2) {
+        j.sp = fmaf(j.r2, 2.6083159809786593541502952575683593750e-6f, -1.981069071916863322258e-4f);
+        j.sp = fmaf(j.sp, j.r2, 8.33307858556509017944e-3f);
+        j.sp = fmaf(j.sp, j.r2, -1.66666597127914428711e-1f);
+        j.cp = fmaf(j.r2, 2.44331571593647822737693786621e-5f, -1.38873163610696792602539062500e-3f);
+        M32_FENCE5(j.k, j.r, j.r2, j.sp, j.cp);
+    } else if constexpr (STAGE == 3) {
+        j.sn = fmaf(j.sp * j.r2, j.r, j.r);
+        j.cp = fmaf(j.cp, j.r2, 4.16666455566883087158203125e-2f);
+        j.cp = fmaf(j.cp, j.r2, -0.5f);
+        j.cs = fmaf(j.cp, j.r2, 1.0f);
+        M32_FENCE3(j.k, j.sn, j.cs);
+    } else {
+        const int q = (int)j.k;
+        const float s0 = (q & 1) ? j.cs : j.sn;
+        const float c0 = (q & 1) ? j.sn : j.cs;
+        out_s = (q & 2) ? -s0 : s0;
+        out_c = ((q + 1) & 2) ? -c0 : c0;
+        M32_FENCE2(out_s, out_c);
+    }
+}
+
+// slice M (0 .. 23) of fragment UN: slots 5 n .. 5 n + 4 carry job n, slot 20 the values that are no job's and half of the split,
+// slot 21 the other half
+template <int UN, int M>
+__device__ __forceinline__ void pe_slot(const float (&hv)[8], PeJob& j, PeFrag& f, half8& xh, half8& xl) {
+    constexpr int NJ = pe_njobs(UN);
+    static_assert(NJ <= 4, "four jobs of five slots");
+    if constexpr (M < 20) {
+        constexpr int n = M / 5, st = M % 5;
+        if constexpr (n < NJ) {
+            constexpr int e = pe_job_e(UN, n), c = pe_c(UN, e), lvl = (pe_t(UN, e) - 1) >> 1;
+            if constexpr (e + 1 < 8) pe_job_stage<st>(j, hv[c], (float)(1 << lvl), f.v8[e], f.v8[e + 1]);
+            else pe_job_stage<st>(j, hv[c], (float)(1 << lvl), f.v8[e], f.cs_out);
+        }
+    } else if constexpr (M == 20) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int jj = 8 * UN + e, t = jj % 13;
+            if (jj >= 104) f.v8[e] = 0.f;
+            else if (t == 0) f.v8[e] = hv[jj / 13];
+            else if (e == 0 && !(t & 1)) f.v8[0] = f.cs_in;
+        }
+        f.cs_in = f.cs_out;
+#define M32_SPLIT_PAIR(P)                                                                                                        \
+        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(f.h[P]) : "v"(f.v8[2 * (P)]), "v"(f.v8[2 * (P) + 1]));                   \
+        asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(f.l[P]) : "v"(f.v8[2 * (P)]), "v"(f.h[P])); \
+        asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(f.l[P]) : "v"(f.v8[2 * (P) + 1]), "v"(f.h[P]));
+        M32_SPLIT_PAIR(0) M32_SPLIT_PAIR(1)
+    } else if constexpr (M == 21) {
+        M32_SPLIT_PAIR(2) M32_SPLIT_PAIR(3)
+#undef M32_SPLIT_PAIR
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        xh = __builtin_bit_cast(half8, u32x4{f.h[0], f.h[1], f.h[2], f.h[3]});
+        xl = __builtin_bit_cast(half8, u32x4{f.l[0], f.l[1], f.l[2], f.l[3]});
+    }
+}
+// fragment UN in one piece (the tile's first)
+template <int UN, int M = 0>
+__device__ __forceinline__ void pe_fragment(const float (&hv)[8], PeJob& j, PeFrag& f, half8& xh, half8& xl) {
+    pe_slot<UN, M>(hv, j, f, xh, xl);
+    if constexpr (M + 1 < 22) pe_fragment<UN, M + 1>(hv, j, f, xh, xl);
+}
+
+// MFMA I (0 .. 5) of a group of the encoding's k-substep, as a statement of its own (m32_group_pe cut in six)
+template <int I, bool FIRST, int CA, int HA, int O0, int Q>
+__device__ __forceinline__ void m32_pe_mfma(const half8& xh, const half8& xl, unsigned nb, const Dma32& d) {
+#define M32_PE1_ASM(TEXT)                                                                                                    \
+    asm volatile(TEXT :: [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl), \
+                 [nb] "v"(nb), [o0] "n"(O0), M32_DMA_OPERANDS : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
+    if constexpr (I == 0) {
+        if constexpr (FIRST) M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", "0") M32_READS);
+        else M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", M32_ACC_A) M32_READS);
+    } else if constexpr (I == 1) {
+        if constexpr (FIRST) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", "0") M32_DMA);
+        else M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", M32_ACC_B) M32_DMA);
+    } else if constexpr (I == 2) M32_PE1_ASM(M32_MF(M32_ACC_A, "0", "%[xl]", M32_ACC_A));
+    else if constexpr (I == 3) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xl]", M32_ACC_B));
+    else if constexpr (I == 4) M32_PE1_ASM(M32_MF(M32_ACC_A, "4", "%[xh]", M32_ACC_A));
+    else M32_PE1_ASM(M32_MF(M32_ACC_B, "12", "%[xh]", M32_ACC_B));
+#undef M32_PE1_ASM
+}
+
+// k-substep U of layer 0 (bank 0) with fragment U + 1 made under it: MFMA m, slice m, MFMA m + 1, ...
+template <int U, int M = 0>
+__device__ __forceinline__ void m32_pe_ksub_sliced(half8 (&xh)[13], half8 (&xl)[13], const float (&hv)[8], PeJob& j, PeFrag& f,
+                                                   unsigned cbase, unsigned nbase, const Dma32& d) {
+    constexpr int G = M / 6, I = M % 6, H = U & 1;
+    constexpr int O0 = G < 3 ? (H * 4 + G + 1) * 4096 : (H ? 0 : 4 * 4096);
+    m32_pe_mfma<I, U == 0, 32 * G, (G & 1) ? 240 : 224, O0, H * 4 + G>(xh[U], xl[U], (G == 3 && H) ? nbase : cbase, d);
+    pe_slot<U + 1, M>(hv, j, f, xh[U + 1], xl[U + 1]);
+    if constexpr (M + 1 < 24) m32_pe_ksub_sliced<U, M + 1>(xh, xl, hv, j, f, cbase, nbase, d);
+}
+
 // the first group's fragments of the chunk at `base` (LDS address, lane * 16 included) -> buffer 0
 __device__ __forceinline__ void m32_prefetch0(unsigned base) {
     asm volatile("ds_read_b128 v[224:227], %0\n\tds_read_b128 v[228:231], %0 offset:1024\n\t"
@@ -432,6 +564,28 @@ __device__ __forceinline__ void m32_pe_layer(Pipe32& p, const half8 (&xh)[13], c
     }
 #undef M32_PE_CHUNK
 #undef M32_PE_KSUB
+}
+
+// layer 0: the same 13 k-substeps into bank 0, each with the next fragment made under it (fragment 0: in front, in one piece)
+__device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 (&xl)[13], const float (&hv)[8], PeJob& j, PeFrag& f) {
+#define M32_PE0_CHUNK(C)                                                                                         \
+    {                                                                                                            \
+        const Dma32 d = pipe32_sync<0>(p, NoExtra());                                                            \
+        const RingPos r = m32_next_chunk(p, ring_lane_addr());                                                   \
+        m32_pe_ksub_sliced<2 * (C)>(xh, xl, hv, j, f, r.cbase, r.nbase, d);                                      \
+        m32_pe_ksub_sliced<2 * (C) + 1>(xh, xl, hv, j, f, r.cbase, r.nbase, d);                                  \
+    }
+    M32_PE0_CHUNK(0) M32_PE0_CHUNK(1) M32_PE0_CHUNK(2) M32_PE0_CHUNK(3) M32_PE0_CHUNK(4) M32_PE0_CHUNK(5)
+#undef M32_PE0_CHUNK
+    {
+        const Dma32 d = pipe32_sync<0>(p, NoExtra());
+        pipe32_issue_half(d);
+        const RingPos r = m32_next_chunk(p, ring_lane_addr());
+        m32_group_pe<false, 0, 224, 1 * 4096, 4>(xh[12], xl[12], r.cbase, d);
+        m32_group_pe<false, 32, 240, 2 * 4096, 5>(xh[12], xl[12], r.cbase, d);
+        m32_group_pe<false, 64, 224, 3 * 4096, 6>(xh[12], xl[12], r.cbase, d);
+        m32_group_pe<false, 96, 240, 0, 7>(xh[12], xl[12], r.nbase, d);
+    }
 }
 
 // view layer (256 -> 128: four result tiles `accv` from bank 1): k-substep U = 2 groups, 4 k-substeps per chunk
@@ -575,18 +729,12 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         for (int c = 0; c < 8; ++c) hv[c] = row_ok ? hv[c] : 0.f;
         if (g_t == 1) hv[7] = 0.f;                                   // channel 15 is padding
         src.next_row0 = (round_base(rnd + 1) + wave) * 32;
-        // the encoding's B fragments, made once per tile and kept for the skip layer
+        // the encoding's B fragments are kept for the skip layer; fragment 0 here, fragment U + 1 under k-substep U of layer 0
         half8 xh[13], xl[13];
-        {
-            float cs_keep = 0.f;
-#ifdef M32_EXP_NOPE        // timing experiment (wrong results): the encoding's VALU work
-#define M32_PE(U) { float v8[8]; for (int e = 0; e < 8; ++e) v8[e] = hv[e]; split8_mix(v8, xh[U], xl[U]); }
-#else
-#define M32_PE(U) { float v8[8]; pe32_ksub<U>(hv, cs_keep, v8); split8_mix(v8, xh[U], xl[U]); }
-#endif
-            M32_PE(0) M32_PE(1) M32_PE(2) M32_PE(3) M32_PE(4) M32_PE(5) M32_PE(6) M32_PE(7) M32_PE(8) M32_PE(9) M32_PE(10) M32_PE(11) M32_PE(12)
-#undef M32_PE
-        }
+        PeJob pe_job;
+        PeFrag pe_frag;
+        pe_frag.cs_in = pe_frag.cs_out = 0.f;
+        pe_fragment<0>(hv, pe_job, pe_frag, xh[0], xl[0]);
         float al = 0.f;
         f32x16 accv[4];          // the view layer's result tiles (features 32 T + 8 (r / 4) + 4 g + r % 4)
         const unsigned tab = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)s_bias;
@@ -595,7 +743,7 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
 #define M32_WINV(L_) m32_lds_f32(winv_at + 4u * (unsigned)(L_))
         m32_prefetch0(ring_lane_addr() + (unsigned)p.cons_slot * CHUNK_BYTES);
         // layer 0: the encoding into bank 0
-        m32_pe_layer<0>(p, xh, xl);
+        m32_pe_layer0(p, xh, xl, hv, pe_job, pe_frag);
         m32_layer_end<0, false>(al, tab + g16, 0u, M32_WINV(0));
 #pragma unroll 1
         for (int pr = 0; pr < 3; ++pr) {
