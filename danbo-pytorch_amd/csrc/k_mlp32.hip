@@ -279,11 +279,7 @@ __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, u
 // head that follows is compiler-generated code, and this compiler takes every AccVGPR it does not know to be live for its own
 // values (it read the head's colour weights into a[0:59]).  EPI 5 / 6: the two groups of a k-substep (6 also without a prefetch:
 // never -- the tile's last group has no epilogue); the table reads of EPI 5 are OLDER than the fragment reads: lgkmcnt(4) = tables landed.
-#ifdef M32_EXP_A1
-#define M32_VIEW_A_CLOBBERS M32_A1_CLOBBERS
-#else
 #define M32_VIEW_A_CLOBBERS M32_A64_CLOBBERS
-#endif
 template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO, int Q>
 __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
 #define M32_VIEW_ASM(TEXT, CONSTRAINT)                                                                                       \
@@ -652,9 +648,6 @@ struct StageView32 {
     const float* cvb;
     __device__ __forceinline__ void operator()() const {
         StageRows32{t}();
-#ifdef M32_EXP_NOCVL
-        return;
-#endif
 #define M32_CVL(K, OFF) "global_load_dwordx4 a[" #K ":" #K "+3], %0, off offset:" #OFF "\n\t"
         asm volatile(M32_CVL(64, 0) M32_CVL(68, 32) M32_CVL(72, 64) M32_CVL(76, 96) M32_CVL(80, 128) M32_CVL(84, 160) M32_CVL(88, 192)
                      M32_CVL(92, 224) M32_CVL(96, 256) M32_CVL(100, 288) M32_CVL(104, 320) M32_CVL(108, 352) M32_CVL(112, 384)

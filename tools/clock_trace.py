@@ -1,5 +1,5 @@
 """Shader clock and socket power (hwmon of the visible GPU) while one kernel runs back to back (dev tool):
-    python tools/clock_trace.py [mlp16|mlp16z|linear16|copy|idle] [seconds]
+    python tools/clock_trace.py [mlp32|mlp32z|mlp16|mlp16z|linear16|copy|idle] [seconds]      (mlp32 / mlp16: K3 in its two forms)
 Samples freq1_input (sclk) and power1_input every ~2 ms from a thread while the main thread keeps the queue full."""
 import glob, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,13 +26,15 @@ def main():
     d = hwmon()
     print("hwmon", d, "cap W", rd(d + "/power1_cap") / 1e6 if d else None)
     dev = torch.device("cuda:0")
-    zeros = what == "mlp16z"           # same launch, all-zero weights and inputs: identical instruction stream, no operand toggling
-    if zeros:
-        what = "mlp16"
-    if what == "mlp16":
+    zeros = what in ("mlp16z", "mlp32z")  # same launch, all-zero weights and inputs: identical instruction stream, no operand toggling
+    form = 16 if what.startswith("mlp16") else 32
+    if what.startswith("mlp"):
+        what = "mlp"
+    if what == "mlp":
         import bench
         from core import hip_ops as ops
         eng, inp, _ = bench.build_workload(dev, 0)
+        eng.mlp_form = form
         eng.refresh()
         near, far = eng.near_far(inp["rays_o"], inp["rays_d"], inp["cyls"], inp["skts"])
         z = ops.coarse_samples(near, far, 48)
