@@ -28,5 +28,9 @@ bash tools/pmc_kernel.sh k2b_$TAG k_assign_bwd > $E/${TAG}_pmc_sq_k2_bwd.txt 2>&
 bash tools/pmc_mlp32.sh $TAG > $E/${TAG}_pmc_sq_k3_forms.txt 2>&1
 (for w in mlp32 mlp16 mlp32z mlp16z idle; do python tools/clock_trace.py $w 4; done) > $E/${TAG}_k3_forms_clock_power.txt 2>&1
 (cd tools/probe && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Wno-unused-value -o cview_probe cview_probe.hip 2>/dev/null; timeout 600 ./cview_probe 2000) > $E/${TAG}_pk_f32_erratum.txt 2>&1
+# gpurun merges at most 64 MiB back: the raw rocprofv3 directories stay on the box, the summaries above are what is kept
+find gpurun_out -mindepth 1 -maxdepth 1 -type d ! -name "evidence_$TAG" -exec rm -rf {} +
+find gpurun_out -maxdepth 1 -type f -size +4M -delete
+du -sh gpurun_out | tail -1
 grep -h '"ms_per_step"' $E/*_bench_config*.json
 tail -3 $E/${TAG}_parity_measured.txt
