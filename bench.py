@@ -655,8 +655,9 @@ def bench_train(args, rank, world, device, dist):
             traffic = rec["step_hbm_bytes"]
             hbm = dict(bytes_per_step=traffic, achieved=traffic / (ms * 1e-3) / 1e12, peak=8.0, unit="TB/s", frac=traffic / (ms * 1e-3) / 8e12,
                        note="steady-state steps only (tools/pmc_train.sh); every activation and gradient of the trunk is written once "
-                            "(forward / input-gradient chain, fragment order) and read by the weight-gradient kernel, whose two "
-                            "128-column halves re-read part of the inputs: 1.3 GB of the step's bytes")
+                            "(forward / input-gradient chain, fragment order: 0.59 + 0.52 GB) and read ONCE by the weight-gradient kernel "
+                            "(k_dw16: 1.07 GB per step against 1.0 GB if no operand were read twice; it streams them at the ~3.8 TB/s a "
+                            "reduction reaches on this part)")
     result = {
         "metric": "training ray-samples/sec (PerfCap danbo_fast step: forward + losses + backward + Adam)", "value": R_global * S / (ms * 1e-3),
         "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
