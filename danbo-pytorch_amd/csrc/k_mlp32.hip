@@ -54,6 +54,10 @@ struct Pipe32 {
     const char* packed;
     char* ring;
     int issue_chunk, issue_slot, cons_slot, wave;
+    // lane * 16 and the ring's LDS address + lane * 16: formed ONCE per kernel and kept (the two-wavefront kernel re-derives them where
+    // they are used to save registers; here the ~ 25 instructions of address arithmetic per hand-over are issued by a wavefront that
+    // has no partner, while the matrix pipe waits: 140 cycles per chunk by the wavefront trace)
+    unsigned l16, ring_lane;
 };
 
 // EVERY LDS-DMA load of this kernel is an asm statement that writes M0 itself.  The groups below set M0 for the piece they carry, and
@@ -118,15 +122,12 @@ __device__ __forceinline__ Dma32 pipe32_sync(Pipe32& p, const Extra& extra) {
     Dma32 d;
     d.src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192;
     d.dst = lds_addr(p.ring + p.issue_slot * CHUNK_BYTES + p.wave * 8192);
-    d.v0 = lane_off16();
+    d.v0 = p.l16;
     d.v1 = d.v0 + 4096u;
     p.issue_chunk = p.issue_chunk + 1 == M32_NCH ? 0 : p.issue_chunk + 1;
     p.issue_slot = p.issue_slot + 1 == RING_SLOTS ? 0 : p.issue_slot + 1;
     return d;
 }
-// pieces 0 .. 3 of a refill by the hand-over itself (the encoding's last chunk has four groups for eight pieces)
-__device__ __forceinline__ void pipe32_issue_half(const Dma32& d) { lds_dma_4k(d.src, d.v0, d.dst); }
-
 __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 #pragma unroll 1
     for (int c = 0; c < M32_NCH; ++c) pipe32_handover<0>(p, NoExtra());
@@ -154,38 +155,7 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 // six MFMAs on two in-place accumulators (hh0 hh1 hl0 hl1 lh0 lh1: per accumulator the order hh, hl, lh of k_pe_mlp16); E0 sits in front
 // of the next group's fragment reads (what it reads from LDS is older than they are), E1..E5 behind the following MFMAs
 #define M32_GROUP_ON(ACC0, ACC1, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
-    M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, M32_DMA, E0, E1, E2, E3, E4, E5)
-#ifndef M32_DMA_SLOT
-#define M32_DMA_SLOT 1      // behind which MFMA of the group (1 .. 5) the LDS-DMA piece sits
-#endif
-#define M32_DMA_AT(N, DMA) M32_DMA_AT_(N, M32_DMA_SLOT, DMA)
-#define M32_DMA_AT_(N, S, DMA) M32_DMA_AT__(N, S, DMA)
-#define M32_DMA_AT__(N, S, DMA) M32_DMA_##N##_##S(DMA)
-#define M32_DMA_1_1(D) D
-#define M32_DMA_2_2(D) D
-#define M32_DMA_3_3(D) D
-#define M32_DMA_4_4(D) D
-#define M32_DMA_5_5(D) D
-#define M32_DMA_1_2(D)
-#define M32_DMA_1_3(D)
-#define M32_DMA_1_4(D)
-#define M32_DMA_1_5(D)
-#define M32_DMA_2_1(D)
-#define M32_DMA_2_3(D)
-#define M32_DMA_2_4(D)
-#define M32_DMA_2_5(D)
-#define M32_DMA_3_1(D)
-#define M32_DMA_3_2(D)
-#define M32_DMA_3_4(D)
-#define M32_DMA_3_5(D)
-#define M32_DMA_4_1(D)
-#define M32_DMA_4_2(D)
-#define M32_DMA_4_3(D)
-#define M32_DMA_4_5(D)
-#define M32_DMA_5_1(D)
-#define M32_DMA_5_2(D)
-#define M32_DMA_5_3(D)
-#define M32_DMA_5_4(D)
+    M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, , E0, E1, E2, E3, E4, E5)
 #ifdef M32_EXP_NOLGKM     // timing experiment (wrong results): what the groups wait for their fragments
 #define M32_HEAD_WAIT ""
 #else
@@ -194,22 +164,34 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 #define M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, DMA, E0, E1, E2, E3, E4, E5) \
     M32_DMA_M0 M32_HEAD_WAIT                                                     \
     M32_MF(ACC0, "0", BH, C0) E0 READS                                           \
-    M32_MF(ACC1, "8", BH, C1) M32_DMA_AT(1, DMA) E1                              \
-    M32_MF(ACC0, "0", BL, ACC0) M32_DMA_AT(2, DMA) E2                            \
-    M32_MF(ACC1, "8", BL, ACC1) M32_DMA_AT(3, DMA) E3                            \
-    M32_MF(ACC0, "4", BH, ACC0) M32_DMA_AT(4, DMA) E4                            \
-    M32_MF(ACC1, "12", BH, ACC1) M32_DMA_AT(5, DMA) E5
-// piece Q of this wavefront's share of the chunk being refilled: M0 (the LDS destination) is written at the head of the group, the load
-// sits behind the second MFMA (a single wavefront issues one instruction per 4 cycles: 8 per MFMA, the MFMA included -- no slot of
-// a group carries more than 6 others)
-#ifdef M32_EXP_NODMA      // timing experiment (wrong results): what the pieces cost where they sit
-#define M32_DMA_M0 ""
-#define M32_DMA ""
-#else
-#define M32_DMA_M0 "s_mov_b32 m0, %[gm]\n\t"
-#define M32_DMA "global_load_lds_dwordx4 %[gv], %[gs] offset:%[gq]\n\t"
+    M32_MF(ACC1, "8", BH, C1) M32_DMA_SITE("0") E1                               \
+    M32_MF(ACC0, "0", BL, ACC0) M32_DMA_SITE("1") E2                             \
+    M32_MF(ACC1, "8", BL, ACC1) M32_DMA_SITE("2") E3                             \
+    M32_MF(ACC0, "4", BH, ACC0) M32_DMA_SITE("3") E4                             \
+    M32_MF(ACC1, "12", BH, ACC1) E5
+// The ring refill rides on the groups: the 8 LDS-DMA pieces a wavefront owes per chunk are issued M32_DMA_PER_GROUP at a time by the
+// FIRST groups of the chunk (behind MFMAs 2 .. 5 of the group, M0 -- the LDS destination -- written at the group's head; a single
+// wavefront issues one instruction per 4 cycles, 8 per MFMA): early, because the hand-over in front of chunk c + 2 waits for them --
+// spread evenly over the chunk the last piece was one chunk old there, and the hand-overs were 13 % of the wavefront's cycles.
+// Which sites of a group are live is decided by the ASSEMBLER (.if on a template constant): one asm text for every group.
+#ifndef M32_DMA_PER_GROUP
+#define M32_DMA_PER_GROUP 2
 #endif
-#define M32_DMA_OPERANDS [gm] "s"(Q >= 4 ? d.dst + 4096u : d.dst), [gv] "v"(Q >= 4 ? d.v1 : d.v0), [gs] "s"(d.src), [gq] "n"((Q & 3) * 1024)
+#ifdef M32_EXP_NODMA      // timing experiment (wrong results)
+#define M32_DMA_M0 ""
+#define M32_DMA_SITE(I) ""
+#else
+#define M32_DMA_M0 ".if %[gon0]\n\ts_mov_b32 m0, %[gm]\n\t.endif\n\t"
+#define M32_DMA_SITE(I) ".if %[gon" I "]\n\tglobal_load_lds_dwordx4 %[gv], %[gs] offset:%[gq" I "]\n\t.endif\n\t"
+#endif
+// group Q (0 .. 7) of a chunk carries pieces P Q .. P Q + P - 1 (P = M32_DMA_PER_GROUP) if those exist
+#define M32_DMA_PIECE(I) (M32_DMA_PER_GROUP * Q + (I))
+#define M32_DMA_ON(I) (((I) < M32_DMA_PER_GROUP && M32_DMA_PIECE(I) < 8) ? 1 : 0)
+#define M32_DMA_OPERANDS                                                                                                      \
+    [gm] "s"(M32_DMA_PIECE(0) >= 4 ? d.dst + 4096u : d.dst), [gv] "v"(M32_DMA_PIECE(0) >= 4 ? d.v1 : d.v0), [gs] "s"(d.src),    \
+    [gon0] "n"(M32_DMA_ON(0)), [gon1] "n"(M32_DMA_ON(1)), [gon2] "n"(M32_DMA_ON(2)), [gon3] "n"(M32_DMA_ON(3)),                  \
+    [gq0] "n"((M32_DMA_PIECE(0) & 3) * 1024), [gq1] "n"((M32_DMA_PIECE(1) & 3) * 1024), [gq2] "n"((M32_DMA_PIECE(2) & 3) * 1024), \
+    [gq3] "n"((M32_DMA_PIECE(3) & 3) * 1024)
 #define M32_GROUP(BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5) \
     M32_GROUP_ON(M32_ACC_A, M32_ACC_B, BH, BL, C0, C1, READS, E0, E1, E2, E3, E4, E5)
 
@@ -262,7 +244,7 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 // EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep.  PF: prefetch the next group's fragments.
 template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO, int Q>
 __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
-    static_assert(PF && EPI >= 0 && EPI <= 4, "");
+    static_assert(PF && EPI >= 0 && EPI <= 4 && (M32_DMA_PER_GROUP == 2 || M32_DMA_PER_GROUP == 4), "");
     if constexpr (EPI == 0) M32_EMIT(M32_READS, "", "", "", "", "", "");
     else if constexpr (EPI == 1)
         M32_EMIT(M32_READS, M32_BIAS_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");      // 6 3 2 2 2 0
@@ -432,11 +414,11 @@ __device__ __forceinline__ void m32_pe_mfma(const half8& xh, const half8& xl, un
         if constexpr (FIRST) M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", "0") M32_READS);
         else M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", M32_ACC_A) M32_READS);
     } else if constexpr (I == 1) {
-        if constexpr (FIRST) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", "0") M32_DMA);
-        else M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", M32_ACC_B) M32_DMA);
-    } else if constexpr (I == 2) M32_PE1_ASM(M32_MF(M32_ACC_A, "0", "%[xl]", M32_ACC_A));
-    else if constexpr (I == 3) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xl]", M32_ACC_B));
-    else if constexpr (I == 4) M32_PE1_ASM(M32_MF(M32_ACC_A, "4", "%[xh]", M32_ACC_A));
+        if constexpr (FIRST) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", "0") M32_DMA_SITE("0"));
+        else M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", M32_ACC_B) M32_DMA_SITE("0"));
+    } else if constexpr (I == 2) M32_PE1_ASM(M32_MF(M32_ACC_A, "0", "%[xl]", M32_ACC_A) M32_DMA_SITE("1"));
+    else if constexpr (I == 3) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xl]", M32_ACC_B) M32_DMA_SITE("2"));
+    else if constexpr (I == 4) M32_PE1_ASM(M32_MF(M32_ACC_A, "4", "%[xh]", M32_ACC_A) M32_DMA_SITE("3"));
     else M32_PE1_ASM(M32_MF(M32_ACC_B, "12", "%[xh]", M32_ACC_B));
 #undef M32_PE1_ASM
 }
@@ -521,13 +503,13 @@ __device__ __forceinline__ void m32_dense_layer(Pipe32& p, float& al, unsigned b
 #define M32_CHUNK(C)                                                                            \
     {                                                                                           \
         const Dma32 d = pipe32_sync<0>(p, NoExtra());                                           \
-        const RingPos r = m32_next_chunk(p, ring_lane_addr());                                  \
+        const RingPos r = m32_next_chunk(p, p.ring_lane);                                  \
         m32_dense_ksub<BANK, 2 * (C), false>(al, r.cbase, r.nbase, ba, w, d);                   \
         m32_dense_ksub<BANK, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba, w, d);               \
     }
     {
         const Dma32 d = pipe32_sync<0>(p, NoExtra());
-        const RingPos r = m32_next_chunk(p, ring_lane_addr());
+        const RingPos r = m32_next_chunk(p, p.ring_lane);
         if (first) m32_dense_ksub<BANK, 0, true>(al, r.cbase, r.nbase, ba, w, d);
         else m32_dense_ksub<BANK, 0, false>(al, r.cbase, r.nbase, ba, w, d);
         m32_dense_ksub<BANK, 1, false>(al, r.cbase, r.nbase, ba, w, d);
@@ -547,16 +529,15 @@ __device__ __forceinline__ void m32_pe_layer(Pipe32& p, const half8 (&xh)[13], c
 #define M32_PE_CHUNK(C)                                                                                          \
     {                                                                                                            \
         const Dma32 d = pipe32_sync<0>(p, NoExtra());                                                            \
-        const RingPos r = m32_next_chunk(p, ring_lane_addr());                                                   \
+        const RingPos r = m32_next_chunk(p, p.ring_lane);                                                   \
         M32_PE_KSUB(2 * (C), (C) == 0, 4 * 4096, r.cbase, 0)                                                     \
         M32_PE_KSUB(2 * (C) + 1, false, 0, r.nbase, 4)                                                           \
     }
     M32_PE_CHUNK(0) M32_PE_CHUNK(1) M32_PE_CHUNK(2) M32_PE_CHUNK(3) M32_PE_CHUNK(4) M32_PE_CHUNK(5)
     {
         const Dma32 d = pipe32_sync<0>(p, NoExtra());
-        pipe32_issue_half(d);           // four groups for eight pieces: pieces 0 .. 3 here, 4 .. 7 behind the groups
-        const RingPos r = m32_next_chunk(p, ring_lane_addr());
-        M32_PE_KSUB(12, false, 0, r.nbase, 4)
+        const RingPos r = m32_next_chunk(p, p.ring_lane);
+        M32_PE_KSUB(12, false, 0, r.nbase, 0)
     }
 #undef M32_PE_CHUNK
 #undef M32_PE_KSUB
@@ -567,7 +548,7 @@ __device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 
 #define M32_PE0_CHUNK(C)                                                                                         \
     {                                                                                                            \
         const Dma32 d = pipe32_sync<0>(p, NoExtra());                                                            \
-        const RingPos r = m32_next_chunk(p, ring_lane_addr());                                                   \
+        const RingPos r = m32_next_chunk(p, p.ring_lane);                                                   \
         m32_pe_ksub_sliced<2 * (C)>(xh, xl, hv, j, f, r.cbase, r.nbase, d);                                      \
         m32_pe_ksub_sliced<2 * (C) + 1>(xh, xl, hv, j, f, r.cbase, r.nbase, d);                                  \
     }
@@ -575,12 +556,11 @@ __device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 
 #undef M32_PE0_CHUNK
     {
         const Dma32 d = pipe32_sync<0>(p, NoExtra());
-        pipe32_issue_half(d);
-        const RingPos r = m32_next_chunk(p, ring_lane_addr());
-        m32_group_pe<false, 0, 224, 1 * 4096, 4>(xh[12], xl[12], r.cbase, d);
-        m32_group_pe<false, 32, 240, 2 * 4096, 5>(xh[12], xl[12], r.cbase, d);
-        m32_group_pe<false, 64, 224, 3 * 4096, 6>(xh[12], xl[12], r.cbase, d);
-        m32_group_pe<false, 96, 240, 0, 7>(xh[12], xl[12], r.nbase, d);
+        const RingPos r = m32_next_chunk(p, p.ring_lane);
+        m32_group_pe<false, 0, 224, 1 * 4096, 0>(xh[12], xl[12], r.cbase, d);
+        m32_group_pe<false, 32, 240, 2 * 4096, 1>(xh[12], xl[12], r.cbase, d);
+        m32_group_pe<false, 64, 224, 3 * 4096, 2>(xh[12], xl[12], r.cbase, d);
+        m32_group_pe<false, 96, 240, 0, 3>(xh[12], xl[12], r.nbase, d);
     }
 }
 
@@ -657,6 +637,12 @@ struct StageView32 {
     }
 };
 
+#ifdef M32_TRACE           // dev variant (tools/ab/build_variant.sh ... -DM32_TRACE): s_memtime stamps of wavefront 0 of workgroup 0, 16 per tile
+__device__ long long* g_m32_trace = nullptr;
+#define M32_STAMP(I) do { if (g_m32_trace && blockIdx.x == 0 && wave == 0 && rnd < 4) { const long long t_ = clock64(); if ((lane_off16() >> 4) == 0) g_m32_trace[rnd * 16 + (I)] = t_; } } while (0)
+#else
+#define M32_STAMP(I) do { } while (0)
+#endif
 __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_bias = reinterpret_cast<float*>(smem + RING_SLOTS * CHUNK_BYTES);  // [8][256]
@@ -685,6 +671,8 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
 
     Pipe32 p;
     p.packed = a.packed; p.ring = smem; p.issue_chunk = 0; p.issue_slot = 0; p.cons_slot = 0; p.wave = wave;
+    p.l16 = (unsigned)(tid & 63) << 4;
+    p.ring_lane = lds_addr(smem) + p.l16;
     pipe32_issue(p);
     pipe32_issue(p);
     pipe32_issue(p);
@@ -734,10 +722,13 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         const unsigned g16 = (lane_off16() >> 9) << 4;        // 16 g bytes: the lane group's 4 floats inside a block of 8 features
         const unsigned winv_at = tab + (unsigned)(M32_TABLE_FLOATS - 12) * 4u;
 #define M32_WINV(L_) m32_lds_f32(winv_at + 4u * (unsigned)(L_))
-        m32_prefetch0(ring_lane_addr() + (unsigned)p.cons_slot * CHUNK_BYTES);
+        M32_STAMP(0);
+        m32_prefetch0(p.ring_lane + (unsigned)p.cons_slot * CHUNK_BYTES);
         // layer 0: the encoding into bank 0
         m32_pe_layer0(p, xh, xl, hv, pe_job, pe_frag);
+        M32_STAMP(1);
         m32_layer_end<0, false>(al, tab + g16, 0u, M32_WINV(0));
+        M32_STAMP(2);
 #pragma unroll 1
         for (int pr = 0; pr < 3; ++pr) {
             // odd layer L = 2 pr + 1: bank 1 <- bank 0 (L = 5: the encoding first); even layer L + 1: bank 0 <- bank 1
@@ -753,7 +744,31 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         // (outside the loop: the view layer's accumulators are compiler variables, and every statement of the loop clobbers every AccVGPR)
         {
             // layer 7: bank 1 <- bank 0
+            M32_STAMP(3);
+#ifdef M32_TRACE           // layer 7 written out, with stamps around the hand-over and the k-substeps of its chunk 3 (12, 13: calibration)
+            {
+                const unsigned ba7 = tab + 6u * 1024u + g16;
+                const float w6 = M32_WINV(6);
+#define M32_TCHUNK(C, FIRST_, S0, S1, S2, S3)                                                       \
+                {                                                                                   \
+                    S0;                                                                             \
+                    const Dma32 d = pipe32_sync<0>(p, NoExtra());                                   \
+                    const RingPos r = m32_next_chunk(p, p.ring_lane);                          \
+                    S1;                                                                             \
+                    m32_dense_ksub<1, 2 * (C), FIRST_>(al, r.cbase, r.nbase, ba7, w6, d);           \
+                    S2;                                                                             \
+                    m32_dense_ksub<1, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba7, w6, d);        \
+                    S3;                                                                             \
+                }
+                M32_TCHUNK(0, true, , , , ) M32_TCHUNK(1, false, , , , ) M32_TCHUNK(2, false, , , , )
+                M32_TCHUNK(3, false, M32_STAMP(12); M32_STAMP(13), M32_STAMP(14), M32_STAMP(15), M32_STAMP(9))
+                M32_TCHUNK(4, false, , , , ) M32_TCHUNK(5, false, , , , ) M32_TCHUNK(6, false, , , , ) M32_TCHUNK(7, false, , , , )
+#undef M32_TCHUNK
+            }
+#else
             m32_dense_layer<1>(p, al, tab + 6u * 1024u + g16, M32_WINV(6), true);
+#endif
+            M32_STAMP(4);
             // view layer (feature_linear merged into views_linears.0): accv <- bank 1, + the density logit
             const unsigned ba_out = tab + 7u * 1024u + g16, aa = tab + 8u * 1024u + g16;
             const float w_7 = M32_WINV(7);
@@ -769,7 +784,7 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
 #define M32_VCHUNK(C, EXTRA_, STAGE_)                                                              \
             {                                                                                      \
                 const Dma32 d = pipe32_sync<EXTRA_>(p, STAGE_);                                    \
-                const RingPos r = m32_next_chunk(p, ring_lane_addr());                             \
+                const RingPos r = m32_next_chunk(p, p.ring_lane);                             \
                 m32_view_ksub<4 * (C)>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);               \
                 m32_view_ksub<4 * (C) + 1>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
                 m32_view_ksub<4 * (C) + 2>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
@@ -778,7 +793,9 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
             M32_VCHUNK(0, 0, stage)            // the staging loads sit between the barrier and the refill:
             M32_VCHUNK(1, 19, NoExtra())       // older than chunk c + 3, younger than what the next hand-over waits for
             M32_VCHUNK(2, 0, NoExtra())
+            M32_STAMP(5);
             M32_VCHUNK(3, 0, NoExtra())
+            M32_STAMP(6);
 #undef M32_VCHUNK
         }
         asm volatile(M32_DRAIN : "+a"(accv[0]), "+a"(accv[1]), "+a"(accv[2]), "+a"(accv[3])::"memory");
@@ -844,6 +861,7 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         const float g_ = pg_ + other(pg_) + s_misc[2];
         const float b_ = pb_ + other(pb_) + s_misc[3];
         const float al_ = al + other(al) + s_misc[0];
+        M32_STAMP(7);
         if (g == 0 && dst >= 0) {
             reinterpret_cast<float4*>(a.raw_out)[dst] = make_float4(r_, g_, b_, al_);
             if (a.aux_out) a.aux_out[(size_t)row * (M32_VW + 1) + M32_VW] = al_;
@@ -858,6 +876,9 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
 using namespace danbo;
 
 // danbo_pe_mlp16_fwd's contract on weights packed by danbo_mlp32_pack
+#ifdef M32_TRACE
+extern "C" int danbo_dev_m32_trace(long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_m32_trace), &buf, sizeof(buf)); }
+#endif
 extern "C" int danbo_pe_mlp32_fwd(const float* h, const int32_t* list, const int32_t* count, int n, int S,
                                    const void* packed32, const float* const* pts_b, const float* alpha_w,
                                    const float* alpha_b, const float* cview, const float* rgb_w,
