@@ -111,13 +111,11 @@ struct Dma32 {
     unsigned dst;         // LDS byte address of the same 8 KB in the slot being refilled (M0)
     unsigned v0, v1;      // lane * 16, lane * 16 + 4096
 };
+// (the hand-over's wait and barrier sit INSIDE the chunk's first group, behind its first MFMA -- M32_SYNC below: what has to lie
+// behind the barrier is the refill of the slot of chunk c - 1 (the group's LDS-DMA sites) and the prefetch of chunk c + 1's first
+// fragments by the chunk's LAST group, not the reads of chunk c itself, which the hand-over in front of chunk c - 1 published)
 template <int EXTRA, class Extra>
 __device__ __forceinline__ Dma32 pipe32_sync(Pipe32& p, const Extra& extra) {
-    wait_vm<8 + EXTRA>();
-#ifndef M32_EXP_NOBARRIER  // timing experiment (races)
-    __builtin_amdgcn_s_barrier();
-#endif
-    asm volatile("" ::: "memory");
     extra();
     Dma32 d;
     d.src = p.packed + (size_t)p.issue_chunk * CHUNK_BYTES + p.wave * 8192;
@@ -163,7 +161,7 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 #endif
 #define M32_GROUP_DMA(ACC0, ACC1, BH, BL, C0, C1, READS, DMA, E0, E1, E2, E3, E4, E5) \
     M32_DMA_M0 M32_HEAD_WAIT                                                     \
-    M32_MF(ACC0, "0", BH, C0) E0 READS                                           \
+    M32_MF(ACC0, "0", BH, C0) M32_SYNC E0 READS                                  \
     M32_MF(ACC1, "8", BH, C1) M32_DMA_SITE("0") E1                               \
     M32_MF(ACC0, "0", BL, ACC0) M32_DMA_SITE("1") E2                             \
     M32_MF(ACC1, "8", BL, ACC1) M32_DMA_SITE("2") E3                             \
@@ -187,7 +185,11 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
 // group Q (0 .. 7) of a chunk carries pieces P Q .. P Q + P - 1 (P = M32_DMA_PER_GROUP) if those exist
 #define M32_DMA_PIECE(I) (M32_DMA_PER_GROUP * Q + (I))
 #define M32_DMA_ON(I) (((I) < M32_DMA_PER_GROUP && M32_DMA_PIECE(I) < 8) ? 1 : 0)
+// the hand-over of chunk c, in the chunk's first group (Q == 0): my share of chunk c + 1 has landed (<= VMW younger loads outstanding),
+// everybody's has and everybody is past chunk c - 1
+#define M32_SYNC ".if %[syn]\n\ts_waitcnt vmcnt(%[vmw])\n\ts_barrier\n\t.endif\n\t"
 #define M32_DMA_OPERANDS                                                                                                      \
+    [syn] "n"(Q == 0 ? 1 : 0), [vmw] "n"(VMW),                                                                                \
     [gm] "s"(M32_DMA_PIECE(0) >= 4 ? d.dst + 4096u : d.dst), [gv] "v"(M32_DMA_PIECE(0) >= 4 ? d.v1 : d.v0), [gs] "s"(d.src),    \
     [gon0] "n"(M32_DMA_ON(0)), [gon1] "n"(M32_DMA_ON(1)), [gon2] "n"(M32_DMA_ON(2)), [gon3] "n"(M32_DMA_ON(3)),                  \
     [gq0] "n"((M32_DMA_PIECE(0) & 3) * 1024), [gq1] "n"((M32_DMA_PIECE(1) & 3) * 1024), [gq2] "n"((M32_DMA_PIECE(2) & 3) * 1024), \
@@ -242,7 +244,7 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
     } while (0)
 
 // EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep.  PF: prefetch the next group's fragments.
-template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO, int Q>
+template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO, int Q, int VMW = 8>
 __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
     static_assert(PF && EPI >= 0 && EPI <= 4 && (M32_DMA_PER_GROUP == 2 || M32_DMA_PER_GROUP == 4), "");
     if constexpr (EPI == 0) M32_EMIT(M32_READS, "", "", "", "", "", "");
@@ -262,7 +264,7 @@ __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, u
 // values (it read the head's colour weights into a[0:59]).  EPI 5 / 6: the two groups of a k-substep (6 also without a prefetch:
 // never -- the tile's last group has no epilogue); the table reads of EPI 5 are OLDER than the fragment reads: lgkmcnt(4) = tables landed.
 #define M32_VIEW_A_CLOBBERS M32_A64_CLOBBERS
-template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO, int Q>
+template <int EPI, bool FIRST, bool PF, int HA, int BQ, int PB, int O0, int BO, int Q, int VMW = 8>
 __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
 #define M32_VIEW_ASM(TEXT, CONSTRAINT)                                                                                       \
     asm volatile(TEXT : [al] "+v"(al), [c0] CONSTRAINT(c0), [c1] CONSTRAINT(c1)                                              \
@@ -290,7 +292,7 @@ __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al
 }
 
 // the same group with the B fragments in compiler registers (the positional-encoding k-substeps: no epilogue rides on them)
-template <bool FIRST, int CA, int HA, int O0, int Q>
+template <bool FIRST, int CA, int HA, int O0, int Q, int VMW = 8>
 __device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb, const Dma32& d) {
 #define M32_PE_ASM(C0, C1)                                                                                                   \
     asm volatile("s_nop 1\n\t" M32_GROUP("%[xh]", "%[xl]", C0, C1, M32_READS, "", "", "", "", "", "")                                    \
@@ -405,14 +407,14 @@ __device__ __forceinline__ void pe_fragment(const float (&hv)[8], PeJob& j, PeFr
 }
 
 // MFMA I (0 .. 5) of a group of the encoding's k-substep, as a statement of its own (m32_group_pe cut in six)
-template <int I, bool FIRST, int CA, int HA, int O0, int Q>
+template <int I, bool FIRST, int CA, int HA, int O0, int Q, int VMW = 8>
 __device__ __forceinline__ void m32_pe_mfma(const half8& xh, const half8& xl, unsigned nb, const Dma32& d) {
 #define M32_PE1_ASM(TEXT)                                                                                                    \
     asm volatile(TEXT :: [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl), \
                  [nb] "v"(nb), [o0] "n"(O0), M32_DMA_OPERANDS : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
     if constexpr (I == 0) {
-        if constexpr (FIRST) M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", "0") M32_READS);
-        else M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", M32_ACC_A) M32_READS);
+        if constexpr (FIRST) M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", "0") M32_SYNC M32_READS);
+        else M32_PE1_ASM("s_nop 1\n\t" M32_DMA_M0 M32_HEAD_WAIT M32_MF(M32_ACC_A, "0", "%[xh]", M32_ACC_A) M32_SYNC M32_READS);
     } else if constexpr (I == 1) {
         if constexpr (FIRST) M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", "0") M32_DMA_SITE("0"));
         else M32_PE1_ASM(M32_MF(M32_ACC_B, "8", "%[xh]", M32_ACC_B) M32_DMA_SITE("0"));
@@ -565,12 +567,12 @@ __device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 
 }
 
 // view layer (256 -> 128: four result tiles `accv` from bank 1): k-substep U = 2 groups, 4 k-substeps per chunk
-template <int U>
+template <int U, int VMW = 8>
 __device__ __forceinline__ void m32_view_ksub(f32x16 (&accv)[4], float& al, unsigned cbase, unsigned nbase, unsigned ba, unsigned aa, float w,
                                               const Dma32& d) {
     constexpr int UC = U & 3, BQ = (U & 1) ? 208 : 216, PB = 128 + 8 * (U + 1), BO = 64 * (U + 1);
     constexpr bool EPI = U < 15, FIRST = U == 0;
-    m32_view_group<EPI ? 5 : 0, FIRST, true, 224, BQ, PB, (UC * 2 + 1) * 4096, BO, 2 * UC>(accv[0], accv[1], al, cbase, ba, aa, w, d);
+    m32_view_group<EPI ? 5 : 0, FIRST, true, 224, BQ, PB, (UC * 2 + 1) * 4096, BO, 2 * UC, VMW>(accv[0], accv[1], al, cbase, ba, aa, w, d);
     // the tile's very last group prefetches nothing: the fragment buffers are dead across the head and the next tile's prologue
     if constexpr (U == 15) m32_view_group<0, false, false, 240, BQ, PB, 0, BO, 2 * UC + 1>(accv[2], accv[3], al, cbase, ba, aa, w, d);
     else m32_view_group<6, FIRST, true, 240, BQ, PB, UC == 3 ? 0 : (UC * 2 + 2) * 4096, BO, 2 * UC + 1>(accv[2], accv[3], al, UC == 3 ? nbase : cbase, ba, aa, w, d);
@@ -785,13 +787,13 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
             {                                                                                      \
                 const Dma32 d = pipe32_sync<EXTRA_>(p, STAGE_);                                    \
                 const RingPos r = m32_next_chunk(p, p.ring_lane);                             \
-                m32_view_ksub<4 * (C)>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);               \
+                m32_view_ksub<4 * (C), 8 + (EXTRA_)>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);               \
                 m32_view_ksub<4 * (C) + 1>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
                 m32_view_ksub<4 * (C) + 2>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
                 m32_view_ksub<4 * (C) + 3>(accv, al, r.cbase, r.nbase, ba_out, aa, w_7, d);           \
             }
-            M32_VCHUNK(0, 0, stage)            // the staging loads sit between the barrier and the refill:
-            M32_VCHUNK(1, 19, NoExtra())       // older than chunk c + 3, younger than what the next hand-over waits for
+            M32_VCHUNK(0, 19, stage)           // the 19 staging loads are issued in front of this chunk's hand-over: younger than what
+            M32_VCHUNK(1, 19, NoExtra())       // it and the next one wait for, older than the refills that follow
             M32_VCHUNK(2, 0, NoExtra())
             M32_STAMP(5);
             M32_VCHUNK(3, 0, NoExtra())
