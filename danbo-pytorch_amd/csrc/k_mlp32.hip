@@ -243,20 +243,32 @@ __device__ __forceinline__ void idle_tile32(Pipe32& p) {
         else M32_ASM(M32_GROUP(M32_BH, M32_BL, M32_ACC_A, M32_ACC_B, READS, E0, E1, E2, E3, E4, E5));    \
     } while (0)
 
-// EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep.  PF: prefetch the next group's fragments.
+// EPI: 0 none | 1..4 = the four groups of a dense layer's k-substep | 13: 3 + a wait state behind the split (the layer's last group: the
+// next MFMA reads the fragment) | 7, 8, 9: 1, 2, 13 with the density logit's 8 fma (layer 7's last k-substep: the view layer's first
+// fragment).  PF: prefetch the next group's fragments.
 template <int EPI, bool FIRST, bool PF, int CA, int HA, int BQ, int PB, int O0, int BO, int Q, int VMW = 8>
 __device__ __forceinline__ void m32_group(float& al, unsigned nb, unsigned ba, unsigned aa, float w, const Dma32& d) {
-    static_assert(PF && EPI >= 0 && EPI <= 4 && (M32_DMA_PER_GROUP == 2 || M32_DMA_PER_GROUP == 4), "");
-    if constexpr (EPI == 0) M32_EMIT(M32_READS, "", "", "", "", "", "");
+    static_assert(PF && (M32_DMA_PER_GROUP == 2 || M32_DMA_PER_GROUP == 4), "");
+    if constexpr (EPI == 0 || EPI == 4) M32_EMIT(M32_READS, "", "", "", "", "", "");
     else if constexpr (EPI == 1)
         M32_EMIT(M32_READS, M32_BIAS_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");      // 6 3 2 2 2 0
-    else if constexpr (EPI == 2)
+    else if constexpr (EPI == 2 || EPI == 8)
         M32_EMIT(M32_READS, M32_FMA(0) M32_FMA(1), M32_FMA(2) M32_FMA(3) M32_FMA(4), M32_FMA(5) M32_FMA(6) M32_FMA(7) M32_MAX(0),
                  M32_MAX(1) M32_MAX(2) M32_MAX(3) M32_MAX(4), M32_MAX(5) M32_MAX(6) M32_MAX(7), "");                                       // 6 4 4 4 3 0
     else if constexpr (EPI == 3)
         M32_EMIT(M32_READS, M32_CVT(0, 0, 1) M32_CVT(1, 2, 3), M32_CVT(2, 4, 5) M32_CVT(3, 6, 7), M32_MIX(0, 0, 1), M32_MIX(1, 2, 3),
                  M32_MIX(2, 4, 5), M32_MIX(3, 6, 7));                                                                                       // 6 3 2 2 2 2
-    else M32_EMIT(M32_READS, "", "", "", "", "", "");
+    else if constexpr (EPI == 13)
+        M32_EMIT(M32_READS, M32_CVT(0, 0, 1) M32_CVT(1, 2, 3), M32_CVT(2, 4, 5) M32_CVT(3, 6, 7), M32_MIX(0, 0, 1), M32_MIX(1, 2, 3),
+                 M32_MIX(2, 4, 5), M32_MIX(3, 6, 7) "s_nop 1\n\t");
+    else if constexpr (EPI == 7)
+        M32_EMIT(M32_READS, M32_BIAS_READS M32_ALPHA_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");
+    else {
+        static_assert(EPI == 9, "");
+        M32_EMIT(M32_READS, M32_AL(0) M32_AL(1), M32_AL(2) M32_AL(3) M32_AL(4), M32_AL(5) M32_AL6 M32_AL7,
+                 M32_CVT(0, 0, 1) M32_CVT(1, 2, 3) M32_CVT(2, 4, 5) M32_CVT(3, 6, 7), M32_MIX(0, 0, 1) M32_MIX(1, 2, 3),
+                 M32_MIX(2, 4, 5) M32_MIX(3, 6, 7) "s_nop 1\n\t");
+    }
 }
 
 // The view layer's groups: their two accumulators are OPERANDS (compiler variables in AccVGPRs), not pinned registers -- the colour
@@ -291,16 +303,33 @@ __device__ __forceinline__ void m32_view_group(f32x16& c0, f32x16& c1, float& al
 #undef M32_VIEW_ASM
 }
 
-// the same group with the B fragments in compiler registers (the positional-encoding k-substeps: no epilogue rides on them)
-template <bool FIRST, int CA, int HA, int O0, int Q, int VMW = 8>
-__device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb, const Dma32& d) {
-#define M32_PE_ASM(C0, C1)                                                                                                   \
-    asm volatile("s_nop 1\n\t" M32_GROUP("%[xh]", "%[xl]", C0, C1, M32_READS, "", "", "", "", "", "")                                    \
+// the same group with the B fragments in compiler registers (the positional-encoding k-substeps).  EPI 1, 2, 13: the groups of layer 0's
+// LAST k-substep carry the first fragment of layer 1 (from tile 0 of the bank they accumulate into: final since the k-substep's
+// first group), as the last k-substep of a dense layer does
+template <bool FIRST, int CA, int HA, int O0, int Q, int VMW = 8, int EPI = 0>
+__device__ __forceinline__ void m32_group_pe(const half8& xh, const half8& xl, unsigned nb, const Dma32& d, unsigned ba = 0u, float w = 0.f) {
+#define M32_PE_ASM(C0, C1, E0, E1, E2, E3, E4, E5)                                                                           \
+    asm volatile("s_nop 1\n\t" M32_GROUP("%[xh]", "%[xl]", C0, C1, M32_READS, E0, E1, E2, E3, E4, E5)                          \
                  :: [ca] "n"(CA), [cb] "n"(CA + 16), [ha] "n"(HA), [na] "n"(HA == 224 ? 240 : 224), [xh] "v"(xh), [xl] "v"(xl),   \
-                    [nb] "v"(nb), [o0] "n"(O0), M32_DMA_OPERANDS                                                             \
+                    [nb] "v"(nb), [o0] "n"(O0), [nq] "n"(216), [pb] "n"((CA / 128) * 128), [ba] "v"(ba), [bo] "n"(0), [w] "v"(w), \
+                    M32_DMA_OPERANDS                                                                                         \
                  : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
-    if constexpr (FIRST) M32_PE_ASM("0", "0");
-    else M32_PE_ASM(M32_ACC_A, M32_ACC_B);
+#define M32_PE_EMIT(E0, E1, E2, E3, E4, E5)                                                      \
+    do {                                                                                         \
+        if constexpr (FIRST) M32_PE_ASM("0", "0", E0, E1, E2, E3, E4, E5);                        \
+        else M32_PE_ASM(M32_ACC_A, M32_ACC_B, E0, E1, E2, E3, E4, E5);                            \
+    } while (0)
+    if constexpr (EPI == 0) M32_PE_EMIT("", "", "", "", "", "");
+    else if constexpr (EPI == 1) M32_PE_EMIT(M32_BIAS_READS, M32_RD(0) M32_RD(1), M32_RD(2) M32_RD(3), M32_RD(4) M32_RD(5), M32_RD(6) M32_RD(7), "");
+    else if constexpr (EPI == 2)
+        M32_PE_EMIT(M32_FMA(0) M32_FMA(1), M32_FMA(2) M32_FMA(3) M32_FMA(4), M32_FMA(5) M32_FMA(6) M32_FMA(7) M32_MAX(0),
+                    M32_MAX(1) M32_MAX(2) M32_MAX(3) M32_MAX(4), M32_MAX(5) M32_MAX(6) M32_MAX(7), "");
+    else {
+        static_assert(EPI == 13, "");
+        M32_PE_EMIT(M32_CVT(0, 0, 1) M32_CVT(1, 2, 3), M32_CVT(2, 4, 5) M32_CVT(3, 6, 7), M32_MIX(0, 0, 1), M32_MIX(1, 2, 3), M32_MIX(2, 4, 5),
+                    M32_MIX(3, 6, 7) "s_nop 1\n\t");
+    }
+#undef M32_PE_EMIT
 #undef M32_PE_ASM
 }
 
@@ -443,27 +472,6 @@ __device__ __forceinline__ void m32_prefetch0(unsigned base) {
                  : M32_V_CLOBBERS, "memory");
 }
 
-// B fragments of k-substep 0 of the next layer from the layer just finished (bank PBANK), into buffer 0; VIEW: + the density logit
-template <int PBANK, bool VIEW>
-__device__ __forceinline__ void m32_layer_end(float& al, unsigned ba, unsigned aa, float w) {
-#define M32_END_ASM(TEXT)                                                                                  \
-    asm volatile(TEXT : [al] "+v"(al) : [nq] "n"(216), [pb] "n"(PBANK * 128), [ba] "v"(ba), [aa] "v"(aa), [bo] "n"(0), [w] "v"(w) \
-                 : M32_V_CLOBBERS, M32_A_CLOBBERS, "memory")
-#define M32_END_HEAD M32_DRAIN M32_BIAS_READS
-#define M32_END_VALUES                                                                                                        \
-    M32_RD(0) M32_RD(1) M32_RD(2) M32_RD(3) M32_RD(4) M32_RD(5) M32_RD(6) M32_RD(7) "s_waitcnt lgkmcnt(0)\n\t"               \
-    M32_FMA(0) M32_FMA(1) M32_FMA(2) M32_FMA(3) M32_FMA(4) M32_FMA(5) M32_FMA(6) M32_FMA(7)                                   \
-    M32_MAX(0) M32_MAX(1) M32_MAX(2) M32_MAX(3) M32_MAX(4) M32_MAX(5) M32_MAX(6) M32_MAX(7)
-#define M32_END_SPLIT                                                                                                         \
-    M32_CVT(0, 0, 1) M32_CVT(1, 2, 3) M32_CVT(2, 4, 5) M32_CVT(3, 6, 7) M32_MIX(0, 0, 1) M32_MIX(1, 2, 3) M32_MIX(2, 4, 5) M32_MIX(3, 6, 7) \
-    "s_nop 2\n\t"
-    if constexpr (VIEW)
-        M32_END_ASM(M32_END_HEAD M32_ALPHA_READS M32_END_VALUES M32_AL(0) M32_AL(1) M32_AL(2) M32_AL(3) M32_AL(4) M32_AL(5) M32_AL6 M32_AL7
-                    M32_END_SPLIT);
-    else M32_END_ASM(M32_END_HEAD M32_END_VALUES M32_END_SPLIT);
-#undef M32_END_ASM
-}
-
 // one float of a table that is written before the first barrier and never again, by a read the compiler does not track (a tracked
 // read -- or a global load, which the "memory" clobbers of the groups would make it repeat per group -- waits with vmcnt(0): the ring)
 __device__ __forceinline__ float m32_lds_f32(unsigned addr) {
@@ -475,16 +483,29 @@ __device__ __forceinline__ float m32_lds_f32(unsigned addr) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // k-substeps and layers
 // ---------------------------------------------------------------------------------------------------------------------------
-// dense layer, k-substep U (chunk U / 2, half U % 2): 4 groups; the epilogue of k-substep U + 1 rides on them (none on U = 15)
-template <int BANK, int U, bool FIRST>
-__device__ __forceinline__ void m32_dense_ksub(float& al, unsigned cbase, unsigned nbase, unsigned ba, float w, const Dma32& d) {
-    constexpr int H = U & 1, BQ = H ? 208 : 216, PB = (1 - BANK) * 128 + 8 * (U + 1), BO = 64 * (U + 1);
-    constexpr bool EPI = U < 15;
-    m32_group<EPI ? 1 : 0, FIRST, true, BANK * 128 + 0, 224, BQ, PB, (H * 4 + 1) * 4096, BO, H * 4 + 0>(al, cbase, ba, ba, w, d);
-    m32_group<EPI ? 2 : 0, FIRST, true, BANK * 128 + 32, 240, BQ, PB, (H * 4 + 2) * 4096, BO, H * 4 + 1>(al, cbase, ba, ba, w, d);
-    m32_group<EPI ? 3 : 0, FIRST, true, BANK * 128 + 64, 224, BQ, PB, (H * 4 + 3) * 4096, BO, H * 4 + 2>(al, cbase, ba, ba, w, d);
-    // the chunk's last group reads the first group of the NEXT chunk (published by the hand-over in front of this one)
-    m32_group<EPI ? 4 : 0, FIRST, true, BANK * 128 + 96, 240, BQ, PB, H ? 0 : 4 * 4096, BO, H * 4 + 3>(al, H ? nbase : cbase, ba, ba, w, d);
+// dense layer, k-substep U (chunk U / 2, half U % 2): 4 groups; the epilogue of k-substep U + 1 rides on them.  On the LAST one (U = 15)
+// rides the first fragment of the NEXT layer (NEXT 1; 2: of the view layer, with the density logit): it is made from tile 0 of the
+// bank this layer accumulates into, which is final since this k-substep's first group -- groups 1 .. 3 carry the three epilogue
+// stages with the next layer's bias row `ban` and scale `wn`.  No layer ever ends with a drained matrix pipe (the stand-alone layer end
+// -- drain, 40 instructions, LDS latency -- was 900 cycles, nine times per tile: 5.5 % of it, by the wavefront trace).
+template <int BANK, int U, bool FIRST, int NEXT = 1>
+__device__ __forceinline__ void m32_dense_ksub(float& al, unsigned cbase, unsigned nbase, unsigned ba, float w, const Dma32& d,
+                                               unsigned ban = 0u, float wn = 0.f, unsigned aa = 0u) {
+    constexpr int H = U & 1, BQ = H ? 208 : 216;
+    if constexpr (U < 15) {
+        constexpr int PB = (1 - BANK) * 128 + 8 * (U + 1), BO = 64 * (U + 1);
+        m32_group<1, FIRST, true, BANK * 128 + 0, 224, BQ, PB, (H * 4 + 1) * 4096, BO, H * 4 + 0>(al, cbase, ba, ba, w, d);
+        m32_group<2, FIRST, true, BANK * 128 + 32, 240, BQ, PB, (H * 4 + 2) * 4096, BO, H * 4 + 1>(al, cbase, ba, ba, w, d);
+        m32_group<3, FIRST, true, BANK * 128 + 64, 224, BQ, PB, (H * 4 + 3) * 4096, BO, H * 4 + 2>(al, cbase, ba, ba, w, d);
+        // the chunk's last group reads the first group of the NEXT chunk (published by the hand-over in front of this one)
+        m32_group<4, FIRST, true, BANK * 128 + 96, 240, BQ, PB, H ? 0 : 4 * 4096, BO, H * 4 + 3>(al, H ? nbase : cbase, ba, ba, w, d);
+    } else {
+        constexpr int PB = BANK * 128;
+        m32_group<0, false, true, BANK * 128 + 0, 224, BQ, PB, 5 * 4096, 0, 4>(al, cbase, ban, aa, wn, d);
+        m32_group<NEXT == 2 ? 7 : 1, false, true, BANK * 128 + 32, 240, BQ, PB, 6 * 4096, 0, 5>(al, cbase, ban, aa, wn, d);
+        m32_group<NEXT == 2 ? 8 : 2, false, true, BANK * 128 + 64, 224, BQ, PB, 7 * 4096, 0, 6>(al, cbase, ban, aa, wn, d);
+        m32_group<NEXT == 2 ? 9 : 13, false, true, BANK * 128 + 96, 240, BQ, PB, 0, 0, 7>(al, nbase, ban, aa, wn, d);
+    }
 }
 
 struct RingPos {
@@ -499,15 +520,16 @@ __device__ __forceinline__ RingPos m32_next_chunk(Pipe32& p, unsigned lds_ring) 
 }
 
 // 256 -> 256 layer into bank BANK from the other bank's result.  first: the accumulators start from zero (false: the skip layer,
-// whose encoding part has been accumulated already).  On entry B buffer 0 holds k-substep 0 (m32_layer_end).
-template <int BANK>
-__device__ __forceinline__ void m32_dense_layer(Pipe32& p, float& al, unsigned ba, float w, bool first) {
+// whose encoding part has been accumulated already).  On entry B buffer 0 holds k-substep 0 (made under the previous layer's last
+// k-substep); on exit it holds the next layer's (bias row `ban`, scale `wn`; NEXT 2: the view layer's, alpha weights at `aa`).
+template <int BANK, int NEXT = 1>
+__device__ __forceinline__ void m32_dense_layer(Pipe32& p, float& al, unsigned ba, float w, bool first, unsigned ban, float wn, unsigned aa = 0u) {
 #define M32_CHUNK(C)                                                                            \
     {                                                                                           \
         const Dma32 d = pipe32_sync<0>(p, NoExtra());                                           \
-        const RingPos r = m32_next_chunk(p, p.ring_lane);                                  \
+        const RingPos r = m32_next_chunk(p, p.ring_lane);                                       \
         m32_dense_ksub<BANK, 2 * (C), false>(al, r.cbase, r.nbase, ba, w, d);                   \
-        m32_dense_ksub<BANK, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba, w, d);               \
+        m32_dense_ksub<BANK, 2 * (C) + 1, false, NEXT>(al, r.cbase, r.nbase, ba, w, d, ban, wn, aa); \
     }
     {
         const Dma32 d = pipe32_sync<0>(p, NoExtra());
@@ -546,7 +568,8 @@ __device__ __forceinline__ void m32_pe_layer(Pipe32& p, const half8 (&xh)[13], c
 }
 
 // layer 0: the same 13 k-substeps into bank 0, each with the next fragment made under it (fragment 0: in front, in one piece)
-__device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 (&xl)[13], const float (&hv)[8], PeJob& j, PeFrag& f) {
+__device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 (&xl)[13], const float (&hv)[8], PeJob& j, PeFrag& f,
+                                              unsigned ba0, float w0) {
 #define M32_PE0_CHUNK(C)                                                                                         \
     {                                                                                                            \
         const Dma32 d = pipe32_sync<0>(p, NoExtra());                                                            \
@@ -559,10 +582,11 @@ __device__ __forceinline__ void m32_pe_layer0(Pipe32& p, half8 (&xh)[13], half8 
     {
         const Dma32 d = pipe32_sync<0>(p, NoExtra());
         const RingPos r = m32_next_chunk(p, p.ring_lane);
+        // ... and the first fragment of layer 1 under the last k-substep's groups 1 .. 3 (bias row and scale of layer 0)
         m32_group_pe<false, 0, 224, 1 * 4096, 0>(xh[12], xl[12], r.cbase, d);
-        m32_group_pe<false, 32, 240, 2 * 4096, 1>(xh[12], xl[12], r.cbase, d);
-        m32_group_pe<false, 64, 224, 3 * 4096, 2>(xh[12], xl[12], r.cbase, d);
-        m32_group_pe<false, 96, 240, 0, 3>(xh[12], xl[12], r.nbase, d);
+        m32_group_pe<false, 32, 240, 2 * 4096, 1, 8, 1>(xh[12], xl[12], r.cbase, d, ba0, w0);
+        m32_group_pe<false, 64, 224, 3 * 4096, 2, 8, 2>(xh[12], xl[12], r.cbase, d, ba0, w0);
+        m32_group_pe<false, 96, 240, 0, 3, 8, 13>(xh[12], xl[12], r.nbase, d, ba0, w0);
     }
 }
 
@@ -724,64 +748,39 @@ __global__ __launch_bounds__(M32_THREADS, 1) void k_pe_mlp32(Mlp32Args a) {
         const unsigned g16 = (lane_off16() >> 9) << 4;        // 16 g bytes: the lane group's 4 floats inside a block of 8 features
         const unsigned winv_at = tab + (unsigned)(M32_TABLE_FLOATS - 12) * 4u;
 #define M32_WINV(L_) m32_lds_f32(winv_at + 4u * (unsigned)(L_))
+        // the ray of this lane's sample and the address of its view constants (dst / S formed here, per tile: not hoisted out of the tile
+        // loop and spilled, not between two layers where the matrix pipe would wait for it)
+        int zero_v = 0, S_ = a.S;
+        asm volatile("" : "+s"(zero_v), "+s"(S_));
+        const int g_v = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_v)) >> 5);
+        const int ray = dst >= 0 ? dst / S_ : 0;
+        const float* cvb = a.cview ? a.cview + (size_t)ray * M32_VW + 4 * g_v : reinterpret_cast<const float*>(a.packed);
         M32_STAMP(0);
         m32_prefetch0(p.ring_lane + (unsigned)p.cons_slot * CHUNK_BYTES);
-        // layer 0: the encoding into bank 0
-        m32_pe_layer0(p, xh, xl, hv, pe_job, pe_frag);
+        // layer 0: the encoding into bank 0 (and, under its last k-substep, the first fragment of layer 1)
+        m32_pe_layer0(p, xh, xl, hv, pe_job, pe_frag, tab + g16, M32_WINV(0));
         M32_STAMP(1);
-        m32_layer_end<0, false>(al, tab + g16, 0u, M32_WINV(0));
         M32_STAMP(2);
 #pragma unroll 1
         for (int pr = 0; pr < 3; ++pr) {
-            // odd layer L = 2 pr + 1: bank 1 <- bank 0 (L = 5: the encoding first); even layer L + 1: bank 0 <- bank 1
+            // odd layer L = 2 pr + 1: bank 1 <- bank 0 (L = 5: the encoding first); even layer L + 1: bank 0 <- bank 1; each makes the
+            // next layer's first fragment under its last k-substep
             const int L = 2 * pr + 1;
             const unsigned ba_in = tab + (unsigned)(L - 1) * 1024u + g16;
+            const float w_in = M32_WINV(L - 1), w_l = M32_WINV(L), w_l1 = M32_WINV(L + 1);
             if (pr == 2) m32_pe_layer<1>(p, xh, xl);
-            m32_dense_layer<1>(p, al, ba_in, M32_WINV(L - 1), pr != 2);
-            const float w_l = M32_WINV(L);
-            m32_layer_end<1, false>(al, ba_in + 1024u, 0u, w_l);
-            m32_dense_layer<0>(p, al, ba_in + 1024u, w_l, true);
-            m32_layer_end<0, false>(al, ba_in + 2048u, 0u, M32_WINV(L + 1));
+            m32_dense_layer<1>(p, al, ba_in, w_in, pr != 2, ba_in + 1024u, w_l);
+            m32_dense_layer<0>(p, al, ba_in + 1024u, w_l, true, ba_in + 2048u, w_l1);
         }
         // (outside the loop: the view layer's accumulators are compiler variables, and every statement of the loop clobbers every AccVGPR)
         {
-            // layer 7: bank 1 <- bank 0
+            // layer 7: bank 1 <- bank 0; under its last k-substep the view layer's first fragment and the density logit's first 16 terms
+            const unsigned ba_out = tab + 7u * 1024u + g16, aa = tab + 8u * 1024u + g16;
+            const float w_6 = M32_WINV(6), w_7 = M32_WINV(7);
             M32_STAMP(3);
-#ifdef M32_TRACE           // layer 7 written out, with stamps around the hand-over and the k-substeps of its chunk 3 (12, 13: calibration)
-            {
-                const unsigned ba7 = tab + 6u * 1024u + g16;
-                const float w6 = M32_WINV(6);
-#define M32_TCHUNK(C, FIRST_, S0, S1, S2, S3)                                                       \
-                {                                                                                   \
-                    S0;                                                                             \
-                    const Dma32 d = pipe32_sync<0>(p, NoExtra());                                   \
-                    const RingPos r = m32_next_chunk(p, p.ring_lane);                          \
-                    S1;                                                                             \
-                    m32_dense_ksub<1, 2 * (C), FIRST_>(al, r.cbase, r.nbase, ba7, w6, d);           \
-                    S2;                                                                             \
-                    m32_dense_ksub<1, 2 * (C) + 1, false>(al, r.cbase, r.nbase, ba7, w6, d);        \
-                    S3;                                                                             \
-                }
-                M32_TCHUNK(0, true, , , , ) M32_TCHUNK(1, false, , , , ) M32_TCHUNK(2, false, , , , )
-                M32_TCHUNK(3, false, M32_STAMP(12); M32_STAMP(13), M32_STAMP(14), M32_STAMP(15), M32_STAMP(9))
-                M32_TCHUNK(4, false, , , , ) M32_TCHUNK(5, false, , , , ) M32_TCHUNK(6, false, , , , ) M32_TCHUNK(7, false, , , , )
-#undef M32_TCHUNK
-            }
-#else
-            m32_dense_layer<1>(p, al, tab + 6u * 1024u + g16, M32_WINV(6), true);
-#endif
+            m32_dense_layer<1, 2>(p, al, tab + 6u * 1024u + g16, w_6, true, ba_out, w_7, aa);
             M32_STAMP(4);
             // view layer (feature_linear merged into views_linears.0): accv <- bank 1, + the density logit
-            const unsigned ba_out = tab + 7u * 1024u + g16, aa = tab + 8u * 1024u + g16;
-            const float w_7 = M32_WINV(7);
-            m32_layer_end<1, true>(al, ba_out, aa, w_7);
-            // the ray of this lane's sample and the address of its view constants (dst / S: formed here, not hoisted out of the tile loop)
-            int zero_v = 0, S_ = a.S;
-            asm volatile("" : "+s"(zero_v), "+s"(S_));
-            const int g_v = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_v)) >> 5);
-            asm volatile("" : "+v"(dst));
-            const int ray = dst >= 0 ? dst / S_ : 0;
-            const float* cvb = a.cview ? a.cview + (size_t)ray * M32_VW + 4 * g_v : reinterpret_cast<const float*>(a.packed);
             const StageView32 stage{src, cvb};
 #define M32_VCHUNK(C, EXTRA_, STAGE_)                                                              \
             {                                                                                      \
