@@ -85,13 +85,12 @@ if "--trace" in sys.argv:
     assert lib.danbo_dev_m32_trace(ctypes.c_void_p(buf.data_ptr())) == 0
     f32(); torch.cuda.synchronize(); f32(); torch.cuda.synchronize()
     t = buf.cpu().numpy().reshape(4, 16)
-    names = ["L0 (13 k-substeps: 9 984 MFMA cycles)", "layer end", "layers 1-6 (109 k-substeps: 83 712)", "layer 7 (16: 12 288)",
-             "layer end + view chunks 0-2 (12 k-substeps of 384: 4 608)", "view chunk 3 (1 536)", "drain + colour head"]
+    names = ["layer 0 (13 k-substeps: 9 984 MFMA cycles; the encoding's slices under them)", "(two stamps back to back: what a stamp costs)",
+             "layers 1-6 (109 k-substeps: 83 712)", "layer 7 (16: 12 288)", "view chunks 0-2 (12 k-substeps of 12 MFMAs: 4 608)",
+             "view chunk 3 (1 536)", "drain + colour head"]
     for r in range(3):
         d = [int(t[r, i + 1] - t[r, i]) for i in range(7)]
         print("tile", r, "total", int(t[r, 7] - t[r, 0]), "| to next tile's start", int(t[r + 1, 0] - t[r, 7]))
         for n_, v in zip(names, d):
-            print("    %-62s %8d" % (n_, v))
-        cal = int(t[r, 13] - t[r, 12])
-        print("    layer 7, chunk 3: stamp-to-stamp %d | hand-over %d | k-substeps 6, 7 (24 MFMAs = 768 cycles each): %d %d   (each less the stamp)" % (
-            cal, int(t[r, 14] - t[r, 13]) - cal, int(t[r, 15] - t[r, 14]) - cal, int(t[r, 9] - t[r, 15]) - cal))
+            print("    %-84s %8d" % (n_, v))
+
