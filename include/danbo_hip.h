@@ -260,7 +260,7 @@ int danbo_pe_mlp16_fwd(const float* h, const int32_t* list, const int32_t* count
 
 /* K3, 32x32x16 form (csrc/k_mlp32.hip, ABI 9): the contract, arithmetic and buffer size of the pair above on
  * v_mfma_f32_32x32x16_f16 -- one wavefront of 32 samples per SIMD with both result banks in AccVGPRs, half the LDS fragment reads per
- * flop, the k-substep's epilogue hand-interleaved into the MFMA stream (7 % faster per launch on the bench frame).  The fragment order
+ * flop, the k-substep's epilogue hand-interleaved into the MFMA stream (9.5 % faster per launch on the bench frame).  The fragment order
  * differs: a buffer packed by danbo_mlp32_pack is for danbo_pe_mlp32_fwd only.  Results differ from danbo_pe_mlp16_fwd in the last
  * bits (the products of a k-step are added in another order: 7e-7 of the channel range on the bench frame); a caller that needs
  * the per-ray empty-space raw of danbo_view_consts bit-equal to this kernel's passes rgb_order = 2 there. */
