@@ -35,6 +35,8 @@ SIGNATURES = {
     "danbo_view_code_table": [P, P, I, I, I, P, P, P, P],
     "danbo_mlp16_pack": [POINTER(c_void_p), P, P, P, P, I, P, P, P],
     "danbo_pe_mlp16_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P],
+    "danbo_transform_batch_pts": [P, P, c_long, I, I, I, I, P, P],
+    "danbo_optcodes_fwd": [P, I, I, P, I, c_long, I, P, P],
     "danbo_mlp32_pack": [POINTER(c_void_p), P, P, P, P, I, P, P, P],
     "danbo_pe_mlp32_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P],
     "danbo_pe_mlp_fwd": [P, P, P, I, I, P, POINTER(c_void_p), P, P, P, P, P, P, P, P, P],

@@ -35,6 +35,19 @@ class _Spec(nn.Module):
         raise RuntimeError(f"{self._name}: fused into libdanbo_hip; there is no eager path")
 
 
+def transform_batch_pts(pts, skt):
+    """reference encoders.py:288-303: pts [N_rays, N_samples, 3] into every joint's local frame -> [N_rays, N_samples, NJ, 3]
+    (skt [N_rays or fewer, NJ, 4, 4]: broadcast over the rays as the reference's expand does) -- danbo_transform_batch_pts"""
+    from . import hip_ops as ops
+    return ops.transform_batch(pts, skt, rot_only=False)
+
+
+def transform_batch_rays(rays_o, rays_d, skt):
+    """reference encoders.py:305-318: the rotational part of skt applied to the directions rays_d [N_rays, N_samples, 3]"""
+    from . import hip_ops as ops
+    return ops.transform_batch(rays_d, skt, rot_only=True)
+
+
 def _pick(kind, table, key):
     if key not in table:
         raise NotImplementedError(f"{kind}={key} is not used by any shipped config (supported: {sorted(table)})")

@@ -561,6 +561,34 @@ def anerf_view_pe(rays_d, skts, L):
     return E
 
 
+def transform_batch(vecs, skt, rot_only=False):
+    """danbo_transform_batch_pts: vecs [N, S, 3] (points; rot_only: directions) into the local frame of every joint of skt
+    [G, J, 4, 4] with G dividing N (ray r belongs to pose r // (N // G)) -> [N, S, J, 3]"""
+    for t, nm in ((vecs, "pts"), (skt, "skt")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError(f"transform_batch {nm}: expected a float32 CUDA/HIP tensor -- libdanbo_hip has no CPU fallback")
+    N, S = vecs.shape[:2]
+    G, J = skt.shape[0], skt.shape[-3]
+    if vecs.shape[-1] != 3 or skt.shape[-2:] != (4, 4) or G < 1 or N % G:
+        raise ValueError(f"transform_batch: pts {tuple(vecs.shape)}, skt {tuple(skt.shape)}")
+    vecs, skt = vecs.contiguous(), skt.contiguous()
+    out = torch.empty(N, S, J, 3, device=vecs.device, dtype=torch.float32)
+    _call("danbo_transform_batch_pts", _p(vecs), _p(skt), N, S, J, N // G, 1 if rot_only else 0, _p(out), _stream())
+    return out
+
+
+def optcodes(codes, idx, mode):
+    """danbo_optcodes_fwd: mode 0 rows codes[idx[:, 0]] (clamped), 1 the mean code per row of idx, 2 lerp(codes[idx[:, 0]],
+    codes[idx[:, 1]], idx[:, 2]) -> [N, code_ch]"""
+    if not codes.is_cuda or codes.dtype != torch.float32 or not idx.is_cuda:
+        raise RuntimeError("optcodes: expected CUDA/HIP tensors -- libdanbo_hip has no CPU fallback")
+    idx = idx.reshape(idx.shape[0], -1).to(torch.float32).contiguous()
+    codes = codes.contiguous()
+    out = torch.empty(idx.shape[0], codes.shape[1], device=codes.device, dtype=torch.float32)
+    _call("danbo_optcodes_fwd", _p(codes), codes.shape[0], codes.shape[1], _p(idx), idx.shape[1], idx.shape[0], int(mode), _p(out), _stream())
+    return out
+
+
 def small_matmul(a, b, bias=None, out=None):
     """a [M, K] @ b [K, N] (+ bias [N]) -> float32 [M, N]; a, b: float32 CUDA tensors of ANY strides (slices and .t() views are read
     in place); the sum over k accumulated in float64 and rounded once (danbo_small_matmul: one thread per output -- the

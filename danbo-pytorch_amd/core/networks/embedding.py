@@ -1,7 +1,8 @@
 """Per-frame appearance codes (reference: core/networks/embedding.py:4-50).
 
-Only parameter storage lives here; the lookup (or the mean code for idx < 0 in eval) happens
-inside danbo_view_consts on the GPU (csrc/k_mlp.hip)."""
+Inside the render / training path the lookup (or the mean code for idx < 0 in eval) happens in danbo_view_consts on the GPU
+(csrc/k_mlp.hip) and the module is parameter storage.  Called on its own -- what a reference-side caller of Optcodes.forward
+does -- it runs the library's stand-alone lookup kernel (danbo_optcodes_fwd, csrc/k_encoders.hip): forward only."""
 import torch
 import torch.nn as nn
 
@@ -26,6 +27,19 @@ class Optcodes(nn.Module):
     def mean_code(self):
         return self.codes.weight.mean(0)
 
-    def forward(self, idx, *args, **kwargs):
-        raise RuntimeError("Optcodes lookups are fused into libdanbo_hip (danbo_view_consts); "
-                           "call the owning NeRF/DANBO module instead")
+    def forward(self, idx, t=None, *args, **kwargs):
+        """reference embedding.py:17-39: idx [N, 1] row indices (clamped to the table with the reference's warning), idx < 0 everywhere
+        in eval mode: the mean code, idx [N, 3] = (row, row, weight): their torch.lerp.  No gradient flows through this call: training
+        differentiates the codes inside the fused step / `torch.ops.danbo` path."""
+        from .. import hip_ops as ops
+        if torch.is_grad_enabled() and self.codes.weight.requires_grad and self.training:
+            raise RuntimeError("Optcodes.forward is forward-only here; the codes' gradient comes from the fused training step "
+                               "(core/train_engine.py) or the autograd path (core/train_path.py)")
+        w = self.codes.weight.detach()
+        if not self.training and float(idx.max()) < 0:
+            return ops.optcodes(w, idx[..., :1], 1)
+        if idx.shape[-1] != 1:
+            return ops.optcodes(w, idx[..., :3], 2)
+        if float(idx.max()) > self.n_codes:
+            print('Warning! Out-of-range index detected in Optcodes input. Clamp it to self.n_codes-1')
+        return ops.optcodes(w, idx, 0)

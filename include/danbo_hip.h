@@ -38,7 +38,8 @@ extern "C" {
  * 7 = danbo_train_mid (additive); DanboTrainBatch.rng_* (appended: a caller of an older header must be rebuilt);
  * 8 = A-NeRF on the library's own kernels end to end (additive): danbo_anerf_view_consts_fwd / _bwd, danbo_anerf_train_step and its
  * building blocks; 9 = K3 in the 32x32x16 form (danbo_mlp32_pack, danbo_pe_mlp32_fwd: additive), danbo_view_consts' rgb_order 2;
- * danbo_render_frame runs it: DanboModel.mlp16 is a buffer packed by danbo_mlp32_pack (a caller of ABI 8 must re-pack). */
+ * danbo_render_frame runs it: DanboModel.mlp16 is a buffer packed by danbo_mlp32_pack (a caller of ABI 8 must re-pack); additive:
+ * danbo_transform_batch_pts, danbo_optcodes_fwd (the reference's eager encoder helpers). */
 int danbo_abi_version(void);
 int danbo_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
@@ -272,6 +273,18 @@ int danbo_pe_mlp32_fwd(const float* h, const int32_t* list, const int32_t* count
                        const float* alpha_w, const float* alpha_b,
                        const float* cview, const float* rgb_w, const float* rgb_b,
                        float* raw_out, float* aux_out, void* stream);
+
+/* The reference's eager encoder helpers (csrc/k_encoders.hip; additive in ABI 9) for callers that use them outside the fused path:
+ *   danbo_transform_batch_pts  core/encoders.py:288-303 transform_batch_pts: out[r, s, j, :] = skt[r / rays_per_pose, j] applied to the
+ *                              point pts[r, s, :] (rot_only = 1: core/encoders.py:305-318 transform_batch_rays, the 3 x 3 part applied to
+ *                              a direction); pts [n_rays, S, 3], skt [n_rays / rays_per_pose, J, 4, 4], out [n_rays, S, J, 3]
+ *   danbo_optcodes_fwd         core/networks/embedding.py:17-39 Optcodes.forward on codes [n_codes, code_ch]: mode 0 row lookup (idx
+ *                              [N, idx_cols] as floats, column 0; clamped to the table), 1 the mean code for every row (evaluation
+ *                              without a frame: idx < 0), 2 torch.lerp of the rows idx[:, 0], idx[:, 1] with weight idx[:, 2] */
+int danbo_transform_batch_pts(const float* pts, const float* skt, long n_rays, int S, int J, int rays_per_pose, int rot_only,
+                              float* out, void* stream);
+int danbo_optcodes_fwd(const float* codes, int n_codes, int code_ch, const float* idx, int idx_cols, long N, int mode, float* out,
+                       void* stream);
 
 /* raw[r,s,:] = raw_empty[r,:] (broadcast fill before K3 scatters the in-volume rows) */
 int danbo_fill_raw(const float* raw_empty, int R, int S, float* raw, void* stream);

@@ -289,3 +289,47 @@ def test_render_of_a_megapixel_image_is_bounded_and_equals_the_chunk_loop_bitwis
         caster.render_rays_whole = orig
     for k in loop:
         assert torch.equal(whole[k], loop[k]) and torch.equal(capped[k], loop[k]), k
+
+
+@pytest.mark.gpu
+def test_eager_encoder_helpers_match_the_reference_formulas():
+    """transform_batch_pts / transform_batch_rays (reference encoders.py:288-318) and Optcodes.forward (embedding.py:17-39) called on
+    their own: stand-alone kernels of the library (csrc/k_encoders.hip), checked against the formulas in float64"""
+    from core import encoders
+    from core.networks.embedding import Optcodes
+    rng = np.random.default_rng(11)
+    N, S, J = 37, 5, 24
+    pts = rng.normal(size=(N, S, 3)).astype(np.float32)
+    skt = rng.normal(size=(N, J, 4, 4)).astype(np.float32)
+    skt[..., 3, :] = (0, 0, 0, 1)
+    hom = np.concatenate([pts, np.ones((N, S, 1), np.float32)], -1).astype(np.float64)
+    want = np.einsum("njab,nsb->nsja", skt.astype(np.float64), hom)[..., :3]
+    got = encoders.transform_batch_pts(torch.tensor(pts, device=DEV), torch.tensor(skt, device=DEV)).cpu().numpy()
+    assert got.shape == (N, S, J, 3) and np.abs(got - want).max() < 2e-6 * np.abs(want).max()
+    # one pose behind all rays (the reference expands skt)
+    got1 = encoders.transform_batch_pts(torch.tensor(pts, device=DEV), torch.tensor(skt[:1], device=DEV)).cpu().numpy()
+    want1 = np.einsum("jab,nsb->nsja", skt[0].astype(np.float64), hom)[..., :3]
+    assert np.abs(got1 - want1).max() < 2e-6 * np.abs(want1).max()
+    wantr = np.einsum("njab,nsb->nsja", skt[..., :3, :3].astype(np.float64), pts.astype(np.float64))
+    gotr = encoders.transform_batch_rays(None, torch.tensor(pts, device=DEV), torch.tensor(skt, device=DEV)).cpu().numpy()
+    assert np.abs(gotr - wantr).max() < 2e-6 * np.abs(wantr).max()
+    with pytest.raises(RuntimeError):
+        encoders.transform_batch_pts(torch.tensor(pts), torch.tensor(skt))            # no CPU path
+    # Optcodes
+    oc = Optcodes(9, 16).to(DEV)
+    w = oc.codes.weight.detach().cpu().numpy().astype(np.float64)
+    oc.eval()
+    idx = torch.tensor(rng.integers(0, 9, size=(20, 1)), device=DEV)
+    assert np.array_equal(oc(idx).cpu().numpy(), w[idx.cpu().numpy()[:, 0]].astype(np.float32))
+    mean = oc(torch.full((7, 1), -1, device=DEV)).cpu().numpy()
+    assert mean.shape == (7, 16) and np.abs(mean - w.mean(0)).max() < 1e-7
+    mix = np.concatenate([rng.integers(0, 9, size=(11, 2)).astype(np.float32), rng.uniform(0, 1, size=(11, 1)).astype(np.float32)], 1)
+    got = oc(torch.tensor(mix, device=DEV)).cpu().numpy()
+    a, b, t = w[mix[:, 0].astype(int)], w[mix[:, 1].astype(int)], mix[:, 2:3].astype(np.float64)
+    assert np.abs(got - (a + t * (b - a))).max() < 1e-6
+    assert np.array_equal(oc(torch.full((3, 1), 12, device=DEV)).cpu().numpy(), np.repeat(w[8:9], 3, 0).astype(np.float32))   # clamped
+    oc.train()
+    with pytest.raises(RuntimeError):
+        oc(idx)                                                                        # forward-only: training goes through the fused step
+    with torch.no_grad():
+        assert np.array_equal(oc(idx).cpu().numpy(), w[idx.cpu().numpy()[:, 0]].astype(np.float32))
