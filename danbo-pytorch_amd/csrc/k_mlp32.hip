@@ -8,7 +8,13 @@
 // fragment feeds twice the flops: half the LDS reads per flop, one instead of two copies of the epilogue's scalar overhead.  With no
 // partner wavefront to cover its latencies the k-substep is hand-interleaved: each group of 6 MFMAs carries, between its MFMAs, the
 // ds_reads of the next group's fragments and a slice of the NEXT k-substep's epilogue (AccVGPR reads of the previous layer's outputs
-// from the other bank, bias fma, ReLU, hi/lo split) -- the matrix pipe never waits for VALU work except at layer and tile boundaries.
+// from the other bank, bias fma, ReLU, hi/lo split).  The same stream carries the ring's refill (LDS-DMA pieces in the first groups of
+// a chunk), the hand-over's wait + barrier (behind the first MFMA of a chunk), the next layer's first fragment (under a layer's last
+// k-substep) and -- in layer 0 -- the sines and cosines of the encoding's next fragment: the matrix pipe waits for VALU work only
+// at tile boundaries (colour head, prologue).  Measured: DESIGN.md section 3 "K3, round 6"; a wavefront's own timeline:
+// tools/micro_mlp32.py --trace.
+//
+// (the view layer's accumulators: compiler-allocated operands in a0 .. a63; a[64:127] receives the tile's view constants meanwhile)
 //
 // Registers the assembly names itself (mlp32_regs.inc lists them as clobbers, so the compiler keeps nothing there across a block):
 //   a[0:127] / a[128:255]  result banks: a layer accumulates into one and reads its input (the previous layer's result) from the other
